@@ -1,0 +1,219 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes loader for ``oracle/liboracle.so`` (the CPU restatement of the
+reference's hot path; see oracle/jet.hpp, functors.hpp, lm.cpp headers for
+what each piece restates and how it is pinned).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this package.  The product package
+``skeres_amd`` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+DENSE_NORMAL_CHOLESKY, DENSE_QR, DENSE_SCHUR = 0, 1, 3
+CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
+MAX_LOG = 256
+
+# functor ids (oracle/functors.hpp; same numbering as include/skeres_amd.h)
+SNAVELY, EXPONENTIAL, POWELL_F1, POWELL_F2, POWELL_F3, POWELL_F4 = 1, 2, 3, 4, 5, 6
+BINARY_SCALAR, BINARY_VECTOR3, TEN_PARAMETER = 7, 8, 9
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("linear_solver_type", C.c_int), ("max_num_iterations", C.c_int),
+        ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double), ("jacobi_scaling", C.c_int),
+        ("max_num_consecutive_invalid_steps", C.c_int), ("num_threads", C.c_int),
+    ]
+
+
+class Iteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int), ("cost", C.c_double), ("cost_change", C.c_double),
+        ("gradient_max_norm", C.c_double), ("step_norm", C.c_double),
+        ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double),
+        ("step_is_valid", C.c_int), ("step_is_successful", C.c_int),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("num_iterations", C.c_int), ("num_successful_steps", C.c_int),
+        ("num_unsuccessful_steps", C.c_int), ("termination_type", C.c_int),
+        ("num_logged", C.c_int), ("num_threads_used", C.c_int),
+        ("total_time_s", C.c_double), ("t_linear_assemble_s", C.c_double),
+        ("t_linear_cholesky_s", C.c_double), ("t_linear_backsub_s", C.c_double),
+        ("message", C.c_char * 256), ("iterations", Iteration * MAX_LOG),
+    ]
+
+    def costs(self):
+        return [self.iterations[i].cost for i in range(self.num_logged)]
+
+
+_lib = None
+
+
+def build():
+    """Compile the oracle (g++; seconds)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int)
+        L.or_options_default.argtypes = [C.POINTER(Options)]
+        L.or_functor_info.argtypes = [C.c_int, ip, ip, ip, ip]
+        L.or_evaluate.argtypes = [C.c_int, dp, C.POINTER(dp), dp, C.POINTER(dp)]
+        L.or_angle_axis_rotate_point.argtypes = [dp, dp, dp]
+        L.or_angle_axis_to_rotation_matrix.argtypes = [dp, dp]
+        L.or_solve.argtypes = [C.c_int, ip, dp, C.c_int, ip, dp, ip, ip, ip,
+                               C.POINTER(Options), C.POINTER(Summary)]
+        L.or_solve_bal.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp,
+                                   C.POINTER(Options), C.POINTER(Summary)]
+        L.or_bal_evaluate.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, dp, dp]
+        L.or_cholesky_lower.argtypes = [dp, C.c_int, C.c_int]
+        L.or_cholesky_solve.argtypes = [dp, C.c_int, dp]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def default_options(**kw):
+    o = Options()
+    lib().or_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def functor_info(fid):
+    nr, nb, nc = C.c_int(), C.c_int(), C.c_int()
+    sizes = (C.c_int * 16)()
+    if not lib().or_functor_info(fid, C.byref(nr), C.byref(nb), C.byref(nc), sizes):
+        raise ValueError("unknown functor id %d" % fid)
+    return nr.value, [sizes[i] for i in range(nb.value)], nc.value
+
+
+def evaluate(fid, consts, params, want_jacobians=True, null_rows=()):
+    """AutoDiffCostFunction.evaluate for one residual block.
+
+    Returns (ok, residuals, jacobians) with jacobians[i] row-major
+    kNumResiduals x N(i), or None where the row pointer was null."""
+    nres, sizes, _ = functor_info(fid)
+    consts = np.ascontiguousarray(consts, dtype=np.float64) if len(consts) else np.zeros(1)
+    blocks = [np.ascontiguousarray(p, dtype=np.float64) for p in params]
+    dp = C.POINTER(C.c_double)
+    pp = (dp * len(blocks))(*[_dp(b) for b in blocks])
+    res = np.zeros(nres)
+    jacs = None
+    jp = None
+    if want_jacobians:
+        jacs = [None if i in null_rows else np.zeros(nres * n) for i, n in enumerate(sizes)]
+        jp = (dp * len(blocks))(*[(_dp(j) if j is not None else dp()) for j in jacs])
+    ok = lib().or_evaluate(fid, _dp(consts), pp, _dp(res), jp)
+    if jacs is not None:
+        jacs = [None if j is None else j.reshape(nres, -1) for j in jacs]
+    return bool(ok), res, jacs
+
+
+def angle_axis_rotate_point(aa, pt):
+    aa = np.ascontiguousarray(aa, dtype=np.float64)
+    pt = np.ascontiguousarray(pt, dtype=np.float64)
+    out = np.zeros(3)
+    lib().or_angle_axis_rotate_point(_dp(aa), _dp(pt), _dp(out))
+    return out
+
+
+def angle_axis_to_rotation_matrix(aa):
+    aa = np.ascontiguousarray(aa, dtype=np.float64)
+    R = np.zeros(9)
+    lib().or_angle_axis_to_rotation_matrix(_dp(aa), _dp(R))
+    return R.reshape(3, 3)
+
+
+def solve(block_sizes, x0, residual_blocks, options=None):
+    """residual_blocks: list of (functor_id, consts, [param block indices])."""
+    o = options or default_options()
+    bs = np.asarray(block_sizes, dtype=np.int32)
+    x = np.array(x0, dtype=np.float64).copy()
+    fids = np.asarray([rb[0] for rb in residual_blocks], dtype=np.int32)
+    consts, coff, pidx, poff = [], [], [], [0]
+    for _, c, idx in residual_blocks:
+        coff.append(len(consts))
+        consts.extend(c)
+        pidx.extend(idx)
+        poff.append(len(pidx))
+    consts = np.asarray(consts + [0.0], dtype=np.float64)
+    coff = np.asarray(coff, dtype=np.int32)
+    pidx = np.asarray(pidx, dtype=np.int32)
+    poff = np.asarray(poff, dtype=np.int32)
+    s = Summary()
+    rc = lib().or_solve(len(bs), _ip(bs), _dp(x), len(fids), _ip(fids), _dp(consts), _ip(coff),
+                        _ip(pidx), _ip(poff), C.byref(o), C.byref(s))
+    if rc != 0:
+        raise RuntimeError("or_solve failed: %d" % rc)
+    return x, s
+
+
+def solve_bal(C_, P_, cam_idx, pt_idx, obs, x0, options=None):
+    o = options or default_options(linear_solver_type=DENSE_SCHUR)
+    cam = np.ascontiguousarray(cam_idx, dtype=np.int32)
+    pt = np.ascontiguousarray(pt_idx, dtype=np.int32)
+    ob = np.ascontiguousarray(obs, dtype=np.float64)
+    x = np.array(x0, dtype=np.float64).copy()
+    s = Summary()
+    rc = lib().or_solve_bal(C_, P_, len(cam), _ip(cam), _ip(pt), _dp(ob), _dp(x), C.byref(o), C.byref(s))
+    if rc != 0:
+        raise RuntimeError("or_solve_bal failed: %d" % rc)
+    return x, s
+
+
+def bal_evaluate(C_, P_, cam_idx, pt_idx, obs, x, jacobians=True):
+    cam = np.ascontiguousarray(cam_idx, dtype=np.int32)
+    pt = np.ascontiguousarray(pt_idx, dtype=np.int32)
+    ob = np.ascontiguousarray(obs, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(cam)
+    r = np.zeros(2 * n)
+    F = np.zeros(18 * n) if jacobians else None
+    E = np.zeros(6 * n) if jacobians else None
+    cost = C.c_double()
+    null = C.POINTER(C.c_double)()
+    ok = lib().or_bal_evaluate(C_, P_, n, _ip(cam), _ip(pt), _dp(ob), _dp(x), _dp(r),
+                               _dp(F) if jacobians else null, _dp(E) if jacobians else null,
+                               C.byref(cost))
+    if not ok:
+        raise RuntimeError("or_bal_evaluate failed")
+    if jacobians:
+        return r.reshape(n, 2), F.reshape(n, 2, 9), E.reshape(n, 2, 3), cost.value
+    return r.reshape(n, 2), None, None, cost.value
+
+
+def cholesky_lower(A, num_threads=1):
+    L = np.array(A, dtype=np.float64, order="C").copy()
+    info = lib().or_cholesky_lower(_dp(L), L.shape[0], num_threads)
+    return info, np.tril(L)

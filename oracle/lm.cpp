@@ -1,0 +1,661 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/jet.hpp header).
+//
+// CPU restatement of the solve the reference delegates to native Ceres:
+// `ceres.solve(options, problem, summary)` at
+//   examples/.../SimpleBundleAdjuster.scala:147-152  (DENSE_SCHUR)
+//   examples/.../CurveFitting.scala:119-127          (DENSE_QR, 25 iterations)
+//   examples/.../Powell.scala:76-87                  (DENSE_QR, 100 iterations)
+//
+// *** PARITY UNPINNED for the LM trajectory. ***  ceres-solver is an
+// un-vendored, un-pinned dependency of the reference (configuration.sh:8-11;
+// version window 1.12 <= v < 2.0).  It is absent from /root/reference, there
+// is no test in the reference that calls solve(), and no JVM/Ceres exists in
+// this pipeline to generate vectors.  The algorithm below restates the
+// PUBLISHED Ceres trust-region Levenberg-Marquardt algorithm (Solver::Options
+// documentation + trust_region_minimizer / levenberg_marquardt_strategy /
+// schur_eliminator as published) with its documented default constants.  What
+// IS pinned: the per-residual-block evaluate step (functors.hpp) by the
+// reference's own KATs, and the converged optimum by SciPy cross-checks
+// (tests/golden/).
+//
+// Linear algebra conventions (published Ceres):
+//   cost = 1/2 sum r^2 ; Jacobi scaling s_j = 1/(1+||J_j||) fixed at iteration 0
+//   D = sqrt(clamp(diag(J^T J), min_lm_diagonal, max_lm_diagonal) / radius)
+//   solve (J^T J + D^2) y = J^T r ; step = -y
+//   model_cost_change = -(J step) . (r + (J step)/2)
+//   rho = (cost - new_cost) / model_cost_change ; accept iff rho > min_relative_decrease
+//   accept: radius /= max(1/3, 1 - (2 rho - 1)^3), decrease_factor = 2
+//   reject: radius /= decrease_factor, decrease_factor *= 2
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "functors.hpp"
+#include "oracle.h"
+
+namespace oracle {
+
+// dense Cholesky (chol.cpp; compiled with vectorisation flags)
+int cholesky_lower_inplace(double* A, int n, int ld, int num_threads);
+void cholesky_solve_lower(const double* L, int n, int ld, double* b);
+
+static double now_s() {
+  using namespace std::chrono;
+  return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// --------------------------------------------------------------------------
+// functor dispatch
+// --------------------------------------------------------------------------
+struct FunctorInfo { int num_residuals, num_blocks, num_consts; const int* N; };
+
+template <class F> static FunctorInfo info_of() {
+  FunctorInfo fi; fi.num_residuals = F::kNumResiduals; fi.num_blocks = F::kNumBlocks;
+  fi.num_consts = F::kNumConsts; fi.N = F::N; return fi;
+}
+
+static bool functor_info(int id, FunctorInfo* fi) {
+  switch (id) {
+    case kSnavelyReprojectionError: *fi = info_of<SnavelyReprojectionError>(); return true;
+    case kExponentialResidual: *fi = info_of<ExponentialResidual>(); return true;
+    case kPowellF1: *fi = info_of<PowellF1>(); return true;
+    case kPowellF2: *fi = info_of<PowellF2>(); return true;
+    case kPowellF3: *fi = info_of<PowellF3>(); return true;
+    case kPowellF4: *fi = info_of<PowellF4>(); return true;
+    case kBinaryScalarCost: *fi = info_of<BinaryScalarCost>(); return true;
+    case kBinaryVector3Cost: *fi = info_of<BinaryVector3Cost>(); return true;
+    case kTenParameterCost: *fi = info_of<TenParameterCost>(); return true;
+  }
+  return false;
+}
+
+static bool evaluate_block(int id, const double* consts, double const* const* params,
+                           double* residuals, double** jacobians) {
+  switch (id) {
+    case kSnavelyReprojectionError: return AutoDiff<SnavelyReprojectionError>::evaluate(consts, params, residuals, jacobians);
+    case kExponentialResidual: return AutoDiff<ExponentialResidual>::evaluate(consts, params, residuals, jacobians);
+    case kPowellF1: return AutoDiff<PowellF1>::evaluate(consts, params, residuals, jacobians);
+    case kPowellF2: return AutoDiff<PowellF2>::evaluate(consts, params, residuals, jacobians);
+    case kPowellF3: return AutoDiff<PowellF3>::evaluate(consts, params, residuals, jacobians);
+    case kPowellF4: return AutoDiff<PowellF4>::evaluate(consts, params, residuals, jacobians);
+    case kBinaryScalarCost: return AutoDiff<BinaryScalarCost>::evaluate(consts, params, residuals, jacobians);
+    case kBinaryVector3Cost: return AutoDiff<BinaryVector3Cost>::evaluate(consts, params, residuals, jacobians);
+    case kTenParameterCost: return AutoDiff<TenParameterCost>::evaluate(consts, params, residuals, jacobians);
+  }
+  return false;
+}
+
+// --------------------------------------------------------------------------
+// small dense helpers
+// --------------------------------------------------------------------------
+static inline bool all_finite(const double* v, size_t n) {
+  for (size_t i = 0; i < n; ++i) if (!std::isfinite(v[i])) return false;
+  return true;
+}
+
+// 3x3 SPD inverse through its Cholesky factor (Ceres: InvertPSDMatrix -> LLT).
+static bool invert_spd3(const double* T, double* Tinv) {
+  double l00 = T[0]; if (!(l00 > 0.0)) return false; l00 = std::sqrt(l00);
+  const double l10 = T[3] / l00, l20 = T[6] / l00;
+  double l11 = T[4] - l10 * l10; if (!(l11 > 0.0)) return false; l11 = std::sqrt(l11);
+  const double l21 = (T[7] - l20 * l10) / l11;
+  double l22 = T[8] - l20 * l20 - l21 * l21; if (!(l22 > 0.0)) return false; l22 = std::sqrt(l22);
+  // M = L^-1 (lower)
+  const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
+  const double m10 = -(l10 * m00) / l11;
+  const double m21 = -(l21 * m11) / l22;
+  const double m20 = -(l20 * m00 + l21 * m10) / l22;
+  // Tinv = M^T M
+  Tinv[0] = m00 * m00 + m10 * m10 + m20 * m20;
+  Tinv[1] = Tinv[3] = m10 * m11 + m20 * m21;
+  Tinv[2] = Tinv[6] = m20 * m22;
+  Tinv[4] = m11 * m11 + m21 * m21;
+  Tinv[5] = Tinv[7] = m21 * m22;
+  Tinv[8] = m22 * m22;
+  return true;
+}
+
+// --------------------------------------------------------------------------
+// Problem in oracle form
+// --------------------------------------------------------------------------
+struct Problem {
+  int num_blocks = 0;
+  std::vector<int> block_size, block_off;  // parameter blocks in x
+  int num_params = 0;
+  int num_res_blocks = 0;
+  std::vector<int> functor, res_off, const_off, pidx_off, pidx;
+  const double* consts = nullptr;
+  int num_residuals = 0;
+};
+
+struct DenseEval {  // dense Jacobian, row-major m x n
+  std::vector<double> r, J;
+};
+
+static bool evaluate_dense(const Problem& P, const double* x, bool want_jac, DenseEval* out,
+                           double* cost) {
+  const int m = P.num_residuals, n = P.num_params;
+  out->r.assign(m, 0.0);
+  if (want_jac) out->J.assign((size_t)m * n, 0.0);
+  bool ok = true;
+  for (int b = 0; b < P.num_res_blocks; ++b) {
+    FunctorInfo fi; functor_info(P.functor[b], &fi);
+    const double* params[16]; double jbuf[16][64]; double* jac[16];
+    for (int i = 0; i < fi.num_blocks; ++i) {
+      params[i] = x + P.block_off[P.pidx[P.pidx_off[b] + i]];
+      jac[i] = jbuf[i];
+    }
+    double res[8];
+    if (!evaluate_block(P.functor[b], P.consts + P.const_off[b], params, res,
+                        want_jac ? jac : nullptr)) { ok = false; break; }
+    for (int r = 0; r < fi.num_residuals; ++r) out->r[P.res_off[b] + r] = res[r];
+    if (want_jac) {
+      for (int i = 0; i < fi.num_blocks; ++i) {
+        const int off = P.block_off[P.pidx[P.pidx_off[b] + i]];
+        for (int r = 0; r < fi.num_residuals; ++r)
+          for (int p = 0; p < fi.N[i]; ++p)
+            out->J[(size_t)(P.res_off[b] + r) * n + off + p] += jbuf[i][r * fi.N[i] + p];
+      }
+    }
+  }
+  if (!ok) return false;
+  double c = 0.0;
+  for (int i = 0; i < m; ++i) c += out->r[i] * out->r[i];
+  *cost = 0.5 * c;
+  return true;
+}
+
+// Householder QR least squares on the (rows x n) column-major matrix A,
+// rhs b (length rows).  Returns y with R y = (Q^T b)[0:n].
+static bool householder_qr_solve(std::vector<double>& A, std::vector<double>& b, int rows, int n,
+                                 double* y) {
+  for (int k = 0; k < n; ++k) {
+    double* a = &A[(size_t)k * rows];
+    double norm = 0.0;
+    for (int i = k; i < rows; ++i) norm += a[i] * a[i];
+    norm = std::sqrt(norm);
+    if (norm == 0.0) return false;
+    const double alpha = a[k] > 0 ? -norm : norm;
+    // v = a[k:] - alpha e_k ; normalised implicitly
+    const double v0 = a[k] - alpha;
+    double vnorm2 = v0 * v0;
+    for (int i = k + 1; i < rows; ++i) vnorm2 += a[i] * a[i];
+    if (vnorm2 == 0.0) { a[k] = alpha; continue; }
+    std::vector<double> v(rows - k);
+    v[0] = v0; for (int i = k + 1; i < rows; ++i) v[i - k] = a[i];
+    a[k] = alpha; for (int i = k + 1; i < rows; ++i) a[i] = 0.0;
+    for (int j = k + 1; j < n; ++j) {
+      double* c = &A[(size_t)j * rows];
+      double dot = 0.0; for (int i = k; i < rows; ++i) dot += v[i - k] * c[i];
+      const double f = 2.0 * dot / vnorm2;
+      for (int i = k; i < rows; ++i) c[i] -= f * v[i - k];
+    }
+    double dot = 0.0; for (int i = k; i < rows; ++i) dot += v[i - k] * b[i];
+    const double f = 2.0 * dot / vnorm2;
+    for (int i = k; i < rows; ++i) b[i] -= f * v[i - k];
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    double s = b[k];
+    for (int j = k + 1; j < n; ++j) s -= A[(size_t)j * rows + k] * y[j];
+    const double d = A[(size_t)k * rows + k];
+    if (d == 0.0) return false;
+    y[k] = s / d;
+  }
+  return true;
+}
+
+// --------------------------------------------------------------------------
+// BAL-shaped (kRes=2, f-block 9, e-block 3) Schur path
+// --------------------------------------------------------------------------
+struct Bal {
+  int C = 0, P = 0, N = 0;
+  std::vector<int> cam, pt;                  // per observation
+  std::vector<int> cam_start, cam_obs;       // CSR: observations of a camera (sorted by point)
+  std::vector<int> pt_start, pt_obs;         // CSR: observations of a point (sorted by camera)
+  const double* consts = nullptr;            // 2 per observation
+  std::vector<double> r, F, E;               // 2N, 18N, 6N
+};
+
+static bool bal_evaluate(Bal& B, const double* x, bool want_jac, double* cost, int nthreads) {
+  const int N = B.N; const double* cams = x; const double* pts = x + 9 * (size_t)B.C;
+  B.r.resize(2 * (size_t)N);
+  if (want_jac) { B.F.resize(18 * (size_t)N); B.E.resize(6 * (size_t)N); }
+  int bad = 0;
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(+ : bad)
+  for (int o = 0; o < N; ++o) {
+    const double* params[2] = {cams + 9 * (size_t)B.cam[o], pts + 3 * (size_t)B.pt[o]};
+    double* jac[2] = {want_jac ? &B.F[18 * (size_t)o] : nullptr, want_jac ? &B.E[6 * (size_t)o] : nullptr};
+    if (!AutoDiff<SnavelyReprojectionError>::evaluate(B.consts + 2 * (size_t)o, params,
+                                                      &B.r[2 * (size_t)o], want_jac ? jac : nullptr)) bad++;
+  }
+  if (bad) return false;
+  double c = 0.0;
+  for (size_t i = 0; i < 2 * (size_t)N; ++i) c += B.r[i] * B.r[i];
+  *cost = 0.5 * c;
+  return std::isfinite(*cost);
+}
+
+struct SchurWork {
+  std::vector<double> S, rhs, Tinv, g, W, Y;
+  double t_assemble = 0, t_chol = 0, t_backsub = 0;
+};
+
+// Solve (J^T J + D^2) y = J^T r for the scaled Jacobian held in B.F / B.E.
+static bool bal_schur_solve(const Bal& B, const double* D, double* y, SchurWork& w, int nthreads) {
+  const int C = B.C, P = B.P, N = B.N; const int n = 9 * C;
+  const double* Dc = D; const double* Dp = D + 9 * (size_t)C;
+  double t0 = now_s();
+  w.S.assign((size_t)n * n, 0.0); w.rhs.assign(n, 0.0);
+  w.Tinv.resize(9 * (size_t)P); w.g.resize(3 * (size_t)P);
+  w.W.resize(27 * (size_t)N); w.Y.resize(27 * (size_t)N);
+  int bad = 0;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 256) reduction(+ : bad)
+  for (int p = 0; p < P; ++p) {
+    double T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int k = B.pt_start[p]; k < B.pt_start[p + 1]; ++k) {
+      const int o = B.pt_obs[k]; const double* E = &B.E[6 * (size_t)o]; const double* r = &B.r[2 * (size_t)o];
+      for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) T[3 * a + b] += E[a] * E[b] + E[3 + a] * E[3 + b];
+        g[a] += E[a] * r[0] + E[3 + a] * r[1];
+      }
+    }
+    for (int a = 0; a < 3; ++a) T[4 * a] += Dp[3 * (size_t)p + a] * Dp[3 * (size_t)p + a];
+    double* Ti = &w.Tinv[9 * (size_t)p];
+    if (!invert_spd3(T, Ti)) { bad++; continue; }
+    for (int a = 0; a < 3; ++a) w.g[3 * (size_t)p + a] = g[a];
+    for (int k = B.pt_start[p]; k < B.pt_start[p + 1]; ++k) {
+      const int o = B.pt_obs[k]; const double* F = &B.F[18 * (size_t)o]; const double* E = &B.E[6 * (size_t)o];
+      double* W = &w.W[27 * (size_t)o]; double* Y = &w.Y[27 * (size_t)o];
+      for (int c = 0; c < 9; ++c)
+        for (int a = 0; a < 3; ++a) W[3 * c + a] = F[c] * E[a] + F[9 + c] * E[3 + a];
+      for (int c = 0; c < 9; ++c)
+        for (int a = 0; a < 3; ++a)
+          Y[3 * c + a] = W[3 * c] * Ti[a] + W[3 * c + 1] * Ti[3 + a] + W[3 * c + 2] * Ti[6 + a];
+    }
+  }
+  if (bad) return false;
+  // Row-block i of S is owned by one thread: deterministic accumulation order
+  // (observations of camera i ascending by point; partners ascending by camera).
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
+  for (int i = 0; i < C; ++i) {
+    double* Srow = &w.S[(size_t)(9 * i) * n]; double* rhs = &w.rhs[9 * (size_t)i];
+    for (int c = 0; c < 9; ++c) Srow[(size_t)c * n + 9 * i + c] += Dc[9 * (size_t)i + c] * Dc[9 * (size_t)i + c];
+    for (int k = B.cam_start[i]; k < B.cam_start[i + 1]; ++k) {
+      const int a = B.cam_obs[k]; const int p = B.pt[a];
+      const double* F = &B.F[18 * (size_t)a]; const double* r = &B.r[2 * (size_t)a];
+      const double* Ya = &w.Y[27 * (size_t)a]; const double* g = &w.g[3 * (size_t)p];
+      for (int c = 0; c < 9; ++c) {
+        for (int d = 0; d < 9; ++d) Srow[(size_t)c * n + 9 * i + d] += F[c] * F[d] + F[9 + c] * F[9 + d];
+        rhs[c] += F[c] * r[0] + F[9 + c] * r[1];
+        rhs[c] -= Ya[3 * c] * g[0] + Ya[3 * c + 1] * g[1] + Ya[3 * c + 2] * g[2];
+      }
+      for (int kk = B.pt_start[p]; kk < B.pt_start[p + 1]; ++kk) {
+        const int b = B.pt_obs[kk]; const int j = B.cam[b];
+        if (j > i) break;  // lower triangle only (pt_obs sorted by camera)
+        const double* Wb = &w.W[27 * (size_t)b];
+        for (int c = 0; c < 9; ++c)
+          for (int d = 0; d < 9; ++d)
+            Srow[(size_t)c * n + 9 * j + d] -= Ya[3 * c] * Wb[3 * d] + Ya[3 * c + 1] * Wb[3 * d + 1] + Ya[3 * c + 2] * Wb[3 * d + 2];
+      }
+    }
+  }
+  double t1 = now_s(); w.t_assemble += t1 - t0;
+  if (cholesky_lower_inplace(w.S.data(), n, n, nthreads) != 0) return false;
+  std::vector<double> yc(w.rhs);
+  cholesky_solve_lower(w.S.data(), n, n, yc.data());
+  double t2 = now_s(); w.t_chol += t2 - t1;
+  for (int i = 0; i < n; ++i) y[i] = yc[i];
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 256)
+  for (int p = 0; p < P; ++p) {
+    double t[3] = {w.g[3 * (size_t)p], w.g[3 * (size_t)p + 1], w.g[3 * (size_t)p + 2]};
+    for (int k = B.pt_start[p]; k < B.pt_start[p + 1]; ++k) {
+      const int o = B.pt_obs[k]; const double* W = &w.W[27 * (size_t)o]; const double* yi = &yc[9 * (size_t)B.cam[o]];
+      for (int a = 0; a < 3; ++a) {
+        double s = 0.0; for (int c = 0; c < 9; ++c) s += W[3 * c + a] * yi[c];
+        t[a] -= s;
+      }
+    }
+    const double* Ti = &w.Tinv[9 * (size_t)p];
+    for (int a = 0; a < 3; ++a) y[n + 3 * (size_t)p + a] = Ti[3 * a] * t[0] + Ti[3 * a + 1] * t[1] + Ti[3 * a + 2] * t[2];
+  }
+  w.t_backsub += now_s() - t2;
+  return true;
+}
+
+// --------------------------------------------------------------------------
+// The trust-region loop, shared by the dense and the BAL/Schur representations
+// --------------------------------------------------------------------------
+struct Model {
+  // evaluate at x: cost (+ residuals/Jacobian kept inside when want_jac)
+  virtual bool evaluate(const double* x, bool want_jac, double* cost) = 0;
+  virtual int num_params() const = 0;
+  virtual void column_sq_norms(double* out) = 0;      // of the CURRENT (possibly scaled) Jacobian
+  virtual void scale_columns(const double* s) = 0;    // J <- J diag(s)
+  virtual void gradient(double* g) = 0;               // J^T r of the CURRENT Jacobian
+  virtual bool solve(const double* D, double* y) = 0;  // (J^T J + D^2) y = J^T r
+  virtual double model_cost_change(const double* step) = 0;
+  virtual ~Model() {}
+};
+
+struct DenseModel : Model {
+  const Problem& P; int solver; DenseEval cur, cand;
+  DenseModel(const Problem& p, int s) : P(p), solver(s) {}
+  int num_params() const override { return P.num_params; }
+  bool evaluate(const double* x, bool want_jac, double* cost) override {
+    return evaluate_dense(P, x, want_jac, want_jac ? &cur : &cand, cost) && std::isfinite(*cost);
+  }
+  void column_sq_norms(double* out) override {
+    const int m = P.num_residuals, n = P.num_params;
+    for (int j = 0; j < n; ++j) out[j] = 0.0;
+    for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) out[j] += cur.J[(size_t)i * n + j] * cur.J[(size_t)i * n + j];
+  }
+  void scale_columns(const double* s) override {
+    const int m = P.num_residuals, n = P.num_params;
+    for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) cur.J[(size_t)i * n + j] *= s[j];
+  }
+  void gradient(double* g) override {
+    const int m = P.num_residuals, n = P.num_params;
+    for (int j = 0; j < n; ++j) g[j] = 0.0;
+    for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) g[j] += cur.J[(size_t)i * n + j] * cur.r[i];
+  }
+  bool solve(const double* D, double* y) override {
+    const int m = P.num_residuals, n = P.num_params;
+    if (solver == OR_DENSE_QR) {
+      const int rows = m + n;
+      std::vector<double> A((size_t)rows * n, 0.0), b(rows, 0.0);
+      for (int i = 0; i < m; ++i) { b[i] = cur.r[i]; for (int j = 0; j < n; ++j) A[(size_t)j * rows + i] = cur.J[(size_t)i * n + j]; }
+      for (int j = 0; j < n; ++j) A[(size_t)j * rows + m + j] = D[j];
+      return householder_qr_solve(A, b, rows, n, y);
+    }
+    std::vector<double> H((size_t)n * n, 0.0);
+    for (int i = 0; i < m; ++i) {
+      const double* Ji = &cur.J[(size_t)i * n];
+      for (int a = 0; a < n; ++a) { const double ja = Ji[a]; if (ja == 0.0) continue; for (int b = 0; b <= a; ++b) H[(size_t)a * n + b] += ja * Ji[b]; }
+    }
+    for (int a = 0; a < n; ++a) H[(size_t)a * n + a] += D[a] * D[a];
+    gradient(y);
+    if (cholesky_lower_inplace(H.data(), n, n, 1) != 0) return false;
+    cholesky_solve_lower(H.data(), n, n, y);
+    return true;
+  }
+  double model_cost_change(const double* step) override {
+    const int m = P.num_residuals, n = P.num_params; double acc = 0.0;
+    for (int i = 0; i < m; ++i) {
+      double mr = 0.0; for (int j = 0; j < n; ++j) mr += cur.J[(size_t)i * n + j] * step[j];
+      acc += mr * (cur.r[i] + mr / 2.0);
+    }
+    return -acc;
+  }
+};
+
+struct BalModel : Model {
+  Bal& B; SchurWork w; int nthreads; std::vector<double> r_cur;
+  BalModel(Bal& b, int nt) : B(b), nthreads(nt) {}
+  int num_params() const override { return 9 * B.C + 3 * B.P; }
+  bool evaluate(const double* x, bool want_jac, double* cost) override {
+    if (!want_jac) { std::vector<double> keep; keep.swap(B.r); bool ok = bal_evaluate(B, x, false, cost, nthreads); B.r.swap(keep); return ok; }
+    return bal_evaluate(B, x, true, cost, nthreads);
+  }
+  void column_sq_norms(double* out) override {
+    const int C = B.C, P = B.P;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 16)
+    for (int i = 0; i < C; ++i) {
+      double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = B.cam_start[i]; k < B.cam_start[i + 1]; ++k) { const double* F = &B.F[18 * (size_t)B.cam_obs[k]]; for (int c = 0; c < 9; ++c) s[c] += F[c] * F[c] + F[9 + c] * F[9 + c]; }
+      for (int c = 0; c < 9; ++c) out[9 * (size_t)i + c] = s[c];
+    }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 256)
+    for (int p = 0; p < P; ++p) {
+      double s[3] = {0, 0, 0};
+      for (int k = B.pt_start[p]; k < B.pt_start[p + 1]; ++k) { const double* E = &B.E[6 * (size_t)B.pt_obs[k]]; for (int a = 0; a < 3; ++a) s[a] += E[a] * E[a] + E[3 + a] * E[3 + a]; }
+      for (int a = 0; a < 3; ++a) out[9 * (size_t)C + 3 * (size_t)p + a] = s[a];
+    }
+  }
+  void scale_columns(const double* s) override {
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int o = 0; o < B.N; ++o) {
+      const double* sc = s + 9 * (size_t)B.cam[o]; const double* sp = s + 9 * (size_t)B.C + 3 * (size_t)B.pt[o];
+      double* F = &B.F[18 * (size_t)o]; double* E = &B.E[6 * (size_t)o];
+      for (int c = 0; c < 9; ++c) { F[c] *= sc[c]; F[9 + c] *= sc[c]; }
+      for (int a = 0; a < 3; ++a) { E[a] *= sp[a]; E[3 + a] *= sp[a]; }
+    }
+  }
+  void gradient(double* g) override {
+    const int C = B.C, P = B.P;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 16)
+    for (int i = 0; i < C; ++i) {
+      double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = B.cam_start[i]; k < B.cam_start[i + 1]; ++k) { const int o = B.cam_obs[k]; const double* F = &B.F[18 * (size_t)o]; for (int c = 0; c < 9; ++c) s[c] += F[c] * B.r[2 * (size_t)o] + F[9 + c] * B.r[2 * (size_t)o + 1]; }
+      for (int c = 0; c < 9; ++c) g[9 * (size_t)i + c] = s[c];
+    }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 256)
+    for (int p = 0; p < P; ++p) {
+      double s[3] = {0, 0, 0};
+      for (int k = B.pt_start[p]; k < B.pt_start[p + 1]; ++k) { const int o = B.pt_obs[k]; const double* E = &B.E[6 * (size_t)o]; for (int a = 0; a < 3; ++a) s[a] += E[a] * B.r[2 * (size_t)o] + E[3 + a] * B.r[2 * (size_t)o + 1]; }
+      for (int a = 0; a < 3; ++a) g[9 * (size_t)C + 3 * (size_t)p + a] = s[a];
+    }
+  }
+  bool solve(const double* D, double* y) override { return bal_schur_solve(B, D, y, w, nthreads); }
+  double model_cost_change(const double* step) override {
+    double acc = 0.0;
+    for (int o = 0; o < B.N; ++o) {
+      const double* sc = step + 9 * (size_t)B.cam[o]; const double* sp = step + 9 * (size_t)B.C + 3 * (size_t)B.pt[o];
+      const double* F = &B.F[18 * (size_t)o]; const double* E = &B.E[6 * (size_t)o];
+      for (int r = 0; r < 2; ++r) {
+        double mr = 0.0;
+        for (int c = 0; c < 9; ++c) mr += F[9 * r + c] * sc[c];
+        for (int a = 0; a < 3; ++a) mr += E[3 * r + a] * sp[a];
+        acc += mr * (B.r[2 * (size_t)o + r] + mr / 2.0);
+      }
+    }
+    return -acc;
+  }
+};
+
+static double max_abs(const double* v, int n) { double m = 0.0; for (int i = 0; i < n; ++i) m = std::max(m, std::fabs(v[i])); return m; }
+static double norm2(const double* v, int n) { double s = 0.0; for (int i = 0; i < n; ++i) s += v[i] * v[i]; return std::sqrt(s); }
+
+static void log_iter(or_summary* S, int it, double cost, double cost_change, double gmax, double step_norm,
+                     double rho, double radius, int valid, int success) {
+  if (it < OR_MAX_LOG) {
+    or_iteration& L = S->iterations[it];
+    L.iteration = it; L.cost = cost; L.cost_change = cost_change; L.gradient_max_norm = gmax;
+    L.step_norm = step_norm; L.relative_decrease = rho; L.trust_region_radius = radius;
+    L.step_is_valid = valid; L.step_is_successful = success;
+    S->num_logged = it + 1;
+  }
+}
+
+static void minimize(Model& M, const or_options& O, double* x, or_summary* S) {
+  const int n = M.num_params();
+  std::vector<double> scale(n, 1.0), diag(n), D(n), y(n), step(n), delta(n), xc(n), g(n), gs(n);
+  double cost = 0.0;
+  std::memset(S, 0, sizeof(*S));
+  double t_begin = now_s();
+  if (!M.evaluate(x, true, &cost)) { S->termination_type = OR_FAILURE; std::snprintf(S->message, sizeof(S->message), "Initial residual and Jacobian evaluation failed."); return; }
+  S->initial_cost = cost;
+  M.gradient(g.data());  // unscaled Jacobian
+  double gmax = max_abs(g.data(), n);
+  if (O.jacobi_scaling) {
+    M.column_sq_norms(diag.data());
+    for (int j = 0; j < n; ++j) scale[j] = 1.0 / (1.0 + std::sqrt(diag[j]));
+    M.scale_columns(scale.data());
+  }
+  double radius = O.initial_trust_region_radius, decrease_factor = 2.0;
+  double x_norm = norm2(x, n);
+  int iteration = 0, invalid = 0, n_success = 0, n_unsuccess = 0;
+  log_iter(S, 0, cost, 0.0, gmax, 0.0, 0.0, radius, 1, 1);
+  S->termination_type = OR_NO_CONVERGENCE;
+  for (;;) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (iteration >= O.max_num_iterations) { S->termination_type = OR_NO_CONVERGENCE; std::snprintf(S->message, sizeof(S->message), "Maximum number of iterations reached. Number of iterations: %d.", iteration); break; }
+    if (gmax <= O.gradient_tolerance) { S->termination_type = OR_CONVERGENCE; std::snprintf(S->message, sizeof(S->message), "Gradient tolerance reached. Gradient max norm: %e <= %e", gmax, O.gradient_tolerance); break; }
+    if (radius < O.min_trust_region_radius) { S->termination_type = OR_CONVERGENCE; std::snprintf(S->message, sizeof(S->message), "Minimum trust region radius reached. Trust region radius: %e <= %e", radius, O.min_trust_region_radius); break; }
+    ++iteration;
+    // LevenbergMarquardtStrategy::ComputeStep
+    M.column_sq_norms(diag.data());
+    for (int j = 0; j < n; ++j) D[j] = std::sqrt(std::min(std::max(diag[j], O.min_lm_diagonal), O.max_lm_diagonal) / radius);
+    bool valid = M.solve(D.data(), y.data()) && all_finite(y.data(), n);
+    double mcc = 0.0;
+    if (valid) {
+      for (int j = 0; j < n; ++j) step[j] = -y[j];
+      mcc = M.model_cost_change(step.data());
+      if (!(mcc > 0.0)) valid = false;
+    }
+    if (!valid) {
+      ++invalid;
+      if (invalid >= O.max_num_consecutive_invalid_steps) { S->termination_type = OR_FAILURE; std::snprintf(S->message, sizeof(S->message), "Number of consecutive invalid steps more than Solver::Options::max_num_consecutive_invalid_steps: %d", O.max_num_consecutive_invalid_steps); log_iter(S, iteration, cost, 0.0, gmax, 0.0, 0.0, radius, 0, 0); break; }
+      radius /= decrease_factor; decrease_factor *= 2.0;  // StepIsInvalid == StepRejected
+      log_iter(S, iteration, cost, 0.0, gmax, 0.0, 0.0, radius, 0, 0);
+      continue;
+    }
+    invalid = 0;
+    for (int j = 0; j < n; ++j) { delta[j] = step[j] * scale[j]; xc[j] = x[j] + delta[j]; }
+    double new_cost = std::numeric_limits<double>::max();
+    if (!M.evaluate(xc.data(), false, &new_cost)) new_cost = std::numeric_limits<double>::max();
+    double sn = 0.0; for (int j = 0; j < n; ++j) { const double d = x[j] - xc[j]; sn += d * d; } sn = std::sqrt(sn);
+    const double cost_change = cost - new_cost;
+    if (sn <= O.parameter_tolerance * (x_norm + O.parameter_tolerance)) {
+      S->termination_type = OR_CONVERGENCE; std::snprintf(S->message, sizeof(S->message), "Parameter tolerance reached. Relative step_norm: %e <= %e.", sn / (x_norm + O.parameter_tolerance), O.parameter_tolerance);
+      log_iter(S, iteration, cost, cost_change, gmax, sn, 0.0, radius, 1, 0); break;
+    }
+    if (std::fabs(cost_change) <= O.function_tolerance * cost) {
+      S->termination_type = OR_CONVERGENCE; std::snprintf(S->message, sizeof(S->message), "Function tolerance reached. |cost_change|/cost: %e <= %e", std::fabs(cost_change) / cost, O.function_tolerance);
+      log_iter(S, iteration, cost, cost_change, gmax, sn, 0.0, radius, 1, 0); break;
+    }
+    const double rho = cost_change / mcc;
+    if (rho > O.min_relative_decrease) {
+      for (int j = 0; j < n; ++j) x[j] = xc[j];
+      x_norm = norm2(x, n);
+      if (!M.evaluate(x, true, &cost)) { S->termination_type = OR_FAILURE; std::snprintf(S->message, sizeof(S->message), "Residual and Jacobian evaluation failed."); break; }
+      M.gradient(g.data()); gmax = max_abs(g.data(), n);
+      if (O.jacobi_scaling) M.scale_columns(scale.data());
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
+      radius = std::min(O.max_trust_region_radius, radius);
+      decrease_factor = 2.0; ++n_success;
+      log_iter(S, iteration, cost, cost_change, gmax, sn, rho, radius, 1, 1);
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; ++n_unsuccess;
+      log_iter(S, iteration, cost, cost_change, gmax, sn, rho, radius, 1, 0);
+    }
+  }
+  S->final_cost = cost; S->num_iterations = iteration;
+  S->num_successful_steps = n_success; S->num_unsuccessful_steps = n_unsuccess;
+  S->total_time_s = now_s() - t_begin;
+}
+
+}  // namespace oracle
+
+// ============================================================================
+// C ABI (ctypes from tests/, bench.py cpu_baseline leg)
+// ============================================================================
+using namespace oracle;
+
+extern "C" {
+
+void or_options_default(or_options* o) {
+  o->linear_solver_type = OR_DENSE_QR;
+  o->max_num_iterations = 50;
+  o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+  o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+  o->jacobi_scaling = 1; o->max_num_consecutive_invalid_steps = 5; o->num_threads = 1;
+}
+
+int or_functor_info(int id, int* num_residuals, int* num_blocks, int* num_consts, int* block_sizes) {
+  FunctorInfo fi; if (!functor_info(id, &fi)) return 0;
+  *num_residuals = fi.num_residuals; *num_blocks = fi.num_blocks; *num_consts = fi.num_consts;
+  for (int i = 0; i < fi.num_blocks; ++i) block_sizes[i] = fi.N[i];
+  return 1;
+}
+
+// AutoDiffCostFunction.evaluate for one residual block (CORE/AutodiffCostFunction.scala:74-134)
+int or_evaluate(int functor_id, const double* consts, double const* const* parameters,
+                double* residuals, double** jacobians) {
+  return evaluate_block(functor_id, consts, parameters, residuals, jacobians) ? 1 : 0;
+}
+
+void or_angle_axis_rotate_point(const double* aa, const double* pt, double* out) {
+  angleAxisRotatePoint<double>(aa, pt, out);
+}
+void or_angle_axis_to_rotation_matrix(const double* aa, double* R_rowmajor) {
+  angleAxisToRotationMatrix(aa, R_rowmajor);
+}
+
+// Generic problem: parameter blocks live in x (block b at x[block_off[b]]).
+int or_solve(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
+             const int* functor_ids, const double* consts, const int* const_off,
+             const int* pidx, const int* pidx_off, const or_options* opt, or_summary* summary) {
+  Problem P; P.num_blocks = num_blocks; P.block_size.assign(block_sizes, block_sizes + num_blocks);
+  P.block_off.resize(num_blocks); int off = 0;
+  for (int b = 0; b < num_blocks; ++b) { P.block_off[b] = off; off += block_sizes[b]; }
+  P.num_params = off; P.num_res_blocks = num_res_blocks;
+  P.functor.assign(functor_ids, functor_ids + num_res_blocks);
+  P.const_off.assign(const_off, const_off + num_res_blocks);
+  P.pidx_off.assign(pidx_off, pidx_off + num_res_blocks + 1);
+  P.pidx.assign(pidx, pidx + pidx_off[num_res_blocks]);
+  P.consts = consts; P.res_off.resize(num_res_blocks); int m = 0;
+  for (int b = 0; b < num_res_blocks; ++b) {
+    FunctorInfo fi; if (!functor_info(functor_ids[b], &fi)) return -1;
+    if (P.pidx_off[b + 1] - P.pidx_off[b] != fi.num_blocks) return -2;
+    for (int i = 0; i < fi.num_blocks; ++i) if (block_sizes[P.pidx[P.pidx_off[b] + i]] != fi.N[i]) return -3;
+    P.res_off[b] = m; m += fi.num_residuals;
+  }
+  P.num_residuals = m;
+  if (opt->linear_solver_type != OR_DENSE_QR && opt->linear_solver_type != OR_DENSE_NORMAL_CHOLESKY) return -4;
+  DenseModel M(P, opt->linear_solver_type);
+  minimize(M, *opt, x, summary);
+  return 0;
+}
+
+// BAL-shaped problem, SnavelyReprojectionError blocks only, x = [9C cameras | 3P points]
+// (memory layout of EX/SimpleBundleAdjuster.scala:18-34).  DENSE_SCHUR.
+int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                 double* x, const or_options* opt, or_summary* summary) {
+  Bal B; B.C = C; B.P = P; B.N = N; B.cam.assign(cam_idx, cam_idx + N); B.pt.assign(pt_idx, pt_idx + N);
+  B.consts = obs;
+  B.cam_start.assign(C + 1, 0); B.pt_start.assign(P + 1, 0);
+  for (int o = 0; o < N; ++o) { if (cam_idx[o] < 0 || cam_idx[o] >= C || pt_idx[o] < 0 || pt_idx[o] >= P) return -1; B.cam_start[cam_idx[o] + 1]++; B.pt_start[pt_idx[o] + 1]++; }
+  for (int i = 0; i < C; ++i) B.cam_start[i + 1] += B.cam_start[i];
+  for (int p = 0; p < P; ++p) B.pt_start[p + 1] += B.pt_start[p];
+  B.cam_obs.resize(N); B.pt_obs.resize(N);
+  { std::vector<int> fill(B.cam_start.begin(), B.cam_start.end() - 1); for (int o = 0; o < N; ++o) B.cam_obs[fill[cam_idx[o]]++] = o; }
+  { std::vector<int> fill(B.pt_start.begin(), B.pt_start.end() - 1); for (int o = 0; o < N; ++o) B.pt_obs[fill[pt_idx[o]]++] = o; }
+  for (int i = 0; i < C; ++i) std::sort(B.cam_obs.begin() + B.cam_start[i], B.cam_obs.begin() + B.cam_start[i + 1], [&](int a, int b) { return pt_idx[a] != pt_idx[b] ? pt_idx[a] < pt_idx[b] : a < b; });
+  for (int p = 0; p < P; ++p) std::sort(B.pt_obs.begin() + B.pt_start[p], B.pt_obs.begin() + B.pt_start[p + 1], [&](int a, int b) { return cam_idx[a] != cam_idx[b] ? cam_idx[a] < cam_idx[b] : a < b; });
+  int nt = opt->num_threads;
+#ifdef _OPENMP
+  if (nt <= 0) nt = omp_get_max_threads();
+#else
+  nt = 1;
+#endif
+  BalModel M(B, nt);
+  minimize(M, *opt, x, summary);
+  summary->t_linear_assemble_s = M.w.t_assemble; summary->t_linear_cholesky_s = M.w.t_chol; summary->t_linear_backsub_s = M.w.t_backsub;
+  summary->num_threads_used = nt;
+  return 0;
+}
+
+// Stand-alone pieces for kernel-level parity tests -------------------------------
+// Evaluate all Snavely blocks: r (2N), F (18N row-major 2x9), E (6N row-major 2x3).
+int or_bal_evaluate(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                    const double* x, double* r, double* F, double* E, double* cost) {
+  Bal B; B.C = C; B.P = P; B.N = N; B.cam.assign(cam_idx, cam_idx + N); B.pt.assign(pt_idx, pt_idx + N); B.consts = obs;
+  const bool jac = F != nullptr;
+  if (!bal_evaluate(B, x, jac, cost, 1)) return 0;
+  std::memcpy(r, B.r.data(), sizeof(double) * 2 * (size_t)N);
+  if (jac) { std::memcpy(F, B.F.data(), sizeof(double) * 18 * (size_t)N); std::memcpy(E, B.E.data(), sizeof(double) * 6 * (size_t)N); }
+  return 1;
+}
+
+int or_cholesky_lower(double* A, int n, int num_threads) { return cholesky_lower_inplace(A, n, n, num_threads); }
+void or_cholesky_solve(const double* L, int n, double* b) { cholesky_solve_lower(L, n, n, b); }
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.  C ABI of the CPU restatement (oracle/ sources).
+ * Loaded through ctypes by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg.  Never linked into or called by the product library. */
+#ifndef SKERES_ORACLE_H
+#define SKERES_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ceres::LinearSolverType numbering (ceres/types.h [ext]) */
+enum { OR_DENSE_NORMAL_CHOLESKY = 0, OR_DENSE_QR = 1, OR_DENSE_SCHUR = 3 };
+/* ceres::TerminationType */
+enum { OR_CONVERGENCE = 0, OR_NO_CONVERGENCE = 1, OR_FAILURE = 2 };
+
+#define OR_MAX_LOG 256
+
+typedef struct or_options {
+  int linear_solver_type;
+  int max_num_iterations;
+  double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+  double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+  double function_tolerance, gradient_tolerance, parameter_tolerance;
+  int jacobi_scaling;
+  int max_num_consecutive_invalid_steps;
+  int num_threads; /* <=0: all cores */
+} or_options;
+
+typedef struct or_iteration {
+  int iteration;
+  double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
+  int step_is_valid, step_is_successful;
+} or_iteration;
+
+typedef struct or_summary {
+  double initial_cost, final_cost;
+  int num_iterations, num_successful_steps, num_unsuccessful_steps, termination_type;
+  int num_logged, num_threads_used;
+  double total_time_s, t_linear_assemble_s, t_linear_cholesky_s, t_linear_backsub_s;
+  char message[256];
+  or_iteration iterations[OR_MAX_LOG];
+} or_summary;
+
+void or_options_default(or_options* o);
+int or_functor_info(int id, int* num_residuals, int* num_blocks, int* num_consts, int* block_sizes);
+int or_evaluate(int functor_id, const double* consts, double const* const* parameters,
+                double* residuals, double** jacobians);
+void or_angle_axis_rotate_point(const double* aa, const double* pt, double* out);
+void or_angle_axis_to_rotation_matrix(const double* aa, double* R_rowmajor);
+int or_solve(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
+             const int* functor_ids, const double* consts, const int* const_off, const int* pidx,
+             const int* pidx_off, const or_options* opt, or_summary* summary);
+int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                 double* x, const or_options* opt, or_summary* summary);
+int or_bal_evaluate(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                    const double* x, double* r, double* F, double* E, double* cost);
+int or_cholesky_lower(double* A, int n, int num_threads);
+void or_cholesky_solve(const double* L, int n, double* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
