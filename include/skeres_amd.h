@@ -1,0 +1,273 @@
+/*
+ * skeres_amd.h — C ABI of libskeres_amd.so, the MI355X (gfx950) replacement for
+ * the SWIG/JNI module `ceres` + native libceres that fgcallari/skeres binds.
+ *
+ * Every entry point states the reference interface it replaces.  Paths are
+ * relative to the reference repository:
+ *   ceres.i
+ *   CORE = core/src/main/scala/org/somelightprojections/skeres
+ *   EX   = examples/src/main/scala/org/somelightprojections/skeres/examples
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; no C++ types, no exceptions cross the ABI;
+ *   - functions returning `int` return an sk_status (0 == SK_OK) unless the
+ *     comment says "boolean"; sk_last_error() holds the message of the last
+ *     failure on the calling thread;
+ *   - parameter memory is CALLER-OWNED host memory, identified by address, and
+ *     is updated in place when sk_solve returns (README.md:51-55);
+ *   - cost / loss objects are caller-owned; a Problem never frees them
+ *     (CORE/Problem.scala:7-13);
+ *   - one caller thread per problem / solver handle; sk_solve blocks;
+ *   - there is NO CPU fallback: every compute entry point needs a gfx950 device
+ *     and fails with SK_ERR_NO_DEVICE without one.
+ */
+#ifndef SKERES_AMD_H
+#define SKERES_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sk_status {
+  SK_OK = 0,
+  SK_ERR_INVALID_ARGUMENT = 1, /* JVM side: require(...) -> IllegalArgumentException */
+  SK_ERR_NO_DEVICE = 2,
+  SK_ERR_HIP = 3,
+  SK_ERR_UNSUPPORTED = 4,
+  SK_ERR_EVALUATION_FAILED = 5,
+  SK_ERR_COMM = 6
+} sk_status;
+
+/* ceres::LinearSolverType (ceres/types.h, %include'd at ceres.i:137);
+ * used at EX/SimpleBundleAdjuster.scala:148, EX/CurveFitting.scala:121 */
+typedef enum sk_linear_solver_type {
+  SK_DENSE_NORMAL_CHOLESKY = 0,
+  SK_DENSE_QR = 1,
+  SK_SPARSE_NORMAL_CHOLESKY = 2, /* not implemented: SK_ERR_UNSUPPORTED */
+  SK_DENSE_SCHUR = 3,
+  SK_SPARSE_SCHUR = 4,    /* not implemented */
+  SK_ITERATIVE_SCHUR = 5, /* not implemented */
+  SK_CGNR = 6             /* not implemented */
+} sk_linear_solver_type;
+
+/* ceres::MinimizerType; EX/Powell.scala:78 */
+typedef enum sk_minimizer_type { SK_LINE_SEARCH = 0, SK_TRUST_REGION = 1 } sk_minimizer_type;
+
+/* ceres::TerminationType, reported through Solver::Summary */
+typedef enum sk_termination_type {
+  SK_CONVERGENCE = 0,
+  SK_NO_CONVERGENCE = 1,
+  SK_FAILURE = 2,
+  SK_USER_SUCCESS = 3,
+  SK_USER_FAILURE = 4
+} sk_termination_type;
+
+/* ceres::Ownership; CORE/Problem.scala:10-13 forces DO_NOT_TAKE_OWNERSHIP */
+typedef enum sk_ownership { SK_DO_NOT_TAKE_OWNERSHIP = 0, SK_TAKE_OWNERSHIP = 1 } sk_ownership;
+
+/* Device functor registry.  In the reference the functor
+ * body is a JVM closure reached through the SWIG director upcall
+ * (ceres.i:48); a GPU cannot call it, so each functor on the hot path is a
+ * device template instantiated for double and Jet<N>, addressed by id, with
+ * its captured doubles passed as `consts`. */
+typedef enum sk_functor_id {
+  SK_FUNCTOR_HOST_CALLBACK = 0,           /* sk_cost_function_new_callback */
+  SK_FUNCTOR_SNAVELY_REPROJECTION = 1,    /* EX/SimpleBundleAdjuster.scala:79-119; consts (observedX, observedY) */
+  SK_FUNCTOR_EXPONENTIAL_RESIDUAL = 2,    /* EX/CurveFitting.scala:92-98; consts (x, y) */
+  SK_FUNCTOR_POWELL_F1 = 3,               /* EX/Powell.scala:14-21 */
+  SK_FUNCTOR_POWELL_F2 = 4,               /* EX/Powell.scala:24-31 */
+  SK_FUNCTOR_POWELL_F3 = 5,               /* EX/Powell.scala:34-42 */
+  SK_FUNCTOR_POWELL_F4 = 6,               /* EX/Powell.scala:45-53 */
+  SK_FUNCTOR_BINARY_SCALAR_COST = 7,      /* core/src/test/.../AutodiffCostFuntionSpec.scala:14-26; consts (a) */
+  SK_FUNCTOR_BINARY_VECTOR3_COST = 8,     /* AutodiffCostFuntionSpec.scala:55-69; consts (a) */
+  SK_FUNCTOR_TEN_PARAMETER_COST = 9       /* AutodiffCostFuntionSpec.scala:111-119 */
+} sk_functor_id;
+
+typedef struct sk_ptrvec sk_ptrvec;
+typedef struct sk_loss_function sk_loss_function;
+typedef struct sk_cost_function sk_cost_function;
+typedef struct sk_problem sk_problem;
+typedef struct sk_options sk_options;
+typedef struct sk_summary sk_summary;
+typedef struct sk_solver sk_solver;
+typedef int sk_residual_block_id; /* CORE/package.scala:13 ResidualBlockId */
+
+/* ---- library ------------------------------------------------------------ */
+const char* sk_version(void);
+const char* sk_last_error(void);
+/* ceres.i:131-135 initGoogleLogging(name): kept for call-site compatibility
+ * (EX/SimpleBundleAdjuster.scala:128); records the program name only. */
+void sk_init_logging(const char* name);
+/* Number of visible gfx950 devices (0 when none); does not fail. */
+int sk_device_count(void);
+
+/* ---- DoubleArray: ceres.i:95-96 %array_class(double, DoubleArray) -------- */
+double* sk_array_new(int n);                         /* new DoubleArray(n) */
+void sk_array_free(double* a);                       /* DoubleArray.delete() */
+double sk_array_getitem(const double* a, int i);     /* getitem; CORE/RichDoubleArray.scala:20 */
+void sk_array_setitem(double* a, int i, double v);   /* setitem; CORE/RichDoubleArray.scala:27 */
+/* DoubleArraySlice.get(buffer, start) == &buffer[start]; ceres.i:99-107,
+ * CORE/RichDoubleArray.scala:52.  Non-owning interior pointer. */
+double* sk_array_slice(double* buffer, int start);
+/* Bulk forms of CORE/RichDoubleArray.scala:36-39 (copyFrom) and :65-69
+ * (toArray), so a JVM caller crosses JNI once instead of once per element. */
+void sk_array_copy_in(double* dst, const double* src, int n);
+void sk_array_copy_out(const double* src, double* dst, int n);
+
+/* ---- DoubleMatrix: ceres.i:113-125 -------------------------------------- */
+int sk_matrix_is_null(double* const* matrix);        /* boolean */
+double* sk_matrix_row(double* const* matrix, int i);
+
+/* ---- StdVectorDoublePointer: ceres.i:82 (std::vector<double*>) ----------- */
+sk_ptrvec* sk_ptrvec_new(void);
+void sk_ptrvec_free(sk_ptrvec* v);
+void sk_ptrvec_add(sk_ptrvec* v, double* p);         /* CORE/Problem.scala:24-25 */
+int sk_ptrvec_size(const sk_ptrvec* v);
+double* sk_ptrvec_get(const sk_ptrvec* v, int i);
+void sk_ptrvec_set(sk_ptrvec* v, int i, double* p);  /* CORE/RichDoubleMatrix.scala:74-75 */
+double** sk_ptrvec_to_pointer_pointer(sk_ptrvec* v); /* DoubleMatrix.toPointerPointer; NULL when empty */
+
+/* ---- LossFunction: PredefinedLossFunctions, ceres.i:168-184 -------------- */
+sk_loss_function* sk_loss_trivial(void);             /* trivialLoss(): rho(s) = s; caller frees (%newobject, ceres.i:160) */
+void sk_loss_free(sk_loss_function* loss);
+
+/* ---- CostFunction -------------------------------------------------------- */
+/* AutoDiffCostFunctor.toAutoDiffCostFunction (CORE/CostFunctor.scala:44) for a
+ * functor with a device body.  Validates like CostFunctor / SizedCostFunction
+ * (CORE/CostFunctor.scala:31-34, CORE/SizedCostFunction.scala:7-13).  Returns
+ * NULL on an unknown id or wrong `num_consts`. */
+sk_cost_function* sk_cost_function_new_autodiff(int functor_id, const double* consts, int num_consts);
+
+/* Host-callback cost function: the reference's director path
+ * ceres::CostFunction::Evaluate(double const* const* parameters,
+ *   double* residuals, double** jacobians) -> bool   (ceres.i:48; overridden
+ * at CORE/AutodiffCostFunction.scala:74-78).  `jacobians` may be NULL and each
+ * jacobians[i] may be NULL; block i is row-major num_residuals x block_sizes[i].
+ * Returns boolean (0 == evaluation failed). */
+typedef int (*sk_evaluate_fn)(void* user, double const* const* parameters, double* residuals,
+                              double** jacobians);
+sk_cost_function* sk_cost_function_new_callback(sk_evaluate_fn fn, void* user, int num_residuals,
+                                                const int* block_sizes, int num_blocks);
+void sk_cost_function_free(sk_cost_function* cf);
+int sk_cost_function_num_residuals(const sk_cost_function* cf);             /* CostFunction.numResiduals() */
+int sk_cost_function_num_parameter_blocks(const sk_cost_function* cf);      /* parameterBlockSizes().size() */
+int sk_cost_function_parameter_block_size(const sk_cost_function* cf, int i);
+/* CostFunction.evaluate (CORE/AutodiffCostFunction.scala:74-134): evaluates ONE
+ * residual block.  Device functors run on the GPU (one lane).  Boolean result;
+ * a negative value is an error (see sk_last_error). */
+int sk_cost_function_evaluate(const sk_cost_function* cf, double const* const* parameters,
+                              double* residuals, double** jacobians);
+
+/* ---- Problem: CeresProblem + CORE/Problem.scala --------------------------- */
+sk_problem* sk_problem_new(void);                    /* new Problem (Options: never owns cost/loss) */
+void sk_problem_free(sk_problem* p);
+/* CeresProblem.addResidualBlock(CostFunction, LossFunction, StdVectorDoublePointer)
+ * (CORE/Problem.scala:20-27; the only overload left by ceres.i:53-70).
+ * Parameter blocks are identified BY POINTER VALUE; first sighting registers a
+ * block of the size the cost function declares; a later sighting with another
+ * size is SK_ERR_INVALID_ARGUMENT.  `loss` may be NULL (== trivial). */
+int sk_problem_add_residual_block(sk_problem* p, const sk_cost_function* cost,
+                                  const sk_loss_function* loss, double* const* parameter_blocks,
+                                  int num_parameter_blocks, sk_residual_block_id* id_out);
+/* Bulk form of the setup loop EX/SimpleBundleAdjuster.scala:139-145: adds
+ * `n` residual blocks of one device functor in one call.  consts is
+ * n x num_consts row-major; parameter_blocks is n x num_blocks row-major. */
+int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const double* consts,
+                                   const sk_loss_function* loss, double* const* parameter_blocks);
+int sk_problem_num_residual_blocks(const sk_problem* p);   /* Problem::NumResidualBlocks */
+int sk_problem_num_parameter_blocks(const sk_problem* p);  /* Problem::NumParameterBlocks */
+int sk_problem_num_parameters(const sk_problem* p);        /* Problem::NumParameters */
+int sk_problem_num_residuals(const sk_problem* p);         /* Problem::NumResiduals */
+
+/* ---- Solver.Options (setters are ceres.i:89-92 lowerCamelCase renames) ---- */
+sk_options* sk_options_new(void);                    /* Ceres 1.x defaults, SURVEY.md §8a row a13 */
+void sk_options_free(sk_options* o);
+int sk_options_set_linear_solver_type(sk_options* o, int type);       /* setLinearSolverType */
+int sk_options_set_minimizer_type(sk_options* o, int type);           /* setMinimizerType; TRUST_REGION only */
+int sk_options_set_max_num_iterations(sk_options* o, int n);          /* setMaxNumIterations */
+int sk_options_set_minimizer_progress_to_stdout(sk_options* o, int on); /* setMinimizerProgressToStdout */
+int sk_options_set_function_tolerance(sk_options* o, double v);
+int sk_options_set_gradient_tolerance(sk_options* o, double v);
+int sk_options_set_parameter_tolerance(sk_options* o, double v);
+int sk_options_set_initial_trust_region_radius(sk_options* o, double v);
+int sk_options_set_max_trust_region_radius(sk_options* o, double v);
+int sk_options_set_min_trust_region_radius(sk_options* o, double v);
+int sk_options_set_min_relative_decrease(sk_options* o, double v);
+int sk_options_set_min_lm_diagonal(sk_options* o, double v);
+int sk_options_set_max_lm_diagonal(sk_options* o, double v);
+int sk_options_set_jacobi_scaling(sk_options* o, int on);
+int sk_options_set_max_num_consecutive_invalid_steps(sk_options* o, int n);
+/* MI355X-side knobs (no reference counterpart) */
+int sk_options_set_device(sk_options* o, int hip_device);             /* default: current device */
+int sk_options_set_stream(sk_options* o, void* hip_stream);           /* default: a private stream */
+/* Multi-GPU: this process is rank `rank` of `world` ranks,
+ * one per GPU.  Points (e-blocks) are partitioned over ranks; the
+ * normal-equation terms are summed with `allreduce` once per linear solve.
+ * The hook must sum `count` doubles in device memory in place across all
+ * ranks, ordered after prior work on `hip_stream`, and return 0. */
+typedef int (*sk_allreduce_fn)(void* user, double* device_buffer, size_t count, void* hip_stream);
+int sk_options_set_distributed(sk_options* o, int rank, int world, sk_allreduce_fn allreduce,
+                               void* user);
+/* The caller may hand the solver the buffer the big all-reduce runs on (so a
+ * torch.distributed / RCCL communicator can register it).  bytes must be >=
+ * sk_reduce_buffer_bytes(problem, options). */
+int sk_options_set_reduce_buffer(sk_options* o, void* device_ptr, size_t bytes);
+size_t sk_reduce_buffer_bytes(const sk_options* o, const sk_problem* p);
+
+/* ---- Solver.Summary ------------------------------------------------------- */
+sk_summary* sk_summary_new(void);
+void sk_summary_free(sk_summary* s);
+double sk_summary_initial_cost(const sk_summary* s);
+double sk_summary_final_cost(const sk_summary* s);
+int sk_summary_num_iterations(const sk_summary* s);          /* iterations incl. iteration 0, as Ceres counts */
+int sk_summary_num_successful_steps(const sk_summary* s);
+int sk_summary_num_unsuccessful_steps(const sk_summary* s);
+int sk_summary_termination_type(const sk_summary* s);
+const char* sk_summary_message(const sk_summary* s);
+const char* sk_summary_brief_report(const sk_summary* s);    /* Summary.briefReport(); EX/CurveFitting.scala:131 */
+const char* sk_summary_full_report(const sk_summary* s);     /* Summary.fullReport(); EX/SimpleBundleAdjuster.scala:154 */
+/* Per-iteration log (what minimizer_progress_to_stdout prints). field:
+ * 0 cost, 1 cost_change, 2 gradient_max_norm, 3 step_norm, 4 relative_decrease,
+ * 5 trust_region_radius, 6 step_is_valid, 7 step_is_successful */
+int sk_summary_num_logged_iterations(const sk_summary* s);
+double sk_summary_iteration_field(const sk_summary* s, int iteration, int field);
+/* Device time per phase, seconds, summed over the solve (HIP events on the
+ * solver's stream). phase: 0 jacobian_eval, 1 schur_assemble (or J^T J),
+ * 2 cholesky (or QR), 3 back_substitute, 4 cost_eval, 5 allreduce, 6 total */
+double sk_summary_phase_seconds(const sk_summary* s, int phase);
+
+/* ---- solve ----------------------------------------------------------------- */
+/* ceres.solve(options, problem, summary) — EX/SimpleBundleAdjuster.scala:152,
+ * EX/CurveFitting.scala:127.  Blocking; parameters updated in place. */
+int sk_solve(const sk_options* options, sk_problem* problem, sk_summary* summary);
+
+/* Stepping form of the same loop, for benchmarks and JVM IterationCallback-style
+ * drivers: create (uploads + iteration 0), step (ONE trust-region iteration),
+ * finish (writes parameters back + fills the summary). */
+sk_solver* sk_solver_create(const sk_options* options, sk_problem* problem);
+void sk_solver_free(sk_solver* s);
+/* Returns SK_OK and sets *done (boolean) when a termination test fired. */
+int sk_solver_step(sk_solver* s, int* done);
+int sk_solver_finish(sk_solver* s, sk_summary* summary);
+/* Device seconds of kernel `name` accumulated since create, and its launch
+ * count (HIP events around every launch when profiling is on). */
+int sk_solver_set_kernel_timing(sk_solver* s, int on);
+double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launches);
+/* Algorithmic flop count of the dense Cholesky's trailing updates per linear
+ * solve (what roofline.achieved is computed from). */
+double sk_solver_syrk_flops_per_solve(const sk_solver* s);
+
+/* ---- dense SPD solve (utility; the factorisation sk_solve uses) --------------
+ * Solves A x = b on the GPU for a symmetric positive definite A (n x n,
+ * row-major HOST memory, only the lower triangle is read) with the blocked
+ * fp64-MFMA Cholesky.  Optional outputs: L (n x n row-major, lower, upper part
+ * zero).  `group` is the SYRK depth in 128-column blocks (0 = default).
+ * Returns SK_ERR_EVALUATION_FAILED when A is not positive definite. */
+int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double* L, int group);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKERES_AMD_H */

@@ -1,0 +1,26 @@
+"""skeres_amd — MI355X-native Levenberg-Marquardt behind the skeres API.
+
+Python host-side mirror of the reference's public names (package
+``org.somelightprojections.skeres`` + SWIG module ``com.google.ceres``) over the
+C ABI of ``libskeres_amd.so`` (include/skeres_amd.h):
+
+    AutoDiffCostFunctor / toAutoDiffCostFunction   CORE/CostFunctor.scala:40-51
+    SizedCostFunction / CostFunction.evaluate      CORE/SizedCostFunction.scala:6-14
+    Problem.addResidualBlock                       CORE/Problem.scala:20-27
+    DoubleArray, RichDoubleArray, RichDoubleMatrix CORE/RichDoubleArray.scala, RichDoubleMatrix.scala
+    PredefinedLossFunctions.trivialLoss            ceres.i:170
+    Solver.Options / Solver.Summary / ceres.solve  EX/SimpleBundleAdjuster.scala:147-154
+
+There is no CPU fallback: every compute call needs the HIP library and a gfx950
+device and raises otherwise.
+"""
+from .api import (  # noqa: F401
+    SkeresError, lib, device_count,
+    DoubleArray, RichDoubleArray, RichDoubleMatrix, StdVectorDoublePointer,
+    CostFunction, SizedCostFunction, AutoDiffCostFunctor, AutoDiffCostFunction,
+    SnavelyReprojectionError, ExponentialResidual, PowellF1, PowellF2, PowellF3, PowellF4,
+    BinaryScalarCost, BinaryVector3Cost, TenParameterCost,
+    PredefinedLossFunctions, Problem, Solver, LinearSolverType, MinimizerType, TerminationType,
+    ceres, StepSolver,
+)
+from . import bal  # noqa: F401

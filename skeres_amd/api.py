@@ -1,0 +1,677 @@
+"""ctypes binding of libskeres_amd.so that mirrors the reference's Scala API.
+
+Names, argument meaning and error behaviour follow the reference so the parity
+tests read like its own specs (core/src/test/scala/.../AutodiffCostFuntionSpec.scala).
+``require`` failures of the Scala side surface as ``ValueError`` here
+(IllegalArgumentException there); native failures as ``SkeresError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libskeres_amd.so")
+
+
+class SkeresError(RuntimeError):
+    pass
+
+
+_dp = C.POINTER(C.c_double)
+_dpp = C.POINTER(_dp)
+_ip = C.POINTER(C.c_int)
+EVALUATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dpp, _dp, _dpp)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+_lib = None
+
+_SIGS = {
+    "sk_version": (C.c_char_p, []),
+    "sk_last_error": (C.c_char_p, []),
+    "sk_init_logging": (None, [C.c_char_p]),
+    "sk_device_count": (C.c_int, []),
+    "sk_array_new": (_dp, [C.c_int]),
+    "sk_array_free": (None, [_dp]),
+    "sk_array_getitem": (C.c_double, [_dp, C.c_int]),
+    "sk_array_setitem": (None, [_dp, C.c_int, C.c_double]),
+    "sk_array_slice": (_dp, [_dp, C.c_int]),
+    "sk_array_copy_in": (None, [_dp, _dp, C.c_int]),
+    "sk_array_copy_out": (None, [_dp, _dp, C.c_int]),
+    "sk_matrix_is_null": (C.c_int, [_dpp]),
+    "sk_matrix_row": (_dp, [_dpp, C.c_int]),
+    "sk_ptrvec_new": (C.c_void_p, []),
+    "sk_ptrvec_free": (None, [C.c_void_p]),
+    "sk_ptrvec_add": (None, [C.c_void_p, _dp]),
+    "sk_ptrvec_size": (C.c_int, [C.c_void_p]),
+    "sk_ptrvec_get": (_dp, [C.c_void_p, C.c_int]),
+    "sk_ptrvec_set": (None, [C.c_void_p, C.c_int, _dp]),
+    "sk_ptrvec_to_pointer_pointer": (_dpp, [C.c_void_p]),
+    "sk_loss_trivial": (C.c_void_p, []),
+    "sk_loss_free": (None, [C.c_void_p]),
+    "sk_cost_function_new_autodiff": (C.c_void_p, [C.c_int, _dp, C.c_int]),
+    "sk_cost_function_new_callback": (C.c_void_p, [EVALUATE_FN, C.c_void_p, C.c_int, _ip, C.c_int]),
+    "sk_cost_function_free": (None, [C.c_void_p]),
+    "sk_cost_function_num_residuals": (C.c_int, [C.c_void_p]),
+    "sk_cost_function_num_parameter_blocks": (C.c_int, [C.c_void_p]),
+    "sk_cost_function_parameter_block_size": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_cost_function_evaluate": (C.c_int, [C.c_void_p, _dpp, _dp, _dpp]),
+    "sk_problem_new": (C.c_void_p, []),
+    "sk_problem_free": (None, [C.c_void_p]),
+    "sk_problem_add_residual_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _dpp, C.c_int, _ip]),
+    "sk_problem_add_residual_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_void_p, _dpp]),
+    "sk_problem_num_residual_blocks": (C.c_int, [C.c_void_p]),
+    "sk_problem_num_parameter_blocks": (C.c_int, [C.c_void_p]),
+    "sk_problem_num_parameters": (C.c_int, [C.c_void_p]),
+    "sk_problem_num_residuals": (C.c_int, [C.c_void_p]),
+    "sk_options_new": (C.c_void_p, []),
+    "sk_options_free": (None, [C.c_void_p]),
+    "sk_options_set_linear_solver_type": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_minimizer_type": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_max_num_iterations": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_minimizer_progress_to_stdout": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_function_tolerance": (C.c_int, [C.c_void_p, C.c_double]),
+    "sk_options_set_gradient_tolerance": (C.c_int, [C.c_void_p, C.c_double]),
+    "sk_options_set_parameter_tolerance": (C.c_int, [C.c_void_p, C.c_double]),
+    "sk_options_set_initial_trust_region_radius": (C.c_int, [C.c_void_p, C.c_double]),
+    "sk_options_set_max_trust_region_radius": (C.c_int, [C.c_void_p, C.c_double]),
+    "sk_options_set_min_trust_region_radius": (C.c_int, [C.c_void_p, C.c_double]),
+    "sk_options_set_min_relative_decrease": (C.c_int, [C.c_void_p, C.c_double]),
+    "sk_options_set_min_lm_diagonal": (C.c_int, [C.c_void_p, C.c_double]),
+    "sk_options_set_max_lm_diagonal": (C.c_int, [C.c_void_p, C.c_double]),
+    "sk_options_set_jacobi_scaling": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_max_num_consecutive_invalid_steps": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sk_options_set_distributed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]),
+    "sk_options_set_reduce_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "sk_reduce_buffer_bytes": (C.c_size_t, [C.c_void_p, C.c_void_p]),
+    "sk_summary_new": (C.c_void_p, []),
+    "sk_summary_free": (None, [C.c_void_p]),
+    "sk_summary_initial_cost": (C.c_double, [C.c_void_p]),
+    "sk_summary_final_cost": (C.c_double, [C.c_void_p]),
+    "sk_summary_num_iterations": (C.c_int, [C.c_void_p]),
+    "sk_summary_num_successful_steps": (C.c_int, [C.c_void_p]),
+    "sk_summary_num_unsuccessful_steps": (C.c_int, [C.c_void_p]),
+    "sk_summary_termination_type": (C.c_int, [C.c_void_p]),
+    "sk_summary_message": (C.c_char_p, [C.c_void_p]),
+    "sk_summary_brief_report": (C.c_char_p, [C.c_void_p]),
+    "sk_summary_full_report": (C.c_char_p, [C.c_void_p]),
+    "sk_summary_num_logged_iterations": (C.c_int, [C.c_void_p]),
+    "sk_summary_iteration_field": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    "sk_summary_phase_seconds": (C.c_double, [C.c_void_p, C.c_int]),
+    "sk_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sk_solver_create": (C.c_void_p, [C.c_void_p, C.c_void_p]),
+    "sk_solver_free": (None, [C.c_void_p]),
+    "sk_solver_step": (C.c_int, [C.c_void_p, _ip]),
+    "sk_solver_finish": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sk_solver_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_solver_kernel_seconds": (C.c_double, [C.c_void_p, C.c_char_p, _ip]),
+    "sk_solver_syrk_flops_per_solve": (C.c_double, [C.c_void_p]),
+    "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
+}
+
+
+def exported_symbols():
+    """Every entry point include/skeres_amd.h declares."""
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load libskeres_amd.so (raises loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise SkeresError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C skeres_amd/csrc). There is no CPU fallback." % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SkeresError("status %d: %s" % (rc, lib().sk_last_error().decode()))
+
+
+def device_count():
+    return lib().sk_device_count()
+
+
+# ---------------------------------------------------------------------------
+# native memory helpers
+# ---------------------------------------------------------------------------
+class DoubleArray:
+    """com.google.ceres.DoubleArray (ceres.i:95-96): a native double[n] the caller owns."""
+
+    def __init__(self, n=None, _ptr=None, _owner=None):
+        if _ptr is not None:
+            self._p, self._own, self._keep = _ptr, False, _owner
+        else:
+            self._p, self._own, self._keep = lib().sk_array_new(int(n)), True, None
+            if not self._p:
+                raise MemoryError("sk_array_new(%r)" % n)
+        self.n = n
+
+    def __del__(self):
+        if getattr(self, "_own", False) and self._p and _lib is not None:
+            _lib.sk_array_free(self._p)
+            self._p = None
+
+    def getitem(self, i):
+        return lib().sk_array_getitem(self._p, i)
+
+    def setitem(self, i, x):
+        lib().sk_array_setitem(self._p, i, float(x))
+
+    get, set = getitem, setitem  # RichDoubleArray.get / set (CORE/RichDoubleArray.scala:20,27)
+
+    def cast(self):
+        return self._p
+
+    toPointer = cast
+
+    @staticmethod
+    def frompointer(p, owner=None):
+        return DoubleArray(_ptr=p, _owner=owner)
+
+    def slice(self, start):  # RichDoubleArray.slice (CORE/RichDoubleArray.scala:52)
+        return DoubleArray(_ptr=lib().sk_array_slice(self._p, int(start)), _owner=self)
+
+    def copyFrom(self, values):  # CORE/RichDoubleArray.scala:36-39 (bulk)
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        lib().sk_array_copy_in(self._p, a.ctypes.data_as(_dp), a.size)
+        return self
+
+    def toArray(self, length):  # CORE/RichDoubleArray.scala:65-69 (bulk)
+        out = np.empty(int(length), dtype=np.float64)
+        lib().sk_array_copy_out(self._p, out.ctypes.data_as(_dp), out.size)
+        return out
+
+    def isNull(self):
+        return not bool(self._p)
+
+
+class RichDoubleArray:
+    """CORE/RichDoubleArray.scala:73-74 factories."""
+
+    @staticmethod
+    def ofSize(n):
+        return DoubleArray(n)
+
+    @staticmethod
+    def fromArray(a):
+        return DoubleArray(len(a)).copyFrom(a)
+
+
+class StdVectorDoublePointer:
+    """com.google.ceres.StdVectorDoublePointer (ceres.i:82)."""
+
+    def __init__(self):
+        self._v = lib().sk_ptrvec_new()
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "_v", None) and _lib is not None:
+            _lib.sk_ptrvec_free(self._v)
+            self._v = None
+
+    def add(self, arr):
+        self._keep.append(arr)
+        lib().sk_ptrvec_add(self._v, arr.cast() if arr is not None else _dp())
+
+    def size(self):
+        return lib().sk_ptrvec_size(self._v)
+
+    def toPointerPointer(self):
+        return lib().sk_ptrvec_to_pointer_pointer(self._v)
+
+
+class RichDoubleMatrix:
+    """View over a native double** (CORE/RichDoubleMatrix.scala:32-99)."""
+
+    def __init__(self, rows):
+        self.rows = rows  # list of DoubleArray or None
+
+    @staticmethod
+    def ofSize(num_rows, num_cols):
+        return RichDoubleMatrix([DoubleArray(num_cols) for _ in range(num_rows)])
+
+    @staticmethod
+    def fromArrays(*arrays):
+        return RichDoubleMatrix([RichDoubleArray.fromArray(a) for a in arrays])
+
+    def isNull(self):
+        return False
+
+    def hasRow(self, i):
+        return self.rows[i] is not None
+
+    def getRow(self, i):
+        return self.rows[i]
+
+    def get(self, i, j):
+        return self.rows[i].get(j)
+
+    def set(self, i, j, x):
+        self.rows[i].set(j, x)
+
+    def _as_pp(self):
+        return (_dp * len(self.rows))(*[(r.cast() if r is not None else _dp()) for r in self.rows])
+
+
+# ---------------------------------------------------------------------------
+# cost functions
+# ---------------------------------------------------------------------------
+class CostFunction:
+    """com.google.ceres.CostFunction director (ceres.i:48).  Subclass and override
+    ``evaluate(parameters, residuals, jacobians) -> bool`` for a host-side cost
+    function; ``parameters``/``jacobians`` are lists of numpy views (``jacobians``
+    is None, or holds None for rows the solver does not want)."""
+
+    def __init__(self):
+        self._h = None
+        self._num_residuals = 0
+        self._block_sizes = []
+
+    def setNumResiduals(self, n):
+        self._num_residuals = int(n)
+
+    def numResiduals(self):
+        return self._num_residuals
+
+    def parameterBlockSizes(self):
+        return list(self._block_sizes)
+
+    def evaluate(self, parameters, residuals, jacobians):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def _handle(self):
+        if self._h is None:
+            nres, sizes = self._num_residuals, self._block_sizes
+
+            def tramp(_user, params, res, jacs):
+                try:
+                    p = [np.ctypeslib.as_array(params[i], shape=(sizes[i],)) for i in range(len(sizes))]
+                    r = np.ctypeslib.as_array(res, shape=(nres,))
+                    j = None
+                    if jacs:
+                        j = [np.ctypeslib.as_array(jacs[i], shape=(nres, sizes[i])) if jacs[i] else None
+                             for i in range(len(sizes))]
+                    return 1 if self.evaluate(p, r, j) else 0
+                except Exception:  # an exception must not unwind through native frames
+                    import traceback
+                    traceback.print_exc()
+                    return 0
+
+            self._tramp = EVALUATE_FN(tramp)
+            bs = (C.c_int * len(sizes))(*sizes)
+            self._h = lib().sk_cost_function_new_callback(self._tramp, None, nres, bs, len(sizes))
+            if not self._h:
+                raise ValueError(lib().sk_last_error().decode())
+        return self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.sk_cost_function_free(self._h)
+            self._h = None
+
+
+class SizedCostFunction(CostFunction):
+    """CORE/SizedCostFunction.scala:6-14."""
+
+    def __init__(self, kNumResiduals, *N):
+        super().__init__()
+        if any(n < 0 for n in N):
+            raise ValueError("Negative block size detected. Block size are: %s" % ", ".join(map(str, N)))
+        if any(not (N[i] == 0 or N[i - 1] > 0) for i in range(1, len(N))):
+            raise ValueError("Zero block cannot precede a non-zero block. Block sizes are (ignore trailing 0's): "
+                             + ", ".join(map(str, N)))
+        self.kNumResiduals = kNumResiduals
+        self.N = tuple(N)
+        self.setNumResiduals(kNumResiduals)
+        self._block_sizes = [n for n in N]
+
+
+class AutoDiffCostFunctor:
+    """CORE/CostFunctor.scala:31-51.  A functor whose generic body lives in the
+    device functor registry (``FUNCTOR_ID``); ``consts`` are the doubles the
+    Scala closure captures."""
+    FUNCTOR_ID = None
+
+    def __init__(self, kNumResiduals, *N, consts=()):
+        if kNumResiduals <= 0:
+            raise ValueError("Nonpositive number of residuals specified: %d" % kNumResiduals)
+        if any(n <= 0 for n in N):
+            raise ValueError("Nonpositive parameter block sizes specified: %s" % ", ".join(map(str, N)))
+        self.kNumResiduals = kNumResiduals
+        self.N = tuple(N)
+        self.consts = tuple(float(c) for c in consts)
+
+    def toAutoDiffCostFunction(self):
+        return AutoDiffCostFunction(self)
+
+
+class AutoDiffCostFunction(SizedCostFunction):
+    """CORE/AutodiffCostFunction.scala:69-135 over a device functor."""
+
+    def __init__(self, costFunctor):
+        super().__init__(costFunctor.kNumResiduals, *costFunctor.N)
+        self.costFunctor = costFunctor
+        if costFunctor.FUNCTOR_ID is None:
+            raise ValueError("functor %s has no device body registered" % type(costFunctor).__name__)
+
+    def _handle(self):
+        if self._h is None:
+            c = np.asarray(self.costFunctor.consts, dtype=np.float64)
+            self._h = lib().sk_cost_function_new_autodiff(self.costFunctor.FUNCTOR_ID,
+                                                         c.ctypes.data_as(_dp) if c.size else _dp(), c.size)
+            if not self._h:
+                raise ValueError(lib().sk_last_error().decode())
+            if lib().sk_cost_function_num_residuals(self._h) != self.kNumResiduals or \
+                    [lib().sk_cost_function_parameter_block_size(self._h, i)
+                     for i in range(lib().sk_cost_function_num_parameter_blocks(self._h))] != list(self.N):
+                raise ValueError("functor sizes do not match its device body")
+        return self._h
+
+    def evaluate(self, parameters, residuals, jacobians):
+        """evaluate(DoublePointerPointer, DoublePointer, DoublePointerPointer): Boolean
+        — runs the device functor on the GPU for this one residual block."""
+        pp = parameters._as_pp()
+        jp = jacobians._as_pp() if jacobians is not None else None
+        rc = lib().sk_cost_function_evaluate(self._handle(), pp, residuals.cast(), jp)
+        if rc < 0:
+            raise SkeresError(lib().sk_last_error().decode())
+        return bool(rc)
+
+
+class SnavelyReprojectionError(AutoDiffCostFunctor):  # EX/SimpleBundleAdjuster.scala:79-119
+    FUNCTOR_ID = 1
+
+    def __init__(self, observedX, observedY):
+        super().__init__(2, 9, 3, consts=(observedX, observedY))
+
+
+class ExponentialResidual(AutoDiffCostFunctor):  # EX/CurveFitting.scala:92-98
+    FUNCTOR_ID = 2
+
+    def __init__(self, x, y):
+        super().__init__(1, 1, 1, consts=(x, y))
+
+
+class PowellF1(AutoDiffCostFunctor):  # EX/Powell.scala:14-21
+    FUNCTOR_ID = 3
+
+    def __init__(self):
+        super().__init__(1, 1, 1)
+
+
+class PowellF2(AutoDiffCostFunctor):
+    FUNCTOR_ID = 4
+
+    def __init__(self):
+        super().__init__(1, 1, 1)
+
+
+class PowellF3(AutoDiffCostFunctor):
+    FUNCTOR_ID = 5
+
+    def __init__(self):
+        super().__init__(1, 1, 1)
+
+
+class PowellF4(AutoDiffCostFunctor):
+    FUNCTOR_ID = 6
+
+    def __init__(self):
+        super().__init__(1, 1, 1)
+
+
+class BinaryScalarCost(AutoDiffCostFunctor):  # TEST/AutodiffCostFuntionSpec.scala:14-26
+    FUNCTOR_ID = 7
+
+    def __init__(self, a):
+        super().__init__(1, 2, 2, consts=(a,))
+
+
+class BinaryVector3Cost(AutoDiffCostFunctor):  # TEST/AutodiffCostFuntionSpec.scala:55-69
+    FUNCTOR_ID = 8
+
+    def __init__(self, a):
+        super().__init__(3, 2, 2, consts=(a,))
+
+
+class TenParameterCost(AutoDiffCostFunctor):  # TEST/AutodiffCostFuntionSpec.scala:111-119
+    FUNCTOR_ID = 9
+
+    def __init__(self):
+        super().__init__(1, *([1] * 10))
+
+
+class _Loss:
+    def __init__(self, h):
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.sk_loss_free(self._h)
+            self._h = None
+
+
+class PredefinedLossFunctions:  # ceres.i:168-184
+    @staticmethod
+    def trivialLoss():
+        return _Loss(lib().sk_loss_trivial())
+
+
+# ---------------------------------------------------------------------------
+# Problem / Solver
+# ---------------------------------------------------------------------------
+class LinearSolverType:
+    DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = range(7)
+
+
+class MinimizerType:
+    LINE_SEARCH, TRUST_REGION = 0, 1
+
+
+class TerminationType:
+    CONVERGENCE, NO_CONVERGENCE, FAILURE, USER_SUCCESS, USER_FAILURE = range(5)
+
+
+class Problem:
+    """CORE/Problem.scala:16-33 — never owns cost / loss objects; keeps Python
+    references so the GC cannot collect objects native code still points at."""
+
+    def __init__(self):
+        self._h = lib().sk_problem_new()
+        self._costs, self._losses, self._arrays = [], [], []
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.sk_problem_free(self._h)
+            self._h = None
+
+    def addResidualBlock(self, cost, loss, *x):
+        self._costs.append(cost)
+        self._losses.append(loss)
+        self._arrays.extend(x)
+        pp = (_dp * len(x))(*[xi.cast() for xi in x])
+        rid = C.c_int()
+        rc = lib().sk_problem_add_residual_block(self._h, cost._handle(), loss._h if loss is not None else None,
+                                                 pp, len(x), C.byref(rid))
+        if rc == 1:
+            raise ValueError(lib().sk_last_error().decode())
+        _check(rc)
+        return rid.value
+
+    def addResidualBlocks(self, functor_id, consts, loss, base, offsets):
+        """Bulk form of the loop at EX/SimpleBundleAdjuster.scala:139-145.
+        ``base`` is a DoubleArray, ``offsets`` an int array [n, num_blocks] of
+        element offsets of each parameter block inside ``base``."""
+        self._arrays.append(base)
+        self._losses.append(loss)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = offsets.shape[0]
+        addr = C.cast(base.cast(), C.c_void_p).value
+        ptrs = np.ascontiguousarray(addr + 8 * offsets.ravel(), dtype=np.uint64)
+        consts = np.ascontiguousarray(consts, dtype=np.float64)
+        rc = lib().sk_problem_add_residual_blocks(self._h, int(functor_id), int(n), consts.ctypes.data_as(_dp),
+                                                  loss._h if loss is not None else None,
+                                                  C.cast(ptrs.ctypes.data, _dpp))
+        if rc == 1:
+            raise ValueError(lib().sk_last_error().decode())
+        _check(rc)
+
+    def numResidualBlocks(self):
+        return lib().sk_problem_num_residual_blocks(self._h)
+
+    def numParameterBlocks(self):
+        return lib().sk_problem_num_parameter_blocks(self._h)
+
+    def numParameters(self):
+        return lib().sk_problem_num_parameters(self._h)
+
+    def numResiduals(self):
+        return lib().sk_problem_num_residuals(self._h)
+
+
+class Solver:
+    class Options:
+        def __init__(self):
+            self._h = lib().sk_options_new()
+            self._keep = []
+
+        def __del__(self):
+            if getattr(self, "_h", None) and _lib is not None:
+                _lib.sk_options_free(self._h)
+                self._h = None
+
+        def _set(self, name, v):
+            rc = getattr(lib(), "sk_options_set_" + name)(self._h, v)
+            if rc == 1:
+                raise ValueError(lib().sk_last_error().decode())
+            _check(rc)
+
+        def setLinearSolverType(self, t): self._set("linear_solver_type", int(t))
+        def setMinimizerType(self, t): self._set("minimizer_type", int(t))
+        def setMaxNumIterations(self, n): self._set("max_num_iterations", int(n))
+        def setMinimizerProgressToStdout(self, on): self._set("minimizer_progress_to_stdout", int(bool(on)))
+        def setFunctionTolerance(self, v): self._set("function_tolerance", float(v))
+        def setGradientTolerance(self, v): self._set("gradient_tolerance", float(v))
+        def setParameterTolerance(self, v): self._set("parameter_tolerance", float(v))
+        def setInitialTrustRegionRadius(self, v): self._set("initial_trust_region_radius", float(v))
+        def setMaxTrustRegionRadius(self, v): self._set("max_trust_region_radius", float(v))
+        def setMinTrustRegionRadius(self, v): self._set("min_trust_region_radius", float(v))
+        def setMinRelativeDecrease(self, v): self._set("min_relative_decrease", float(v))
+        def setMinLmDiagonal(self, v): self._set("min_lm_diagonal", float(v))
+        def setMaxLmDiagonal(self, v): self._set("max_lm_diagonal", float(v))
+        def setJacobiScaling(self, on): self._set("jacobi_scaling", int(bool(on)))
+        def setMaxNumConsecutiveInvalidSteps(self, n): self._set("max_num_consecutive_invalid_steps", int(n))
+        def setDevice(self, d): self._set("device", int(d))
+        def setStream(self, s): self._set("stream", C.c_void_p(int(s)))
+
+        def setDistributed(self, rank, world, allreduce):
+            """allreduce(device_ptr:int, count:int, stream:int) -> None: in-place sum over ranks."""
+            def tramp(_u, ptr, count, stream):
+                try:
+                    allreduce(int(ptr), int(count), int(stream or 0))
+                    return 0
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = ALLREDUCE_FN(tramp)
+            self._keep.append(cb)
+            _check(lib().sk_options_set_distributed(self._h, int(rank), int(world), cb, None))
+
+        def setReduceBuffer(self, ptr, nbytes):
+            _check(lib().sk_options_set_reduce_buffer(self._h, C.c_void_p(int(ptr)), int(nbytes)))
+
+    class Summary:
+        def __init__(self):
+            self._h = lib().sk_summary_new()
+
+        def __del__(self):
+            if getattr(self, "_h", None) and _lib is not None:
+                _lib.sk_summary_free(self._h)
+                self._h = None
+
+        def initialCost(self): return lib().sk_summary_initial_cost(self._h)
+        def finalCost(self): return lib().sk_summary_final_cost(self._h)
+        def numIterations(self): return lib().sk_summary_num_iterations(self._h)
+        def numSuccessfulSteps(self): return lib().sk_summary_num_successful_steps(self._h)
+        def numUnsuccessfulSteps(self): return lib().sk_summary_num_unsuccessful_steps(self._h)
+        def terminationType(self): return lib().sk_summary_termination_type(self._h)
+        def message(self): return lib().sk_summary_message(self._h).decode()
+        def briefReport(self): return lib().sk_summary_brief_report(self._h).decode()
+        def fullReport(self): return lib().sk_summary_full_report(self._h).decode()
+        def phaseSeconds(self, k): return lib().sk_summary_phase_seconds(self._h, k)
+
+        def iterations(self):
+            names = ["cost", "cost_change", "gradient_max_norm", "step_norm", "relative_decrease",
+                     "trust_region_radius", "step_is_valid", "step_is_successful"]
+            return [{nm: lib().sk_summary_iteration_field(self._h, i, k) for k, nm in enumerate(names)}
+                    for i in range(lib().sk_summary_num_logged_iterations(self._h))]
+
+
+class ceres:
+    """Module-level functions of the SWIG module (ceres.i)."""
+
+    @staticmethod
+    def initGoogleLogging(name):
+        lib().sk_init_logging(name.encode())
+
+    @staticmethod
+    def solve(options, problem, summary):
+        _check(lib().sk_solve(options._h, problem._h, summary._h))
+
+
+class StepSolver:
+    """Stepping form of ceres.solve (sk_solver_create / step / finish)."""
+
+    def __init__(self, options, problem):
+        self._keep = (options, problem)
+        self._h = lib().sk_solver_create(options._h, problem._h)
+        if not self._h:
+            raise SkeresError(lib().sk_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.sk_solver_free(self._h)
+            self._h = None
+
+    def step(self):
+        done = C.c_int()
+        _check(lib().sk_solver_step(self._h, C.byref(done)))
+        return bool(done.value)
+
+    def finish(self, summary):
+        _check(lib().sk_solver_finish(self._h, summary._h))
+
+    def setKernelTiming(self, on):
+        lib().sk_solver_set_kernel_timing(self._h, int(bool(on)))
+
+    def kernelSeconds(self, name):
+        n = C.c_int()
+        s = lib().sk_solver_kernel_seconds(self._h, name.encode(), C.byref(n))
+        return s, n.value
+
+    def syrkFlopsPerSolve(self):
+        return lib().sk_solver_syrk_flops_per_solve(self._h)
+
+
+def cholesky_solve(A, b, want_L=False, group=0):
+    """Dense SPD solve on the GPU (sk_cholesky_solve)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    n = A.shape[0]
+    x = np.empty(n)
+    L = np.empty((n, n)) if want_L else None
+    _check(lib().sk_cholesky_solve(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp),
+                                   L.ctypes.data_as(_dp) if want_L else _dp(), int(group)))
+    return (x, L) if want_L else x

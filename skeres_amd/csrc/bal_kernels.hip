@@ -1,0 +1,482 @@
+// HIP kernels (gfx950) for the bundle-adjustment-shaped hot path:
+//   A. per-residual-block Jet autodiff  (replaces the director upcall into
+//      CORE/AutodiffCostFunction.scala:74-134 + EX/SimpleBundleAdjuster.scala:79-119)
+//   B. Schur-complement assembly        (replaces [ext] ceres SchurEliminator<2,3,9>)
+//   D. back-substitution + candidate cost (replaces [ext] ceres BackSubstitute / Evaluate)
+//
+// Data layout in HBM (all fp64, structure-of-arrays so that lane o touches
+// element o of each plane: every wave access is a contiguous 512-B run):
+//   observations are stored POINT-MAJOR (all observations of a local point are
+//   contiguous, ascending camera) — obs index `o` below is that order.
+//   r   [2][N]   residuals                      F  [18][N]  d r / d camera  (row-major 2x9 per obs)
+//   E   [6][N]   d r / d point (2x3)            What [27][N] F^T (E M^T)    (9x3 per obs)
+//   rt  [2][N]   r - E T^-1 g
+// Jacobi column scaling is folded into F / E as they are written.
+#include <hip/hip_runtime.h>
+#include "functors.hpp"
+#include "bal_kernels.hpp"
+
+namespace sk {
+
+static constexpr int kBlock = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Block-level sum of up to 4 values; result valid in thread 0.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* out_partial, int nblocks_stride) {
+  __shared__ double sh[K][kBlock / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = wave_sum(v[k]);
+    if (lane == 0) sh[k][w] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double s = 0.0;
+      for (int i = 0; i < kBlock / 64; ++i) s += sh[k][i];
+      out_partial[(size_t)k * nblocks_stride + blockIdx.x] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// A. residuals + Jacobians, T = Jet<12>, seeding order camera[0..9) then
+//    point[0..3)  (AutodiffCostFunction.scala:96-106); Jacobian blocks row-major
+//    kNumResiduals x N(i) (:115-130), stored as SoA planes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void bal_eval_jac_kernel(BalDev d) {
+  double acc[1] = {0.0};
+  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    const int ci = d.cam[o], pi = d.pt[o];
+    typedef Jet<12> J;
+    J cam[9], X[3], out[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cam[k] = J(d.xc[9 * (size_t)ci + k], k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) X[k] = J(d.xp[3 * (size_t)pi + k], 9 + k);
+    const J* params[2] = {cam, X};
+    const double c[2] = {d.obs[o], d.obs[(size_t)d.N + o]};
+    SnavelyReprojectionError::apply<J>(c, params, out);
+    const double r0 = out[0].a, r1 = out[1].a;
+    d.r[o] = r0;
+    d.r[(size_t)d.N + o] = r1;
+    acc[0] += r0 * r0 + r1 * r1;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double s = d.scale_c[9 * (size_t)ci + k];
+      d.F[(size_t)k * d.N + o] = out[0].v[k] * s;
+      d.F[(size_t)(9 + k) * d.N + o] = out[1].v[k] * s;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double s = d.scale_p[3 * (size_t)pi + k];
+      d.E[(size_t)k * d.N + o] = out[0].v[9 + k] * s;
+      d.E[(size_t)(3 + k) * d.N + o] = out[1].v[9 + k] * s;
+    }
+  }
+  block_sum<1>(acc, d.partial, d.partial_stride);
+}
+
+// Candidate cost at (xc_new, xp_new) with T = double (cost-only branch,
+// AutodiffCostFunction.scala:80-93) fused with the model residual J*step that
+// the trust-region ratio needs:  m = F s_c + E s_p ; term = m . (r + m/2).
+__global__ __launch_bounds__(kBlock) void bal_eval_cost_kernel(BalDev d) {
+  double acc[2] = {0.0, 0.0};
+  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    const int ci = d.cam[o], pi = d.pt[o];
+    double cam[9], X[3], out[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cam[k] = d.xc_new[9 * (size_t)ci + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) X[k] = d.xp_new[3 * (size_t)pi + k];
+    const double* params[2] = {cam, X};
+    const double c[2] = {d.obs[o], d.obs[(size_t)d.N + o]};
+    SnavelyReprojectionError::apply<double>(c, params, out);
+    acc[0] += out[0] * out[0] + out[1] * out[1];
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double s = d.step_c[9 * (size_t)ci + k];
+      m0 += d.F[(size_t)k * d.N + o] * s;
+      m1 += d.F[(size_t)(9 + k) * d.N + o] * s;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double s = d.step_p[3 * (size_t)pi + k];
+      m0 += d.E[(size_t)k * d.N + o] * s;
+      m1 += d.E[(size_t)(3 + k) * d.N + o] * s;
+    }
+    acc[1] += m0 * (d.r[o] + m0 / 2.0) + m1 * (d.r[(size_t)d.N + o] + m1 / 2.0);
+  }
+  block_sum<2>(acc, d.partial, d.partial_stride);
+}
+
+// In-place column scaling of F / E (only at iteration 0, when the Jacobi
+// scale is first known).
+__global__ __launch_bounds__(kBlock) void bal_scale_jac_kernel(BalDev d) {
+  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    const int ci = d.cam[o], pi = d.pt[o];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double s = d.scale_c[9 * (size_t)ci + k];
+      d.F[(size_t)k * d.N + o] *= s;
+      d.F[(size_t)(9 + k) * d.N + o] *= s;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double s = d.scale_p[3 * (size_t)pi + k];
+      d.E[(size_t)k * d.N + o] *= s;
+      d.E[(size_t)(3 + k) * d.N + o] *= s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Column reductions.  Camera columns: one wave per camera over its observation
+// list (fixed lane assignment + fixed butterfly => run-to-run reproducible).
+//   colsq_c = sum F^2 (squared column norm), gs_c = sum F^T r (scaled gradient)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void bal_cam_reduce_kernel(BalDev d) {
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= d.C) return;
+  double sq[9], g[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { sq[k] = 0.0; g[k] = 0.0; }
+  for (int e = d.cam_start[wave] + lane; e < d.cam_start[wave + 1]; e += 64) {
+    const int o = d.cam_obs[e];
+    const double r0 = d.r[o], r1 = d.r[(size_t)d.N + o];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double f0 = d.F[(size_t)k * d.N + o], f1 = d.F[(size_t)(9 + k) * d.N + o];
+      sq[k] += f0 * f0 + f1 * f1;
+      g[k] += f0 * r0 + f1 * r1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { sq[k] = wave_sum(sq[k]); g[k] = wave_sum(g[k]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { d.colsq_c[9 * (size_t)wave + k] = sq[k]; d.gs_c[9 * (size_t)wave + k] = g[k]; }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void bal_pt_reduce_kernel(BalDev d) {
+  const int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= d.P) return;
+  double sq[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+  for (int o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
+    const double r0 = d.r[o], r1 = d.r[(size_t)d.N + o];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double e0 = d.E[(size_t)k * d.N + o], e1 = d.E[(size_t)(3 + k) * d.N + o];
+      sq[k] += e0 * e0 + e1 * e1;
+      g[k] += e0 * r0 + e1 * r1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { d.colsq_p[3 * (size_t)p + k] = sq[k]; d.gs_p[3 * (size_t)p + k] = g[k]; }
+}
+
+// Generic small vector kernels -------------------------------------------------
+// scale_j = 1 / (1 + sqrt(colsq_j))   (Jacobi scaling, fixed at iteration 0)
+__global__ void jacobi_scale_kernel(const double* colsq, double* scale, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) scale[j] = 1.0 / (1.0 + sqrt(colsq[j]));
+}
+// After scaling J in place, colsq and the scaled gradient follow algebraically.
+__global__ void apply_scale_to_reductions_kernel(double* colsq, double* gs, const double* scale, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) { const double s = scale[j]; colsq[j] = colsq[j] * s * s; gs[j] = gs[j] * s; }
+}
+// D_j = sqrt(clamp(colsq_j, lo, hi) / radius)   (LevenbergMarquardtStrategy)
+__global__ void lm_diagonal_kernel(const double* colsq, double* D, int n, double lo, double hi, double radius) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) D[j] = sqrt(fmin(fmax(colsq[j], lo), hi) / radius);
+}
+// partial[0] = max |gs_j / scale_j| , partial[1] = sum x_j^2 over this block
+__global__ __launch_bounds__(kBlock) void grad_max_xnorm_kernel(const double* gs, const double* scale, const double* x,
+                                                                int n, double* partial, int stride) {
+  double m = 0.0, s = 0.0;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+    m = fmax(m, fabs(gs[j] / scale[j]));
+    s += x[j] * x[j];
+  }
+  __shared__ double shm[kBlock / 64], shs[kBlock / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off, 64)); s += __shfl_xor(s, off, 64); }
+  if ((threadIdx.x & 63) == 0) { shm[threadIdx.x >> 6] = m; shs[threadIdx.x >> 6] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < kBlock / 64; ++i) { m = fmax(m, shm[i]); s += shs[i]; }
+    partial[blockIdx.x] = m;
+    partial[stride + blockIdx.x] = s;
+  }
+}
+
+// out[k] = reduce(partial[k*stride .. +count)) in fixed order; bit k of maxmask: 0 sum, 1 max
+__global__ void final_reduce_kernel(const double* partial, int stride, int count, int K, int maxmask, double* out) {
+  const int k = threadIdx.x;
+  if (k >= K) return;
+  double a = 0.0;
+  if (((maxmask >> k) & 1) == 0) for (int i = 0; i < count; ++i) a += partial[(size_t)k * stride + i];
+  else for (int i = 0; i < count; ++i) a = fmax(a, partial[(size_t)k * stride + i]);
+  out[k] = a;
+}
+
+// ---------------------------------------------------------------------------
+// B. Schur elimination of the point blocks.
+//   T_p = sum E^T E + D_p^2 ; M = chol(T)^-1 (lower) so T^-1 = M^T M ; q = T^-1 g
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void bal_point_block_kernel(BalDev d) {
+  const int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= d.P) return;
+  double t00 = 0, t10 = 0, t11 = 0, t20 = 0, t21 = 0, t22 = 0;
+  for (int o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
+    const double a0 = d.E[o], a1 = d.E[(size_t)d.N + o], a2 = d.E[2 * (size_t)d.N + o];
+    const double b0 = d.E[3 * (size_t)d.N + o], b1 = d.E[4 * (size_t)d.N + o], b2 = d.E[5 * (size_t)d.N + o];
+    t00 += a0 * a0 + b0 * b0; t10 += a1 * a0 + b1 * b0; t11 += a1 * a1 + b1 * b1;
+    t20 += a2 * a0 + b2 * b0; t21 += a2 * a1 + b2 * b1; t22 += a2 * a2 + b2 * b2;
+  }
+  const double d0 = d.D_p[3 * (size_t)p], d1 = d.D_p[3 * (size_t)p + 1], d2 = d.D_p[3 * (size_t)p + 2];
+  t00 += d0 * d0; t11 += d1 * d1; t22 += d2 * d2;
+  // Cholesky T = L L^T
+  const double l00 = sqrt(t00);
+  const double l10 = t10 / l00, l20 = t20 / l00;
+  const double l11 = sqrt(t11 - l10 * l10);
+  const double l21 = (t21 - l20 * l10) / l11;
+  const double l22 = sqrt(t22 - l20 * l20 - l21 * l21);
+  // M = L^-1
+  const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
+  const double m10 = -(l10 * m00) / l11;
+  const double m21 = -(l21 * m11) / l22;
+  const double m20 = -(l20 * m00 + l21 * m10) / l22;
+  const size_t P = d.P;
+  d.M[p] = m00; d.M[P + p] = m10; d.M[2 * P + p] = m11; d.M[3 * P + p] = m20; d.M[4 * P + p] = m21; d.M[5 * P + p] = m22;
+  // q = M^T (M g)
+  const double g0 = d.gs_p[3 * (size_t)p], g1 = d.gs_p[3 * (size_t)p + 1], g2 = d.gs_p[3 * (size_t)p + 2];
+  const double u0 = m00 * g0, u1 = m10 * g0 + m11 * g1, u2 = m20 * g0 + m21 * g1 + m22 * g2;
+  d.q[p] = m00 * u0 + m10 * u1 + m20 * u2;
+  d.q[P + p] = m11 * u1 + m21 * u2;
+  d.q[2 * P + p] = m22 * u2;
+  if (!(l00 > 0.0) || !(l11 > 0.0) || !(l22 > 0.0)) *d.fail_flag = 1;  // not positive definite
+}
+
+// Per observation: Ehat = E M^T (2x3), What = F^T Ehat (9x3), rt = r - E q
+__global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
+  const size_t N = d.N, P = d.P;
+  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    const int p = d.pt[o];
+    const double m00 = d.M[p], m10 = d.M[P + p], m11 = d.M[2 * P + p], m20 = d.M[3 * P + p], m21 = d.M[4 * P + p], m22 = d.M[5 * P + p];
+    const double q0 = d.q[p], q1 = d.q[P + p], q2 = d.q[2 * P + p];
+    double eh[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double e0 = d.E[(3 * r) * N + o], e1 = d.E[(3 * r + 1) * N + o], e2 = d.E[(3 * r + 2) * N + o];
+      eh[r][0] = e0 * m00;
+      eh[r][1] = e0 * m10 + e1 * m11;
+      eh[r][2] = e0 * m20 + e1 * m21 + e2 * m22;
+      d.rt[r * N + o] = d.r[r * N + o] - (e0 * q0 + e1 * q1 + e2 * q2);
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const double f0 = d.F[c * N + o], f1 = d.F[(9 + c) * N + o];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) d.What[(3 * c + a) * N + o] = f0 * eh[0][a] + f1 * eh[1][a];
+    }
+  }
+}
+
+// Diagonal blocks + right-hand side, one wave per camera:
+//   S_ii = sum_o (F^T F - What What^T)      (D_c^2 is added after the all-reduce)
+//   rhs_i = sum_o F^T rt
+// rhs goes to row `rhs_row` of S (the augmented row the factorisation carries).
+__global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
+  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (i >= d.C) return;
+  const size_t N = d.N;
+  double acc[45], rh[9];
+#pragma unroll
+  for (int k = 0; k < 45; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) rh[k] = 0.0;
+  for (int e = d.cam_start[i] + lane; e < d.cam_start[i + 1]; e += 64) {
+    const int o = d.cam_obs[e];
+    double f0[9], f1[9], w[27];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { f0[c] = d.F[c * N + o]; f1[c] = d.F[(9 + c) * N + o]; }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) w[k] = d.What[k * N + o];
+    const double r0 = d.rt[o], r1 = d.rt[N + o];
+    int k = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      rh[c] += f0[c] * r0 + f1[c] * r1;
+#pragma unroll
+      for (int e2 = 0; e2 <= c; ++e2, ++k)
+        acc[k] += (f0[c] * f0[e2] + f1[c] * f1[e2]) - (w[3 * c] * w[3 * e2] + w[3 * c + 1] * w[3 * e2 + 1] + w[3 * c + 2] * w[3 * e2 + 2]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 45; ++k) acc[k] = wave_sum(acc[k]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) rh[k] = wave_sum(rh[k]);
+  if (lane == 0) {
+    int k = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      d.S[(size_t)d.rhs_row * d.ld + 9 * i + c] = rh[c];
+#pragma unroll
+      for (int e2 = 0; e2 <= c; ++e2, ++k) d.S[(size_t)(9 * i + c) * d.ld + 9 * i + e2] = acc[k];
+    }
+  }
+}
+
+// Off-diagonal blocks.  The (row camera i > col camera j) pairs that share at
+// least one point are listed once at setup, sorted by (i, j); segment s owns
+// block (i, j) and sums its entries IN LIST ORDER (ascending point):
+//   S_ij = - sum_e What[obs_row(e)] What[obs_col(e)]^T
+// Nine lanes per block, lane c owns row c of the 9x9 block; 7 blocks per wave.
+// No atomics: every block has exactly one writer, so results are reproducible.
+__global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int sub = lane / 9, c = lane - 9 * sub;
+  const int seg = wave * 7 + sub;
+  if (sub >= 7 || seg >= d.num_segments) return;
+  const size_t N = d.N;
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  const int e0 = d.seg_start[seg], e1 = d.seg_start[seg + 1];
+  for (int e = e0; e < e1; ++e) {
+    const int ob = d.pair_row_obs[e], oa = d.pair_col_obs[e];
+    const double y0 = d.What[(3 * c) * N + ob], y1 = d.What[(3 * c + 1) * N + ob], y2 = d.What[(3 * c + 2) * N + ob];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      acc[k] += y0 * d.What[(3 * k) * N + oa] + y1 * d.What[(3 * k + 1) * N + oa] + y2 * d.What[(3 * k + 2) * N + oa];
+  }
+  const int i = d.seg_row[seg], j = d.seg_col[seg];
+  double* out = d.S + (size_t)(9 * i + c) * d.ld + 9 * j;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) out[k] = -acc[k];
+}
+
+// After the (optional) all-reduce: add D_c^2 on the diagonal, make the padded
+// tail of S an identity and give the augmented rhs row a huge diagonal so the
+// factorisation stays positive definite (its own diagonal entry is unused).
+__global__ void bal_finish_S_kernel(double* S, int ld, int n, int npad, int rhs_row, const double* D_c) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npad) return;
+  if (j < n) S[(size_t)j * ld + j] += D_c[j] * D_c[j];
+  else if (j == rhs_row) S[(size_t)j * ld + j] = 1e300;
+  else S[(size_t)j * ld + j] = 1.0;
+}
+
+// ---------------------------------------------------------------------------
+// D. back-substitution.  y_c is the reduced-system solution (length 9C).
+//   y_p = T^-1 (g_p - sum_o E_o^T (F_o y_c[cam o]))
+//   step = -y ; x_new = x + step * scale
+// partial[0] += |delta|^2 (points),  one thread per point.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
+  const int p = blockIdx.x * kBlock + threadIdx.x;
+  double acc[1] = {0.0};
+  if (p < d.P) {
+    const size_t N = d.N, P = d.P;
+    double t0 = d.gs_p[3 * (size_t)p], t1 = d.gs_p[3 * (size_t)p + 1], t2 = d.gs_p[3 * (size_t)p + 2];
+    for (int o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
+      const double* yc = d.y_c + 9 * (size_t)d.cam[o];
+      double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { f0 += d.F[c * N + o] * yc[c]; f1 += d.F[(9 + c) * N + o] * yc[c]; }
+      t0 -= d.E[o] * f0 + d.E[3 * N + o] * f1;
+      t1 -= d.E[N + o] * f0 + d.E[4 * N + o] * f1;
+      t2 -= d.E[2 * N + o] * f0 + d.E[5 * N + o] * f1;
+    }
+    const double m00 = d.M[p], m10 = d.M[P + p], m11 = d.M[2 * P + p], m20 = d.M[3 * P + p], m21 = d.M[4 * P + p], m22 = d.M[5 * P + p];
+    const double u0 = m00 * t0, u1 = m10 * t0 + m11 * t1, u2 = m20 * t0 + m21 * t1 + m22 * t2;
+    const double y[3] = {m00 * u0 + m10 * u1 + m20 * u2, m11 * u1 + m21 * u2, m22 * u2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double st = -y[k];
+      const double dl = st * d.scale_p[3 * (size_t)p + k];
+      d.step_p[3 * (size_t)p + k] = st;
+      const double xo = d.xp[3 * (size_t)p + k];
+      const double xn = xo + dl;
+      d.xp_new[3 * (size_t)p + k] = xn;
+      const double df = xo - xn;
+      acc[0] += df * df;
+    }
+  }
+  block_sum<1>(acc, d.partial, d.partial_stride);
+}
+
+// cameras: step_c = -y_c ; xc_new = xc + step_c * scale_c ; out[0] = |delta_c|^2
+__global__ __launch_bounds__(kBlock) void bal_cam_step_kernel(BalDev d, double* out) {
+  double acc = 0.0;
+  const int n = 9 * d.C;
+  for (int j = threadIdx.x; j < n; j += kBlock) {
+    const double st = -d.y_c[j];
+    d.step_c[j] = st;
+    const double xo = d.xc[j];
+    const double xn = xo + st * d.scale_c[j];
+    d.xc_new[j] = xn;
+    const double df = xo - xn;
+    acc += df * df;
+  }
+  __shared__ double sh[kBlock / 64];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { double s = 0.0; for (int i = 0; i < kBlock / 64; ++i) s += sh[i]; out[0] = s; }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline int grid_for(int n, int cap = 2048) {
+  int g = (n + kBlock - 1) / kBlock;
+  return g < 1 ? 1 : (g > cap ? cap : g);
+}
+
+int bal_partial_blocks(int N) { return grid_for(N); }
+
+void launch_bal_eval_jac(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_eval_jac_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
+void launch_bal_eval_cost(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_eval_cost_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
+void launch_bal_scale_jac(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_scale_jac_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
+void launch_bal_cam_reduce(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_reduce_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+void launch_bal_pt_reduce(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_pt_reduce_kernel, dim3((d.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(jacobi_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, scale, n); }
+void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(apply_scale_to_reductions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, gs, scale, n); }
+void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(lm_diagonal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, D, n, lo, hi, radius); }
+int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x, int n, double* partial, int stride, hipStream_t s) {
+  const int g = grid_for(n, 256);
+  hipLaunchKernelGGL(grad_max_xnorm_kernel, dim3(g), dim3(kBlock), 0, s, gs, scale, x, n, partial, stride);
+  return g;
+}
+void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s) { hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, s, partial, stride, count, K, maxmask, out); }
+void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_point_block_kernel, dim3((d.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
+void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+void launch_bal_pair(const BalDev& d, hipStream_t s) {
+  if (d.num_segments <= 0) return;
+  const int waves = (d.num_segments + 6) / 7;
+  hipLaunchKernelGGL(bal_pair_kernel, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
+}
+void launch_bal_finish_S(double* S, int ld, int n, int npad, int rhs_row, const double* D_c, hipStream_t s) { hipLaunchKernelGGL(bal_finish_S_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, n, npad, rhs_row, D_c); }
+int launch_bal_point_backsub(const BalDev& d, hipStream_t s) {
+  const int g = d.P > 0 ? (d.P + kBlock - 1) / kBlock : 1;
+  hipLaunchKernelGGL(bal_point_backsub_kernel, dim3(g), dim3(kBlock), 0, s, d);
+  return g;
+}
+void launch_bal_cam_step(const BalDev& d, double* out, hipStream_t s) { hipLaunchKernelGGL(bal_cam_step_kernel, dim3(1), dim3(kBlock), 0, s, d, out); }
+
+}  // namespace sk

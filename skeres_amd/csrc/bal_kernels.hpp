@@ -1,0 +1,63 @@
+// Device-side view of one rank's shard of a bundle-adjustment-shaped problem
+// and the launchers of bal_kernels.hip.  See bal_kernels.hip for the layout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sk {
+
+struct BalDev {
+  int C, P, N;            // cameras (all, replicated), LOCAL points, LOCAL observations
+  // structure (built once on the host, point-major observation order)
+  const int* cam;         // [N] camera of observation o
+  const int* pt;          // [N] local point of observation o
+  const double* obs;      // [2][N] observed x, y
+  const int* pt_start;    // [P+1] observations of point p are [pt_start[p], pt_start[p+1])
+  const int* cam_start;   // [C+1] CSR into cam_obs
+  const int* cam_obs;     // [N] observation indices of each camera, ascending point
+  // pair lists for the off-diagonal blocks of S
+  int num_segments;
+  const int* seg_start;   // [num_segments+1]
+  const int* seg_row;     // [num_segments] row camera i
+  const int* seg_col;     // [num_segments] col camera j (< i)
+  const int* pair_row_obs;  // [num_pairs] observation of camera i
+  const int* pair_col_obs;  // [num_pairs] observation of camera j
+  // state
+  double* xc;  double* xp;          // current parameters [9C], [3P]
+  double* xc_new;  double* xp_new;  // candidate
+  double* scale_c;  double* scale_p;  // Jacobi scaling
+  double* colsq_c;  double* colsq_p;  // squared column norms of the scaled Jacobian
+  double* gs_c;  double* gs_p;        // scaled gradient J_s^T r
+  double* D_c;  double* D_p;          // LM diagonal
+  double* step_c;  double* step_p;    // step in scaled space
+  double* y_c;                        // reduced-system solution
+  // per-observation planes
+  double* r;  double* F;  double* E;  double* What;  double* rt;
+  // per-point
+  double* M;  double* q;
+  // reduced camera system, row-major npad x ld, lower triangle; rhs in row rhs_row
+  double* S;  int ld;  int rhs_row;
+  // reductions
+  double* partial;  int partial_stride;
+  int* fail_flag;
+};
+
+int bal_partial_blocks(int N);
+void launch_bal_eval_jac(const BalDev& d, hipStream_t s);
+void launch_bal_eval_cost(const BalDev& d, hipStream_t s);
+void launch_bal_scale_jac(const BalDev& d, hipStream_t s);
+void launch_bal_cam_reduce(const BalDev& d, hipStream_t s);
+void launch_bal_pt_reduce(const BalDev& d, hipStream_t s);
+void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s);
+void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* scale, int n, hipStream_t s);
+void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s);
+int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x, int n, double* partial, int stride, hipStream_t s);
+void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s);
+void launch_bal_point_block(const BalDev& d, hipStream_t s);
+void launch_bal_obs_precompute(const BalDev& d, hipStream_t s);
+void launch_bal_cam_diag(const BalDev& d, hipStream_t s);
+void launch_bal_pair(const BalDev& d, hipStream_t s);
+void launch_bal_finish_S(double* S, int ld, int n, int npad, int rhs_row, const double* D_c, hipStream_t s);
+int launch_bal_point_backsub(const BalDev& d, hipStream_t s);
+void launch_bal_cam_step(const BalDev& d, double* out, hipStream_t s);
+
+}  // namespace sk

@@ -1,0 +1,349 @@
+// DENSE_SCHUR path for bundle-adjustment-shaped problems
+// (EX/SimpleBundleAdjuster.scala:126-155): every residual block is
+// SnavelyReprojectionError on (camera[9], point[3]).  Points are the e-blocks
+// that the Schur complement eliminates; the 9C x 9C reduced camera system is
+// factored by the MFMA Cholesky.  Multi-GPU: points (and their observations)
+// are partitioned over ranks, cameras are replicated, and the reduced system
+// is summed with one all-reduce per linear solve.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "bal_kernels.hpp"
+#include "solver.hpp"
+
+namespace sk {
+
+bool problem_is_bal_shaped(const Problem& p, std::string* why) {
+  const size_t nb = p.rb_functor.size();
+  if (nb == 0) { *why = "problem has no residual blocks"; return false; }
+  for (size_t b = 0; b < nb; ++b)
+    if (p.rb_functor[b] != SK_FUNCTOR_SNAVELY_REPROJECTION) {
+      *why = "DENSE_SCHUR is implemented for SnavelyReprojectionError residual blocks (2 residuals; 9- and 3-parameter blocks) only";
+      return false;
+    }
+  std::vector<char> role(p.block_size.size(), 0);
+  for (size_t b = 0; b < nb; ++b) {
+    const int c = p.rb_pidx[p.rb_pidx_off[b]], q = p.rb_pidx[p.rb_pidx_off[b] + 1];
+    if ((role[c] | 1) != 1 || (role[q] | 2) != 2) { *why = "a parameter block is used both as camera and as point"; return false; }
+    role[c] = 1; role[q] = 2;
+  }
+  return true;
+}
+
+namespace {
+
+class BalSolver : public SolverBase {
+ public:
+  BalSolver(const Options& o, Problem* p) : SolverBase(o, p) {}
+  double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, opt_.cholesky_group); }
+
+ protected:
+  int setup() override;
+  int evaluate_with_jacobian(bool first) override;
+  int try_step(double radius, bool* valid, double* mcc, double* new_cost, double* step_norm) override;
+  void accept_candidate() override { std::swap(d_.xc, d_.xc_new); std::swap(d_.xp, d_.xp_new); }
+  int write_back() override;
+  void describe(Summary* s) override {
+    s->num_parameter_blocks = (int)problem_->block_size.size();
+    s->num_parameters = problem_->num_parameters();
+    s->num_residual_blocks = (int)problem_->rb_functor.size();
+    s->num_residuals = problem_->num_residuals;
+    s->num_e_blocks = P_total_; s->num_f_blocks = C_;
+  }
+
+ private:
+  int gather_rank_scalars(double* vals, int K, const int* ops);
+
+  int C_ = 0, P_total_ = 0, P_ = 0, N_ = 0;   // cameras, all points, local points, local observations
+  int n_ = 0, npad_ = 0, rhs_row_ = 0;
+  std::vector<int> cam_block_, pt_block_;     // parameter block id of camera i / global point p
+  std::vector<int> local_pt_;                 // global point id of local point
+  BalDev d_{};
+  DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_fail_, b_info_;
+  DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
+      b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
+  double* h_scal_ = nullptr;  // pinned
+  int partial_stride_ = 0;
+ public:
+  ~BalSolver() override { if (h_scal_) (void)hipHostFree(h_scal_); }
+};
+
+int BalSolver::setup() {
+  std::string why;
+  if (!problem_is_bal_shaped(*problem_, &why)) { set_error("%s", why.c_str()); return SK_ERR_UNSUPPORTED; }
+  const Problem& p = *problem_;
+  const int Nall = (int)p.rb_functor.size();
+  // cameras / points in first-appearance order
+  std::vector<int> cam_of_block(p.block_size.size(), -1), pt_of_block(p.block_size.size(), -1);
+  std::vector<int> ocam(Nall), opt(Nall);
+  for (int b = 0; b < Nall; ++b) {
+    const int cb = p.rb_pidx[p.rb_pidx_off[b]], pb = p.rb_pidx[p.rb_pidx_off[b] + 1];
+    if (cam_of_block[cb] < 0) { cam_of_block[cb] = (int)cam_block_.size(); cam_block_.push_back(cb); }
+    if (pt_of_block[pb] < 0) { pt_of_block[pb] = (int)pt_block_.size(); pt_block_.push_back(pb); }
+    ocam[b] = cam_of_block[cb]; opt[b] = pt_of_block[pb];
+  }
+  C_ = (int)cam_block_.size(); P_total_ = (int)pt_block_.size();
+  // partition points over ranks: contiguous runs with equal sum of k_p^2 (Schur work is quadratic in track length)
+  std::vector<int> kp(P_total_, 0);
+  for (int b = 0; b < Nall; ++b) kp[opt[b]]++;
+  int p_lo = 0, p_hi = P_total_;
+  if (opt_.world > 1) {
+    double total = 0.0; for (int q = 0; q < P_total_; ++q) total += (double)kp[q] * kp[q];
+    std::vector<int> cut(opt_.world + 1, P_total_); cut[0] = 0;
+    double acc = 0.0; int r = 1;
+    for (int q = 0; q < P_total_ && r < opt_.world; ++q) {
+      acc += (double)kp[q] * kp[q];
+      while (r < opt_.world && acc >= total * r / opt_.world) { cut[r++] = q + 1; }
+    }
+    p_lo = cut[opt_.rank]; p_hi = cut[opt_.rank + 1];
+  }
+  P_ = p_hi - p_lo;
+  local_pt_.resize(P_); std::iota(local_pt_.begin(), local_pt_.end(), p_lo);
+  // local observations, point-major, ascending camera within a point
+  std::vector<int> pt_start(P_ + 1, 0);
+  for (int b = 0; b < Nall; ++b) if (opt[b] >= p_lo && opt[b] < p_hi) pt_start[opt[b] - p_lo + 1]++;
+  for (int q = 0; q < P_; ++q) pt_start[q + 1] += pt_start[q];
+  N_ = pt_start[P_];
+  std::vector<int> order(N_);
+  { std::vector<int> fill(pt_start.begin(), pt_start.end() - 1);
+    for (int b = 0; b < Nall; ++b) if (opt[b] >= p_lo && opt[b] < p_hi) order[fill[opt[b] - p_lo]++] = b; }
+  for (int q = 0; q < P_; ++q)
+    std::sort(order.begin() + pt_start[q], order.begin() + pt_start[q + 1], [&](int a, int b) { return ocam[a] != ocam[b] ? ocam[a] < ocam[b] : a < b; });
+  std::vector<int> cam(N_), pt(N_);
+  std::vector<double> obs(2 * (size_t)N_);
+  for (int o = 0; o < N_; ++o) {
+    const int b = order[o];
+    cam[o] = ocam[b]; pt[o] = opt[b] - p_lo;
+    obs[o] = p.consts[p.rb_const_off[b]]; obs[(size_t)N_ + o] = p.consts[p.rb_const_off[b] + 1];
+    if (o > 0 && pt[o] == pt[o - 1] && cam[o] == cam[o - 1]) { set_error("two residual blocks share the same (camera, point) pair: not supported by the Schur path"); return SK_ERR_UNSUPPORTED; }
+  }
+  // camera CSR (ascending point because observation order is point-major)
+  std::vector<int> cam_start(C_ + 1, 0), cam_obs(N_);
+  for (int o = 0; o < N_; ++o) cam_start[cam[o] + 1]++;
+  for (int i = 0; i < C_; ++i) cam_start[i + 1] += cam_start[i];
+  { std::vector<int> fill(cam_start.begin(), cam_start.end() - 1); for (int o = 0; o < N_; ++o) cam_obs[fill[cam[o]]++] = o; }
+  // pair lists: for every point, every (larger camera, smaller camera) pair of its observations
+  size_t npairs = 0;
+  for (int q = 0; q < P_; ++q) { const size_t k = pt_start[q + 1] - pt_start[q]; npairs += k * (k - 1) / 2; }
+  if (npairs > 2000000000ull) { set_error("pair list too large"); return SK_ERR_UNSUPPORTED; }
+  std::vector<int> pair_row(npairs), pair_col(npairs), seg_start, seg_row, seg_col;
+  {
+    const size_t CC = (size_t)C_ * C_;
+    std::vector<unsigned> count(CC + 1, 0);  // key = row * C + col
+    for (int q = 0; q < P_; ++q)
+      for (int b = pt_start[q] + 1; b < pt_start[q + 1]; ++b)
+        for (int a = pt_start[q]; a < b; ++a) count[(size_t)cam[b] * C_ + cam[a] + 1]++;
+    seg_start.push_back(0);
+    std::vector<unsigned> pos(CC, 0);
+    unsigned run = 0;
+    for (size_t key = 0; key < CC; ++key) {
+      pos[key] = run;
+      if (count[key + 1]) { seg_row.push_back((int)(key / C_)); seg_col.push_back((int)(key % C_)); run += count[key + 1]; seg_start.push_back((int)run); }
+    }
+    for (int q = 0; q < P_; ++q)  // ascending point => entries of a segment are in ascending point order
+      for (int b = pt_start[q] + 1; b < pt_start[q + 1]; ++b)
+        for (int a = pt_start[q]; a < b; ++a) { const unsigned e = pos[(size_t)cam[b] * C_ + cam[a]]++; pair_row[e] = b; pair_col[e] = a; }
+  }
+  n_ = 9 * C_; rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
+  // ---- device buffers ----
+  hipStream_t s = stream_;
+  SK_HIP_TRY(b_cam_.upload(cam, s)); SK_HIP_TRY(b_pt_.upload(pt, s)); SK_HIP_TRY(b_obs_.upload(obs, s));
+  SK_HIP_TRY(b_pt_start_.upload(pt_start, s)); SK_HIP_TRY(b_cam_start_.upload(cam_start, s)); SK_HIP_TRY(b_cam_obs_.upload(cam_obs, s));
+  SK_HIP_TRY(b_seg_start_.upload(seg_start, s)); SK_HIP_TRY(b_seg_row_.upload(seg_row, s)); SK_HIP_TRY(b_seg_col_.upload(seg_col, s));
+  SK_HIP_TRY(b_pair_row_.upload(pair_row, s)); SK_HIP_TRY(b_pair_col_.upload(pair_col, s));
+  const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_, nx = nc + np;
+  std::vector<double> x(nx);
+  for (int i = 0; i < C_; ++i) std::memcpy(&x[9 * (size_t)i], p.block_ptr[cam_block_[i]], 9 * sizeof(double));
+  for (int q = 0; q < P_; ++q) std::memcpy(&x[nc + 3 * (size_t)q], p.block_ptr[pt_block_[local_pt_[q]]], 3 * sizeof(double));
+  // x vectors are stored [cameras | points] so whole-vector kernels run once
+  SK_HIP_TRY(b_xc_.upload(x, s)); SK_HIP_TRY(b_xc_new_.alloc(nx));
+  SK_HIP_TRY(b_scale_.alloc(nx)); SK_HIP_TRY(b_colsq_.alloc(nx)); SK_HIP_TRY(b_gs_.alloc(nx)); SK_HIP_TRY(b_D_.alloc(nx)); SK_HIP_TRY(b_step_.alloc(nx));
+  { std::vector<double> ones(nx, 1.0); SK_HIP_TRY(hipMemcpyAsync(b_scale_.p, ones.data(), nx * sizeof(double), hipMemcpyHostToDevice, s)); SK_HIP_TRY(hipStreamSynchronize(s)); }
+  SK_HIP_TRY(b_y_.alloc(npad_));
+  SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
+  SK_HIP_TRY(b_W_.alloc(27 * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
+  SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
+  const size_t s_elems = (size_t)npad_ * npad_;
+  if (opt_.reduce_buffer) {
+    if (opt_.reduce_buffer_bytes < s_elems * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", s_elems * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
+    b_S_.adopt(static_cast<double*>(opt_.reduce_buffer), s_elems);
+  } else {
+    SK_HIP_TRY(b_S_.alloc(s_elems));
+  }
+  SK_HIP_TRY(b_Linv_.alloc((size_t)npad_ * 128)); SK_HIP_TRY(b_Linv_.zero(s));
+  partial_stride_ = std::max(std::max(bal_partial_blocks(N_), (P_ + 255) / 256), 256);
+  SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
+  SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
+  SK_HIP_TRY(b_fail_.alloc(1)); SK_HIP_TRY(b_fail_.zero(s)); SK_HIP_TRY(b_info_.alloc(1)); SK_HIP_TRY(b_info_.zero(s));
+  SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
+  SK_HIP_TRY(cholesky_init());
+  // ---- device view ----
+  d_.C = C_; d_.P = P_; d_.N = N_;
+  d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p;
+  d_.num_segments = (int)seg_row.size(); d_.seg_start = b_seg_start_.p; d_.seg_row = b_seg_row_.p; d_.seg_col = b_seg_col_.p;
+  d_.pair_row_obs = b_pair_row_.p; d_.pair_col_obs = b_pair_col_.p;
+  d_.xc = b_xc_.p; d_.xp = b_xc_.p + nc; d_.xc_new = b_xc_new_.p; d_.xp_new = b_xc_new_.p + nc;
+  d_.scale_c = b_scale_.p; d_.scale_p = b_scale_.p + nc; d_.colsq_c = b_colsq_.p; d_.colsq_p = b_colsq_.p + nc;
+  d_.gs_c = b_gs_.p; d_.gs_p = b_gs_.p + nc; d_.D_c = b_D_.p; d_.D_p = b_D_.p + nc; d_.step_c = b_step_.p; d_.step_p = b_step_.p + nc;
+  d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.rt = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
+  d_.S = b_S_.p; d_.ld = npad_; d_.rhs_row = rhs_row_; d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = b_fail_.p;
+  SK_HIP_TRY(hipStreamSynchronize(s));
+  return SK_OK;
+}
+
+// Combine per-rank scalars: every rank writes its K values into its own slot of
+// a world x K table, the table is sum-reduced, then each rank folds the slots
+// in rank order (identical result on every rank; ops: 0 sum, 1 max).
+int BalSolver::gather_rank_scalars(double* vals, int K, const int* ops) {
+  if (opt_.world <= 1) return SK_OK;
+  const int W = opt_.world;
+  std::vector<double> table((size_t)W * K, 0.0);
+  for (int k = 0; k < K; ++k) table[(size_t)opt_.rank * K + k] = vals[k];
+  double* dev = b_small_.p + 2 * 9 * (size_t)C_ + 64;
+  SK_HIP_TRY(hipMemcpyAsync(dev, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  int rc = allreduce(dev, table.size());
+  if (rc) return rc;
+  SK_HIP_TRY(hipMemcpyAsync(table.data(), dev, table.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  SK_HIP_TRY(hipStreamSynchronize(stream_));
+  for (int k = 0; k < K; ++k) {
+    double a = 0.0;
+    for (int r = 0; r < W; ++r) a = ops[k] ? std::max(a, table[(size_t)r * K + k]) : a + table[(size_t)r * K + k];
+    vals[k] = a;
+  }
+  return SK_OK;
+}
+
+int BalSolver::evaluate_with_jacobian(bool first) {
+  hipStream_t s = stream_;
+  const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_;
+  SK_HIP_TRY(hipEventRecord(ev_[kEvBegin], s));
+  kt_.begin("bal_eval_jac", s); launch_bal_eval_jac(d_, s); kt_.end("bal_eval_jac", s);
+  const int nb = bal_partial_blocks(N_);
+  launch_bal_cam_reduce(d_, s);
+  launch_bal_pt_reduce(d_, s);
+  if (opt_.world > 1) {  // camera columns are summed over all ranks' observations
+    double* buf = b_small_.p;
+    SK_HIP_TRY(hipMemcpyAsync(buf, d_.colsq_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
+    SK_HIP_TRY(hipMemcpyAsync(buf + nc, d_.gs_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
+    int rc = allreduce(buf, 2 * nc);
+    if (rc) return rc;
+    SK_HIP_TRY(hipMemcpyAsync(d_.colsq_c, buf, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
+    SK_HIP_TRY(hipMemcpyAsync(d_.gs_c, buf + nc, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  if (first && opt_.jacobi_scaling) {
+    launch_jacobi_scale(b_colsq_.p, b_scale_.p, (int)(nc + np), s);
+    launch_bal_scale_jac(d_, s);
+    launch_apply_scale_to_reductions(b_colsq_.p, b_gs_.p, b_scale_.p, (int)(nc + np), s);
+  }
+  // scalars: sum r^2 (slot 4) ; gradient max-norm and |x|^2 (cameras once, points local)
+  launch_final_reduce(b_partial_.p, partial_stride_, nb, 1, 0, b_scal_.p + 4, s);
+  const int gc = launch_grad_max_xnorm(d_.gs_c, d_.scale_c, d_.xc, (int)nc, b_partial_.p, partial_stride_, s);
+  launch_final_reduce(b_partial_.p, partial_stride_, gc, 2, 1, b_scal_.p, s);
+  const int gp = launch_grad_max_xnorm(d_.gs_p, d_.scale_p, d_.xp, (int)np, b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, s);
+  launch_final_reduce(b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, np ? gp : 0, 2, 1, b_scal_.p + 2, s);
+  SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
+  SK_HIP_TRY(hipEventRecord(ev_[kEvJac], s));
+  SK_HIP_TRY(hipStreamSynchronize(s));
+  const double sumsq = h_scal_[4];
+  const double gmax_c = h_scal_[0], x2_c = h_scal_[1];
+  double loc[3] = {sumsq, h_scal_[2], h_scal_[3]};  // local: sum r^2, max |g_p|, |x_p|^2
+  const int ops3[3] = {0, 1, 0};
+  int rc = gather_rank_scalars(loc, 3, ops3);
+  if (rc) return rc;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvJac]) == hipSuccess) phase_[0] += 1e-3 * ms;
+  cost_ = 0.5 * loc[0];
+  gmax_ = std::max(gmax_c, loc[1]);
+  xnorm_ = std::sqrt(x2_c + loc[2]);
+  if (!std::isfinite(cost_)) return SK_ERR_EVALUATION_FAILED;
+  return SK_OK;
+}
+
+int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cost, double* step_norm) {
+  hipStream_t s = stream_;
+  const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_;
+  *valid = false;
+  SK_HIP_TRY(hipEventRecord(ev_[kEvBegin], s));
+  launch_lm_diagonal(b_colsq_.p, b_D_.p, (int)(nc + np), opt_.min_lm_diagonal, opt_.max_lm_diagonal, radius, s);
+  // ---- B. Schur complement assembly ----
+  kt_.begin("memset_S", s);
+  SK_HIP_TRY(hipMemsetAsync(b_S_.p, 0, (size_t)npad_ * npad_ * sizeof(double), s));
+  kt_.end("memset_S", s);
+  SK_HIP_TRY(hipMemsetAsync(b_fail_.p, 0, sizeof(int), s));
+  SK_HIP_TRY(hipMemsetAsync(b_info_.p, 0, sizeof(int), s));
+  launch_bal_point_block(d_, s);
+  launch_bal_obs_precompute(d_, s);
+  kt_.begin("bal_cam_diag", s); launch_bal_cam_diag(d_, s); kt_.end("bal_cam_diag", s);
+  kt_.begin("bal_pair", s); launch_bal_pair(d_, s); kt_.end("bal_pair", s);
+  if (opt_.world > 1) {
+    // sum S (with the rhs row) over ranks; only rows [0, rhs_row] carry data
+    int rc = allreduce(b_S_.p, (size_t)(rhs_row_ + 1) * npad_);
+    if (rc) return rc;
+  }
+  launch_bal_finish_S(b_S_.p, npad_, n_, npad_, rhs_row_, d_.D_c, s);
+  SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
+  // ---- C. dense Cholesky + solves ----
+  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.cholesky_group, s, &kt_);
+  cholesky_backsolve(b_S_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_y_.p, s, &kt_);
+  SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
+  // ---- D. back-substitution, candidate point ----
+  launch_bal_cam_step(d_, b_scal_.p + 8, s);
+  const int gb = launch_bal_point_backsub(d_, s);
+  launch_final_reduce(b_partial_.p, partial_stride_, P_ > 0 ? gb : 0, 1, 0, b_scal_.p + 9, s);
+  SK_HIP_TRY(hipEventRecord(ev_[kEvBacksub], s));
+  kt_.begin("bal_eval_cost", s); launch_bal_eval_cost(d_, s); kt_.end("bal_eval_cost", s);
+  launch_final_reduce(b_partial_.p, partial_stride_, bal_partial_blocks(N_), 2, 0, b_scal_.p, s);
+  SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
+  SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
+  SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 16, b_fail_.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 17, b_info_.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  SK_HIP_TRY(hipStreamSynchronize(s));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvAssemble]) == hipSuccess) phase_[1] += 1e-3 * ms;
+  if (hipEventElapsedTime(&ms, ev_[kEvAssemble], ev_[kEvChol]) == hipSuccess) phase_[2] += 1e-3 * ms;
+  if (hipEventElapsedTime(&ms, ev_[kEvChol], ev_[kEvBacksub]) == hipSuccess) phase_[3] += 1e-3 * ms;
+  if (hipEventElapsedTime(&ms, ev_[kEvBacksub], ev_[kEvCost]) == hipSuccess) phase_[4] += 1e-3 * ms;
+  int fail = 0, info = 0;
+  std::memcpy(&fail, h_scal_ + 16, sizeof(int)); std::memcpy(&info, h_scal_ + 17, sizeof(int));
+  double loc[4] = {h_scal_[0], h_scal_[1], h_scal_[9], (double)(fail | info)};  // sum r_new^2, model term, |delta_p|^2, failure
+  const int ops4[4] = {0, 0, 0, 1};
+  int rc = gather_rank_scalars(loc, 4, ops4);
+  if (rc) return rc;
+  const double step_sq = h_scal_[8] + loc[2];
+  if (loc[3] != 0.0 || !std::isfinite(step_sq) || !std::isfinite(loc[1])) return SK_OK;  // invalid step
+  *valid = true;
+  *mcc = -loc[1];
+  *new_cost = 0.5 * loc[0];
+  *step_norm = std::sqrt(step_sq);
+  return SK_OK;
+}
+
+int BalSolver::write_back() {
+  const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_;
+  std::vector<double> x(nc + np);
+  SK_HIP_TRY(hipMemcpyAsync(x.data(), d_.xc, (nc + np) * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  SK_HIP_TRY(hipStreamSynchronize(stream_));
+  for (int i = 0; i < C_; ++i) std::memcpy(problem_->block_ptr[cam_block_[i]], &x[9 * (size_t)i], 9 * sizeof(double));
+  if (opt_.world <= 1) {
+    for (int q = 0; q < P_; ++q) std::memcpy(problem_->block_ptr[pt_block_[local_pt_[q]]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
+    return SK_OK;
+  }
+  // every rank returns ALL points: zero-filled table, own slice filled, sum-reduced
+  std::vector<double> all(3 * (size_t)P_total_, 0.0);
+  for (int q = 0; q < P_; ++q) std::memcpy(&all[3 * (size_t)local_pt_[q]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
+  DevBuf<double> tmp;
+  SK_HIP_TRY(tmp.upload(all, stream_));
+  int rc = allreduce(tmp.p, all.size());
+  if (rc) return rc;
+  SK_HIP_TRY(hipMemcpyAsync(all.data(), tmp.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  SK_HIP_TRY(hipStreamSynchronize(stream_));
+  for (int q = 0; q < P_total_; ++q) std::memcpy(problem_->block_ptr[pt_block_[q]], &all[3 * (size_t)q], 3 * sizeof(double));
+  return SK_OK;
+}
+
+}  // namespace
+
+std::unique_ptr<SolverBase> make_bal_solver(const Options& o, Problem* p) { return std::unique_ptr<SolverBase>(new BalSolver(o, p)); }
+
+}  // namespace sk

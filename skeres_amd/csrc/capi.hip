@@ -1,0 +1,364 @@
+// C ABI of libskeres_amd.so (include/skeres_amd.h).  No C++ types or
+// exceptions cross this boundary.
+#include <cmath>
+#include <cstdlib>
+#include <new>
+
+#include "dense_kernels.hpp"
+#include "solver.hpp"
+
+using namespace sk;
+
+struct sk_ptrvec { std::vector<double*> v; };
+struct sk_loss_function { LossFunction l; };
+struct sk_cost_function { CostFunction c; };
+struct sk_problem { Problem p; };
+struct sk_options { Options o; };
+struct sk_summary { Summary s; };
+struct sk_solver { std::unique_ptr<SolverBase> impl; };
+
+static std::string g_program_name;
+
+#define SK_GUARD_BEGIN try {
+#define SK_GUARD_END(ret)                                                   \
+  } catch (const std::bad_alloc&) { set_error("out of host memory"); return ret; } \
+  catch (const std::exception& e) { set_error("internal error: %s", e.what()); return ret; } \
+  catch (...) { set_error("internal error"); return ret; }
+
+extern "C" {
+
+const char* sk_version(void) { return "skeres_amd 0.1 (gfx950)"; }
+const char* sk_last_error(void) { return get_error(); }
+void sk_init_logging(const char* name) { g_program_name = name ? name : ""; }
+int sk_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+// ---- DoubleArray ------------------------------------------------------------
+double* sk_array_new(int n) { if (n < 0) return nullptr; return static_cast<double*>(std::calloc((size_t)(n > 0 ? n : 1), sizeof(double))); }
+void sk_array_free(double* a) { std::free(a); }
+double sk_array_getitem(const double* a, int i) { return a[i]; }
+void sk_array_setitem(double* a, int i, double v) { a[i] = v; }
+double* sk_array_slice(double* buffer, int start) { return &buffer[start]; }
+void sk_array_copy_in(double* dst, const double* src, int n) { if (n > 0) std::memcpy(dst, src, (size_t)n * sizeof(double)); }
+void sk_array_copy_out(const double* src, double* dst, int n) { if (n > 0) std::memcpy(dst, src, (size_t)n * sizeof(double)); }
+
+// ---- DoubleMatrix -------------------------------------------------------------
+int sk_matrix_is_null(double* const* m) { return m == nullptr; }
+double* sk_matrix_row(double* const* m, int i) { return m[i]; }
+
+// ---- StdVectorDoublePointer -----------------------------------------------------
+sk_ptrvec* sk_ptrvec_new(void) { return new (std::nothrow) sk_ptrvec(); }
+void sk_ptrvec_free(sk_ptrvec* v) { delete v; }
+void sk_ptrvec_add(sk_ptrvec* v, double* p) { v->v.push_back(p); }
+int sk_ptrvec_size(const sk_ptrvec* v) { return (int)v->v.size(); }
+double* sk_ptrvec_get(const sk_ptrvec* v, int i) { return v->v[i]; }
+void sk_ptrvec_set(sk_ptrvec* v, int i, double* p) { v->v[i] = p; }
+double** sk_ptrvec_to_pointer_pointer(sk_ptrvec* v) { return v->v.empty() ? nullptr : v->v.data(); }
+
+// ---- LossFunction -----------------------------------------------------------------
+sk_loss_function* sk_loss_trivial(void) { return new (std::nothrow) sk_loss_function(); }
+void sk_loss_free(sk_loss_function* l) { delete l; }
+
+// ---- CostFunction -----------------------------------------------------------------
+sk_cost_function* sk_cost_function_new_autodiff(int functor_id, const double* consts, int num_consts) {
+  FunctorDesc d;
+  if (!functor_desc(functor_id, &d)) { set_error("unknown device functor id %d", functor_id); return nullptr; }
+  if (num_consts != d.num_consts || (num_consts > 0 && !consts)) { set_error("functor %d captures %d constants, %d given", functor_id, d.num_consts, num_consts); return nullptr; }
+  sk_cost_function* cf = new (std::nothrow) sk_cost_function();
+  if (!cf) { set_error("out of host memory"); return nullptr; }
+  cf->c.functor_id = functor_id;
+  cf->c.consts.assign(consts, consts + num_consts);
+  cf->c.num_residuals = d.num_residuals;
+  cf->c.block_sizes.assign(d.block_sizes, d.block_sizes + d.num_blocks);
+  return cf;
+}
+
+sk_cost_function* sk_cost_function_new_callback(sk_evaluate_fn fn, void* user, int num_residuals, const int* block_sizes, int num_blocks) {
+  // CostFunctor / SizedCostFunction validation (CORE/CostFunctor.scala:31-34, CORE/SizedCostFunction.scala:7-11)
+  if (!fn) { set_error("null evaluate callback"); return nullptr; }
+  if (num_residuals <= 0) { set_error("Nonpositive number of residuals specified: %d", num_residuals); return nullptr; }
+  if (num_blocks <= 0 || !block_sizes) { set_error("a cost function needs at least one parameter block"); return nullptr; }
+  for (int i = 0; i < num_blocks; ++i) if (block_sizes[i] <= 0) { set_error("Nonpositive parameter block sizes specified"); return nullptr; }
+  sk_cost_function* cf = new (std::nothrow) sk_cost_function();
+  if (!cf) { set_error("out of host memory"); return nullptr; }
+  cf->c.functor_id = SK_FUNCTOR_HOST_CALLBACK; cf->c.callback = fn; cf->c.user = user; cf->c.num_residuals = num_residuals;
+  cf->c.block_sizes.assign(block_sizes, block_sizes + num_blocks);
+  return cf;
+}
+void sk_cost_function_free(sk_cost_function* cf) { delete cf; }
+int sk_cost_function_num_residuals(const sk_cost_function* cf) { return cf->c.num_residuals; }
+int sk_cost_function_num_parameter_blocks(const sk_cost_function* cf) { return (int)cf->c.block_sizes.size(); }
+int sk_cost_function_parameter_block_size(const sk_cost_function* cf, int i) { return cf->c.block_sizes[i]; }
+
+int sk_cost_function_evaluate(const sk_cost_function* cf, double const* const* parameters, double* residuals, double** jacobians) {
+  SK_GUARD_BEGIN
+  const CostFunction& c = cf->c;
+  if (c.functor_id == SK_FUNCTOR_HOST_CALLBACK) return c.callback(c.user, parameters, residuals, jacobians) ? 1 : 0;
+  if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return -SK_ERR_NO_DEVICE; }
+  const int nb = (int)c.block_sizes.size(), nres = c.num_residuals;
+  std::vector<int> x_off(nb), j_off(nb);
+  int nx = 0, nj = 0; unsigned mask = 0;
+  for (int q = 0; q < nb; ++q) { x_off[q] = nx; nx += c.block_sizes[q]; j_off[q] = nj; nj += nres * c.block_sizes[q]; if (jacobians && jacobians[q]) mask |= 1u << q; }
+  std::vector<double> x(nx);
+  for (int q = 0; q < nb; ++q) std::memcpy(&x[x_off[q]], parameters[q], c.block_sizes[q] * sizeof(double));
+  DevBuf<double> dx, dc, dr, dj; DevBuf<int> dxo, djo, dok;
+  std::vector<double> consts = c.consts; if (consts.empty()) consts.push_back(0.0);
+  hipStream_t s = nullptr;
+#define SK_TRYN(e) do { if ((e) != hipSuccess) { set_error("HIP error in sk_cost_function_evaluate"); return -SK_ERR_HIP; } } while (0)
+  SK_TRYN(dx.upload(x, s)); SK_TRYN(dc.upload(consts, s)); SK_TRYN(dxo.upload(x_off, s)); SK_TRYN(djo.upload(j_off, s));
+  SK_TRYN(dr.alloc(nres)); SK_TRYN(dj.alloc(nj)); SK_TRYN(dok.alloc(1));
+  launch_single_eval(c.functor_id, dc.p, dx.p, dxo.p, dr.p, dj.p, djo.p, jacobians ? 1 : 0, mask, dok.p, s);
+  int ok = 0;
+  std::vector<double> r(nres), j(nj);
+  SK_TRYN(hipMemcpy(&ok, dok.p, sizeof(int), hipMemcpyDeviceToHost));
+  SK_TRYN(hipMemcpy(r.data(), dr.p, nres * sizeof(double), hipMemcpyDeviceToHost));
+  SK_TRYN(hipMemcpy(j.data(), dj.p, nj * sizeof(double), hipMemcpyDeviceToHost));
+#undef SK_TRYN
+  if (!ok) return 0;
+  std::memcpy(residuals, r.data(), nres * sizeof(double));
+  for (int q = 0; q < nb; ++q) if ((mask >> q) & 1u) std::memcpy(jacobians[q], &j[j_off[q]], (size_t)nres * c.block_sizes[q] * sizeof(double));
+  return 1;
+  SK_GUARD_END(-SK_ERR_INVALID_ARGUMENT)
+}
+
+// ---- Problem ------------------------------------------------------------------------
+sk_problem* sk_problem_new(void) { return new (std::nothrow) sk_problem(); }
+void sk_problem_free(sk_problem* p) { delete p; }
+
+static int register_block(Problem& P, double* ptr, int size) {
+  if (!ptr) { set_error("null parameter block pointer"); return -1; }
+  auto it = P.block_of.find(ptr);
+  if (it != P.block_of.end()) {
+    if (P.block_size[it->second] != size) { set_error("parameter block %p was registered with size %d, now used with size %d", (void*)ptr, P.block_size[it->second], size); return -1; }
+    return it->second;
+  }
+  const int id = (int)P.block_ptr.size();
+  P.block_of.emplace(ptr, id); P.block_ptr.push_back(ptr); P.block_size.push_back(size);
+  return id;
+}
+
+int sk_problem_add_residual_block(sk_problem* p, const sk_cost_function* cost, const sk_loss_function* loss, double* const* parameter_blocks,
+                                  int num_parameter_blocks, sk_residual_block_id* id_out) {
+  SK_GUARD_BEGIN
+  (void)loss;  // trivial loss only (rho(s) = s)
+  if (!p || !cost || !parameter_blocks) { set_error("null argument"); return SK_ERR_INVALID_ARGUMENT; }
+  const CostFunction& c = cost->c;
+  if (num_parameter_blocks != (int)c.block_sizes.size()) { set_error("cost function expects %d parameter blocks, %d given", (int)c.block_sizes.size(), num_parameter_blocks); return SK_ERR_INVALID_ARGUMENT; }
+  Problem& P = p->p;
+  std::vector<int> ids(num_parameter_blocks);
+  for (int q = 0; q < num_parameter_blocks; ++q) {
+    ids[q] = register_block(P, parameter_blocks[q], c.block_sizes[q]);
+    if (ids[q] < 0) return SK_ERR_INVALID_ARGUMENT;
+    for (int t = 0; t < q; ++t) if (ids[t] == ids[q]) { set_error("duplicate parameter blocks in a residual block are not allowed"); return SK_ERR_INVALID_ARGUMENT; }
+  }
+  P.rb_functor.push_back(c.functor_id); P.rb_num_residuals.push_back(c.num_residuals);
+  P.rb_const_off.push_back(P.consts.size()); P.consts.insert(P.consts.end(), c.consts.begin(), c.consts.end());
+  P.rb_pidx.insert(P.rb_pidx.end(), ids.begin(), ids.end()); P.rb_pidx_off.push_back(P.rb_pidx.size());
+  P.rb_cost.push_back(c.functor_id == SK_FUNCTOR_HOST_CALLBACK ? &c : nullptr);
+  if (c.functor_id == SK_FUNCTOR_HOST_CALLBACK) P.has_callbacks = true;
+  P.num_residuals += c.num_residuals;
+  if (id_out) *id_out = (int)P.rb_functor.size() - 1;
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
+int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const double* consts, const sk_loss_function* loss, double* const* parameter_blocks) {
+  SK_GUARD_BEGIN
+  (void)loss;
+  FunctorDesc d;
+  if (!p || n < 0 || !parameter_blocks) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (!functor_desc(functor_id, &d)) { set_error("unknown device functor id %d", functor_id); return SK_ERR_INVALID_ARGUMENT; }
+  if (d.num_consts > 0 && !consts) { set_error("functor %d needs %d constants per block", functor_id, d.num_consts); return SK_ERR_INVALID_ARGUMENT; }
+  Problem& P = p->p;
+  P.rb_functor.reserve(P.rb_functor.size() + n); P.rb_pidx.reserve(P.rb_pidx.size() + (size_t)n * d.num_blocks);
+  P.consts.reserve(P.consts.size() + (size_t)n * d.num_consts);
+  for (int b = 0; b < n; ++b) {
+    int ids[10];
+    for (int q = 0; q < d.num_blocks; ++q) {
+      ids[q] = register_block(P, parameter_blocks[(size_t)b * d.num_blocks + q], d.block_sizes[q]);
+      if (ids[q] < 0) return SK_ERR_INVALID_ARGUMENT;
+      for (int t = 0; t < q; ++t) if (ids[t] == ids[q]) { set_error("duplicate parameter blocks in a residual block are not allowed"); return SK_ERR_INVALID_ARGUMENT; }
+    }
+    P.rb_functor.push_back(functor_id); P.rb_num_residuals.push_back(d.num_residuals);
+    P.rb_const_off.push_back(P.consts.size());
+    if (d.num_consts) P.consts.insert(P.consts.end(), consts + (size_t)b * d.num_consts, consts + (size_t)(b + 1) * d.num_consts);
+    P.rb_pidx.insert(P.rb_pidx.end(), ids, ids + d.num_blocks); P.rb_pidx_off.push_back(P.rb_pidx.size());
+    P.rb_cost.push_back(nullptr);
+    P.num_residuals += d.num_residuals;
+  }
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+int sk_problem_num_residual_blocks(const sk_problem* p) { return (int)p->p.rb_functor.size(); }
+int sk_problem_num_parameter_blocks(const sk_problem* p) { return (int)p->p.block_size.size(); }
+int sk_problem_num_parameters(const sk_problem* p) { return p->p.num_parameters(); }
+int sk_problem_num_residuals(const sk_problem* p) { return (int)p->p.num_residuals; }
+
+// ---- Options --------------------------------------------------------------------------
+sk_options* sk_options_new(void) { return new (std::nothrow) sk_options(); }
+void sk_options_free(sk_options* o) { delete o; }
+int sk_options_set_linear_solver_type(sk_options* o, int t) {
+  if (t != SK_DENSE_NORMAL_CHOLESKY && t != SK_DENSE_QR && t != SK_DENSE_SCHUR) { set_error("linear solver type %s is not implemented (DENSE_QR, DENSE_NORMAL_CHOLESKY, DENSE_SCHUR are)", linear_solver_name(t)); return SK_ERR_UNSUPPORTED; }
+  o->o.linear_solver_type = t; return SK_OK;
+}
+int sk_options_set_minimizer_type(sk_options* o, int t) {
+  if (t != SK_TRUST_REGION) { set_error("only TRUST_REGION is implemented"); return SK_ERR_UNSUPPORTED; }
+  o->o.minimizer_type = t; return SK_OK;
+}
+int sk_options_set_max_num_iterations(sk_options* o, int n) { if (n < 0) { set_error("max_num_iterations must be >= 0"); return SK_ERR_INVALID_ARGUMENT; } o->o.max_num_iterations = n; return SK_OK; }
+int sk_options_set_minimizer_progress_to_stdout(sk_options* o, int on) { o->o.progress_to_stdout = on != 0; return SK_OK; }
+#define SK_SET_D(NAME, FIELD) int sk_options_set_##NAME(sk_options* o, double v) { if (!(v >= 0.0)) { set_error(#NAME " must be >= 0"); return SK_ERR_INVALID_ARGUMENT; } o->o.FIELD = v; return SK_OK; }
+SK_SET_D(function_tolerance, function_tolerance)
+SK_SET_D(gradient_tolerance, gradient_tolerance)
+SK_SET_D(parameter_tolerance, parameter_tolerance)
+SK_SET_D(initial_trust_region_radius, initial_trust_region_radius)
+SK_SET_D(max_trust_region_radius, max_trust_region_radius)
+SK_SET_D(min_trust_region_radius, min_trust_region_radius)
+SK_SET_D(min_relative_decrease, min_relative_decrease)
+SK_SET_D(min_lm_diagonal, min_lm_diagonal)
+SK_SET_D(max_lm_diagonal, max_lm_diagonal)
+int sk_options_set_jacobi_scaling(sk_options* o, int on) { o->o.jacobi_scaling = on != 0; return SK_OK; }
+int sk_options_set_max_num_consecutive_invalid_steps(sk_options* o, int n) { if (n < 1) { set_error("must be >= 1"); return SK_ERR_INVALID_ARGUMENT; } o->o.max_num_consecutive_invalid_steps = n; return SK_OK; }
+int sk_options_set_device(sk_options* o, int dev) { o->o.device = dev; return SK_OK; }
+int sk_options_set_stream(sk_options* o, void* stream) { o->o.stream = (hipStream_t)stream; o->o.stream_set = true; return SK_OK; }
+int sk_options_set_distributed(sk_options* o, int rank, int world, sk_allreduce_fn fn, void* user) {
+  if (world < 1 || rank < 0 || rank >= world) { set_error("invalid rank/world %d/%d", rank, world); return SK_ERR_INVALID_ARGUMENT; }
+  if (world > 1 && !fn) { set_error("world > 1 needs an allreduce hook"); return SK_ERR_INVALID_ARGUMENT; }
+  o->o.rank = rank; o->o.world = world; o->o.allreduce = fn; o->o.allreduce_user = user; return SK_OK;
+}
+int sk_options_set_reduce_buffer(sk_options* o, void* ptr, size_t bytes) { o->o.reduce_buffer = ptr; o->o.reduce_buffer_bytes = bytes; return SK_OK; }
+size_t sk_reduce_buffer_bytes(const sk_options* o, const sk_problem* p) {
+  (void)o;
+  // cameras = distinct blocks in parameter slot 0 of the residual blocks
+  const Problem& P = p->p;
+  std::vector<char> seen(P.block_size.size(), 0); size_t C = 0;
+  for (size_t b = 0; b < P.rb_functor.size(); ++b) { const int c = P.rb_pidx[P.rb_pidx_off[b]]; if (!seen[c]) { seen[c] = 1; ++C; } }
+  const size_t n = 9 * C, npad = ((n + 1 + 127) / 128) * 128;
+  return npad * npad * sizeof(double);
+}
+
+// ---- Summary --------------------------------------------------------------------------
+sk_summary* sk_summary_new(void) { return new (std::nothrow) sk_summary(); }
+void sk_summary_free(sk_summary* s) { delete s; }
+double sk_summary_initial_cost(const sk_summary* s) { return s->s.initial_cost; }
+double sk_summary_final_cost(const sk_summary* s) { return s->s.final_cost; }
+int sk_summary_num_iterations(const sk_summary* s) { return (int)s->s.iterations.size(); }
+int sk_summary_num_successful_steps(const sk_summary* s) { return s->s.num_successful_steps; }
+int sk_summary_num_unsuccessful_steps(const sk_summary* s) { return s->s.num_unsuccessful_steps; }
+int sk_summary_termination_type(const sk_summary* s) { return s->s.termination_type; }
+const char* sk_summary_message(const sk_summary* s) { return s->s.message.c_str(); }
+const char* sk_summary_brief_report(const sk_summary* s) { return s->s.brief.c_str(); }
+const char* sk_summary_full_report(const sk_summary* s) { return s->s.full.c_str(); }
+int sk_summary_num_logged_iterations(const sk_summary* s) { return (int)s->s.iterations.size(); }
+double sk_summary_iteration_field(const sk_summary* s, int it, int field) {
+  if (it < 0 || it >= (int)s->s.iterations.size()) return NAN;
+  const IterationLog& L = s->s.iterations[it];
+  switch (field) {
+    case 0: return L.cost; case 1: return L.cost_change; case 2: return L.gradient_max_norm; case 3: return L.step_norm;
+    case 4: return L.relative_decrease; case 5: return L.trust_region_radius; case 6: return L.step_is_valid; case 7: return L.step_is_successful;
+  }
+  return NAN;
+}
+double sk_summary_phase_seconds(const sk_summary* s, int phase) { return (phase >= 0 && phase < 7) ? s->s.phase_seconds[phase] : NAN; }
+
+// ---- solve ------------------------------------------------------------------------------
+static std::unique_ptr<SolverBase> make_solver(const Options& o, Problem* p, int* rc) {
+  *rc = SK_OK;
+  if (o.linear_solver_type == SK_DENSE_SCHUR) {
+    std::string why;
+    if (!problem_is_bal_shaped(*p, &why)) { set_error("%s", why.c_str()); *rc = SK_ERR_UNSUPPORTED; return nullptr; }
+    return make_bal_solver(o, p);
+  }
+  return make_dense_solver(o, p);
+}
+
+sk_solver* sk_solver_create(const sk_options* options, sk_problem* problem) {
+  SK_GUARD_BEGIN
+  if (!options || !problem) { set_error("null argument"); return nullptr; }
+  int rc;
+  std::unique_ptr<SolverBase> impl = make_solver(options->o, &problem->p, &rc);
+  if (!impl) return nullptr;
+  rc = impl->create();
+  if (rc) return nullptr;
+  sk_solver* s = new sk_solver();
+  s->impl = std::move(impl);
+  return s;
+  SK_GUARD_END(nullptr)
+}
+void sk_solver_free(sk_solver* s) { delete s; }
+int sk_solver_step(sk_solver* s, int* done) {
+  SK_GUARD_BEGIN
+  bool d = false;
+  const int rc = s->impl->step(&d);
+  if (done) *done = d ? 1 : 0;
+  return rc;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+int sk_solver_finish(sk_solver* s, sk_summary* summary) {
+  SK_GUARD_BEGIN
+  Summary tmp;
+  const int rc = s->impl->finish(&tmp);
+  if (rc == SK_OK && summary) summary->s = tmp;
+  return rc;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+int sk_solver_set_kernel_timing(sk_solver* s, int on) { s->impl->kernel_timer().enable(on != 0); return SK_OK; }
+double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launches) {
+  KernelTimer::Stat st = s->impl->kernel_timer().get_stat(name);
+  if (launches) *launches = st.launches;
+  return st.seconds;
+}
+double sk_solver_syrk_flops_per_solve(const sk_solver* s) { return s->impl->syrk_flops_per_solve(); }
+
+int sk_solve(const sk_options* options, sk_problem* problem, sk_summary* summary) {
+  SK_GUARD_BEGIN
+  sk_solver* s = sk_solver_create(options, problem);
+  if (!s) {
+    // map the recorded reason to a status
+    const std::string e = get_error();
+    if (e.find("no HIP device") != std::string::npos) return SK_ERR_NO_DEVICE;
+    if (e.find("not implemented") != std::string::npos || e.find("implemented for") != std::string::npos || e.find("not supported") != std::string::npos) return SK_ERR_UNSUPPORTED;
+    if (e.find("failed:") != std::string::npos) return SK_ERR_HIP;
+    return SK_ERR_INVALID_ARGUMENT;
+  }
+  int rc = SK_OK, done = 0;
+  while (!done) { rc = sk_solver_step(s, &done); if (rc) break; }
+  if (rc == SK_OK) rc = sk_solver_finish(s, summary);
+  sk_solver_free(s);
+  return rc;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
+int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double* L, int group) {
+  SK_GUARD_BEGIN
+  if (n <= 0 || !A || !b || !x) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
+  if (group <= 0) group = Options().cholesky_group;
+  const int rhs_row = n, npad = ((n + 1 + 127) / 128) * 128;
+  std::vector<double> S((size_t)npad * npad, 0.0);
+  for (int i = 0; i < n; ++i) std::memcpy(&S[(size_t)i * npad], A + (size_t)i * n, (size_t)(i + 1) * sizeof(double));
+  std::memcpy(&S[(size_t)rhs_row * npad], b, (size_t)n * sizeof(double));
+  S[(size_t)rhs_row * npad + rhs_row] = 1e300;
+  for (int j = n + 1; j < npad; ++j) S[(size_t)j * npad + j] = 1.0;
+  DevBuf<double> dS, dLinv, dy; DevBuf<int> dinfo;
+  hipStream_t s = nullptr;
+  SK_HIP_TRY(dS.upload(S, s)); SK_HIP_TRY(dLinv.alloc((size_t)npad * 128)); SK_HIP_TRY(dLinv.zero(s));
+  SK_HIP_TRY(dy.alloc(npad)); SK_HIP_TRY(dinfo.alloc(1)); SK_HIP_TRY(dinfo.zero(s));
+  SK_HIP_TRY(cholesky_init());
+  cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, nullptr);
+  cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dy.p, s, nullptr);
+  SK_HIP_TRY(hipStreamSynchronize(s));
+  int info = 0;
+  SK_HIP_TRY(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (info) { set_error("matrix is not positive definite"); return SK_ERR_EVALUATION_FAILED; }
+  std::vector<double> y(npad);
+  SK_HIP_TRY(hipMemcpy(y.data(), dy.p, npad * sizeof(double), hipMemcpyDeviceToHost));
+  std::memcpy(x, y.data(), (size_t)n * sizeof(double));
+  if (L) {
+    SK_HIP_TRY(hipMemcpy(S.data(), dS.p, S.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) L[(size_t)i * n + j] = j <= i ? S[(size_t)i * npad + j] : 0.0;
+  }
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// Dense fp64 Cholesky on gfx950 matrix cores — host entry points (chol_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace sk {
+
+// HIP-event timing of named kernel launches on the stream they run on.
+// Off by default; bench.py switches it on to measure the dominant kernel's
+// average launch duration live (roofline.achieved).
+class KernelTimer {
+ public:
+  struct Stat { double seconds = 0.0; int launches = 0; };
+  void enable(bool on) { enabled_ = on; }
+  bool enabled() const { return enabled_; }
+  void begin(const char* name, hipStream_t s) {
+    if (!enabled_) return;
+    hipEvent_t e = get();
+    hipEventRecord(e, s);
+    pending_.push_back({name, e, nullptr});
+  }
+  void end(const char* name, hipStream_t s) {
+    if (!enabled_ || pending_.empty()) return;
+    hipEvent_t e = get();
+    hipEventRecord(e, s);
+    pending_.back().stop = e;
+    (void)name;
+  }
+  // Resolve everything recorded so far (blocks until the events have completed).
+  void collect() {
+    for (auto& p : pending_) {
+      if (!p.stop) { free_.push_back(p.start); continue; }
+      hipEventSynchronize(p.stop);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+        Stat& st = stats_[p.name];
+        st.seconds += 1e-3 * ms;
+        st.launches += 1;
+      }
+      free_.push_back(p.start);
+      free_.push_back(p.stop);
+    }
+    pending_.clear();
+  }
+  Stat get_stat(const std::string& name) {
+    collect();
+    auto it = stats_.find(name);
+    return it == stats_.end() ? Stat() : it->second;
+  }
+  void reset() { collect(); stats_.clear(); }
+  ~KernelTimer() {
+    collect();
+    for (hipEvent_t e : free_) hipEventDestroy(e);
+  }
+
+ private:
+  struct Pending { std::string name; hipEvent_t start, stop; };
+  hipEvent_t get() {
+    if (!free_.empty()) { hipEvent_t e = free_.back(); free_.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+  bool enabled_ = false;
+  std::vector<Pending> pending_;
+  std::vector<hipEvent_t> free_;
+  std::map<std::string, Stat> stats_;
+};
+
+hipError_t cholesky_init();
+size_t potrf128_lds_bytes();
+// Factor the lower triangle of S (npad x ld, npad % 128 == 0) in place.
+// Linv: (npad/128) blocks of 128x128, zero-initialised once by the caller.
+void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, KernelTimer* kt);
+void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* y, hipStream_t s,
+                        KernelTimer* kt);
+double cholesky_syrk_flops(int npad, int group);
+
+}  // namespace sk

@@ -1,0 +1,137 @@
+// Shared host-side helpers: error reporting across the C ABI, device buffers,
+// and the host mirror of Problem / CostFunction / Options / Summary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/skeres_amd.h"
+#include "functors.hpp"
+
+namespace sk {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define SK_HIP_TRY(expr)                                                                 \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      sk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return SK_ERR_HIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  bool owned = true;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p && owned) (void)hipFree(p);
+    p = nullptr; n = 0; owned = true;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+  }
+  void adopt(T* ext, size_t count) { release(); p = ext; n = count; owned = false; }
+  hipError_t upload(const std::vector<T>& h, hipStream_t s) {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+  hipError_t zero(hipStream_t s) { return n ? hipMemsetAsync(p, 0, n * sizeof(T), s) : hipSuccess; }
+};
+
+// ---- host mirror of the reference objects ----------------------------------
+struct CostFunction {  // com.google.ceres.CostFunction as sized by CORE/SizedCostFunction.scala
+  int functor_id = 0;
+  std::vector<double> consts;
+  sk_evaluate_fn callback = nullptr;
+  void* user = nullptr;
+  int num_residuals = 0;
+  std::vector<int> block_sizes;
+};
+
+struct LossFunction { int kind = 0; };  // 0 == trivial
+
+struct Problem {  // CeresProblem; parameter blocks identified by pointer value
+  std::unordered_map<double*, int> block_of;
+  std::vector<double*> block_ptr;
+  std::vector<int> block_size;
+  // residual blocks (compact form)
+  std::vector<int> rb_functor;
+  std::vector<int> rb_num_residuals;
+  std::vector<size_t> rb_const_off;
+  std::vector<size_t> rb_pidx_off;  // size = blocks + 1
+  std::vector<int> rb_pidx;
+  std::vector<double> consts;
+  std::vector<const CostFunction*> rb_cost;  // non-null only for host-callback blocks
+  long num_residuals = 0;
+  bool has_callbacks = false;
+  Problem() { rb_pidx_off.push_back(0); }
+  int num_parameters() const { long s = 0; for (int b : block_size) s += b; return (int)s; }
+};
+
+struct Options {  // Solver.Options; Ceres 1.x defaults
+  int linear_solver_type = SK_DENSE_QR;  // ceres default is SPARSE_NORMAL_CHOLESKY when built with a sparse backend, else DENSE_QR
+  int minimizer_type = SK_TRUST_REGION;
+  int max_num_iterations = 50;
+  bool progress_to_stdout = false;
+  double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  double initial_trust_region_radius = 1e4, max_trust_region_radius = 1e16, min_trust_region_radius = 1e-32;
+  double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
+  bool jacobi_scaling = true;
+  int max_num_consecutive_invalid_steps = 5;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool stream_set = false;
+  int rank = 0, world = 1;
+  sk_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  void* reduce_buffer = nullptr;
+  size_t reduce_buffer_bytes = 0;
+  int cholesky_group = 4;  // SYRK K = group * 128
+};
+
+struct IterationLog {
+  int iteration = 0;
+  double cost = 0, cost_change = 0, gradient_max_norm = 0, step_norm = 0, relative_decrease = 0,
+         trust_region_radius = 0, iter_time = 0, total_time = 0;
+  int step_is_valid = 1, step_is_successful = 1;
+};
+
+struct Summary {
+  double initial_cost = 0, final_cost = 0;
+  int num_successful_steps = 0, num_unsuccessful_steps = 0;
+  int termination_type = SK_NO_CONVERGENCE;
+  std::string message;
+  std::vector<IterationLog> iterations;
+  double phase_seconds[7] = {0, 0, 0, 0, 0, 0, 0};
+  // problem / solver description for the reports
+  int num_parameter_blocks = 0, num_parameters = 0, num_residual_blocks = 0;
+  long num_residuals = 0;
+  int linear_solver_type = 0;
+  int num_e_blocks = 0, num_f_blocks = 0;
+  int world = 1;
+  std::string device_name;
+  std::string brief, full;
+  void build_reports();
+};
+
+const char* linear_solver_name(int t);
+const char* termination_name(int t);
+
+}  // namespace sk

@@ -1,0 +1,278 @@
+// HIP kernels for the generic (dense Jacobian) path: any mix of registered
+// device functors over arbitrary parameter blocks, DENSE_QR or
+// DENSE_NORMAL_CHOLESKY  (EX/CurveFitting.scala:100-133, EX/Powell.scala:55-91).
+// J is row-major m x n in HBM with the Jacobi column scaling folded in.
+#include <hip/hip_runtime.h>
+#include "dense_kernels.hpp"
+#include "functors.hpp"
+
+namespace sk {
+
+// One lane per residual block of functor F.  Mirrors
+// AutoDiffCostFunction.evaluate (CORE/AutodiffCostFunction.scala:74-134):
+// cost-only with T = double, else T = Jet<sum N(i)> seeded in block order.
+template <class F, bool kJac>
+__global__ void dense_eval_kernel(DenseEvalArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.count) return;
+  const int b = a.blocks[i];
+  const double* c = a.consts + a.const_off[b];
+  const int* pidx = a.pidx + a.pidx_off[b];
+  const int row0 = a.res_off[b];
+  if (!kJac) {
+    double store[F::kDim];
+    const double* params[F::kBlocks];
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < F::kBlocks; ++q) {
+      params[q] = &store[k];
+      const double* src = a.x + pidx[q];
+      for (int j = 0; j < F::N(q); ++j) store[k++] = src[j];
+    }
+    double out[F::kRes];
+    if (!F::template apply<double>(c, params, out)) { *a.fail_flag = 1; return; }
+#pragma unroll
+    for (int r = 0; r < F::kRes; ++r) a.r[row0 + r] = out[r];
+  } else {
+    typedef Jet<F::kDim> J;
+    J store[F::kDim];
+    const J* params[F::kBlocks];
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < F::kBlocks; ++q) {
+      params[q] = &store[k];
+      const double* src = a.x + pidx[q];
+      for (int j = 0; j < F::N(q); ++j) { store[k] = J(src[j], k); ++k; }
+    }
+    J out[F::kRes];
+    if (!F::template apply<J>(c, params, out)) { *a.fail_flag = 1; return; }
+#pragma unroll
+    for (int r = 0; r < F::kRes; ++r) a.r[row0 + r] = out[r].a;
+    k = 0;
+#pragma unroll
+    for (int q = 0; q < F::kBlocks; ++q) {
+      const int off = pidx[q];
+      for (int j = 0; j < F::N(q); ++j, ++k)
+#pragma unroll
+        for (int r = 0; r < F::kRes; ++r) a.J[(size_t)(row0 + r) * a.n + off + j] = out[r].v[k] * a.scale[off + j];
+    }
+  }
+}
+
+void launch_dense_eval(int functor_id, bool jac, const DenseEvalArgs& a, hipStream_t s) {
+  if (a.count <= 0) return;
+  const dim3 g((a.count + 127) / 128), b(128);
+#define SK_LAUNCH(F)                                                             \
+  do {                                                                           \
+    if (jac) hipLaunchKernelGGL((dense_eval_kernel<F, true>), g, b, 0, s, a);    \
+    else hipLaunchKernelGGL((dense_eval_kernel<F, false>), g, b, 0, s, a);       \
+  } while (0)
+  SK_DISPATCH_FUNCTOR(functor_id, SK_LAUNCH)
+#undef SK_LAUNCH
+}
+
+// Single residual block (sk_cost_function_evaluate): parameters / outputs are
+// small flat device buffers.  jac_mask bit q set => write block q's Jacobian
+// (row-major kRes x N(q)) at jac + jac_off[q].
+template <class F>
+__global__ void single_eval_kernel(const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
+                                   const int* jac_off, int want_jac, unsigned jac_mask, int* ok) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!want_jac) {
+    const double* params[F::kBlocks];
+    for (int q = 0; q < F::kBlocks; ++q) params[q] = x + x_off[q];
+    double out[F::kRes];
+    const bool good = F::template apply<double>(consts, params, out);
+    *ok = good ? 1 : 0;
+    if (good) for (int r = 0; r < F::kRes; ++r) residuals[r] = out[r];
+    return;
+  }
+  typedef Jet<F::kDim> J;
+  J store[F::kDim];
+  const J* params[F::kBlocks];
+  int k = 0;
+  for (int q = 0; q < F::kBlocks; ++q) {
+    params[q] = &store[k];
+    for (int j = 0; j < F::N(q); ++j) { store[k] = J(x[x_off[q] + j], k); ++k; }
+  }
+  J out[F::kRes];
+  const bool good = F::template apply<J>(consts, params, out);
+  *ok = good ? 1 : 0;
+  if (!good) return;
+  for (int r = 0; r < F::kRes; ++r) residuals[r] = out[r].a;
+  int off = 0;
+  for (int q = 0; q < F::kBlocks; ++q) {
+    const int nq = F::N(q);
+    if ((jac_mask >> q) & 1u) {
+      int col = 0;
+      for (int r = 0; r < F::kRes; ++r)
+        for (int p = 0; p < nq; ++p) jac[jac_off[q] + col++] = out[r].v[off + p];
+    }
+    off += nq;
+  }
+}
+
+void launch_single_eval(int functor_id, const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
+                        const int* jac_off, int want_jac, unsigned jac_mask, int* ok, hipStream_t s) {
+#define SK_LAUNCH(F) hipLaunchKernelGGL((single_eval_kernel<F>), dim3(1), dim3(64), 0, s, consts, x, x_off, residuals, jac, jac_off, want_jac, jac_mask, ok)
+  SK_DISPATCH_FUNCTOR(functor_id, SK_LAUNCH)
+#undef SK_LAUNCH
+}
+
+// colsq_j = sum_i J_ij^2 ; gs_j = sum_i J_ij r_i   (lane j: coalesced rows)
+__global__ void dense_col_reduce_kernel(const double* J, const double* r, int m, int n, double* colsq, double* gs) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double sq = 0.0, g = 0.0;
+  for (int i = 0; i < m; ++i) { const double v = J[(size_t)i * n + j]; sq += v * v; g += v * r[i]; }
+  colsq[j] = sq; gs[j] = g;
+}
+__global__ void dense_scale_kernel(double* J, const double* scale, int m, int n) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (size_t)m * n) J[e] *= scale[e % n];
+}
+// 0.5 * sum r^2 partials and friends -----------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_sumsq_kernel(const double* r, int m, double* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < m; i += 256) s += r[i] * r[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+// H (n_pad x ld, lower) = J^T J ; rhs row = J^T r.  Small-n form: one lane per (a, b <= a).
+__global__ void dense_normal_kernel(const double* J, const double* r, int m, int n, double* H, int ld, int rhs_row) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * (n + 1)) return;
+  const int a = e / (n + 1), b = e % (n + 1);
+  if (b == n) {  // rhs
+    double s = 0.0;
+    for (int i = 0; i < m; ++i) s += J[(size_t)i * n + a] * r[i];
+    H[(size_t)rhs_row * ld + a] = s;
+  } else if (b <= a) {
+    double s = 0.0;
+    for (int i = 0; i < m; ++i) s += J[(size_t)i * n + a] * J[(size_t)i * n + b];
+    H[(size_t)a * ld + b] = s;
+  }
+}
+// step = -y ; x_new = x + step*scale ; out[0] = |x - x_new|^2
+__global__ __launch_bounds__(256) void dense_step_kernel(const double* y, const double* scale, const double* x, double* step, double* x_new,
+                                                         int n, double* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const double st = -y[j];
+    step[j] = st;
+    const double xn = x[j] + st * scale[j];
+    x_new[j] = xn;
+    const double d = x[j] - xn;
+    s += d * d;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+// out[0] = sum_i m_i (r_i + m_i / 2),  m = J step
+__global__ __launch_bounds__(256) void dense_model_kernel(const double* J, const double* r, const double* step, int m, int n, double* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < m; i += 256) {
+    double mr = 0.0;
+    for (int j = 0; j < n; ++j) mr += J[(size_t)i * n + j] * step[j];
+    s += mr * (r[i] + mr / 2.0);
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+// out[0] = max_j |gs_j / scale_j| ; out[1] = |x|^2
+__global__ __launch_bounds__(256) void dense_gmax_kernel(const double* gs, const double* scale, const double* x, int n, double* out) {
+  __shared__ double shm[256], shs[256];
+  double mx = 0.0, s = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) { mx = fmax(mx, fabs(gs[j] / scale[j])); s += x[j] * x[j]; }
+  shm[threadIdx.x] = mx; shs[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) { shm[threadIdx.x] = fmax(shm[threadIdx.x], shm[threadIdx.x + w]); shs[threadIdx.x] += shs[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = shm[0]; out[1] = shs[0]; }
+}
+
+// ---------------------------------------------------------------------------
+// DENSE_QR: Householder QR of the augmented system [J ; diag(D)] y = [r ; 0]
+// (what Ceres' DenseQRSolver hands to Eigen), one workgroup, A column-major
+// rows x n in HBM, b = rhs (length rows).  y[0..n) on exit; *ok = 0 on a zero pivot.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_reduce_sum(double v, double* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = blockDim.x / 2; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  const double out = sh[0];
+  __syncthreads();
+  return out;
+}
+__global__ __launch_bounds__(256) void dense_qr_build_kernel(const double* J, const double* r, const double* D, int m, int n, double* A, double* b) {
+  const int rows = m + n;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < (size_t)rows * n; e += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e / rows), i = (int)(e % rows);
+    A[e] = i < m ? J[(size_t)i * n + j] : (i - m == j ? D[j] : 0.0);
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) b[i] = i < m ? r[i] : 0.0;
+}
+__global__ __launch_bounds__(256) void dense_qr_solve_kernel(double* A, double* b, int rows, int n, double* y, int* ok) {
+  __shared__ double sh[256];
+  const int t = threadIdx.x;
+  for (int k = 0; k < n; ++k) {
+    double* a = A + (size_t)k * rows;
+    double s = 0.0;
+    for (int i = k + t; i < rows; i += 256) s += a[i] * a[i];
+    const double norm = sqrt(block_reduce_sum(s, sh));
+    if (norm == 0.0) { if (t == 0) *ok = 0; return; }
+    const double akk = a[k];
+    const double alpha = akk > 0.0 ? -norm : norm;
+    const double v0 = akk - alpha;
+    // |v|^2 = norm^2 - akk^2 + v0^2
+    const double vnorm2 = (norm * norm - akk * akk) + v0 * v0;
+    __syncthreads();
+    if (vnorm2 != 0.0) {
+      // apply H = I - 2 v v^T / |v|^2 to the remaining columns and to b; v = (v0, a[k+1..])
+      for (int j = k + 1; j <= n; ++j) {
+        double* c = j < n ? A + (size_t)j * rows : b;
+        double dot = 0.0;
+        for (int i = k + t; i < rows; i += 256) dot += (i == k ? v0 : a[i]) * c[i];
+        const double f = 2.0 * block_reduce_sum(dot, sh) / vnorm2;
+        for (int i = k + t; i < rows; i += 256) c[i] -= f * (i == k ? v0 : a[i]);
+        __syncthreads();
+      }
+    }
+    if (t == 0) a[k] = alpha;  // R_kk (the rest of the column is the reflector and is not needed again)
+    __syncthreads();
+  }
+  if (t == 0) {
+    for (int k = n - 1; k >= 0; --k) {
+      double s = b[k];
+      for (int j = k + 1; j < n; ++j) s -= A[(size_t)j * rows + k] * y[j];
+      const double d = A[(size_t)k * rows + k];
+      if (d == 0.0) { *ok = 0; return; }
+      y[k] = s / d;
+    }
+  }
+}
+
+void launch_dense_col_reduce(const double* J, const double* r, int m, int n, double* colsq, double* gs, hipStream_t s) { hipLaunchKernelGGL(dense_col_reduce_kernel, dim3((n + 127) / 128), dim3(128), 0, s, J, r, m, n, colsq, gs); }
+void launch_dense_scale(double* J, const double* scale, int m, int n, hipStream_t s) { const size_t e = (size_t)m * n; hipLaunchKernelGGL(dense_scale_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, s, J, scale, m, n); }
+void launch_dense_sumsq(const double* r, int m, double* out, hipStream_t s) { hipLaunchKernelGGL(dense_sumsq_kernel, dim3(1), dim3(256), 0, s, r, m, out); }
+void launch_dense_normal(const double* J, const double* r, int m, int n, double* H, int ld, int rhs_row, hipStream_t s) { const int e = n * (n + 1); hipLaunchKernelGGL(dense_normal_kernel, dim3((e + 255) / 256), dim3(256), 0, s, J, r, m, n, H, ld, rhs_row); }
+void launch_dense_step(const double* y, const double* scale, const double* x, double* step, double* x_new, int n, double* out, hipStream_t s) { hipLaunchKernelGGL(dense_step_kernel, dim3(1), dim3(256), 0, s, y, scale, x, step, x_new, n, out); }
+void launch_dense_model(const double* J, const double* r, const double* step, int m, int n, double* out, hipStream_t s) { hipLaunchKernelGGL(dense_model_kernel, dim3(1), dim3(256), 0, s, J, r, step, m, n, out); }
+void launch_dense_gmax(const double* gs, const double* scale, const double* x, int n, double* out, hipStream_t s) { hipLaunchKernelGGL(dense_gmax_kernel, dim3(1), dim3(256), 0, s, gs, scale, x, n, out); }
+void launch_dense_qr(const double* J, const double* r, const double* D, int m, int n, double* A, double* b, double* y, int* ok, hipStream_t s) {
+  hipLaunchKernelGGL(dense_qr_build_kernel, dim3(64), dim3(256), 0, s, J, r, D, m, n, A, b);
+  hipLaunchKernelGGL(dense_qr_solve_kernel, dim3(1), dim3(256), 0, s, A, b, m + n, n, y, ok);
+}
+
+}  // namespace sk

@@ -1,0 +1,35 @@
+// Launchers of dense_kernels.hip (generic dense-Jacobian path).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sk {
+
+struct DenseEvalArgs {
+  int count;              // residual blocks of this functor
+  const int* blocks;      // [count] residual block ids
+  const double* consts;   // all constants
+  const size_t* const_off;  // [num blocks]
+  const int* pidx;        // x offsets of the parameter blocks, flattened
+  const size_t* pidx_off;   // [num blocks]
+  const int* res_off;     // first residual row of each block
+  const double* x;        // parameters
+  const double* scale;    // Jacobi column scaling
+  double* r;              // [m]
+  double* J;              // [m][n]
+  int n;
+  int* fail_flag;
+};
+
+void launch_dense_eval(int functor_id, bool jac, const DenseEvalArgs& a, hipStream_t s);
+void launch_single_eval(int functor_id, const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
+                        const int* jac_off, int want_jac, unsigned jac_mask, int* ok, hipStream_t s);
+void launch_dense_col_reduce(const double* J, const double* r, int m, int n, double* colsq, double* gs, hipStream_t s);
+void launch_dense_scale(double* J, const double* scale, int m, int n, hipStream_t s);
+void launch_dense_sumsq(const double* r, int m, double* out, hipStream_t s);
+void launch_dense_normal(const double* J, const double* r, int m, int n, double* H, int ld, int rhs_row, hipStream_t s);
+void launch_dense_step(const double* y, const double* scale, const double* x, double* step, double* x_new, int n, double* out, hipStream_t s);
+void launch_dense_model(const double* J, const double* r, const double* step, int m, int n, double* out, hipStream_t s);
+void launch_dense_gmax(const double* gs, const double* scale, const double* x, int n, double* out, hipStream_t s);
+void launch_dense_qr(const double* J, const double* r, const double* D, int m, int n, double* A, double* b, double* y, int* ok, hipStream_t s);
+
+}  // namespace sk

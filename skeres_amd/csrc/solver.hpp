@@ -1,0 +1,66 @@
+// Trust-region Levenberg-Marquardt driver (host) over device linear algebra.
+// Restates the loop native Ceres [ext] runs behind `ceres.solve`
+// (EX/SimpleBundleAdjuster.scala:152, EX/CurveFitting.scala:127); constants and
+// update rules as published for Ceres 1.x.  Only a
+// handful of scalars cross PCIe per iteration.
+#pragma once
+#include <chrono>
+#include <memory>
+
+#include "chol_kernels.hpp"
+#include "common.hpp"
+
+namespace sk {
+
+class SolverBase {
+ public:
+  SolverBase(const Options& o, Problem* p) : opt_(o), problem_(p) {}
+  virtual ~SolverBase();
+  int create();                 // device setup + iteration 0
+  int step(bool* done);         // one trust-region iteration
+  int finish(Summary* s);       // parameters back to caller memory + summary
+  KernelTimer& kernel_timer() { return kt_; }
+  virtual double syrk_flops_per_solve() const { return 0.0; }
+
+ protected:
+  // --- representation-specific pieces -------------------------------------
+  virtual int setup() = 0;                        // build device structures, upload x
+  virtual int evaluate_with_jacobian(bool first) = 0;  // at current x: cost_, gmax_, xnorm_
+  // D from radius, solve, candidate point, candidate cost:
+  virtual int try_step(double radius, bool* valid, double* model_cost_change, double* new_cost, double* step_norm) = 0;
+  virtual void accept_candidate() = 0;            // x <- candidate (pointer swap)
+  virtual int write_back() = 0;                   // device x -> caller memory
+  virtual void describe(Summary* s) = 0;
+
+  int init_device();
+  double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); }
+  void log_iteration(int it, double cost_change, double step_norm, double rho, int valid, int success, double iter_time);
+  int allreduce(double* dev, size_t count);
+
+  Options opt_;
+  Problem* problem_;
+  hipStream_t stream_ = nullptr;
+  bool own_stream_ = false;
+  KernelTimer kt_;
+  // phase timing (HIP events on stream_)
+  enum { kEvBegin = 0, kEvJac, kEvAssemble, kEvChol, kEvBacksub, kEvCost, kEvCount };
+  hipEvent_t ev_[16] = {};
+  double phase_[7] = {0, 0, 0, 0, 0, 0, 0};
+  // LM state
+  double cost_ = 0, gmax_ = 0, xnorm_ = 0;
+  double radius_ = 0, decrease_factor_ = 2.0;
+  int iteration_ = 0, invalid_ = 0, n_success_ = 0, n_unsuccess_ = 0;
+  bool terminated_ = false;
+  Summary sum_;
+  std::chrono::steady_clock::time_point t0_;
+  std::string device_name_;
+};
+
+// BAL-shaped problems (2 residuals, one 9-block + one 3-block per residual
+// block): Schur elimination of the 3-blocks + dense Cholesky of the reduced system.
+std::unique_ptr<SolverBase> make_bal_solver(const Options& o, Problem* p);
+bool problem_is_bal_shaped(const Problem& p, std::string* why_not);
+// Generic dense Jacobian path: DENSE_QR / DENSE_NORMAL_CHOLESKY.
+std::unique_ptr<SolverBase> make_dense_solver(const Options& o, Problem* p);
+
+}  // namespace sk

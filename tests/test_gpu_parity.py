@@ -1,0 +1,323 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Tolerances (fp64):
+  * evaluate step vs the reference's known-answer values: exact
+  * Snavely residuals / Jacobians GPU vs oracle: <= 1e-12 relative (sin/cos/division
+    on the GPU are not bit-identical to glibc, everything else is the same formula)
+  * per-iteration cost, first 5 iterations: <= 1e-10 relative; final cost <= 1e-9
+  * iteration count equal +-1; final parameters compared through cost and
+    reprojection RMS (bundle adjustment has gauge freedom)
+"""
+import numpy as np
+import pytest
+
+import oracle
+import skeres_amd as sk
+from skeres_amd import bal
+from helpers import bal_problem_to_sk, solve_bal_gpu, curve_fitting_data
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built):
+    if sk.device_count() < 1:
+        pytest.fail("GPU tests need a HIP device: libskeres_amd has no CPU fallback")
+
+
+# ---------------------------------------------------------------------------
+# AutodiffCostFuntionSpec.scala, re-stated against the device functors
+# ---------------------------------------------------------------------------
+def _matrix(rows):
+    m = sk.RichDoubleMatrix.ofSize(len(rows), len(rows[0]))
+    for i, r in enumerate(rows):
+        for j, v in enumerate(r):
+            m.set(i, j, v)
+    return m
+
+
+def test_bilinear_scalar_cost_function():
+    # core/src/test/scala/.../AutodiffCostFuntionSpec.scala:13-52
+    parameters = _matrix([[1.0, 2.0], [3.0, 4.0]])
+    residuals = sk.DoubleArray(1)
+    costFunction = sk.BinaryScalarCost(1.0).toAutoDiffCostFunction()
+    assert costFunction.evaluate(parameters, residuals, None) is True
+    assert residuals.get(0) == 10.0
+    residuals.set(0, 0.0)
+    jacobians = sk.RichDoubleMatrix.ofSize(2, 2)
+    assert costFunction.evaluate(parameters, residuals, jacobians) is True
+    assert residuals.get(0) == 10.0
+    assert [jacobians.get(0, 0), jacobians.get(0, 1)] == [3, 4]
+    assert [jacobians.get(1, 0), jacobians.get(1, 1)] == [1, 2]
+
+
+def test_bilinear_vector_cost_function():
+    # AutodiffCostFuntionSpec.scala:54-109
+    parameters = _matrix([[1.0, 2.0], [3.0, 4.0]])
+    residuals = sk.DoubleArray(3)
+    costFunction = sk.BinaryVector3Cost(1.0).toAutoDiffCostFunction()
+    assert costFunction.evaluate(parameters, residuals, None) is True
+    assert list(residuals.toArray(3)) == [10.0, -4.0, 24.0]
+    residuals.copyFrom([0.0, 0.0, 0.0])
+    jacobians = sk.RichDoubleMatrix.ofSize(2, 6)
+    assert costFunction.evaluate(parameters, residuals, jacobians) is True
+    assert list(residuals.toArray(3)) == [10.0, -4.0, 24.0]
+    assert list(jacobians.getRow(0).toArray(6)) == [3, 4, 3, -4, 2, 1]
+    assert list(jacobians.getRow(1).toArray(6)) == [1, 2, 1, -2, 4, 3]
+
+
+def test_many_parameter_blocks_and_null_rows():
+    # AutodiffCostFuntionSpec.scala:110-139 (+ the null-row branch of AutodiffCostFunction.scala:118)
+    parameters = _matrix([[float(i)] for i in range(10)])
+    residuals = sk.DoubleArray(1)
+    costFunction = sk.TenParameterCost().toAutoDiffCostFunction()
+    assert costFunction.evaluate(parameters, residuals, None) is True
+    assert residuals.get(0) == 45.0
+    jacobians = sk.RichDoubleMatrix.ofSize(10, 1)
+    assert costFunction.evaluate(parameters, residuals, jacobians) is True
+    assert all(jacobians.get(i, 0) == 1.0 for i in range(10))
+    sparse = sk.RichDoubleMatrix([sk.DoubleArray(1) if i % 2 == 0 else None for i in range(10)])
+    for i in range(0, 10, 2):
+        sparse.set(i, 0, -7.0)
+    assert costFunction.evaluate(parameters, residuals, sparse) is True
+    assert all(sparse.get(i, 0) == 1.0 for i in range(0, 10, 2))
+
+
+def test_snavely_single_block_vs_oracle():
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        cam = np.concatenate([rng.normal(0, 0.3, 3), rng.normal(0, 1, 3), [rng.uniform(400, 1200)],
+                              [rng.normal(0, 1e-6)], [rng.normal(0, 1e-11)]])
+        if trial == 0:
+            cam[:3] = 0.0  # exercises the small-angle branch (Rotation.scala:493-521)
+        if trial == 1:
+            cam[:3] = [1e-9, -2e-9, 3e-9]
+        pt = rng.normal(0, 1, 3) + [0, 0, -5]
+        obs = rng.normal(0, 100, 2)
+        ok, r_o, j_o = oracle.evaluate(oracle.SNAVELY, obs, [cam, pt])
+        cf = sk.SnavelyReprojectionError(obs[0], obs[1]).toAutoDiffCostFunction()
+        parameters = sk.RichDoubleMatrix.fromArrays(cam, pt)
+        residuals = sk.DoubleArray(2)
+        jac = sk.RichDoubleMatrix([sk.DoubleArray(18), sk.DoubleArray(6)])
+        assert cf.evaluate(parameters, residuals, jac)
+        np.testing.assert_allclose(residuals.toArray(2), r_o, rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(jac.getRow(0).toArray(18).reshape(2, 9), j_o[0], rtol=1e-11, atol=1e-9)
+        np.testing.assert_allclose(jac.getRow(1).toArray(6).reshape(2, 3), j_o[1], rtol=1e-11, atol=1e-9)
+        res2 = sk.DoubleArray(2)
+        assert cf.evaluate(parameters, res2, None)  # cost-only branch returns the same residuals
+        np.testing.assert_allclose(res2.toArray(2), r_o, rtol=1e-12, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------
+# dense fp64 MFMA Cholesky
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,group", [(5, 4), (127, 4), (128, 4), (300, 1), (300, 4), (700, 2), (1100, 4), (1500, 3)])
+def test_cholesky_solve_vs_numpy(n, group):
+    rng = np.random.default_rng(n)
+    G = rng.normal(size=(n, n + 20))
+    A = G @ G.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    x, L = sk.api.cholesky_solve(A, b, want_L=True, group=group)
+    Lref = np.linalg.cholesky(A)
+    np.testing.assert_allclose(L, Lref, rtol=1e-10, atol=1e-10 * np.abs(Lref).max())
+    np.testing.assert_allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+
+
+def test_cholesky_mfma_layout_asymmetric():
+    # A = L0 L0^T with an asymmetric integer-valued L0: a swapped row/col map in the
+    # MFMA C/D layout cannot reproduce L0.
+    n = 260
+    L0 = np.tril(((np.arange(n)[:, None] * 7 + np.arange(n)[None, :] * 3) % 5).astype(float))
+    L0[np.arange(n), np.arange(n)] = 10.0 + (np.arange(n) % 3)
+    A = L0 @ L0.T
+    x, L = sk.api.cholesky_solve(A, np.ones(n), want_L=True)
+    np.testing.assert_allclose(L, L0, rtol=0, atol=1e-9)
+
+
+def test_cholesky_rejects_indefinite():
+    A = np.eye(200)
+    A[150, 150] = -1.0
+    with pytest.raises(sk.SkeresError):
+        sk.api.cholesky_solve(A, np.ones(200))
+
+
+# ---------------------------------------------------------------------------
+# full solves vs the oracle
+# ---------------------------------------------------------------------------
+def _reproj_rms(prob, x):
+    r, _, _, _ = oracle.bal_evaluate(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index,
+                                     prob.observations, x, jacobians=False)
+    return np.sqrt(np.mean(r * r))
+
+
+def _check_against_oracle(prob, summary, x_gpu, so, x_cpu):
+    g = [it["cost"] for it in summary.iterations()]
+    c = so.costs()
+    assert abs(len(g) - len(c)) <= 1, (len(g), len(c))
+    for k in range(min(5, len(g), len(c))):
+        assert abs(g[k] - c[k]) <= 1e-10 * abs(c[k]), (k, g[k], c[k])
+    assert abs(summary.finalCost() - so.final_cost) <= 1e-9 * so.final_cost
+    assert summary.terminationType() == so.termination_type
+    assert abs(_reproj_rms(prob, x_gpu) - _reproj_rms(prob, x_cpu)) <= 1e-7
+
+
+@pytest.mark.parametrize("C,P,N,seed", [(6, 40, 200, 1), (16, 600, 2600, 11), (49, 7776, 31843, 49), (150, 3000, 14000, 5)])
+def test_bal_dense_schur_vs_oracle(C, P, N, seed):
+    prob = bal.generate(C, P, N, seed=seed)
+    x_gpu, summary = solve_bal_gpu(prob)
+    x_cpu, so = oracle.solve_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=4))
+    _check_against_oracle(prob, summary, x_gpu, so, x_cpu)
+    assert summary.numIterations() >= 3
+
+
+def test_bal_iteration_log_fields_vs_oracle():
+    prob = bal.generate(20, 500, 2400, seed=21, perturb=(3e-2, 3e-1, 3e-1))
+    _, summary = solve_bal_gpu(prob)
+    _, so = oracle.solve_bal(20, 500, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                             oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR))
+    its = summary.iterations()
+    for k in range(min(4, len(its), so.num_logged)):
+        o = so.iterations[k]
+        assert abs(its[k]["gradient_max_norm"] - o.gradient_max_norm) <= 1e-8 * max(1.0, o.gradient_max_norm)
+        assert abs(its[k]["step_norm"] - o.step_norm) <= 1e-7 * max(1.0, o.step_norm)
+        assert abs(its[k]["trust_region_radius"] - o.trust_region_radius) <= 1e-7 * o.trust_region_radius
+        assert int(its[k]["step_is_successful"]) == o.step_is_successful
+
+
+def test_bal_individual_add_residual_block_and_in_place_update():
+    # the literal loop of EX/SimpleBundleAdjuster.scala:139-145 (one addResidualBlock per observation)
+    prob = bal.generate(5, 30, 130, seed=2)
+    params = sk.RichDoubleArray.fromArray(prob.parameters)
+    cameras, points = params, params.slice(9 * prob.num_cameras)
+    problem = sk.Problem()
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    for i in range(prob.num_observations):
+        cost = sk.SnavelyReprojectionError(*prob.observations[i]).toAutoDiffCostFunction()
+        problem.addResidualBlock(cost, loss, cameras.slice(9 * int(prob.camera_index[i])),
+                                 points.slice(3 * int(prob.point_index[i])))
+    assert problem.numResidualBlocks() == 130 and problem.numParameterBlocks() == 35
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    x_cpu, so = oracle.solve_bal(5, 30, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR))
+    assert abs(summary.finalCost() - so.final_cost) <= 1e-9 * so.final_cost
+    assert not np.array_equal(params.toArray(prob.num_parameters), prob.parameters)  # updated in place
+    assert "DENSE_SCHUR" in summary.fullReport() and "Final cost" in summary.briefReport()
+
+
+def _curve_fitting_blocks():
+    return [(oracle.EXPONENTIAL, [x, y], [0, 1]) for x, y in curve_fitting_data()]
+
+
+@pytest.mark.parametrize("solver", ["DENSE_QR", "DENSE_NORMAL_CHOLESKY"])
+def test_curve_fitting_vs_oracle(solver):
+    # EX/CurveFitting.scala:100-133
+    m, c = sk.DoubleArray(1), sk.DoubleArray(1)
+    m.set(0, 0.0)
+    c.set(0, 0.0)
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    problem = sk.Problem()
+    for x, y in curve_fitting_data():
+        problem.addResidualBlock(sk.ExponentialResidual(x, y).toAutoDiffCostFunction(), loss, m, c)
+    options = sk.Solver.Options()
+    options.setMaxNumIterations(25)
+    options.setLinearSolverType(getattr(sk.LinearSolverType, solver))
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    xo, so = oracle.solve([1, 1], [0.0, 0.0], _curve_fitting_blocks(),
+                          oracle.default_options(linear_solver_type=getattr(oracle, solver), max_num_iterations=25))
+    g = [it["cost"] for it in summary.iterations()]
+    for k in range(min(len(g), so.num_logged)):
+        assert abs(g[k] - so.iterations[k].cost) <= 1e-9 * so.iterations[k].cost
+    assert abs(summary.finalCost() - so.final_cost) <= 1e-9 * so.final_cost
+    np.testing.assert_allclose([m.get(0), c.get(0)], xo, rtol=1e-7)
+    np.testing.assert_allclose([m.get(0), c.get(0)], [0.2915, 0.1314], atol=2e-3)  # m ~ 0.3, c ~ 0.1 (CurveFitting.scala:11-19)
+
+
+def test_powell_vs_oracle():
+    # EX/Powell.scala:55-91
+    xs = [sk.DoubleArray(1) for _ in range(4)]
+    for a, v in zip(xs, [3.0, -1.0, 0.0, 1.0]):
+        a.set(0, v)
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    problem = sk.Problem()
+    problem.addResidualBlock(sk.PowellF1().toAutoDiffCostFunction(), loss, xs[0], xs[1])
+    problem.addResidualBlock(sk.PowellF2().toAutoDiffCostFunction(), loss, xs[2], xs[3])
+    problem.addResidualBlock(sk.PowellF3().toAutoDiffCostFunction(), loss, xs[1], xs[2])
+    problem.addResidualBlock(sk.PowellF4().toAutoDiffCostFunction(), loss, xs[0], xs[3])
+    options = sk.Solver.Options()
+    options.setMinimizerType(sk.MinimizerType.TRUST_REGION)
+    options.setMaxNumIterations(100)
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_QR)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    blocks = [(oracle.POWELL_F1, [], [0, 1]), (oracle.POWELL_F2, [], [2, 3]), (oracle.POWELL_F3, [], [1, 2]),
+              (oracle.POWELL_F4, [], [0, 3])]
+    xo, so = oracle.solve([1, 1, 1, 1], [3.0, -1.0, 0.0, 1.0], blocks,
+                          oracle.default_options(linear_solver_type=oracle.DENSE_QR, max_num_iterations=100))
+    g = [it["cost"] for it in summary.iterations()]
+    for k in range(min(8, len(g), so.num_logged)):
+        assert abs(g[k] - so.iterations[k].cost) <= 1e-9 * max(so.iterations[k].cost, 1e-30)
+    assert summary.finalCost() <= 1e-10 and so.final_cost <= 1e-10
+    np.testing.assert_allclose([a.get(0) for a in xs], xo, atol=1e-5)
+
+
+def test_host_callback_cost_function_director_path():
+    # a SizedCostFunction subclass with an analytic Jacobian (the shape of EX/PowellAnalytic.scala)
+    class F1(sk.SizedCostFunction):
+        def __init__(self):
+            super().__init__(1, 1, 1)
+
+        def evaluate(self, parameters, residuals, jacobians):
+            residuals[0] = parameters[0][0] + 10.0 * parameters[1][0]
+            if jacobians is not None:
+                if jacobians[0] is not None:
+                    jacobians[0][0, 0] = 1.0
+                if jacobians[1] is not None:
+                    jacobians[1][0, 0] = 10.0
+            return True
+
+    xs = [sk.DoubleArray(1) for _ in range(4)]
+    for a, v in zip(xs, [3.0, -1.0, 0.0, 1.0]):
+        a.set(0, v)
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    problem = sk.Problem()
+    problem.addResidualBlock(F1(), loss, xs[0], xs[1])  # host callback
+    problem.addResidualBlock(sk.PowellF2().toAutoDiffCostFunction(), loss, xs[2], xs[3])
+    problem.addResidualBlock(sk.PowellF3().toAutoDiffCostFunction(), loss, xs[1], xs[2])
+    problem.addResidualBlock(sk.PowellF4().toAutoDiffCostFunction(), loss, xs[0], xs[3])
+    options = sk.Solver.Options()
+    options.setMaxNumIterations(100)
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_QR)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    blocks = [(oracle.POWELL_F1, [], [0, 1]), (oracle.POWELL_F2, [], [2, 3]), (oracle.POWELL_F3, [], [1, 2]),
+              (oracle.POWELL_F4, [], [0, 3])]
+    xo, so = oracle.solve([1, 1, 1, 1], [3.0, -1.0, 0.0, 1.0], blocks,
+                          oracle.default_options(linear_solver_type=oracle.DENSE_QR, max_num_iterations=100))
+    g = [it["cost"] for it in summary.iterations()]
+    for k in range(min(8, len(g), so.num_logged)):
+        assert abs(g[k] - so.iterations[k].cost) <= 1e-9 * max(so.iterations[k].cost, 1e-30)
+
+
+# ---------------------------------------------------------------------------
+# size-independent properties at larger sizes
+# ---------------------------------------------------------------------------
+def test_bal_medium_properties_and_reproducibility():
+    prob = bal.generate(400, 30000, 140000, seed=77)
+    x1, s1 = solve_bal_gpu(prob)
+    x2, s2 = solve_bal_gpu(prob)
+    # no atomics anywhere on the path: two runs are bit-identical
+    assert np.array_equal(x1, x2)
+    costs = [it["cost"] for it in s1.iterations()]
+    succ = [it for it in s1.iterations() if it["step_is_successful"]]
+    assert all(b["cost"] <= a["cost"] for a, b in zip(succ, succ[1:]))  # accepted steps never increase the cost
+    assert s1.finalCost() < 0.01 * s1.initialCost()
+    # final cost equals the oracle's evaluation of the returned parameters
+    _, _, _, c = oracle.bal_evaluate(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index,
+                                     prob.observations, x1, jacobians=False)
+    assert abs(c - s1.finalCost()) <= 1e-10 * c
+    assert costs[0] == pytest.approx(s1.initialCost())
