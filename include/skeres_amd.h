@@ -259,6 +259,18 @@ double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launc
  * solve (what roofline.achieved is computed from). */
 double sk_solver_syrk_flops_per_solve(const sk_solver* s);
 
+/* ---- multi-GPU sharding (host logic, no device needed) -----------------------
+ * How sk_solve splits a bundle-adjustment-shaped problem over `world` ranks
+ * (SURVEY.md §8e): cameras are the distinct blocks in parameter slot 0, points
+ * those in slot 1, both numbered in first-appearance order.  Rank r owns the
+ * points [cuts[r], cuts[r+1]) and every observation of them; the runs have
+ * (nearly) equal sum of squared track lengths.  `cuts` has world+1 entries.
+ * point_of_block[i] (optional, one entry per residual block) receives the point
+ * number of residual block i.  Returns SK_ERR_UNSUPPORTED when the problem is
+ * not bundle-adjustment shaped. */
+int sk_problem_point_partition(const sk_problem* p, int world, int* cuts, int* num_cameras,
+                               int* num_points, int* point_of_block);
+
 /* ---- dense SPD solve (utility; the factorisation sk_solve uses) --------------
  * Solves A x = b on the GPU for a symmetric positive definite A (n x n,
  * row-major HOST memory, only the lower triangle is read) with the blocked

@@ -88,6 +88,7 @@ def lib():
         L.or_solve_bal.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp,
                                    C.POINTER(Options), C.POINTER(Summary)]
         L.or_bal_evaluate.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, dp, dp]
+        L.or_bal_reduced_system.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
         L.or_cholesky_lower.argtypes = [dp, C.c_int, C.c_int]
         L.or_cholesky_solve.argtypes = [dp, C.c_int, dp]
         _lib = L
@@ -217,3 +218,19 @@ def cholesky_lower(A, num_threads=1):
     L = np.array(A, dtype=np.float64, order="C").copy()
     info = lib().or_cholesky_lower(_dp(L), L.shape[0], num_threads)
     return info, np.tril(L)
+
+
+def bal_reduced_system(C_, P_, cam_idx, pt_idx, obs, x, D, add_Dc=True):
+    """Reduced camera system (S lower, rhs) of the given observations."""
+    cam = np.ascontiguousarray(cam_idx, dtype=np.int32)
+    pt = np.ascontiguousarray(pt_idx, dtype=np.int32)
+    ob = np.ascontiguousarray(obs, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    n = 9 * C_
+    S = np.zeros((n, n))
+    rhs = np.zeros(n)
+    rc = lib().or_bal_reduced_system(C_, P_, len(cam), _ip(cam), _ip(pt), _dp(ob), _dp(x), _dp(D), int(add_Dc), _dp(S), _dp(rhs))
+    if rc != 0:
+        raise RuntimeError("or_bal_reduced_system failed: %d" % rc)
+    return S, rhs

@@ -247,8 +247,10 @@ struct SchurWork {
   double t_assemble = 0, t_chol = 0, t_backsub = 0;
 };
 
-// Solve (J^T J + D^2) y = J^T r for the scaled Jacobian held in B.F / B.E.
-static bool bal_schur_solve(const Bal& B, const double* D, double* y, SchurWork& w, int nthreads) {
+// Reduced camera system S (lower), rhs for the Jacobian held in B.F / B.E:
+// eliminate the point blocks of (J^T J + D^2) y = J^T r.  add_Dc == false leaves
+// D_c^2 off the diagonal (used to check that per-shard systems add up).
+static bool bal_schur_assemble(const Bal& B, const double* D, SchurWork& w, int nthreads, bool add_Dc) {
   const int C = B.C, P = B.P, N = B.N; const int n = 9 * C;
   const double* Dc = D; const double* Dp = D + 9 * (size_t)C;
   double t0 = now_s();
@@ -286,7 +288,7 @@ static bool bal_schur_solve(const Bal& B, const double* D, double* y, SchurWork&
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
   for (int i = 0; i < C; ++i) {
     double* Srow = &w.S[(size_t)(9 * i) * n]; double* rhs = &w.rhs[9 * (size_t)i];
-    for (int c = 0; c < 9; ++c) Srow[(size_t)c * n + 9 * i + c] += Dc[9 * (size_t)i + c] * Dc[9 * (size_t)i + c];
+    if (add_Dc) for (int c = 0; c < 9; ++c) Srow[(size_t)c * n + 9 * i + c] += Dc[9 * (size_t)i + c] * Dc[9 * (size_t)i + c];
     for (int k = B.cam_start[i]; k < B.cam_start[i + 1]; ++k) {
       const int a = B.cam_obs[k]; const int p = B.pt[a];
       const double* F = &B.F[18 * (size_t)a]; const double* r = &B.r[2 * (size_t)a];
@@ -306,7 +308,15 @@ static bool bal_schur_solve(const Bal& B, const double* D, double* y, SchurWork&
       }
     }
   }
-  double t1 = now_s(); w.t_assemble += t1 - t0;
+  w.t_assemble += now_s() - t0;
+  return true;
+}
+
+// Solve (J^T J + D^2) y = J^T r for the scaled Jacobian held in B.F / B.E.
+static bool bal_schur_solve(const Bal& B, const double* D, double* y, SchurWork& w, int nthreads) {
+  const int C = B.C, P = B.P; const int n = 9 * C;
+  if (!bal_schur_assemble(B, D, w, nthreads, true)) return false;
+  double t1 = now_s();
   if (cholesky_lower_inplace(w.S.data(), n, n, nthreads) != 0) return false;
   std::vector<double> yc(w.rhs);
   cholesky_solve_lower(w.S.data(), n, n, yc.data());
@@ -617,9 +627,8 @@ int or_solve(int num_blocks, const int* block_sizes, double* x, int num_res_bloc
 
 // BAL-shaped problem, SnavelyReprojectionError blocks only, x = [9C cameras | 3P points]
 // (memory layout of EX/SimpleBundleAdjuster.scala:18-34).  DENSE_SCHUR.
-int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
-                 double* x, const or_options* opt, or_summary* summary) {
-  Bal B; B.C = C; B.P = P; B.N = N; B.cam.assign(cam_idx, cam_idx + N); B.pt.assign(pt_idx, pt_idx + N);
+static int bal_build(Bal& B, int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs) {
+  B.C = C; B.P = P; B.N = N; B.cam.assign(cam_idx, cam_idx + N); B.pt.assign(pt_idx, pt_idx + N);
   B.consts = obs;
   B.cam_start.assign(C + 1, 0); B.pt_start.assign(P + 1, 0);
   for (int o = 0; o < N; ++o) { if (cam_idx[o] < 0 || cam_idx[o] >= C || pt_idx[o] < 0 || pt_idx[o] >= P) return -1; B.cam_start[cam_idx[o] + 1]++; B.pt_start[pt_idx[o] + 1]++; }
@@ -630,6 +639,13 @@ int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, con
   { std::vector<int> fill(B.pt_start.begin(), B.pt_start.end() - 1); for (int o = 0; o < N; ++o) B.pt_obs[fill[pt_idx[o]]++] = o; }
   for (int i = 0; i < C; ++i) std::sort(B.cam_obs.begin() + B.cam_start[i], B.cam_obs.begin() + B.cam_start[i + 1], [&](int a, int b) { return pt_idx[a] != pt_idx[b] ? pt_idx[a] < pt_idx[b] : a < b; });
   for (int p = 0; p < P; ++p) std::sort(B.pt_obs.begin() + B.pt_start[p], B.pt_obs.begin() + B.pt_start[p + 1], [&](int a, int b) { return cam_idx[a] != cam_idx[b] ? cam_idx[a] < cam_idx[b] : a < b; });
+  return 0;
+}
+
+int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                 double* x, const or_options* opt, or_summary* summary) {
+  Bal B;
+  if (int rc = bal_build(B, C, P, N, cam_idx, pt_idx, obs)) return rc;
   int nt = opt->num_threads;
 #ifdef _OPENMP
   if (nt <= 0) nt = omp_get_max_threads();
@@ -653,6 +669,24 @@ int or_bal_evaluate(int C, int P, int N, const int* cam_idx, const int* pt_idx, 
   std::memcpy(r, B.r.data(), sizeof(double) * 2 * (size_t)N);
   if (jac) { std::memcpy(F, B.F.data(), sizeof(double) * 18 * (size_t)N); std::memcpy(E, B.E.data(), sizeof(double) * 6 * (size_t)N); }
   return 1;
+}
+
+// Reduced camera system of the observations given (any subset of a problem's
+// observations; P is the full point count): S (n x n row-major, lower triangle
+// filled) and rhs (n), n = 9C, unscaled Jacobian at x, LM diagonal D (9C + 3P).
+// add_Dc != 0 adds D_c^2 to the diagonal.
+int or_bal_reduced_system(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                          const double* x, const double* D, int add_Dc, double* S, double* rhs) {
+  Bal B;
+  if (int rc = bal_build(B, C, P, N, cam_idx, pt_idx, obs)) return rc;
+  double cost;
+  if (!bal_evaluate(B, x, true, &cost, 1)) return -2;
+  SchurWork w;
+  if (!bal_schur_assemble(B, D, w, 1, add_Dc != 0)) return -3;
+  const size_t n = 9 * (size_t)C;
+  std::memcpy(S, w.S.data(), n * n * sizeof(double));
+  std::memcpy(rhs, w.rhs.data(), n * sizeof(double));
+  return 0;
 }
 
 int or_cholesky_lower(double* A, int n, int num_threads) { return cholesky_lower_inplace(A, n, n, num_threads); }

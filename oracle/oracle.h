@@ -53,6 +53,8 @@ int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, con
                  double* x, const or_options* opt, or_summary* summary);
 int or_bal_evaluate(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                     const double* x, double* r, double* F, double* E, double* cost);
+int or_bal_reduced_system(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                          const double* x, const double* D, int add_Dc, double* S, double* rhs);
 int or_cholesky_lower(double* A, int n, int num_threads);
 void or_cholesky_solve(const double* L, int n, double* b);
 

@@ -109,6 +109,7 @@ _SIGS = {
     "sk_solver_kernel_seconds": (C.c_double, [C.c_void_p, C.c_char_p, _ip]),
     "sk_solver_syrk_flops_per_solve": (C.c_double, [C.c_void_p]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
+    "sk_problem_point_partition": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip]),
 }
 
 
@@ -526,6 +527,17 @@ class Problem:
         if rc == 1:
             raise ValueError(lib().sk_last_error().decode())
         _check(rc)
+
+    def pointPartition(self, world):
+        """(cuts[world+1], num_cameras, num_points, point_of_block[num residual blocks]):
+        how sk_solve shards this problem over `world` ranks (host logic only)."""
+        cuts = np.zeros(world + 1, dtype=np.int32)
+        pob = np.zeros(self.numResidualBlocks(), dtype=np.int32)
+        nc, npts = C.c_int(), C.c_int()
+        rc = lib().sk_problem_point_partition(self._h, int(world), cuts.ctypes.data_as(_ip), C.byref(nc), C.byref(npts),
+                                              pob.ctypes.data_as(_ip))
+        _check(rc)
+        return cuts, nc.value, npts.value, pob
 
     def numResidualBlocks(self):
         return lib().sk_problem_num_residual_blocks(self._h)

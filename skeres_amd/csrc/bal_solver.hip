@@ -31,6 +31,38 @@ bool problem_is_bal_shaped(const Problem& p, std::string* why) {
   return true;
 }
 
+// Cameras (parameter slot 0) and points (slot 1) in first-appearance order, the
+// per-observation indices, and the partition of points over `world` ranks:
+// contiguous runs with (nearly) equal sum of k_p^2, because the Schur work of a
+// point is quadratic in its track length k_p.
+void bal_index_problem(const Problem& p, std::vector<int>* cam_block, std::vector<int>* pt_block, std::vector<int>* ocam,
+                       std::vector<int>* opt) {
+  const int Nall = (int)p.rb_functor.size();
+  std::vector<int> cam_of_block(p.block_size.size(), -1), pt_of_block(p.block_size.size(), -1);
+  ocam->resize(Nall); opt->resize(Nall);
+  for (int b = 0; b < Nall; ++b) {
+    const int cb = p.rb_pidx[p.rb_pidx_off[b]], pb = p.rb_pidx[p.rb_pidx_off[b] + 1];
+    if (cam_of_block[cb] < 0) { cam_of_block[cb] = (int)cam_block->size(); cam_block->push_back(cb); }
+    if (pt_of_block[pb] < 0) { pt_of_block[pb] = (int)pt_block->size(); pt_block->push_back(pb); }
+    (*ocam)[b] = cam_of_block[cb]; (*opt)[b] = pt_of_block[pb];
+  }
+}
+
+void bal_partition_points(const std::vector<int>& opt, int num_points, int world, std::vector<int>* cut) {
+  std::vector<int> kp(num_points, 0);
+  for (int q : opt) kp[q]++;
+  cut->assign(world + 1, num_points);
+  (*cut)[0] = 0;
+  double total = 0.0;
+  for (int q = 0; q < num_points; ++q) total += (double)kp[q] * kp[q];
+  double acc = 0.0;
+  int r = 1;
+  for (int q = 0; q < num_points && r < world; ++q) {
+    acc += (double)kp[q] * kp[q];
+    while (r < world && acc >= total * r / world) (*cut)[r++] = q + 1;
+  }
+}
+
 namespace {
 
 class BalSolver : public SolverBase {
@@ -74,28 +106,13 @@ int BalSolver::setup() {
   if (!problem_is_bal_shaped(*problem_, &why)) { set_error("%s", why.c_str()); return SK_ERR_UNSUPPORTED; }
   const Problem& p = *problem_;
   const int Nall = (int)p.rb_functor.size();
-  // cameras / points in first-appearance order
-  std::vector<int> cam_of_block(p.block_size.size(), -1), pt_of_block(p.block_size.size(), -1);
-  std::vector<int> ocam(Nall), opt(Nall);
-  for (int b = 0; b < Nall; ++b) {
-    const int cb = p.rb_pidx[p.rb_pidx_off[b]], pb = p.rb_pidx[p.rb_pidx_off[b] + 1];
-    if (cam_of_block[cb] < 0) { cam_of_block[cb] = (int)cam_block_.size(); cam_block_.push_back(cb); }
-    if (pt_of_block[pb] < 0) { pt_of_block[pb] = (int)pt_block_.size(); pt_block_.push_back(pb); }
-    ocam[b] = cam_of_block[cb]; opt[b] = pt_of_block[pb];
-  }
+  std::vector<int> ocam, opt;
+  bal_index_problem(p, &cam_block_, &pt_block_, &ocam, &opt);
   C_ = (int)cam_block_.size(); P_total_ = (int)pt_block_.size();
-  // partition points over ranks: contiguous runs with equal sum of k_p^2 (Schur work is quadratic in track length)
-  std::vector<int> kp(P_total_, 0);
-  for (int b = 0; b < Nall; ++b) kp[opt[b]]++;
   int p_lo = 0, p_hi = P_total_;
   if (opt_.world > 1) {
-    double total = 0.0; for (int q = 0; q < P_total_; ++q) total += (double)kp[q] * kp[q];
-    std::vector<int> cut(opt_.world + 1, P_total_); cut[0] = 0;
-    double acc = 0.0; int r = 1;
-    for (int q = 0; q < P_total_ && r < opt_.world; ++q) {
-      acc += (double)kp[q] * kp[q];
-      while (r < opt_.world && acc >= total * r / opt_.world) { cut[r++] = q + 1; }
-    }
+    std::vector<int> cut;
+    bal_partition_points(opt, P_total_, opt_.world, &cut);
     p_lo = cut[opt_.rank]; p_hi = cut[opt_.rank + 1];
   }
   P_ = p_hi - p_lo;
@@ -196,7 +213,7 @@ int BalSolver::setup() {
 // a world x K table, the table is sum-reduced, then each rank folds the slots
 // in rank order (identical result on every rank; ops: 0 sum, 1 max).
 int BalSolver::gather_rank_scalars(double* vals, int K, const int* ops) {
-  if (opt_.world <= 1) return SK_OK;
+  if (!opt_.allreduce) return SK_OK;
   const int W = opt_.world;
   std::vector<double> table((size_t)W * K, 0.0);
   for (int k = 0; k < K; ++k) table[(size_t)opt_.rank * K + k] = vals[k];
@@ -222,7 +239,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   const int nb = bal_partial_blocks(N_);
   launch_bal_cam_reduce(d_, s);
   launch_bal_pt_reduce(d_, s);
-  if (opt_.world > 1) {  // camera columns are summed over all ranks' observations
+  if (opt_.allreduce) {  // camera columns are summed over all ranks' observations
     double* buf = b_small_.p;
     SK_HIP_TRY(hipMemcpyAsync(buf, d_.colsq_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
     SK_HIP_TRY(hipMemcpyAsync(buf + nc, d_.gs_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -276,7 +293,7 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
   launch_bal_obs_precompute(d_, s);
   kt_.begin("bal_cam_diag", s); launch_bal_cam_diag(d_, s); kt_.end("bal_cam_diag", s);
   kt_.begin("bal_pair", s); launch_bal_pair(d_, s); kt_.end("bal_pair", s);
-  if (opt_.world > 1) {
+  if (opt_.allreduce) {
     // sum S (with the rhs row) over ranks; only rows [0, rhs_row] carry data
     int rc = allreduce(b_S_.p, (size_t)(rhs_row_ + 1) * npad_);
     if (rc) return rc;
@@ -325,7 +342,7 @@ int BalSolver::write_back() {
   SK_HIP_TRY(hipMemcpyAsync(x.data(), d_.xc, (nc + np) * sizeof(double), hipMemcpyDeviceToHost, stream_));
   SK_HIP_TRY(hipStreamSynchronize(stream_));
   for (int i = 0; i < C_; ++i) std::memcpy(problem_->block_ptr[cam_block_[i]], &x[9 * (size_t)i], 9 * sizeof(double));
-  if (opt_.world <= 1) {
+  if (!opt_.allreduce) {
     for (int q = 0; q < P_; ++q) std::memcpy(problem_->block_ptr[pt_block_[local_pt_[q]]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
     return SK_OK;
   }

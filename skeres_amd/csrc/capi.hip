@@ -328,6 +328,22 @@ int sk_solve(const sk_options* options, sk_problem* problem, sk_summary* summary
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }
 
+int sk_problem_point_partition(const sk_problem* p, int world, int* cuts, int* num_cameras, int* num_points, int* point_of_block) {
+  SK_GUARD_BEGIN
+  if (!p || world < 1 || !cuts) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  std::string why;
+  if (!problem_is_bal_shaped(p->p, &why)) { set_error("%s", why.c_str()); return SK_ERR_UNSUPPORTED; }
+  std::vector<int> cam_block, pt_block, ocam, opt, cut;
+  bal_index_problem(p->p, &cam_block, &pt_block, &ocam, &opt);
+  bal_partition_points(opt, (int)pt_block.size(), world, &cut);
+  for (int r = 0; r <= world; ++r) cuts[r] = cut[r];
+  if (num_cameras) *num_cameras = (int)cam_block.size();
+  if (num_points) *num_points = (int)pt_block.size();
+  if (point_of_block) for (size_t b = 0; b < opt.size(); ++b) point_of_block[b] = opt[b];
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
 int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double* L, int group) {
   SK_GUARD_BEGIN
   if (n <= 0 || !A || !b || !x) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }

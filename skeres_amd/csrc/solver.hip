@@ -68,8 +68,7 @@ int SolverBase::init_device() {
 }
 
 int SolverBase::allreduce(double* dev, size_t count) {
-  if (opt_.world <= 1) return SK_OK;
-  if (!opt_.allreduce) { set_error("world > 1 but no allreduce hook was set"); return SK_ERR_COMM; }
+  if (!opt_.allreduce) return SK_OK;  // the hook decides: a world of 1 with a hook still exercises the whole path
   hipEvent_t a = ev_[kEvCount], b = ev_[kEvCount + 1];
   if (!a) { SK_HIP_TRY(hipEventCreate(&ev_[kEvCount])); SK_HIP_TRY(hipEventCreate(&ev_[kEvCount + 1])); a = ev_[kEvCount]; b = ev_[kEvCount + 1]; }
   SK_HIP_TRY(hipEventRecord(a, stream_));

@@ -60,6 +60,9 @@ class SolverBase {
 // block): Schur elimination of the 3-blocks + dense Cholesky of the reduced system.
 std::unique_ptr<SolverBase> make_bal_solver(const Options& o, Problem* p);
 bool problem_is_bal_shaped(const Problem& p, std::string* why_not);
+void bal_index_problem(const Problem& p, std::vector<int>* cam_block, std::vector<int>* pt_block, std::vector<int>* ocam,
+                       std::vector<int>* opt);
+void bal_partition_points(const std::vector<int>& opt, int num_points, int world, std::vector<int>* cut);
 // Generic dense Jacobian path: DENSE_QR / DENSE_NORMAL_CHOLESKY.
 std::unique_ptr<SolverBase> make_dense_solver(const Options& o, Problem* p);
 

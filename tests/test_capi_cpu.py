@@ -1,0 +1,190 @@
+"""CPU-only checks of the C ABI and the host logic (no compute calls: no GPU here).
+
+* the library loads and exports every symbol include/skeres_amd.h declares;
+* native-memory helpers (ports of DoubleArraySliceSpec / RichDoubleArraySpec /
+  RichDoubleMatrixSpec of the reference);
+* argument validation (the Scala side's `require`s) and Problem bookkeeping;
+* BAL text format round trip; compute entry points fail LOUDLY without a device.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import skeres_amd as sk
+from skeres_amd import bal
+from helpers import bal_problem_to_sk
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built(built):
+    return built
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "skeres_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(sk_[a-z0-9_]+)\s*\(", header))
+    declared -= {"sk_evaluate_fn", "sk_allreduce_fn"}
+    assert len(declared) > 80
+    L = sk.lib()
+    missing = [name for name in sorted(declared) if not hasattr(L, name)]
+    assert not missing, missing
+    # and the Python binding covers all of them
+    assert set(sk.api.exported_symbols()) == declared
+
+
+def test_version_and_device_count():
+    assert b"skeres_amd" in sk.lib().sk_version()
+    assert sk.device_count() >= 0
+
+
+# ---- DoubleArraySliceSpec.scala:8-23, RichDoubleArraySpec.scala:8-33 ----------------
+def test_double_array_slice():
+    a = sk.DoubleArray(10)
+    for i in range(10):
+        a.setitem(i, float(i))
+    s = a.slice(3)
+    assert [s.get(i) for i in range(7)] == [3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0]
+    s.set(0, -1.0)
+    assert a.get(3) == -1.0  # a slice is a view, not a copy
+
+
+def test_rich_double_array_round_trips():
+    a = sk.RichDoubleArray.fromArray([1.0, 2.0, 3.0])
+    assert list(a.toArray(3)) == [1.0, 2.0, 3.0]
+    b = sk.RichDoubleArray.ofSize(3)
+    b.copyFrom([4.0, 5.0, 6.0])
+    assert [b.get(i) for i in range(3)] == [4.0, 5.0, 6.0]
+    assert not a.isNull()
+
+
+# ---- RichDoubleMatrixSpec.scala:8-94 --------------------------------------------------
+def test_rich_double_matrix():
+    m = sk.RichDoubleMatrix.ofSize(3, 4)
+    for i in range(3):
+        for j in range(4):
+            m.set(i, j, 10 * i + j)
+    assert m.get(2, 3) == 23 and m.hasRow(1) and not m.isNull()
+    assert list(m.getRow(1).toArray(4)) == [10, 11, 12, 13]
+    m2 = sk.RichDoubleMatrix.fromArrays([1.0, 2.0], [3.0, 4.0, 5.0])
+    assert m2.get(1, 2) == 5.0
+    v = sk.StdVectorDoublePointer()
+    assert v.size() == 0 and not v.toPointerPointer()  # DoubleMatrix.toPointerPointer: NULL when empty (ceres.i:121-123)
+    v.add(m.getRow(0))
+    assert v.size() == 1 and bool(v.toPointerPointer())
+
+
+# ---- validation ---------------------------------------------------------------------------
+def test_cost_functor_validation():
+    with pytest.raises(ValueError):  # CORE/CostFunctor.scala:32
+        sk.AutoDiffCostFunctor(0, 1)
+    with pytest.raises(ValueError):  # CORE/CostFunctor.scala:33
+        sk.AutoDiffCostFunctor(1, 2, 0)
+    with pytest.raises(ValueError):  # CORE/SizedCostFunction.scala:7
+        sk.SizedCostFunction(1, -1)
+    with pytest.raises(ValueError):  # CORE/SizedCostFunction.scala:8-11
+        sk.SizedCostFunction(1, 0, 2)
+    cf = sk.SnavelyReprojectionError(1.0, 2.0).toAutoDiffCostFunction()
+    assert cf.numResiduals() == 2 and cf.parameterBlockSizes() == [9, 3]
+
+
+def test_problem_bookkeeping_and_errors():
+    m, c, bad = sk.DoubleArray(1), sk.DoubleArray(1), sk.DoubleArray(9)
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    p = sk.Problem()
+    rid0 = p.addResidualBlock(sk.ExponentialResidual(0.0, 1.0).toAutoDiffCostFunction(), loss, m, c)
+    rid1 = p.addResidualBlock(sk.ExponentialResidual(1.0, 2.0).toAutoDiffCostFunction(), loss, m, c)
+    assert (rid0, rid1) == (0, 1)
+    assert (p.numResidualBlocks(), p.numParameterBlocks(), p.numParameters(), p.numResiduals()) == (2, 2, 2, 2)
+    with pytest.raises(ValueError):  # wrong number of parameter blocks
+        p.addResidualBlock(sk.ExponentialResidual(0.0, 1.0).toAutoDiffCostFunction(), loss, m)
+    with pytest.raises(ValueError):  # same pointer, different size
+        p.addResidualBlock(sk.SnavelyReprojectionError(0.0, 0.0).toAutoDiffCostFunction(), loss, bad, m)
+    with pytest.raises(ValueError):  # duplicate parameter block inside one residual block
+        p.addResidualBlock(sk.ExponentialResidual(0.0, 1.0).toAutoDiffCostFunction(), loss, m, m)
+
+
+def test_options_validation():
+    o = sk.Solver.Options()
+    o.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    o.setMaxNumIterations(25)
+    o.setMinimizerProgressToStdout(True)
+    with pytest.raises(sk.SkeresError):
+        o.setLinearSolverType(sk.LinearSolverType.SPARSE_NORMAL_CHOLESKY)
+    with pytest.raises(sk.SkeresError):
+        o.setMinimizerType(sk.MinimizerType.LINE_SEARCH)
+    with pytest.raises(ValueError):
+        o.setMaxNumIterations(-1)
+    with pytest.raises(ValueError):
+        o.setFunctionTolerance(-1.0)
+
+
+def test_compute_fails_loudly_without_a_device():
+    if sk.device_count() > 0:
+        pytest.skip("a GPU is present")
+    prob = bal.generate(4, 24, 90, seed=42)
+    problem, params, loss = bal_problem_to_sk(prob)
+    o = sk.Solver.Options()
+    o.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    with pytest.raises(sk.SkeresError, match="no HIP device"):
+        sk.ceres.solve(o, problem, sk.Solver.Summary())
+    assert np.array_equal(params.toArray(prob.num_parameters), prob.parameters)  # untouched: no silent CPU path
+    with pytest.raises(sk.SkeresError, match="no HIP device"):
+        sk.api.cholesky_solve(np.eye(4), np.ones(4))
+    cf = sk.BinaryScalarCost(1.0).toAutoDiffCostFunction()
+    with pytest.raises(sk.SkeresError, match="no HIP device"):
+        cf.evaluate(sk.RichDoubleMatrix.ofSize(2, 2), sk.DoubleArray(1), None)
+
+
+def test_dense_schur_rejects_non_bundle_shapes():
+    m, c = sk.DoubleArray(1), sk.DoubleArray(1)
+    p = sk.Problem()
+    p.addResidualBlock(sk.ExponentialResidual(0.0, 1.0).toAutoDiffCostFunction(), None, m, c)
+    with pytest.raises(sk.SkeresError, match="DENSE_SCHUR"):
+        p.pointPartition(2)
+
+
+# ---- host logic: sharding ------------------------------------------------------------------
+def test_point_partition_covers_every_point_once_and_balances_squares():
+    prob = bal.generate(30, 2000, 9500, seed=9)
+    problem, _, _ = bal_problem_to_sk(prob)
+    for world in (1, 2, 3, 8):
+        cuts, nc, npts, pob = problem.pointPartition(world)
+        assert nc == 30 and npts == 2000
+        assert cuts[0] == 0 and cuts[-1] == npts and np.all(np.diff(cuts) >= 0)
+        k2 = np.bincount(pob, minlength=npts).astype(np.int64) ** 2
+        loads = [k2[cuts[r]:cuts[r + 1]].sum() for r in range(world)]
+        assert sum(loads) == k2.sum()
+        assert max(loads) <= k2.sum() / world + k2.max()  # contiguous cut: within one point of ideal
+
+
+# ---- BAL text format (SimpleBundleAdjuster.scala:37-76) ---------------------------------
+def test_bal_text_round_trip(tmp_path):
+    prob = bal.generate(3, 12, 40, seed=1)
+    path = tmp_path / "problem.txt"
+    prob.to_file(str(path))
+    back = bal.BalProblem.from_file(str(path))
+    assert (back.num_cameras, back.num_points, back.num_observations) == (3, 12, 40)
+    assert np.array_equal(back.camera_index, prob.camera_index) and np.array_equal(back.point_index, prob.point_index)
+    np.testing.assert_array_equal(back.observations, prob.observations)
+    np.testing.assert_array_equal(back.parameters, prob.parameters)
+    first = open(path).readline().split()
+    assert first == ["3", "12", "40"]
+
+
+def test_generator_shapes_are_exact_and_visible():
+    for name in ("problem-49-7776",):
+        C, P, N = bal.SHAPES[name]
+        prob = bal.generate_named(name)
+        assert (prob.num_cameras, prob.num_points, prob.num_observations) == (C, P, N)
+        k = np.bincount(prob.point_index, minlength=P)
+        assert k.min() >= 2
+        # no duplicate (camera, point) observation
+        key = prob.camera_index.astype(np.int64) * P + prob.point_index
+        assert np.unique(key).size == N
+        _, depth = bal.snavely_project(prob.cameras()[prob.camera_index], prob.points()[prob.point_index])
+        assert (depth < 0).all()  # in front of the camera (Snavely sign convention)
