@@ -31,8 +31,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (datasheet; MI355X_MICROARCH.md has no fp64 row)
-PERTURB = (5e-2, 5e-1, 5e-1)  # angle-axis, translation, point perturbation of the initial guess
+PERTURB = (1e-2, 1e-1, 1e-1)  # angle-axis, translation, point perturbation of the initial guess
 SEED = 1723
+
+
+def available_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host, e.g. 256, on a box whose share is 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, int(os.environ.get("SKERES_CPU_THREADS", "16"))))
 
 
 def build_problem(sk, prob):
@@ -79,7 +99,7 @@ def cpu_baseline(prob, iters):
     """The oracle (CPU restatement, kind "port") on the same problem: `iters` LM
     iterations on all host cores, wall-clock of the steady-state iterations."""
     import oracle
-    nthreads = os.cpu_count() or 1
+    nthreads = available_cpus()
     o = oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=nthreads, max_num_iterations=iters,
                                function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
     t0 = time.time()
@@ -101,6 +121,7 @@ def main():
     ap.add_argument("--workload", default="ladybug-1723-156502")
     ap.add_argument("--cpu-iters", type=int, default=2, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--group", type=int, default=0, help="(tuning) SYRK depth in 128-column blocks")
+    ap.add_argument("--no-lookahead", action="store_true", help="(tuning) single-stream Cholesky")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,6 +150,7 @@ def main():
     options.setGradientTolerance(0.0)
     options.setParameterTolerance(0.0)
     options.setDevice(local_rank)
+    options.setCholeskyTuning(args.group, not args.no_lookahead)
     stream = torch.cuda.current_stream()
     options.setStream(stream.cuda_stream)
     hook = None

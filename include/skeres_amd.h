@@ -202,6 +202,10 @@ int sk_options_set_max_num_consecutive_invalid_steps(sk_options* o, int n);
 /* MI355X-side knobs (no reference counterpart) */
 int sk_options_set_device(sk_options* o, int hip_device);             /* default: current device */
 int sk_options_set_stream(sk_options* o, void* hip_stream);           /* default: a private stream */
+/* Tuning of the dense Cholesky: `group` = depth of the trailing SYRK in
+ * 128-column blocks (K = 128*group; <= 0 keeps the default 4); `lookahead` != 0
+ * overlaps the panel factorisation with the trailing update on a second stream. */
+int sk_options_set_cholesky_tuning(sk_options* o, int group, int lookahead);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,
  * one per GPU.  Points (e-blocks) are partitioned over ranks; the
  * normal-equation terms are summed with `allreduce` once per linear solve.

@@ -82,6 +82,7 @@ _SIGS = {
     "sk_options_set_jacobi_scaling": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_max_num_consecutive_invalid_steps": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_cholesky_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "sk_options_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sk_options_set_distributed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]),
     "sk_options_set_reduce_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -585,6 +586,9 @@ class Solver:
         def setJacobiScaling(self, on): self._set("jacobi_scaling", int(bool(on)))
         def setMaxNumConsecutiveInvalidSteps(self, n): self._set("max_num_consecutive_invalid_steps", int(n))
         def setDevice(self, d): self._set("device", int(d))
+
+        def setCholeskyTuning(self, group=0, lookahead=True):
+            _check(lib().sk_options_set_cholesky_tuning(self._h, int(group), int(bool(lookahead))))
         def setStream(self, s): self._set("stream", C.c_void_p(int(s)))
 
         def setDistributed(self, rank, world, allreduce):

@@ -101,6 +101,8 @@ def generate(num_cameras, num_points, num_observations, seed=1723, sigma_px=0.5,
     C, P, N = int(num_cameras), int(num_points), int(num_observations)
     if N < 2 * P:
         raise ValueError("need at least 2 observations per point")
+    if N > P * C:
+        raise ValueError("more observations than (camera, point) pairs")
     rng = np.random.default_rng(seed)
     kmax = max(2, min(C, max(4, C // 4, int(np.ceil(N / P)) + 2)))
     mean_extra = N / P - 2.0

@@ -222,13 +222,23 @@ __global__ __launch_bounds__(kBlock) void grad_max_xnorm_kernel(const double* gs
 }
 
 // out[k] = reduce(partial[k*stride .. +count)) in fixed order; bit k of maxmask: 0 sum, 1 max
-__global__ void final_reduce_kernel(const double* partial, int stride, int count, int K, int maxmask, double* out) {
-  const int k = threadIdx.x;
-  if (k >= K) return;
+// One workgroup per value; fixed lane assignment + fixed tree => reproducible.
+__global__ __launch_bounds__(kBlock) void final_reduce_kernel(const double* partial, int stride, int count, int K, int maxmask, double* out) {
+  __shared__ double sh[kBlock];
+  const int k = blockIdx.x;
+  const bool is_max = ((maxmask >> k) & 1) != 0;
   double a = 0.0;
-  if (((maxmask >> k) & 1) == 0) for (int i = 0; i < count; ++i) a += partial[(size_t)k * stride + i];
-  else for (int i = 0; i < count; ++i) a = fmax(a, partial[(size_t)k * stride + i]);
-  out[k] = a;
+  for (int i = threadIdx.x; i < count; i += kBlock) {
+    const double v = partial[(size_t)k * stride + i];
+    a = is_max ? fmax(a, v) : a + v;
+  }
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = kBlock / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] = is_max ? fmax(sh[threadIdx.x], sh[threadIdx.x + w]) : sh[threadIdx.x] + sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[k] = sh[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -386,6 +396,22 @@ __global__ void bal_finish_S_kernel(double* S, int ld, int n, int npad, int rhs_
 //   step = -y ; x_new = x + step * scale
 // partial[0] += |delta|^2 (points),  one thread per point.
 // ---------------------------------------------------------------------------
+// Per observation u_o = E_o^T (F_o y_c[cam o]) into planes 0..2 of What (free by
+// now: What is only read during the Schur assembly).  Keeps the per-point pass
+// light, so a 400-observation track does not stall its wave.
+__global__ __launch_bounds__(kBlock) void bal_obs_backsub_kernel(BalDev d) {
+  const size_t N = d.N;
+  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    const double* yc = d.y_c + 9 * (size_t)d.cam[o];
+    double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { f0 += d.F[c * N + o] * yc[c]; f1 += d.F[(9 + c) * N + o] * yc[c]; }
+    d.What[o] = d.E[o] * f0 + d.E[3 * N + o] * f1;
+    d.What[N + o] = d.E[N + o] * f0 + d.E[4 * N + o] * f1;
+    d.What[2 * N + o] = d.E[2 * N + o] * f0 + d.E[5 * N + o] * f1;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
   const int p = blockIdx.x * kBlock + threadIdx.x;
   double acc[1] = {0.0};
@@ -393,13 +419,9 @@ __global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
     const size_t N = d.N, P = d.P;
     double t0 = d.gs_p[3 * (size_t)p], t1 = d.gs_p[3 * (size_t)p + 1], t2 = d.gs_p[3 * (size_t)p + 2];
     for (int o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
-      const double* yc = d.y_c + 9 * (size_t)d.cam[o];
-      double f0 = 0.0, f1 = 0.0;
-#pragma unroll
-      for (int c = 0; c < 9; ++c) { f0 += d.F[c * N + o] * yc[c]; f1 += d.F[(9 + c) * N + o] * yc[c]; }
-      t0 -= d.E[o] * f0 + d.E[3 * N + o] * f1;
-      t1 -= d.E[N + o] * f0 + d.E[4 * N + o] * f1;
-      t2 -= d.E[2 * N + o] * f0 + d.E[5 * N + o] * f1;
+      t0 -= d.What[o];
+      t1 -= d.What[N + o];
+      t2 -= d.What[2 * N + o];
     }
     const double m00 = d.M[p], m10 = d.M[P + p], m11 = d.M[2 * P + p], m20 = d.M[3 * P + p], m21 = d.M[4 * P + p], m22 = d.M[5 * P + p];
     const double u0 = m00 * t0, u1 = m10 * t0 + m11 * t1, u2 = m20 * t0 + m21 * t1 + m22 * t2;
@@ -462,7 +484,7 @@ int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x
   hipLaunchKernelGGL(grad_max_xnorm_kernel, dim3(g), dim3(kBlock), 0, s, gs, scale, x, n, partial, stride);
   return g;
 }
-void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s) { hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, s, partial, stride, count, K, maxmask, out); }
+void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s) { hipLaunchKernelGGL(final_reduce_kernel, dim3(K), dim3(kBlock), 0, s, partial, stride, count, K, maxmask, out); }
 void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_point_block_kernel, dim3((d.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
@@ -474,6 +496,7 @@ void launch_bal_pair(const BalDev& d, hipStream_t s) {
 void launch_bal_finish_S(double* S, int ld, int n, int npad, int rhs_row, const double* D_c, hipStream_t s) { hipLaunchKernelGGL(bal_finish_S_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, n, npad, rhs_row, D_c); }
 int launch_bal_point_backsub(const BalDev& d, hipStream_t s) {
   const int g = d.P > 0 ? (d.P + kBlock - 1) / kBlock : 1;
+  hipLaunchKernelGGL(bal_obs_backsub_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
   hipLaunchKernelGGL(bal_point_backsub_kernel, dim3(g), dim3(kBlock), 0, s, d);
   return g;
 }

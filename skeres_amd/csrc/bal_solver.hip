@@ -95,6 +95,8 @@ class BalSolver : public SolverBase {
   DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_fail_, b_info_;
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
+  DevBuf<double> b_w_;
+  CholeskyContext chol_ctx_;
   double* h_scal_ = nullptr;  // pinned
   int partial_stride_ = 0;
  public:
@@ -195,6 +197,8 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_fail_.alloc(1)); SK_HIP_TRY(b_fail_.zero(s)); SK_HIP_TRY(b_info_.alloc(1)); SK_HIP_TRY(b_info_.zero(s));
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
   SK_HIP_TRY(cholesky_init());
+  SK_HIP_TRY(b_w_.alloc(npad_));
+  if (opt_.lookahead) SK_HIP_TRY(chol_ctx_.init());
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p;
@@ -301,8 +305,8 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
   launch_bal_finish_S(b_S_.p, npad_, n_, npad_, rhs_row_, d_.D_c, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
-  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.cholesky_group, s, &kt_);
-  cholesky_backsolve(b_S_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_y_.p, s, &kt_);
+  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.cholesky_group, s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_);
+  cholesky_backsolve(b_S_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_);
   SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----
   launch_bal_cam_step(d_, b_scal_.p + 8, s);

@@ -219,6 +219,12 @@ SK_SET_D(max_lm_diagonal, max_lm_diagonal)
 int sk_options_set_jacobi_scaling(sk_options* o, int on) { o->o.jacobi_scaling = on != 0; return SK_OK; }
 int sk_options_set_max_num_consecutive_invalid_steps(sk_options* o, int n) { if (n < 1) { set_error("must be >= 1"); return SK_ERR_INVALID_ARGUMENT; } o->o.max_num_consecutive_invalid_steps = n; return SK_OK; }
 int sk_options_set_device(sk_options* o, int dev) { o->o.device = dev; return SK_OK; }
+int sk_options_set_cholesky_tuning(sk_options* o, int group, int lookahead) {
+  if (group > 64) { set_error("group must be <= 64"); return SK_ERR_INVALID_ARGUMENT; }
+  if (group > 0) o->o.cholesky_group = group;
+  o->o.lookahead = lookahead != 0;
+  return SK_OK;
+}
 int sk_options_set_stream(sk_options* o, void* stream) { o->o.stream = (hipStream_t)stream; o->o.stream_set = true; return SK_OK; }
 int sk_options_set_distributed(sk_options* o, int rank, int world, sk_allreduce_fn fn, void* user) {
   if (world < 1 || rank < 0 || rank >= world) { set_error("invalid rank/world %d/%d", rank, world); return SK_ERR_INVALID_ARGUMENT; }
@@ -358,10 +364,18 @@ int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double
   DevBuf<double> dS, dLinv, dy; DevBuf<int> dinfo;
   hipStream_t s = nullptr;
   SK_HIP_TRY(dS.upload(S, s)); SK_HIP_TRY(dLinv.alloc((size_t)npad * 128)); SK_HIP_TRY(dLinv.zero(s));
-  SK_HIP_TRY(dy.alloc(npad)); SK_HIP_TRY(dinfo.alloc(1)); SK_HIP_TRY(dinfo.zero(s));
+  DevBuf<double> dw;
+  SK_HIP_TRY(dy.alloc(npad)); SK_HIP_TRY(dw.alloc(npad)); SK_HIP_TRY(dinfo.alloc(1)); SK_HIP_TRY(dinfo.zero(s));
   SK_HIP_TRY(cholesky_init());
-  cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, nullptr);
-  cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dy.p, s, nullptr);
+  CholeskyContext ctx;  // exercise the look-ahead path the solver uses
+  SK_HIP_TRY(ctx.init());
+  SK_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  SK_HIP_TRY(hipDeviceSynchronize());  // uploads above ran on the null stream
+  cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, &ctx, nullptr);
+  cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dw.p, dy.p, s, nullptr);
+  SK_HIP_TRY(hipStreamSynchronize(s));
+  SK_HIP_TRY(hipStreamDestroy(s));
+  s = nullptr;
   SK_HIP_TRY(hipStreamSynchronize(s));
   int info = 0;
   SK_HIP_TRY(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));

@@ -34,12 +34,15 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 static constexpr int kBK = 16;
 static constexpr int kLd = 18;  // LDS row stride in doubles
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(double* C, long ldc, const double* A, long lda,
-                                                               const double* B, long ldb,
-                                                               int K, int tiles_m, int tri, int mode) {
+// kShape: 0 rectangular grid (tiles_m x tiles_n), 1 lower-triangular tile enumeration,
+//         2 rectangular grid that skips tiles strictly above the diagonal (ti < tj)
+template <int kMode, int kShape>
+__device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
+                                                 int tiles_m, int skip_upper) {
+  constexpr int mode = kMode;
   __shared__ __attribute__((aligned(16))) double sh[2][2][128 * kLd];
   int ti, tj;
-  if (tri) {
+  if (kShape == 1) {
     const int b = blockIdx.x;
     int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((r + 1) * (r + 2) / 2 <= b) ++r;
@@ -47,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(double* C, long ldc
     ti = r; tj = b - r * (r + 1) / 2;
   } else {
     ti = blockIdx.x % tiles_m; tj = blockIdx.x / tiles_m;
+    if (skip_upper && ti < tj) return;
   }
   const double* Ag = A + (long)ti * 128 * lda;
   const double* Bg = B + (long)tj * 128 * ldb;
@@ -120,6 +124,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(double* C, long ldc
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         Cg[(long)(wr * 64 + mt * 16 + l4 + 4 * i) * ldc + wc * 64 + nt * 16 + l15] = sgn * acc[mt][nt][i];
+}
+
+// The three uses get their own kernel symbols so profiles separate them.
+// Trailing SYRK of the blocked Cholesky (the dominant kernel): lower-triangular tiles, C -= A A^T.
+__global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K) {
+  gemm_nt_f64_body<0, 1>(C, ldc, A, lda, A, lda, K, 0, 0);
+}
+// Panel updates (lazy left-looking update of a block column; look-ahead part of the SYRK): C -= A B^T.
+__global__ __launch_bounds__(256, 2) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
+                                                                 long ldb, int K, int tiles_m, int skip_upper) {
+  gemm_nt_f64_body<0, 0>(C, ldc, A, lda, B, ldb, K, tiles_m, skip_upper);
+}
+// TRSM as a GEMM with the inverted diagonal block: C = A Linv^T (in place, C == A).
+__global__ __launch_bounds__(256, 2) void trsm_gemm_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
+                                                               int tiles_m) {
+  gemm_nt_f64_body<1, 0>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -324,30 +344,45 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 }
 
 // ---------------------------------------------------------------------------
-// Backward substitution L^T y = z over 128-blocks, last block first.
-//   bs_diag  : y_kb = Linv_kb^T w_kb                      (one workgroup)
-//   bs_update: w[c] -= sum_r L[kb*128+r][c] y_kb[r], c < kb*128
+// Backward substitution L^T y = z over 128-blocks, last block first; one
+// launch per block step kb:
+//   y_kb = Linv_kb^T w_kb                      (every workgroup, redundantly: L2-resident 128 KB)
+//   w[c] -= sum_r L[kb*128+r][c] y_kb[r]       (c < kb*128; 256 columns per workgroup)
+// 1024 threads so that each lane has only a few dependent HBM/L2 round trips.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void bs_diag_kernel(const double* __restrict__ Linv, double* __restrict__ y) {
-  __shared__ double w[128];
-  const int c = threadIdx.x;
-  w[c] = y[c];
+__global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict__ Linv, const double* __restrict__ Lrow, long ld,
+                                                        double* __restrict__ w, double* __restrict__ yout, int kb, int ncols) {
+  __shared__ double wk[128], ykb[128], part[8][128], red[4][256];
+  const int t = threadIdx.x;
+  if (t < 128) wk[t] = w[kb * 128 + t];
   __syncthreads();
-  double s = 0.0;
-  for (int r = c; r < 128; ++r) s += Linv[(long)r * 128 + c] * w[r];
-  y[c] = s;
-}
-__global__ __launch_bounds__(256) void bs_update_kernel(const double* __restrict__ Lrow, long ld, const double* __restrict__ ykb,
-                                                         double* __restrict__ w, int ncols) {
-  __shared__ double ys[128];
-  if (threadIdx.x < 128) ys[threadIdx.x] = ykb[threadIdx.x];
+  {
+    const int c = t & 127, g = t >> 7;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int r = g * 16 + i; s += Linv[(long)r * 128 + c] * wk[r]; }
+    part[g][c] = s;
+  }
   __syncthreads();
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncols) return;
+  if (t < 128) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += part[g][t];
+    ykb[t] = s;
+    if (blockIdx.x == 0) yout[kb * 128 + t] = s;
+  }
+  __syncthreads();
+  const int cl = t & 255, rg = t >> 8;
+  const int col = blockIdx.x * 256 + cl;
   double s = 0.0;
+  if (col < ncols) {
+    const double* p = Lrow + (long)(rg * 32) * ld + col;
 #pragma unroll 8
-  for (int r = 0; r < 128; ++r) s += Lrow[(long)r * ld + c] * ys[r];
-  w[c] -= s;
+    for (int i = 0; i < 32; ++i) s += p[(long)i * ld] * ykb[rg * 32 + i];
+  }
+  red[rg][cl] = s;
+  __syncthreads();
+  if (t < 256 && col < ncols) w[col] -= (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
 __global__ void copy_row_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int npad) {
@@ -358,15 +393,6 @@ __global__ void copy_row_kernel(const double* __restrict__ src, double* __restri
 // ---------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------
-static void launch_gemm(double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
-                        int tiles_m, int tiles_n, bool tri, int mode, hipStream_t s, KernelTimer* kt, const char* name) {
-  const int nblocks = tri ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
-  if (nblocks <= 0) return;
-  if (kt) kt->begin(name, s);
-  hipLaunchKernelGGL(gemm_nt_f64_kernel, dim3(nblocks), dim3(256), 0, s, C, ldc, A, lda, B, ldb, K, tiles_m, tri ? 1 : 0, mode);
-  if (kt) kt->end(name, s);
-}
-
 size_t potrf128_lds_bytes() { return (size_t)(10 + 4) * kB * kBs * sizeof(double); }
 
 hipError_t cholesky_init() {
@@ -374,61 +400,121 @@ hipError_t cholesky_init() {
                              (int)potrf128_lds_bytes());
 }
 
-// Factor S (npad x ld, lower) in place.  Linv: nblk x 128 x 128 (pre-zeroed once).
-void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, KernelTimer* kt) {
-  const int nblk = npad / 128;
-  int k0 = 0;
-  for (int kb = 0; kb < nblk; ++kb) {
-    double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
-    const int rows_below = nblk - kb - 1;
-    if (kb > k0)  // (1) lazy update of block column kb (diagonal block included) from columns [k0, kb)
-      launch_gemm(Akk, ld, S + (long)kb * 128 * ld + (long)k0 * 128, ld, S + (long)kb * 128 * ld + (long)k0 * 128, ld,
-                  (kb - k0) * 128, rows_below + 1, 1, false, 0, s, kt, "gemm_panel_update");
-    if (kt) kt->begin("potrf128", s);
-    hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), s, Akk, ld, Linv + (long)kb * 128 * 128, info);
-    if (kt) kt->end("potrf128", s);
-    if (rows_below > 0) {
-      double* A21 = Akk + 128 * ld;
-      launch_gemm(A21, ld, A21, ld, Linv + (long)kb * 128 * 128, 128, 128, rows_below, 1, false, 1, s, kt, "gemm_trsm");
-      if (kb + 1 - k0 == group || kb + 1 == nblk) {
-        // right-looking SYRK of the trailing matrix with the whole group, K = (kb+1-k0)*128
-        double* A22 = S + (long)(kb + 1) * 128 * ld + (long)(kb + 1) * 128;
-        const double* P = S + (long)(kb + 1) * 128 * ld + (long)k0 * 128;
-        launch_gemm(A22, ld, P, ld, P, ld, (kb + 1 - k0) * 128, rows_below, rows_below, true, 0, s, kt, "gemm_syrk");
-        k0 = kb + 1;
-      }
-    }
-  }
+CholeskyContext::~CholeskyContext() {
+  for (hipEvent_t e : events) (void)hipEventDestroy(e);
+  if (chain) (void)hipStreamDestroy(chain);
 }
 
-// y (npad) <- solution of L^T y = z, with z^T = row rhs_row of L (first n entries).
-void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* y, hipStream_t s,
-                        KernelTimer* kt) {
+hipError_t CholeskyContext::init() {
+  if (chain) return hipSuccess;
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) return e;
+  return hipStreamCreateWithPriority(&chain, hipStreamNonBlocking, greatest);
+}
+
+hipEvent_t CholeskyContext::event(size_t i) {
+  while (events.size() <= i) {
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    events.push_back(e);
+  }
+  return events[i];
+}
+
+// Factor the lower triangle of S (npad x ld) in place.  Linv: nblk blocks of 128x128
+// (zero-initialised once).  With a context the panel chain of group g+1 (lazy
+// update, potrf128, TRSM — latency-bound, few workgroups) runs on a high-priority
+// helper stream WHILE the bulk of group g's trailing SYRK runs on `s` (look-ahead):
+//   chain : [panel ops of group g] -> SYRK part (a): the next group's block columns
+//   s     : SYRK part (b): everything right of them
+// (a)[g] waits for (b)[g-1] (same tiles), (b)[g] waits for the panel ops of group g.
+void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
+                     KernelTimer* kt) {
   const int nblk = npad / 128;
-  hipLaunchKernelGGL(copy_row_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, y, n, npad);
+  const bool la = ctx != nullptr && ctx->chain != nullptr;
+  hipStream_t sc = la ? ctx->chain : s;
+  size_t ev = 0;
+  if (la) { hipEvent_t e = ctx->event(ev++); (void)hipEventRecord(e, s); (void)hipStreamWaitEvent(sc, e, 0); }
+  hipEvent_t ev_b_prev = nullptr;
+  for (int k0 = 0; k0 < nblk; k0 += group) {
+    const int k1 = k0 + group < nblk ? k0 + group : nblk;
+    for (int kb = k0; kb < k1; ++kb) {
+      double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
+      const int rows_below = nblk - kb - 1;
+      if (kb > k0) {  // lazy update of block column kb (diagonal block included) from columns [k0, kb)
+        const double* P = S + (long)kb * 128 * ld + (long)k0 * 128;
+        if (kt) kt->begin("gemm_panel_update", sc);
+        hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(rows_below + 1), dim3(256), 0, sc, Akk, ld, P, ld, P, ld, (kb - k0) * 128,
+                           rows_below + 1, 0);
+        if (kt) kt->end("gemm_panel_update", sc);
+      }
+      if (kt) kt->begin("potrf128", sc);
+      hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), sc, Akk, ld, Linv + (long)kb * 128 * 128, info);
+      if (kt) kt->end("potrf128", sc);
+      if (rows_below > 0) {
+        double* A21 = Akk + 128 * ld;
+        if (kt) kt->begin("gemm_trsm", sc);
+        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(rows_below), dim3(256), 0, sc, A21, ld, A21, ld, Linv + (long)kb * 128 * 128, rows_below);
+        if (kt) kt->end("gemm_trsm", sc);
+      }
+    }
+    const int T = nblk - k1;  // trailing tile rows
+    if (T <= 0) break;
+    const int K = (k1 - k0) * 128;
+    const int na = group < T ? group : T;  // tile columns of the next group
+    double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
+    const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
+    hipEvent_t ev_chain = nullptr;
+    if (la) {
+      ev_chain = ctx->event(ev++);
+      (void)hipEventRecord(ev_chain, sc);
+      if (ev_b_prev) (void)hipStreamWaitEvent(sc, ev_b_prev, 0);
+    }
+    // (a) next group's block columns: T x na tiles, tiles above the diagonal skipped
+    if (kt) kt->begin("gemm_syrk_next", sc);
+    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(T * na), dim3(256), 0, sc, A22, ld, P, ld, P, ld, K, T, 1);
+    if (kt) kt->end("gemm_syrk_next", sc);
+    // (b) the rest: lower triangle of the (T-na) x (T-na) tiles starting at block k1+na
+    const int Tb = T - na;
+    if (Tb > 0) {
+      if (la) (void)hipStreamWaitEvent(s, ev_chain, 0);
+      double* Cb = S + (long)(k1 + na) * 128 * ld + (long)(k1 + na) * 128;
+      const double* Pb = S + (long)(k1 + na) * 128 * ld + (long)k0 * 128;
+      if (kt) kt->begin("gemm_syrk", s);
+      hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, s, Cb, ld, Pb, ld, K);
+      if (kt) kt->end("gemm_syrk", s);
+      if (la) { ev_b_prev = ctx->event(ev++); (void)hipEventRecord(ev_b_prev, s); }
+    }
+  }
+  if (la) { hipEvent_t e = ctx->event(ev++); (void)hipEventRecord(e, sc); (void)hipStreamWaitEvent(s, e, 0); }
+}
+
+// y (npad) <- solution of L^T y = z, with z^T = row rhs_row of L (first n entries).  w: scratch (npad).
+void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
+                        hipStream_t s, KernelTimer* kt) {
+  const int nblk = npad / 128;
+  hipLaunchKernelGGL(copy_row_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, n, npad);
   if (kt) kt->begin("backsolve", s);
   for (int kb = nblk - 1; kb >= 0; --kb) {
-    hipLaunchKernelGGL(bs_diag_kernel, dim3(1), dim3(128), 0, s, Linv + (long)kb * 128 * 128, y + kb * 128);
-    if (kb > 0) {
-      const int ncols = kb * 128;
-      hipLaunchKernelGGL(bs_update_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, S + (long)kb * 128 * ld, ld, y + kb * 128, y, ncols);
-    }
+    const int ncols = kb * 128;
+    const int grid = ncols > 0 ? (ncols + 255) / 256 : 1;
+    hipLaunchKernelGGL(bs_step_kernel, dim3(grid), dim3(1024), 0, s, Linv + (long)kb * 128 * 128, S + (long)kb * 128 * ld, ld, w, y, kb, ncols);
   }
   if (kt) kt->end("backsolve", s);
 }
 
+// Algorithmic flops of the dominant kernel's launches (part (b) of each trailing SYRK:
+// lower-triangular 128x128 tiles incl. the diagonal tiles, 2*128*128*K each).
 double cholesky_syrk_flops(int npad, int group) {
-  // algorithmic flops of the trailing SYRK launches: lower-triangular tiles incl. the diagonal tiles
   const int nblk = npad / 128;
   double f = 0.0;
-  int k0 = 0;
-  for (int kb = 0; kb < nblk; ++kb) {
-    const int rows_below = nblk - kb - 1;
-    if (rows_below > 0 && (kb + 1 - k0 == group || kb + 1 == nblk)) {
-      const double tiles = 0.5 * rows_below * (rows_below + 1.0);
-      f += tiles * 2.0 * 128.0 * 128.0 * (double)((kb + 1 - k0) * 128);
-      k0 = kb + 1;
-    }
+  for (int k0 = 0; k0 < nblk; k0 += group) {
+    const int k1 = k0 + group < nblk ? k0 + group : nblk;
+    const int T = nblk - k1;
+    if (T <= 0) break;
+    const int na = group < T ? group : T, Tb = T - na;
+    f += 0.5 * Tb * (Tb + 1.0) * 2.0 * 128.0 * 128.0 * (double)((k1 - k0) * 128);
   }
   return f;
 }

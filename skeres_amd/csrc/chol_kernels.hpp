@@ -67,13 +67,24 @@ class KernelTimer {
   std::map<std::string, Stat> stats_;
 };
 
+// Helper stream (highest priority) + events for the look-ahead of cholesky_factor.
+struct CholeskyContext {
+  hipStream_t chain = nullptr;
+  std::vector<hipEvent_t> events;
+  hipError_t init();
+  hipEvent_t event(size_t i);
+  ~CholeskyContext();
+};
+
 hipError_t cholesky_init();
 size_t potrf128_lds_bytes();
 // Factor the lower triangle of S (npad x ld, npad % 128 == 0) in place.
 // Linv: (npad/128) blocks of 128x128, zero-initialised once by the caller.
-void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, KernelTimer* kt);
-void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* y, hipStream_t s,
-                        KernelTimer* kt);
+// ctx == nullptr: everything on `s`; otherwise the panel chain overlaps the trailing SYRK.
+void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
+                     KernelTimer* kt);
+void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
+                        hipStream_t s, KernelTimer* kt);
 double cholesky_syrk_flops(int npad, int group);
 
 }  // namespace sk

@@ -104,6 +104,7 @@ struct Options {  // Solver.Options; Ceres 1.x defaults
   void* reduce_buffer = nullptr;
   size_t reduce_buffer_bytes = 0;
   int cholesky_group = 4;  // SYRK K = group * 128
+  bool lookahead = true;   // overlap the Cholesky panel chain with the trailing SYRK (second stream)
 };
 
 struct IterationLog {

@@ -44,6 +44,7 @@ class DenseSolver : public SolverBase {
   std::vector<int> cb_blocks_;
   std::vector<int> res_off_h_;
   DevBuf<double> b_consts_, b_xa_, b_xb_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_, b_r_, b_rc_, b_J_, b_H_, b_Linv_, b_A_, b_b_, b_scal_;
+  DevBuf<double> b_w_;
   DevBuf<size_t> b_const_off_, b_pidx_off_;
   DevBuf<int> b_pidx_, b_res_off_, b_fail_, b_info_, b_ok_;
   double* x_ = nullptr; double* x_new_ = nullptr;
@@ -87,7 +88,7 @@ int DenseSolver::setup() {
   } else {
     SK_HIP_TRY(b_A_.alloc((size_t)(m_ + n_) * n_)); SK_HIP_TRY(b_b_.alloc(m_ + n_));
   }
-  SK_HIP_TRY(b_y_.alloc(npad_)); SK_HIP_TRY(b_scal_.alloc(16));
+  SK_HIP_TRY(b_y_.alloc(npad_)); SK_HIP_TRY(b_w_.alloc(npad_)); SK_HIP_TRY(b_scal_.alloc(16));
   SK_HIP_TRY(b_fail_.alloc(1)); SK_HIP_TRY(b_fail_.zero(s)); SK_HIP_TRY(b_info_.alloc(1)); SK_HIP_TRY(b_info_.zero(s)); SK_HIP_TRY(b_ok_.alloc(1));
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
   SK_HIP_TRY(hipStreamSynchronize(s));
@@ -183,8 +184,8 @@ int DenseSolver::try_step(double radius, bool* valid, double* mcc, double* new_c
     launch_dense_normal(b_J_.p, b_r_.p, m_, n_, b_H_.p, npad_, rhs_row_, s);
     launch_bal_finish_S(b_H_.p, npad_, n_, npad_, rhs_row_, b_D_.p, s);
     SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
-    cholesky_factor(b_H_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.cholesky_group, s, &kt_);
-    cholesky_backsolve(b_H_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_y_.p, s, &kt_);
+    cholesky_factor(b_H_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.cholesky_group, s, nullptr, &kt_);
+    cholesky_backsolve(b_H_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_);
   } else {
     SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
     launch_dense_qr(b_J_.p, b_r_.p, b_D_.p, m_, n_, b_A_.p, b_b_.p, b_y_.p, b_ok_.p, s);

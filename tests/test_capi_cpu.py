@@ -164,16 +164,16 @@ def test_point_partition_covers_every_point_once_and_balances_squares():
 
 # ---- BAL text format (SimpleBundleAdjuster.scala:37-76) ---------------------------------
 def test_bal_text_round_trip(tmp_path):
-    prob = bal.generate(3, 12, 40, seed=1)
+    prob = bal.generate(3, 12, 30, seed=1)
     path = tmp_path / "problem.txt"
     prob.to_file(str(path))
     back = bal.BalProblem.from_file(str(path))
-    assert (back.num_cameras, back.num_points, back.num_observations) == (3, 12, 40)
+    assert (back.num_cameras, back.num_points, back.num_observations) == (3, 12, 30)
     assert np.array_equal(back.camera_index, prob.camera_index) and np.array_equal(back.point_index, prob.point_index)
     np.testing.assert_array_equal(back.observations, prob.observations)
     np.testing.assert_array_equal(back.parameters, prob.parameters)
     first = open(path).readline().split()
-    assert first == ["3", "12", "40"]
+    assert first == ["3", "12", "30"]
 
 
 def test_generator_shapes_are_exact_and_visible():

@@ -12,8 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import skeres_amd as sk  # noqa: E402
 from skeres_amd import bal  # noqa: E402
 
-KERNELS = ["bal_eval_jac", "memset_S", "bal_cam_diag", "bal_pair", "gemm_panel_update", "potrf128", "gemm_trsm", "gemm_syrk",
-           "backsolve", "bal_eval_cost"]
+KERNELS = ["bal_eval_jac", "memset_S", "bal_cam_diag", "bal_pair", "gemm_panel_update", "potrf128", "gemm_trsm", "gemm_syrk_next",
+           "gemm_syrk", "backsolve", "bal_eval_cost"]
 
 
 def main():
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--perturb", type=float, nargs=3, default=[5e-2, 5e-1, 5e-1])
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--group", type=int, default=0)
+    ap.add_argument("--no-lookahead", action="store_true")
     args = ap.parse_args()
     prob = bal.generate_named(args.workload, seed=1723, perturb=tuple(args.perturb))
     params = sk.RichDoubleArray.fromArray(prob.parameters)
@@ -34,6 +35,7 @@ def main():
     o.setFunctionTolerance(0.0)
     o.setGradientTolerance(0.0)
     o.setParameterTolerance(0.0)
+    o.setCholeskyTuning(args.group, not args.no_lookahead)
     t0 = time.time()
     s = sk.StepSolver(o, problem)
     print("setup + iteration 0: %.2f s" % (time.time() - t0))
