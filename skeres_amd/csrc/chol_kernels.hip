@@ -31,16 +31,20 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // conflict-free ds_read_b64 for the MFMA operand pattern), global loads of the
 // next step in flight during the MFMAs of the current one.
 // ---------------------------------------------------------------------------
-static constexpr int kBK = 16;
-static constexpr int kLd = 18;  // LDS row stride in doubles
-
-// kShape: 0 rectangular grid (tiles_m x tiles_n), 1 lower-triangular tile enumeration,
-//         2 rectangular grid that skips tiles strictly above the diagonal (ti < tj)
-template <int kMode, int kShape>
+// kShape: 0 rectangular grid (tiles_m x tiles_n; skip_upper drops tiles with ti < tj),
+//         1 lower-triangular tile enumeration.
+// kBKT  : K-step width (16 or 32 doubles); LDS row stride kBKT + 2 keeps ds_read_b64 conflict-free.
+// kPF   : prefetch distance in K-steps (register sets in flight).  The throughput kernel (SYRK,
+//         thousands of workgroups, 2 per CU) uses <16, 1>; the latency-bound panel kernels (a few
+//         dozen workgroups, nothing else on the CU to hide an HBM round trip) use <32, 2>.
+template <int kMode, int kShape, int kBKT, int kPF>
 __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
                                                  int tiles_m, int skip_upper) {
   constexpr int mode = kMode;
-  __shared__ __attribute__((aligned(16))) double sh[2][2][128 * kLd];
+  constexpr int kLdT = kBKT + 2;        // LDS row stride in doubles
+  constexpr int kCh = kBKT / 4;         // 16-byte chunks per thread, operand and stage
+  constexpr int kRowStep = 512 / kBKT;  // rows covered by the 256 threads per chunk index
+  __shared__ __attribute__((aligned(16))) double sh[2][2][128 * kLdT];
   int ti, tj;
   if (kShape == 1) {
     const int b = blockIdx.x;
@@ -76,44 +80,60 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
   }
 
-  // staging: chunk q = i*256 + t -> row q>>3, 16-byte column chunk q&7
-  double2 ra[4], rb[4];
-  const int srow = t >> 3, sc = (t & 7) * 2;
-#define SK_LOAD_STAGE(kbase)                                                            \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-    ra[i] = *reinterpret_cast<const double2*>(Ag + (long)(i * 32 + srow) * lda + (kbase) + sc); \
-    rb[i] = *reinterpret_cast<const double2*>(Bg + (long)(i * 32 + srow) * ldb + (kbase) + sc); \
+  // staging: chunk q = i*256 + t -> row q / (kBKT/2), 16-byte column chunk q % (kBKT/2): every
+  // wave-level load covers whole 128-B (kBKT = 16) or 256-B (kBKT = 32) row segments
+  typedef double dstage __attribute__((ext_vector_type(2 * kCh)));  // one operand stage of a lane: SSA vector, never an alloca
+  dstage ra0, rb0, ra1, rb1;
+  const int srow = t / (kBKT / 2), sc = (t % (kBKT / 2)) * 2;
+#define SK_LOAD_STAGE(set, kbase)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < kCh; ++i) {                                                        \
+    { const double2 v_ = *reinterpret_cast<const double2*>(Ag + (long)(i * kRowStep + srow) * lda + (kbase) + sc); ra##set[2 * i] = v_.x; ra##set[2 * i + 1] = v_.y; } \
+    { const double2 v_ = *reinterpret_cast<const double2*>(Bg + (long)(i * kRowStep + srow) * ldb + (kbase) + sc); rb##set[2 * i] = v_.x; rb##set[2 * i + 1] = v_.y; } \
   }
-#define SK_STORE_STAGE(buf)                                                              \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
-    *reinterpret_cast<double2*>(&sh[buf][0][(i * 32 + srow) * kLd + sc]) = ra[i];        \
-    *reinterpret_cast<double2*>(&sh[buf][1][(i * 32 + srow) * kLd + sc]) = rb[i];        \
+#define SK_STORE_STAGE(set, buf)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < kCh; ++i) {                                                 \
+    *reinterpret_cast<double2*>(&sh[buf][0][(i * kRowStep + srow) * kLdT + sc]) = make_double2(ra##set[2 * i], ra##set[2 * i + 1]); \
+    *reinterpret_cast<double2*>(&sh[buf][1][(i * kRowStep + srow) * kLdT + sc]) = make_double2(rb##set[2 * i], rb##set[2 * i + 1]); \
   }
-  const int nk = K / kBK;
-  SK_LOAD_STAGE(0)
-  SK_STORE_STAGE(0)
+  const int nk = K / kBKT;  // a multiple of kPF (K is a multiple of 128)
+  SK_LOAD_STAGE(0, 0)
+  if (kPF == 2) { SK_LOAD_STAGE(1, (nk > 1 ? 1 : 0) * kBKT) }
+  SK_STORE_STAGE(0, 0)
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    // prefetch the next K-step (the last iteration re-reads its own step: no branch, no effect)
-    const int knext = (kt + 1 < nk ? kt + 1 : kt) * kBK;
-    SK_LOAD_STAGE(knext)
-    const double* sa = &sh[buf][0][(wr * 64 + l15) * kLd + l4];
-    const double* sb = &sh[buf][1][(wc * 64 + l15) * kLd + l4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double a[4], b[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) { a[m] = sa[m * 16 * kLd + kk * 4]; b[m] = sb[m * 16 * kLd + kk * 4]; }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-    }
-    SK_STORE_STAGE(buf ^ 1)
-    __syncthreads();
+  // one K-step: register set SETL held K-step kt, which is already in LDS: refill it with K-step
+  // kt + kPF (clamped at the end: re-reads the last step, no branch, no effect); compute K-step kt;
+  // then K-step kt + 1 (set SETS, loaded kPF iterations ago) goes to the other LDS buffer.
+#define SK_LOAD_STAGE_X(set, kbase) SK_LOAD_STAGE(set, kbase)
+#define SK_STORE_STAGE_X(set, buf) SK_STORE_STAGE(set, buf)
+#define SK_KSTEP(kt, SETL, SETS)                                                                   \
+  {                                                                                                \
+    const int buf = (kt) & 1;                                                                      \
+    const int knext = ((kt) + kPF < nk ? (kt) + kPF : nk - 1) * kBKT;                              \
+    SK_LOAD_STAGE_X(SETL, knext)                                                                   \
+    const double* sa = &sh[buf][0][(wr * 64 + l15) * kLdT + l4];                                   \
+    const double* sb = &sh[buf][1][(wc * 64 + l15) * kLdT + l4];                                   \
+    _Pragma("unroll") for (int kk = 0; kk < kBKT / 4; ++kk) {                                      \
+      double a[4], b[4];                                                                           \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m) { a[m] = sa[m * 16 * kLdT + kk * 4]; b[m] = sb[m * 16 * kLdT + kk * 4]; } \
+      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                             \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                           \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);  \
+    }                                                                                              \
+    SK_STORE_STAGE_X(SETS, buf ^ 1)                                                                \
+    __syncthreads();                                                                               \
   }
+  if (kPF == 1) {
+    for (int kt = 0; kt < nk; ++kt) SK_KSTEP(kt, 0, 0)
+  } else {
+    for (int kt = 0; kt < nk; kt += 2) {
+      SK_KSTEP(kt, 0, 1)
+      SK_KSTEP(kt + 1, 1, 0)
+    }
+  }
+#undef SK_KSTEP
+#undef SK_LOAD_STAGE_X
+#undef SK_STORE_STAGE_X
+  (void)ra1; (void)rb1;
 #undef SK_LOAD_STAGE
 #undef SK_STORE_STAGE
   const double sgn = mode == 0 ? -1.0 : 1.0;
@@ -129,17 +149,17 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
 // The three uses get their own kernel symbols so profiles separate them.
 // Trailing SYRK of the blocked Cholesky (the dominant kernel): lower-triangular tiles, C -= A A^T.
 __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K) {
-  gemm_nt_f64_body<0, 1>(C, ldc, A, lda, A, lda, K, 0, 0);
+  gemm_nt_f64_body<0, 1, 16, 1>(C, ldc, A, lda, A, lda, K, 0, 0);
 }
 // Panel updates (lazy left-looking update of a block column; look-ahead part of the SYRK): C -= A B^T.
-__global__ __launch_bounds__(256, 2) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
+__global__ __launch_bounds__(256, 1) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
                                                                  long ldb, int K, int tiles_m, int skip_upper) {
-  gemm_nt_f64_body<0, 0>(C, ldc, A, lda, B, ldb, K, tiles_m, skip_upper);
+  gemm_nt_f64_body<0, 0, 32, 2>(C, ldc, A, lda, B, ldb, K, tiles_m, skip_upper);
 }
 // TRSM as a GEMM with the inverted diagonal block: C = A Linv^T (in place, C == A).
-__global__ __launch_bounds__(256, 2) void trsm_gemm_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
+__global__ __launch_bounds__(256, 1) void trsm_gemm_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
                                                                int tiles_m) {
-  gemm_nt_f64_body<1, 0>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0);
+  gemm_nt_f64_body<1, 0, 32, 2>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -158,9 +178,25 @@ __device__ __forceinline__ int blk_off(int bi, int bj) { return (bi * (bi + 1) /
 // Lane l works on row l & 31 (lanes 32..63 mirror 0..31: same values to the
 // same addresses).  Cross-lane values travel through LDS broadcast reads
 // (uniform address), which a single wave sees in program order.
-__device__ __forceinline__ void wave_potrf32_inv(double* D, double* colbuf, double (&a)[32], bool* ok) {
+// 1/sqrt(x) for the pivots: hardware estimate + two Newton steps (full fp64
+// accuracy to ~1 ulp), far shorter than sqrt followed by a division on the
+// 128-deep serial chain of a diagonal block.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double h = 0.5 * x;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+
+// One wave: factor the 32x32 block D (LDS, row stride kBs) in place, D <- L
+// (lower, zeros above the diagonal), rinv[j] = 1 / L(j,j).  The row of L each
+// lane computed is returned in `a` for the write-back to global memory.
+// Lane l works on row l & 31 (lanes 32..63 mirror 0..31: same values to the
+// same addresses).  Cross-lane values travel through LDS broadcast reads
+// (uniform address), which a single wave sees in program order.
+__device__ __forceinline__ void wave_potrf32(double* D, double* colbuf, double* rinv, double (&a)[32], bool* ok) {
   const int row = threadIdx.x & 31;
-  double rinv[32];
   bool good = true;
 #pragma unroll
   for (int c = 0; c < 32; ++c) a[c] = D[row * kBs + c];
@@ -170,29 +206,45 @@ __device__ __forceinline__ void wave_potrf32_inv(double* D, double* colbuf, doub
     __builtin_amdgcn_wave_barrier();
     const double djj = colbuf[j];
     good = good && (djj > 0.0);
-    const double ri = 1.0 / sqrt(djj);
-    rinv[j] = ri;
+    const double ri = fast_rsqrt(djj);
+    rinv[j] = ri;  // every lane stores the same value: a branch here would split the unrolled chain into 32 blocks (spills)
     a[j] = a[j] * ri;  // column j of L (row j: sqrt(djj))
 #pragma unroll
     for (int c = j + 1; c < 32; ++c) a[c] -= a[j] * (colbuf[c] * ri);
     __builtin_amdgcn_wave_barrier();
+    // one scheduling region per column: without it the fully unrolled chain is scheduled as one
+    // block, the scheduler hoists across columns and the kernel spills past 512 registers
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int c = 0; c < 32; ++c) D[row * kBs + c] = a[c];
-  __builtin_amdgcn_wave_barrier();
-  // inverse: lane c solves L x = e_c ; L(i,t) is a broadcast read
-  double x[32];
+  for (int c = 0; c < 32; ++c) D[row * kBs + c] = c <= row ? a[c] : 0.0;
+  *ok = good;
+}
+
+// Column `col` of the inverse of the lower-triangular 32x32 block D (LDS), by
+// forward substitution; L(i,t) are broadcast reads.  x[i] = 0 for i < col.
+__device__ __forceinline__ void lane_inverse32(const double* D, const double* rinv, int col, double (&x)[32]) {
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
-    double s = (i == row) ? 1.0 : 0.0;
+    double s = (i == col) ? 1.0 : 0.0;
 #pragma unroll
     for (int t = 0; t < i; ++t) s -= D[i * kBs + t] * x[t];
-    x[i] = (i >= row) ? s * rinv[i] : 0.0;
+    x[i] = (i >= col) ? s * rinv[i] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);  // keep the broadcast reads of later rows from being hoisted (register pressure)
   }
-  __builtin_amdgcn_wave_barrier();
+}
+
+// One row of the panel below a factored diagonal block: x L^T = a, i.e.
+// x_j = (a_j - sum_{t<j} x_t L(j,t)) / L(j,j), L(j,t) broadcast from LDS.
+__device__ __forceinline__ void row_trsm32(const double* D, const double* rinv, double (&a)[32]) {
 #pragma unroll
-  for (int i = 0; i < 32; ++i) D[i * kBs + row] = x[i];
-  *ok = good;
+  for (int j = 0; j < 32; ++j) {
+    double s = a[j];
+#pragma unroll
+    for (int t = 0; t < j; ++t) s -= a[t] * D[j * kBs + t];
+    a[j] = s * rinv[j];
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // acc(2x2 MFMA tiles of a 32x32 block) += P Q^T, P/Q 32x32 blocks in LDS (stride kBs)
@@ -237,27 +289,50 @@ __device__ __forceinline__ void block_load32(d4 (&acc)[2][2], const double* src,
 
 __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* T = lds;                        // 10 packed blocks
-  double* tmp = lds + 10 * kB * kBs;      // 4 per-wave 32x32 scratch blocks
+  double* T = lds;                          // 10 packed 32x32 blocks (lower triangle of the tile)
+  double* colbuf = lds + 10 * kB * kBs;     // 64 doubles: column broadcast of the wave-level factorisation
+  double* rinv = colbuf + 64;               // 32 doubles: 1 / L(j,j) of the current diagonal sub-block
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // load lower blocks
-  for (int bi = 0; bi < 4; ++bi)
-    for (int bj = 0; bj <= bi; ++bj) {
-      double* dst = T + blk_off(bi, bj);
-      for (int e = t; e < kB * kB; e += 256) {
-        const int r = e >> 5, c = e & 31;
-        dst[r * kBs + c] = A[(long)(bi * kB + r) * ld + bj * kB + c];
+  // load the lower blocks: all 40 loads of a lane are issued before the first LDS write (one HBM round trip)
+  // element e = t + 256 i of a 32x32 block: per-lane offsets inside a block (global and LDS); the block
+  // offsets are wave-uniform, so only these eight values stay live for the load and the write-backs
+  long goff[4];
+  int loff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = t + 256 * i;
+    goff[i] = (long)(e >> 5) * ld + (e & 31);
+    loff[i] = (e >> 5) * kBs + (e & 31);
+  }
+  {
+    double v[10][4];
+    int b = 0;
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj, ++b) {
+        const double* Ab = A + ((long)bi * kB * ld + bj * kB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[b][i] = Ab[goff[i]];
       }
-    }
+    b = 0;
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int bj = 0; bj <= bi; ++bj, ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T[blk_off(bi, bj) + loff[i]] = v[b][i];
+  }
   __syncthreads();
+#pragma unroll 1
   for (int jb = 0; jb < 4; ++jb) {
-    // (a) diagonal sub-block: factor + invert in registers, wave 0
+    double* D = T + blk_off(jb, jb);
+    // (a) diagonal sub-block: factor, wave 0
     if (wave == 0) {
       double a[32];
-      double* D = T + blk_off(jb, jb);
       const int row = lane & 31;
       bool ok;
-      wave_potrf32_inv(D, tmp, a, &ok);
+      wave_potrf32(D, colbuf, rinv, a, &ok);
       if (!ok && lane == 0) *info = 1;
       if (lane < 32) {
 #pragma unroll
@@ -266,37 +341,36 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
       }
     }
     __syncthreads();
-    // (b) panel: X = T(bi, jb) * InvD^T  for bi > jb  (waves 1..3 -> bi = jb+wave, wave 0 helps when needed)
+    // (b) panel rows below: one lane per row, x L^T = a by forward substitution
     {
-      const double* InvD = T + blk_off(jb, jb);
-      for (int bi = jb + 1 + wave; bi < 4; bi += 4) {
-        d4 acc[2][2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+      const int bi = jb + 1 + (t >> 5), r = t & 31;
+      if (bi < 4) {
+        double a[32];
         double* Xb = T + blk_off(bi, jb);
-        block_mma32<false>(acc, Xb, InvD, lane);
-        // all operand reads of this wave are done before it overwrites its own block
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        block_store32(Xb, acc, lane, 1.0);
-        const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int c = 0; c < 32; ++c) a[c] = Xb[r * kBs + c];
+        row_trsm32(D, rinv, a);
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              A[(long)(bi * kB + mt * 16 + l4 + 4 * i) * ld + jb * kB + nt * 16 + l15] = acc[mt][nt][i];
+        for (int c = 0; c < 32; ++c) Xb[r * kBs + c] = a[c];
       }
     }
     __syncthreads();
-    // (c) trailing update inside the tile: T(bi,bj) -= X_bi X_bj^T, jb < bj <= bi
-    {
+    // (c) trailing update inside the tile on waves 0..2: T(bi,bj) -= X_bi X_bj^T, jb < bj <= bi;
+    //     meanwhile wave 3 replaces L(jb,jb) (no longer needed in LDS) by its inverse, one lane per
+    //     column: every lane finishes its broadcast reads of D before the first write (same wave).
+    if (wave == 3) {
+      double xinv[32];
+      lane_inverse32(D, rinv, lane & 31, xinv);
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) D[i * kBs + lane] = xinv[i];
+      }
+    } else {
       int idx = 0;
       for (int bi = jb + 1; bi < 4; ++bi)
         for (int bj = jb + 1; bj <= bi; ++bj, ++idx) {
-          if ((idx & 3) != wave) continue;
+          if ((idx % 3) != wave) continue;
           d4 acc[2][2];
           double* Cb = T + blk_off(bi, bj);
           block_load32(acc, Cb, lane, -1.0);
@@ -306,9 +380,19 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
     }
     __syncthreads();
   }
-  // LDS now: diagonal blocks = inverses of the diagonal blocks of L,
-  // off-diagonal blocks = L.  Blocked in-place triangular inverse, block
-  // columns right to left:  Inv(bi,bj) = -(sum_{t=bj+1..bi} Inv(bi,t) L(t,bj)) InvD_bj
+  // LDS now: diagonal blocks = inverses of the diagonal blocks of L, off-diagonal blocks = L.
+  // Write the off-diagonal blocks of L back (coalesced, from LDS).
+#pragma unroll
+  for (int bi = 1; bi < 4; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < bi; ++bj) {
+      double* Ab = A + ((long)bi * kB * ld + bj * kB);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Ab[goff[i]] = T[blk_off(bi, bj) + loff[i]];
+    }
+  // Blocked in-place triangular inverse, block columns right to left:
+  //   Inv(bi,bj) = -(sum_{t=bj+1..bi} Inv(bi,t) L(t,bj)) InvD_bj
+  // The product P parks in the destination block itself once every L(t,bj) of the column has been read.
   for (int bj = 2; bj >= 0; --bj) {
     const int bi = bj + 1 + wave;  // one wave per block of this block column
     d4 acc[2][2];
@@ -319,28 +403,33 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
       for (int tt = bj + 1; tt <= bi; ++tt) block_mma32<true>(acc, T + blk_off(bi, tt), T + blk_off(tt, bj), lane);
-      block_store32(tmp + wave * kB * kBs, acc, lane, 1.0);
     }
-    __syncthreads();  // every L(t,bj) of this column has been read
+    __syncthreads();  // every L(t,bj) of this column has been read (and written back above)
     if (active) {
+      double* dstb = T + blk_off(bi, bj);
+      block_store32(dstb, acc, lane, 1.0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
-      block_mma32<true>(acc, tmp + wave * kB * kBs, T + blk_off(bj, bj), lane);
-      block_store32(T + blk_off(bi, bj), acc, lane, -1.0);
+      block_mma32<true>(acc, dstb, T + blk_off(bj, bj), lane);
+      // the MFMA results depend on every read of dstb, so the overwrite below cannot pass them
+      block_store32(dstb, acc, lane, -1.0);
     }
     __syncthreads();
   }
   // write the inverse (lower blocks; diagonal blocks carry explicit zeros above the diagonal)
+#pragma unroll
   for (int bi = 0; bi < 4; ++bi)
-    for (int bj = 0; bj <= bi; ++bj) {
-      const double* src = T + blk_off(bi, bj);
-      for (int e = t; e < kB * kB; e += 256) {
-        const int r = e >> 5, c = e & 31;
-        Linv[(long)(bi * kB + r) * 128 + bj * kB + c] = src[r * kBs + c];
+#pragma unroll
+    for (int bj = 0; bj <= bi; ++bj)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = t + 256 * i;
+        Linv[(bi * kB + (e >> 5)) * 128 + bj * kB + (e & 31)] = T[blk_off(bi, bj) + loff[i]];
       }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -393,7 +482,9 @@ __global__ void copy_row_kernel(const double* __restrict__ src, double* __restri
 // ---------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------
-size_t potrf128_lds_bytes() { return (size_t)(10 + 4) * kB * kBs * sizeof(double); }
+// 84.6 KB: leaves room for one SYRK workgroup (72 KB) on the same CU, so the look-ahead
+// potrf does not have to wait for a CU to drain completely.
+size_t potrf128_lds_bytes() { return (size_t)(10 * kB * kBs + 64 + 32) * sizeof(double); }
 
 hipError_t cholesky_init() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
