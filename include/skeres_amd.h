@@ -203,8 +203,9 @@ int sk_options_set_max_num_consecutive_invalid_steps(sk_options* o, int n);
 int sk_options_set_device(sk_options* o, int hip_device);             /* default: current device */
 int sk_options_set_stream(sk_options* o, void* hip_stream);           /* default: a private stream */
 /* Tuning of the dense Cholesky: `group` = depth of the trailing SYRK in
- * 128-column blocks (K = 128*group; <= 0 keeps the default 4); `lookahead` != 0
- * overlaps the panel factorisation with the trailing update on a second stream. */
+ * 128-column blocks (K = 128*group; <= 0 keeps the default 2); `lookahead` != 0
+ * runs the serial diagonal-block factorisation on a second stream next to the
+ * block-column update / trailing SYRK that does not depend on it. */
 int sk_options_set_cholesky_tuning(sk_options* o, int group, int lookahead);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,
  * one per GPU.  Points (e-blocks) are partitioned over ranks; the
@@ -256,7 +257,9 @@ void sk_solver_free(sk_solver* s);
 int sk_solver_step(sk_solver* s, int* done);
 int sk_solver_finish(sk_solver* s, sk_summary* summary);
 /* Device seconds of kernel `name` accumulated since create, and its launch
- * count (HIP events around every launch when profiling is on). */
+ * count (HIP events around the launches when profiling is on).  on: 0 off,
+ * 1 every named launch (diagnostic: the event packets slow the small kernels
+ * of the panel chain), 2 only the dominant kernel "gemm_syrk". */
 int sk_solver_set_kernel_timing(sk_solver* s, int on);
 double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launches);
 /* Algorithmic flop count of the dense Cholesky's trailing updates per linear

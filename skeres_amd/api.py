@@ -670,7 +670,8 @@ class StepSolver:
         _check(lib().sk_solver_finish(self._h, summary._h))
 
     def setKernelTiming(self, on):
-        lib().sk_solver_set_kernel_timing(self._h, int(bool(on)))
+        """0/False off, 1/True every named launch (diagnostic), 2 only the dominant kernel."""
+        lib().sk_solver_set_kernel_timing(self._h, int(on))
 
     def kernelSeconds(self, name):
         n = C.c_int()

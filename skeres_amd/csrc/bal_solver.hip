@@ -198,7 +198,10 @@ int BalSolver::setup() {
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
   SK_HIP_TRY(cholesky_init());
   SK_HIP_TRY(b_w_.alloc(npad_));
-  if (opt_.lookahead) SK_HIP_TRY(chol_ctx_.init());
+  if (opt_.lookahead && chol_ctx_.init() != hipSuccess) {  // CU-masked streams unavailable: plain in-order factorisation
+    (void)hipGetLastError();
+    opt_.lookahead = false;
+  }
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p;

@@ -307,7 +307,11 @@ int sk_solver_finish(sk_solver* s, sk_summary* summary) {
   return rc;
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }
-int sk_solver_set_kernel_timing(sk_solver* s, int on) { s->impl->kernel_timer().enable(on != 0); return SK_OK; }
+int sk_solver_set_kernel_timing(sk_solver* s, int on) {
+  s->impl->kernel_timer().only(on == 2 ? "gemm_syrk" : "");
+  s->impl->kernel_timer().enable(on != 0);
+  return SK_OK;
+}
 double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launches) {
   KernelTimer::Stat st = s->impl->kernel_timer().get_stat(name);
   if (launches) *launches = st.launches;
@@ -368,10 +372,11 @@ int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double
   SK_HIP_TRY(dy.alloc(npad)); SK_HIP_TRY(dw.alloc(npad)); SK_HIP_TRY(dinfo.alloc(1)); SK_HIP_TRY(dinfo.zero(s));
   SK_HIP_TRY(cholesky_init());
   CholeskyContext ctx;  // exercise the look-ahead path the solver uses
-  SK_HIP_TRY(ctx.init());
+  const bool la = ctx.init() == hipSuccess;
+  if (!la) (void)hipGetLastError();
   SK_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   SK_HIP_TRY(hipDeviceSynchronize());  // uploads above ran on the null stream
-  cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, &ctx, nullptr);
+  cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr);
   cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dw.p, dy.p, s, nullptr);
   SK_HIP_TRY(hipStreamSynchronize(s));
   SK_HIP_TRY(hipStreamDestroy(s));

@@ -16,6 +16,7 @@
 //   gemm_nt_f64_kernel : C (-)= A B^T, 128x128 tile, v_mfma_f64_16x16x4_f64.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include "chol_kernels.hpp"
 
 namespace sk {
@@ -47,14 +48,15 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
   __shared__ __attribute__((aligned(16))) double sh[2][2][128 * kLdT];
   int ti, tj;
   if (kShape == 1) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x + skip_upper;  // lower-triangular enumeration: skip_upper carries the slice's first tile
     int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((r + 1) * (r + 2) / 2 <= b) ++r;
     while (r * (r + 1) / 2 > b) --r;
     ti = r; tj = b - r * (r + 1) / 2;
   } else {
     ti = blockIdx.x % tiles_m; tj = blockIdx.x / tiles_m;
-    if (skip_upper && ti < tj) return;
+    if ((skip_upper & 1) && ti < tj) return;
+    if ((skip_upper & 2) && blockIdx.x == 0) return;
   }
   const double* Ag = A + (long)ti * 128 * lda;
   const double* Bg = B + (long)tj * 128 * ldb;
@@ -148,17 +150,20 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
 
 // The three uses get their own kernel symbols so profiles separate them.
 // Trailing SYRK of the blocked Cholesky (the dominant kernel): lower-triangular tiles, C -= A A^T.
-__global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K) {
-  gemm_nt_f64_body<0, 1, 16, 1>(C, ldc, A, lda, A, lda, K, 0, 0);
+// Launched in slices of the tile enumeration [tile_off, tile_off + gridDim.x).
+__global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tile_off) {
+  gemm_nt_f64_body<0, 1, 16, 1>(C, ldc, A, lda, A, lda, K, 0, tile_off);
 }
 // Panel updates (lazy left-looking update of a block column; look-ahead part of the SYRK): C -= A B^T.
 __global__ __launch_bounds__(256, 1) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
                                                                  long ldb, int K, int tiles_m, int skip_upper) {
+  __builtin_amdgcn_s_setprio(2);  // on the critical path of the factorisation
   gemm_nt_f64_body<0, 0, 32, 2>(C, ldc, A, lda, B, ldb, K, tiles_m, skip_upper);
 }
 // TRSM as a GEMM with the inverted diagonal block: C = A Linv^T (in place, C == A).
 __global__ __launch_bounds__(256, 1) void trsm_gemm_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
                                                                int tiles_m) {
+  __builtin_amdgcn_s_setprio(2);
   gemm_nt_f64_body<1, 0, 32, 2>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0);
 }
 
@@ -224,19 +229,43 @@ __device__ __forceinline__ void wave_potrf32(double* D, double* colbuf, double* 
 // Column `col` of the inverse of the lower-triangular 32x32 block D (LDS), by
 // forward substitution; L(i,t) are broadcast reads.  x[i] = 0 for i < col.
 __device__ __forceinline__ void lane_inverse32(const double* D, const double* rinv, int col, double (&x)[32]) {
+  // column-oriented (axpy) form: once x[i] is final it is folded into every later row, so the 32
+  // steps are a chain of (mul, fma) pairs with 31-i INDEPENDENT fmas each, not a serial dot product
+#pragma unroll
+  for (int i = 0; i < 32; ++i) x[i] = (i == col) ? 1.0 : 0.0;
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
-    double s = (i == col) ? 1.0 : 0.0;
+    x[i] = (i >= col) ? x[i] * rinv[i] : 0.0;
 #pragma unroll
-    for (int t = 0; t < i; ++t) s -= D[i * kBs + t] * x[t];
-    x[i] = (i >= col) ? s * rinv[i] : 0.0;
-    __builtin_amdgcn_sched_barrier(0);  // keep the broadcast reads of later rows from being hoisted (register pressure)
+    for (int t = i + 1; t < 32; ++t) x[t] -= D[t * kBs + i] * x[i];
+    __builtin_amdgcn_sched_barrier(0);  // keep the broadcast reads of later columns from being hoisted (register pressure)
   }
 }
 
 // One row of the panel below a factored diagonal block: x L^T = a, i.e.
 // x_j = (a_j - sum_{t<j} x_t L(j,t)) / L(j,j), L(j,t) broadcast from LDS.
 __device__ __forceinline__ void row_trsm32(const double* D, const double* rinv, double (&a)[32]) {
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    a[j] = a[j] * rinv[j];
+#pragma unroll
+    for (int t = j + 1; t < 32; ++t) a[t] -= a[j] * D[t * kBs + j];  // independent fmas (axpy form)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Row-oriented (dot-product) forms of the two helpers above, kept for A/B timing (SK_POTRF_DOT=1).
+__device__ __forceinline__ void lane_inverse32_dot(const double* D, const double* rinv, int col, double (&x)[32]) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    double s = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < i; ++t) s -= D[i * kBs + t] * x[t];
+    x[i] = (i >= col) ? s * rinv[i] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+__device__ __forceinline__ void row_trsm32_dot(const double* D, const double* rinv, double (&a)[32]) {
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
     double s = a[j];
@@ -287,12 +316,16 @@ __device__ __forceinline__ void block_load32(d4 (&acc)[2][2], const double* src,
       for (int i = 0; i < 4; ++i) acc[mt][nt][i] = sgn * src[(mt * 16 + l4 + 4 * i) * kBs + nt * 16 + l15];
 }
 
+template <bool kAxpy>
 __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* T = lds;                          // 10 packed 32x32 blocks (lower triangle of the tile)
   double* colbuf = lds + 10 * kB * kBs;     // 64 doubles: column broadcast of the wave-level factorisation
   double* rinv = colbuf + 64;               // 32 doubles: 1 / L(j,j) of the current diagonal sub-block
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // this workgroup is the serial bottleneck of the factorisation and may share its CU with a
+  // trailing-update workgroup (look-ahead): win the issue arbitration
+  __builtin_amdgcn_s_setprio(3);
   // load the lower blocks: all 40 loads of a lane are issued before the first LDS write (one HBM round trip)
   // element e = t + 256 i of a 32x32 block: per-lane offsets inside a block (global and LDS); the block
   // offsets are wave-uniform, so only these eight values stay live for the load and the write-backs
@@ -349,7 +382,7 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
         double* Xb = T + blk_off(bi, jb);
 #pragma unroll
         for (int c = 0; c < 32; ++c) a[c] = Xb[r * kBs + c];
-        row_trsm32(D, rinv, a);
+        if (kAxpy) row_trsm32(D, rinv, a); else row_trsm32_dot(D, rinv, a);
 #pragma unroll
         for (int c = 0; c < 32; ++c) Xb[r * kBs + c] = a[c];
       }
@@ -360,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
     //     column: every lane finishes its broadcast reads of D before the first write (same wave).
     if (wave == 3) {
       double xinv[32];
-      lane_inverse32(D, rinv, lane & 31, xinv);
+      if (kAxpy) lane_inverse32(D, rinv, lane & 31, xinv); else lane_inverse32_dot(D, rinv, lane & 31, xinv);
       __builtin_amdgcn_wave_barrier();
       if (lane < 32) {
 #pragma unroll
@@ -484,24 +517,28 @@ __global__ void copy_row_kernel(const double* __restrict__ src, double* __restri
 // ---------------------------------------------------------------------------
 // 84.6 KB: leaves room for one SYRK workgroup (72 KB) on the same CU, so the look-ahead
 // potrf does not have to wait for a CU to drain completely.
-size_t potrf128_lds_bytes() { return (size_t)(10 * kB * kBs + 64 + 32) * sizeof(double); }
+// 84.6 KB of dynamic LDS (SK_POTRF_LDS_KB=160 makes it claim a whole CU, for look-ahead experiments).
+static bool g_potrf_dot = true;  // row-oriented helpers measured 30 us per block faster than the axpy form
+static size_t g_potrf_lds = (size_t)(10 * kB * kBs + 64 + 32) * sizeof(double);
+size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
 hipError_t cholesky_init() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)potrf128_lds_bytes());
+  // developer knobs for A/B timing
+  if (const char* e = getenv("SK_POTRF_DOT")) g_potrf_dot = atoi(e) != 0;
+  if (const char* e = getenv("SK_POTRF_LDS_KB")) g_potrf_lds = (size_t)atoi(e) * 1024;
+  hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (rc != hipSuccess) return rc;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 CholeskyContext::~CholeskyContext() {
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
-  if (chain) (void)hipStreamDestroy(chain);
+  if (pot) (void)hipStreamDestroy(pot);
 }
 
 hipError_t CholeskyContext::init() {
-  if (chain) return hipSuccess;
-  int least = 0, greatest = 0;
-  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-  if (e != hipSuccess) return e;
-  return hipStreamCreateWithPriority(&chain, hipStreamNonBlocking, greatest);
+  if (pot) return hipSuccess;
+  return hipStreamCreateWithFlags(&pot, hipStreamNonBlocking);
 }
 
 hipEvent_t CholeskyContext::event(size_t i) {
@@ -514,40 +551,63 @@ hipEvent_t CholeskyContext::event(size_t i) {
 }
 
 // Factor the lower triangle of S (npad x ld) in place.  Linv: nblk blocks of 128x128
-// (zero-initialised once).  With a context the panel chain of group g+1 (lazy
-// update, potrf128, TRSM — latency-bound, few workgroups) runs on a high-priority
-// helper stream WHILE the bulk of group g's trailing SYRK runs on `s` (look-ahead):
-//   chain : [panel ops of group g] -> SYRK part (a): the next group's block columns
-//   s     : SYRK part (b): everything right of them
-// (a)[g] waits for (b)[g-1] (same tiles), (b)[g] waits for the panel ops of group g.
+// (zero-initialised once).  Right-looking over groups of `group` block columns, lazy
+// left-looking inside a group.
+//
+// potrf128 is one workgroup and serial (~85 us, 122 of them at n = 15 507), so with a context it
+// is taken off the critical path: the update that feeds it is split into the DIAGONAL tile (one
+// workgroup) and the rest of the block column, and potrf128 runs on a second stream next to that
+// rest.  The first diagonal block of a group comes out of the trailing SYRK, which is split the
+// same way, so that potrf128 hides behind the whole SYRK.  (What was measured and dropped:
+// overlapping the panel chain with the SYRK on two queues — a 6000-workgroup grid starves the
+// other queue, and under full fp64-MFMA load the clock drops so far that a co-running potrf128
+// takes 2.3x longer; see DESIGN.md.)
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
                      KernelTimer* kt) {
   const int nblk = npad / 128;
-  const bool la = ctx != nullptr && ctx->chain != nullptr;
-  hipStream_t sc = la ? ctx->chain : s;
+  const bool la = ctx != nullptr && ctx->pot != nullptr;
+  hipStream_t sp = la ? ctx->pot : s;
   size_t ev = 0;
-  if (la) { hipEvent_t e = ctx->event(ev++); (void)hipEventRecord(e, s); (void)hipStreamWaitEvent(sc, e, 0); }
-  hipEvent_t ev_b_prev = nullptr;
+  auto bulk_to_pot = [&]() { if (la) { hipEvent_t e = ctx->event(ev++); (void)hipEventRecord(e, s); (void)hipStreamWaitEvent(sp, e, 0); } };
+  auto pot_to_bulk = [&]() { if (la) { hipEvent_t e = ctx->event(ev++); (void)hipEventRecord(e, sp); (void)hipStreamWaitEvent(s, e, 0); } };
+  auto potrf = [&](int kb) {
+    double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
+    if (kt) kt->begin("potrf128", sp);
+    if (g_potrf_dot) hipLaunchKernelGGL(potrf128_kernel<false>, dim3(1), dim3(256), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
+    else hipLaunchKernelGGL(potrf128_kernel<true>, dim3(1), dim3(256), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
+    if (kt) kt->end("potrf128", sp);
+  };
+  // C[tiles_m x tiles_n tiles] -= A B^T on the bulk stream
+  auto update = [&](const char* name, double* C, const double* A, const double* B, int K, int tiles_m, int tiles_n, int flags) {
+    if (tiles_m <= 0 || tiles_n <= 0) return;
+    if (kt) kt->begin(name, s);
+    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, s, C, ld, A, ld, B, ld, K, tiles_m, flags);
+    if (kt) kt->end(name, s);
+  };
+  bulk_to_pot();  // S is assembled: the first diagonal block may be factored
   for (int k0 = 0; k0 < nblk; k0 += group) {
     const int k1 = k0 + group < nblk ? k0 + group : nblk;
     for (int kb = k0; kb < k1; ++kb) {
       double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
       const int rows_below = nblk - kb - 1;
-      if (kb > k0) {  // lazy update of block column kb (diagonal block included) from columns [k0, kb)
+      if (kb > k0) {
+        // lazy left-looking update of block column kb from columns [k0, kb): diagonal tile first ...
         const double* P = S + (long)kb * 128 * ld + (long)k0 * 128;
-        if (kt) kt->begin("gemm_panel_update", sc);
-        hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(rows_below + 1), dim3(256), 0, sc, Akk, ld, P, ld, P, ld, (kb - k0) * 128,
-                           rows_below + 1, 0);
-        if (kt) kt->end("gemm_panel_update", sc);
+        const int K = (kb - k0) * 128;
+        update("gemm_panel_update", Akk, P, P, K, 1, 1, 0);
+        bulk_to_pot();
+        potrf(kb);
+        // ... then the rows below it, next to potrf128
+        update("gemm_panel_update", Akk + 128 * ld, P + 128 * ld, P, K, rows_below, 1, 0);
+      } else {
+        potrf(kb);  // its diagonal tile was finished by the previous group's SYRK (or by the assembly)
       }
-      if (kt) kt->begin("potrf128", sc);
-      hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), sc, Akk, ld, Linv + (long)kb * 128 * 128, info);
-      if (kt) kt->end("potrf128", sc);
+      pot_to_bulk();
       if (rows_below > 0) {
         double* A21 = Akk + 128 * ld;
-        if (kt) kt->begin("gemm_trsm", sc);
-        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(rows_below), dim3(256), 0, sc, A21, ld, A21, ld, Linv + (long)kb * 128 * 128, rows_below);
-        if (kt) kt->end("gemm_trsm", sc);
+        if (kt) kt->begin("gemm_trsm", s);
+        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(rows_below), dim3(256), 0, s, A21, ld, A21, ld, Linv + (long)kb * 128 * 128, rows_below);
+        if (kt) kt->end("gemm_trsm", s);
       }
     }
     const int T = nblk - k1;  // trailing tile rows
@@ -556,29 +616,22 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     const int na = group < T ? group : T;  // tile columns of the next group
     double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
-    hipEvent_t ev_chain = nullptr;
-    if (la) {
-      ev_chain = ctx->event(ev++);
-      (void)hipEventRecord(ev_chain, sc);
-      if (ev_b_prev) (void)hipStreamWaitEvent(sc, ev_b_prev, 0);
-    }
-    // (a) next group's block columns: T x na tiles, tiles above the diagonal skipped
-    if (kt) kt->begin("gemm_syrk_next", sc);
-    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(T * na), dim3(256), 0, sc, A22, ld, P, ld, P, ld, K, T, 1);
-    if (kt) kt->end("gemm_syrk_next", sc);
-    // (b) the rest: lower triangle of the (T-na) x (T-na) tiles starting at block k1+na
+    // trailing SYRK, K = group * 128.  Its first tile is the next diagonal block: do it alone, release potrf128 ...
+    update("gemm_syrk_next", A22, P, P, K, 1, 1, 0);
+    bulk_to_pot();
+    // ... then (a) the rest of the next group's block columns (T x na tiles; above-diagonal and first tile skipped) ...
+    update("gemm_syrk_next", A22, P, P, K, T, na, 3);
+    // ... and (b) everything right of them: lower triangle of the (T-na) x (T-na) tiles (the dominant launch)
     const int Tb = T - na;
     if (Tb > 0) {
-      if (la) (void)hipStreamWaitEvent(s, ev_chain, 0);
       double* Cb = S + (long)(k1 + na) * 128 * ld + (long)(k1 + na) * 128;
       const double* Pb = S + (long)(k1 + na) * 128 * ld + (long)k0 * 128;
       if (kt) kt->begin("gemm_syrk", s);
-      hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, s, Cb, ld, Pb, ld, K);
+      hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, s, Cb, ld, Pb, ld, K, 0);
       if (kt) kt->end("gemm_syrk", s);
-      if (la) { ev_b_prev = ctx->event(ev++); (void)hipEventRecord(ev_b_prev, s); }
     }
   }
-  if (la) { hipEvent_t e = ctx->event(ev++); (void)hipEventRecord(e, sc); (void)hipStreamWaitEvent(s, e, 0); }
+  pot_to_bulk();
 }
 
 // y (npad) <- solution of L^T y = z, with z^T = row rhs_row of L (first n entries).  w: scratch (npad).

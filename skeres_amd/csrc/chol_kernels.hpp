@@ -1,6 +1,7 @@
 // Dense fp64 Cholesky on gfx950 matrix cores — host entry points (chol_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include <map>
 #include <string>
 #include <vector>
@@ -14,15 +15,20 @@ class KernelTimer {
  public:
   struct Stat { double seconds = 0.0; int launches = 0; };
   void enable(bool on) { enabled_ = on; }
+  // Time only launches of this name (empty: all).  Events are barrier packets: timing every
+  // small kernel of the panel chain would slow the chain it measures.
+  void only(const std::string& name) { only_ = name; }
   bool enabled() const { return enabled_; }
   void begin(const char* name, hipStream_t s) {
     if (!enabled_) return;
+    if (!only_.empty() && only_ != name) { skip_ = true; return; }
+    skip_ = false;
     hipEvent_t e = get();
     hipEventRecord(e, s);
     pending_.push_back({name, e, nullptr});
   }
   void end(const char* name, hipStream_t s) {
-    if (!enabled_ || pending_.empty()) return;
+    if (!enabled_ || skip_ || pending_.empty()) return;
     hipEvent_t e = get();
     hipEventRecord(e, s);
     pending_.back().stop = e;
@@ -61,15 +67,16 @@ class KernelTimer {
     if (!free_.empty()) { hipEvent_t e = free_.back(); free_.pop_back(); return e; }
     hipEvent_t e; hipEventCreate(&e); return e;
   }
-  bool enabled_ = false;
+  bool enabled_ = false, skip_ = false;
+  std::string only_;
   std::vector<Pending> pending_;
   std::vector<hipEvent_t> free_;
   std::map<std::string, Stat> stats_;
 };
 
-// Helper stream (highest priority) + events for the look-ahead of cholesky_factor.
+// Second stream + events that take potrf128 off the critical path of cholesky_factor.
 struct CholeskyContext {
-  hipStream_t chain = nullptr;
+  hipStream_t pot = nullptr;   // second stream: potrf128 only
   std::vector<hipEvent_t> events;
   hipError_t init();
   hipEvent_t event(size_t i);

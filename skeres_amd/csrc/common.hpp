@@ -103,8 +103,8 @@ struct Options {  // Solver.Options; Ceres 1.x defaults
   void* allreduce_user = nullptr;
   void* reduce_buffer = nullptr;
   size_t reduce_buffer_bytes = 0;
-  int cholesky_group = 4;  // SYRK K = group * 128
-  bool lookahead = true;   // overlap the Cholesky panel chain with the trailing SYRK (second stream)
+  int cholesky_group = 2;  // SYRK K = group * 128 (2 measured best with the potrf look-ahead)
+  bool lookahead = true;   // potrf128 on a second stream, off the critical path
 };
 
 struct IterationLog {

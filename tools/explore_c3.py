@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--group", type=int, default=0)
     ap.add_argument("--no-lookahead", action="store_true")
+    ap.add_argument("--timing", type=int, default=1, help="0 none, 1 all named kernels (slows the chain), 2 SYRK only")
     args = ap.parse_args()
     prob = bal.generate_named(args.workload, seed=1723, perturb=tuple(args.perturb))
     params = sk.RichDoubleArray.fromArray(prob.parameters)
@@ -40,7 +41,7 @@ def main():
     s = sk.StepSolver(o, problem)
     print("setup + iteration 0: %.2f s" % (time.time() - t0))
     s.step()
-    s.setKernelTiming(True)
+    s.setKernelTiming(args.timing)
     t0 = time.time()
     for _ in range(args.iters):
         s.step()
