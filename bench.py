@@ -19,7 +19,6 @@ iteration; the Cholesky runs replicated.  Total work is fixed => "strong".
 Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -63,36 +62,6 @@ def build_problem(sk, prob):
                      9 * prob.num_cameras + 3 * prob.point_index.astype(np.int64)], axis=1)
     problem.addResidualBlocks(sk.SnavelyReprojectionError.FUNCTOR_ID, prob.observations, loss, params, offs)
     return problem, params, loss
-
-
-class TorchAllReduce:
-    """sk_allreduce_fn over torch.distributed (backend nccl == RCCL on ROCm).
-    The big reduced-system buffer is a torch tensor handed to the solver, so its
-    all-reduce is zero-copy; the few small vectors go through a staging tensor."""
-
-    def __init__(self, torch, dist, big):
-        self.torch, self.dist, self.big = torch, dist, big
-        self.base = big.data_ptr() if big is not None else 0
-        self.nbytes = big.numel() * 8 if big is not None else 0
-        self.stage = None
-        self.hip = ctypes.CDLL("libamdhip64.so")
-        self.hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
-        self.hip.hipMemcpyAsync.restype = ctypes.c_int
-
-    def __call__(self, ptr, count, stream):
-        torch, dist = self.torch, self.dist
-        if self.base and self.base <= ptr and ptr + 8 * count <= self.base + self.nbytes:
-            off = (ptr - self.base) // 8
-            dist.all_reduce(self.big[off:off + count])
-            return
-        if self.stage is None or self.stage.numel() < count:
-            self.stage = torch.empty(max(count, 1 << 16), dtype=torch.float64, device="cuda")
-        st = self.stage[:count]
-        if self.hip.hipMemcpyAsync(st.data_ptr(), ptr, 8 * count, 3, stream) != 0:
-            raise RuntimeError("hipMemcpyAsync D2D failed")
-        dist.all_reduce(st)
-        if self.hip.hipMemcpyAsync(ptr, st.data_ptr(), 8 * count, 3, stream) != 0:
-            raise RuntimeError("hipMemcpyAsync D2D failed")
 
 
 def cpu_baseline(prob, iters):
@@ -155,11 +124,8 @@ def main():
     options.setStream(stream.cuda_stream)
     hook = None
     if world > 1:
-        nbytes = sk.lib().sk_reduce_buffer_bytes(options._h, problem._h)
-        big = torch.zeros(nbytes // 8, dtype=torch.float64, device="cuda")
-        options.setReduceBuffer(big.data_ptr(), nbytes)
-        hook = TorchAllReduce(torch, dist, big)
-        options.setDistributed(rank, world, hook)
+        from skeres_amd import dist as sk_dist
+        hook = sk_dist.attach(options, problem, rank, world)  # reduce buffer + all-reduce hook over torch.distributed (RCCL)
 
     solver = sk.StepSolver(options, problem)  # uploads the shard, builds the pair lists, runs iteration 0
     for _ in range(args.warmup):

@@ -323,3 +323,35 @@ def test_bal_medium_properties_and_reproducibility():
                                      prob.observations, x1, jacobians=False)
     assert abs(c - s1.finalCost()) <= 1e-10 * c
     assert costs[0] == pytest.approx(s1.initialCost())
+
+
+# ---------------------------------------------------------------------------
+# the multi-GPU code path, exercised on ONE GPU: RCCL process group of size 1
+# ---------------------------------------------------------------------------
+def test_distributed_hook_path_world_of_one_matches_plain_solve():
+    import os
+    import torch
+    import torch.distributed as dist
+    from skeres_amd import dist as sk_dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        prob = bal.generate(16, 600, 2600, seed=11)
+        x_plain, s_plain = solve_bal_gpu(prob)
+        problem, params, loss = bal_problem_to_sk(prob)
+        options = sk.Solver.Options()
+        options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+        options.setStream(torch.cuda.current_stream().cuda_stream)
+        hook = sk_dist.attach(options, problem, 0, 1)
+        summary = sk.Solver.Summary()
+        sk.ceres.solve(options, problem, summary)
+        torch.cuda.synchronize()
+        assert hook.calls >= 3 * summary.numIterations()  # column norms, reduced system, scalars: every iteration
+        # a sum over one rank is the identity: same trajectory, bit for bit
+        assert [it["cost"] for it in summary.iterations()] == [it["cost"] for it in s_plain.iterations()]
+        assert np.array_equal(params.toArray(prob.num_parameters), x_plain)
+    finally:
+        dist.destroy_process_group()
