@@ -329,29 +329,14 @@ def test_bal_medium_properties_and_reproducibility():
 # the multi-GPU code path, exercised on ONE GPU: RCCL process group of size 1
 # ---------------------------------------------------------------------------
 def test_distributed_hook_path_world_of_one_matches_plain_solve():
+    """Runs tests/dist_gpu_worker.py in a fresh process (torch must initialise HIP before the
+    library does when both live in one process, as in bench.py)."""
     import os
-    import torch
-    import torch.distributed as dist
-    from skeres_amd import dist as sk_dist
-
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        prob = bal.generate(16, 600, 2600, seed=11)
-        x_plain, s_plain = solve_bal_gpu(prob)
-        problem, params, loss = bal_problem_to_sk(prob)
-        options = sk.Solver.Options()
-        options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
-        options.setStream(torch.cuda.current_stream().cuda_stream)
-        hook = sk_dist.attach(options, problem, 0, 1)
-        summary = sk.Solver.Summary()
-        sk.ceres.solve(options, problem, summary)
-        torch.cuda.synchronize()
-        assert hook.calls >= 3 * summary.numIterations()  # column norms, reduced system, scalars: every iteration
-        # a sum over one rank is the identity: same trajectory, bit for bit
-        assert [it["cost"] for it in summary.iterations()] == [it["cost"] for it in s_plain.iterations()]
-        assert np.array_equal(params.toArray(prob.num_parameters), x_plain)
-    finally:
-        dist.destroy_process_group()
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_gpu_worker.py")], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "DIST_GPU_OK" in out.stdout
