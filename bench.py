@@ -64,6 +64,21 @@ def build_problem(sk, prob):
     return problem, params, loss
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/*pmc_traffic.json, made by tools/pmc_summary.py from two separate rocprofv3 --pmc
+    runs of this script).  PMC counters cannot be read from inside the timed run: null when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]["sk::syrk_trailing_f64_kernel"]
+        return k["hbm_bytes_per_launch_corrected"]
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def cpu_baseline(prob, iters):
     """The oracle (CPU restatement, kind "port") on the same problem: `iters` LM
     iterations on all host cores, wall-clock of the steady-state iterations."""
@@ -80,6 +95,11 @@ def cpu_baseline(prob, iters):
             "sample": "%d LM iterations of the same %s-shaped problem (CPU restatement, not Ceres; %.1f s wall; "
                       "cholesky %.1f s, schur assembly %.1f s)" % (it, "bundle-adjustment", wall, s.t_linear_cholesky_s,
                                                                     s.t_linear_assemble_s)}
+
+
+def args_group_k(args):
+    """SYRK depth in 128-column blocks (library default 2)."""
+    return args.group if args.group > 0 else 2
 
 
 def main():
@@ -168,9 +188,12 @@ def main():
                 "linear_solver": "DENSE_SCHUR", "reduced_system_n": 9 * prob.num_cameras,
                 "successful_steps_in_timed_region": n_success, "parallelism": "points sharded x%d, Cholesky replicated" % world,
                 "cost_first_timed": timed[0]["cost"] if timed else None, "cost_last_timed": timed[-1]["cost"] if timed else None},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f64_kernel (Cholesky trailing SYRK, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "sk::syrk_trailing_f64_kernel (Cholesky trailing SYRK, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                         "traffic_note": "bytes/launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled, gfx950; "
+                                         "includes Infinity-Cache hits); algorithmic C-tile bytes/launch = %.3e" % (
+                                             syrk_flops / max(1, syrk_n / max(1, args.steps)) / (2.0 * 128 * 128 * 128 * args_group_k(args)) * 2 * 131072),
                          "launches": syrk_n, "avg_launch_ms": 1e3 * syrk_s / max(1, syrk_n),
                          "flops_per_solve": syrk_flops},
             "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(
