@@ -82,7 +82,12 @@ typedef enum sk_functor_id {
   SK_FUNCTOR_POWELL_F4 = 6,               /* EX/Powell.scala:45-53 */
   SK_FUNCTOR_BINARY_SCALAR_COST = 7,      /* core/src/test/.../AutodiffCostFuntionSpec.scala:14-26; consts (a) */
   SK_FUNCTOR_BINARY_VECTOR3_COST = 8,     /* AutodiffCostFuntionSpec.scala:55-69; consts (a) */
-  SK_FUNCTOR_TEN_PARAMETER_COST = 9       /* AutodiffCostFuntionSpec.scala:111-119 */
+  SK_FUNCTOR_TEN_PARAMETER_COST = 9,      /* AutodiffCostFuntionSpec.scala:111-119 */
+  /* BASELINE.json config 5 (synthetic dense problem; no reference counterpart): one residual
+   * r = tanh(a . x) - y over ONE parameter block of any size n, the row a regenerated on the
+   * device from a counter-based generator; consts (seed, row index, y).  Added with
+   * sk_problem_add_dense_rows. */
+  SK_FUNCTOR_SYNTH_TANH_ROW = 10
 } sk_functor_id;
 
 typedef struct sk_ptrvec sk_ptrvec;
@@ -176,6 +181,10 @@ int sk_problem_add_residual_block(sk_problem* p, const sk_cost_function* cost,
  * n x num_consts row-major; parameter_blocks is n x num_blocks row-major. */
 int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const double* consts,
                                    const sk_loss_function* loss, double* const* parameter_blocks);
+/* Bulk add of `num_rows` residual blocks of a dense-row functor (SK_FUNCTOR_SYNTH_TANH_ROW) that all
+ * depend on the single parameter block x[0..n).  consts is num_rows x 3 row-major. */
+int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const double* consts,
+                              const sk_loss_function* loss, double* x, int n);
 int sk_problem_num_residual_blocks(const sk_problem* p);   /* Problem::NumResidualBlocks */
 int sk_problem_num_parameter_blocks(const sk_problem* p);  /* Problem::NumParameterBlocks */
 int sk_problem_num_parameters(const sk_problem* p);        /* Problem::NumParameters */

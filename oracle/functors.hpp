@@ -9,6 +9,7 @@
 // compiled with -ffp-contract=off so no FMA contraction changes rounding.
 #pragma once
 #include <cmath>
+#include <cstdint>
 #include <limits>
 #include "jet.hpp"
 
@@ -207,6 +208,40 @@ struct TenParameterCost {  // TEST/AutodiffCostFuntionSpec.scala:111-119
     return true;
   }
 };
+
+// ---------------------------------------------------------------------------
+// BASELINE.json config 5 (synthetic dense problem, no reference counterpart):
+//   r(x) = tanh(a . x) - y over ONE block of any size n, a_j = unit(seed, row, j) / sqrt(n) with
+//   unit() the counter-based draw documented in skeres_amd/csrc/synth.hpp (restated here).
+// Evaluated with Jet semantics: the Jet of u = a . x has infinitesimal part a, and
+// tanh(u, v) = (tanh u, (1 - tanh^2 u) v)  [spire / Ceres jet rule].
+// ---------------------------------------------------------------------------
+static const int kSynthTanhRow = 10;
+inline uint64_t synth_mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+inline double synth_unit(uint64_t seed, uint64_t i, uint64_t n, uint64_t j) {
+  const uint64_t h = synth_mix64(seed ^ ((i * n + j) * 0xD6E8FEB86659FD93ull));
+  const double s = (double)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + ((h >> 48) & 0xffff)) + 2.0;
+  return (s * (1.0 / 65536.0) - 2.0) * 1.7320508075688772;
+}
+// jac_row may be null (cost-only branch)
+inline bool synth_tanh_row_evaluate(const double* c, const double* x, int n, double* residual, double* jac_row) {
+  const uint64_t seed = (uint64_t)c[0], row = (uint64_t)c[1];
+  const double inv_sqrt_n = 1.0 / std::sqrt((double)n);
+  double u = 0.0;
+  for (int j = 0; j < n; ++j) u += synth_unit(seed, row, (uint64_t)n, (uint64_t)j) * x[j];
+  const double t = std::tanh(u * inv_sqrt_n);
+  residual[0] = t - c[2];
+  if (jac_row) {
+    const double sd = (1.0 - t * t) * inv_sqrt_n;
+    for (int j = 0; j < n; ++j) jac_row[j] = sd * synth_unit(seed, row, (uint64_t)n, (uint64_t)j);
+  }
+  return true;
+}
 
 // ---------------------------------------------------------------------------
 // AutoDiffCostFunction.evaluate  (CORE/AutodiffCostFunction.scala:74-134)

@@ -146,6 +146,12 @@ static bool evaluate_dense(const Problem& P, const double* x, bool want_jac, Den
   if (want_jac) out->J.assign((size_t)m * n, 0.0);
   bool ok = true;
   for (int b = 0; b < P.num_res_blocks; ++b) {
+    if (P.functor[b] == kSynthTanhRow) {  // dense row over one block of any size
+      const int blk = P.pidx[P.pidx_off[b]], off = P.block_off[blk], nb = P.block_size[blk];
+      if (!synth_tanh_row_evaluate(P.consts + P.const_off[b], x + off, nb, &out->r[P.res_off[b]],
+                                   want_jac ? &out->J[(size_t)P.res_off[b] * n + off] : nullptr)) { ok = false; break; }
+      continue;
+    }
     FunctorInfo fi; functor_info(P.functor[b], &fi);
     const double* params[16]; double jbuf[16][64]; double* jac[16];
     for (int i = 0; i < fi.num_blocks; ++i) {
@@ -613,6 +619,11 @@ int or_solve(int num_blocks, const int* block_sizes, double* x, int num_res_bloc
   P.pidx.assign(pidx, pidx + pidx_off[num_res_blocks]);
   P.consts = consts; P.res_off.resize(num_res_blocks); int m = 0;
   for (int b = 0; b < num_res_blocks; ++b) {
+    if (functor_ids[b] == kSynthTanhRow) {
+      if (P.pidx_off[b + 1] - P.pidx_off[b] != 1) return -2;
+      P.res_off[b] = m; m += 1;
+      continue;
+    }
     FunctorInfo fi; if (!functor_info(functor_ids[b], &fi)) return -1;
     if (P.pidx_off[b + 1] - P.pidx_off[b] != fi.num_blocks) return -2;
     for (int i = 0; i < fi.num_blocks; ++i) if (block_sizes[P.pidx[P.pidx_off[b] + i]] != fi.N[i]) return -3;

@@ -60,6 +60,7 @@ _SIGS = {
     "sk_problem_free": (None, [C.c_void_p]),
     "sk_problem_add_residual_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _dpp, C.c_int, _ip]),
     "sk_problem_add_residual_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_void_p, _dpp]),
+    "sk_problem_add_dense_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_void_p, _dp, C.c_int]),
     "sk_problem_num_residual_blocks": (C.c_int, [C.c_void_p]),
     "sk_problem_num_parameter_blocks": (C.c_int, [C.c_void_p]),
     "sk_problem_num_parameters": (C.c_int, [C.c_void_p]),
@@ -525,6 +526,18 @@ class Problem:
         rc = lib().sk_problem_add_residual_blocks(self._h, int(functor_id), int(n), consts.ctypes.data_as(_dp),
                                                   loss._h if loss is not None else None,
                                                   C.cast(ptrs.ctypes.data, _dpp))
+        if rc == 1:
+            raise ValueError(lib().sk_last_error().decode())
+        _check(rc)
+
+    def addDenseRows(self, functor_id, consts, loss, x, n):
+        """num_rows residual blocks of a dense-row functor over the single parameter block x[0..n)
+        (BASELINE.json config 5); consts is [num_rows, 3] = (seed, row index, y)."""
+        self._arrays.append(x)
+        self._losses.append(loss)
+        consts = np.ascontiguousarray(consts, dtype=np.float64)
+        rc = lib().sk_problem_add_dense_rows(self._h, int(functor_id), int(consts.shape[0]), consts.ctypes.data_as(_dp),
+                                             loss._h if loss is not None else None, x.cast(), int(n))
         if rc == 1:
             raise ValueError(lib().sk_last_error().decode())
         _check(rc)

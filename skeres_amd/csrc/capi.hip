@@ -188,6 +188,26 @@ int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const d
   return SK_OK;
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }
+int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const double* consts, const sk_loss_function* loss, double* x, int n) {
+  SK_GUARD_BEGIN
+  (void)loss;
+  if (!p || num_rows < 0 || !consts || !x || n <= 0) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (functor_id != SK_FUNCTOR_SYNTH_TANH_ROW) { set_error("functor %d is not a dense-row functor", functor_id); return SK_ERR_INVALID_ARGUMENT; }
+  Problem& P = p->p;
+  const int id = register_block(P, x, n);
+  if (id < 0) return SK_ERR_INVALID_ARGUMENT;
+  const size_t base = P.rb_functor.size();
+  P.rb_functor.resize(base + num_rows, functor_id); P.rb_num_residuals.resize(base + num_rows, 1); P.rb_cost.resize(base + num_rows, nullptr);
+  P.rb_const_off.reserve(base + num_rows); P.rb_pidx.reserve(P.rb_pidx.size() + num_rows); P.rb_pidx_off.reserve(P.rb_pidx_off.size() + num_rows);
+  for (int i = 0; i < num_rows; ++i) {
+    P.rb_const_off.push_back(P.consts.size() + 3 * (size_t)i);
+    P.rb_pidx.push_back(id); P.rb_pidx_off.push_back(P.rb_pidx.size());
+  }
+  P.consts.insert(P.consts.end(), consts, consts + 3 * (size_t)num_rows);
+  P.num_residuals += num_rows;
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
 int sk_problem_num_residual_blocks(const sk_problem* p) { return (int)p->p.rb_functor.size(); }
 int sk_problem_num_parameter_blocks(const sk_problem* p) { return (int)p->p.block_size.size(); }
 int sk_problem_num_parameters(const sk_problem* p) { return p->p.num_parameters(); }
@@ -274,6 +294,11 @@ static std::unique_ptr<SolverBase> make_solver(const Options& o, Problem* p, int
     if (!problem_is_bal_shaped(*p, &why)) { set_error("%s", why.c_str()); *rc = SK_ERR_UNSUPPORTED; return nullptr; }
     return make_bal_solver(o, p);
   }
+  if (problem_is_dense_rows(*p)) {
+    if (o.linear_solver_type != SK_DENSE_NORMAL_CHOLESKY) { set_error("dense-row problems are implemented for DENSE_NORMAL_CHOLESKY only (not supported: %s)", linear_solver_name(o.linear_solver_type)); *rc = SK_ERR_UNSUPPORTED; return nullptr; }
+    return make_dense_rows_solver(o, p);
+  }
+  for (int f : p->rb_functor) if (f == SK_FUNCTOR_SYNTH_TANH_ROW) { set_error("dense-row functors cannot be mixed with other residual blocks (not supported)"); *rc = SK_ERR_UNSUPPORTED; return nullptr; }
   return make_dense_solver(o, p);
 }
 

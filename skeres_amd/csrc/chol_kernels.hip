@@ -154,6 +154,11 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
 __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tile_off) {
   gemm_nt_f64_body<0, 1, 16, 1>(C, ldc, A, lda, A, lda, K, 0, tile_off);
 }
+// Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
+// transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
+__global__ __launch_bounds__(256, 2) void syrk_gram_f64_kernel(double* C, long ldc, const double* A, long lda, int K) {
+  gemm_nt_f64_body<1, 1, 16, 1>(C, ldc, A, lda, A, lda, K, 0, 0);
+}
 // Panel updates (lazy left-looking update of a block column; look-ahead part of the SYRK): C -= A B^T.
 __global__ __launch_bounds__(256, 1) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
                                                                  long ldb, int K, int tiles_m, int skip_upper) {
@@ -646,6 +651,14 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
     hipLaunchKernelGGL(bs_step_kernel, dim3(grid), dim3(1024), 0, s, Linv + (long)kb * 128 * 128, S + (long)kb * 128 * ld, ld, w, y, kb, ncols);
   }
   if (kt) kt->end("backsolve", s);
+}
+
+// H (tiles x tiles blocks of 128, lower) = A A^T, A row-major (tiles*128) x K, K a multiple of 16.
+void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int K, int tiles, hipStream_t s, KernelTimer* kt) {
+  if (tiles <= 0) return;
+  if (kt) kt->begin("syrk_gram", s);
+  hipLaunchKernelGGL(syrk_gram_f64_kernel, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, s, H, ldh, A, lda, K);
+  if (kt) kt->end("syrk_gram", s);
 }
 
 // Algorithmic flops of the dominant kernel's launches (part (b) of each trailing SYRK:

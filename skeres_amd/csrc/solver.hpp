@@ -65,5 +65,8 @@ void bal_index_problem(const Problem& p, std::vector<int>* cam_block, std::vecto
 void bal_partition_points(const std::vector<int>& opt, int num_points, int world, std::vector<int>* cut);
 // Generic dense Jacobian path: DENSE_QR / DENSE_NORMAL_CHOLESKY.
 std::unique_ptr<SolverBase> make_dense_solver(const Options& o, Problem* p);
+// Tall dense rows over one parameter block (transposed Jacobian + long-K MFMA SYRK): DENSE_NORMAL_CHOLESKY.
+std::unique_ptr<SolverBase> make_dense_rows_solver(const Options& o, Problem* p);
+bool problem_is_dense_rows(const Problem& p);
 
 }  // namespace sk

@@ -340,3 +340,55 @@ def test_distributed_hook_path_world_of_one_matches_plain_solve():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "DIST_GPU_OK" in out.stdout
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json config 5: dense rows over one block, DENSE_NORMAL_CHOLESKY with a long-K MFMA SYRK
+# ---------------------------------------------------------------------------
+def _solve_dense_rows_gpu(consts, n, max_iter=50):
+    from skeres_amd import dense_synth  # noqa: F401
+    x = sk.DoubleArray(n)
+    problem = sk.Problem()
+    problem.addDenseRows(10, consts, None, x, n)
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_NORMAL_CHOLESKY)
+    options.setMaxNumIterations(max_iter)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    return x.toArray(n), summary
+
+
+@pytest.mark.parametrize("m,n", [(3000, 200), (777, 40), (5000, 300)])
+def test_dense_rows_vs_oracle(m, n):
+    from skeres_amd import dense_synth
+    consts, x_star = dense_synth.generate(m, n, seed=m + n)
+    x_gpu, summary = _solve_dense_rows_gpu(consts, n)
+    blocks = [(oracle.SYNTH_TANH_ROW, list(consts[i]), [0]) for i in range(m)]
+    x_cpu, so = oracle.solve([n], np.zeros(n), blocks, oracle.default_options(linear_solver_type=oracle.DENSE_NORMAL_CHOLESKY))
+    g = [it["cost"] for it in summary.iterations()]
+    c = so.costs()
+    assert abs(len(g) - len(c)) <= 1
+    for k in range(min(5, len(g), len(c))):
+        assert abs(g[k] - c[k]) <= 1e-9 * max(abs(c[k]), 1e-12), (k, g[k], c[k])
+    assert abs(summary.finalCost() - so.final_cost) <= 1e-8 * so.final_cost + 1e-15
+    np.testing.assert_allclose(x_gpu, x_cpu, atol=1e-7)
+    np.testing.assert_allclose(x_gpu, x_star, atol=5e-3)  # recovers the planted parameters
+
+
+def test_dense_rows_medium_properties():
+    from skeres_amd import dense_synth
+    m, n = 60000, 1000
+    consts, x_star = dense_synth.generate(m, n, seed=9)
+    x1, s1 = _solve_dense_rows_gpu(consts, n)
+    x2, s2 = _solve_dense_rows_gpu(consts, n)
+    assert np.array_equal(x1, x2)  # reproducible
+    assert s1.terminationType() == sk.TerminationType.CONVERGENCE
+    assert s1.finalCost() < 1e-3 * s1.initialCost()
+    np.testing.assert_allclose(x1, x_star, atol=2e-3)
+    with pytest.raises(sk.SkeresError, match="DENSE_NORMAL_CHOLESKY"):
+        x = sk.DoubleArray(n)
+        p = sk.Problem()
+        p.addDenseRows(10, consts[:100], None, x, n)
+        o = sk.Solver.Options()
+        o.setLinearSolverType(sk.LinearSolverType.DENSE_QR)
+        sk.ceres.solve(o, p, sk.Solver.Summary())
