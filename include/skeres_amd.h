@@ -287,6 +287,12 @@ double sk_solver_syrk_flops_per_solve(const sk_solver* s);
 int sk_problem_point_partition(const sk_problem* p, int world, int* cuts, int* num_cameras,
                                int* num_points, int* point_of_block);
 
+/* ---- inputs of BASELINE.json config 5 (utility) ----------------------------------
+ * y_out[i] = tanh(a_i . x_star) for the generated rows a_i of SK_FUNCTOR_SYNTH_TANH_ROW
+ * (rows 0 .. m-1 of `seed`, n parameters), computed on the GPU: the planted targets of the
+ * synthetic dense problem at sizes where a host loop over m * n generated coefficients is too slow. */
+int sk_synth_dense_targets(double seed, int m, int n, const double* x_star, double* y_out);
+
 /* ---- dense SPD solve (utility; the factorisation sk_solve uses) --------------
  * Solves A x = b on the GPU for a symmetric positive definite A (n x n,
  * row-major HOST memory, only the lower triangle is read) with the blocked

@@ -111,6 +111,7 @@ _SIGS = {
     "sk_solver_kernel_seconds": (C.c_double, [C.c_void_p, C.c_char_p, _ip]),
     "sk_solver_syrk_flops_per_solve": (C.c_double, [C.c_void_p]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
+    "sk_synth_dense_targets": (C.c_int, [C.c_double, C.c_int, C.c_int, _dp, _dp]),
     "sk_problem_point_partition": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip]),
 }
 
@@ -705,3 +706,11 @@ def cholesky_solve(A, b, want_L=False, group=0):
     _check(lib().sk_cholesky_solve(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp),
                                    L.ctypes.data_as(_dp) if want_L else _dp(), int(group)))
     return (x, L) if want_L else x
+
+
+def synth_dense_targets(seed, m, n, x_star):
+    """tanh(A x_star) of the synthetic dense problem, computed on the GPU (sk_synth_dense_targets)."""
+    xs = np.ascontiguousarray(x_star, dtype=np.float64)
+    y = np.empty(int(m))
+    _check(lib().sk_synth_dense_targets(float(seed), int(m), int(n), xs.ctypes.data_as(_dp), y.ctypes.data_as(_dp)))
+    return y

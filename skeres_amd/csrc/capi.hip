@@ -5,6 +5,7 @@
 #include <new>
 
 #include "dense_kernels.hpp"
+#include "dense_rows_kernels.hpp"
 #include "solver.hpp"
 
 using namespace sk;
@@ -375,6 +376,23 @@ int sk_problem_point_partition(const sk_problem* p, int world, int* cuts, int* n
   if (num_cameras) *num_cameras = (int)cam_block.size();
   if (num_points) *num_points = (int)pt_block.size();
   if (point_of_block) for (size_t b = 0; b < opt.size(); ++b) point_of_block[b] = opt[b];
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
+int sk_synth_dense_targets(double seed, int m, int n, const double* x_star, double* y_out) {
+  SK_GUARD_BEGIN
+  if (m <= 0 || n <= 0 || !x_star || !y_out) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
+  std::vector<double> consts(3 * (size_t)m);
+  for (int i = 0; i < m; ++i) { consts[3 * (size_t)i] = seed; consts[3 * (size_t)i + 1] = (double)i; consts[3 * (size_t)i + 2] = 0.0; }
+  std::vector<double> xs(x_star, x_star + n);
+  DevBuf<double> dc, dx, dr;
+  hipStream_t s = nullptr;
+  SK_HIP_TRY(dc.upload(consts, s)); SK_HIP_TRY(dx.upload(xs, s)); SK_HIP_TRY(dr.alloc(m));
+  DenseRowsArgs a; a.m = m; a.n = n; a.m_pad = m; a.consts = dc.p; a.inv_sqrt_n = 1.0 / std::sqrt((double)n);
+  launch_rows_residual(a, dx.p, dr.p, nullptr, false, s);
+  SK_HIP_TRY(hipMemcpy(y_out, dr.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
   return SK_OK;
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }
