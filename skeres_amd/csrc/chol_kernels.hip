@@ -156,8 +156,25 @@ __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, lo
 }
 // Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
 // transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
-__global__ __launch_bounds__(256, 2) void syrk_gram_f64_kernel(double* C, long ldc, const double* A, long lda, int K) {
-  gemm_nt_f64_body<1, 1, 16, 1>(C, ldc, A, lda, A, lda, K, 0, 0);
+// The K range is split over blockIdx.y (chunk c covers columns [c*K, (c+1)*K) of A and writes slab c of C):
+// a few thousand tiles x one huge K leave a ragged last wave of workgroups; tiles x chunks do not.
+__global__ __launch_bounds__(256, 2) void syrk_gram_f64_kernel(double* C, long ldc, size_t slab_stride, const double* A, long lda, int K) {
+  gemm_nt_f64_body<1, 1, 16, 1>(C + (size_t)blockIdx.y * slab_stride, ldc, A + (size_t)blockIdx.y * K, lda, A + (size_t)blockIdx.y * K, lda, K, 0, 0);
+}
+// H = sum of the slabs, in slab order (deterministic); lower-triangular 128x128 tiles only
+__global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ H, const double* __restrict__ slabs, size_t slab_stride, long ld,
+                                                          int nslabs) {
+  const int b = blockIdx.x;
+  int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+  while ((r + 1) * (r + 2) / 2 <= b) ++r;
+  while (r * (r + 1) / 2 > b) --r;
+  const int ti = r, tj = b - r * (r + 1) / 2;
+  for (int e = threadIdx.x; e < 128 * 128; e += 256) {
+    const size_t off = (size_t)(ti * 128 + (e >> 7)) * ld + tj * 128 + (e & 127);
+    double s = 0.0;
+    for (int c = 0; c < nslabs; ++c) s += slabs[(size_t)c * slab_stride + off];
+    H[off] = s;
+  }
 }
 // Panel updates (lazy left-looking update of a block column; look-ahead part of the SYRK): C -= A B^T.
 __global__ __launch_bounds__(256, 1) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
@@ -654,11 +671,15 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
 }
 
 // H (tiles x tiles blocks of 128, lower) = A A^T, A row-major (tiles*128) x K, K a multiple of 16.
-void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int K, int tiles, hipStream_t s, KernelTimer* kt) {
+// K = nslabs * Kc; slabs: nslabs x (tiles*128 x ldh) scratch (may be null when nslabs == 1: H is written directly).
+void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,
+                      KernelTimer* kt) {
   if (tiles <= 0) return;
+  const size_t slab_stride = (size_t)tiles * 128 * ldh;
   if (kt) kt->begin("syrk_gram", s);
-  hipLaunchKernelGGL(syrk_gram_f64_kernel, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, s, H, ldh, A, lda, K);
+  hipLaunchKernelGGL(syrk_gram_f64_kernel, dim3(tiles * (tiles + 1) / 2, nslabs), dim3(256), 0, s, nslabs > 1 ? slabs : H, ldh, slab_stride, A, lda, Kc);
   if (kt) kt->end("syrk_gram", s);
+  if (nslabs > 1) hipLaunchKernelGGL(gram_reduce_kernel, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, s, H, slabs, slab_stride, ldh, nslabs);
 }
 
 // Algorithmic flops of the dominant kernel's launches (part (b) of each trailing SYRK:

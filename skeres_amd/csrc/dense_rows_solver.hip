@@ -40,6 +40,8 @@ class DenseRowsSolver : public SolverBase {
  private:
   int n_ = 0, m_ = 0, npad_ = 0, rhs_row_ = 0;
   size_t m_pad_ = 0;
+  int nslabs_ = 1;
+  DevBuf<double> b_slabs_;
   DenseRowsArgs a_{};
   DevBuf<double> b_consts_, b_xa_, b_xb_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_, b_w_, b_r_, b_rc_, b_sd_, b_Jt_, b_H_, b_Linv_,
       b_partial_, b_small_, b_scal_;
@@ -53,7 +55,14 @@ int DenseRowsSolver::setup() {
   const Problem& p = *problem_;
   if (opt_.world > 1) { set_error("the dense path does not shard: run replicas (world must be 1)"); return SK_ERR_UNSUPPORTED; }
   n_ = p.block_size[0]; m_ = (int)p.rb_functor.size();
-  m_pad_ = ((size_t)m_ + 15) / 16 * 16;
+  // J^T J splits K = m_pad into nslabs_ chunks when the tile count alone would leave a ragged last wave of workgroups
+  {
+    const long tiles = (long)((n_ + 1 + 127) / 128) * ((n_ + 1 + 127) / 128 + 1) / 2;
+    nslabs_ = 1;
+    while (nslabs_ < 16 && tiles * nslabs_ < 8192 && (size_t)m_ / (nslabs_ * 2) >= 4096) nslabs_ *= 2;
+    const size_t q = (size_t)16 * nslabs_;
+    m_pad_ = ((size_t)m_ + q - 1) / q * q;
+  }
   rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
   hipStream_t s = stream_;
   SK_HIP_TRY(b_consts_.upload(p.consts, s));
@@ -66,6 +75,7 @@ int DenseRowsSolver::setup() {
   // rows [n, npad) of Jt stay zero: they pad the SYRK tiles; columns [m, m_pad) stay zero: they pad K
   SK_HIP_TRY(b_Jt_.alloc((size_t)npad_ * m_pad_)); SK_HIP_TRY(b_Jt_.zero(s));
   SK_HIP_TRY(b_H_.alloc((size_t)npad_ * npad_)); SK_HIP_TRY(b_H_.zero(s));
+  if (nslabs_ > 1) SK_HIP_TRY(b_slabs_.alloc((size_t)nslabs_ * npad_ * npad_));
   SK_HIP_TRY(b_Linv_.alloc((size_t)npad_ * 128)); SK_HIP_TRY(b_Linv_.zero(s));
   SK_HIP_TRY(b_y_.alloc(npad_)); SK_HIP_TRY(b_w_.alloc(npad_)); SK_HIP_TRY(b_scal_.alloc(16));
   SK_HIP_TRY(b_partial_.alloc((size_t)(m_ + 255) / 256 + 16)); SK_HIP_TRY(b_small_.alloc(512)); SK_HIP_TRY(b_info_.alloc(1));
@@ -109,7 +119,7 @@ int DenseRowsSolver::try_step(double radius, bool* valid, double* mcc, double* n
   launch_lm_diagonal(b_colsq_.p, b_D_.p, n_, opt_.min_lm_diagonal, opt_.max_lm_diagonal, radius, s);
   SK_HIP_TRY(hipMemsetAsync(b_info_.p, 0, sizeof(int), s));
   // J^T J: one long-K MFMA SYRK over the transposed Jacobian (every lower tile is overwritten)
-  launch_syrk_gram(b_H_.p, npad_, b_Jt_.p, (long)m_pad_, (int)m_pad_, npad_ / 128, s, &kt_);
+  launch_syrk_gram(b_H_.p, npad_, b_Jt_.p, (long)m_pad_, (int)(m_pad_ / nslabs_), nslabs_, b_slabs_.p, npad_ / 128, s, &kt_);
   launch_rows_set_rhs(b_H_.p, npad_, rhs_row_, b_gs_.p, n_, s);
   launch_bal_finish_S(b_H_.p, npad_, n_, npad_, rhs_row_, b_D_.p, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
