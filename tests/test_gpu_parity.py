@@ -397,11 +397,11 @@ def test_dense_rows_medium_properties():
 # ---------------------------------------------------------------------------
 # the reference's example programs, run end to end
 # ---------------------------------------------------------------------------
-def test_example_programs_end_to_end(tmp_path, capsys):
+def test_example_programs_end_to_end(tmp_path, capfd):  # capfd: the progress table is printed by the native library
     from skeres_amd.examples import curve_fitting, powell, simple_bundle_adjuster
     final = curve_fitting.main()
     np.testing.assert_allclose(final, [0.2919, 0.1314], atol=1e-3)
-    out = capsys.readouterr().out
+    out = capfd.readouterr().out
     assert "Initial: 0.0, 0.0" in out and "Ceres Solver Report" in out and "iter      cost" in out
     xout = powell.main()
     np.testing.assert_allclose(xout, 0.0, atol=1e-3)
@@ -409,6 +409,6 @@ def test_example_programs_end_to_end(tmp_path, capsys):
     path = tmp_path / "problem-5-60.txt"
     prob.to_file(str(path))
     assert simple_bundle_adjuster.main(["prog", str(path)]) == 0
-    out = capsys.readouterr().out
+    out = capfd.readouterr().out
     assert "Loading BalProblem from" in out and " done" in out and "DENSE_SCHUR" in out and "Termination" in out
     assert simple_bundle_adjuster.main(["prog"]) == 1  # usage
