@@ -38,65 +38,81 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // kPF   : prefetch distance in K-steps (register sets in flight).  The throughput kernel (SYRK,
 //         thousands of workgroups, 2 per CU) uses <16, 1>; the latency-bound panel kernels (a few
 //         dozen workgroups, nothing else on the CU to hide an HBM round trip) use <32, 2>.
-template <int kMode, int kShape, int kBKT, int kPF>
+// kTM x kTN: output tile of one workgroup (2 x 2 waves, each (kTM/2) x (kTN/2)).  128 x 128 for the
+//         throughput kernels; 64 x 128 / 64 x 64 for the panel kernels, whose grids are otherwise
+//         too small to occupy 256 CUs (their cost is latency, not flops).
+// skip  : kShape 0: bit 0 drops tiles whose 128-block row is above their 128-block column, bit 1
+//         drops the tiles of 128-block (0, 0), bit 2 drops tiles entirely above the diagonal.
+//         kShape 1: first tile of the slice.
+template <int kMode, int kShape, int kBKT, int kPF, int kTM, int kTN>
 __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
-                                                 int tiles_m, int skip_upper) {
+                                                 int tiles_m, int skip) {
   constexpr int mode = kMode;
-  constexpr int kLdT = kBKT + 2;        // LDS row stride in doubles
-  constexpr int kCh = kBKT / 4;         // 16-byte chunks per thread, operand and stage
-  constexpr int kRowStep = 512 / kBKT;  // rows covered by the 256 threads per chunk index
-  __shared__ __attribute__((aligned(16))) double sh[2][2][128 * kLdT];
+  constexpr int kLdT = kBKT + 2;            // LDS row stride in doubles
+  constexpr int kChA = kTM * kBKT / 512;    // 16-byte chunks per thread and stage, A operand
+  constexpr int kChB = kTN * kBKT / 512;    // ... B operand
+  constexpr int kRowStep = 512 / kBKT;      // rows covered by the 256 threads per chunk index
+  constexpr int kMT = kTM / 32, kNT = kTN / 32;  // 16x16 MFMA tiles per wave
+  static_assert(kChA >= 1 && kChB >= 1, "tile too small for 256 staging threads");
+  __shared__ __attribute__((aligned(16))) double sh[2][(kTM + kTN) * kLdT];
   int ti, tj;
   if (kShape == 1) {
-    const int b = blockIdx.x + skip_upper;  // lower-triangular enumeration: skip_upper carries the slice's first tile
+    const int b = blockIdx.x + skip;  // lower-triangular enumeration
     int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
     while ((r + 1) * (r + 2) / 2 <= b) ++r;
     while (r * (r + 1) / 2 > b) --r;
     ti = r; tj = b - r * (r + 1) / 2;
   } else {
     ti = blockIdx.x % tiles_m; tj = blockIdx.x / tiles_m;
-    if ((skip_upper & 1) && ti < tj) return;
-    if ((skip_upper & 2) && blockIdx.x == 0) return;
+    const int bi = ti * kTM / 128, bj = tj * kTN / 128;
+    if ((skip & 1) && bi < bj) return;
+    if ((skip & 2) && bi == 0 && bj == 0) return;
+    if ((skip & 4) && (ti + 1) * kTM <= tj * kTN) return;
   }
-  const double* Ag = A + (long)ti * 128 * lda;
-  const double* Bg = B + (long)tj * 128 * ldb;
-  double* Cg = C + (long)ti * 128 * ldc + (long)tj * 128;
+  const double* Ag = A + (long)ti * kTM * lda;
+  const double* Bg = B + (long)tj * kTN * ldb;
+  double* Cg = C + (long)ti * kTM * ldc + (long)tj * kTN;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l15 = lane & 15, l4 = lane >> 4;
+  const int crow = wr * (kTM / 2) + l4, ccol = wc * (kTN / 2) + l15;
 
-  d4 acc[4][4];
+  d4 acc[kMT][kNT];
   if (mode == 0) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < kNT; ++nt)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[mt][nt][i] = -Cg[(long)(wr * 64 + mt * 16 + l4 + 4 * i) * ldc + wc * 64 + nt * 16 + l15];
+          acc[mt][nt][i] = -Cg[(long)(crow + mt * 16 + 4 * i) * ldc + ccol + nt * 16];
   } else {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int nt = 0; nt < kNT; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
   }
 
   // staging: chunk q = i*256 + t -> row q / (kBKT/2), 16-byte column chunk q % (kBKT/2): every
   // wave-level load covers whole 128-B (kBKT = 16) or 256-B (kBKT = 32) row segments
-  typedef double dstage __attribute__((ext_vector_type(2 * kCh)));  // one operand stage of a lane: SSA vector, never an alloca
-  dstage ra0, rb0, ra1, rb1;
+  typedef double dstage_a __attribute__((ext_vector_type(2 * kChA)));  // one operand stage of a lane: SSA vector, never an alloca
+  typedef double dstage_b __attribute__((ext_vector_type(2 * kChB)));
+  dstage_a ra0, ra1;
+  dstage_b rb0, rb1;
   const int srow = t / (kBKT / 2), sc = (t % (kBKT / 2)) * 2;
 #define SK_LOAD_STAGE(set, kbase)                                                                         \
-  _Pragma("unroll") for (int i = 0; i < kCh; ++i) {                                                        \
-    { const double2 v_ = *reinterpret_cast<const double2*>(Ag + (long)(i * kRowStep + srow) * lda + (kbase) + sc); ra##set[2 * i] = v_.x; ra##set[2 * i + 1] = v_.y; } \
-    { const double2 v_ = *reinterpret_cast<const double2*>(Bg + (long)(i * kRowStep + srow) * ldb + (kbase) + sc); rb##set[2 * i] = v_.x; rb##set[2 * i + 1] = v_.y; } \
+  _Pragma("unroll") for (int i = 0; i < kChA; ++i) {                                                       \
+    const double2 v_ = *reinterpret_cast<const double2*>(Ag + (long)(i * kRowStep + srow) * lda + (kbase) + sc); ra##set[2 * i] = v_.x; ra##set[2 * i + 1] = v_.y; \
+  }                                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < kChB; ++i) {                                                       \
+    const double2 v_ = *reinterpret_cast<const double2*>(Bg + (long)(i * kRowStep + srow) * ldb + (kbase) + sc); rb##set[2 * i] = v_.x; rb##set[2 * i + 1] = v_.y; \
   }
 #define SK_STORE_STAGE(set, buf)                                                                   \
-  _Pragma("unroll") for (int i = 0; i < kCh; ++i) {                                                 \
-    *reinterpret_cast<double2*>(&sh[buf][0][(i * kRowStep + srow) * kLdT + sc]) = make_double2(ra##set[2 * i], ra##set[2 * i + 1]); \
-    *reinterpret_cast<double2*>(&sh[buf][1][(i * kRowStep + srow) * kLdT + sc]) = make_double2(rb##set[2 * i], rb##set[2 * i + 1]); \
-  }
+  _Pragma("unroll") for (int i = 0; i < kChA; ++i)                                                  \
+    *reinterpret_cast<double2*>(&sh[buf][(i * kRowStep + srow) * kLdT + sc]) = make_double2(ra##set[2 * i], ra##set[2 * i + 1]); \
+  _Pragma("unroll") for (int i = 0; i < kChB; ++i)                                                  \
+    *reinterpret_cast<double2*>(&sh[buf][(kTM + i * kRowStep + srow) * kLdT + sc]) = make_double2(rb##set[2 * i], rb##set[2 * i + 1]);
   const int nk = K / kBKT;  // a multiple of kPF (K is a multiple of 128)
   SK_LOAD_STAGE(0, 0)
   if (kPF == 2) { SK_LOAD_STAGE(1, (nk > 1 ? 1 : 0) * kBKT) }
@@ -112,13 +128,14 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
     const int buf = (kt) & 1;                                                                      \
     const int knext = ((kt) + kPF < nk ? (kt) + kPF : nk - 1) * kBKT;                              \
     SK_LOAD_STAGE_X(SETL, knext)                                                                   \
-    const double* sa = &sh[buf][0][(wr * 64 + l15) * kLdT + l4];                                   \
-    const double* sb = &sh[buf][1][(wc * 64 + l15) * kLdT + l4];                                   \
+    const double* sa = &sh[buf][(wr * (kTM / 2) + l15) * kLdT + l4];                               \
+    const double* sb = &sh[buf][(kTM + wc * (kTN / 2) + l15) * kLdT + l4];                         \
     _Pragma("unroll") for (int kk = 0; kk < kBKT / 4; ++kk) {                                      \
-      double a[4], b[4];                                                                           \
-      _Pragma("unroll") for (int m = 0; m < 4; ++m) { a[m] = sa[m * 16 * kLdT + kk * 4]; b[m] = sb[m * 16 * kLdT + kk * 4]; } \
-      _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                             \
-        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                           \
+      double a[kMT], b[kNT];                                                                       \
+      _Pragma("unroll") for (int m = 0; m < kMT; ++m) a[m] = sa[m * 16 * kLdT + kk * 4];           \
+      _Pragma("unroll") for (int m = 0; m < kNT; ++m) b[m] = sb[m * 16 * kLdT + kk * 4];           \
+      _Pragma("unroll") for (int mt = 0; mt < kMT; ++mt)                                           \
+        _Pragma("unroll") for (int nt = 0; nt < kNT; ++nt)                                         \
           acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);  \
     }                                                                                              \
     SK_STORE_STAGE_X(SETS, buf ^ 1)                                                                \
@@ -140,26 +157,26 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
 #undef SK_STORE_STAGE
   const double sgn = mode == 0 ? -1.0 : 1.0;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < kNT; ++nt)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        Cg[(long)(wr * 64 + mt * 16 + l4 + 4 * i) * ldc + wc * 64 + nt * 16 + l15] = sgn * acc[mt][nt][i];
+        Cg[(long)(crow + mt * 16 + 4 * i) * ldc + ccol + nt * 16] = sgn * acc[mt][nt][i];
 }
 
 // The three uses get their own kernel symbols so profiles separate them.
 // Trailing SYRK of the blocked Cholesky (the dominant kernel): lower-triangular tiles, C -= A A^T.
 // Launched in slices of the tile enumeration [tile_off, tile_off + gridDim.x).
 __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tile_off) {
-  gemm_nt_f64_body<0, 1, 16, 1>(C, ldc, A, lda, A, lda, K, 0, tile_off);
+  gemm_nt_f64_body<0, 1, 16, 1, 128, 128>(C, ldc, A, lda, A, lda, K, 0, tile_off);
 }
 // Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
 // transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
 // The K range is split over blockIdx.y (chunk c covers columns [c*K, (c+1)*K) of A and writes slab c of C):
 // a few thousand tiles x one huge K leave a ragged last wave of workgroups; tiles x chunks do not.
 __global__ __launch_bounds__(256, 2) void syrk_gram_f64_kernel(double* C, long ldc, size_t slab_stride, const double* A, long lda, int K) {
-  gemm_nt_f64_body<1, 1, 16, 1>(C + (size_t)blockIdx.y * slab_stride, ldc, A + (size_t)blockIdx.y * K, lda, A + (size_t)blockIdx.y * K, lda, K, 0, 0);
+  gemm_nt_f64_body<1, 1, 16, 1, 128, 128>(C + (size_t)blockIdx.y * slab_stride, ldc, A + (size_t)blockIdx.y * K, lda, A + (size_t)blockIdx.y * K, lda, K, 0, 0);
 }
 // H = sum of the slabs, in slab order (deterministic); lower-triangular 128x128 tiles only
 __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ H, const double* __restrict__ slabs, size_t slab_stride, long ld,
@@ -176,17 +193,23 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ H
     H[off] = s;
   }
 }
-// Panel updates (lazy left-looking update of a block column; look-ahead part of the SYRK): C -= A B^T.
-__global__ __launch_bounds__(256, 1) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
-                                                                 long ldb, int K, int tiles_m, int skip_upper) {
+// Panel updates (lazy left-looking update of a block column; look-ahead part of the SYRK): C -= A B^T,
+// 64 x 128 tiles (tiles_m counts 64-row tiles), two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
+                                                                 long ldb, int K, int tiles_m, int skip) {
   __builtin_amdgcn_s_setprio(2);  // on the critical path of the factorisation
-  gemm_nt_f64_body<0, 0, 32, 2>(C, ldc, A, lda, B, ldb, K, tiles_m, skip_upper);
+  gemm_nt_f64_body<0, 0, 16, 2, 64, 128>(C, ldc, A, lda, B, ldb, K, tiles_m, skip);
 }
-// TRSM as a GEMM with the inverted diagonal block: C = A Linv^T (in place, C == A).
-__global__ __launch_bounds__(256, 1) void trsm_gemm_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
+// One 128 x 128 diagonal block, C -= A A^T, as 64 x 64 tiles (the upper one skipped): potrf128 waits on it.
+__global__ __launch_bounds__(256, 1) void gemm_diag_f64_kernel(double* C, long ldc, const double* A, long lda, int K) {
+  __builtin_amdgcn_s_setprio(3);
+  gemm_nt_f64_body<0, 0, 32, 2, 64, 64>(C, ldc, A, lda, A, lda, K, 2, 4);
+}
+// TRSM as a GEMM with the inverted diagonal block: C = A Linv^T (in place, C == A); 64 x 128 tiles.
+__global__ __launch_bounds__(256, 2) void trsm_gemm_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
                                                                int tiles_m) {
   __builtin_amdgcn_s_setprio(2);
-  gemm_nt_f64_body<1, 0, 32, 2>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0);
+  gemm_nt_f64_body<1, 0, 16, 2, 64, 128>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -603,7 +626,13 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   auto update = [&](const char* name, double* C, const double* A, const double* B, int K, int tiles_m, int tiles_n, int flags) {
     if (tiles_m <= 0 || tiles_n <= 0) return;
     if (kt) kt->begin(name, s);
-    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, s, C, ld, A, ld, B, ld, K, tiles_m, flags);
+    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(2 * tiles_m * tiles_n), dim3(256), 0, s, C, ld, A, ld, B, ld, K, 2 * tiles_m, flags);
+    if (kt) kt->end(name, s);
+  };
+  // one diagonal 128-block: C -= A A^T
+  auto update_diag = [&](const char* name, double* C, const double* A, int K) {
+    if (kt) kt->begin(name, s);
+    hipLaunchKernelGGL(gemm_diag_f64_kernel, dim3(4), dim3(256), 0, s, C, ld, A, ld, K);
     if (kt) kt->end(name, s);
   };
   bulk_to_pot();  // S is assembled: the first diagonal block may be factored
@@ -616,7 +645,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
         // lazy left-looking update of block column kb from columns [k0, kb): diagonal tile first ...
         const double* P = S + (long)kb * 128 * ld + (long)k0 * 128;
         const int K = (kb - k0) * 128;
-        update("gemm_panel_update", Akk, P, P, K, 1, 1, 0);
+        update_diag("gemm_diag_update", Akk, P, K);
         bulk_to_pot();
         potrf(kb);
         // ... then the rows below it, next to potrf128
@@ -628,7 +657,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       if (rows_below > 0) {
         double* A21 = Akk + 128 * ld;
         if (kt) kt->begin("gemm_trsm", s);
-        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(rows_below), dim3(256), 0, s, A21, ld, A21, ld, Linv + (long)kb * 128 * 128, rows_below);
+        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(2 * rows_below), dim3(256), 0, s, A21, ld, A21, ld, Linv + (long)kb * 128 * 128, 2 * rows_below);
         if (kt) kt->end("gemm_trsm", s);
       }
     }
@@ -639,7 +668,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
     // trailing SYRK, K = group * 128.  Its first tile is the next diagonal block: do it alone, release potrf128 ...
-    update("gemm_syrk_next", A22, P, P, K, 1, 1, 0);
+    update_diag("gemm_diag_update", A22, P, K);
     bulk_to_pot();
     // ... then (a) the rest of the next group's block columns (T x na tiles; above-diagonal and first tile skipped) ...
     update("gemm_syrk_next", A22, P, P, K, T, na, 3);
