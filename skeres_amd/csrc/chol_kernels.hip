@@ -214,23 +214,27 @@ __global__ __launch_bounds__(256, 2) void trsm_gemm_f64_kernel(double* C, long l
 
 // ---------------------------------------------------------------------------
 // potrf128: Cholesky of one 128x128 diagonal block and its inverse, one
-// workgroup, everything resident in LDS as ten packed 32x32 blocks.
+// workgroup (4 waves), everything resident in LDS as packed 32x32 blocks.
 //   in : A (row-major, ld) lower triangle
 //   out: A <- L (lower);  Linv (row-major 128x128, dense lower, upper stays 0)
 //        info flag set when a pivot is not positive
+//
+// The kernel is the serial bottleneck of the blocked factorisation, so it is
+// organised around its critical path, which wave 0 walks alone:
+//   P(jb)  the 32x32 diagonal factorisation (32 dependent column steps), L_jj -> global,
+//          W_jj = L_jj^-1 -> LDS (free: lanes 32..63, see wave_potrf32)
+//   B(jb)  X(jb+1,jb) = T(jb+1,jb) W_jj^T, T(jb+1,jb+1) -= X X^T
+// Waves 1..3 do everything else between the same barriers: the other panel blocks and their
+// diagonal updates, the off-diagonal updates, the blocked inverse (row by row, partial sums
+// S(bi,bj) = sum_t L(bi,t) Inv(t,bj) accumulated as soon as their operands are final) and the
+// write-backs, balanced so that no phase is longer than wave 0's.
 // ---------------------------------------------------------------------------
 static constexpr int kB = 32, kBs = 33;  // sub-block size and its LDS row stride
-__device__ __forceinline__ int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * (kB * kBs); }
+static constexpr int kBlk = kB * kBs;
+__device__ __forceinline__ int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * kBlk; }       // bj <= bi: L / W blocks
+__device__ __forceinline__ int inv_off(int bi, int bj) { return (10 + bi * (bi - 1) / 2 + bj) * kBlk; }  // bj <  bi: inverse blocks
 
-// One wave: factor the 32x32 block D (LDS, row stride kBs) in place and
-// replace it by its INVERSE (zeros above the diagonal).  The row of L each
-// lane computed is returned in `a` for the write-back to global memory.
-// Lane l works on row l & 31 (lanes 32..63 mirror 0..31: same values to the
-// same addresses).  Cross-lane values travel through LDS broadcast reads
-// (uniform address), which a single wave sees in program order.
-// 1/sqrt(x) for the pivots: hardware estimate + two Newton steps (full fp64
-// accuracy to ~1 ulp), far shorter than sqrt followed by a division on the
-// 128-deep serial chain of a diagonal block.
+// 1/sqrt(x): hardware estimate + two Newton steps (~1 ulp)
 __device__ __forceinline__ double fast_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
   double h = 0.5 * x;
@@ -238,91 +242,131 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   y = y * (1.5 - h * y * y);
   return y;
 }
+// 1/x: hardware estimate (~2^-23) + one cubic step y (1 + e + e^2), e = 1 - x y: three dependent fmas
+__device__ __forceinline__ double fast_rcp(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, y, 1.0);
+  const double q = __builtin_fma(e, e, e);
+  return __builtin_fma(y, q, y);
+}
+// value of x in lane `src` (compile-time constant) as a wave-uniform scalar
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
 
-// One wave: factor the 32x32 block D (LDS, row stride kBs) in place, D <- L
-// (lower, zeros above the diagonal), rinv[j] = 1 / L(j,j).  The row of L each
-// lane computed is returned in `a` for the write-back to global memory.
-// Lane l works on row l & 31 (lanes 32..63 mirror 0..31: same values to the
-// same addresses).  Cross-lane values travel through LDS broadcast reads
-// (uniform address), which a single wave sees in program order.
-__device__ __forceinline__ void wave_potrf32(double* D, double* colbuf, double* rinv, double (&a)[32], bool* ok) {
-  const int row = threadIdx.x & 31;
-  bool good = true;
+// One wave: factor the 32x32 block D (LDS, row stride kBs).  Lanes 0..31 hold row `lane` of D and
+// end with row `lane` of L in `a`.  Lanes 32..63 start from the unit vector e_k (k = lane - 32) and
+// execute the same column operations, which for them is the forward substitution L w = e_k: they
+// end with column k of W = L^-1, a[c] = W(c,k).
+//
+// Column j, with d = A'(j,j) and every lane's a[j] = A'(row,j) (updated by the columns before):
+//   m = a[j] / d;  a[c] -= m A'(c,j) for c > j;  a[j] /= sqrt(d).
+// The dependent chain from one column to the next is
+//   d (v_readlane from lane j) -> y = rcp(d) -> e = 1 - d y -> q = e + e^2 -> m = a[j] y (1 + q) -> a[j+1] -= m A'(j+1,j)
+// (A'(j+1,j) by v_readlane from lane j+1): five dependent VALU instructions and no LDS round trip.
+// Everything else is filler that is issued BETWEEN the chain instructions, one column late:
+//   - the other updates of column j-1 (c >= j+1), whose A'(c,j-1) every lane published to LDS as soon
+//     as its a[j-1] was final (colbuf: 3 x 64 doubles, column j in buffer j % 3) and which were read back
+//     into registers one column ago,
+//   - the 1/sqrt(d) of column j-1 (two Newton steps) and the scaling of a[j-1].
+// The in-order issue of one wave makes the placement matter: left to itself the scheduler puts the
+// fillers first and the chain last, and a column costs their sum (measured 390 clocks per column).
+// Each slot is pinned with sched_barrier.
+__device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, double (&a)[32], int lane) {
+  const int row = lane & 31;
+  const bool unit = lane >= 32;
 #pragma unroll
-  for (int c = 0; c < 32; ++c) a[c] = D[row * kBs + c];
+  for (int c = 0; c < 32; ++c) {
+    const double d = D[row * kBs + c];
+    a[c] = unit ? (c == row ? 1.0 : 0.0) : d;
+  }
+  colbuf[lane] = a[0];  // lanes 32..63 write slots nobody reads (no branch in the chain)
+  double cbp[32], cbn[32];  // column j-1 (in use) and column j (in flight) of A', c-indexed; SSA after unrolling
+  double m_prev = 0.0, d_prev = 1.0;
+  int sgn = 0;  // sign bits of the pivots
+  // keeps a filler value where it is written: pure arithmetic otherwise sinks to its use after the
+  // loop, where the 32 refinements of 1/sqrt(d) ran back to back (measured 1.3 us per block)
+#define SK_PIN(x) asm volatile("" : "+v"(x));
+#ifndef SK_PROBE_VARIANT
+#define SK_PROBE_VARIANT 0
+#endif
+#define SK_FILL(k)                                                                                  \
+  if (j >= 1 && SK_PROBE_VARIANT != 1) {                                                                                     \
+    _Pragma("unroll") for (int c = j + 1 + ((k) * (31 - j) + 4) / 5; c < j + 1 + (((k) + 1) * (31 - j) + 4) / 5; ++c) /* c = j+1 always in slot 0 */ \
+      a[c] = __builtin_fma(-m_prev, cbp[c], a[c]);                                                  \
+  }
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
-    colbuf[row] = a[j];
-    __builtin_amdgcn_wave_barrier();
-    const double djj = colbuf[j];
-    good = good && (djj > 0.0);
-    const double ri = fast_rsqrt(djj);
-    rinv[j] = ri;  // every lane stores the same value: a branch here would split the unrolled chain into 32 blocks (spills)
-    a[j] = a[j] * ri;  // column j of L (row j: sqrt(djj))
+    // prefetch: column j of A' for the late updates of the NEXT step
+    {
+      const double* cbj = colbuf + (j % 3) * 64;
 #pragma unroll
-    for (int c = j + 1; c < 32; ++c) a[c] -= a[j] * (colbuf[c] * ri);
-    __builtin_amdgcn_wave_barrier();
-    // one scheduling region per column: without it the fully unrolled chain is scheduled as one
-    // block, the scheduler hoists across columns and the kernel spills past 512 registers
+      for (int c = j + 2; c < 32; ++c) cbn[c] = SK_PROBE_VARIANT == 2 ? a[c] * 0.5 : cbj[c];
+    }
+    // ---- chain 0
+    const double d = lane_bcast(a[j], j);
+    const double y = __builtin_amdgcn_rcp(d);
+    const double l1 = lane_bcast(a[j], j + 1 < 32 ? j + 1 : j);
+    const double m0 = a[j] * y;
     __builtin_amdgcn_sched_barrier(0);
-  }
+    sgn |= __double2hiint(d);  // scalar: d is wave-uniform
+    asm volatile("" : "+s"(sgn));
+    double ry = __builtin_amdgcn_rsq(d_prev);
+    double rh = 0.5 * d_prev;
+    SK_PIN(ry) SK_PIN(rh)
+    SK_FILL(0)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chain 1
+    const double e = __builtin_fma(-d, y, 1.0);
+    __builtin_amdgcn_sched_barrier(0);
+    double t = rh * ry;
+    SK_PIN(t)
+    SK_FILL(1)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chain 2
+    const double q = __builtin_fma(e, e, e);
+    __builtin_amdgcn_sched_barrier(0);
+    t = __builtin_fma(-t, ry, 1.5);
+    SK_PIN(t)
+    ry = ry * t;
+    SK_PIN(ry)
+    SK_FILL(2)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chain 3
+    const double m = __builtin_fma(m0, q, m0);
+    __builtin_amdgcn_sched_barrier(0);
+    t = rh * ry;
+    SK_PIN(t)
+    t = __builtin_fma(-t, ry, 1.5);
+    SK_PIN(t)
+    SK_FILL(3)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- chain 4
+    if (j + 1 < 32) {
+      a[j + 1] = __builtin_fma(-m, l1, a[j + 1]);
+      colbuf[((j + 1) % 3) * 64 + lane] = a[j + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ry = ry * t;
+    SK_PIN(ry)
+    if (j >= 1) { a[j - 1] = a[j - 1] * ry; SK_PIN(a[j - 1]) }
+    SK_FILL(4)
+    __builtin_amdgcn_sched_barrier(0);
+    m_prev = m;
+    d_prev = d;
 #pragma unroll
-  for (int c = 0; c < 32; ++c) D[row * kBs + c] = c <= row ? a[c] : 0.0;
-  *ok = good;
+    for (int c = j + 2; c < 32; ++c) cbp[c] = cbn[c];
+  }
+#undef SK_FILL
+#undef SK_PIN
+  a[31] = a[31] * fast_rsqrt(d_prev);
+  // a zero or NaN pivot poisons every later one, so the last pivot speaks for them
+  return sgn >= 0 && d_prev > 0.0;
 }
 
-// Column `col` of the inverse of the lower-triangular 32x32 block D (LDS), by
-// forward substitution; L(i,t) are broadcast reads.  x[i] = 0 for i < col.
-__device__ __forceinline__ void lane_inverse32(const double* D, const double* rinv, int col, double (&x)[32]) {
-  // column-oriented (axpy) form: once x[i] is final it is folded into every later row, so the 32
-  // steps are a chain of (mul, fma) pairs with 31-i INDEPENDENT fmas each, not a serial dot product
-#pragma unroll
-  for (int i = 0; i < 32; ++i) x[i] = (i == col) ? 1.0 : 0.0;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    x[i] = (i >= col) ? x[i] * rinv[i] : 0.0;
-#pragma unroll
-    for (int t = i + 1; t < 32; ++t) x[t] -= D[t * kBs + i] * x[i];
-    __builtin_amdgcn_sched_barrier(0);  // keep the broadcast reads of later columns from being hoisted (register pressure)
-  }
-}
-
-// One row of the panel below a factored diagonal block: x L^T = a, i.e.
-// x_j = (a_j - sum_{t<j} x_t L(j,t)) / L(j,j), L(j,t) broadcast from LDS.
-__device__ __forceinline__ void row_trsm32(const double* D, const double* rinv, double (&a)[32]) {
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    a[j] = a[j] * rinv[j];
-#pragma unroll
-    for (int t = j + 1; t < 32; ++t) a[t] -= a[j] * D[t * kBs + j];  // independent fmas (axpy form)
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// Row-oriented (dot-product) forms of the two helpers above, kept for A/B timing (SK_POTRF_DOT=1).
-__device__ __forceinline__ void lane_inverse32_dot(const double* D, const double* rinv, int col, double (&x)[32]) {
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    double s = (i == col) ? 1.0 : 0.0;
-#pragma unroll
-    for (int t = 0; t < i; ++t) s -= D[i * kBs + t] * x[t];
-    x[i] = (i >= col) ? s * rinv[i] : 0.0;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-__device__ __forceinline__ void row_trsm32_dot(const double* D, const double* rinv, double (&a)[32]) {
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    double s = a[j];
-#pragma unroll
-    for (int t = 0; t < j; ++t) s -= a[t] * D[j * kBs + t];
-    a[j] = s * rinv[j];
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// acc(2x2 MFMA tiles of a 32x32 block) += P Q^T, P/Q 32x32 blocks in LDS (stride kBs)
-// transQ == false: Q used as rows (C = P Q^T);  true: Q used as is (C = P Q)
+// acc(2x2 MFMA tiles of a 32x32 block) += P Q^T (kPlainB false) or P Q (true); P, Q 32x32 blocks in LDS (stride kBs)
 template <bool kPlainB>
 __device__ __forceinline__ void block_mma32(d4 (&acc)[2][2], const double* P, const double* Q, int lane) {
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -342,6 +386,12 @@ __device__ __forceinline__ void block_mma32(d4 (&acc)[2][2], const double* P, co
         acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
   }
 }
+__device__ __forceinline__ void block_zero32(d4 (&acc)[2][2]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+}
 __device__ __forceinline__ void block_store32(double* dst, const d4 (&acc)[2][2], int lane, double sgn) {
   const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
@@ -360,29 +410,53 @@ __device__ __forceinline__ void block_load32(d4 (&acc)[2][2], const double* src,
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[mt][nt][i] = sgn * src[(mt * 16 + l4 + 4 * i) * kBs + nt * 16 + l15];
 }
+// C -= P Q^T on one wave (all three 32x32 LDS blocks)
+__device__ __forceinline__ void block_update32(double* Cb, const double* P, const double* Q, int lane) {
+  d4 acc[2][2];
+  block_load32(acc, Cb, lane, -1.0);
+  block_mma32<false>(acc, P, Q, lane);
+  block_store32(Cb, acc, lane, -1.0);
+}
+// one wave: 32x32 LDS block -> global, 256-byte row segments.  dst is wave-uniform; goff = (lane >> 5) * ldd + (lane & 31)
+// and loff = (lane >> 5) * kBs + (lane & 31) are the lane's offsets, step2 = 2 * ldd (32-bit: scalar base + vector offset addressing)
+__device__ __forceinline__ void block_to_global(double* dst, unsigned step2, unsigned goff, const double* src, int loff) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dst[goff + i * step2] = src[loff + i * 2 * kBs];
+}
+// one wave: dst (LDS block, may be a scratch partial sum S) <- -W S, S read completely before the overwrite
+__device__ __forceinline__ void block_neg_left_mul32(double* dst, const double* W, int lane) {
+  d4 acc[2][2];
+  block_zero32(acc);
+  block_mma32<true>(acc, W, dst, lane);
+  // the MFMA results depend on every read of dst, so the overwrite cannot pass them
+  block_store32(dst, acc, lane, -1.0);
+}
 
-template <bool kAxpy>
+#ifdef SK_POTRF_STAMPS
+__device__ long long g_potrf_stamps[4][16], g_potrf_clk[4][16];
+#define SK_STAMP(i) if (lane == 0) { g_potrf_stamps[wave][i] = wall_clock64(); g_potrf_clk[wave][i] = clock64(); }
+#else
+#define SK_STAMP(i)
+#endif
+
 __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* T = lds;                          // 10 packed 32x32 blocks (lower triangle of the tile)
-  double* colbuf = lds + 10 * kB * kBs;     // 64 doubles: column broadcast of the wave-level factorisation
-  double* rinv = colbuf + 64;               // 32 doubles: 1 / L(j,j) of the current diagonal sub-block
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // this workgroup is the serial bottleneck of the factorisation and may share its CU with a
-  // trailing-update workgroup (look-ahead): win the issue arbitration
+  double* T = lds;                      // blocks 0..9: lower triangle of the tile (diagonal slots end as W_jj); 10..15: inverse, below the diagonal
+  double* E = lds + 16 * kBlk;          // block 16: staging of L_jj on its way to global memory
+  double* colbuf = lds + 17 * kBlk;     // 3 x 64 doubles
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   __builtin_amdgcn_s_setprio(3);
+  SK_STAMP(0)
   // load the lower blocks: all 40 loads of a lane are issued before the first LDS write (one HBM round trip)
-  // element e = t + 256 i of a 32x32 block: per-lane offsets inside a block (global and LDS); the block
-  // offsets are wave-uniform, so only these eight values stay live for the load and the write-backs
-  long goff[4];
-  int loff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int e = t + 256 * i;
-    goff[i] = (long)(e >> 5) * ld + (e & 31);
-    loff[i] = (e >> 5) * kBs + (e & 31);
-  }
   {
+    long goff[4];
+    int loff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t + 256 * i;
+      goff[i] = (long)(e >> 5) * ld + (e & 31);
+      loff[i] = (e >> 5) * kBs + (e & 31);
+    }
     double v[10][4];
     int b = 0;
 #pragma unroll
@@ -402,112 +476,150 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
         for (int i = 0; i < 4; ++i) T[blk_off(bi, bj) + loff[i]] = v[b][i];
   }
   __syncthreads();
+  SK_STAMP(1)
+  const unsigned uld = (unsigned)ld;
+  const unsigned go_a = (unsigned)(lane >> 5) * uld + (lane & 31), go_i = (unsigned)(lane >> 5) * 128u + (lane & 31);
+  const int lo_w = (lane >> 5) * kBs + (lane & 31);
+#define SK_L(bi, bj) (T + blk_off(bi, bj))
+#define SK_V(bi, bj) (T + inv_off(bi, bj))
+#define SK_GA(bi, bj) (A + ((long)(bi) * kB * ld + (bj) * kB))
+#define SK_GI(bi, bj) (Linv + ((bi) * kB * 128 + (bj) * kB))
+  // phase B: panel block bi below W_jj, then its own diagonal update (same wave: no barrier in between)
+#define SK_PHASE_B(jb, bi)                                                                      \
+  if ((bi) < 4) {                                                                               \
+    d4 acc[2][2];                                                                               \
+    block_zero32(acc);                                                                          \
+    block_mma32<false>(acc, SK_L(bi, jb), SK_L(jb, jb), lane);                                  \
+    block_store32(SK_L(bi, jb), acc, lane, 1.0); /* every read of the block feeds the MFMAs */  \
+    block_update32(SK_L(bi, bi), SK_L(bi, jb), SK_L(bi, jb), lane);                             \
+  }
+#define SK_WRITE_L(bi, bj) block_to_global(SK_GA(bi, bj), 2 * uld, go_a, SK_L(bi, bj), lo_w);
+#define SK_WRITE_W(bi) block_to_global(SK_GI(bi, bi), 256u, go_i, SK_L(bi, bi), lo_w);
+#define SK_WRITE_V(bi, bj) block_to_global(SK_GI(bi, bj), 256u, go_i, SK_V(bi, bj), lo_w);
+#define SK_WRITE_E(bi) block_to_global(SK_GA(bi, bi), 2 * uld, go_a, E, lo_w);
+  // Wave 0 runs a loop (one copy of the 32-column chain in the instruction cache); waves 1..3 run
+  // straight-line code with the same number of barriers (7).  `wave` is scalar: the branches are uniform.
+  if (wave == 0) {
 #pragma unroll 1
-  for (int jb = 0; jb < 4; ++jb) {
-    double* D = T + blk_off(jb, jb);
-    // (a) diagonal sub-block: factor, wave 0
-    if (wave == 0) {
+    for (int jb = 0; jb < 4; ++jb) {
+      double* D = SK_L(jb, jb);
       double a[32];
-      const int row = lane & 31;
-      bool ok;
-      wave_potrf32(D, colbuf, rinv, a, &ok);
+      const bool ok = wave_potrf32(D, colbuf, a, lane);
+      SK_STAMP(11 + jb)
       if (!ok && lane == 0) *info = 1;
-      if (lane < 32) {
+      {
+        // lanes 0..31: row of L_jj -> staging block E (written to global by wave 3 in the next phase);
+        // lanes 32..63: column k of W_jj -> the slot of D (zeros above the diagonal in both)
+        const int row = lane & 31;
+        double* dst = lane < 32 ? E + row * kBs : D + row;
+        const int step = lane < 32 ? 1 : kBs;
 #pragma unroll
-        for (int c = 0; c < 32; ++c)
-          if (c <= row) A[(long)(jb * kB + row) * ld + jb * kB + c] = a[c];
+        for (int c = 0; c < 32; ++c) dst[c * step] = (lane >= 32 || c <= row) ? a[c] : 0.0;
+      }
+      SK_STAMP(2 + 2 * jb)
+      __syncthreads();
+      if (jb < 3) {
+        SK_PHASE_B(jb, jb + 1)
+        SK_STAMP(3 + 2 * jb)
+        __syncthreads();
       }
     }
-    __syncthreads();
-    // (b) panel rows below: one lane per row, x L^T = a by forward substitution
-    {
-      const int bi = jb + 1 + (t >> 5), r = t & 31;
-      if (bi < 4) {
-        double a[32];
-        double* Xb = T + blk_off(bi, jb);
-#pragma unroll
-        for (int c = 0; c < 32; ++c) a[c] = Xb[r * kBs + c];
-        if (kAxpy) row_trsm32(D, rinv, a); else row_trsm32_dot(D, rinv, a);
-#pragma unroll
-        for (int c = 0; c < 32; ++c) Xb[r * kBs + c] = a[c];
-      }
+  } else {
+    d4 accs[2][2];  // a partial sum S carried in registers across a barrier
+    SK_STAMP(2)
+    __syncthreads();  // ---- B0
+    SK_PHASE_B(0, 1 + wave)
+    if (wave == 3) { SK_WRITE_E(0) }
+    SK_STAMP(3)
+    __syncthreads();  // ---- next to P(1): off-diagonal updates of step 0
+    if (wave == 1) block_update32(SK_L(2, 1), SK_L(2, 0), SK_L(1, 0), lane);
+    if (wave == 2) block_update32(SK_L(3, 1), SK_L(3, 0), SK_L(1, 0), lane);
+    if (wave == 3) block_update32(SK_L(3, 2), SK_L(3, 0), SK_L(2, 0), lane);
+    SK_STAMP(4)
+    __syncthreads();  // ---- B1
+    if (wave == 1) { SK_PHASE_B(1, 3) }
+    if (wave == 2) {  // Inv(1,0) = -W_1 (L_10 W_0)
+      d4 acc[2][2];
+      block_zero32(acc);
+      block_mma32<true>(acc, SK_L(1, 0), SK_L(0, 0), lane);
+      block_store32(SK_V(1, 0), acc, lane, 1.0);
+      block_neg_left_mul32(SK_V(1, 0), SK_L(1, 1), lane);
     }
-    __syncthreads();
-    // (c) trailing update inside the tile on waves 0..2: T(bi,bj) -= X_bi X_bj^T, jb < bj <= bi;
-    //     meanwhile wave 3 replaces L(jb,jb) (no longer needed in LDS) by its inverse, one lane per
-    //     column: every lane finishes its broadcast reads of D before the first write (same wave).
+    if (wave == 3) {  // S(2,0) = L_20 W_0 ...
+      block_zero32(accs);
+      block_mma32<true>(accs, SK_L(2, 0), SK_L(0, 0), lane);
+      SK_WRITE_E(1) SK_WRITE_L(1, 0) SK_WRITE_L(2, 0) SK_WRITE_L(3, 0) SK_WRITE_W(0)
+    }
+    SK_STAMP(5)
+    __syncthreads();  // ---- next to P(2)
+    if (wave == 1) { block_update32(SK_L(3, 2), SK_L(3, 1), SK_L(2, 1), lane); SK_WRITE_L(2, 1) }
+    if (wave == 2) {  // S(2,1) = L_21 W_1
+      d4 acc[2][2];
+      block_zero32(acc);
+      block_mma32<true>(acc, SK_L(2, 1), SK_L(1, 1), lane);
+      block_store32(SK_V(2, 1), acc, lane, 1.0);
+      SK_WRITE_V(1, 0)
+    }
+    if (wave == 3) {  // ... + L_21 Inv(1,0)
+      block_mma32<true>(accs, SK_L(2, 1), SK_V(1, 0), lane);
+      block_store32(SK_V(2, 0), accs, lane, 1.0);
+    }
+    SK_STAMP(6)
+    __syncthreads();  // ---- B2 (wave 0 alone on the panel): row 2 of the inverse, start of row 3
+    if (wave == 1) {  // S(3,0) = L_30 W_0 + L_31 Inv(1,0) ...
+      block_zero32(accs);
+      block_mma32<true>(accs, SK_L(3, 0), SK_L(0, 0), lane);
+      block_mma32<true>(accs, SK_L(3, 1), SK_V(1, 0), lane);
+      SK_WRITE_L(3, 1)
+    }
+    if (wave == 2) {  // Inv(2,1) = -W_2 S(2,1);  S(3,1) = L_31 W_1 ...
+      block_neg_left_mul32(SK_V(2, 1), SK_L(2, 2), lane);
+      block_zero32(accs);
+      block_mma32<true>(accs, SK_L(3, 1), SK_L(1, 1), lane);
+    }
+    if (wave == 3) {  // Inv(2,0) = -W_2 S(2,0)
+      SK_WRITE_E(2)
+      block_neg_left_mul32(SK_V(2, 0), SK_L(2, 2), lane);
+      SK_WRITE_W(1)
+    }
+    SK_STAMP(7)
+    __syncthreads();  // ---- next to P(3): the partial sums of row 3 are completed with L_32
+    if (wave == 1) {
+      block_mma32<true>(accs, SK_L(3, 2), SK_V(2, 0), lane);
+      block_store32(SK_V(3, 0), accs, lane, 1.0);
+      SK_WRITE_V(2, 0)
+    }
+    if (wave == 2) {
+      block_mma32<true>(accs, SK_L(3, 2), SK_V(2, 1), lane);
+      block_store32(SK_V(3, 1), accs, lane, 1.0);
+      SK_WRITE_V(2, 1)
+    }
     if (wave == 3) {
-      double xinv[32];
-      if (kAxpy) lane_inverse32(D, rinv, lane & 31, xinv); else lane_inverse32_dot(D, rinv, lane & 31, xinv);
-      __builtin_amdgcn_wave_barrier();
-      if (lane < 32) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) D[i * kBs + lane] = xinv[i];
-      }
-    } else {
-      int idx = 0;
-      for (int bi = jb + 1; bi < 4; ++bi)
-        for (int bj = jb + 1; bj <= bi; ++bj, ++idx) {
-          if ((idx % 3) != wave) continue;
-          d4 acc[2][2];
-          double* Cb = T + blk_off(bi, bj);
-          block_load32(acc, Cb, lane, -1.0);
-          block_mma32<false>(acc, T + blk_off(bi, jb), T + blk_off(bj, jb), lane);
-          block_store32(Cb, acc, lane, -1.0);
-        }
+      block_zero32(accs);
+      block_mma32<true>(accs, SK_L(3, 2), SK_L(2, 2), lane);
+      block_store32(SK_V(3, 2), accs, lane, 1.0);
+      SK_WRITE_L(3, 2) SK_WRITE_W(2)
     }
+    SK_STAMP(8)
     __syncthreads();
   }
-  // LDS now: diagonal blocks = inverses of the diagonal blocks of L, off-diagonal blocks = L.
-  // Write the off-diagonal blocks of L back (coalesced, from LDS).
-#pragma unroll
-  for (int bi = 1; bi < 4; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < bi; ++bj) {
-      double* Ab = A + ((long)bi * kB * ld + bj * kB);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) Ab[goff[i]] = T[blk_off(bi, bj) + loff[i]];
-    }
-  // Blocked in-place triangular inverse, block columns right to left:
-  //   Inv(bi,bj) = -(sum_{t=bj+1..bi} Inv(bi,t) L(t,bj)) InvD_bj
-  // The product P parks in the destination block itself once every L(t,bj) of the column has been read.
-  for (int bj = 2; bj >= 0; --bj) {
-    const int bi = bj + 1 + wave;  // one wave per block of this block column
-    d4 acc[2][2];
-    const bool active = bi < 4;
-    if (active) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int tt = bj + 1; tt <= bi; ++tt) block_mma32<true>(acc, T + blk_off(bi, tt), T + blk_off(tt, bj), lane);
-    }
-    __syncthreads();  // every L(t,bj) of this column has been read (and written back above)
-    if (active) {
-      double* dstb = T + blk_off(bi, bj);
-      block_store32(dstb, acc, lane, 1.0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
-      block_mma32<true>(acc, dstb, T + blk_off(bj, bj), lane);
-      // the MFMA results depend on every read of dstb, so the overwrite below cannot pass them
-      block_store32(dstb, acc, lane, -1.0);
-    }
-    __syncthreads();
+  // row 3 of the inverse: Inv(3,bj) = -W_3 S(3,bj)
+  if (wave < 3) {
+    block_neg_left_mul32(SK_V(3, wave), SK_L(3, 3), lane);
+    SK_WRITE_V(3, wave)
+  } else {
+    SK_WRITE_E(3) SK_WRITE_W(3)
   }
-  // write the inverse (lower blocks; diagonal blocks carry explicit zeros above the diagonal)
-#pragma unroll
-  for (int bi = 0; bi < 4; ++bi)
-#pragma unroll
-    for (int bj = 0; bj <= bi; ++bj)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int e = t + 256 * i;
-        Linv[(bi * kB + (e >> 5)) * 128 + bj * kB + (e & 31)] = T[blk_off(bi, bj) + loff[i]];
-      }
+#undef SK_PHASE_B
+#undef SK_WRITE_L
+#undef SK_WRITE_W
+#undef SK_WRITE_V
+#undef SK_WRITE_E
+  SK_STAMP(10)
+#undef SK_L
+#undef SK_V
+#undef SK_GA
+#undef SK_GI
 }
 
 // ---------------------------------------------------------------------------
@@ -560,20 +672,12 @@ __global__ void copy_row_kernel(const double* __restrict__ src, double* __restri
 // ---------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------
-// 84.6 KB: leaves room for one SYRK workgroup (72 KB) on the same CU, so the look-ahead
-// potrf does not have to wait for a CU to drain completely.
-// 84.6 KB of dynamic LDS (SK_POTRF_LDS_KB=160 makes it claim a whole CU, for look-ahead experiments).
-static bool g_potrf_dot = true;  // row-oriented helpers measured 30 us per block faster than the axpy form
-static size_t g_potrf_lds = (size_t)(10 * kB * kBs + 64 + 32) * sizeof(double);
+// 17 packed 32x32 blocks + the column buffer: 142 KB of dynamic LDS
+static const size_t g_potrf_lds = (size_t)(17 * kBlk + 192) * sizeof(double);
 size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
 hipError_t cholesky_init() {
-  // developer knobs for A/B timing
-  if (const char* e = getenv("SK_POTRF_DOT")) g_potrf_dot = atoi(e) != 0;
-  if (const char* e = getenv("SK_POTRF_LDS_KB")) g_potrf_lds = (size_t)atoi(e) * 1024;
-  hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (rc != hipSuccess) return rc;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 CholeskyContext::~CholeskyContext() {
@@ -618,8 +722,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   auto potrf = [&](int kb) {
     double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
     if (kt) kt->begin("potrf128", sp);
-    if (g_potrf_dot) hipLaunchKernelGGL(potrf128_kernel<false>, dim3(1), dim3(256), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
-    else hipLaunchKernelGGL(potrf128_kernel<true>, dim3(1), dim3(256), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
+    hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
     if (kt) kt->end("potrf128", sp);
   };
   // C[tiles_m x tiles_n tiles] -= A B^T on the bulk stream
