@@ -98,8 +98,8 @@ def cpu_baseline(prob, iters):
 
 
 def args_group_k(args):
-    """SYRK depth in 128-column blocks (library default 2)."""
-    return args.group if args.group > 0 else 2
+    """SYRK depth in 128-column blocks (library default 3)."""
+    return args.group if args.group > 0 else 3
 
 
 def main():
@@ -140,7 +140,10 @@ def main():
     options.setParameterTolerance(0.0)
     options.setDevice(local_rank)
     options.setCholeskyTuning(args.group, not args.no_lookahead)
-    stream = torch.cuda.current_stream()
+    # a stream of our own, not torch's default (null) stream: the null stream synchronises implicitly with every
+    # blocking stream, which would serialise the factorisation's CU-masked SYRK stream against it
+    stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(stream)  # torch's current stream too: the all-reduce hook's collectives are ordered with the solver's kernels
     options.setStream(stream.cuda_stream)
     hook = None
     if world > 1:
@@ -173,6 +176,26 @@ def main():
     syrk_flops = solver.syrkFlopsPerSolve()
     summary = sk.Solver.Summary()
     solver.finish(summary)
+    # Untimed side measurement: the same kernel with the look-ahead off, i.e. alone on the chip.  In the
+    # timed region above it shares the CUs with the panel chain of the next block-column group (and its
+    # stream is masked off a few CUs per XCD), so its per-launch time there is longer by design.
+    alone = None
+    if world == 1 and not args.no_lookahead:
+        del solver
+        prob2 = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB)
+        problem2, params2, loss2 = build_problem(sk, prob2)
+        options.setCholeskyTuning(args.group, False)
+        solver2 = sk.StepSolver(options, problem2)
+        solver2.step()
+        solver2.setKernelTiming(2)
+        for _ in range(3):
+            solver2.step()
+        torch.cuda.synchronize()
+        s2, n2 = solver2.kernelSeconds("gemm_syrk")
+        if s2 > 0:
+            alone = (solver2.syrkFlopsPerSolve() * 3) / s2 * 1e-12
+        solver2.finish(sk.Solver.Summary())
+        del solver2
     its = summary.iterations()
     timed = its[1 + args.warmup: 1 + args.warmup + args.steps]
     n_success = int(sum(it["step_is_successful"] for it in timed))
@@ -195,7 +218,10 @@ def main():
                                          "includes Infinity-Cache hits); algorithmic C-tile bytes/launch = %.3e" % (
                                              syrk_flops / max(1, syrk_n / max(1, args.steps)) / (2.0 * 128 * 128 * 128 * args_group_k(args)) * 2 * 131072),
                          "launches": syrk_n, "avg_launch_ms": 1e3 * syrk_s / max(1, syrk_n),
-                         "flops_per_solve": syrk_flops},
+                         "flops_per_solve": syrk_flops,
+                         "achieved_alone": alone, "frac_alone": (alone / FP64_MFMA_PEAK_TFLOPS) if alone else None,
+                         "note": "achieved/frac: live, inside the timed region, where the SYRK shares the chip with the look-ahead "
+                                 "panel chain (masked off 16-32 CUs); *_alone: same kernel, look-ahead off, 3 untimed steps"},
             "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(
                 ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"])},
         }

@@ -682,12 +682,58 @@ hipError_t cholesky_init() {
 
 CholeskyContext::~CholeskyContext() {
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
-  if (pot) (void)hipStreamDestroy(pot);
+}
+
+// The two streams are created once per process and shared by every context (one process drives one
+// GPU): creating a second CU-masked stream after destroying the first one hangs on this ROCm build.
+static hipStream_t g_panel_stream = nullptr, g_bulk_stream = nullptr, g_bulk_early_stream = nullptr;
+static int g_reserved_cus = 0, g_early_tiles = 0;
+
+// stream whose kernels stay off the first `per_xcd` CUs of every XCD (plain stream when per_xcd == 0 or masks are unavailable)
+static hipError_t create_bulk_stream(hipStream_t* out, int per_xcd, int ncu, int* reserved) {
+  *reserved = 0;
+  if (per_xcd > 0 && ncu >= 64 && ncu % 8 == 0 && per_xcd < ncu / 8) {
+    // mask bit i <-> XCD i % 8, CU i / 8 of that XCD (measured with tools/cumask_probe.hip)
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = per_xcd * 8; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()) == hipSuccess) { *reserved = per_xcd * 8; return hipSuccess; }
+    (void)hipGetLastError();
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
 
 hipError_t CholeskyContext::init() {
-  if (pot) return hipSuccess;
-  return hipStreamCreateWithFlags(&pot, hipStreamNonBlocking);
+  if (panel) return hipSuccess;
+  if (!g_panel_stream) {
+    hipStream_t p = nullptr, b = nullptr, be = nullptr;
+    hipError_t rc = hipStreamCreateWithFlags(&p, hipStreamNonBlocking);
+    if (rc != hipSuccess) return rc;
+    int dev = 0, ncu = 0, reserved = 0, reserved_early = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    // CUs per XCD kept free of the SYRK; developer knobs (0 = no mask)
+    int per_xcd = 4, per_xcd_early = 2, early_tiles = 72;
+    if (const char* e = getenv("SK_LA_RESERVED_PER_XCD")) per_xcd = atoi(e);
+    if (const char* e = getenv("SK_LA_RESERVED_EARLY")) per_xcd_early = atoi(e);
+    if (const char* e = getenv("SK_LA_EARLY_TILES")) early_tiles = atoi(e);
+    rc = create_bulk_stream(&b, per_xcd, ncu, &reserved);
+    if (rc == hipSuccess) rc = create_bulk_stream(&be, per_xcd_early, ncu, &reserved_early);
+    if (rc != hipSuccess) {
+      if (b) (void)hipStreamDestroy(b);
+      (void)hipStreamDestroy(p);
+      return rc;
+    }
+    g_panel_stream = p; g_bulk_stream = b; g_bulk_early_stream = be; g_reserved_cus = reserved; g_early_tiles = early_tiles;
+    // destroyed once, at process exit, before the HIP runtime's own teardown (handlers run in reverse order of registration)
+    atexit([] {
+      if (g_bulk_stream) (void)hipStreamDestroy(g_bulk_stream);
+      if (g_bulk_early_stream) (void)hipStreamDestroy(g_bulk_early_stream);
+      if (g_panel_stream) (void)hipStreamDestroy(g_panel_stream);
+      g_bulk_stream = g_bulk_early_stream = g_panel_stream = nullptr;
+    });
+  }
+  panel = g_panel_stream; bulk = g_bulk_stream; bulk_early = g_bulk_early_stream; reserved_cus = g_reserved_cus; early_tiles = g_early_tiles;
+  return hipSuccess;
 }
 
 hipEvent_t CholeskyContext::event(size_t i) {
@@ -703,89 +749,97 @@ hipEvent_t CholeskyContext::event(size_t i) {
 // (zero-initialised once).  Right-looking over groups of `group` block columns, lazy
 // left-looking inside a group.
 //
-// potrf128 is one workgroup and serial (~85 us, 122 of them at n = 15 507), so with a context it
-// is taken off the critical path: the update that feeds it is split into the DIAGONAL tile (one
-// workgroup) and the rest of the block column, and potrf128 runs on a second stream next to that
-// rest.  The first diagonal block of a group comes out of the trailing SYRK, which is split the
-// same way, so that potrf128 hides behind the whole SYRK.  (What was measured and dropped:
-// overlapping the panel chain with the SYRK on two queues — a 6000-workgroup grid starves the
-// other queue, and under full fp64-MFMA load the clock drops so far that a co-running potrf128
-// takes 2.3x longer; see DESIGN.md.)
+// Per group g (block columns [k0, k1)):
+//   panel(g)      potrf128 / TRSM of each block column, lazy updates from the columns of the group before it
+//   next(g)       the part of the trailing update that the NEXT panel needs: block columns [k1, k1 + group)
+//   syrk(g)       the rest of the trailing update (the dominant launch)
+// panel(g+1) depends on next(g) only and next(g) on panel(g) and syrk(g-1), so with a context
+// next(g), panel(g+1) run on the panel stream next to syrk(g) on the bulk stream and the SYRKs
+// follow each other without a gap: the serial chain (potrf128 is one workgroup; the TRSM and update
+// grids are a few hundred workgroups) is hidden behind the SYRK as long as the SYRK is the longer
+// of the two, which it is for the first half of the groups (87 % of the flops).  The bulk stream's CU
+// mask keeps a few CUs per XCD free: without them the panel kernels sit behind the SYRK's
+// workgroups in the dispatcher and nothing overlaps (measured).
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
                      KernelTimer* kt) {
   const int nblk = npad / 128;
-  const bool la = ctx != nullptr && ctx->pot != nullptr;
-  hipStream_t sp = la ? ctx->pot : s;
+  const bool la = ctx != nullptr && ctx->panel != nullptr && ctx->bulk != nullptr;
+  hipStream_t sp = la ? ctx->panel : s;
+  hipStream_t sb = la ? ctx->bulk : s;  // of the current group (chosen below)
+  hipStream_t sb_prev = sb;
   size_t ev = 0;
-  auto bulk_to_pot = [&]() { if (la) { hipEvent_t e = ctx->event(ev++); (void)hipEventRecord(e, s); (void)hipStreamWaitEvent(sp, e, 0); } };
-  auto pot_to_bulk = [&]() { if (la) { hipEvent_t e = ctx->event(ev++); (void)hipEventRecord(e, sp); (void)hipStreamWaitEvent(s, e, 0); } };
-  auto potrf = [&](int kb) {
-    double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
-    if (kt) kt->begin("potrf128", sp);
-    hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
-    if (kt) kt->end("potrf128", sp);
+  auto order = [&](hipStream_t from, hipStream_t to) {  // work enqueued on `to` from here on runs after everything enqueued on `from` so far
+    if (from == to) return;
+    hipEvent_t e = ctx->event(ev++);
+    (void)hipEventRecord(e, from);
+    (void)hipStreamWaitEvent(to, e, 0);
   };
-  // C[tiles_m x tiles_n tiles] -= A B^T on the bulk stream
-  auto update = [&](const char* name, double* C, const double* A, const double* B, int K, int tiles_m, int tiles_n, int flags) {
+  // C[tiles_m x tiles_n tiles of 128] -= A B^T
+  auto update = [&](hipStream_t st, const char* name, double* C, const double* A, const double* B, int K, int tiles_m, int tiles_n, int flags) {
     if (tiles_m <= 0 || tiles_n <= 0) return;
-    if (kt) kt->begin(name, s);
-    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(2 * tiles_m * tiles_n), dim3(256), 0, s, C, ld, A, ld, B, ld, K, 2 * tiles_m, flags);
-    if (kt) kt->end(name, s);
+    if (kt) kt->begin(name, st);
+    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(2 * tiles_m * tiles_n), dim3(256), 0, st, C, ld, A, ld, B, ld, K, 2 * tiles_m, flags);
+    if (kt) kt->end(name, st);
   };
   // one diagonal 128-block: C -= A A^T
-  auto update_diag = [&](const char* name, double* C, const double* A, int K) {
-    if (kt) kt->begin(name, s);
-    hipLaunchKernelGGL(gemm_diag_f64_kernel, dim3(4), dim3(256), 0, s, C, ld, A, ld, K);
-    if (kt) kt->end(name, s);
+  auto update_diag = [&](hipStream_t st, const char* name, double* C, const double* A, int K) {
+    if (kt) kt->begin(name, st);
+    hipLaunchKernelGGL(gemm_diag_f64_kernel, dim3(4), dim3(256), 0, st, C, ld, A, ld, K);
+    if (kt) kt->end(name, st);
   };
-  bulk_to_pot();  // S is assembled: the first diagonal block may be factored
-  for (int k0 = 0; k0 < nblk; k0 += group) {
-    const int k1 = k0 + group < nblk ? k0 + group : nblk;
+  auto panel = [&](int k0, int k1) {
     for (int kb = k0; kb < k1; ++kb) {
       double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
       const int rows_below = nblk - kb - 1;
-      if (kb > k0) {
-        // lazy left-looking update of block column kb from columns [k0, kb): diagonal tile first ...
-        const double* P = S + (long)kb * 128 * ld + (long)k0 * 128;
-        const int K = (kb - k0) * 128;
-        update_diag("gemm_diag_update", Akk, P, K);
-        bulk_to_pot();
-        potrf(kb);
-        // ... then the rows below it, next to potrf128
-        update("gemm_panel_update", Akk + 128 * ld, P + 128 * ld, P, K, rows_below, 1, 0);
-      } else {
-        potrf(kb);  // its diagonal tile was finished by the previous group's SYRK (or by the assembly)
-      }
-      pot_to_bulk();
+      const double* P = S + (long)kb * 128 * ld + (long)k0 * 128;
+      const int K = (kb - k0) * 128;
+      if (kb > k0) update_diag(sp, "gemm_diag_update", Akk, P, K);  // lazy left-looking update from columns [k0, kb): diagonal tile ...
+      if (kt) kt->begin("potrf128", sp);
+      hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
+      if (kt) kt->end("potrf128", sp);
       if (rows_below > 0) {
         double* A21 = Akk + 128 * ld;
-        if (kt) kt->begin("gemm_trsm", s);
-        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(2 * rows_below), dim3(256), 0, s, A21, ld, A21, ld, Linv + (long)kb * 128 * 128, 2 * rows_below);
-        if (kt) kt->end("gemm_trsm", s);
+        if (kb > k0) update(sp, "gemm_panel_update", A21, P + 128 * ld, P, K, rows_below, 1, 0);  // ... and the rows below it
+        if (kt) kt->begin("gemm_trsm", sp);
+        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(2 * rows_below), dim3(256), 0, sp, A21, ld, A21, ld, Linv + (long)kb * 128 * 128, 2 * rows_below);
+        if (kt) kt->end("gemm_trsm", sp);
       }
     }
+  };
+  order(s, sp);
+  if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }
+  panel(0, group < nblk ? group : nblk);
+  hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
+  for (int k0 = 0; k0 < nblk; k0 += group) {
+    const int k1 = k0 + group < nblk ? k0 + group : nblk;
     const int T = nblk - k1;  // trailing tile rows
     if (T <= 0) break;
     const int K = (k1 - k0) * 128;
     const int na = group < T ? group : T;  // tile columns of the next group
     double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
-    // trailing SYRK, K = group * 128.  Its first tile is the next diagonal block: do it alone, release potrf128 ...
-    update_diag("gemm_diag_update", A22, P, K);
-    bulk_to_pot();
-    // ... then (a) the rest of the next group's block columns (T x na tiles; above-diagonal and first tile skipped) ...
-    update("gemm_syrk_next", A22, P, P, K, T, na, 3);
-    // ... and (b) everything right of them: lower triangle of the (T-na) x (T-na) tiles (the dominant launch)
+    if (la) sb = T >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
+    if (sb != sb_prev && syrk_done) (void)hipStreamWaitEvent(sb, syrk_done, 0);  // syrk(g) after syrk(g-1) across the two bulk streams
+    sb_prev = sb;
+    order(sp, sb);  // panel(g) is final: syrk(g) may start (after syrk(g-1))
+    // next(g): T x na tiles, above-diagonal tiles skipped; on the panel stream, after syrk(g-1)
+    if (la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
+    update(sp, "gemm_syrk_next", A22, P, P, K, T, na, 1);
+    // syrk(g): everything right of them, lower triangle of the (T-na) x (T-na) tiles
     const int Tb = T - na;
+    syrk_done = nullptr;
     if (Tb > 0) {
       double* Cb = S + (long)(k1 + na) * 128 * ld + (long)(k1 + na) * 128;
       const double* Pb = S + (long)(k1 + na) * 128 * ld + (long)k0 * 128;
-      if (kt) kt->begin("gemm_syrk", s);
-      hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, s, Cb, ld, Pb, ld, K, 0);
-      if (kt) kt->end("gemm_syrk", s);
+      if (kt) kt->begin("gemm_syrk", sb);
+      hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, Cb, ld, Pb, ld, K, 0);
+      if (kt) kt->end("gemm_syrk", sb);
+      if (la) { syrk_done = ctx->event(ev++); (void)hipEventRecord(syrk_done, sb); }
     }
+    panel(k1, k1 + na);
   }
-  pot_to_bulk();
+  order(sp, s);
+  if (la) { order(ctx->bulk, s); order(ctx->bulk_early, s); }
 }
 
 // y (npad) <- solution of L^T y = z, with z^T = row rhs_row of L (first n entries).  w: scratch (npad).

@@ -74,9 +74,15 @@ class KernelTimer {
   std::map<std::string, Stat> stats_;
 };
 
-// Second stream + events that take potrf128 off the critical path of cholesky_factor.
+// Streams + events of the look-ahead factorisation: the panel chain of the next block-column group
+// runs on `panel` while the trailing SYRK of the current group runs on `bulk`, whose CU mask leaves
+// a few CUs per XCD free so that the panel kernels are never queued behind a 6000-workgroup grid.
 struct CholeskyContext {
-  hipStream_t pot = nullptr;   // second stream: potrf128 only
+  hipStream_t panel = nullptr;
+  hipStream_t bulk = nullptr;        // SYRK of the late groups (short SYRK, the panel chain decides: more CUs kept free)
+  hipStream_t bulk_early = nullptr;  // SYRK of the early groups (long SYRK hides a slow chain: fewer CUs kept free)
+  int early_tiles = 0;               // groups with at least this many trailing tile rows use bulk_early
+  int reserved_cus = 0;              // CUs kept free of the SYRK on `bulk` (0: ordinary stream)
   std::vector<hipEvent_t> events;
   hipError_t init();
   hipEvent_t event(size_t i);

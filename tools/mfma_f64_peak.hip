@@ -8,7 +8,8 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, double a0, double b0) {
+__global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, double a0, double b0, long long* clk) {
+  const long long w0 = wall_clock64(), c0 = clock64();
   d4 acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
   double a = a0 + threadIdx.x * 1e-3, b = b0 - threadIdx.x * 1e-3;
@@ -19,6 +20,7 @@ __global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, double 
   double s = 0;
   for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = wall_clock64() - w0; clk[1] = clock64() - c0; }
 }
 
 __global__ void copy_kernel(const double2* __restrict__ in, double2* __restrict__ out, size_t n) {
@@ -29,28 +31,34 @@ template <int NACC>
 static void run(int waves_per_simd, int iters) {
   const int blocks = 256 * waves_per_simd;  // 256 threads = 4 waves = one per SIMD of a CU
   double* out;
+  long long* clk;
   hipMalloc(&out, (size_t)blocks * 256 * sizeof(double));
+  hipMalloc(&clk, 16);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(mfma_loop<NACC>, dim3(blocks), dim3(256), 0, 0, out, iters / 10, 1.0, 2.0);
+  hipLaunchKernelGGL(mfma_loop<NACC>, dim3(blocks), dim3(256), 0, 0, out, iters / 10, 1.0, 2.0, clk);
   hipDeviceSynchronize();
   float best = 1e30f;
   for (int rep = 0; rep < 5; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(mfma_loop<NACC>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0 + rep, 2.0);
+    hipLaunchKernelGGL(mfma_loop<NACC>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0 + rep, 2.0, clk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
   const double flops = (double)blocks * 4 * (double)iters * NACC * 2.0 * 16 * 16 * 4;
-  printf("mfma_f64_16x16x4 acc=%d waves/SIMD=%d : %.3f ms  %.2f TFLOP/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", NACC, waves_per_simd, best,
-         flops / best * 1e-9, 2.4e9 * best * 1e-3 / ((double)iters * NACC * waves_per_simd));
+  long long h[2];
+  hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  const double mhz = 100.0 * (double)h[1] / (double)h[0];  // s_memtime ticks per 100 MHz wall-clock tick
+  printf("mfma_f64_16x16x4 acc=%d waves/SIMD=%d : %.3f ms  %.2f TFLOP/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz; shader clock counter %.0f MHz)\n", NACC,
+         waves_per_simd, best, flops / best * 1e-9, 2.4e9 * best * 1e-3 / ((double)iters * NACC * waves_per_simd), mhz);
+  hipFree(clk);
   hipFree(out);
 }
 
 int main() {
-  run<4>(1, 20000); run<8>(1, 10000); run<16>(1, 5000); run<8>(2, 10000);
+  run<4>(1, 20000); run<8>(1, 10000); run<16>(1, 5000); run<8>(2, 10000); run<8>(4, 5000); run<4>(8, 5000);
   const size_t n = (size_t)1 << 28;  // 4 GiB in + 4 GiB out
   double2 *a, *b;
   hipMalloc(&a, n * sizeof(double2)); hipMalloc(&b, n * sizeof(double2));
