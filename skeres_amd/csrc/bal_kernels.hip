@@ -9,7 +9,8 @@
 //   observations are stored POINT-MAJOR (all observations of a local point are
 //   contiguous, ascending camera) — obs index `o` below is that order.
 //   r   [2][N]   residuals                      F  [18][N]  d r / d camera  (row-major 2x9 per obs)
-//   E   [6][N]   d r / d point (2x3)            What [27][N] F^T (E M^T)    (9x3 per obs)
+//   E   [6][N]   d r / d point (2x3)            What [N][28] F^T (E M^T)    (9x3 per obs, one 216-byte run: the
+//                                                            Schur kernels gather whole observations)
 //   rt  [2][N]   r - E T^-1 g
 // Jacobi column scaling is folded into F / E as they are written.
 #include <hip/hip_runtime.h>
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
     for (int c = 0; c < 9; ++c) {
       const double f0 = d.F[c * N + o], f1 = d.F[(9 + c) * N + o];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) d.What[(3 * c + a) * N + o] = f0 * eh[0][a] + f1 * eh[1][a];
+      for (int a = 0; a < 3; ++a) d.What[(size_t)o * kWs + 3 * c + a] = f0 * eh[0][a] + f1 * eh[1][a];
     }
   }
 }
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) { f0[c] = d.F[c * N + o]; f1[c] = d.F[(9 + c) * N + o]; }
 #pragma unroll
-    for (int k = 0; k < 27; ++k) w[k] = d.What[k * N + o];
+    for (int k = 0; k < 27; ++k) w[k] = d.What[(size_t)o * kWs + k];
     const double r0 = d.rt[o], r1 = d.rt[N + o];
     int k = 0;
 #pragma unroll
@@ -368,10 +369,11 @@ __global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d) {
   const int e0 = d.seg_start[seg], e1 = d.seg_start[seg + 1];
   for (int e = e0; e < e1; ++e) {
     const int ob = d.pair_row_obs[e], oa = d.pair_col_obs[e];
-    const double y0 = d.What[(3 * c) * N + ob], y1 = d.What[(3 * c + 1) * N + ob], y2 = d.What[(3 * c + 2) * N + ob];
+    const double* wr = d.What + (size_t)ob * kWs + 3 * c;
+    const double* wc = d.What + (size_t)oa * kWs;  // the same 27 values for the nine lanes of a block: one 216-byte run
+    const double y0 = wr[0], y1 = wr[1], y2 = wr[2];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-      acc[k] += y0 * d.What[(3 * k) * N + oa] + y1 * d.What[(3 * k + 1) * N + oa] + y2 * d.What[(3 * k + 2) * N + oa];
+    for (int k = 0; k < 9; ++k) acc[k] += y0 * wc[3 * k] + y1 * wc[3 * k + 1] + y2 * wc[3 * k + 2];
   }
   const int i = d.seg_row[seg], j = d.seg_col[seg];
   double* out = d.S + (size_t)(9 * i + c) * d.ld + 9 * j;
@@ -396,7 +398,7 @@ __global__ void bal_finish_S_kernel(double* S, int ld, int n, int npad, int rhs_
 //   step = -y ; x_new = x + step * scale
 // partial[0] += |delta|^2 (points),  one thread per point.
 // ---------------------------------------------------------------------------
-// Per observation u_o = E_o^T (F_o y_c[cam o]) into planes 0..2 of What (free by
+// Per observation u_o = E_o^T (F_o y_c[cam o]) into the first three slots of the observation's What record (free by
 // now: What is only read during the Schur assembly).  Keeps the per-point pass
 // light, so a 400-observation track does not stall its wave.
 __global__ __launch_bounds__(kBlock) void bal_obs_backsub_kernel(BalDev d) {
@@ -406,9 +408,9 @@ __global__ __launch_bounds__(kBlock) void bal_obs_backsub_kernel(BalDev d) {
     double f0 = 0.0, f1 = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) { f0 += d.F[c * N + o] * yc[c]; f1 += d.F[(9 + c) * N + o] * yc[c]; }
-    d.What[o] = d.E[o] * f0 + d.E[3 * N + o] * f1;
-    d.What[N + o] = d.E[N + o] * f0 + d.E[4 * N + o] * f1;
-    d.What[2 * N + o] = d.E[2 * N + o] * f0 + d.E[5 * N + o] * f1;
+    d.What[(size_t)o * kWs] = d.E[o] * f0 + d.E[3 * N + o] * f1;
+    d.What[(size_t)o * kWs + 1] = d.E[N + o] * f0 + d.E[4 * N + o] * f1;
+    d.What[(size_t)o * kWs + 2] = d.E[2 * N + o] * f0 + d.E[5 * N + o] * f1;
   }
 }
 
@@ -419,9 +421,9 @@ __global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
     const size_t N = d.N, P = d.P;
     double t0 = d.gs_p[3 * (size_t)p], t1 = d.gs_p[3 * (size_t)p + 1], t2 = d.gs_p[3 * (size_t)p + 2];
     for (int o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
-      t0 -= d.What[o];
-      t1 -= d.What[N + o];
-      t2 -= d.What[2 * N + o];
+      t0 -= d.What[(size_t)o * kWs];
+      t1 -= d.What[(size_t)o * kWs + 1];
+      t2 -= d.What[(size_t)o * kWs + 2];
     }
     const double m00 = d.M[p], m10 = d.M[P + p], m11 = d.M[2 * P + p], m20 = d.M[3 * P + p], m21 = d.M[4 * P + p], m22 = d.M[5 * P + p];
     const double u0 = m00 * t0, u1 = m10 * t0 + m11 * t1, u2 = m20 * t0 + m21 * t1 + m22 * t2;

@@ -5,6 +5,7 @@
 
 namespace sk {
 
+constexpr int kWs = 28;  // doubles per observation record of What (27 used; 224 bytes keeps records 32-byte aligned)
 struct BalDev {
   int C, P, N;            // cameras (all, replicated), LOCAL points, LOCAL observations
   // structure (built once on the host, point-major observation order)

@@ -181,7 +181,7 @@ int BalSolver::setup() {
   { std::vector<double> ones(nx, 1.0); SK_HIP_TRY(hipMemcpyAsync(b_scale_.p, ones.data(), nx * sizeof(double), hipMemcpyHostToDevice, s)); SK_HIP_TRY(hipStreamSynchronize(s)); }
   SK_HIP_TRY(b_y_.alloc(npad_));
   SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
-  SK_HIP_TRY(b_W_.alloc(27 * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
+  SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
   const size_t s_elems = (size_t)npad_ * npad_;
   if (opt_.reduce_buffer) {

@@ -626,12 +626,12 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 // Backward substitution L^T y = z over 128-blocks, last block first; one
 // launch per block step kb:
 //   y_kb = Linv_kb^T w_kb                      (every workgroup, redundantly: L2-resident 128 KB)
-//   w[c] -= sum_r L[kb*128+r][c] y_kb[r]       (c < kb*128; 256 columns per workgroup)
+//   w[c] -= sum_r L[kb*128+r][c] y_kb[r]       (c < kb*128; 64 columns per workgroup)
 // 1024 threads so that each lane has only a few dependent HBM/L2 round trips.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict__ Linv, const double* __restrict__ Lrow, long ld,
                                                         double* __restrict__ w, double* __restrict__ yout, int kb, int ncols) {
-  __shared__ double wk[128], ykb[128], part[8][128], red[4][256];
+  __shared__ double wk[128], ykb[128], part[8][128];
   const int t = threadIdx.x;
   if (t < 128) wk[t] = w[kb * 128 + t];
   __syncthreads();
@@ -651,17 +651,25 @@ __global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict_
     if (blockIdx.x == 0) yout[kb * 128 + t] = s;
   }
   __syncthreads();
-  const int cl = t & 255, rg = t >> 8;
-  const int col = blockIdx.x * 256 + cl;
+  // 64 columns per workgroup (512-B row segments), 16 row groups of 8 rows: four times the workgroups of
+  // a 256-column split — the grid is what limits this HBM-bound phase (<= 244 workgroups on 256 CUs)
+  const int cl = t & 63, rg = t >> 6;
+  const int col = blockIdx.x * 64 + cl;
   double s = 0.0;
   if (col < ncols) {
-    const double* p = Lrow + (long)(rg * 32) * ld + col;
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) s += p[(long)i * ld] * ykb[rg * 32 + i];
+    const double* p = Lrow + (long)(rg * 8) * ld + col;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += p[(long)i * ld] * ykb[rg * 8 + i];
   }
-  red[rg][cl] = s;
+  double* red = &part[0][0];  // part[][] is free again: its readers finished before the barrier above
+  red[rg * 64 + cl] = s;
   __syncthreads();
-  if (t < 256 && col < ncols) w[col] -= (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  if (t < 64 && col < ncols) {
+    double u = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) u += red[g * 64 + t];
+    w[col] -= u;
+  }
 }
 
 __global__ void copy_row_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int npad) {
@@ -850,7 +858,7 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
   if (kt) kt->begin("backsolve", s);
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int ncols = kb * 128;
-    const int grid = ncols > 0 ? (ncols + 255) / 256 : 1;
+    const int grid = ncols > 0 ? (ncols + 63) / 64 : 1;
     hipLaunchKernelGGL(bs_step_kernel, dim3(grid), dim3(1024), 0, s, Linv + (long)kb * 128 * 128, S + (long)kb * 128 * ld, ld, w, y, kb, ncols);
   }
   if (kt) kt->end("backsolve", s);
