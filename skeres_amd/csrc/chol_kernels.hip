@@ -684,7 +684,10 @@ __global__ void copy_row_kernel(const double* __restrict__ src, double* __restri
 static const size_t g_potrf_lds = (size_t)(17 * kBlk + 192) * sizeof(double);
 size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
+static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
 hipError_t cholesky_init() {
+  if (const char* e = getenv("SK_TAIL_TILES")) g_tail_tiles = atoi(e);  // developer knobs
+  if (const char* e = getenv("SK_TAIL_GROUP")) g_tail_group = atoi(e);
   return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -753,6 +756,24 @@ hipEvent_t CholeskyContext::event(size_t i) {
   return events[i];
 }
 
+// Block-column groups of the factorisation: `group` columns while the trailing matrix is large (the
+// SYRK is the long pole and wants a deep K), then groups of kTailGroup once fewer than kTailTiles tile
+// rows remain: there the serial panel chain is the long pole and a narrow group keeps it short (no lazy
+// updates inside the group, a K = 128 update for the next panel).  Returns the group start indices + nblk.
+std::vector<int> cholesky_group_bounds(int nblk, int group) {
+  std::vector<int> b;
+  int k = 0;
+  while (k < nblk) {
+    b.push_back(k);
+    const int remaining = nblk - k;
+    int g = remaining <= g_tail_tiles ? g_tail_group : group;
+    if (g < 1) g = 1;
+    k += g < remaining ? g : remaining;
+  }
+  b.push_back(nblk);
+  return b;
+}
+
 // Factor the lower triangle of S (npad x ld) in place.  Linv: nblk blocks of 128x128
 // (zero-initialised once).  Right-looking over groups of `group` block columns, lazy
 // left-looking inside a group.
@@ -814,16 +835,17 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       }
     }
   };
+  const std::vector<int> gb = cholesky_group_bounds(nblk, group);
+  const int ngroups = (int)gb.size() - 1;
   order(s, sp);
   if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }
-  panel(0, group < nblk ? group : nblk);
+  panel(gb[0], gb[1]);
   hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
-  for (int k0 = 0; k0 < nblk; k0 += group) {
-    const int k1 = k0 + group < nblk ? k0 + group : nblk;
+  for (int g = 0; g + 1 < ngroups; ++g) {
+    const int k0 = gb[g], k1 = gb[g + 1];
     const int T = nblk - k1;  // trailing tile rows
-    if (T <= 0) break;
     const int K = (k1 - k0) * 128;
-    const int na = group < T ? group : T;  // tile columns of the next group
+    const int na = gb[g + 2] - k1;  // tile columns of the next group
     double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
     if (la) sb = T >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
@@ -880,12 +902,11 @@ void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, in
 // lower-triangular 128x128 tiles incl. the diagonal tiles, 2*128*128*K each).
 double cholesky_syrk_flops(int npad, int group) {
   const int nblk = npad / 128;
+  const std::vector<int> gb = cholesky_group_bounds(nblk, group);
   double f = 0.0;
-  for (int k0 = 0; k0 < nblk; k0 += group) {
-    const int k1 = k0 + group < nblk ? k0 + group : nblk;
-    const int T = nblk - k1;
-    if (T <= 0) break;
-    const int na = group < T ? group : T, Tb = T - na;
+  for (size_t g = 0; g + 2 < gb.size(); ++g) {
+    const int k0 = gb[g], k1 = gb[g + 1], na = gb[g + 2] - k1;
+    const int Tb = nblk - k1 - na;
     f += 0.5 * Tb * (Tb + 1.0) * 2.0 * 128.0 * 128.0 * (double)((k1 - k0) * 128);
   }
   return f;

@@ -99,6 +99,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
                         hipStream_t s, KernelTimer* kt);
 double cholesky_syrk_flops(int npad, int group);
+std::vector<int> cholesky_group_bounds(int nblk, int group);
 void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,
                       KernelTimer* kt);
 
