@@ -97,9 +97,24 @@ def cpu_baseline(prob, iters):
                                                                     s.t_linear_assemble_s)}
 
 
-def args_group_k(args):
-    """SYRK depth in 128-column blocks (library default 3)."""
-    return args.group if args.group > 0 else 3
+def syrk_c_tile_bytes_per_launch(n, group, tail_tiles=48, tail_group=1):
+    """Algorithmic bytes of one trailing-SYRK launch, averaged over a factorisation: every 128x128 fp64 C
+    tile of the launch is read once and written once (the panel operands are shared through L2 and not
+    counted).  Mirrors the group schedule of cholesky_group_bounds (csrc/chol_kernels.hip)."""
+    nblk = (n + 1 + 127) // 128
+    bounds, k = [], 0
+    while k < nblk:
+        bounds.append(k)
+        rem = nblk - k
+        k += min(tail_group if rem <= tail_tiles else group, rem)
+    bounds.append(nblk)
+    tiles = launches = 0
+    for g in range(len(bounds) - 2):
+        tb = nblk - bounds[g + 2]
+        if tb > 0:
+            tiles += tb * (tb + 1) // 2
+            launches += 1
+    return 2.0 * 131072 * tiles / max(1, launches)
 
 
 def main():
@@ -111,6 +126,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--group", type=int, default=0, help="(tuning) SYRK depth in 128-column blocks")
     ap.add_argument("--no-lookahead", action="store_true", help="(tuning) single-stream Cholesky")
+    ap.add_argument("--no-alone", action="store_true", help="skip the untimed look-ahead-off side measurement (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,7 +196,7 @@ def main():
     # timed region above it shares the CUs with the panel chain of the next block-column group (and its
     # stream is masked off a few CUs per XCD), so its per-launch time there is longer by design.
     alone = None
-    if world == 1 and not args.no_lookahead:
+    if world == 1 and not args.no_lookahead and not args.no_alone:
         del solver
         prob2 = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB)
         problem2, params2, loss2 = build_problem(sk, prob2)
@@ -215,8 +231,8 @@ def main():
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                          "traffic_note": "bytes/launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled, gfx950; "
-                                         "includes Infinity-Cache hits); algorithmic C-tile bytes/launch = %.3e" % (
-                                             syrk_flops / max(1, syrk_n / max(1, args.steps)) / (2.0 * 128 * 128 * 128 * args_group_k(args)) * 2 * 131072),
+                                         "includes Infinity-Cache hits); algorithmic C-tile bytes/launch (read + write) = %.3e" % (
+                                             syrk_c_tile_bytes_per_launch(9 * prob.num_cameras, args.group if args.group > 0 else 3)),
                          "launches": syrk_n, "avg_launch_ms": 1e3 * syrk_s / max(1, syrk_n),
                          "flops_per_solve": syrk_flops,
                          "achieved_alone": alone, "frac_alone": (alone / FP64_MFMA_PEAK_TFLOPS) if alone else None,
