@@ -136,6 +136,19 @@ double** sk_ptrvec_to_pointer_pointer(sk_ptrvec* v); /* DoubleMatrix.toPointerPo
 
 /* ---- LossFunction: PredefinedLossFunctions, ceres.i:168-184 -------------- */
 sk_loss_function* sk_loss_trivial(void);             /* trivialLoss(): rho(s) = s; caller frees (%newobject, ceres.i:160) */
+sk_loss_function* sk_loss_huber(double a);           /* huberLoss(a), ceres.i:171 */
+sk_loss_function* sk_loss_soft_l_one(double a);      /* softLOneLoss(a), ceres.i:172 */
+sk_loss_function* sk_loss_cauchy(double a);          /* cauchyLoss(a), ceres.i:173 */
+sk_loss_function* sk_loss_tukey(double a);           /* tukeyLoss(a), ceres.i:174 */
+sk_loss_function* sk_loss_tolerant(double a, double b); /* tolerantLoss(a, b), ceres.i:175 */
+/* composedLoss(f, g): rho(s) = f(g(s)); scaledLoss(rho, a): a * rho(s), rho may be NULL (= a * s), ceres.i:176-182.
+ * The reference builds both with DO_NOT_TAKE_OWNERSHIP; here the arguments are COPIED, so they may be freed
+ * at once.  Nesting deeper than 4 is SK_ERR_UNSUPPORTED (NULL + sk_last_error). */
+sk_loss_function* sk_loss_composed(const sk_loss_function* f, const sk_loss_function* g);
+sk_loss_function* sk_loss_scaled(const sk_loss_function* rho, double a);
+/* ceres::LossFunction::Evaluate(sq_norm, rho[3]) for n squared norms: rho + 3*i receives rho(s_i), rho'(s_i), rho''(s_i).
+ * Evaluated ON THE DEVICE by the code the solvers run (known-answer tests). */
+int sk_loss_evaluate(const sk_loss_function* loss, const double* sq_norm, int n, double* rho);
 void sk_loss_free(sk_loss_function* loss);
 
 /* ---- CostFunction -------------------------------------------------------- */

@@ -90,6 +90,11 @@ def lib():
                                    C.POINTER(Options), C.POINTER(Summary)]
         L.or_bal_evaluate.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, dp, dp]
         L.or_bal_reduced_system.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
+        L.or_loss_evaluate.argtypes = [dp, C.c_int, C.c_double, dp]
+        L.or_solve_loss.argtypes = [C.c_int, ip, dp, C.c_int, ip, dp, ip, ip, ip, dp, ip,
+                                    C.POINTER(Options), C.POINTER(Summary)]
+        L.or_solve_bal_loss.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, C.c_int, dp,
+                                        C.POINTER(Options), C.POINTER(Summary)]
         L.or_cholesky_lower.argtypes = [dp, C.c_int, C.c_int]
         L.or_cholesky_solve.argtypes = [dp, C.c_int, dp]
         _lib = L
@@ -157,8 +162,45 @@ def angle_axis_to_rotation_matrix(aa):
     return R.reshape(3, 3)
 
 
+# ---- robust losses (oracle/loss.hpp) ----------------------------------------------
+# A loss is None (trivial) or a tuple: ("huber", a), ("softlone", a), ("cauchy", a), ("tukey", a),
+# ("tolerant", a, b), ("composed", f, g), ("scaled", rho_or_None, a).
+_LOSS_TYPES = {"trivial": 0, "huber": 1, "softlone": 2, "cauchy": 3, "tukey": 4, "tolerant": 5, "composed": 6, "scaled": 7}
+
+
+def _flatten_loss(loss, nodes):
+    """Append `loss` to `nodes` (rows of 5: type, a, b, f, g; children first); returns its root index, -1 for trivial."""
+    if loss is None or loss[0] == "trivial":
+        return -1
+    kind = loss[0]
+    if kind == "composed":
+        g = _flatten_loss(loss[2], nodes)
+        f = _flatten_loss(loss[1], nodes)
+        nodes.append([6.0, 0.0, 0.0, float(f), float(g)])
+    elif kind == "scaled":
+        f = _flatten_loss(loss[1], nodes)
+        nodes.append([7.0, float(loss[2]), 0.0, float(f), -1.0])
+    else:
+        nodes.append([float(_LOSS_TYPES[kind]), float(loss[1]), float(loss[2]) if kind == "tolerant" else 0.0, -1.0, -1.0])
+    return len(nodes) - 1
+
+
+def loss_evaluate(loss, s):
+    """(rho, rho', rho'') of `loss` at squared norm s."""
+    nodes = []
+    root = _flatten_loss(loss, nodes)
+    arr = np.asarray(nodes if nodes else [[0.0] * 5], dtype=np.float64)
+    rho = np.zeros(3)
+    lib().or_loss_evaluate(_dp(arr), root, float(s), _dp(rho))
+    return rho
+
+
 def solve(block_sizes, x0, residual_blocks, options=None):
-    """residual_blocks: list of (functor_id, consts, [param block indices])."""
+    """residual_blocks: list of (functor_id, consts, [param block indices]) or
+    (functor_id, consts, [param block indices], loss)."""
+    if any(len(rb) > 3 and rb[3] is not None for rb in residual_blocks):
+        return _solve_loss(block_sizes, x0, residual_blocks, options)
+    residual_blocks = [rb[:3] for rb in residual_blocks]
     o = options or default_options()
     bs = np.asarray(block_sizes, dtype=np.int32)
     x = np.array(x0, dtype=np.float64).copy()
@@ -181,14 +223,47 @@ def solve(block_sizes, x0, residual_blocks, options=None):
     return x, s
 
 
-def solve_bal(C_, P_, cam_idx, pt_idx, obs, x0, options=None):
+def _solve_loss(block_sizes, x0, residual_blocks, options=None):
+    o = options or default_options()
+    bs = np.asarray(block_sizes, dtype=np.int32)
+    x = np.array(x0, dtype=np.float64).copy()
+    fids = np.asarray([rb[0] for rb in residual_blocks], dtype=np.int32)
+    consts, coff, pidx, poff, nodes, roots, seen = [], [], [], [0], [], [], {}
+    for rb in residual_blocks:
+        coff.append(len(consts))
+        consts.extend(rb[1])
+        pidx.extend(rb[2])
+        poff.append(len(pidx))
+        loss = rb[3] if len(rb) > 3 else None
+        key = repr(loss)
+        if key not in seen:
+            seen[key] = _flatten_loss(loss, nodes)
+        roots.append(seen[key])
+    consts = np.asarray(consts + [0.0], dtype=np.float64)
+    coff = np.asarray(coff, dtype=np.int32)
+    pidx = np.asarray(pidx, dtype=np.int32)
+    poff = np.asarray(poff, dtype=np.int32)
+    nodes = np.asarray(nodes if nodes else [[0.0] * 5], dtype=np.float64)
+    roots = np.asarray(roots, dtype=np.int32)
+    s = Summary()
+    rc = lib().or_solve_loss(len(bs), _ip(bs), _dp(x), len(fids), _ip(fids), _dp(consts), _ip(coff),
+                             _ip(pidx), _ip(poff), _dp(nodes), _ip(roots), C.byref(o), C.byref(s))
+    if rc != 0:
+        raise RuntimeError("or_solve_loss failed: %d" % rc)
+    return x, s
+
+
+def solve_bal(C_, P_, cam_idx, pt_idx, obs, x0, options=None, loss=None):
     o = options or default_options(linear_solver_type=DENSE_SCHUR)
     cam = np.ascontiguousarray(cam_idx, dtype=np.int32)
     pt = np.ascontiguousarray(pt_idx, dtype=np.int32)
     ob = np.ascontiguousarray(obs, dtype=np.float64)
     x = np.array(x0, dtype=np.float64).copy()
     s = Summary()
-    rc = lib().or_solve_bal(C_, P_, len(cam), _ip(cam), _ip(pt), _dp(ob), _dp(x), C.byref(o), C.byref(s))
+    nodes = []
+    root = _flatten_loss(loss, nodes)
+    arr = np.asarray(nodes if nodes else [[0.0] * 5], dtype=np.float64)
+    rc = lib().or_solve_bal_loss(C_, P_, len(cam), _ip(cam), _ip(pt), _dp(ob), _dp(arr), root, _dp(x), C.byref(o), C.byref(s))
     if rc != 0:
         raise RuntimeError("or_solve_bal failed: %d" % rc)
     return x, s

@@ -38,6 +38,7 @@
 #include <omp.h>
 #endif
 #include "functors.hpp"
+#include "loss.hpp"
 #include "oracle.h"
 
 namespace oracle {
@@ -133,6 +134,8 @@ struct Problem {
   std::vector<int> functor, res_off, const_off, pidx_off, pidx;
   const double* consts = nullptr;
   int num_residuals = 0;
+  const double* loss_nodes = nullptr;  // oracle/loss.hpp; block_loss[b] = root node or -1
+  std::vector<int> block_loss;
 };
 
 struct DenseEval {  // dense Jacobian, row-major m x n
@@ -145,11 +148,13 @@ static bool evaluate_dense(const Problem& P, const double* x, bool want_jac, Den
   out->r.assign(m, 0.0);
   if (want_jac) out->J.assign((size_t)m * n, 0.0);
   bool ok = true;
+  double csum = 0.0;  // sum of the blocks' cost terms rho(|r_b|^2)
   for (int b = 0; b < P.num_res_blocks; ++b) {
     if (P.functor[b] == kSynthTanhRow) {  // dense row over one block of any size
       const int blk = P.pidx[P.pidx_off[b]], off = P.block_off[blk], nb = P.block_size[blk];
       if (!synth_tanh_row_evaluate(P.consts + P.const_off[b], x + off, nb, &out->r[P.res_off[b]],
                                    want_jac ? &out->J[(size_t)P.res_off[b] * n + off] : nullptr)) { ok = false; break; }
+      csum += out->r[P.res_off[b]] * out->r[P.res_off[b]];
       continue;
     }
     FunctorInfo fi; functor_info(P.functor[b], &fi);
@@ -161,6 +166,8 @@ static bool evaluate_dense(const Problem& P, const double* x, bool want_jac, Den
     double res[8];
     if (!evaluate_block(P.functor[b], P.consts + P.const_off[b], params, res,
                         want_jac ? jac : nullptr)) { ok = false; break; }
+    csum += oracle::loss_correct(P.loss_nodes, P.block_loss.empty() ? -1 : P.block_loss[b], fi.num_residuals, res, fi.num_blocks, fi.N,
+                                 want_jac ? jac : nullptr);
     for (int r = 0; r < fi.num_residuals; ++r) out->r[P.res_off[b] + r] = res[r];
     if (want_jac) {
       for (int i = 0; i < fi.num_blocks; ++i) {
@@ -172,9 +179,7 @@ static bool evaluate_dense(const Problem& P, const double* x, bool want_jac, Den
     }
   }
   if (!ok) return false;
-  double c = 0.0;
-  for (int i = 0; i < m; ++i) c += out->r[i] * out->r[i];
-  *cost = 0.5 * c;
+  *cost = 0.5 * csum;
   return true;
 }
 
@@ -227,6 +232,7 @@ struct Bal {
   std::vector<int> pt_start, pt_obs;         // CSR: observations of a point (sorted by camera)
   const double* consts = nullptr;            // 2 per observation
   std::vector<double> r, F, E;               // 2N, 18N, 6N
+  const double* loss_nodes = nullptr; int loss_root = -1;  // one loss for all blocks (oracle/loss.hpp)
 };
 
 static bool bal_evaluate(Bal& B, const double* x, bool want_jac, double* cost, int nthreads) {
@@ -234,16 +240,22 @@ static bool bal_evaluate(Bal& B, const double* x, bool want_jac, double* cost, i
   B.r.resize(2 * (size_t)N);
   if (want_jac) { B.F.resize(18 * (size_t)N); B.E.resize(6 * (size_t)N); }
   int bad = 0;
+  std::vector<double> term(B.loss_root >= 0 ? N : 0);
 #pragma omp parallel for num_threads(nthreads) schedule(static) reduction(+ : bad)
   for (int o = 0; o < N; ++o) {
     const double* params[2] = {cams + 9 * (size_t)B.cam[o], pts + 3 * (size_t)B.pt[o]};
     double* jac[2] = {want_jac ? &B.F[18 * (size_t)o] : nullptr, want_jac ? &B.E[6 * (size_t)o] : nullptr};
     if (!AutoDiff<SnavelyReprojectionError>::evaluate(B.consts + 2 * (size_t)o, params,
-                                                      &B.r[2 * (size_t)o], want_jac ? jac : nullptr)) bad++;
+                                                      &B.r[2 * (size_t)o], want_jac ? jac : nullptr)) { bad++; continue; }
+    if (B.loss_root >= 0) {
+      static const int kN[2] = {9, 3};
+      term[o] = oracle::loss_correct(B.loss_nodes, B.loss_root, 2, &B.r[2 * (size_t)o], 2, kN, want_jac ? jac : nullptr);
+    }
   }
   if (bad) return false;
   double c = 0.0;
-  for (size_t i = 0; i < 2 * (size_t)N; ++i) c += B.r[i] * B.r[i];
+  if (B.loss_root >= 0) for (int o = 0; o < N; ++o) c += term[o];
+  else for (size_t i = 0; i < 2 * (size_t)N; ++i) c += B.r[i] * B.r[i];
   *cost = 0.5 * c;
   return std::isfinite(*cost);
 }
@@ -609,7 +621,16 @@ void or_angle_axis_to_rotation_matrix(const double* aa, double* R_rowmajor) {
 int or_solve(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
              const int* functor_ids, const double* consts, const int* const_off,
              const int* pidx, const int* pidx_off, const or_options* opt, or_summary* summary) {
-  Problem P; P.num_blocks = num_blocks; P.block_size.assign(block_sizes, block_sizes + num_blocks);
+  return or_solve_loss(num_blocks, block_sizes, x, num_res_blocks, functor_ids, consts, const_off, pidx, pidx_off, nullptr, nullptr, opt, summary);
+}
+
+// The same with robust losses: loss_nodes as in oracle/loss.hpp, block_loss[b] = root node of block b's loss or -1.
+int or_solve_loss(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
+                  const int* functor_ids, const double* consts, const int* const_off,
+                  const int* pidx, const int* pidx_off, const double* loss_nodes, const int* block_loss,
+                  const or_options* opt, or_summary* summary) {
+  Problem P; P.num_blocks = num_blocks;
+  if (loss_nodes && block_loss) { P.loss_nodes = loss_nodes; P.block_loss.assign(block_loss, block_loss + num_res_blocks); } P.block_size.assign(block_sizes, block_sizes + num_blocks);
   P.block_off.resize(num_blocks); int off = 0;
   for (int b = 0; b < num_blocks; ++b) { P.block_off[b] = off; off += block_sizes[b]; }
   P.num_params = off; P.num_res_blocks = num_res_blocks;
@@ -655,8 +676,16 @@ static int bal_build(Bal& B, int C, int P, int N, const int* cam_idx, const int*
 
 int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                  double* x, const or_options* opt, or_summary* summary) {
+  return or_solve_bal_loss(C, P, N, cam_idx, pt_idx, obs, nullptr, -1, x, opt, summary);
+}
+
+void or_loss_evaluate(const double* loss_nodes, int root, double s, double* rho) { oracle::loss_evaluate(loss_nodes, root, s, rho); }
+
+int or_solve_bal_loss(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                      const double* loss_nodes, int loss_root, double* x, const or_options* opt, or_summary* summary) {
   Bal B;
   if (int rc = bal_build(B, C, P, N, cam_idx, pt_idx, obs)) return rc;
+  B.loss_nodes = loss_nodes; B.loss_root = loss_nodes ? loss_root : -1;
   int nt = opt->num_threads;
 #ifdef _OPENMP
   if (nt <= 0) nt = omp_get_max_threads();

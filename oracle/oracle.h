@@ -51,6 +51,14 @@ int or_solve(int num_blocks, const int* block_sizes, double* x, int num_res_bloc
              const int* pidx_off, const or_options* opt, or_summary* summary);
 int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                  double* x, const or_options* opt, or_summary* summary);
+/* robust losses (oracle/loss.hpp): nodes of 5 doubles {type, a, b, f, g} */
+void or_loss_evaluate(const double* loss_nodes, int root, double s, double* rho);
+int or_solve_loss(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
+                  const int* functor_ids, const double* consts, const int* const_off, const int* pidx,
+                  const int* pidx_off, const double* loss_nodes, const int* block_loss,
+                  const or_options* opt, or_summary* summary);
+int or_solve_bal_loss(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                      const double* loss_nodes, int loss_root, double* x, const or_options* opt, or_summary* summary);
 int or_bal_evaluate(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                     const double* x, double* r, double* F, double* E, double* cost);
 int or_bal_reduced_system(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,

@@ -8,7 +8,7 @@ C ABI of ``libskeres_amd.so`` (include/skeres_amd.h):
     SizedCostFunction / CostFunction.evaluate      CORE/SizedCostFunction.scala:6-14
     Problem.addResidualBlock                       CORE/Problem.scala:20-27
     DoubleArray, RichDoubleArray, RichDoubleMatrix CORE/RichDoubleArray.scala, RichDoubleMatrix.scala
-    PredefinedLossFunctions.trivialLoss            ceres.i:170
+    PredefinedLossFunctions (trivial, huber, softLOne, cauchy, tukey, tolerant, composed, scaled)  ceres.i:159-184
     Solver.Options / Solver.Summary / ceres.solve  EX/SimpleBundleAdjuster.scala:147-154
 
 There is no CPU fallback: every compute call needs the HIP library and a gfx950
@@ -20,7 +20,7 @@ from .api import (  # noqa: F401
     CostFunction, SizedCostFunction, AutoDiffCostFunctor, AutoDiffCostFunction,
     SnavelyReprojectionError, ExponentialResidual, PowellF1, PowellF2, PowellF3, PowellF4,
     BinaryScalarCost, BinaryVector3Cost, TenParameterCost,
-    PredefinedLossFunctions, Problem, Solver, LinearSolverType, MinimizerType, TerminationType,
+    PredefinedLossFunctions, LossFunction, Problem, Solver, LinearSolverType, MinimizerType, TerminationType,
     ceres, StepSolver,
 )
 from . import bal  # noqa: F401

@@ -48,6 +48,14 @@ _SIGS = {
     "sk_ptrvec_set": (None, [C.c_void_p, C.c_int, _dp]),
     "sk_ptrvec_to_pointer_pointer": (_dpp, [C.c_void_p]),
     "sk_loss_trivial": (C.c_void_p, []),
+    "sk_loss_huber": (C.c_void_p, [C.c_double]),
+    "sk_loss_soft_l_one": (C.c_void_p, [C.c_double]),
+    "sk_loss_cauchy": (C.c_void_p, [C.c_double]),
+    "sk_loss_tukey": (C.c_void_p, [C.c_double]),
+    "sk_loss_tolerant": (C.c_void_p, [C.c_double, C.c_double]),
+    "sk_loss_composed": (C.c_void_p, [C.c_void_p, C.c_void_p]),
+    "sk_loss_scaled": (C.c_void_p, [C.c_void_p, C.c_double]),
+    "sk_loss_evaluate": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
     "sk_loss_free": (None, [C.c_void_p]),
     "sk_cost_function_new_autodiff": (C.c_void_p, [C.c_int, _dp, C.c_int]),
     "sk_cost_function_new_callback": (C.c_void_p, [EVALUATE_FN, C.c_void_p, C.c_int, _ip, C.c_int]),
@@ -456,9 +464,20 @@ class TenParameterCost(AutoDiffCostFunctor):  # TEST/AutodiffCostFuntionSpec.sca
         super().__init__(1, *([1] * 10))
 
 
-class _Loss:
+class LossFunction:
+    """com.google.ceres.LossFunction as built by PredefinedLossFunctions (ceres.i:159-184)."""
+
     def __init__(self, h):
+        if not h:
+            raise SkeresError(lib().sk_last_error().decode())
         self._h = h
+
+    def evaluate(self, sq_norm):
+        """LossFunction::Evaluate on the device: rows (rho, rho', rho'') for every squared norm given."""
+        s = np.ascontiguousarray(np.atleast_1d(sq_norm), dtype=np.float64)
+        rho = np.zeros((len(s), 3))
+        _check(lib().sk_loss_evaluate(self._h, s.ctypes.data_as(_dp), len(s), rho.ctypes.data_as(_dp)))
+        return rho
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
@@ -466,10 +485,41 @@ class _Loss:
             self._h = None
 
 
+_Loss = LossFunction
+
+
 class PredefinedLossFunctions:  # ceres.i:168-184
     @staticmethod
     def trivialLoss():
-        return _Loss(lib().sk_loss_trivial())
+        return LossFunction(lib().sk_loss_trivial())
+
+    @staticmethod
+    def huberLoss(a):
+        return LossFunction(lib().sk_loss_huber(a))
+
+    @staticmethod
+    def softLOneLoss(a):
+        return LossFunction(lib().sk_loss_soft_l_one(a))
+
+    @staticmethod
+    def cauchyLoss(a):
+        return LossFunction(lib().sk_loss_cauchy(a))
+
+    @staticmethod
+    def tukeyLoss(a):
+        return LossFunction(lib().sk_loss_tukey(a))
+
+    @staticmethod
+    def tolerantLoss(a, b):
+        return LossFunction(lib().sk_loss_tolerant(a, b))
+
+    @staticmethod
+    def composedLoss(f, g):
+        return LossFunction(lib().sk_loss_composed(f._h if f is not None else None, g._h if g is not None else None))
+
+    @staticmethod
+    def scaledLoss(rho, a):
+        return LossFunction(lib().sk_loss_scaled(rho._h if rho is not None else None, a))
 
 
 # ---------------------------------------------------------------------------

@@ -53,6 +53,9 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* out_partial, i
 //    point[0..3)  (AutodiffCostFunction.scala:96-106); Jacobian blocks row-major
 //    kNumResiduals x N(i) (:115-130), stored as SoA planes.
 // ---------------------------------------------------------------------------
+// kLoss: robust loss (loss.hpp) — the block's residuals and both Jacobian blocks are corrected before they
+// are stored, the cost term is rho(|r|^2).  A separate instantiation: the trivial-loss kernel stays as it was.
+template <bool kLoss>
 __global__ __launch_bounds__(kBlock) void bal_eval_jac_kernel(BalDev d) {
   double acc[1] = {0.0};
   for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
@@ -67,9 +70,26 @@ __global__ __launch_bounds__(kBlock) void bal_eval_jac_kernel(BalDev d) {
     const double c[2] = {d.obs[o], d.obs[(size_t)d.N + o]};
     SnavelyReprojectionError::apply<J>(c, params, out);
     const double r0 = out[0].a, r1 = out[1].a;
-    d.r[o] = r0;
-    d.r[(size_t)d.N + o] = r1;
-    acc[0] += r0 * r0 + r1 * r1;
+    if (kLoss) {
+      const double sq = r0 * r0 + r1 * r1;
+      double rho[3];
+      loss_evaluate(d.loss_nodes, d.loss_root, sq, rho);
+      const LossCorrector lc(sq, rho);
+      acc[0] += rho[0];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const double j0 = out[0].v[k], j1 = out[1].v[k];
+        const double rtj = lc.alpha_sq_norm * (r0 * j0 + r1 * j1);
+        out[0].v[k] = lc.sqrt_rho1 * (j0 - r0 * rtj);
+        out[1].v[k] = lc.sqrt_rho1 * (j1 - r1 * rtj);
+      }
+      d.r[o] = r0 * lc.residual_scaling;
+      d.r[(size_t)d.N + o] = r1 * lc.residual_scaling;
+    } else {
+      d.r[o] = r0;
+      d.r[(size_t)d.N + o] = r1;
+      acc[0] += r0 * r0 + r1 * r1;
+    }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const double s = d.scale_c[9 * (size_t)ci + k];
@@ -89,6 +109,7 @@ __global__ __launch_bounds__(kBlock) void bal_eval_jac_kernel(BalDev d) {
 // Candidate cost at (xc_new, xp_new) with T = double (cost-only branch,
 // AutodiffCostFunction.scala:80-93) fused with the model residual J*step that
 // the trust-region ratio needs:  m = F s_c + E s_p ; term = m . (r + m/2).
+template <bool kLoss>
 __global__ __launch_bounds__(kBlock) void bal_eval_cost_kernel(BalDev d) {
   double acc[2] = {0.0, 0.0};
   for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
@@ -101,7 +122,13 @@ __global__ __launch_bounds__(kBlock) void bal_eval_cost_kernel(BalDev d) {
     const double* params[2] = {cam, X};
     const double c[2] = {d.obs[o], d.obs[(size_t)d.N + o]};
     SnavelyReprojectionError::apply<double>(c, params, out);
-    acc[0] += out[0] * out[0] + out[1] * out[1];
+    if (kLoss) {
+      double rho[3];
+      loss_evaluate(d.loss_nodes, d.loss_root, out[0] * out[0] + out[1] * out[1], rho);
+      acc[0] += rho[0];
+    } else {
+      acc[0] += out[0] * out[0] + out[1] * out[1];
+    }
     double m0 = 0.0, m1 = 0.0;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -473,8 +500,14 @@ static inline int grid_for(int n, int cap = 2048) {
 
 int bal_partial_blocks(int N) { return grid_for(N); }
 
-void launch_bal_eval_jac(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_eval_jac_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
-void launch_bal_eval_cost(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_eval_cost_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
+void launch_bal_eval_jac(const BalDev& d, hipStream_t s) {
+  if (d.loss_root >= 0) hipLaunchKernelGGL(bal_eval_jac_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
+  else hipLaunchKernelGGL(bal_eval_jac_kernel<false>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
+}
+void launch_bal_eval_cost(const BalDev& d, hipStream_t s) {
+  if (d.loss_root >= 0) hipLaunchKernelGGL(bal_eval_cost_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
+  else hipLaunchKernelGGL(bal_eval_cost_kernel<false>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
+}
 void launch_bal_scale_jac(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_scale_jac_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_reduce(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_reduce_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_pt_reduce(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_pt_reduce_kernel, dim3((d.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "loss.hpp"
+
 namespace sk {
 
 constexpr int kWs = 28;  // doubles per observation record of What (27 used; 224 bytes keeps records 32-byte aligned)
@@ -40,6 +42,8 @@ struct BalDev {
   // reductions
   double* partial;  int partial_stride;
   int* fail_flag;
+  // robust loss shared by every residual block (loss.hpp); loss_root < 0 = trivial
+  const LossNode* loss_nodes;  int loss_root;
 };
 
 int bal_partial_blocks(int N);

@@ -22,6 +22,8 @@ bool problem_is_bal_shaped(const Problem& p, std::string* why) {
       *why = "DENSE_SCHUR is implemented for SnavelyReprojectionError residual blocks (2 residuals; 9- and 3-parameter blocks) only";
       return false;
     }
+  for (size_t b = 1; b < nb && b < p.rb_loss.size(); ++b)
+    if (p.rb_loss[b] != p.rb_loss[0]) { *why = "DENSE_SCHUR takes one loss function for all residual blocks"; return false; }
   std::vector<char> role(p.block_size.size(), 0);
   for (size_t b = 0; b < nb; ++b) {
     const int c = p.rb_pidx[p.rb_pidx_off[b]], q = p.rb_pidx[p.rb_pidx_off[b] + 1];
@@ -92,6 +94,7 @@ class BalSolver : public SolverBase {
   std::vector<int> cam_block_, pt_block_;     // parameter block id of camera i / global point p
   std::vector<int> local_pt_;                 // global point id of local point
   BalDev d_{};
+  DevBuf<LossNode> b_loss_nodes_;
   DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_fail_, b_info_;
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
@@ -212,6 +215,8 @@ int BalSolver::setup() {
   d_.gs_c = b_gs_.p; d_.gs_p = b_gs_.p + nc; d_.D_c = b_D_.p; d_.D_p = b_D_.p + nc; d_.step_c = b_step_.p; d_.step_p = b_step_.p + nc;
   d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.rt = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
   d_.S = b_S_.p; d_.ld = npad_; d_.rhs_row = rhs_row_; d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = b_fail_.p;
+  d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0];
+  if (d_.loss_root >= 0) { SK_HIP_TRY(b_loss_nodes_.upload(p.loss_nodes, s)); d_.loss_nodes = b_loss_nodes_.p; }
   SK_HIP_TRY(hipStreamSynchronize(s));
   return SK_OK;
 }

@@ -26,6 +26,27 @@ static std::string g_program_name;
   catch (const std::exception& e) { set_error("internal error: %s", e.what()); return ret; } \
   catch (...) { set_error("internal error"); return ret; }
 
+namespace sk {
+// Every distinct loss expression is stored once per problem; the key is its content, so freed and
+// re-allocated caller objects cannot alias.
+int Problem::intern_loss(const LossFunction* l) {
+  if (!l || l->nodes.empty()) return -1;
+  std::string key(reinterpret_cast<const char*>(l->nodes.data()), l->nodes.size() * sizeof(LossNode));
+  auto it = loss_root_of.find(key);
+  if (it != loss_root_of.end()) return it->second;
+  const int base = (int)loss_nodes.size();
+  for (LossNode n : l->nodes) {
+    if (n.f >= 0) n.f += base;
+    if (n.g >= 0) n.g += base;
+    loss_nodes.push_back(n);
+  }
+  const int root = (int)loss_nodes.size() - 1;
+  loss_root_of.emplace(std::move(key), root);
+  has_loss = true;
+  return root;
+}
+}  // namespace sk
+
 extern "C" {
 
 const char* sk_version(void) { return "skeres_amd 0.1 (gfx950)"; }
@@ -58,6 +79,88 @@ double** sk_ptrvec_to_pointer_pointer(sk_ptrvec* v) { return v->v.empty() ? null
 // ---- LossFunction -----------------------------------------------------------------
 sk_loss_function* sk_loss_trivial(void) { return new (std::nothrow) sk_loss_function(); }
 void sk_loss_free(sk_loss_function* l) { delete l; }
+
+static sk_loss_function* loss_leaf_new(int type, double a, double b) {
+  if (!(a > 0.0) || (type == kLossTolerant && !(b > 0.0))) { set_error("loss function parameters must be positive"); return nullptr; }
+  sk_loss_function* l = new (std::nothrow) sk_loss_function();
+  if (!l) { set_error("out of host memory"); return nullptr; }
+  LossNode n; n.type = type; n.f = n.g = -1; n.depth = 0; n.a = a; n.b = b;
+  l->l.nodes.push_back(n);
+  return l;
+}
+sk_loss_function* sk_loss_huber(double a) { return loss_leaf_new(kLossHuber, a, 0.0); }
+sk_loss_function* sk_loss_soft_l_one(double a) { return loss_leaf_new(kLossSoftLOne, a, 0.0); }
+sk_loss_function* sk_loss_cauchy(double a) { return loss_leaf_new(kLossCauchy, a, 0.0); }
+sk_loss_function* sk_loss_tukey(double a) { return loss_leaf_new(kLossTukey, a, 0.0); }
+sk_loss_function* sk_loss_tolerant(double a, double b) { return loss_leaf_new(kLossTolerant, a, b); }
+
+// appends a copy of `child` to `dst`, returns its root index there (-1 for a NULL / trivial child) and its depth
+static int loss_append(std::vector<LossNode>* dst, const sk_loss_function* child, int* depth) {
+  *depth = -1;
+  if (!child || child->l.nodes.empty()) return -1;
+  const int base = (int)dst->size();
+  for (LossNode n : child->l.nodes) {
+    if (n.f >= 0) n.f += base;
+    if (n.g >= 0) n.g += base;
+    dst->push_back(n);
+  }
+  *depth = dst->back().depth;
+  return (int)dst->size() - 1;
+}
+sk_loss_function* sk_loss_composed(const sk_loss_function* f, const sk_loss_function* g) {
+  SK_GUARD_BEGIN
+  sk_loss_function* l = new sk_loss_function();
+  int df = -1, dg = -1;
+  LossNode n; n.type = kLossComposed; n.a = n.b = 0.0;
+  n.g = loss_append(&l->l.nodes, g, &dg);
+  n.f = loss_append(&l->l.nodes, f, &df);
+  n.depth = 1 + (df > dg ? df : dg);
+  if (n.depth < 1) n.depth = 1;
+  if (n.depth > kLossMaxDepth) { delete l; set_error("loss functions nested deeper than %d", kLossMaxDepth); return nullptr; }
+  l->l.nodes.push_back(n);
+  return l;
+  SK_GUARD_END(nullptr)
+}
+sk_loss_function* sk_loss_scaled(const sk_loss_function* rho, double a) {
+  SK_GUARD_BEGIN
+  sk_loss_function* l = new sk_loss_function();
+  int d = -1;
+  LossNode n; n.type = kLossScaled; n.a = a; n.b = 0.0; n.g = -1;
+  n.f = loss_append(&l->l.nodes, rho, &d);
+  n.depth = 1 + (d > 0 ? d : 0);
+  if (n.depth > kLossMaxDepth) { delete l; set_error("loss functions nested deeper than %d", kLossMaxDepth); return nullptr; }
+  l->l.nodes.push_back(n);
+  return l;
+  SK_GUARD_END(nullptr)
+}
+
+__global__ void loss_evaluate_kernel(const LossNode* nodes, int root, const double* s, int n, double* rho) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r[3];
+  loss_evaluate(nodes, root, s[i], r);
+  rho[3 * i] = r[0]; rho[3 * i + 1] = r[1]; rho[3 * i + 2] = r[2];
+}
+// LossFunction::Evaluate for n squared norms at once, ON THE DEVICE (the code the solvers run)
+int sk_loss_evaluate(const sk_loss_function* loss, const double* sq_norm, int n, double* rho) {
+  SK_GUARD_BEGIN
+  if (n < 0 || (n > 0 && (!sq_norm || !rho))) { set_error("sk_loss_evaluate: bad arguments"); return SK_ERR_INVALID_ARGUMENT; }
+  if (n == 0) return SK_OK;
+  if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
+  DevBuf<LossNode> dn; DevBuf<double> ds, dr;
+  std::vector<LossNode> nodes;
+  if (loss) nodes = loss->l.nodes;
+  const int root = nodes.empty() ? -1 : (int)nodes.size() - 1;
+  if (nodes.empty()) { LossNode t; t.type = kLossTrivial; t.f = t.g = -1; t.depth = 0; t.a = t.b = 0.0; nodes.push_back(t); }
+  SK_HIP_TRY(dn.upload(nodes, nullptr));
+  SK_HIP_TRY(ds.upload(std::vector<double>(sq_norm, sq_norm + n), nullptr));
+  SK_HIP_TRY(dr.alloc(3 * (size_t)n));
+  hipLaunchKernelGGL(loss_evaluate_kernel, dim3((n + 127) / 128), dim3(128), 0, nullptr, dn.p, root, ds.p, n, dr.p);
+  SK_HIP_TRY(hipGetLastError());
+  SK_HIP_TRY(hipMemcpy(rho, dr.p, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
 
 // ---- CostFunction -----------------------------------------------------------------
 sk_cost_function* sk_cost_function_new_autodiff(int functor_id, const double* consts, int num_consts) {
@@ -140,7 +243,6 @@ static int register_block(Problem& P, double* ptr, int size) {
 int sk_problem_add_residual_block(sk_problem* p, const sk_cost_function* cost, const sk_loss_function* loss, double* const* parameter_blocks,
                                   int num_parameter_blocks, sk_residual_block_id* id_out) {
   SK_GUARD_BEGIN
-  (void)loss;  // trivial loss only (rho(s) = s)
   if (!p || !cost || !parameter_blocks) { set_error("null argument"); return SK_ERR_INVALID_ARGUMENT; }
   const CostFunction& c = cost->c;
   if (num_parameter_blocks != (int)c.block_sizes.size()) { set_error("cost function expects %d parameter blocks, %d given", (int)c.block_sizes.size(), num_parameter_blocks); return SK_ERR_INVALID_ARGUMENT; }
@@ -155,6 +257,7 @@ int sk_problem_add_residual_block(sk_problem* p, const sk_cost_function* cost, c
   P.rb_const_off.push_back(P.consts.size()); P.consts.insert(P.consts.end(), c.consts.begin(), c.consts.end());
   P.rb_pidx.insert(P.rb_pidx.end(), ids.begin(), ids.end()); P.rb_pidx_off.push_back(P.rb_pidx.size());
   P.rb_cost.push_back(c.functor_id == SK_FUNCTOR_HOST_CALLBACK ? &c : nullptr);
+  P.rb_loss.push_back(P.intern_loss(loss ? &loss->l : nullptr));
   if (c.functor_id == SK_FUNCTOR_HOST_CALLBACK) P.has_callbacks = true;
   P.num_residuals += c.num_residuals;
   if (id_out) *id_out = (int)P.rb_functor.size() - 1;
@@ -164,12 +267,12 @@ int sk_problem_add_residual_block(sk_problem* p, const sk_cost_function* cost, c
 
 int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const double* consts, const sk_loss_function* loss, double* const* parameter_blocks) {
   SK_GUARD_BEGIN
-  (void)loss;
   FunctorDesc d;
   if (!p || n < 0 || !parameter_blocks) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
   if (!functor_desc(functor_id, &d)) { set_error("unknown device functor id %d", functor_id); return SK_ERR_INVALID_ARGUMENT; }
   if (d.num_consts > 0 && !consts) { set_error("functor %d needs %d constants per block", functor_id, d.num_consts); return SK_ERR_INVALID_ARGUMENT; }
   Problem& P = p->p;
+  const int loss_root = P.intern_loss(loss ? &loss->l : nullptr);
   P.rb_functor.reserve(P.rb_functor.size() + n); P.rb_pidx.reserve(P.rb_pidx.size() + (size_t)n * d.num_blocks);
   P.consts.reserve(P.consts.size() + (size_t)n * d.num_consts);
   for (int b = 0; b < n; ++b) {
@@ -184,6 +287,7 @@ int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const d
     if (d.num_consts) P.consts.insert(P.consts.end(), consts + (size_t)b * d.num_consts, consts + (size_t)(b + 1) * d.num_consts);
     P.rb_pidx.insert(P.rb_pidx.end(), ids, ids + d.num_blocks); P.rb_pidx_off.push_back(P.rb_pidx.size());
     P.rb_cost.push_back(nullptr);
+    P.rb_loss.push_back(loss_root);
     P.num_residuals += d.num_residuals;
   }
   return SK_OK;
@@ -191,7 +295,7 @@ int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const d
 }
 int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const double* consts, const sk_loss_function* loss, double* x, int n) {
   SK_GUARD_BEGIN
-  (void)loss;
+  if (loss && !loss->l.nodes.empty()) { set_error("dense rows take the trivial loss only"); return SK_ERR_UNSUPPORTED; }
   if (!p || num_rows < 0 || !consts || !x || n <= 0) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
   if (functor_id != SK_FUNCTOR_SYNTH_TANH_ROW) { set_error("functor %d is not a dense-row functor", functor_id); return SK_ERR_INVALID_ARGUMENT; }
   Problem& P = p->p;
@@ -199,6 +303,7 @@ int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const
   if (id < 0) return SK_ERR_INVALID_ARGUMENT;
   const size_t base = P.rb_functor.size();
   P.rb_functor.resize(base + num_rows, functor_id); P.rb_num_residuals.resize(base + num_rows, 1); P.rb_cost.resize(base + num_rows, nullptr);
+  P.rb_loss.resize(base + num_rows, -1);
   P.rb_const_off.reserve(base + num_rows); P.rb_pidx.reserve(P.rb_pidx.size() + num_rows); P.rb_pidx_off.reserve(P.rb_pidx_off.size() + num_rows);
   for (int i = 0; i < num_rows; ++i) {
     P.rb_const_off.push_back(P.consts.size() + 3 * (size_t)i);

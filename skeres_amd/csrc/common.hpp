@@ -12,6 +12,7 @@
 
 #include "../../include/skeres_amd.h"
 #include "functors.hpp"
+#include "loss.hpp"
 
 namespace sk {
 
@@ -65,7 +66,11 @@ struct CostFunction {  // com.google.ceres.CostFunction as sized by CORE/SizedCo
   std::vector<int> block_sizes;
 };
 
-struct LossFunction { int kind = 0; };  // 0 == trivial
+// PredefinedLossFunctions (ceres.i:159-184): a flattened expression, children before parents; empty == trivial
+struct LossFunction {
+  std::vector<LossNode> nodes;
+  int root() const { return nodes.empty() ? -1 : (int)nodes.size() - 1; }
+};
 
 struct Problem {  // CeresProblem; parameter blocks identified by pointer value
   std::unordered_map<double*, int> block_of;
@@ -79,6 +84,13 @@ struct Problem {  // CeresProblem; parameter blocks identified by pointer value
   std::vector<int> rb_pidx;
   std::vector<double> consts;
   std::vector<const CostFunction*> rb_cost;  // non-null only for host-callback blocks
+  // loss functions: every distinct loss expression once in loss_nodes (copied: the caller may free its object);
+  // rb_loss[b] = root node of block b's loss, -1 = trivial
+  std::vector<LossNode> loss_nodes;
+  std::vector<int> rb_loss;
+  std::unordered_map<std::string, int> loss_root_of;
+  bool has_loss = false;
+  int intern_loss(const LossFunction* l);
   long num_residuals = 0;
   bool has_callbacks = false;
   Problem() { rb_pidx_off.push_back(0); }

@@ -71,6 +71,52 @@ void launch_dense_eval(int functor_id, bool jac, const DenseEvalArgs& a, hipStre
 #undef SK_LAUNCH
 }
 
+// Robust losses (loss.hpp): one lane per residual block, after the evaluation (and after the upload of
+// host-callback rows).  s = |r|^2; the block's rows of r and J are corrected in place (J has non-zeros
+// only in the columns of the block's parameter blocks, and the correction maps that pattern to itself),
+// and cterm receives the block's cost term: rho(s) in its first row, zero in the others, so that
+// cost = 1/2 sum(cterm).  Blocks with the trivial loss get cterm = r^2 row by row.
+__global__ void dense_loss_kernel(DenseLossArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.num_blocks) return;
+  const int row0 = a.res_off[b], nres = a.res_off[b + 1] - row0;
+  const int root = a.rb_loss[b];
+  double s = 0.0;
+  for (int r = 0; r < nres; ++r) { const double v = a.r[row0 + r]; s += v * v; if (root < 0) a.cterm[row0 + r] = v * v; }
+  if (root < 0) return;
+  double rho[3];
+  loss_evaluate(a.nodes, root, s, rho);
+  a.cterm[row0] = rho[0];
+  for (int r = 1; r < nres; ++r) a.cterm[row0 + r] = 0.0;
+  const LossCorrector c(s, rho);
+  if (a.J) {
+    for (size_t q = a.pidx_off[b]; q < a.pidx_off[b + 1]; ++q) {
+      const int off = a.pidx[q], nq = a.psize[q];
+      for (int j = 0; j < nq; ++j) {
+        double* col = a.J + (size_t)row0 * a.n + off + j;
+        double rtj = 0.0;
+        if (c.alpha_sq_norm != 0.0)
+          for (int r = 0; r < nres; ++r) rtj += a.r[row0 + r] * col[(size_t)r * a.n];
+        for (int r = 0; r < nres; ++r) col[(size_t)r * a.n] = c.sqrt_rho1 * (col[(size_t)r * a.n] - c.alpha_sq_norm * a.r[row0 + r] * rtj);
+      }
+    }
+  }
+  for (int r = 0; r < nres; ++r) a.r[row0 + r] *= c.residual_scaling;
+}
+void launch_dense_loss(const DenseLossArgs& a, hipStream_t s) {
+  if (a.num_blocks > 0) hipLaunchKernelGGL(dense_loss_kernel, dim3((a.num_blocks + 127) / 128), dim3(128), 0, s, a);
+}
+__global__ __launch_bounds__(256) void dense_sum_kernel(const double* v, int m, double* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < m; i += 256) s += v[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+void launch_dense_sum(const double* v, int m, double* out, hipStream_t s) { hipLaunchKernelGGL(dense_sum_kernel, dim3(1), dim3(256), 0, s, v, m, out); }
+
 // Single residual block (sk_cost_function_evaluate): parameters / outputs are
 // small flat device buffers.  jac_mask bit q set => write block q's Jacobian
 // (row-major kRes x N(q)) at jac + jac_off[q].

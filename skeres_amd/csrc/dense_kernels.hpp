@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "loss.hpp"
+
 namespace sk {
 
 struct DenseEvalArgs {
@@ -20,7 +22,23 @@ struct DenseEvalArgs {
   int* fail_flag;
 };
 
+struct DenseLossArgs {
+  int num_blocks;          // all residual blocks
+  const int* res_off;      // [num_blocks + 1] first residual row of each block
+  const int* rb_loss;      // [num_blocks] root node of the block's loss, -1 = trivial
+  const LossNode* nodes;
+  const int* pidx;         // x offsets of the parameter blocks, flattened
+  const int* psize;        // their sizes, same indexing
+  const size_t* pidx_off;  // [num_blocks + 1]
+  double* r;               // [m] residuals, corrected in place
+  double* J;               // [m][n] or null (cost-only evaluation)
+  double* cterm;           // [m] cost terms: cost = 1/2 sum
+  int n;
+};
+
 void launch_dense_eval(int functor_id, bool jac, const DenseEvalArgs& a, hipStream_t s);
+void launch_dense_loss(const DenseLossArgs& a, hipStream_t s);
+void launch_dense_sum(const double* v, int m, double* out, hipStream_t s);
 void launch_single_eval(int functor_id, const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
                         const int* jac_off, int want_jac, unsigned jac_mask, int* ok, hipStream_t s);
 void launch_dense_col_reduce(const double* J, const double* r, int m, int n, double* colsq, double* gs, hipStream_t s);

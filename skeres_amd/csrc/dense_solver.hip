@@ -47,6 +47,12 @@ class DenseSolver : public SolverBase {
   DevBuf<double> b_w_;
   DevBuf<size_t> b_const_off_, b_pidx_off_;
   DevBuf<int> b_pidx_, b_res_off_, b_fail_, b_info_, b_ok_;
+  // robust losses (only when the problem has any)
+  bool has_loss_ = false;
+  DevBuf<int> b_psize_, b_rb_loss_;
+  DevBuf<LossNode> b_loss_nodes_;
+  DevBuf<double> b_cterm_;
+  void apply_loss(double* r, bool jac);
   double* x_ = nullptr; double* x_new_ = nullptr;
   double* h_scal_ = nullptr;
 };
@@ -61,15 +67,23 @@ int DenseSolver::setup() {
   for (size_t b = 0; b < p.block_size.size(); ++b) { block_off_[b] = n_; n_ += p.block_size[b]; }
   m_ = (int)p.num_residuals;
   if ((double)m_ * n_ > 2e9) { set_error("dense Jacobian of %d x %d is too large for this build", m_, n_); return SK_ERR_UNSUPPORTED; }
-  res_off_h_.resize(nb);
+  res_off_h_.resize(nb + 1);
   std::vector<int> pidx(p.rb_pidx.size());
   int row = 0;
   for (int b = 0; b < nb; ++b) {
     res_off_h_[b] = row; row += p.rb_num_residuals[b];
     if (p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK) cb_blocks_.push_back(b); else by_functor_[p.rb_functor[b]].push_back(b);
   }
+  res_off_h_[nb] = row;
   for (size_t i = 0; i < pidx.size(); ++i) pidx[i] = block_off_[p.rb_pidx[i]];
   hipStream_t s = stream_;
+  has_loss_ = p.has_loss;
+  if (has_loss_) {
+    std::vector<int> psize(p.rb_pidx.size());
+    for (size_t i = 0; i < psize.size(); ++i) psize[i] = p.block_size[p.rb_pidx[i]];
+    SK_HIP_TRY(b_psize_.upload(psize, s)); SK_HIP_TRY(b_rb_loss_.upload(p.rb_loss, s)); SK_HIP_TRY(b_loss_nodes_.upload(p.loss_nodes, s));
+    SK_HIP_TRY(b_cterm_.alloc(m_));
+  }
   std::vector<double> consts = p.consts; if (consts.empty()) consts.push_back(0.0);
   SK_HIP_TRY(b_consts_.upload(consts, s)); SK_HIP_TRY(b_const_off_.upload(p.rb_const_off, s));
   SK_HIP_TRY(b_pidx_off_.upload(p.rb_pidx_off, s)); SK_HIP_TRY(b_pidx_.upload(pidx, s)); SK_HIP_TRY(b_res_off_.upload(res_off_h_, s));
@@ -134,6 +148,14 @@ int DenseSolver::host_callbacks(const double* x_dev, bool jac) {
   return SK_OK;
 }
 
+// loss correction of the freshly evaluated rows (and Jacobian) + the per-row cost terms
+void DenseSolver::apply_loss(double* r, bool jac) {
+  DenseLossArgs a;
+  a.num_blocks = (int)problem_->rb_functor.size(); a.res_off = b_res_off_.p; a.rb_loss = b_rb_loss_.p; a.nodes = b_loss_nodes_.p;
+  a.pidx = b_pidx_.p; a.psize = b_psize_.p; a.pidx_off = b_pidx_off_.p; a.r = r; a.J = jac ? b_J_.p : nullptr; a.cterm = b_cterm_.p; a.n = n_;
+  launch_dense_loss(a, stream_);
+}
+
 int DenseSolver::evaluate(const double* x_dev, bool jac) {
   DenseEvalArgs a;
   a.consts = b_consts_.p; a.const_off = b_const_off_.p; a.pidx = b_pidx_.p; a.pidx_off = b_pidx_off_.p; a.res_off = b_res_off_.p;
@@ -151,13 +173,14 @@ int DenseSolver::evaluate_with_jacobian(bool first) {
   SK_HIP_TRY(hipMemsetAsync(b_fail_.p, 0, sizeof(int), s));
   int rc = evaluate(x_, true);
   if (rc) return rc;
+  if (has_loss_) apply_loss(b_r_.p, true);  // before the column norms: the Jacobi scaling is that of the corrected Jacobian
   launch_dense_col_reduce(b_J_.p, b_r_.p, m_, n_, b_colsq_.p, b_gs_.p, s);
   if (first && opt_.jacobi_scaling) {
     launch_jacobi_scale(b_colsq_.p, b_scale_.p, n_, s);
     launch_dense_scale(b_J_.p, b_scale_.p, m_, n_, s);
     launch_apply_scale_to_reductions(b_colsq_.p, b_gs_.p, b_scale_.p, n_, s);
   }
-  launch_dense_sumsq(b_r_.p, m_, b_scal_.p, s);
+  if (has_loss_) launch_dense_sum(b_cterm_.p, m_, b_scal_.p, s); else launch_dense_sumsq(b_r_.p, m_, b_scal_.p, s);
   launch_dense_gmax(b_gs_.p, b_scale_.p, x_, n_, b_scal_.p + 1, s);
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 16, b_fail_.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -197,7 +220,8 @@ int DenseSolver::try_step(double radius, bool* valid, double* mcc, double* new_c
   int rc = evaluate(x_new_, false);
   const bool eval_failed = rc == SK_ERR_EVALUATION_FAILED;
   if (rc && !eval_failed) return rc;
-  launch_dense_sumsq(b_rc_.p, m_, b_scal_.p + 2, s);
+  if (has_loss_) { apply_loss(b_rc_.p, false); launch_dense_sum(b_cterm_.p, m_, b_scal_.p + 2, s); }
+  else launch_dense_sumsq(b_rc_.p, m_, b_scal_.p + 2, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 16, b_fail_.p, sizeof(int), hipMemcpyDeviceToHost, s));

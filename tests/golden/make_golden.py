@@ -10,6 +10,10 @@ come from tools that share no code with either the oracle or the product:
   optima.json              SciPy least_squares (trf, exact Jacobians from SymPy /
                            analytic formulas) minimisers of CurveFitting, Powell
                            and a tiny bundle-adjustment problem
+  robust_optima.json       SciPy least_squares with loss = 'cauchy' / 'huber' / 'soft_l1'
+                           (the same rho as Ceres' CauchyLoss / HuberLoss / SoftLOneLoss with
+                           f_scale = a) on the RobustCurveFitting samples and on a tiny
+                           bundle-adjustment problem with gross outliers
 
 Run from the repository root:  python tests/golden/make_golden.py
 """
@@ -98,7 +102,69 @@ def make_optima():
         json.dump({"source": "scipy.optimize.least_squares (trf)", **out}, f, indent=1)
 
 
+def make_robust_optima():
+    out = {}
+    data = np.loadtxt(os.path.join(HERE, "robust_curve_fitting_data.txt"))
+    xs, ys = data[:, 0], data[:, 1]
+
+    def f(p): return ys - np.exp(p[0] * xs + p[1])
+    def j(p): e = np.exp(p[0] * xs + p[1]); return np.stack([-xs * e, -e], axis=1)
+
+    def rho_cost(kind, a, r2):  # 1/2 sum rho(s), Ceres conventions
+        if kind == "cauchy":
+            return 0.5 * np.sum(a * a * np.log1p(r2 / (a * a)))
+        if kind == "huber":
+            return 0.5 * np.sum(np.where(r2 <= a * a, r2, 2 * a * np.sqrt(r2) - a * a))
+        return 0.5 * np.sum(2 * a * a * (np.sqrt(1 + r2 / (a * a)) - 1))
+
+    cf = {}
+    for kind, a in (("cauchy", 0.5), ("huber", 0.3), ("soft_l1", 0.4)):
+        s = least_squares(f, [0.0, 0.0], jac=j, method="trf", loss=kind, f_scale=a, xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        cf[kind] = {"a": a, "x": s.x.tolist(), "cost": float(rho_cost(kind, a, s.fun ** 2)), "scipy_cost": float(s.cost)}
+    out["robust_curve_fitting"] = cf
+
+    # tiny BAL with gross outliers in the observations.  Ceres applies one rho(|r|^2) per residual BLOCK
+    # (2 residuals), which SciPy's per-residual `loss` cannot express; so each block is fed as the single
+    # residual sqrt(rho_huber(s)) — 1/2 sum of its squares IS the robust cost — and minimised plainly.
+    C, P, N, seed = 4, 24, 80, 11
+    prob = bal.generate(C, P, N, seed=seed)
+    rng = np.random.default_rng(5)
+    obs = prob.observations.copy()
+    bad = rng.choice(N, 6, replace=False)
+    obs[bad] += rng.normal(0, 40.0, (6, 2))
+    a = 2.0
+
+    def blocks(x):
+        cams = x[:9 * C].reshape(C, 9)[prob.camera_index]
+        pts = x[9 * C:].reshape(P, 3)[prob.point_index]
+        pred, _ = bal.snavely_project(cams, pts)
+        return pred - obs
+
+    def fr(x):  # one residual per block: sqrt(rho_huber(s)), so that 1/2 sum fr^2 = 1/2 sum rho(s)
+        s2 = np.sum(blocks(x) ** 2, axis=1)
+        return np.sqrt(np.where(s2 <= a * a, s2, 2 * a * np.sqrt(s2) - a * a))
+
+    def cost(x):
+        return 0.5 * np.sum(fr(x) ** 2)
+    s = least_squares(fr, prob.parameters, method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-14, max_nfev=3000)
+    # sqrt(rho) is not smooth at s = 0: polish the robust cost itself (C^1) with a quasi-Newton method
+    from scipy.optimize import minimize
+    xm = s.x
+    for _ in range(6):
+        xm = minimize(cost, xm, method="L-BFGS-B", options={"maxiter": 20000, "maxfun": 2000000, "ftol": 1e-16, "gtol": 1e-9}).x
+
+    class _S:  # what the record below reads
+        fun = fr(xm)
+    s = _S
+    out["tiny_bal_huber"] = {"shape": [C, P, N], "seed": seed, "a": a, "observations": obs.tolist(),
+                             "cost": float(0.5 * np.sum(s.fun ** 2)),
+                             "initial_cost": float(0.5 * np.sum(fr(prob.parameters) ** 2))}
+    with open(os.path.join(HERE, "robust_optima.json"), "w") as f:
+        json.dump({"source": "scipy.optimize.least_squares (robust losses)", **out}, f, indent=1)
+
+
 if __name__ == "__main__":
     make_snavely()
     make_optima()
+    make_robust_optima()
     print("golden fixtures written to", HERE)

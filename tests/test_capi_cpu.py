@@ -123,6 +123,37 @@ def test_options_validation():
         o.setFunctionTolerance(-1.0)
 
 
+def test_predefined_loss_functions_construction_and_validation():
+    # ceres.i:159-184: constructors exist for every predefined loss; bad parameters and over-deep nesting are errors.
+    # (No evaluation here: LossFunction.evaluate runs on the device.)
+    L = sk.PredefinedLossFunctions
+    losses = [L.trivialLoss(), L.huberLoss(1.0), L.softLOneLoss(0.5), L.cauchyLoss(0.5), L.tukeyLoss(2.0), L.tolerantLoss(1.0, 0.3)]
+    losses.append(L.composedLoss(losses[1], losses[3]))
+    losses.append(L.scaledLoss(losses[2], 0.5))
+    losses.append(L.scaledLoss(None, 2.0))
+    assert all(l._h for l in losses)
+    for bad in (lambda: L.huberLoss(0.0), lambda: L.cauchyLoss(-1.0), lambda: L.tolerantLoss(1.0, 0.0)):
+        with pytest.raises(sk.SkeresError):
+            bad()
+    deep = L.cauchyLoss(1.0)
+    for _ in range(4):
+        deep = L.composedLoss(deep, L.trivialLoss())
+    with pytest.raises(sk.SkeresError, match="nested deeper"):
+        L.composedLoss(deep, None)
+    # a problem accepts any of them per residual block; dense rows take the trivial loss only
+    m, c = sk.DoubleArray(1), sk.DoubleArray(1)
+    problem = sk.Problem()
+    for l in losses:
+        problem.addResidualBlock(sk.ExponentialResidual(1.0, 2.0).toAutoDiffCostFunction(), l, m, c)
+    assert problem.numResidualBlocks() == len(losses)
+    x = sk.DoubleArray(8)
+    with pytest.raises(sk.SkeresError):
+        sk.Problem().addDenseRows(10, np.zeros((4, 3)), L.huberLoss(1.0), x, 8)
+    if sk.device_count() == 0:
+        with pytest.raises(sk.SkeresError, match="no HIP device"):
+            L.huberLoss(1.0).evaluate([1.0])
+
+
 def test_compute_fails_loudly_without_a_device():
     if sk.device_count() > 0:
         pytest.skip("a GPU is present")
