@@ -87,7 +87,8 @@ typedef enum sk_functor_id {
    * r = tanh(a . x) - y over ONE parameter block of any size n, the row a regenerated on the
    * device from a counter-based generator; consts (seed, row index, y).  Added with
    * sk_problem_add_dense_rows. */
-  SK_FUNCTOR_SYNTH_TANH_ROW = 10
+  SK_FUNCTOR_SYNTH_TANH_ROW = 10,
+  SK_FUNCTOR_HELLO_WORLD = 11             /* EX/HelloWorld.scala:11-14: r = 10 - x */
 } sk_functor_id;
 
 typedef struct sk_ptrvec sk_ptrvec;

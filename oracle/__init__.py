@@ -24,6 +24,7 @@ MAX_LOG = 256
 # functor ids (oracle/functors.hpp; same numbering as include/skeres_amd.h)
 SNAVELY, EXPONENTIAL, POWELL_F1, POWELL_F2, POWELL_F3, POWELL_F4 = 1, 2, 3, 4, 5, 6
 BINARY_SCALAR, BINARY_VECTOR3, TEN_PARAMETER = 7, 8, 9
+HELLO_WORLD = 11  # EX/HelloWorld.scala:11-14
 SYNTH_TANH_ROW = 10  # BASELINE.json config 5 (dense rows over one block of any size)
 
 

@@ -26,6 +26,7 @@ enum FunctorId {
   kBinaryScalarCost = 7,          // TEST/AutodiffCostFuntionSpec.scala:14-26
   kBinaryVector3Cost = 8,         // TEST/AutodiffCostFuntionSpec.scala:55-69
   kTenParameterCost = 9,          // TEST/AutodiffCostFuntionSpec.scala:111-119
+  kHelloCostFunctor = 11,         // EX/HelloWorld.scala:11-14
 };
 
 // ulp(1.0) == 2^-52  (CORE/package.scala:15, CORE/Rotation.scala:457)
@@ -205,6 +206,16 @@ struct TenParameterCost {  // TEST/AutodiffCostFuntionSpec.scala:111-119
     T s = p[0][0];  // p.map(_(0)).reduce(_ + _): left fold
     for (int i = 1; i < 10; ++i) s = s + p[i][0];
     out[0] = s;
+    return true;
+  }
+};
+
+struct HelloCostFunctor {  // EX/HelloWorld.scala:11-14
+  static constexpr int kNumResiduals = 1, kNumBlocks = 1, kNumConsts = 0;
+  static constexpr int N[1] = {1};
+  template <class T>
+  static bool apply(const double*, const T* const* p, T* out) {
+    out[0] = 10.0 - p[0][0];
     return true;
   }
 };

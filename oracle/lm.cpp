@@ -73,6 +73,7 @@ static bool functor_info(int id, FunctorInfo* fi) {
     case kBinaryScalarCost: *fi = info_of<BinaryScalarCost>(); return true;
     case kBinaryVector3Cost: *fi = info_of<BinaryVector3Cost>(); return true;
     case kTenParameterCost: *fi = info_of<TenParameterCost>(); return true;
+    case kHelloCostFunctor: *fi = info_of<HelloCostFunctor>(); return true;
   }
   return false;
 }
@@ -89,6 +90,7 @@ static bool evaluate_block(int id, const double* consts, double const* const* pa
     case kBinaryScalarCost: return AutoDiff<BinaryScalarCost>::evaluate(consts, params, residuals, jacobians);
     case kBinaryVector3Cost: return AutoDiff<BinaryVector3Cost>::evaluate(consts, params, residuals, jacobians);
     case kTenParameterCost: return AutoDiff<TenParameterCost>::evaluate(consts, params, residuals, jacobians);
+    case kHelloCostFunctor: return AutoDiff<HelloCostFunctor>::evaluate(consts, params, residuals, jacobians);
   }
   return false;
 }

@@ -6,6 +6,7 @@ C ABI of ``libskeres_amd.so`` (include/skeres_amd.h):
 
     AutoDiffCostFunctor / toAutoDiffCostFunction   CORE/CostFunctor.scala:40-51
     SizedCostFunction / CostFunction.evaluate      CORE/SizedCostFunction.scala:6-14
+    NumericDiffCostFunctor / NumericDiffCostFunction   CORE/NumericDiffCostFunction.scala:69-162 (host side)
     Problem.addResidualBlock                       CORE/Problem.scala:20-27
     DoubleArray, RichDoubleArray, RichDoubleMatrix CORE/RichDoubleArray.scala, RichDoubleMatrix.scala
     PredefinedLossFunctions (trivial, huber, softLOne, cauchy, tukey, tolerant, composed, scaled)  ceres.i:159-184
@@ -17,9 +18,10 @@ device and raises otherwise.
 from .api import (  # noqa: F401
     SkeresError, lib, device_count,
     DoubleArray, RichDoubleArray, RichDoubleMatrix, StdVectorDoublePointer,
-    CostFunction, SizedCostFunction, AutoDiffCostFunctor, AutoDiffCostFunction,
+    CostFunction, SizedCostFunction, CostFunctor, AutoDiffCostFunctor, AutoDiffCostFunction,
+    NumericDiffCostFunctor, NumericDiffCostFunction, NumericDiffMethodType, NumericDiffOptions,
     SnavelyReprojectionError, ExponentialResidual, PowellF1, PowellF2, PowellF3, PowellF4,
-    BinaryScalarCost, BinaryVector3Cost, TenParameterCost,
+    BinaryScalarCost, BinaryVector3Cost, TenParameterCost, HelloCostFunctor,
     PredefinedLossFunctions, LossFunction, Problem, Solver, LinearSolverType, MinimizerType, TerminationType,
     ceres, StepSolver,
 )

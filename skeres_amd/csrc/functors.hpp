@@ -150,6 +150,16 @@ struct TenParameterCost {  // TEST/AutodiffCostFuntionSpec.scala:111-119
   }
 };
 
+struct HelloCostFunctor {  // EX/HelloWorld.scala:11-14: 10 - x
+  static constexpr int kRes = 1, kBlocks = 1, kConsts = 0, kDim = 1;
+  static SK_HD int N(int) { return 1; }
+  template <class T>
+  static SK_HD bool apply(const double*, const T* const* p, T* out) {
+    out[0] = 10.0 - p[0][0];
+    return true;
+  }
+};
+
 // Static description usable on the host (sizes for validation).
 struct FunctorDesc {
   int id, num_residuals, num_blocks, num_consts;
@@ -172,6 +182,7 @@ inline bool functor_desc(int id, FunctorDesc* d) {
     SK_DESC(7, BinaryScalarCost)
     SK_DESC(8, BinaryVector3Cost)
     SK_DESC(9, TenParameterCost)
+    SK_DESC(11, HelloCostFunctor)
   }
 #undef SK_DESC
   return false;
@@ -189,6 +200,7 @@ inline bool functor_desc(int id, FunctorDesc* d) {
     case 7: MACRO(sk::BinaryScalarCost); break;         \
     case 8: MACRO(sk::BinaryVector3Cost); break;        \
     case 9: MACRO(sk::TenParameterCost); break;         \
+    case 11: MACRO(sk::HelloCostFunctor); break;        \
     default: break;                               \
   }
 

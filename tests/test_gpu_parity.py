@@ -305,6 +305,52 @@ def test_host_callback_cost_function_director_path():
         assert abs(g[k] - so.iterations[k].cost) <= 1e-9 * max(so.iterations[k].cost, 1e-30)
 
 
+def test_numeric_diff_cost_function_through_the_solver_vs_oracle_autodiff():
+    # CurveFitting with every residual block numerically differentiated on the host (central differences):
+    # same optimum and, to the differencing error, the same trajectory as the oracle's Jet autodiff
+    class Exp(sk.NumericDiffCostFunctor):
+        def __init__(self, x, y):
+            super().__init__(1, 1, 1)
+            self.x, self.y = x, y
+
+        def apply(self, m, c):
+            return [self.y - np.exp(m[0] * self.x + c[0])]
+    data = curve_fitting_data()[::3]
+    m, c = sk.DoubleArray(1), sk.DoubleArray(1)
+    m.set(0, 0.0)
+    c.set(0, 0.0)
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    problem = sk.Problem()
+    costs = [Exp(x, y).toNumericDiffCostFunction(sk.NumericDiffMethodType.CENTRAL) for x, y in data]
+    for cf in costs:
+        problem.addResidualBlock(cf, loss, m, c)
+    options = sk.Solver.Options()
+    options.setMaxNumIterations(25)
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_QR)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    xo, so = oracle.solve([1, 1], [0.0, 0.0], [(oracle.EXPONENTIAL, [x, y], [0, 1]) for x, y in data],
+                          oracle.default_options(linear_solver_type=oracle.DENSE_QR, max_num_iterations=25))
+    g = [it["cost"] for it in summary.iterations()]
+    assert abs(len(g) - so.num_logged) <= 1
+    for k in range(min(len(g), so.num_logged)):
+        assert abs(g[k] - so.iterations[k].cost) <= 1e-6 * so.iterations[k].cost
+    np.testing.assert_allclose([m.get(0), c.get(0)], xo, rtol=1e-5)
+
+
+def test_hello_world_vs_oracle():  # EX/HelloWorld.scala
+    x = sk.DoubleArray(1)
+    x.set(0, 0.5)
+    problem = sk.Problem()
+    problem.addResidualBlock(sk.HelloCostFunctor().toAutoDiffCostFunction(), sk.PredefinedLossFunctions.trivialLoss(), x)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(sk.Solver.Options(), problem, summary)
+    xo, so = oracle.solve([1], [0.5], [(oracle.HELLO_WORLD, [], [0])], oracle.default_options())
+    assert x.get(0) == pytest.approx(10.0, abs=1e-7) and xo[0] == pytest.approx(10.0, abs=1e-7)
+    assert summary.initialCost() == so.initial_cost == 0.5 * 9.5 ** 2
+    assert len(summary.iterations()) == so.num_logged  # iteration 0 included on both sides
+
+
 # ---------------------------------------------------------------------------
 # size-independent properties at larger sizes
 # ---------------------------------------------------------------------------
@@ -557,3 +603,10 @@ def test_example_programs_end_to_end(tmp_path, capfd):  # capfd: the progress ta
     out = capfd.readouterr().out
     assert "Loading BalProblem from" in out and " done" in out and "DENSE_SCHUR" in out and "Termination" in out
     assert simple_bundle_adjuster.main(["prog"]) == 1  # usage
+    # the small examples: HelloWorld (autodiff on the device), HelloWorldNumericDiff and PowellAnalytic (host cost functions)
+    from skeres_amd.examples import hello_world, hello_world_numeric_diff, powell_analytic
+    assert hello_world.main() == pytest.approx(10.0, abs=1e-6)
+    assert hello_world_numeric_diff.main() == pytest.approx(10.0, abs=1e-6)
+    np.testing.assert_allclose(powell_analytic.main(), 0.0, atol=1e-3)
+    out = capfd.readouterr().out
+    assert out.count("Ceres Solver Report") == 3 and "Initial: x1 = 3.0, x2 = -1.0, x3 = 0.0, x4 = 1.0" in out
