@@ -137,10 +137,17 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # developer knobs to rehearse the multi-rank path on a one-GPU box: all ranks on one device, exchange over gloo
+    backend = os.environ.get("SK_BENCH_DIST_BACKEND", "nccl")
+    if "SK_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SK_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import skeres_amd as sk
     from skeres_amd import bal
@@ -167,6 +174,7 @@ def main():
         hook = sk_dist.attach(options, problem, rank, world)  # reduce buffer + all-reduce hook over torch.distributed (RCCL)
 
     solver = sk.StepSolver(options, problem)  # uploads the shard, builds the pair lists, runs iteration 0
+    dist_mode, t_allreduce, t_saved = solver.distribution() if world > 1 else ("single", 0.0, 0.0)
     for _ in range(args.warmup):
         solver.step()
     solver.setKernelTiming(2)  # HIP events around the dominant kernel's launches only
@@ -225,11 +233,15 @@ def main():
             "config": {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d), DENSE_SCHUR" % (
                 args.workload, prob.num_cameras, prob.num_points, prob.num_observations, SEED),
                 "linear_solver": "DENSE_SCHUR", "reduced_system_n": 9 * prob.num_cameras,
-                "successful_steps_in_timed_region": n_success, "parallelism": "points sharded x%d, Cholesky replicated" % world,
+                "successful_steps_in_timed_region": n_success, "parallelism": ("one GPU" if world == 1 else
+                                "points sharded x%d, reduced system all-reduced, Cholesky replicated" % world if dist_mode == "sharded" else
+                                "replicated x%d: the solver measured %.1f ms for the all-reduce of the reduced system against %.1f ms of "
+                                "per-iteration work sharding would remove, and did not shard" % (world, 1e3 * t_allreduce, 1e3 * t_saved)),
                 "cost_first_timed": timed[0]["cost"] if timed else None, "cost_last_timed": timed[-1]["cost"] if timed else None},
             "roofline": {"bound": "mfma", "kernel": "sk::syrk_trailing_f64_kernel (Cholesky trailing SYRK, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": pmc_traffic() if (args.workload == "ladybug-1723-156502" and args.group <= 0) else None,
                          "traffic_note": "bytes/launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled, gfx950; "
                                          "includes Infinity-Cache hits); algorithmic C-tile bytes/launch (read + write) = %.3e" % (
                                              syrk_c_tile_bytes_per_launch(9 * prob.num_cameras, args.group if args.group > 0 else 3)),

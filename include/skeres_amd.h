@@ -238,6 +238,12 @@ int sk_options_set_cholesky_tuning(sk_options* o, int group, int lookahead);
 typedef int (*sk_allreduce_fn)(void* user, double* device_buffer, size_t count, void* hip_stream);
 int sk_options_set_distributed(sk_options* o, int rank, int world, sk_allreduce_fn allreduce,
                                void* user);
+/* What a world > 1 does with its ranks.  SHARDED: points partitioned, one all-reduce of the reduced system
+ * (its lower block triangle, packed) per linear solve.  REPLICATED: every rank solves the whole problem, no
+ * collective.  AUTO (default): the solver times the all-reduce on the real buffer at set-up, estimates the
+ * per-iteration work sharding would remove, and shards only when that pays (same decision on every rank). */
+enum { SK_DISTRIBUTION_AUTO = 0, SK_DISTRIBUTION_SHARDED = 1, SK_DISTRIBUTION_REPLICATED = 2 };
+int sk_options_set_distribution_mode(sk_options* o, int mode);
 /* The caller may hand the solver the buffer the big all-reduce runs on (so a
  * torch.distributed / RCCL communicator can register it).  bytes must be >=
  * sk_reduce_buffer_bytes(problem, options). */
@@ -288,6 +294,10 @@ double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launc
 /* Algorithmic flop count of the dense Cholesky's trailing updates per linear
  * solve (what roofline.achieved is computed from). */
 double sk_solver_syrk_flops_per_solve(const sk_solver* s);
+/* SK_DISTRIBUTION_SHARDED or _REPLICATED as decided at sk_solver_create; with AUTO, *allreduce_seconds is the
+ * measured all-reduce of the reduced system and *saved_seconds the estimated per-iteration work sharding removes
+ * (either pointer may be NULL). */
+int sk_solver_distribution(const sk_solver* s, double* allreduce_seconds, double* saved_seconds);
 
 /* ---- multi-GPU sharding (host logic, no device needed) -----------------------
  * How sk_solve splits a bundle-adjustment-shaped problem over `world` ranks

@@ -118,6 +118,8 @@ _SIGS = {
     "sk_solver_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_solver_kernel_seconds": (C.c_double, [C.c_void_p, C.c_char_p, _ip]),
     "sk_solver_syrk_flops_per_solve": (C.c_double, [C.c_void_p]),
+    "sk_solver_distribution": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
     "sk_synth_dense_targets": (C.c_int, [C.c_double, C.c_int, C.c_int, _dp, _dp]),
     "sk_problem_point_partition": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip]),
@@ -805,6 +807,10 @@ class Solver:
             self._keep.append(cb)
             _check(lib().sk_options_set_distributed(self._h, int(rank), int(world), cb, None))
 
+        def setDistributionMode(self, mode):
+            """0 auto (default), 1 sharded, 2 replicated: what a world > 1 does (include/skeres_amd.h)."""
+            _check(lib().sk_options_set_distribution_mode(self._h, int(mode)))
+
         def setReduceBuffer(self, ptr, nbytes):
             _check(lib().sk_options_set_reduce_buffer(self._h, C.c_void_p(int(ptr)), int(nbytes)))
 
@@ -880,6 +886,12 @@ class StepSolver:
 
     def syrkFlopsPerSolve(self):
         return lib().sk_solver_syrk_flops_per_solve(self._h)
+
+    def distribution(self):
+        """("sharded" | "replicated", measured all-reduce seconds, estimated seconds of work sharding removes per iteration)."""
+        a, b = C.c_double(), C.c_double()
+        mode = lib().sk_solver_distribution(self._h, C.byref(a), C.byref(b))
+        return {1: "sharded", 2: "replicated"}.get(mode, "sharded"), a.value, b.value
 
 
 def cholesky_solve(A, b, want_L=False, group=0):

@@ -490,6 +490,20 @@ __global__ __launch_bounds__(kBlock) void bal_cam_step_kernel(BalDev d, double* 
   if (threadIdx.x == 0) { double s = 0.0; for (int i = 0; i < kBlock / 64; ++i) s += sh[i]; out[0] = s; }
 }
 
+// Lower block triangle of S <-> packed buffer (see bal_kernels.hpp), 16 bytes per lane.
+__global__ __launch_bounds__(256) void tri_pack_kernel(double* S, int ld, double* packed, int to_packed) {
+  const int kb = blockIdx.y;
+  const size_t width = (size_t)(kb + 1) * 128;
+  double* pk = packed + (size_t)128 * 128 * ((size_t)kb * (kb + 1) / 2);
+  const size_t n2 = 128 * width / 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+    const size_t e = 2 * i, r = e / width, c = e % width;
+    double2* a = reinterpret_cast<double2*>(S + ((size_t)kb * 128 + r) * ld + c);
+    double2* b = reinterpret_cast<double2*>(pk + e);
+    if (to_packed) *b = *a; else *a = *b;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -499,6 +513,10 @@ static inline int grid_for(int n, int cap = 2048) {
 }
 
 int bal_partial_blocks(int N) { return grid_for(N); }
+size_t tri_packed_elems(int nblk) { return (size_t)128 * 128 * ((size_t)nblk * (nblk + 1) / 2); }
+void launch_tri_pack(double* S, int ld, double* packed, int nblk, bool to_packed, hipStream_t s) {
+  if (nblk > 0) hipLaunchKernelGGL(tri_pack_kernel, dim3(64, nblk), dim3(256), 0, s, S, ld, packed, to_packed ? 1 : 0);
+}
 
 void launch_bal_eval_jac(const BalDev& d, hipStream_t s) {
   if (d.loss_root >= 0) hipLaunchKernelGGL(bal_eval_jac_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);

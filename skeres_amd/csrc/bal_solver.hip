@@ -71,6 +71,11 @@ class BalSolver : public SolverBase {
  public:
   BalSolver(const Options& o, Problem* p) : SolverBase(o, p) {}
   double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, opt_.cholesky_group); }
+  int distribution(double* allreduce_s, double* saved_s) const override {
+    if (allreduce_s) *allreduce_s = est_allreduce_s_;
+    if (saved_s) *saved_s = est_saved_s_;
+    return distribution_;
+  }
 
  protected:
   int setup() override;
@@ -98,13 +103,57 @@ class BalSolver : public SolverBase {
   DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_fail_, b_info_;
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
-  DevBuf<double> b_w_;
+  DevBuf<double> b_w_, b_pack_;
+  size_t packed_elems_ = 0;
+  int distribution_ = SK_DISTRIBUTION_SHARDED;
+  double est_allreduce_s_ = 0.0, est_saved_s_ = 0.0;
+  int choose_distribution(const std::vector<int>& opt);
   CholeskyContext chol_ctx_;
   double* h_scal_ = nullptr;  // pinned
   int partial_stride_ = 0;
  public:
   ~BalSolver() override { if (h_scal_) (void)hipHostFree(h_scal_); }
 };
+
+// Sharding the points pays when the per-iteration work it removes from a rank (evaluation, Schur
+// assembly, back-substitution: linear in observations and pair entries) exceeds the all-reduce of the
+// reduced system it adds.  The all-reduce is MEASURED here (second and third call of the hook on the real
+// buffer); the work is estimated from constants measured on MI355X (profiles/r01_c_*).  All ranks
+// take the same decision: the measured times are averaged over ranks through the hook itself.
+// In replicated mode every rank solves the whole problem with no collective at all (the results are
+// bitwise those of one GPU); the speed-up is then 1, which for a small reduced system beats < 1.
+int BalSolver::choose_distribution(const std::vector<int>& opt) {
+  const int W = opt_.world;
+  distribution_ = SK_DISTRIBUTION_SHARDED;
+  if (W <= 1 || opt_.distribution_mode == SK_DISTRIBUTION_SHARDED) return SK_OK;
+  if (opt_.distribution_mode != SK_DISTRIBUTION_REPLICATED) {
+    std::vector<size_t> k(P_total_, 0);
+    for (int v : opt) k[v]++;
+    double pairs = 0.0;
+    for (size_t v : k) pairs += 0.5 * (double)v * (double)(v - 1);
+    const double per_iter = 0.45e-9 * pairs + 1.9e-9 * (double)opt.size();  // seconds on one MI355X
+    est_saved_s_ = per_iter * (1.0 - 1.0 / W);
+    int rc = allreduce(b_pack_.p, packed_elems_);  // first call: connection set-up, not timed
+    if (rc) return rc;
+    SK_HIP_TRY(hipStreamSynchronize(stream_));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int rep = 0; rep < 2; ++rep) { rc = allreduce(b_pack_.p, packed_elems_); if (rc) return rc; }
+    SK_HIP_TRY(hipStreamSynchronize(stream_));
+    double mine = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 2.0;
+    double vals[1] = {mine};
+    const int ops[1] = {0};
+    SK_HIP_TRY(b_small_.alloc(2 * 9 * (size_t)C_ + 64 + 16 * (size_t)W));
+    rc = gather_rank_scalars(vals, 1, ops);
+    if (rc) return rc;
+    est_allreduce_s_ = vals[0] / W;
+    phase_[5] = 0.0;  // the probe is set-up, not an iteration phase
+    if (est_allreduce_s_ <= est_saved_s_) return SK_OK;  // sharding pays
+  }
+  distribution_ = SK_DISTRIBUTION_REPLICATED;
+  opt_.allreduce = nullptr; opt_.world = 1; opt_.rank = 0;
+  b_pack_.release();
+  return SK_OK;
+}
 
 int BalSolver::setup() {
   std::string why;
@@ -114,6 +163,20 @@ int BalSolver::setup() {
   std::vector<int> ocam, opt;
   bal_index_problem(p, &cam_block_, &pt_block_, &ocam, &opt);
   C_ = (int)cam_block_.size(); P_total_ = (int)pt_block_.size();
+  n_ = 9 * C_; rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
+  // ---- multi-GPU: shard the points, or replicate? ----
+  packed_elems_ = tri_packed_elems(npad_ / 128);
+  if (opt_.allreduce) {
+    if (opt_.reduce_buffer) {
+      if (opt_.reduce_buffer_bytes < packed_elems_ * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", packed_elems_ * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
+      b_pack_.adopt(static_cast<double*>(opt_.reduce_buffer), packed_elems_);
+    } else {
+      SK_HIP_TRY(b_pack_.alloc(packed_elems_));
+    }
+    SK_HIP_TRY(b_pack_.zero(stream_));
+    int rc = choose_distribution(opt);
+    if (rc) return rc;
+  }
   int p_lo = 0, p_hi = P_total_;
   if (opt_.world > 1) {
     std::vector<int> cut;
@@ -167,7 +230,6 @@ int BalSolver::setup() {
       for (int b = pt_start[q] + 1; b < pt_start[q + 1]; ++b)
         for (int a = pt_start[q]; a < b; ++a) { const unsigned e = pos[(size_t)cam[b] * C_ + cam[a]]++; pair_row[e] = b; pair_col[e] = a; }
   }
-  n_ = 9 * C_; rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
   // ---- device buffers ----
   hipStream_t s = stream_;
   SK_HIP_TRY(b_cam_.upload(cam, s)); SK_HIP_TRY(b_pt_.upload(pt, s)); SK_HIP_TRY(b_obs_.upload(obs, s));
@@ -186,13 +248,7 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
   SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
-  const size_t s_elems = (size_t)npad_ * npad_;
-  if (opt_.reduce_buffer) {
-    if (opt_.reduce_buffer_bytes < s_elems * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", s_elems * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
-    b_S_.adopt(static_cast<double*>(opt_.reduce_buffer), s_elems);
-  } else {
-    SK_HIP_TRY(b_S_.alloc(s_elems));
-  }
+  SK_HIP_TRY(b_S_.alloc((size_t)npad_ * npad_));
   SK_HIP_TRY(b_Linv_.alloc((size_t)npad_ * 128)); SK_HIP_TRY(b_Linv_.zero(s));
   partial_stride_ = std::max(std::max(bal_partial_blocks(N_), (P_ + 255) / 256), 256);
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
@@ -306,9 +362,11 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
   kt_.begin("bal_cam_diag", s); launch_bal_cam_diag(d_, s); kt_.end("bal_cam_diag", s);
   kt_.begin("bal_pair", s); launch_bal_pair(d_, s); kt_.end("bal_pair", s);
   if (opt_.allreduce) {
-    // sum S (with the rhs row) over ranks; only rows [0, rhs_row] carry data
-    int rc = allreduce(b_S_.p, (size_t)(rhs_row_ + 1) * npad_);
+    // sum S (with the rhs row) over ranks: only its lower block triangle travels (half the bytes)
+    launch_tri_pack(b_S_.p, npad_, b_pack_.p, npad_ / 128, true, s);
+    int rc = allreduce(b_pack_.p, packed_elems_);
     if (rc) return rc;
+    launch_tri_pack(b_S_.p, npad_, b_pack_.p, npad_ / 128, false, s);
   }
   launch_bal_finish_S(b_S_.p, npad_, n_, npad_, rhs_row_, d_.D_c, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <new>
 
+#include "bal_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "dense_rows_kernels.hpp"
 #include "solver.hpp"
@@ -357,6 +358,10 @@ int sk_options_set_distributed(sk_options* o, int rank, int world, sk_allreduce_
   if (world > 1 && !fn) { set_error("world > 1 needs an allreduce hook"); return SK_ERR_INVALID_ARGUMENT; }
   o->o.rank = rank; o->o.world = world; o->o.allreduce = fn; o->o.allreduce_user = user; return SK_OK;
 }
+int sk_options_set_distribution_mode(sk_options* o, int mode) {
+  if (mode != SK_DISTRIBUTION_AUTO && mode != SK_DISTRIBUTION_SHARDED && mode != SK_DISTRIBUTION_REPLICATED) { set_error("invalid distribution mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
+  o->o.distribution_mode = mode; return SK_OK;
+}
 int sk_options_set_reduce_buffer(sk_options* o, void* ptr, size_t bytes) { o->o.reduce_buffer = ptr; o->o.reduce_buffer_bytes = bytes; return SK_OK; }
 size_t sk_reduce_buffer_bytes(const sk_options* o, const sk_problem* p) {
   (void)o;
@@ -365,7 +370,7 @@ size_t sk_reduce_buffer_bytes(const sk_options* o, const sk_problem* p) {
   std::vector<char> seen(P.block_size.size(), 0); size_t C = 0;
   for (size_t b = 0; b < P.rb_functor.size(); ++b) { const int c = P.rb_pidx[P.rb_pidx_off[b]]; if (!seen[c]) { seen[c] = 1; ++C; } }
   const size_t n = 9 * C, npad = ((n + 1 + 127) / 128) * 128;
-  return npad * npad * sizeof(double);
+  return tri_packed_elems((int)(npad / 128)) * sizeof(double);  // lower block triangle, packed
 }
 
 // ---- Summary --------------------------------------------------------------------------
@@ -449,6 +454,7 @@ double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launc
   return st.seconds;
 }
 double sk_solver_syrk_flops_per_solve(const sk_solver* s) { return s->impl->syrk_flops_per_solve(); }
+int sk_solver_distribution(const sk_solver* s, double* allreduce_seconds, double* saved_seconds) { return s->impl->distribution(allreduce_seconds, saved_seconds); }
 
 int sk_solve(const sk_options* options, sk_problem* problem, sk_summary* summary) {
   SK_GUARD_BEGIN

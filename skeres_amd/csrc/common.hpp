@@ -113,6 +113,7 @@ struct Options {  // Solver.Options; Ceres 1.x defaults
   int rank = 0, world = 1;
   sk_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  int distribution_mode = SK_DISTRIBUTION_AUTO;
   void* reduce_buffer = nullptr;
   size_t reduce_buffer_bytes = 0;
   int cholesky_group = 3;  // SYRK K = group * 128 (3 measured best with the panel look-ahead; 2 and 4 within 1 %)

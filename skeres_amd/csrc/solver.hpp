@@ -21,6 +21,12 @@ class SolverBase {
   int finish(Summary* s);       // parameters back to caller memory + summary
   KernelTimer& kernel_timer() { return kt_; }
   virtual double syrk_flops_per_solve() const { return 0.0; }
+  // how a world > 1 is used (SK_DISTRIBUTION_*), with the estimates behind an automatic choice
+  virtual int distribution(double* allreduce_s, double* saved_s) const {
+    if (allreduce_s) *allreduce_s = 0.0;
+    if (saved_s) *saved_s = 0.0;
+    return SK_DISTRIBUTION_REPLICATED;
+  }
 
  protected:
   // --- representation-specific pieces -------------------------------------

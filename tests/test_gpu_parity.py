@@ -388,6 +388,21 @@ def test_distributed_hook_path_world_of_one_matches_plain_solve():
     assert "DIST_GPU_OK" in out.stdout
 
 
+@pytest.mark.parametrize("world,mode", [(2, "sharded"), (3, "sharded"), (2, "replicated"), (2, "auto")])
+def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode):
+    """tests/dist_gpu_worker2.py: `world` ranks share GPU 0 and exchange through gloo (host-staged hook)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29900 + world + (os.getpid() % 60)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker2.py"), mode]
+    out = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "DIST_GPU2_OK world=%d" % world in out.stdout
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json config 5: dense rows over one block, DENSE_NORMAL_CHOLESKY with a long-K MFMA SYRK
 # ---------------------------------------------------------------------------
