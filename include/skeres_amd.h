@@ -135,6 +135,32 @@ double* sk_ptrvec_get(const sk_ptrvec* v, int i);
 void sk_ptrvec_set(sk_ptrvec* v, int i, double* p);  /* CORE/RichDoubleMatrix.scala:74-75 */
 double** sk_ptrvec_to_pointer_pointer(sk_ptrvec* v); /* DoubleMatrix.toPointerPointer; NULL when empty */
 
+/* ---- Rotation (CORE/Rotation.scala:63-522) ----------------------------------------------
+ * The conversion / rotation functions device functors call (csrc/rotation.hpp), evaluated ON THE DEVICE for
+ * `n` inputs at once.  jet_dim 0: `in` is [n][in_len] doubles, `out` [n][out_len].  jet_dim K in 1..4: every
+ * value is a Jet, stored as (real, K infinitesimal parts): in [n][in_len][1+K], out [n][out_len][1+K] — what
+ * the functions compute under automatic differentiation (RotationSpec.scala:459-562).  Quaternions are
+ * (w, x, y, z); 3x3 matrices are 9 values, column-major unless row_major != 0 (the reference's
+ * ColumnMajorMatrixAdapter3x3 / RowMajorMatrixAdapter3x3); Euler angles are (pitch, roll, yaw) in degrees.
+ * Input layout of the two-argument functions: first argument, then second (q then pt; z then w; x then y). */
+typedef enum {
+  SK_ROT_ANGLE_AXIS_TO_QUATERNION = 0,         /* :72   3 -> 4 */
+  SK_ROT_QUATERNION_TO_ANGLE_AXIS = 1,         /* :104  4 -> 3 */
+  SK_ROT_ROTATION_MATRIX_TO_QUATERNION = 2,    /* :162  9 -> 4 */
+  SK_ROT_ROTATION_MATRIX_TO_ANGLE_AXIS = 3,    /* :203  9 -> 3 */
+  SK_ROT_ANGLE_AXIS_TO_ROTATION_MATRIX = 4,    /* :211  3 -> 9 */
+  SK_ROT_EULER_ANGLES_TO_ROTATION_MATRIX = 5,  /* :269  3 -> 9 */
+  SK_ROT_QUATERNION_TO_SCALED_ROTATION = 6,    /* :326  4 -> 9 */
+  SK_ROT_QUATERNION_TO_ROTATION = 7,           /* :364  4 -> 9; the zero quaternion is SK_ERR_EVALUATION_FAILED (`require`) */
+  SK_ROT_UNIT_QUATERNION_ROTATE_POINT = 8,     /* :393  4+3 -> 3 */
+  SK_ROT_QUATERNION_ROTATE_POINT = 9,          /* :422  4+3 -> 3 */
+  SK_ROT_QUATERNION_PRODUCT = 10,              /* :435  4+4 -> 4 */
+  SK_ROT_CROSS_PRODUCT = 11,                   /* :441  3+3 -> 3 (the mathematical product; the reference's first component is a typo) */
+  SK_ROT_DOT_PRODUCT = 12,                     /* :445  3+3 -> 1 */
+  SK_ROT_ANGLE_AXIS_ROTATE_POINT = 13          /* :449  3+3 -> 3 */
+} sk_rotation_op;
+int sk_rotation_apply(int op, int row_major, int jet_dim, const double* in, int n, double* out);
+
 /* ---- LossFunction: PredefinedLossFunctions, ceres.i:168-184 -------------- */
 sk_loss_function* sk_loss_trivial(void);             /* trivialLoss(): rho(s) = s; caller frees (%newobject, ceres.i:160) */
 sk_loss_function* sk_loss_huber(double a);           /* huberLoss(a), ceres.i:171 */

@@ -91,6 +91,7 @@ def lib():
                                    C.POINTER(Options), C.POINTER(Summary)]
         L.or_bal_evaluate.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, dp, dp]
         L.or_bal_reduced_system.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
+        L.or_rotation_apply.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]
         L.or_loss_evaluate.argtypes = [dp, C.c_int, C.c_double, dp]
         L.or_solve_loss.argtypes = [C.c_int, ip, dp, C.c_int, ip, dp, ip, ip, ip, dp, ip,
                                     C.POINTER(Options), C.POINTER(Summary)]
@@ -311,3 +312,20 @@ def bal_reduced_system(C_, P_, cam_idx, pt_idx, obs, x, D, add_Dc=True):
     if rc != 0:
         raise RuntimeError("or_bal_reduced_system failed: %d" % rc)
     return S, rhs
+
+
+ROTATION_IN = (3, 4, 9, 9, 3, 3, 4, 4, 7, 7, 8, 6, 6, 6)
+ROTATION_OUT = (4, 3, 4, 3, 9, 9, 9, 9, 3, 3, 4, 3, 1, 3)
+
+
+def rotation_apply(op, values, row_major=False, jet_dim=0):
+    """Rotation op `op` (ids of include/skeres_amd.h: sk_rotation_op) on an [n, in_len] array
+    (jet_dim K > 0: [n, in_len, 1 + K]); returns [n, out_len(, 1 + K)]."""
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    n = a.shape[0]
+    shape = (n, ROTATION_OUT[op]) + ((1 + jet_dim,) if jet_dim else ())
+    out = np.zeros(shape)
+    rc = lib().or_rotation_apply(op, int(row_major), jet_dim, _dp(a), n, _dp(out))
+    if rc != 0:
+        raise ValueError("or_rotation_apply failed: %d" % rc)
+    return out

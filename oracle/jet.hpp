@@ -88,6 +88,15 @@ template <int N> inline Jet<N> exp(const Jet<N>& f) {
   Jet<N> h; h.a = e; for (int i = 0; i < N; ++i) h.v[i] = e * f.v[i]; return h;
 }
 
+// atan2(y, x) with d = (x dy - y dx) / (x^2 + y^2)
+template <int N> inline Jet<N> atan2(const Jet<N>& y, const Jet<N>& x) {
+  const double t = 1.0 / (x.a * x.a + y.a * y.a);
+  Jet<N> h; h.a = std::atan2(y.a, x.a);
+  for (int i = 0; i < N; ++i) h.v[i] = (-(y.a * t)) * x.v[i] + (x.a * t) * y.v[i];
+  return h;
+}
+inline double atan2(double y, double x) { return std::atan2(y, x); }
+
 // Plain-double overloads so functor bodies are generic in T.
 inline double sqrt(double x) { return std::sqrt(x); }
 inline double cos(double x) { return std::cos(x); }

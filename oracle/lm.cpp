@@ -39,6 +39,7 @@
 #endif
 #include "functors.hpp"
 #include "loss.hpp"
+#include "rotation.hpp"
 #include "oracle.h"
 
 namespace oracle {
@@ -679,6 +680,24 @@ static int bal_build(Bal& B, int C, int P, int N, const int* cam_idx, const int*
 int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                  double* x, const or_options* opt, or_summary* summary) {
   return or_solve_bal_loss(C, P, N, cam_idx, pt_idx, obs, nullptr, -1, x, opt, summary);
+}
+
+// Rotation functions (oracle/rotation.hpp).  jet_dim 0: in [n][in_len] doubles; jet_dim K in 1..4: every value is
+// (real, K infinitesimals).  Returns 0, or -1 for a bad op / jet_dim / a quaternionToRotation of the zero quaternion.
+int or_rotation_apply(int op, int row_major, int jet_dim, const double* in, int n, double* out) {
+  if (op < 0 || op > 13) return -1;
+  if (jet_dim == 0) {
+    for (int i = 0; i < n; ++i)
+      if (!oracle::rotationApply<double>(op, row_major, in + (size_t)i * oracle::kRotationIn[op], out + (size_t)i * oracle::kRotationOut[op])) return -1;
+    return 0;
+  }
+  switch (jet_dim) {
+    case 1: return oracle::rotationApplyJets<1>(op, row_major, in, n, out) ? 0 : -1;
+    case 2: return oracle::rotationApplyJets<2>(op, row_major, in, n, out) ? 0 : -1;
+    case 3: return oracle::rotationApplyJets<3>(op, row_major, in, n, out) ? 0 : -1;
+    case 4: return oracle::rotationApplyJets<4>(op, row_major, in, n, out) ? 0 : -1;
+  }
+  return -1;
 }
 
 void or_loss_evaluate(const double* loss_nodes, int root, double s, double* rho) { oracle::loss_evaluate(loss_nodes, root, s, rho); }

@@ -51,6 +51,8 @@ int or_solve(int num_blocks, const int* block_sizes, double* x, int num_res_bloc
              const int* pidx_off, const or_options* opt, or_summary* summary);
 int or_solve_bal(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                  double* x, const or_options* opt, or_summary* summary);
+/* Rotation functions (oracle/rotation.hpp); op ids as sk_rotation_op in include/skeres_amd.h */
+int or_rotation_apply(int op, int row_major, int jet_dim, const double* in, int n, double* out);
 /* robust losses (oracle/loss.hpp): nodes of 5 doubles {type, a, b, f, g} */
 void or_loss_evaluate(const double* loss_nodes, int root, double s, double* rho);
 int or_solve_loss(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,

@@ -26,3 +26,5 @@ from .api import (  # noqa: F401
     ceres, StepSolver,
 )
 from . import bal  # noqa: F401
+from . import rotation  # noqa: F401
+from .rotation import Rotation, Jet, Quaternion, MatrixAdapter, RowMajorMatrixAdapter3x3, ColumnMajorMatrixAdapter3x3  # noqa: F401

@@ -47,6 +47,7 @@ _SIGS = {
     "sk_ptrvec_get": (_dp, [C.c_void_p, C.c_int]),
     "sk_ptrvec_set": (None, [C.c_void_p, C.c_int, _dp]),
     "sk_ptrvec_to_pointer_pointer": (_dpp, [C.c_void_p]),
+    "sk_rotation_apply": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp]),
     "sk_loss_trivial": (C.c_void_p, []),
     "sk_loss_huber": (C.c_void_p, [C.c_double]),
     "sk_loss_soft_l_one": (C.c_void_p, [C.c_double]),

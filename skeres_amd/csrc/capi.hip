@@ -48,6 +48,8 @@ int Problem::intern_loss(const LossFunction* l) {
 }
 }  // namespace sk
 
+namespace sk { int rotation_apply(int op, int row_major, int jet_dim, const double* in, int n, double* out); }
+
 extern "C" {
 
 const char* sk_version(void) { return "skeres_amd 0.1 (gfx950)"; }
@@ -76,6 +78,13 @@ int sk_ptrvec_size(const sk_ptrvec* v) { return (int)v->v.size(); }
 double* sk_ptrvec_get(const sk_ptrvec* v, int i) { return v->v[i]; }
 void sk_ptrvec_set(sk_ptrvec* v, int i, double* p) { v->v[i] = p; }
 double** sk_ptrvec_to_pointer_pointer(sk_ptrvec* v) { return v->v.empty() ? nullptr : v->v.data(); }
+
+// ---- Rotation ---------------------------------------------------------------------
+int sk_rotation_apply(int op, int row_major, int jet_dim, const double* in, int n, double* out) {
+  SK_GUARD_BEGIN
+  return sk::rotation_apply(op, row_major, jet_dim, in, n, out);
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
 
 // ---- LossFunction -----------------------------------------------------------------
 sk_loss_function* sk_loss_trivial(void) { return new (std::nothrow) sk_loss_function(); }

@@ -110,6 +110,16 @@ template <int N> SK_HD Jet<N> jexp(const Jet<N>& f) {
   for (int i = 0; i < N; ++i) h.v[i] = e * f.v[i];
   return h;
 }
+// atan2(y, x): d = (x dy - y dx) / (x^2 + y^2)
+template <int N> SK_HD Jet<N> jatan2(const Jet<N>& y, const Jet<N>& x) {
+  const double t = 1.0 / (x.a * x.a + y.a * y.a);
+  Jet<N> h; h.a = ::atan2(y.a, x.a);
+  const double cy = x.a * t, cx = -(y.a * t);
+#pragma unroll
+  for (int i = 0; i < N; ++i) h.v[i] = cx * x.v[i] + cy * y.v[i];
+  return h;
+}
+SK_HD double jatan2(double y, double x) { return ::atan2(y, x); }
 SK_HD double jsqrt(double x) { return ::sqrt(x); }
 SK_HD void jsincos(double x, double* s, double* c) { ::sincos(x, s, c); }
 SK_HD double jexp(double x) { return ::exp(x); }

@@ -229,7 +229,7 @@ void Summary::build_reports() {
            "\nSolver Summary (skeres_amd, MI355X-native Levenberg-Marquardt)\n\n"
            "Parameter blocks            % 12d\nParameters                  % 12d\nResidual blocks             % 12d\nResiduals                   % 12ld\n\n"
            "Minimizer                        TRUST_REGION\nTrust region strategy     LEVENBERG_MARQUARDT\n\n"
-           "Linear solver          % 22s\nDevice                 %s\nGPUs                        % 12d\n",
+           "Linear solver          %22s\nDevice                 %s\nGPUs                        % 12d\n",
            num_parameter_blocks, num_parameters, num_residual_blocks, num_residuals, linear_solver_name(linear_solver_type),
            device_name.c_str(), world);
   f += b;
@@ -242,7 +242,7 @@ void Summary::build_reports() {
            "Minimizer iterations        % 12d\nSuccessful steps            % 12d\nUnsuccessful steps          % 12d\n\n"
            "Device time (s):\n  Jacobian evaluation       % 12.6f\n  Linear solver assembly    % 12.6f\n  Linear solver factor      % 12.6f\n"
            "  Back-substitution         % 12.6f\n  Cost evaluation           % 12.6f\n  All-reduce                % 12.6f\nTotal wall time             % 12.6f\n\n"
-           "Termination:          % 22s (%s)\n",
+           "Termination:          %22s (%s)\n",
            initial_cost, final_cost, initial_cost - final_cost, iters, num_successful_steps, num_unsuccessful_steps, phase_seconds[0],
            phase_seconds[1], phase_seconds[2], phase_seconds[3], phase_seconds[4], phase_seconds[5], phase_seconds[6],
            termination_name(termination_type), message.c_str());

@@ -459,6 +459,56 @@ def test_dense_rows_medium_properties():
 # the reference's example programs, run end to end
 # ---------------------------------------------------------------------------
 # ---------------------------------------------------------------------------
+# Rotation: CORE/Rotation.scala on the device, pinned by the reference's RotationSpec
+# ---------------------------------------------------------------------------
+def test_reference_rotation_spec_on_the_device():
+    from rotation_spec import run_all
+    assert run_all(sk.rotation.apply)
+
+
+def test_rotation_device_vs_oracle_all_ops_doubles_and_jets():
+    rng = np.random.default_rng(8)
+    for op in range(14):
+        n_in = sk.rotation.IN_LEN[op]
+        for row_major in (False, True):
+            x = rng.uniform(-1, 1, (500, n_in))
+            if op in (2, 3):  # proper rotation matrices, covering every branch of the conversion
+                aa = rng.uniform(-1, 1, (500, 3)) * rng.uniform(0, np.pi, (500, 1)) * 1.7
+                x = oracle.rotation_apply(4, aa, row_major)
+            got = sk.rotation.apply(op, x, row_major)
+            np.testing.assert_allclose(got, oracle.rotation_apply(op, x, row_major), rtol=1e-13, atol=1e-14, err_msg="op %d" % op)
+            for K in (1, 3, 4):
+                xj = np.concatenate([x[:50, :, None], rng.uniform(-1, 1, (50, n_in, K))], axis=2)
+                np.testing.assert_allclose(sk.rotation.apply(op, xj, row_major, K), oracle.rotation_apply(op, xj, row_major, K),
+                                           rtol=1e-12, atol=1e-13, err_msg="op %d jets %d" % (op, K))
+
+
+def test_rotation_object_api():
+    R = sk.Rotation
+    q = R.angleAxisToQuaternion([np.pi / 2, 0, 0])
+    np.testing.assert_allclose(q.parts(), [np.sqrt(0.5), np.sqrt(0.5), 0, 0], atol=1e-15)
+    np.testing.assert_allclose(R.quaternionToAngleAxis(q), [np.pi / 2, 0, 0], atol=1e-15)
+    M = R.angleAxisToRotationMatrix([0, 0, np.pi / 3])
+    assert isinstance(M, sk.ColumnMajorMatrixAdapter3x3) and M(1, 0) == pytest.approx(np.sqrt(3) / 2)
+    np.testing.assert_allclose(R.rotationMatrixToAngleAxis(M), [0, 0, np.pi / 3], atol=1e-15)
+    np.testing.assert_allclose(R.rotationMatrixToAngleAxis(M.data), [0, 0, np.pi / 3], atol=1e-15)  # bare array: column major
+    E = R.eulerAnglesToRotationMatrix([0.0, 0.0, 90.0])
+    assert isinstance(E, sk.RowMajorMatrixAdapter3x3) and E(1, 0) == pytest.approx(1.0) and abs(E(0, 0)) < 1e-15
+    np.testing.assert_allclose(R.quaternionRotatePoint(sk.Quaternion(2, 0, 0, 0), [1, 2, 3]), [1, 2, 3], atol=1e-15)
+    np.testing.assert_allclose(R.crossProduct([1, 0, 0], [0, 1, 0]), [0, 0, 1])
+    assert R.dotProduct([1, 2, 3], [4, 5, 6]) == 32.0
+    np.testing.assert_allclose(R.angleAxisRotatePoint([0, 0, np.pi / 2], [1, 0, 0]), [0, 1, 0], atol=1e-15)
+    zw = R.quaternionProduct(sk.Quaternion(0, 1, 0, 0), sk.Quaternion(0, 0, 1, 0))
+    assert zw.parts() == [0, 0, 0, 1]  # i * j = k
+    with pytest.raises(ValueError, match="requirement failed"):
+        R.quaternionToRotation(sk.Quaternion(0, 0, 0, 0))
+    # with jets: d(quaternion)/d(angle-axis) at zero is 1/2 (RotationSpec.scala:498-509)
+    aa = [sk.Jet(0.0, k, dim=3) for k in range(3)]
+    qj = R.angleAxisToQuaternion(aa)
+    assert qj.r.real == 1.0 and list(qj.i.infinitesimal) == [0.5, 0, 0] and list(qj.k.infinitesimal) == [0, 0, 0.5]
+
+
+# ---------------------------------------------------------------------------
 # robust losses: PredefinedLossFunctions, ceres.i:159-184
 # ---------------------------------------------------------------------------
 LOSS_SPECS = [("huber", 1.3), ("softlone", 0.7), ("cauchy", 0.5), ("tukey", 2.0), ("tolerant", 1.5, 0.4),
