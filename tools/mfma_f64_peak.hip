@@ -28,8 +28,8 @@ __global__ void copy_kernel(const double2* __restrict__ in, double2* __restrict_
 }
 
 template <int NACC>
-static void run(int waves_per_simd, int iters) {
-  const int blocks = 256 * waves_per_simd;  // 256 threads = 4 waves = one per SIMD of a CU
+static void run(int waves_per_simd, int iters, int cus = 256) {
+  const int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD of a CU
   double* out;
   long long* clk;
   hipMalloc(&out, (size_t)blocks * 256 * sizeof(double));
@@ -51,14 +51,16 @@ static void run(int waves_per_simd, int iters) {
   long long h[2];
   hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
   const double mhz = 100.0 * (double)h[1] / (double)h[0];  // s_memtime ticks per 100 MHz wall-clock tick
-  printf("mfma_f64_16x16x4 acc=%d waves/SIMD=%d : %.3f ms  %.2f TFLOP/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz; shader clock counter %.0f MHz)\n", NACC,
-         waves_per_simd, best, flops / best * 1e-9, 2.4e9 * best * 1e-3 / ((double)iters * NACC * waves_per_simd), mhz);
+  printf("mfma_f64_16x16x4 acc=%d waves/SIMD=%d on %3d CUs: %.3f ms  %.2f TFLOP/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz; shader clock counter %.0f MHz)\n", NACC,
+         waves_per_simd, cus, best, flops / best * 1e-9, 2.4e9 * best * 1e-3 / ((double)iters * NACC * waves_per_simd), mhz);
   hipFree(clk);
   hipFree(out);
 }
 
 int main() {
   run<4>(1, 20000); run<8>(1, 10000); run<16>(1, 5000); run<8>(2, 10000); run<8>(4, 5000); run<4>(8, 5000);
+  // fewer busy CUs: is the per-SIMD rate a property of the pipe, or of the whole chip under load?
+  run<8>(2, 10000, 8); run<8>(2, 10000, 64); run<8>(2, 10000, 128); run<8>(1, 10000, 8);
   const size_t n = (size_t)1 << 28;  // 4 GiB in + 4 GiB out
   double2 *a, *b;
   hipMalloc(&a, n * sizeof(double2)); hipMalloc(&b, n * sizeof(double2));
