@@ -371,6 +371,57 @@ def test_bal_medium_properties_and_reproducibility():
     assert costs[0] == pytest.approx(s1.initialCost())
 
 
+def test_full_size_ladybug_1723_properties():
+    """BASELINE.json configs[1] at FULL size (C = 1723, P = 156 502, N = 678 718; reduced system n = 15 507):
+    the oracle needs ~28 s per iteration there, so parity is checked through size-independent properties."""
+    prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1))
+    x1, s1 = solve_bal_gpu(prob, setMaxNumIterations=6)
+    x2, s2 = solve_bal_gpu(prob, setMaxNumIterations=6)
+    assert np.array_equal(x1, x2)  # bit-identical reruns: one writer per Schur block, fixed reduction orders, no atomics
+    its = s1.iterations()
+    assert [a["cost"] for a in its] == [b["cost"] for b in s2.iterations()]
+    succ = [it for it in its if it["step_is_successful"]]
+    assert len(succ) >= 4 and all(b["cost"] < a["cost"] for a, b in zip(succ, succ[1:]))
+    assert s1.finalCost() < 1e-3 * s1.initialCost()
+    # the reported costs are the oracle's evaluation of the same parameters (start and end)
+    for x, c_gpu in ((prob.parameters, s1.initialCost()), (x1, s1.finalCost())):
+        _, _, _, c = oracle.bal_evaluate(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index,
+                                         prob.observations, x, jacobians=False)
+        assert abs(c - c_gpu) <= 1e-10 * c
+    # an accepted step's actual decrease agrees with the model's in sign and is bounded by it near convergence
+    assert all(it["relative_decrease"] > 1e-3 for it in succ[1:])
+
+
+def test_full_size_venice_1778_properties():
+    """BASELINE.json's largest bundle-adjustment configuration at FULL size (C = 1778, P = 993 923, N = 5 001 946)."""
+    prob = bal.generate_named("venice-1778-993923", seed=1778, perturb=(1e-2, 1e-1, 1e-1))
+    x1, s1 = solve_bal_gpu(prob, setMaxNumIterations=4)
+    x2, s2 = solve_bal_gpu(prob, setMaxNumIterations=4)
+    assert np.array_equal(x1, x2)
+    succ = [it for it in s1.iterations() if it["step_is_successful"]]
+    assert len(succ) >= 3 and all(b["cost"] < a["cost"] for a, b in zip(succ, succ[1:]))
+    _, _, _, c = oracle.bal_evaluate(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index,
+                                     prob.observations, x1, jacobians=False)
+    assert abs(c - s1.finalCost()) <= 1e-10 * c
+
+
+def test_full_size_cholesky_15507_residual():
+    """The dense fp64 MFMA Cholesky at the reduced-system size of Ladybug-1723, look-ahead path: solve A x = b and
+    check the residual and a sample of L L^T = A in numpy."""
+    n = 15507
+    rng = np.random.default_rng(15507)
+    U = rng.normal(size=(n, 48))
+    A = U @ U.T
+    A[np.arange(n), np.arange(n)] += 10.0 + rng.uniform(0, 5, n)
+    b = rng.normal(size=n)
+    x, L = sk.api.cholesky_solve(A, b, want_L=True)
+    r = A @ x - b
+    assert np.linalg.norm(r) <= 1e-10 * np.linalg.norm(b)  # cond(A) ~ 1e3: backward error at fp64 level
+    for i in rng.choice(n, 40, replace=False):
+        np.testing.assert_allclose((L[i] @ L.T)[: i + 1], A[i, : i + 1], rtol=0, atol=1e-10 * A[i, i])
+    assert np.all(np.diag(L)[::500] > 0) and np.all(np.triu(L[:200, :200], 1) == 0)
+
+
 # ---------------------------------------------------------------------------
 # the multi-GPU code path, exercised on ONE GPU: RCCL process group of size 1
 # ---------------------------------------------------------------------------
