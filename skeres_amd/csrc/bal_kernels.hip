@@ -377,35 +377,75 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
   }
 }
 
-// Off-diagonal blocks.  The (row camera i > col camera j) pairs that share at
-// least one point are listed once at setup, sorted by (i, j); segment s owns
-// block (i, j) and sums its entries IN LIST ORDER (ascending point):
-//   S_ij = - sum_e What[obs_row(e)] What[obs_col(e)]^T
-// Nine lanes per block, lane c owns row c of the 9x9 block; 7 blocks per wave.
-// No atomics: every block has exactly one writer, so results are reproducible.
+// acc[k] += sum over entries e = e_begin, e_begin + stride, ... < e_end of  What[row obs][3c..3c+2] . What[col obs][3k..3k+2].
+// The indices of the next entry are fetched while the current one is being multiplied (one memory latency per
+// entry on the dependent chain instead of two).
+__device__ __forceinline__ void pair_accumulate(const BalDev& d, int e_begin, int e_end, int stride, int c, double (&acc)[9]) {
+  if (e_begin >= e_end) return;
+  int ob = d.pair_row_obs[e_begin], oa = d.pair_col_obs[e_begin];
+  for (int e = e_begin; e < e_end; e += stride) {
+    const int en = e + stride < e_end ? e + stride : e;
+    const int ob_next = d.pair_row_obs[en], oa_next = d.pair_col_obs[en];
+    const double* wr = d.What + (size_t)ob * kWs + 3 * c;
+    // the same 27 values for the nine lanes of a block: one 224-byte record, fetched as fourteen 16-byte loads
+    const double2* wc2 = reinterpret_cast<const double2*>(d.What + (size_t)oa * kWs);
+    double wc[kWs];
+#pragma unroll
+    for (int k = 0; k < kWs / 2; ++k) { const double2 v = wc2[k]; wc[2 * k] = v.x; wc[2 * k + 1] = v.y; }
+    const double y0 = wr[0], y1 = wr[1], y2 = wr[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] += y0 * wc[3 * k] + y1 * wc[3 * k + 1] + y2 * wc[3 * k + 2];
+    ob = ob_next; oa = oa_next;
+  }
+}
+
+// Short segments: seven per wave, nine lanes each, entries in list order.
 __global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int sub = lane / 9, c = lane - 9 * sub;
-  const int seg = wave * 7 + sub;
-  if (sub >= 7 || seg >= d.num_segments) return;
-  const size_t N = d.N;
+  const int slot = wave * 7 + sub;
+  if (sub >= 7 || slot >= d.num_short_segments) return;
+  const int seg = d.short_segments[slot];
   double acc[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-  const int e0 = d.seg_start[seg], e1 = d.seg_start[seg + 1];
-  for (int e = e0; e < e1; ++e) {
-    const int ob = d.pair_row_obs[e], oa = d.pair_col_obs[e];
-    const double* wr = d.What + (size_t)ob * kWs + 3 * c;
-    const double* wc = d.What + (size_t)oa * kWs;  // the same 27 values for the nine lanes of a block: one 216-byte run
-    const double y0 = wr[0], y1 = wr[1], y2 = wr[2];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] += y0 * wc[3 * k] + y1 * wc[3 * k + 1] + y2 * wc[3 * k + 2];
-  }
+  pair_accumulate(d, d.seg_start[seg], d.seg_start[seg + 1], 1, c, acc);
   const int i = d.seg_row[seg], j = d.seg_col[seg];
   double* out = d.S + (size_t)(9 * i + c) * d.ld + 9 * j;
 #pragma unroll
   for (int k = 0; k < 9; ++k) out[k] = -acc[k];
+}
+
+// Long segments (camera pairs that share many points; a few per cent of the segments, most of the entries):
+// one wave per segment.  The seven nine-lane groups take every seventh entry; their partial blocks are summed
+// in group order through LDS, so the result does not depend on timing (but the summation order differs from
+// the short-segment kernel's list order: which kernel a segment goes to is fixed at set-up).
+__global__ __launch_bounds__(kBlock) void bal_pair_long_kernel(BalDev d) {
+  __shared__ double red[kBlock / 64][7][81];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int slot = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  if (slot >= d.num_long_segments) return;  // wave-uniform
+  const int seg = d.long_segments[slot];
+  const int sub = lane / 9, c = lane - 9 * sub;
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  if (sub < 7) {
+    pair_accumulate(d, d.seg_start[seg] + sub, d.seg_start[seg + 1], 7, c, acc);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[w][sub][9 * c + k] = acc[k];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+  const int i = d.seg_row[seg], j = d.seg_col[seg];
+  for (int e = lane; e < 81; e += 64) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 7; ++g) s += red[w][g][e];
+    d.S[(size_t)(9 * i + e / 9) * d.ld + 9 * j + e % 9] = -s;
+  }
 }
 
 // After the (optional) all-reduce: add D_c^2 on the diagonal, make the padded
@@ -542,9 +582,12 @@ void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLa
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_pair(const BalDev& d, hipStream_t s) {
-  if (d.num_segments <= 0) return;
-  const int waves = (d.num_segments + 6) / 7;
-  hipLaunchKernelGGL(bal_pair_kernel, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
+  if (d.num_long_segments > 0)  // first: the long ones take longest
+    hipLaunchKernelGGL(bal_pair_long_kernel, dim3((d.num_long_segments * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
+  if (d.num_short_segments > 0) {
+    const int waves = (d.num_short_segments + 6) / 7;
+    hipLaunchKernelGGL(bal_pair_kernel, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
+  }
 }
 void launch_bal_finish_S(double* S, int ld, int n, int npad, int rhs_row, const double* D_c, hipStream_t s) { hipLaunchKernelGGL(bal_finish_S_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, n, npad, rhs_row, D_c); }
 int launch_bal_point_backsub(const BalDev& d, hipStream_t s) {

@@ -7,6 +7,7 @@
 
 namespace sk {
 
+constexpr int kLongSegment = 32;  // entries from which a camera pair gets a wave of its own (bal_pair_long_kernel)
 constexpr int kWs = 28;  // doubles per observation record of What (27 used; 224 bytes keeps records 32-byte aligned)
 struct BalDev {
   int C, P, N;            // cameras (all, replicated), LOCAL points, LOCAL observations
@@ -22,6 +23,9 @@ struct BalDev {
   const int* seg_start;   // [num_segments+1]
   const int* seg_row;     // [num_segments] row camera i
   const int* seg_col;     // [num_segments] col camera j (< i)
+  int num_short_segments, num_long_segments;  // segments with fewer / at least kLongSegment entries
+  const int* short_segments;  // [num_short_segments] segment ids
+  const int* long_segments;   // [num_long_segments]
   const int* pair_row_obs;  // [num_pairs] observation of camera i
   const int* pair_col_obs;  // [num_pairs] observation of camera j
   // state

@@ -100,7 +100,7 @@ class BalSolver : public SolverBase {
   std::vector<int> local_pt_;                 // global point id of local point
   BalDev d_{};
   DevBuf<LossNode> b_loss_nodes_;
-  DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_fail_, b_info_;
+  DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_, b_fail_, b_info_;
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   DevBuf<double> b_w_, b_pack_;
@@ -236,6 +236,12 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_pt_start_.upload(pt_start, s)); SK_HIP_TRY(b_cam_start_.upload(cam_start, s)); SK_HIP_TRY(b_cam_obs_.upload(cam_obs, s));
   SK_HIP_TRY(b_seg_start_.upload(seg_start, s)); SK_HIP_TRY(b_seg_row_.upload(seg_row, s)); SK_HIP_TRY(b_seg_col_.upload(seg_col, s));
   SK_HIP_TRY(b_pair_row_.upload(pair_row, s)); SK_HIP_TRY(b_pair_col_.upload(pair_col, s));
+  std::vector<int> short_segs, long_segs;
+  for (int g = 0; g < (int)seg_row.size(); ++g) (seg_start[g + 1] - seg_start[g] >= kLongSegment ? long_segs : short_segs).push_back(g);
+  // longest first: the last waves of the launch are the short ones
+  std::stable_sort(long_segs.begin(), long_segs.end(), [&](int a, int b) { return seg_start[a + 1] - seg_start[a] > seg_start[b + 1] - seg_start[b]; });
+  SK_HIP_TRY(b_short_segs_.upload(short_segs, s)); SK_HIP_TRY(b_long_segs_.upload(long_segs, s));
+  d_.num_short_segments = (int)short_segs.size(); d_.num_long_segments = (int)long_segs.size();
   const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_, nx = nc + np;
   std::vector<double> x(nx);
   for (int i = 0; i < C_; ++i) std::memcpy(&x[9 * (size_t)i], p.block_ptr[cam_block_[i]], 9 * sizeof(double));
@@ -265,6 +271,7 @@ int BalSolver::setup() {
   d_.C = C_; d_.P = P_; d_.N = N_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p;
   d_.num_segments = (int)seg_row.size(); d_.seg_start = b_seg_start_.p; d_.seg_row = b_seg_row_.p; d_.seg_col = b_seg_col_.p;
+  d_.short_segments = b_short_segs_.p; d_.long_segments = b_long_segs_.p;
   d_.pair_row_obs = b_pair_row_.p; d_.pair_col_obs = b_pair_col_.p;
   d_.xc = b_xc_.p; d_.xp = b_xc_.p + nc; d_.xc_new = b_xc_new_.p; d_.xp_new = b_xc_new_.p + nc;
   d_.scale_c = b_scale_.p; d_.scale_p = b_scale_.p + nc; d_.colsq_c = b_colsq_.p; d_.colsq_p = b_colsq_.p + nc;
