@@ -131,7 +131,7 @@ int BalSolver::choose_distribution(const std::vector<int>& opt) {
     for (int v : opt) k[v]++;
     double pairs = 0.0;
     for (size_t v : k) pairs += 0.5 * (double)v * (double)(v - 1);
-    const double per_iter = 0.45e-9 * pairs + 1.9e-9 * (double)opt.size();  // seconds on one MI355X
+    const double per_iter = 0.15e-9 * pairs + 1.9e-9 * (double)opt.size();  // seconds on one MI355X (profiles/r01_d_*)
     est_saved_s_ = per_iter * (1.0 - 1.0 / W);
     int rc = allreduce(b_pack_.p, packed_elems_);  // first call: connection set-up, not timed
     if (rc) return rc;
