@@ -256,6 +256,11 @@ int sk_options_set_stream(sk_options* o, void* hip_stream);           /* default
  * runs the serial diagonal-block factorisation on a second stream next to the
  * block-column update / trailing SYRK that does not depend on it. */
 int sk_options_set_cholesky_tuning(sk_options* o, int group, int lookahead);
+/* DENSE_SCHUR: the reduced camera system of a bundle-adjustment problem is block-banded (cameras that share no
+ * point give a zero block, and the Cholesky factor keeps the block envelope).  on != 0 (default): the dense
+ * factorisation touches only the 128-blocks inside the envelope; the blocks it leaves out are exact zeros in the
+ * full computation too, so the result is bit-identical to on == 0, which factors every block. */
+int sk_options_set_cholesky_envelope(sk_options* o, int on);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,
  * one per GPU.  Points (e-blocks) are partitioned over ranks; the
  * normal-equation terms are summed with `allreduce` once per linear solve.

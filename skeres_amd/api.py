@@ -121,6 +121,7 @@ _SIGS = {
     "sk_solver_syrk_flops_per_solve": (C.c_double, [C.c_void_p]),
     "sk_solver_distribution": (C.c_int, [C.c_void_p, _dp, _dp]),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
     "sk_synth_dense_targets": (C.c_int, [C.c_double, C.c_int, C.c_int, _dp, _dp]),
     "sk_problem_point_partition": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip]),
@@ -807,6 +808,10 @@ class Solver:
             cb = ALLREDUCE_FN(tramp)
             self._keep.append(cb)
             _check(lib().sk_options_set_distributed(self._h, int(rank), int(world), cb, None))
+
+        def setCholeskyEnvelope(self, on):
+            """DENSE_SCHUR: factor only the blocks inside the reduced system's block envelope (default on; bit-identical)."""
+            _check(lib().sk_options_set_cholesky_envelope(self._h, int(bool(on))))
 
         def setDistributionMode(self, mode):
             """0 auto (default), 1 sharded, 2 replicated: what a world > 1 does (include/skeres_amd.h)."""

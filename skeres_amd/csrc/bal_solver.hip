@@ -70,7 +70,7 @@ namespace {
 class BalSolver : public SolverBase {
  public:
   BalSolver(const Options& o, Problem* p) : SolverBase(o, p) {}
-  double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, opt_.cholesky_group); }
+  double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, opt_.cholesky_group, env_last_.empty() ? nullptr : env_last_.data()); }
   int distribution(double* allreduce_s, double* saved_s) const override {
     if (allreduce_s) *allreduce_s = est_allreduce_s_;
     if (saved_s) *saved_s = est_saved_s_;
@@ -103,6 +103,7 @@ class BalSolver : public SolverBase {
   DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_, b_fail_, b_info_;
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
+  std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
   DevBuf<double> b_w_, b_pack_;
   size_t packed_elems_ = 0;
   int distribution_ = SK_DISTRIBUTION_SHARDED;
@@ -114,6 +115,73 @@ class BalSolver : public SolverBase {
  public:
   ~BalSolver() override { if (h_scal_) (void)hipHostFree(h_scal_); }
 };
+
+// ---- camera ordering for the reduced system --------------------------------------------------------------
+// The order of the cameras inside S is the solver's to choose (Ceres, too, orders the blocks of the reduced
+// system itself).  A block-banded S factors in a fraction of the flops of a full one (cholesky_factor's
+// envelope), and whether S is banded depends on that order alone.  Candidates: first appearance in the residual
+// blocks (what bal_index_problem yields), memory order of the camera blocks (the BAL file's numbering when the
+// caller uses the reference's layout, EX/SimpleBundleAdjuster.scala:18-34), and reverse Cuthill-McKee on the
+// co-visibility graph.  The one with the fewest trailing-update flops wins; ties keep the earlier candidate.
+static std::vector<int> envelope_of_order(const std::vector<int>& ocam, const std::vector<int>& opt, const std::vector<int>& new_id, int C, int P,
+                                          int nblk) {
+  std::vector<int> cmin(P, C);
+  for (size_t b = 0; b < ocam.size(); ++b) cmin[opt[b]] = std::min(cmin[opt[b]], new_id[ocam[b]]);
+  std::vector<int> first_col(nblk);
+  for (int i = 0; i < nblk; ++i) first_col[i] = i;
+  for (size_t b = 0; b < ocam.size(); ++b) {  // camera c shares point opt[b] with camera cmin: block (rows of c, columns of cmin)
+    const int c = new_id[ocam[b]], col = (9 * cmin[opt[b]]) / 128;
+    for (int row = (9 * c) / 128; row <= (9 * c + 8) / 128; ++row) first_col[row] = std::min(first_col[row], col);
+  }
+  return cholesky_envelope_last(first_col);
+}
+
+static std::vector<int> rcm_order(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P) {
+  // co-visibility graph, thinned: the cameras of a point are chained in index order and the ends joined
+  std::vector<std::vector<int>> of_point(P);
+  for (size_t b = 0; b < ocam.size(); ++b) of_point[opt[b]].push_back(ocam[b]);
+  std::vector<std::pair<int, int>> edges;
+  for (auto& v : of_point) {
+    std::sort(v.begin(), v.end());
+    for (size_t i = 0; i + 1 < v.size(); ++i) edges.emplace_back(v[i], v[i + 1]);
+    if (v.size() > 2) edges.emplace_back(v.front(), v.back());
+  }
+  std::sort(edges.begin(), edges.end());
+  edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+  std::vector<std::vector<int>> adj(C);
+  for (auto& e : edges) if (e.first != e.second) { adj[e.first].push_back(e.second); adj[e.second].push_back(e.first); }
+  for (auto& a : adj) std::sort(a.begin(), a.end(), [&](int x, int y) { return adj[x].size() != adj[y].size() ? adj[x].size() < adj[y].size() : x < y; });
+  std::vector<int> order, level(C, -1);
+  order.reserve(C);
+  auto bfs = [&](int root, std::vector<int>* out) {  // Cuthill-McKee sweep of root's component (unvisited part); returns the last vertex
+    const size_t begin = out->size();
+    out->push_back(root); level[root] = 0;
+    for (size_t h = begin; h < out->size(); ++h) {
+      const int u = (*out)[h];
+      for (int v : adj[u]) if (level[v] < 0) { level[v] = level[u] + 1; out->push_back(v); }
+    }
+    return out->back();
+  };
+  std::vector<char> done(C, 0);
+  for (int seed = 0; seed < C; ++seed) {
+    if (done[seed]) continue;
+    // pseudo-peripheral start: two sweeps, each restarting from the far end of the previous one
+    int root = seed;
+    for (int rep = 0; rep < 2; ++rep) {
+      std::vector<int> tmp;
+      const int far = bfs(root, &tmp);
+      for (int v : tmp) level[v] = -1;
+      root = far;
+    }
+    const size_t begin = order.size();
+    bfs(root, &order);
+    for (size_t h = begin; h < order.size(); ++h) done[order[h]] = 1;
+  }
+  std::reverse(order.begin(), order.end());
+  std::vector<int> new_id(C);
+  for (int k = 0; k < C; ++k) new_id[order[k]] = k;
+  return new_id;
+}
 
 // Sharding the points pays when the per-iteration work it removes from a rank (evaluation, Schur
 // assembly, back-substitution: linear in observations and pair entries) exceeds the all-reduce of the
@@ -164,6 +232,36 @@ int BalSolver::setup() {
   bal_index_problem(p, &cam_block_, &pt_block_, &ocam, &opt);
   C_ = (int)cam_block_.size(); P_total_ = (int)pt_block_.size();
   n_ = 9 * C_; rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
+  // ---- camera order + block envelope of the reduced system (all ranks' observations: the all-reduced S has the union structure).
+  // The order is chosen the same way whether or not the envelope is then used (opt_.envelope), so that the two
+  // settings differ in nothing but the blocks they skip and give bit-identical results. ----
+  {
+    const int nblk = npad_ / 128;
+    std::vector<std::vector<int>> cand;
+    { std::vector<int> id(C_); std::iota(id.begin(), id.end(), 0); cand.push_back(id); }  // first appearance
+    { std::vector<int> by_addr(C_); std::iota(by_addr.begin(), by_addr.end(), 0);
+      std::sort(by_addr.begin(), by_addr.end(), [&](int a, int b) { return p.block_ptr[cam_block_[a]] < p.block_ptr[cam_block_[b]]; });
+      std::vector<int> id(C_); for (int k = 0; k < C_; ++k) id[by_addr[k]] = k; cand.push_back(id); }
+    cand.push_back(rcm_order(ocam, opt, C_, P_total_));
+    double best = -1.0; int best_k = 0; std::vector<int> best_env;
+    for (size_t k = 0; k < cand.size(); ++k) {
+      std::vector<int> env = envelope_of_order(ocam, opt, cand[k], C_, P_total_, nblk);
+      const double f = cholesky_syrk_flops(npad_, opt_.cholesky_group, env.data());
+      if (best < 0.0 || f < best * (1.0 - 1e-9)) { best = f; best_k = (int)k; best_env.swap(env); }
+    }
+    const std::vector<int>& id = cand[best_k];
+    std::vector<int> cb(C_);
+    for (int c = 0; c < C_; ++c) cb[id[c]] = cam_block_[c];
+    cam_block_.swap(cb);
+    for (int& c : ocam) c = id[c];
+    if (opt_.envelope) env_last_.swap(best_env);
+    if (getenv("SK_DEBUG_ENVELOPE") && opt_.envelope) {
+      long h = 0;
+      for (int c = 0; c < nblk; ++c) h += env_last_[c] - c;
+      std::fprintf(stderr, "[skeres_amd] camera order %d (0 first appearance, 1 memory, 2 RCM); envelope: %d block columns, mean height %.1f; "
+                   "trailing-update flops %.3e (full %.3e)\n", best_k, nblk, (double)h / nblk, best, cholesky_syrk_flops(npad_, opt_.cholesky_group, nullptr));
+    }
+  }
   // ---- multi-GPU: shard the points, or replicate? ----
   packed_elems_ = tri_packed_elems(npad_ / 128);
   if (opt_.allreduce) {
@@ -378,8 +476,9 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
   launch_bal_finish_S(b_S_.p, npad_, n_, npad_, rhs_row_, d_.D_c, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
-  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.cholesky_group, s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_);
-  cholesky_backsolve(b_S_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_);
+  const int* env = env_last_.empty() ? nullptr : env_last_.data();
+  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.cholesky_group, s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_, env);
+  cholesky_backsolve(b_S_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_, env);
   SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----
   launch_bal_cam_step(d_, b_scal_.p + 8, s);

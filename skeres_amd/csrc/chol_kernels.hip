@@ -44,9 +44,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // skip  : kShape 0: bit 0 drops tiles whose 128-block row is above their 128-block column, bit 1
 //         drops the tiles of 128-block (0, 0), bit 2 drops tiles entirely above the diagonal.
 //         kShape 1: first tile of the slice.
+// main_t, jump_t: the tile rows (kShape 1: and tile columns) of the launch are the first main_t consecutive
+//         ones, then rows jump_t tiles further down (units of kTM rows): the active rows of an envelope
+//         factorisation are a contiguous run plus the last block row, which carries the right-hand side.
 template <int kMode, int kShape, int kBKT, int kPF, int kTM, int kTN>
 __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
-                                                 int tiles_m, int skip) {
+                                                 int tiles_m, int skip, int main_t = 0x7fffffff, int jump_t = 0) {
   constexpr int mode = kMode;
   constexpr int kLdT = kBKT + 2;            // LDS row stride in doubles
   constexpr int kChA = kTM * kBKT / 512;    // 16-byte chunks per thread and stage, A operand
@@ -62,8 +65,11 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
     while ((r + 1) * (r + 2) / 2 <= b) ++r;
     while (r * (r + 1) / 2 > b) --r;
     ti = r; tj = b - r * (r + 1) / 2;
+    if (ti >= main_t) ti += jump_t;
+    if (tj >= main_t) tj += jump_t;
   } else {
     ti = blockIdx.x % tiles_m; tj = blockIdx.x / tiles_m;
+    if (ti >= main_t) ti += jump_t;
     const int bi = ti * kTM / 128, bj = tj * kTN / 128;
     if ((skip & 1) && bi < bj) return;
     if ((skip & 2) && bi == 0 && bj == 0) return;
@@ -168,8 +174,9 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
 // The three uses get their own kernel symbols so profiles separate them.
 // Trailing SYRK of the blocked Cholesky (the dominant kernel): lower-triangular tiles, C -= A A^T.
 // Launched in slices of the tile enumeration [tile_off, tile_off + gridDim.x).
-__global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tile_off) {
-  gemm_nt_f64_body<0, 1, 16, 1, 128, 128>(C, ldc, A, lda, A, lda, K, 0, tile_off);
+__global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tile_off, int main_t,
+                                                                   int jump_t) {
+  gemm_nt_f64_body<0, 1, 16, 1, 128, 128>(C, ldc, A, lda, A, lda, K, 0, tile_off, main_t, jump_t);
 }
 // Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
 // transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
@@ -196,9 +203,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ H
 // Panel updates (lazy left-looking update of a block column; look-ahead part of the SYRK): C -= A B^T,
 // 64 x 128 tiles (tiles_m counts 64-row tiles), two workgroups per CU.
 __global__ __launch_bounds__(256, 2) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
-                                                                 long ldb, int K, int tiles_m, int skip) {
+                                                                 long ldb, int K, int tiles_m, int skip, int main_t, int jump_t) {
   __builtin_amdgcn_s_setprio(2);  // on the critical path of the factorisation
-  gemm_nt_f64_body<0, 0, 16, 2, 64, 128>(C, ldc, A, lda, B, ldb, K, tiles_m, skip);
+  gemm_nt_f64_body<0, 0, 16, 2, 64, 128>(C, ldc, A, lda, B, ldb, K, tiles_m, skip, main_t, jump_t);
 }
 // One 128 x 128 diagonal block, C -= A A^T, as 64 x 64 tiles (the upper one skipped): potrf128 waits on it.
 __global__ __launch_bounds__(256, 1) void gemm_diag_f64_kernel(double* C, long ldc, const double* A, long lda, int K) {
@@ -207,9 +214,9 @@ __global__ __launch_bounds__(256, 1) void gemm_diag_f64_kernel(double* C, long l
 }
 // TRSM as a GEMM with the inverted diagonal block: C = A Linv^T (in place, C == A); 64 x 128 tiles.
 __global__ __launch_bounds__(256, 2) void trsm_gemm_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
-                                                               int tiles_m) {
+                                                               int tiles_m, int main_t, int jump_t) {
   __builtin_amdgcn_s_setprio(2);
-  gemm_nt_f64_body<1, 0, 16, 2, 64, 128>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0);
+  gemm_nt_f64_body<1, 0, 16, 2, 64, 128>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0, main_t, jump_t);
 }
 
 // ---------------------------------------------------------------------------
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 // 1024 threads so that each lane has only a few dependent HBM/L2 round trips.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict__ Linv, const double* __restrict__ Lrow, long ld,
-                                                        double* __restrict__ w, double* __restrict__ yout, int kb, int ncols) {
+                                                        double* __restrict__ w, double* __restrict__ yout, int kb, int col0, int ncols) {
   __shared__ double wk[128], ykb[128], part[8][128];
   const int t = threadIdx.x;
   if (t < 128) wk[t] = w[kb * 128 + t];
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict_
   // 64 columns per workgroup (512-B row segments), 16 row groups of 8 rows: four times the workgroups of
   // a 256-column split — the grid is what limits this HBM-bound phase (<= 244 workgroups on 256 CUs)
   const int cl = t & 63, rg = t >> 6;
-  const int col = blockIdx.x * 64 + cl;
+  const int col = col0 + blockIdx.x * 64 + cl;  // columns left of col0 are structurally zero in this block row
   double s = 0.0;
   if (col < ncols) {
     const double* p = Lrow + (long)(rg * 8) * ld + col;
@@ -789,8 +796,14 @@ std::vector<int> cholesky_group_bounds(int nblk, int group) {
 // of the two, which it is for the first half of the groups (87 % of the flops).  The bulk stream's CU
 // mask keeps a few CUs per XCD free: without them the panel kernels sit behind the SYRK's
 // workgroups in the dispatcher and nothing overlaps (measured).
+// `last` (optional, nblk entries): the block envelope of the matrix.  last[c] >= c is the last block row, among
+// rows 0 .. nblk-2, in which block column c of the FACTOR can be non-zero (non-decreasing in c); the final block
+// row nblk-1, which carries the right-hand side, is always active.  Every launch then covers the active rows only:
+// a contiguous run plus that last row (main_t / jump_t of the GEMM body).  Blocks outside are exact zeros in the
+// dense algorithm too (0 - 0 * x), so the result is bit-identical to last == nullptr; only the work differs
+// (Ladybug-1723-shaped S: 0.17 of 1.27 TFlop).
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt) {
+                     KernelTimer* kt, const int* last) {
   const int nblk = npad / 128;
   const bool la = ctx != nullptr && ctx->panel != nullptr && ctx->bulk != nullptr;
   hipStream_t sp = la ? ctx->panel : s;
@@ -803,11 +816,23 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     (void)hipEventRecord(e, from);
     (void)hipStreamWaitEvent(to, e, 0);
   };
-  // C[tiles_m x tiles_n tiles of 128] -= A B^T
-  auto update = [&](hipStream_t st, const char* name, double* C, const double* A, const double* B, int K, int tiles_m, int tiles_n, int flags) {
+  // last active main row of block column c, and whether block row nblk-1 comes on top of the run that ends there
+  auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
+  struct Rows { int main, extra, jump; };  // `main` consecutive block rows from `first_row`, then `extra` (0/1) row nblk-1, `jump` blocks further
+  auto rows_from = [&](int first_row, int last_row) {
+    Rows r;
+    r.main = last_row >= first_row ? last_row - first_row + 1 : 0;
+    r.extra = (first_row + r.main <= nblk - 1 && last_row < nblk - 1) ? 1 : 0;
+    r.jump = r.extra ? (nblk - 1) - (first_row + r.main) : 0;
+    return r;
+  };
+  // C[rows x tiles_n tiles of 128] -= A B^T; rows as above, 64-row tiles
+  auto update = [&](hipStream_t st, const char* name, double* C, const double* A, const double* B, int K, Rows r, int tiles_n, int flags) {
+    const int tiles_m = r.main + r.extra;
     if (tiles_m <= 0 || tiles_n <= 0) return;
     if (kt) kt->begin(name, st);
-    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(2 * tiles_m * tiles_n), dim3(256), 0, st, C, ld, A, ld, B, ld, K, 2 * tiles_m, flags);
+    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(2 * tiles_m * tiles_n), dim3(256), 0, st, C, ld, A, ld, B, ld, K, 2 * tiles_m, flags, 2 * r.main,
+                       2 * r.jump);
     if (kt) kt->end(name, st);
   };
   // one diagonal 128-block: C -= A A^T
@@ -819,18 +844,19 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   auto panel = [&](int k0, int k1) {
     for (int kb = k0; kb < k1; ++kb) {
       double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
-      const int rows_below = nblk - kb - 1;
+      const Rows below = rows_from(kb + 1, last_main(kb));
       const double* P = S + (long)kb * 128 * ld + (long)k0 * 128;
       const int K = (kb - k0) * 128;
       if (kb > k0) update_diag(sp, "gemm_diag_update", Akk, P, K);  // lazy left-looking update from columns [k0, kb): diagonal tile ...
       if (kt) kt->begin("potrf128", sp);
       hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
       if (kt) kt->end("potrf128", sp);
-      if (rows_below > 0) {
+      if (below.main + below.extra > 0) {
         double* A21 = Akk + 128 * ld;
-        if (kb > k0) update(sp, "gemm_panel_update", A21, P + 128 * ld, P, K, rows_below, 1, 0);  // ... and the rows below it
+        if (kb > k0) update(sp, "gemm_panel_update", A21, P + 128 * ld, P, K, below, 1, 0);  // ... and the rows below it
         if (kt) kt->begin("gemm_trsm", sp);
-        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(2 * rows_below), dim3(256), 0, sp, A21, ld, A21, ld, Linv + (long)kb * 128 * 128, 2 * rows_below);
+        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(2 * (below.main + below.extra)), dim3(256), 0, sp, A21, ld, A21, ld, Linv + (long)kb * 128 * 128,
+                           2 * (below.main + below.extra), 2 * below.main, 2 * below.jump);
         if (kt) kt->end("gemm_trsm", sp);
       }
     }
@@ -843,26 +869,28 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
   for (int g = 0; g + 1 < ngroups; ++g) {
     const int k0 = gb[g], k1 = gb[g + 1];
-    const int T = nblk - k1;  // trailing tile rows
     const int K = (k1 - k0) * 128;
     const int na = gb[g + 2] - k1;  // tile columns of the next group
+    const int Lg = last_main(k1 - 1);  // rows below Lg (other than nblk-1) are zero in every column of this group
+    const Rows rn = rows_from(k1, Lg);       // rows that next(g) updates
+    const Rows rs = rows_from(k1 + na, Lg);  // rows (and columns) that syrk(g) updates
     double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
-    if (la) sb = T >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
+    const int Tb = rs.main + rs.extra;
+    if (la) sb = Tb >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
     if (sb != sb_prev && syrk_done) (void)hipStreamWaitEvent(sb, syrk_done, 0);  // syrk(g) after syrk(g-1) across the two bulk streams
     sb_prev = sb;
     order(sp, sb);  // panel(g) is final: syrk(g) may start (after syrk(g-1))
-    // next(g): T x na tiles, above-diagonal tiles skipped; on the panel stream, after syrk(g-1)
+    // next(g): active rows x na tiles, above-diagonal tiles skipped; on the panel stream, after syrk(g-1)
     if (la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
-    update(sp, "gemm_syrk_next", A22, P, P, K, T, na, 1);
-    // syrk(g): everything right of them, lower triangle of the (T-na) x (T-na) tiles
-    const int Tb = T - na;
+    update(sp, "gemm_syrk_next", A22, P, P, K, rn, na, 1);
+    // syrk(g): everything right of them, lower triangle over the active rows
     syrk_done = nullptr;
     if (Tb > 0) {
       double* Cb = S + (long)(k1 + na) * 128 * ld + (long)(k1 + na) * 128;
       const double* Pb = S + (long)(k1 + na) * 128 * ld + (long)k0 * 128;
       if (kt) kt->begin("gemm_syrk", sb);
-      hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, Cb, ld, Pb, ld, K, 0);
+      hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
       if (kt) kt->end("gemm_syrk", sb);
       if (la) { syrk_done = ctx->event(ev++); (void)hipEventRecord(syrk_done, sb); }
     }
@@ -873,15 +901,23 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
 }
 
 // y (npad) <- solution of L^T y = z, with z^T = row rhs_row of L (first n entries).  w: scratch (npad).
+// With an envelope, block row kb of L is zero left of the first block column c with last[c] >= kb.
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt) {
+                        hipStream_t s, KernelTimer* kt, const int* last) {
   const int nblk = npad / 128;
   hipLaunchKernelGGL(copy_row_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, n, npad);
   if (kt) kt->begin("backsolve", s);
+  int c0 = 0;
+  std::vector<int> first(nblk, 0);
+  if (last)
+    for (int kb = 0; kb < nblk - 1; ++kb) {  // last is non-decreasing: one sweep
+      while (c0 < kb && last[c0] < kb) ++c0;
+      first[kb] = c0;
+    }
   for (int kb = nblk - 1; kb >= 0; --kb) {
-    const int ncols = kb * 128;
-    const int grid = ncols > 0 ? (ncols + 63) / 64 : 1;
-    hipLaunchKernelGGL(bs_step_kernel, dim3(grid), dim3(1024), 0, s, Linv + (long)kb * 128 * 128, S + (long)kb * 128 * ld, ld, w, y, kb, ncols);
+    const int ncols = kb * 128, col0 = first[kb] * 128;
+    const int grid = ncols > col0 ? (ncols - col0 + 63) / 64 : 1;
+    hipLaunchKernelGGL(bs_step_kernel, dim3(grid), dim3(1024), 0, s, Linv + (long)kb * 128 * 128, S + (long)kb * 128 * ld, ld, w, y, kb, col0, ncols);
   }
   if (kt) kt->end("backsolve", s);
 }
@@ -900,16 +936,31 @@ void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, in
 
 // Algorithmic flops of the dominant kernel's launches (part (b) of each trailing SYRK:
 // lower-triangular 128x128 tiles incl. the diagonal tiles, 2*128*128*K each).
-double cholesky_syrk_flops(int npad, int group) {
+double cholesky_syrk_flops(int npad, int group, const int* last) {
   const int nblk = npad / 128;
   const std::vector<int> gb = cholesky_group_bounds(nblk, group);
   double f = 0.0;
   for (size_t g = 0; g + 2 < gb.size(); ++g) {
     const int k0 = gb[g], k1 = gb[g + 1], na = gb[g + 2] - k1;
-    const int Tb = nblk - k1 - na;
+    const int Lg = last ? (last[k1 - 1] < nblk - 1 ? last[k1 - 1] : nblk - 1) : nblk - 1;
+    const int first_row = k1 + na;
+    const int main_rows = Lg >= first_row ? Lg - first_row + 1 : 0;
+    const int Tb = main_rows + ((first_row + main_rows <= nblk - 1 && Lg < nblk - 1) ? 1 : 0);
     f += 0.5 * Tb * (Tb + 1.0) * 2.0 * 128.0 * 128.0 * (double)((k1 - k0) * 128);
   }
   return f;
+}
+
+// Envelope from the block rows' first non-zero block columns (first_col[i] <= i for i < nblk-1; the entry of the
+// last block row is ignored: that row is always active): last[c] = max{ i <= nblk-2 : first_col[i] <= c }.
+std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col) {
+  const int nblk = (int)first_col.size();
+  std::vector<int> last(nblk);
+  for (int c = 0; c < nblk; ++c) last[c] = c < nblk - 1 ? c : nblk - 1;
+  for (int i = 0; i + 1 < nblk; ++i) { const int c = first_col[i] < i ? first_col[i] : i; if (c >= 0 && last[c] < i) last[c] = i; }
+  for (int c = 1; c < nblk; ++c) if (last[c] < last[c - 1]) last[c] = last[c - 1];
+  if (nblk >= 2 && last[nblk - 2] > nblk - 2) last[nblk - 2] = nblk - 2;
+  return last;
 }
 
 }  // namespace sk

@@ -95,10 +95,11 @@ size_t potrf128_lds_bytes();
 // Linv: (npad/128) blocks of 128x128, zero-initialised once by the caller.
 // ctx == nullptr: everything on `s`; otherwise the panel chain overlaps the trailing SYRK.
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt);
+                     KernelTimer* kt, const int* last = nullptr);
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt);
-double cholesky_syrk_flops(int npad, int group);
+                        hipStream_t s, KernelTimer* kt, const int* last = nullptr);
+double cholesky_syrk_flops(int npad, int group, const int* last = nullptr);
+std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col);
 std::vector<int> cholesky_group_bounds(int nblk, int group);
 void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,
                       KernelTimer* kt);

@@ -118,6 +118,7 @@ struct Options {  // Solver.Options; Ceres 1.x defaults
   size_t reduce_buffer_bytes = 0;
   int cholesky_group = 3;  // SYRK K = group * 128 (3 measured best with the panel look-ahead; 2 and 4 within 1 %)
   bool lookahead = true;   // potrf128 on a second stream, off the critical path
+  bool envelope = true;    // DENSE_SCHUR: skip the blocks of the reduced system outside its block envelope (bit-identical result)
 };
 
 struct IterationLog {

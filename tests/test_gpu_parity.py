@@ -392,6 +392,32 @@ def test_full_size_ladybug_1723_properties():
     assert all(it["relative_decrease"] > 1e-3 for it in succ[1:])
 
 
+def test_envelope_factorisation_is_bit_identical_to_the_full_one():
+    """sk_options_set_cholesky_envelope: the blocks outside the reduced system's block envelope are exact zeros in
+    the full factorisation too, so skipping them changes no bit of the trajectory — at full Ladybug size, where the
+    envelope leaves 13 % of the trailing-update flops, and on a small problem with a full envelope."""
+    for prob, iters in ((bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1)), 5),
+                        (bal.generate(40, 900, 5000, seed=3), 8)):
+        x_env, s_env = solve_bal_gpu(prob, setMaxNumIterations=iters, setCholeskyEnvelope=True)
+        x_full, s_full = solve_bal_gpu(prob, setMaxNumIterations=iters, setCholeskyEnvelope=False)
+        assert np.array_equal(x_env, x_full)
+        assert [a["cost"] for a in s_env.iterations()] == [b["cost"] for b in s_full.iterations()]
+        assert [a["step_norm"] for a in s_env.iterations()] == [b["step_norm"] for b in s_full.iterations()]
+
+
+def test_camera_order_follows_the_band_even_when_the_blocks_are_added_in_scrambled_order():
+    # residual blocks added in random order (first-appearance order of the cameras is then random): the solver still
+    # finds the banded order (memory order of the camera blocks / RCM) and the result matches the oracle
+    prob = bal.generate(60, 2500, 12000, seed=13)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(prob.num_observations)
+    prob.camera_index, prob.point_index, prob.observations = prob.camera_index[perm], prob.point_index[perm], prob.observations[perm]
+    x_gpu, summary = solve_bal_gpu(prob)
+    x_cpu, so = oracle.solve_bal(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index, prob.observations,
+                                 prob.parameters, oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=4))
+    _check_against_oracle(prob, summary, x_gpu, so, x_cpu)
+
+
 def test_full_size_venice_1778_properties():
     """BASELINE.json's largest bundle-adjustment configuration at FULL size (C = 1778, P = 993 923, N = 5 001 946)."""
     prob = bal.generate_named("venice-1778-993923", seed=1778, perturb=(1e-2, 1e-1, 1e-1))

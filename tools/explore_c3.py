@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--group", type=int, default=0)
     ap.add_argument("--no-lookahead", action="store_true")
+    ap.add_argument("--dense-factor", action="store_true", help="factor every block (no envelope)")
     ap.add_argument("--timing", type=int, default=1, help="0 none, 1 all named kernels (slows the chain), 2 SYRK only")
     args = ap.parse_args()
     prob = bal.generate_named(args.workload, seed=1723, perturb=tuple(args.perturb))
@@ -37,6 +38,7 @@ def main():
     o.setGradientTolerance(0.0)
     o.setParameterTolerance(0.0)
     o.setCholeskyTuning(args.group, not args.no_lookahead)
+    o.setCholeskyEnvelope(not args.dense_factor)
     t0 = time.time()
     s = sk.StepSolver(o, problem)
     print("setup + iteration 0: %.2f s" % (time.time() - t0))
