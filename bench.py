@@ -97,26 +97,6 @@ def cpu_baseline(prob, iters):
                                                                     s.t_linear_assemble_s)}
 
 
-def syrk_c_tile_bytes_per_launch(n, group, tail_tiles=48, tail_group=1):
-    """Algorithmic bytes of one trailing-SYRK launch, averaged over a factorisation: every 128x128 fp64 C
-    tile of the launch is read once and written once (the panel operands are shared through L2 and not
-    counted).  Mirrors the group schedule of cholesky_group_bounds (csrc/chol_kernels.hip)."""
-    nblk = (n + 1 + 127) // 128
-    bounds, k = [], 0
-    while k < nblk:
-        bounds.append(k)
-        rem = nblk - k
-        k += min(tail_group if rem <= tail_tiles else group, rem)
-    bounds.append(nblk)
-    tiles = launches = 0
-    for g in range(len(bounds) - 2):
-        tb = nblk - bounds[g + 2]
-        if tb > 0:
-            tiles += tb * (tb + 1) // 2
-            launches += 1
-    return 2.0 * 131072 * tiles / max(1, launches)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,7 +106,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2, help="LM iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--group", type=int, default=0, help="(tuning) SYRK depth in 128-column blocks")
     ap.add_argument("--no-lookahead", action="store_true", help="(tuning) single-stream Cholesky")
-    ap.add_argument("--no-alone", action="store_true", help="skip the untimed look-ahead-off side measurement (profiling runs)")
+    ap.add_argument("--no-alone", action="store_true", help="skip the untimed side measurements (profiling runs)")
+    ap.add_argument("--full-factorisation", action="store_true", help="factor every 128-block of the reduced system (no block envelope)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,6 +144,7 @@ def main():
     options.setParameterTolerance(0.0)
     options.setDevice(local_rank)
     options.setCholeskyTuning(args.group, not args.no_lookahead)
+    options.setCholeskyEnvelope(not args.full_factorisation)
     # a stream of our own, not torch's default (null) stream: the null stream synchronises implicitly with every
     # blocking stream, which would serialise the factorisation's CU-masked SYRK stream against it
     stream = torch.cuda.Stream(device=local_rank)
@@ -204,22 +186,35 @@ def main():
     # timed region above it shares the CUs with the panel chain of the next block-column group (and its
     # stream is masked off a few CUs per XCD), so its per-launch time there is longer by design.
     alone = None
+    full_ms = None
     if world == 1 and not args.no_lookahead and not args.no_alone:
         del solver
-        prob2 = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB)
-        problem2, params2, loss2 = build_problem(sk, prob2)
-        options.setCholeskyTuning(args.group, False)
-        solver2 = sk.StepSolver(options, problem2)
-        solver2.step()
-        solver2.setKernelTiming(2)
-        for _ in range(3):
+
+        def side_run(lookahead, envelope):
+            prob2 = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB)
+            problem2, params2, loss2 = build_problem(sk, prob2)
+            options.setCholeskyTuning(args.group, lookahead)
+            options.setCholeskyEnvelope(envelope)
+            solver2 = sk.StepSolver(options, problem2)
             solver2.step()
-        torch.cuda.synchronize()
-        s2, n2 = solver2.kernelSeconds("gemm_syrk")
-        if s2 > 0:
-            alone = (solver2.syrkFlopsPerSolve() * 3) / s2 * 1e-12
-        solver2.finish(sk.Solver.Summary())
-        del solver2
+            solver2.setKernelTiming(2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                solver2.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 3
+            s2, n2 = solver2.kernelSeconds("gemm_syrk")
+            rate = (solver2.syrkFlopsPerSolve() * 3) / s2 * 1e-12 if s2 > 0 else None
+            flops2 = solver2.syrkFlopsPerSolve()
+            solver2.finish(sk.Solver.Summary())
+            del solver2
+            return rate, dt, flops2
+        alone, _, _ = side_run(False, not args.full_factorisation)
+        # ... and the factorisation of EVERY block (no envelope): same numbers out (bit-identical), more work in
+        if not args.full_factorisation:
+            _, full_dt, full_flops = side_run(True, False)
+            full_ms = 1e3 * full_dt
     its = summary.iterations()
     timed = its[1 + args.warmup: 1 + args.warmup + args.steps]
     n_success = int(sum(it["step_is_successful"] for it in timed))
@@ -233,6 +228,10 @@ def main():
             "config": {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d), DENSE_SCHUR" % (
                 args.workload, prob.num_cameras, prob.num_points, prob.num_observations, SEED),
                 "linear_solver": "DENSE_SCHUR", "reduced_system_n": 9 * prob.num_cameras,
+                "cholesky": ("full: every 128-block of the reduced system" if args.full_factorisation else
+                             "block envelope: cameras ordered for a banded reduced system, the structurally zero 128-blocks outside the envelope "
+                             "skipped; bit-identical to the full factorisation (tests/test_gpu_parity.py::test_envelope_*)"),
+                "ms_per_step_full_factorisation": full_ms,
                 "successful_steps_in_timed_region": n_success, "parallelism": ("one GPU" if world == 1 else
                                 "points sharded x%d, reduced system all-reduced, Cholesky replicated" % world if dist_mode == "sharded" else
                                 "replicated x%d: the solver measured %.1f ms for the all-reduce of the reduced system against %.1f ms of "
@@ -241,15 +240,17 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "sk::syrk_trailing_f64_kernel (Cholesky trailing SYRK, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic() if (args.workload == "ladybug-1723-156502" and args.group <= 0) else None,
+                         "traffic": pmc_traffic() if (args.workload == "ladybug-1723-156502" and args.group <= 0 and not args.full_factorisation) else None,
                          "traffic_note": "bytes/launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled, gfx950; "
-                                         "includes Infinity-Cache hits); algorithmic C-tile bytes/launch (read + write) = %.3e" % (
-                                             syrk_c_tile_bytes_per_launch(9 * prob.num_cameras, args.group if args.group > 0 else 3)),
+                                         "includes Infinity-Cache hits); algorithmic C-tile bytes/launch (read + write, K = 128 per launch with the "
+                                         "envelope's automatic group of 1) = %.3e" % (
+                                             (syrk_flops / max(1, syrk_n // max(1, args.steps))) / (2.0 * 128 * 128 * 128) * 2 * 131072),
                          "launches": syrk_n, "avg_launch_ms": 1e3 * syrk_s / max(1, syrk_n),
                          "flops_per_solve": syrk_flops,
                          "achieved_alone": alone, "frac_alone": (alone / FP64_MFMA_PEAK_TFLOPS) if alone else None,
                          "note": "achieved/frac: live, inside the timed region, where the SYRK shares the chip with the look-ahead "
-                                 "panel chain (masked off 16-32 CUs); *_alone: same kernel, look-ahead off, 3 untimed steps"},
+                                 "panel chain (masked off 16-32 CUs); *_alone: same kernel, look-ahead off, 3 untimed steps; "
+                                 "flops_per_solve counts the blocks inside the envelope only"},
             "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(
                 ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"])},
         }

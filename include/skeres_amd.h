@@ -251,10 +251,10 @@ int sk_options_set_max_num_consecutive_invalid_steps(sk_options* o, int n);
 /* MI355X-side knobs (no reference counterpart) */
 int sk_options_set_device(sk_options* o, int hip_device);             /* default: current device */
 int sk_options_set_stream(sk_options* o, void* hip_stream);           /* default: a private stream */
-/* Tuning of the dense Cholesky: `group` = depth of the trailing SYRK in
- * 128-column blocks (K = 128*group; <= 0 keeps the default 2); `lookahead` != 0
- * runs the serial diagonal-block factorisation on a second stream next to the
- * block-column update / trailing SYRK that does not depend on it. */
+/* Tuning of the dense Cholesky: `group` = depth of the trailing SYRK in 128-column blocks (K = 128*group;
+ * <= 0 keeps the automatic choice: 3 for a full factorisation, 1 when the block envelope makes the serial panel
+ * chain the long pole); `lookahead` != 0 factors the next block-column group on its own stream next to the
+ * trailing SYRK of the current one. */
 int sk_options_set_cholesky_tuning(sk_options* o, int group, int lookahead);
 /* DENSE_SCHUR: the reduced camera system of a bundle-adjustment problem is block-banded (cameras that share no
  * point give a zero block, and the Cholesky factor keeps the block envelope).  on != 0 (default): the dense

@@ -70,7 +70,7 @@ namespace {
 class BalSolver : public SolverBase {
  public:
   BalSolver(const Options& o, Problem* p) : SolverBase(o, p) {}
-  double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, opt_.cholesky_group, env_last_.empty() ? nullptr : env_last_.data()); }
+  double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, group_, env_last_.empty() ? nullptr : env_last_.data()); }
   int distribution(double* allreduce_s, double* saved_s) const override {
     if (allreduce_s) *allreduce_s = est_allreduce_s_;
     if (saved_s) *saved_s = est_saved_s_;
@@ -104,6 +104,7 @@ class BalSolver : public SolverBase {
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
+  int group_ = 3;              // SYRK depth actually used (Options::cholesky_group, or chosen from the envelope)
   DevBuf<double> b_w_, b_pack_;
   size_t packed_elems_ = 0;
   int distribution_ = SK_DISTRIBUTION_SHARDED;
@@ -246,7 +247,7 @@ int BalSolver::setup() {
     double best = -1.0; int best_k = 0; std::vector<int> best_env;
     for (size_t k = 0; k < cand.size(); ++k) {
       std::vector<int> env = envelope_of_order(ocam, opt, cand[k], C_, P_total_, nblk);
-      const double f = cholesky_syrk_flops(npad_, opt_.cholesky_group, env.data());
+      const double f = cholesky_syrk_flops(npad_, 1, env.data());
       if (best < 0.0 || f < best * (1.0 - 1e-9)) { best = f; best_k = (int)k; best_env.swap(env); }
     }
     const std::vector<int>& id = cand[best_k];
@@ -254,12 +255,14 @@ int BalSolver::setup() {
     for (int c = 0; c < C_; ++c) cb[id[c]] = cam_block_[c];
     cam_block_.swap(cb);
     for (int& c : ocam) c = id[c];
+    const double full = cholesky_syrk_flops(npad_, 1, nullptr);
+    group_ = opt_.group_or(opt_.envelope && best < 0.5 * full ? 1 : 3);
     if (opt_.envelope) env_last_.swap(best_env);
     if (getenv("SK_DEBUG_ENVELOPE") && opt_.envelope) {
       long h = 0;
       for (int c = 0; c < nblk; ++c) h += env_last_[c] - c;
       std::fprintf(stderr, "[skeres_amd] camera order %d (0 first appearance, 1 memory, 2 RCM); envelope: %d block columns, mean height %.1f; "
-                   "trailing-update flops %.3e (full %.3e)\n", best_k, nblk, (double)h / nblk, best, cholesky_syrk_flops(npad_, opt_.cholesky_group, nullptr));
+                   "trailing-update flops %.3e (full %.3e)\n", best_k, nblk, (double)h / nblk, best, full);
     }
   }
   // ---- multi-GPU: shard the points, or replicate? ----
@@ -477,7 +480,7 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
   SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
   const int* env = env_last_.empty() ? nullptr : env_last_.data();
-  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.cholesky_group, s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_, env);
+  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, group_, s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_, env);
   cholesky_backsolve(b_S_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_, env);
   SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----

@@ -522,7 +522,7 @@ int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double
   SK_GUARD_BEGIN
   if (n <= 0 || !A || !b || !x) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
   if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
-  if (group <= 0) group = Options().cholesky_group;
+  if (group <= 0) group = 3;
   const int rhs_row = n, npad = ((n + 1 + 127) / 128) * 128;
   std::vector<double> S((size_t)npad * npad, 0.0);
   for (int i = 0; i < n; ++i) std::memcpy(&S[(size_t)i * npad], A + (size_t)i * n, (size_t)(i + 1) * sizeof(double));

@@ -116,7 +116,11 @@ struct Options {  // Solver.Options; Ceres 1.x defaults
   int distribution_mode = SK_DISTRIBUTION_AUTO;
   void* reduce_buffer = nullptr;
   size_t reduce_buffer_bytes = 0;
-  int cholesky_group = 3;  // SYRK K = group * 128 (3 measured best with the panel look-ahead; 2 and 4 within 1 %)
+  // SYRK depth in 128-column blocks (K = group * 128).  0 = automatic: 3 when the trailing SYRK is the long pole
+  // (full factorisation; 2 and 4 within 1 %), 1 when the block envelope leaves so little of it that the serial
+  // panel chain decides (measured on Ladybug-1723: 13.2 / 13.4 / 14.0 / 14.6 ms per iteration for 1 / 2 / 3 / 4).
+  int cholesky_group = 0;
+  int group_or(int automatic) const { return cholesky_group > 0 ? cholesky_group : automatic; }
   bool lookahead = true;   // potrf128 on a second stream, off the critical path
   bool envelope = true;    // DENSE_SCHUR: skip the blocks of the reduced system outside its block envelope (bit-identical result)
 };

@@ -123,7 +123,7 @@ int DenseRowsSolver::try_step(double radius, bool* valid, double* mcc, double* n
   launch_rows_set_rhs(b_H_.p, npad_, rhs_row_, b_gs_.p, n_, s);
   launch_bal_finish_S(b_H_.p, npad_, n_, npad_, rhs_row_, b_D_.p, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
-  cholesky_factor(b_H_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.cholesky_group, s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_);
+  cholesky_factor(b_H_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.group_or(3), s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_);
   cholesky_backsolve(b_H_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_);
   SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   launch_dense_step(b_y_.p, b_scale_.p, x_, b_step_.p, x_new_, n_, b_scal_.p, s);

@@ -398,8 +398,19 @@ def test_envelope_factorisation_is_bit_identical_to_the_full_one():
     envelope leaves 13 % of the trailing-update flops, and on a small problem with a full envelope."""
     for prob, iters in ((bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1)), 5),
                         (bal.generate(40, 900, 5000, seed=3), 8)):
-        x_env, s_env = solve_bal_gpu(prob, setMaxNumIterations=iters, setCholeskyEnvelope=True)
-        x_full, s_full = solve_bal_gpu(prob, setMaxNumIterations=iters, setCholeskyEnvelope=False)
+        # the same SYRK depth on both sides (left automatic it would follow the envelope and regroup the sums)
+        def run(envelope):
+            problem, params, loss = bal_problem_to_sk(prob)
+            options = sk.Solver.Options()
+            options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+            options.setMaxNumIterations(iters)
+            options.setCholeskyTuning(2, True)
+            options.setCholeskyEnvelope(envelope)
+            summary = sk.Solver.Summary()
+            sk.ceres.solve(options, problem, summary)
+            return params.toArray(prob.num_parameters), summary
+        x_env, s_env = run(True)
+        x_full, s_full = run(False)
         assert np.array_equal(x_env, x_full)
         assert [a["cost"] for a in s_env.iterations()] == [b["cost"] for b in s_full.iterations()]
         assert [a["step_norm"] for a in s_env.iterations()] == [b["step_norm"] for b in s_full.iterations()]
