@@ -207,6 +207,18 @@ __global__ __launch_bounds__(256, 2) void gemm_update_f64_kernel(double* C, long
   __builtin_amdgcn_s_setprio(2);  // on the critical path of the factorisation
   gemm_nt_f64_body<0, 0, 16, 2, 64, 128>(C, ldc, A, lda, B, ldb, K, tiles_m, skip, main_t, jump_t);
 }
+// 32 x 128 tiles for short panels (a sparse envelope leaves a few dozen block rows per column): twice the
+// workgroups again, each with half the rows to fetch; these kernels are bound by the latency of one workgroup.
+__global__ __launch_bounds__(256, 2) void gemm_update_thin_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
+                                                                      long ldb, int K, int tiles_m, int skip, int main_t, int jump_t) {
+  __builtin_amdgcn_s_setprio(2);
+  gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(C, ldc, A, lda, B, ldb, K, tiles_m, skip, main_t, jump_t);
+}
+__global__ __launch_bounds__(256, 2) void trsm_gemm_thin_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
+                                                                    int tiles_m, int main_t, int jump_t) {
+  __builtin_amdgcn_s_setprio(2);
+  gemm_nt_f64_body<1, 0, 16, 2, 32, 128>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0, main_t, jump_t);
+}
 // One 128 x 128 diagonal block, C -= A A^T, as 64 x 64 tiles (the upper one skipped): potrf128 waits on it.
 __global__ __launch_bounds__(256, 1) void gemm_diag_f64_kernel(double* C, long ldc, const double* A, long lda, int K) {
   __builtin_amdgcn_s_setprio(3);
@@ -691,10 +703,12 @@ __global__ void copy_row_kernel(const double* __restrict__ src, double* __restri
 static const size_t g_potrf_lds = (size_t)(17 * kBlk + 192) * sizeof(double);
 size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
+static int g_thin_grid = 512;  // panel launches of at most this many 32-row workgroups use the 32 x 128 kernels (developer knob SK_THIN_GRID)
 static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
 hipError_t cholesky_init() {
   if (const char* e = getenv("SK_TAIL_TILES")) g_tail_tiles = atoi(e);  // developer knobs
   if (const char* e = getenv("SK_TAIL_GROUP")) g_tail_group = atoi(e);
+  if (const char* e = getenv("SK_THIN_GRID")) g_thin_grid = atoi(e);
   return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -831,8 +845,12 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     const int tiles_m = r.main + r.extra;
     if (tiles_m <= 0 || tiles_n <= 0) return;
     if (kt) kt->begin(name, st);
-    hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(2 * tiles_m * tiles_n), dim3(256), 0, st, C, ld, A, ld, B, ld, K, 2 * tiles_m, flags, 2 * r.main,
-                       2 * r.jump);
+    if (4 * tiles_m * tiles_n <= g_thin_grid)
+      hipLaunchKernelGGL(gemm_update_thin_f64_kernel, dim3(4 * tiles_m * tiles_n), dim3(256), 0, st, C, ld, A, ld, B, ld, K, 4 * tiles_m, flags, 4 * r.main,
+                         4 * r.jump);
+    else
+      hipLaunchKernelGGL(gemm_update_f64_kernel, dim3(2 * tiles_m * tiles_n), dim3(256), 0, st, C, ld, A, ld, B, ld, K, 2 * tiles_m, flags, 2 * r.main,
+                         2 * r.jump);
     if (kt) kt->end(name, st);
   };
   // one diagonal 128-block: C -= A A^T
@@ -855,8 +873,12 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
         double* A21 = Akk + 128 * ld;
         if (kb > k0) update(sp, "gemm_panel_update", A21, P + 128 * ld, P, K, below, 1, 0);  // ... and the rows below it
         if (kt) kt->begin("gemm_trsm", sp);
-        hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(2 * (below.main + below.extra)), dim3(256), 0, sp, A21, ld, A21, ld, Linv + (long)kb * 128 * 128,
-                           2 * (below.main + below.extra), 2 * below.main, 2 * below.jump);
+        if (4 * (below.main + below.extra) <= g_thin_grid)
+          hipLaunchKernelGGL(trsm_gemm_thin_f64_kernel, dim3(4 * (below.main + below.extra)), dim3(256), 0, sp, A21, ld, A21, ld,
+                             Linv + (long)kb * 128 * 128, 4 * (below.main + below.extra), 4 * below.main, 4 * below.jump);
+        else
+          hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(2 * (below.main + below.extra)), dim3(256), 0, sp, A21, ld, A21, ld, Linv + (long)kb * 128 * 128,
+                             2 * (below.main + below.extra), 2 * below.main, 2 * below.jump);
         if (kt) kt->end("gemm_trsm", sp);
       }
     }
