@@ -552,6 +552,22 @@ static inline int grid_for(int n, int cap = 2048) {
   return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
+// S <- 0 on block row kb, columns [col0[kb] * 128, (kb + 1) * 128): the part of the lower block triangle the
+// factorisation can read (everything left of it is outside the block envelope, everything right of it is the
+// upper triangle)
+__global__ __launch_bounds__(256) void zero_envelope_kernel(double* S, int ld, const int* col0) {
+  const int kb = blockIdx.y;
+  const size_t c0 = (size_t)col0[kb] * 128, width = (size_t)(kb + 1) * 128 - c0;
+  const size_t n2 = 128 * width / 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+    const size_t e = 2 * i, r = e / width, c = e % width;
+    *reinterpret_cast<double2*>(S + ((size_t)kb * 128 + r) * ld + c0 + c) = make_double2(0.0, 0.0);
+  }
+}
+void launch_zero_envelope(double* S, int ld, const int* col0, int nblk, hipStream_t s) {
+  if (nblk > 0) hipLaunchKernelGGL(zero_envelope_kernel, dim3(32, nblk), dim3(256), 0, s, S, ld, col0);
+}
+
 int bal_partial_blocks(int N) { return grid_for(N); }
 size_t tri_packed_elems(int nblk) { return (size_t)128 * 128 * ((size_t)nblk * (nblk + 1) / 2); }
 void launch_tri_pack(double* S, int ld, double* packed, int nblk, bool to_packed, hipStream_t s) {

@@ -53,6 +53,7 @@ struct BalDev {
 int bal_partial_blocks(int N);
 // lower block triangle of S (nblk x nblk blocks of 128) as one contiguous run: block row kb holds its
 // 128 rows x (kb+1)*128 columns row-major; this is what travels in the all-reduce
+void launch_zero_envelope(double* S, int ld, const int* col0, int nblk, hipStream_t s);
 size_t tri_packed_elems(int nblk);
 void launch_tri_pack(double* S, int ld, double* packed, int nblk, bool to_packed, hipStream_t s);
 void launch_bal_eval_jac(const BalDev& d, hipStream_t s);

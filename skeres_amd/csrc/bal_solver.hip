@@ -100,6 +100,7 @@ class BalSolver : public SolverBase {
   std::vector<int> local_pt_;                 // global point id of local point
   BalDev d_{};
   DevBuf<LossNode> b_loss_nodes_;
+  DevBuf<int> b_zero_col0_;
   DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_, b_fail_, b_info_;
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
@@ -356,6 +357,22 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
   SK_HIP_TRY(b_S_.alloc((size_t)npad_ * npad_));
+  SK_HIP_TRY(b_S_.zero(s));  // once: the blocks outside the envelope are never touched again
+  {
+    // first block column each block row is zeroed from: the row envelope, widened by the SYRK depth - 1 (inside a
+    // group, the lazy updates read every column of the group down to the LAST column's envelope) — and the whole
+    // width for the last block row (right-hand side) and without an envelope
+    const int nblk = npad_ / 128;
+    std::vector<int> col0(nblk, 0);
+    if (!env_last_.empty()) {
+      int c = 0;
+      for (int i = 0; i + 1 < nblk; ++i) {
+        while (c < i && env_last_[c] < i) ++c;
+        col0[i] = std::max(0, c - (group_ - 1));
+      }
+    }
+    SK_HIP_TRY(b_zero_col0_.upload(col0, s));
+  }
   SK_HIP_TRY(b_Linv_.alloc((size_t)npad_ * 128)); SK_HIP_TRY(b_Linv_.zero(s));
   partial_stride_ = std::max(std::max(bal_partial_blocks(N_), (P_ + 255) / 256), 256);
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
@@ -461,7 +478,7 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
   launch_lm_diagonal(b_colsq_.p, b_D_.p, (int)(nc + np), opt_.min_lm_diagonal, opt_.max_lm_diagonal, radius, s);
   // ---- B. Schur complement assembly ----
   kt_.begin("memset_S", s);
-  SK_HIP_TRY(hipMemsetAsync(b_S_.p, 0, (size_t)npad_ * npad_ * sizeof(double), s));
+  launch_zero_envelope(b_S_.p, npad_, b_zero_col0_.p, npad_ / 128, s);  // only what the factorisation can read
   kt_.end("memset_S", s);
   SK_HIP_TRY(hipMemsetAsync(b_fail_.p, 0, sizeof(int), s));
   SK_HIP_TRY(hipMemsetAsync(b_info_.p, 0, sizeof(int), s));
