@@ -15,6 +15,7 @@
 // the trailing matrix.  (1), (3) and the SYRK are one kernel:
 //   gemm_nt_f64_kernel : C (-)= A B^T, 128x128 tile, v_mfma_f64_16x16x4_f64.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
 #include "chol_kernels.hpp"
@@ -704,11 +705,13 @@ static const size_t g_potrf_lds = (size_t)(17 * kBlk + 192) * sizeof(double);
 size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
 static int g_thin_grid = 512;  // panel launches of at most this many 32-row workgroups use the 32 x 128 kernels (developer knob SK_THIN_GRID)
+static int g_ext_events = 1;  // events on the producing kernel's own dispatch (developer knob SK_LA_EXT_EVENTS=0: separate records)
 static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
 hipError_t cholesky_init() {
   if (const char* e = getenv("SK_TAIL_TILES")) g_tail_tiles = atoi(e);  // developer knobs
   if (const char* e = getenv("SK_TAIL_GROUP")) g_tail_group = atoi(e);
   if (const char* e = getenv("SK_THIN_GRID")) g_thin_grid = atoi(e);
+  if (const char* e = getenv("SK_LA_EXT_EVENTS")) g_ext_events = atoi(e);
   return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -859,7 +862,12 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     hipLaunchKernelGGL(gemm_diag_f64_kernel, dim3(4), dim3(256), 0, st, C, ld, A, ld, K);
     if (kt) kt->end(name, st);
   };
+  // the completion of the group's last TRSM is what syrk(g) waits for: the event rides on that kernel's own dispatch
+  // (hipExtLaunchKernelGGL stop event) instead of a separate record, which would sit in the panel queue as a packet
+  // of its own in front of the next chain kernel (about 10 us)
+  hipEvent_t panel_done = nullptr;
   auto panel = [&](int k0, int k1) {
+    panel_done = nullptr;
     for (int kb = k0; kb < k1; ++kb) {
       double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
       const Rows below = rows_from(kb + 1, last_main(kb));
@@ -872,13 +880,17 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       if (below.main + below.extra > 0) {
         double* A21 = Akk + 128 * ld;
         if (kb > k0) update(sp, "gemm_panel_update", A21, P + 128 * ld, P, K, below, 1, 0);  // ... and the rows below it
+        hipEvent_t stop = nullptr;
+        if (la && g_ext_events && kb == k1 - 1) stop = panel_done = ctx->event(ev++);
         if (kt) kt->begin("gemm_trsm", sp);
         if (4 * (below.main + below.extra) <= g_thin_grid)
-          hipLaunchKernelGGL(trsm_gemm_thin_f64_kernel, dim3(4 * (below.main + below.extra)), dim3(256), 0, sp, A21, ld, A21, ld,
-                             Linv + (long)kb * 128 * 128, 4 * (below.main + below.extra), 4 * below.main, 4 * below.jump);
+          hipExtLaunchKernelGGL(trsm_gemm_thin_f64_kernel, dim3(4 * (below.main + below.extra)), dim3(256), 0, sp, nullptr, stop, 0, A21, ld,
+                                (const double*)A21, ld, (const double*)(Linv + (long)kb * 128 * 128), 4 * (below.main + below.extra), 4 * below.main,
+                                4 * below.jump);
         else
-          hipLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(2 * (below.main + below.extra)), dim3(256), 0, sp, A21, ld, A21, ld, Linv + (long)kb * 128 * 128,
-                             2 * (below.main + below.extra), 2 * below.main, 2 * below.jump);
+          hipExtLaunchKernelGGL(trsm_gemm_f64_kernel, dim3(2 * (below.main + below.extra)), dim3(256), 0, sp, nullptr, stop, 0, A21, ld,
+                                (const double*)A21, ld, (const double*)(Linv + (long)kb * 128 * 128), 2 * (below.main + below.extra), 2 * below.main,
+                                2 * below.jump);
         if (kt) kt->end("gemm_trsm", sp);
       }
     }
@@ -902,7 +914,9 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     if (la) sb = Tb >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
     if (sb != sb_prev && syrk_done) (void)hipStreamWaitEvent(sb, syrk_done, 0);  // syrk(g) after syrk(g-1) across the two bulk streams
     sb_prev = sb;
-    order(sp, sb);  // panel(g) is final: syrk(g) may start (after syrk(g-1))
+    // panel(g) is final: syrk(g) may start (after syrk(g-1))
+    if (panel_done) (void)hipStreamWaitEvent(sb, panel_done, 0);
+    else order(sp, sb);
     // next(g): active rows x na tiles, above-diagonal tiles skipped; on the panel stream, after syrk(g-1)
     if (la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
     update(sp, "gemm_syrk_next", A22, P, P, K, rn, na, 1);
