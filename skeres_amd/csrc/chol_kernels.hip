@@ -50,7 +50,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 //         factorisation are a contiguous run plus the last block row, which carries the right-hand side.
 template <int kMode, int kShape, int kBKT, int kPF, int kTM, int kTN>
 __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
-                                                 int tiles_m, int skip, int main_t = 0x7fffffff, int jump_t = 0) {
+                                                 int tiles_m, int skip, int main_t = 0x7fffffff, int jump_t = 0, int main_n = 0x7fffffff,
+                                                 int jump_n = 0) {
   constexpr int mode = kMode;
   constexpr int kLdT = kBKT + 2;            // LDS row stride in doubles
   constexpr int kChA = kTM * kBKT / 512;    // 16-byte chunks per thread and stage, A operand
@@ -71,6 +72,7 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
   } else {
     ti = blockIdx.x % tiles_m; tj = blockIdx.x / tiles_m;
     if (ti >= main_t) ti += jump_t;
+    if (tj >= main_n) tj += jump_n;  // kShape 0 with mapped tile columns (units of kTN): a small SYRK run as a rectangle
     const int bi = ti * kTM / 128, bj = tj * kTN / 128;
     if ((skip & 1) && bi < bj) return;
     if ((skip & 2) && bi == 0 && bj == 0) return;
@@ -178,6 +180,14 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
 __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tile_off, int main_t,
                                                                    int jump_t) {
   gemm_nt_f64_body<0, 1, 16, 1, 128, 128>(C, ldc, A, lda, A, lda, K, 0, tile_off, main_t, jump_t);
+}
+// The same update for a SMALL trailing matrix (block envelope: a few dozen block rows): as a rectangle of 32 x 128
+// tiles with the tiles above the diagonal dropped.  A 128 x 128 tile with K = 128 is one workgroup-latency of
+// 30-50 us however few tiles there are (load 128 KB of C, eight K-steps, store 128 KB); 32-row tiles are four
+// times as many workgroups, each a quarter as long, and the whole launch fits in two rounds.
+__global__ __launch_bounds__(256, 2) void syrk_trailing_thin_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tiles_m, int main_t,
+                                                                        int jump_t, int main_n, int jump_n) {
+  gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(C, ldc, A, lda, A, lda, K, tiles_m, 1, main_t, jump_t, main_n, jump_n);
 }
 // Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
 // transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
@@ -706,11 +716,15 @@ size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
 static int g_thin_grid = 512;  // panel launches of at most this many 32-row workgroups use the 32 x 128 kernels (developer knob SK_THIN_GRID)
 static int g_ext_events = 1;  // events on the producing kernel's own dispatch (developer knob SK_LA_EXT_EVENTS=0: separate records)
+static unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;  // developer knob SK_LA_SYSTEM_FENCE=1: default fences
+static int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK (developer knob SK_THIN_SYRK)
 static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
 hipError_t cholesky_init() {
   if (const char* e = getenv("SK_TAIL_TILES")) g_tail_tiles = atoi(e);  // developer knobs
   if (const char* e = getenv("SK_TAIL_GROUP")) g_tail_group = atoi(e);
   if (const char* e = getenv("SK_THIN_GRID")) g_thin_grid = atoi(e);
+  if (const char* e = getenv("SK_THIN_SYRK")) g_thin_syrk_tiles = atoi(e);
+  if (const char* e = getenv("SK_LA_SYSTEM_FENCE")) { if (atoi(e)) g_event_flags = hipEventDisableTiming; }
   if (const char* e = getenv("SK_LA_EXT_EVENTS")) g_ext_events = atoi(e);
   return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -774,7 +788,9 @@ hipError_t CholeskyContext::init() {
 hipEvent_t CholeskyContext::event(size_t i) {
   while (events.size() <= i) {
     hipEvent_t e = nullptr;
-    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    // ordering between streams of ONE device: no system-scope fence (cache write-back and invalidation towards the host)
+    // when the event fires — the kernels' own device-scope release at their end is what the consumers need
+    (void)hipEventCreateWithFlags(&e, g_event_flags);
     events.push_back(e);
   }
   return events[i];
@@ -926,7 +942,11 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       double* Cb = S + (long)(k1 + na) * 128 * ld + (long)(k1 + na) * 128;
       const double* Pb = S + (long)(k1 + na) * 128 * ld + (long)k0 * 128;
       if (kt) kt->begin("gemm_syrk", sb);
-      hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
+      if (Tb <= g_thin_syrk_tiles)
+        hipLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(4 * Tb * Tb), dim3(256), 0, sb, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main, 4 * rs.jump, rs.main,
+                           rs.jump);
+      else
+        hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
       if (kt) kt->end("gemm_syrk", sb);
       if (la) { syrk_done = ctx->event(ev++); (void)hipEventRecord(syrk_done, sb); }
     }

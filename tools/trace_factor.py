@@ -15,7 +15,7 @@ pi = [i for i, r in enumerate(rows) if r['n'] == 'bal_pair_kernel'][-1]
 it = rows[pi:]
 end = [i for i, r in enumerate(it) if r['n'] == 'copy_row_kernel'][0]
 names = ('potrf128_kernel', 'trsm_gemm_f64_kernel', 'trsm_gemm_thin_f64_kernel', 'gemm_update_f64_kernel', 'gemm_update_thin_f64_kernel',
-         'gemm_diag_f64_kernel', 'syrk_trailing_f64_kernel')
+         'gemm_diag_f64_kernel', 'syrk_trailing_f64_kernel', 'syrk_trailing_thin_f64_kernel')
 ch = [r for r in it[1:end] if r['n'] in names]
 t0 = ch[0]['s']; t1 = max(r['e'] for r in ch)
 print("factor wall %.2f ms, kernels %d" % ((t1 - t0) / 1e6, len(ch)))
@@ -37,7 +37,7 @@ def union(iv):
     return tot
 
 
-sy = [(r['s'], r['e']) for r in ch if r['n'] == 'syrk_trailing_f64_kernel']
+sy = [(r['s'], r['e']) for r in ch if r['n'].startswith('syrk_trailing')]
 print("union busy %.2f ms; syrk union %.2f ms; syrk gaps: first start +%.2f ms, last end -%.2f ms" % (
     union([(r['s'], r['e']) for r in ch]) / 1e6, union(sy) / 1e6, (sy[0][0] - t0) / 1e6, (t1 - sy[-1][1]) / 1e6))
 gaps = [(sy[i + 1][0] - sy[i][1]) / 1e3 for i in range(len(sy) - 1)]
