@@ -416,6 +416,28 @@ __device__ __forceinline__ void block_mma32(d4 (&acc)[2][2], const double* P, co
         acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
   }
 }
+// one 16x16 quadrant (qi, qj) of a 32x32 block product P Q^T: 8 MFMAs over two accumulators (fresh == true: acc starts at zero)
+__device__ __forceinline__ void quad_mma16(d4& acc, const double* P, const double* Q, int qi, int qj, int lane, bool fresh) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+  d4 a0 = fresh ? (d4){0.0, 0.0, 0.0, 0.0} : acc, a1 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 8; kk += 2) {
+    const int k = kk * 4 + l4;
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(qi * 16 + l15) * kBs + k], Q[(qj * 16 + l15) * kBs + k], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(qi * 16 + l15) * kBs + k + 4], Q[(qj * 16 + l15) * kBs + k + 4], a1, 0, 0, 0);
+  }
+  acc = a0 + a1;
+}
+__device__ __forceinline__ void quad_store16(double* dst, const d4& acc, int qi, int qj, int lane, double sgn) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[(qi * 16 + l4 + 4 * i) * kBs + qj * 16 + l15] = sgn * acc[i];
+}
+__device__ __forceinline__ void quad_load16(d4& acc, const double* src, int qi, int qj, int lane, double sgn) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = sgn * src[(qi * 16 + l4 + 4 * i) * kBs + qj * 16 + l15];
+}
 __device__ __forceinline__ void block_zero32(d4 (&acc)[2][2]) {
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -472,8 +494,9 @@ __device__ long long g_potrf_stamps[4][16], g_potrf_clk[4][16];
 __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* T = lds;                      // blocks 0..9: lower triangle of the tile (diagonal slots end as W_jj); 10..15: inverse, below the diagonal
-  double* E = lds + 16 * kBlk;          // block 16: staging of L_jj on its way to global memory
-  double* colbuf = lds + 17 * kBlk;     // 3 x 64 doubles
+  double* E = lds + 16 * kBlk;          // blocks 16, 17: staging of L_jj on its way to global memory (even / odd jb)
+  double* colbuf = lds + 18 * kBlk;     // 3 x 64 doubles
+  volatile int* flags = reinterpret_cast<volatile int*>(colbuf + 192);  // 4 hand-over flags of waves 1..3
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   __builtin_amdgcn_s_setprio(3);
   SK_STAMP(0)
@@ -505,6 +528,7 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 #pragma unroll
         for (int i = 0; i < 4; ++i) T[blk_off(bi, bj) + loff[i]] = v[b][i];
   }
+  if (t < 4) flags[t] = 0;
   __syncthreads();
   SK_STAMP(1)
   const unsigned uld = (unsigned)ld;
@@ -514,21 +538,40 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 #define SK_V(bi, bj) (T + inv_off(bi, bj))
 #define SK_GA(bi, bj) (A + ((long)(bi) * kB * ld + (bj) * kB))
 #define SK_GI(bi, bj) (Linv + ((bi) * kB * 128 + (bj) * kB))
-  // phase B: panel block bi below W_jj, then its own diagonal update (same wave: no barrier in between)
-#define SK_PHASE_B(jb, bi)                                                                      \
-  if ((bi) < 4) {                                                                               \
+  // one wave: X(bi,jb) = T(bi,jb) W_jj^T in place, then its own diagonal update (same wave: no barrier in between)
+#define SK_PANEL_ROW(jb, bi)                                                                    \
+  {                                                                                             \
     d4 acc[2][2];                                                                               \
     block_zero32(acc);                                                                          \
     block_mma32<false>(acc, SK_L(bi, jb), SK_L(jb, jb), lane);                                  \
     block_store32(SK_L(bi, jb), acc, lane, 1.0); /* every read of the block feeds the MFMAs */  \
-    block_update32(SK_L(bi, bi), SK_L(bi, jb), SK_L(bi, jb), lane);                             \
+  }
+  // the step between two diagonal factorisations, on the critical path: X(jb+1,jb) = T(jb+1,jb) W_jj^T and
+  // T(jb+1,jb+1) -= X X^T, each split into four 16x16 quadrants, one per wave (8 MFMAs instead of 32)
+#define SK_CRITICAL_B(jb)                                                                        \
+  {                                                                                              \
+    d4 xq;                                                                                       \
+    quad_mma16(xq, SK_L((jb) + 1, jb), SK_L(jb, jb), qi, qj, lane, true);                        \
+    __syncthreads(); /* every wave has read T(jb+1,jb) */                                        \
+    quad_store16(SK_L((jb) + 1, jb), xq, qi, qj, lane, 1.0);                                     \
+    __syncthreads(); /* X(jb+1,jb) is complete */                                                \
+    d4 uq;                                                                                       \
+    quad_load16(uq, SK_L((jb) + 1, (jb) + 1), qi, qj, lane, -1.0);                               \
+    quad_mma16(uq, SK_L((jb) + 1, jb), SK_L((jb) + 1, jb), qi, qj, lane, false);                 \
+    quad_store16(SK_L((jb) + 1, (jb) + 1), uq, qi, qj, lane, -1.0);                              \
+    __syncthreads();                                                                             \
   }
 #define SK_WRITE_L(bi, bj) block_to_global(SK_GA(bi, bj), 2 * uld, go_a, SK_L(bi, bj), lo_w);
 #define SK_WRITE_W(bi) block_to_global(SK_GI(bi, bi), 256u, go_i, SK_L(bi, bi), lo_w);
 #define SK_WRITE_V(bi, bj) block_to_global(SK_GI(bi, bj), 256u, go_i, SK_V(bi, bj), lo_w);
-#define SK_WRITE_E(bi) block_to_global(SK_GA(bi, bi), 2 * uld, go_a, E, lo_w);
+#define SK_WRITE_E(bi) block_to_global(SK_GA(bi, bi), 2 * uld, go_a, E + ((bi) & 1) * kBlk, lo_w);
+  // flags in LDS by which waves 1..3 pass blocks to each other while wave 0 is inside a diagonal factorisation
+  // (a workgroup barrier would need wave 0): the producer's LDS writes are complete (lgkmcnt) before the flag
+#define SK_FLAG_SET(i) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); if (lane == 0) flags[i] = 1; }
+#define SK_FLAG_WAIT(i) { while (__builtin_amdgcn_readfirstlane(flags[i]) == 0) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+  const int qi = wave >> 1, qj = wave & 1;
   // Wave 0 runs a loop (one copy of the 32-column chain in the instruction cache); waves 1..3 run
-  // straight-line code with the same number of barriers (7).  `wave` is scalar: the branches are uniform.
+  // straight-line code with the same barriers.  `wave` is scalar: the branches are uniform.
   if (wave == 0) {
 #pragma unroll 1
     for (int jb = 0; jb < 4; ++jb) {
@@ -538,97 +581,108 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
       SK_STAMP(11 + jb)
       if (!ok && lane == 0) *info = 1;
       {
-        // lanes 0..31: row of L_jj -> staging block E (written to global by wave 3 in the next phase);
-        // lanes 32..63: column k of W_jj -> the slot of D (zeros above the diagonal in both)
+        // lanes 0..31: row of L_jj -> staging block E[jb & 1] (written to global by wave 3 during the next diagonal
+        // factorisation); lanes 32..63: column k of W_jj -> the slot of D (zeros above the diagonal in both)
         const int row = lane & 31;
-        double* dst = lane < 32 ? E + row * kBs : D + row;
+        double* dst = lane < 32 ? E + (jb & 1) * kBlk + row * kBs : D + row;
         const int step = lane < 32 ? 1 : kBs;
 #pragma unroll
         for (int c = 0; c < 32; ++c) dst[c * step] = (lane >= 32 || c <= row) ? a[c] : 0.0;
       }
       SK_STAMP(2 + 2 * jb)
       __syncthreads();
-      if (jb < 3) {
-        SK_PHASE_B(jb, jb + 1)
-        SK_STAMP(3 + 2 * jb)
-        __syncthreads();
-      }
+      if (jb == 0) SK_CRITICAL_B(0)
+      if (jb == 1) SK_CRITICAL_B(1)
+      if (jb == 2) SK_CRITICAL_B(2)
+      SK_STAMP(3 + 2 * jb)
     }
   } else {
-    d4 accs[2][2];  // a partial sum S carried in registers across a barrier
+    d4 accs[2][2];  // a partial sum S carried in registers
     SK_STAMP(2)
-    __syncthreads();  // ---- B0
-    SK_PHASE_B(0, 1 + wave)
-    if (wave == 3) { SK_WRITE_E(0) }
+    __syncthreads();
+    SK_CRITICAL_B(0)
     SK_STAMP(3)
-    __syncthreads();  // ---- next to P(1): off-diagonal updates of step 0
-    if (wave == 1) block_update32(SK_L(2, 1), SK_L(2, 0), SK_L(1, 0), lane);
-    if (wave == 2) block_update32(SK_L(3, 1), SK_L(3, 0), SK_L(1, 0), lane);
-    if (wave == 3) block_update32(SK_L(3, 2), SK_L(3, 0), SK_L(2, 0), lane);
+    // ---- next to P(1): the rest of block column 0 and everything it updates
+    if (wave == 1) {
+      SK_PANEL_ROW(0, 2)
+      SK_FLAG_SET(0)
+      block_update32(SK_L(2, 2), SK_L(2, 0), SK_L(2, 0), lane);
+      block_update32(SK_L(2, 1), SK_L(2, 0), SK_L(1, 0), lane);
+      SK_WRITE_L(2, 0)
+    }
+    if (wave == 2) {
+      SK_PANEL_ROW(0, 3)
+      SK_FLAG_SET(1)
+      block_update32(SK_L(3, 3), SK_L(3, 0), SK_L(3, 0), lane);
+      block_update32(SK_L(3, 1), SK_L(3, 0), SK_L(1, 0), lane);
+      SK_WRITE_L(3, 0)
+    }
+    if (wave == 3) {
+      SK_WRITE_E(0) SK_WRITE_L(1, 0) SK_WRITE_W(0)
+      SK_FLAG_WAIT(0) SK_FLAG_WAIT(1)
+      block_update32(SK_L(3, 2), SK_L(3, 0), SK_L(2, 0), lane);
+    }
     SK_STAMP(4)
-    __syncthreads();  // ---- B1
-    if (wave == 1) { SK_PHASE_B(1, 3) }
-    if (wave == 2) {  // Inv(1,0) = -W_1 (L_10 W_0)
+    __syncthreads();
+    SK_CRITICAL_B(1)
+    SK_STAMP(5)
+    // ---- next to P(2): the rest of block column 1; Inv(1,0) = -W_1 (L_10 W_0); S(2,0) = L_20 W_0 + L_21 Inv(1,0)
+    if (wave == 1) {
+      SK_PANEL_ROW(1, 3)
+      block_update32(SK_L(3, 3), SK_L(3, 1), SK_L(3, 1), lane);
+      block_update32(SK_L(3, 2), SK_L(3, 1), SK_L(2, 1), lane);
+      SK_WRITE_L(3, 1) SK_WRITE_L(2, 1)
+    }
+    if (wave == 2) {
       d4 acc[2][2];
       block_zero32(acc);
       block_mma32<true>(acc, SK_L(1, 0), SK_L(0, 0), lane);
       block_store32(SK_V(1, 0), acc, lane, 1.0);
       block_neg_left_mul32(SK_V(1, 0), SK_L(1, 1), lane);
-    }
-    if (wave == 3) {  // S(2,0) = L_20 W_0 ...
-      block_zero32(accs);
-      block_mma32<true>(accs, SK_L(2, 0), SK_L(0, 0), lane);
-      SK_WRITE_E(1) SK_WRITE_L(1, 0) SK_WRITE_L(2, 0) SK_WRITE_L(3, 0) SK_WRITE_W(0)
-    }
-    SK_STAMP(5)
-    __syncthreads();  // ---- next to P(2)
-    if (wave == 1) { block_update32(SK_L(3, 2), SK_L(3, 1), SK_L(2, 1), lane); SK_WRITE_L(2, 1) }
-    if (wave == 2) {  // S(2,1) = L_21 W_1
-      d4 acc[2][2];
-      block_zero32(acc);
+      SK_FLAG_SET(2)
+      block_zero32(acc);  // S(2,1) = L_21 W_1
       block_mma32<true>(acc, SK_L(2, 1), SK_L(1, 1), lane);
       block_store32(SK_V(2, 1), acc, lane, 1.0);
       SK_WRITE_V(1, 0)
     }
-    if (wave == 3) {  // ... + L_21 Inv(1,0)
+    if (wave == 3) {
+      SK_WRITE_E(1) SK_WRITE_W(1)
+      block_zero32(accs);
+      block_mma32<true>(accs, SK_L(2, 0), SK_L(0, 0), lane);
+      SK_FLAG_WAIT(2)
       block_mma32<true>(accs, SK_L(2, 1), SK_V(1, 0), lane);
       block_store32(SK_V(2, 0), accs, lane, 1.0);
     }
     SK_STAMP(6)
-    __syncthreads();  // ---- B2 (wave 0 alone on the panel): row 2 of the inverse, start of row 3
-    if (wave == 1) {  // S(3,0) = L_30 W_0 + L_31 Inv(1,0) ...
+    __syncthreads();
+    SK_CRITICAL_B(2)
+    SK_STAMP(7)
+    // ---- next to P(3): row 2 of the inverse, and the partial sums S(3,bj) = sum_{t<3} L(3,t) Inv(t,bj) of row 3
+    if (wave == 1) {  // S(3,0) = L_30 W_0 + L_31 Inv(1,0) + L_32 Inv(2,0)
       block_zero32(accs);
       block_mma32<true>(accs, SK_L(3, 0), SK_L(0, 0), lane);
       block_mma32<true>(accs, SK_L(3, 1), SK_V(1, 0), lane);
-      SK_WRITE_L(3, 1)
-    }
-    if (wave == 2) {  // Inv(2,1) = -W_2 S(2,1);  S(3,1) = L_31 W_1 ...
-      block_neg_left_mul32(SK_V(2, 1), SK_L(2, 2), lane);
-      block_zero32(accs);
-      block_mma32<true>(accs, SK_L(3, 1), SK_L(1, 1), lane);
-    }
-    if (wave == 3) {  // Inv(2,0) = -W_2 S(2,0)
-      SK_WRITE_E(2)
-      block_neg_left_mul32(SK_V(2, 0), SK_L(2, 2), lane);
-      SK_WRITE_W(1)
-    }
-    SK_STAMP(7)
-    __syncthreads();  // ---- next to P(3): the partial sums of row 3 are completed with L_32
-    if (wave == 1) {
+      SK_WRITE_L(3, 2)
+      SK_FLAG_WAIT(3)
       block_mma32<true>(accs, SK_L(3, 2), SK_V(2, 0), lane);
       block_store32(SK_V(3, 0), accs, lane, 1.0);
       SK_WRITE_V(2, 0)
     }
-    if (wave == 2) {
+    if (wave == 2) {  // Inv(2,1) = -W_2 S(2,1);  S(3,1) = L_31 W_1 + L_32 Inv(2,1)
+      block_neg_left_mul32(SK_V(2, 1), SK_L(2, 2), lane);
+      block_zero32(accs);
+      block_mma32<true>(accs, SK_L(3, 1), SK_L(1, 1), lane);
       block_mma32<true>(accs, SK_L(3, 2), SK_V(2, 1), lane);
       block_store32(SK_V(3, 1), accs, lane, 1.0);
       SK_WRITE_V(2, 1)
     }
-    if (wave == 3) {
+    if (wave == 3) {  // Inv(2,0) = -W_2 S(2,0);  S(3,2) = L_32 W_2
+      block_neg_left_mul32(SK_V(2, 0), SK_L(2, 2), lane);
+      SK_FLAG_SET(3)
       block_zero32(accs);
       block_mma32<true>(accs, SK_L(3, 2), SK_L(2, 2), lane);
       block_store32(SK_V(3, 2), accs, lane, 1.0);
-      SK_WRITE_L(3, 2) SK_WRITE_W(2)
+      SK_WRITE_E(2) SK_WRITE_W(2)
     }
     SK_STAMP(8)
     __syncthreads();
@@ -640,12 +694,15 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
   } else {
     SK_WRITE_E(3) SK_WRITE_W(3)
   }
-#undef SK_PHASE_B
+  SK_STAMP(10)
+#undef SK_PANEL_ROW
+#undef SK_CRITICAL_B
+#undef SK_FLAG_SET
+#undef SK_FLAG_WAIT
 #undef SK_WRITE_L
 #undef SK_WRITE_W
 #undef SK_WRITE_V
 #undef SK_WRITE_E
-  SK_STAMP(10)
 #undef SK_L
 #undef SK_V
 #undef SK_GA
@@ -710,8 +767,8 @@ __global__ void copy_row_kernel(const double* __restrict__ src, double* __restri
 // ---------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------
-// 17 packed 32x32 blocks + the column buffer: 142 KB of dynamic LDS
-static const size_t g_potrf_lds = (size_t)(17 * kBlk + 192) * sizeof(double);
+// 18 packed 32x32 blocks + the column buffer + flags: 150 KB of dynamic LDS
+static const size_t g_potrf_lds = (size_t)(18 * kBlk + 192 + 4) * sizeof(double);
 size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
 static int g_thin_grid = 512;  // panel launches of at most this many 32-row workgroups use the 32 x 128 kernels (developer knob SK_THIN_GRID)
