@@ -70,7 +70,9 @@ namespace {
 class BalSolver : public SolverBase {
  public:
   BalSolver(const Options& o, Problem* p) : SolverBase(o, p) {}
-  double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, group_, env_last_.empty() ? nullptr : env_last_.data()); }
+  double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, group_, env_last_.empty() ? nullptr : env_last_.data(), chain_ok()); }
+  // the grouping is the library's choice (Options::cholesky_group == 0) and the masked streams of the resident panel chain exist
+  bool chain_ok() const { return opt_.cholesky_group == 0 && opt_.lookahead && chol_ctx_.server != nullptr; }
   int distribution(double* allreduce_s, double* saved_s) const override {
     if (allreduce_s) *allreduce_s = est_allreduce_s_;
     if (saved_s) *saved_s = est_saved_s_;
@@ -357,6 +359,11 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
   SK_HIP_TRY(b_S_.alloc((size_t)npad_ * npad_));
+  SK_HIP_TRY(cholesky_init());
+  if (opt_.lookahead && chol_ctx_.init() != hipSuccess) {  // CU-masked streams unavailable: plain in-order factorisation
+    (void)hipGetLastError();
+    opt_.lookahead = false;
+  }
   SK_HIP_TRY(b_S_.zero(s));  // once: the blocks outside the envelope are never touched again
   {
     // first block column each block row is zeroed from: the row envelope, widened by the SYRK depth - 1 (inside a
@@ -364,11 +371,13 @@ int BalSolver::setup() {
     // width for the last block row (right-hand side) and without an envelope
     const int nblk = npad_ / 128;
     std::vector<int> col0(nblk, 0);
+    // the widest group of either way to factor (with / without the resident chain, which a timing mode switches off)
+    const int widen = env_last_.empty() ? 1 : std::max(group_, cholesky_plan_max_group(cholesky_plan(nblk, group_, env_last_.data(), chain_ok())));
     if (!env_last_.empty()) {
       int c = 0;
       for (int i = 0; i + 1 < nblk; ++i) {
         while (c < i && env_last_[c] < i) ++c;
-        col0[i] = std::max(0, c - (group_ - 1));
+        col0[i] = std::max(0, c - (widen - 1));
       }
     }
     SK_HIP_TRY(b_zero_col0_.upload(col0, s));
@@ -379,12 +388,7 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
   SK_HIP_TRY(b_fail_.alloc(1)); SK_HIP_TRY(b_fail_.zero(s)); SK_HIP_TRY(b_info_.alloc(1)); SK_HIP_TRY(b_info_.zero(s));
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
-  SK_HIP_TRY(cholesky_init());
   SK_HIP_TRY(b_w_.alloc(npad_));
-  if (opt_.lookahead && chol_ctx_.init() != hipSuccess) {  // CU-masked streams unavailable: plain in-order factorisation
-    (void)hipGetLastError();
-    opt_.lookahead = false;
-  }
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p;
@@ -497,7 +501,7 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
   SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
   const int* env = env_last_.empty() ? nullptr : env_last_.data();
-  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, group_, s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_, env);
+  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, group_, s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_, env, chain_ok());
   cholesky_backsolve(b_S_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_, env);
   SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----

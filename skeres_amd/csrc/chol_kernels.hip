@@ -48,10 +48,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // main_t, jump_t: the tile rows (kShape 1: and tile columns) of the launch are the first main_t consecutive
 //         ones, then rows jump_t tiles further down (units of kTM rows): the active rows of an envelope
 //         factorisation are a contiguous run plus the last block row, which carries the right-hand side.
+constexpr int gemm_lds_doubles(int kBKT, int kTM, int kTN) { return 2 * (kTM + kTN) * (kBKT + 2); }
+#define SK_GEMM_LDS(kBKT, kTM, kTN) __shared__ __attribute__((aligned(16))) double sh[gemm_lds_doubles(kBKT, kTM, kTN)];
 template <int kMode, int kShape, int kBKT, int kPF, int kTM, int kTN>
-__device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
+__device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
                                                  int tiles_m, int skip, int main_t = 0x7fffffff, int jump_t = 0, int main_n = 0x7fffffff,
-                                                 int jump_n = 0) {
+                                                 int jump_n = 0, int block_id = -1) {
   constexpr int mode = kMode;
   constexpr int kLdT = kBKT + 2;            // LDS row stride in doubles
   constexpr int kChA = kTM * kBKT / 512;    // 16-byte chunks per thread and stage, A operand
@@ -59,7 +61,7 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
   constexpr int kRowStep = 512 / kBKT;      // rows covered by the 256 threads per chunk index
   constexpr int kMT = kTM / 32, kNT = kTN / 32;  // 16x16 MFMA tiles per wave
   static_assert(kChA >= 1 && kChB >= 1, "tile too small for 256 staging threads");
-  __shared__ __attribute__((aligned(16))) double sh[2][(kTM + kTN) * kLdT];
+  constexpr int kShBuf = (kTM + kTN) * kLdT;  // shp: 2 * kShBuf doubles of LDS (gemm_lds_doubles), 16-byte aligned
   int ti, tj;
   if (kShape == 1) {
     const int b = blockIdx.x + skip;  // lower-triangular enumeration
@@ -70,7 +72,8 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
     if (ti >= main_t) ti += jump_t;
     if (tj >= main_t) tj += jump_t;
   } else {
-    ti = blockIdx.x % tiles_m; tj = blockIdx.x / tiles_m;
+    const int bx = block_id >= 0 ? block_id : (int)blockIdx.x;  // (chain_column_kernel numbers its tiles itself)
+    ti = bx % tiles_m; tj = bx / tiles_m;
     if (ti >= main_t) ti += jump_t;
     if (tj >= main_n) tj += jump_n;  // kShape 0 with mapped tile columns (units of kTN): a small SYRK run as a rectangle
     const int bi = ti * kTM / 128, bj = tj * kTN / 128;
@@ -119,9 +122,9 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
   }
 #define SK_STORE_STAGE(set, buf)                                                                   \
   _Pragma("unroll") for (int i = 0; i < kChA; ++i)                                                  \
-    *reinterpret_cast<double2*>(&sh[buf][(i * kRowStep + srow) * kLdT + sc]) = make_double2(ra##set[2 * i], ra##set[2 * i + 1]); \
+    *reinterpret_cast<double2*>(&shp[(buf) * kShBuf + (i * kRowStep + srow) * kLdT + sc]) = make_double2(ra##set[2 * i], ra##set[2 * i + 1]); \
   _Pragma("unroll") for (int i = 0; i < kChB; ++i)                                                  \
-    *reinterpret_cast<double2*>(&sh[buf][(kTM + i * kRowStep + srow) * kLdT + sc]) = make_double2(rb##set[2 * i], rb##set[2 * i + 1]);
+    *reinterpret_cast<double2*>(&shp[(buf) * kShBuf + (kTM + i * kRowStep + srow) * kLdT + sc]) = make_double2(rb##set[2 * i], rb##set[2 * i + 1]);
   const int nk = K / kBKT;  // a multiple of kPF (K is a multiple of 128)
   SK_LOAD_STAGE(0, 0)
   if (kPF == 2) { SK_LOAD_STAGE(1, (nk > 1 ? 1 : 0) * kBKT) }
@@ -137,8 +140,8 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
     const int buf = (kt) & 1;                                                                      \
     const int knext = ((kt) + kPF < nk ? (kt) + kPF : nk - 1) * kBKT;                              \
     SK_LOAD_STAGE_X(SETL, knext)                                                                   \
-    const double* sa = &sh[buf][(wr * (kTM / 2) + l15) * kLdT + l4];                               \
-    const double* sb = &sh[buf][(kTM + wc * (kTN / 2) + l15) * kLdT + l4];                         \
+    const double* sa = &shp[buf * kShBuf + (wr * (kTM / 2) + l15) * kLdT + l4];                               \
+    const double* sb = &shp[buf * kShBuf + (kTM + wc * (kTN / 2) + l15) * kLdT + l4];                         \
     _Pragma("unroll") for (int kk = 0; kk < kBKT / 4; ++kk) {                                      \
       double a[kMT], b[kNT];                                                                       \
       _Pragma("unroll") for (int m = 0; m < kMT; ++m) a[m] = sa[m * 16 * kLdT + kk * 4];           \
@@ -179,7 +182,8 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* C, long ldc, const doub
 // Launched in slices of the tile enumeration [tile_off, tile_off + gridDim.x).
 __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tile_off, int main_t,
                                                                    int jump_t) {
-  gemm_nt_f64_body<0, 1, 16, 1, 128, 128>(C, ldc, A, lda, A, lda, K, 0, tile_off, main_t, jump_t);
+  SK_GEMM_LDS(16, 128, 128)
+  gemm_nt_f64_body<0, 1, 16, 1, 128, 128>(sh, C, ldc, A, lda, A, lda, K, 0, tile_off, main_t, jump_t);
 }
 // The same update for a SMALL trailing matrix (block envelope: a few dozen block rows): as a rectangle of 32 x 128
 // tiles with the tiles above the diagonal dropped.  A 128 x 128 tile with K = 128 is one workgroup-latency of
@@ -187,14 +191,16 @@ __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, lo
 // times as many workgroups, each a quarter as long, and the whole launch fits in two rounds.
 __global__ __launch_bounds__(256, 2) void syrk_trailing_thin_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tiles_m, int main_t,
                                                                         int jump_t, int main_n, int jump_n) {
-  gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(C, ldc, A, lda, A, lda, K, tiles_m, 1, main_t, jump_t, main_n, jump_n);
+  SK_GEMM_LDS(16, 32, 128)
+  gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(sh, C, ldc, A, lda, A, lda, K, tiles_m, 1, main_t, jump_t, main_n, jump_n);
 }
 // Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
 // transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
 // The K range is split over blockIdx.y (chunk c covers columns [c*K, (c+1)*K) of A and writes slab c of C):
 // a few thousand tiles x one huge K leave a ragged last wave of workgroups; tiles x chunks do not.
 __global__ __launch_bounds__(256, 2) void syrk_gram_f64_kernel(double* C, long ldc, size_t slab_stride, const double* A, long lda, int K) {
-  gemm_nt_f64_body<1, 1, 16, 1, 128, 128>(C + (size_t)blockIdx.y * slab_stride, ldc, A + (size_t)blockIdx.y * K, lda, A + (size_t)blockIdx.y * K, lda, K, 0, 0);
+  SK_GEMM_LDS(16, 128, 128)
+  gemm_nt_f64_body<1, 1, 16, 1, 128, 128>(sh, C + (size_t)blockIdx.y * slab_stride, ldc, A + (size_t)blockIdx.y * K, lda, A + (size_t)blockIdx.y * K, lda, K, 0, 0);
 }
 // H = sum of the slabs, in slab order (deterministic); lower-triangular 128x128 tiles only
 __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ H, const double* __restrict__ slabs, size_t slab_stride, long ld,
@@ -216,30 +222,35 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(double* __restrict__ H
 __global__ __launch_bounds__(256, 2) void gemm_update_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
                                                                  long ldb, int K, int tiles_m, int skip, int main_t, int jump_t) {
   __builtin_amdgcn_s_setprio(2);  // on the critical path of the factorisation
-  gemm_nt_f64_body<0, 0, 16, 2, 64, 128>(C, ldc, A, lda, B, ldb, K, tiles_m, skip, main_t, jump_t);
+  SK_GEMM_LDS(16, 64, 128)
+  gemm_nt_f64_body<0, 0, 16, 2, 64, 128>(sh, C, ldc, A, lda, B, ldb, K, tiles_m, skip, main_t, jump_t);
 }
 // 32 x 128 tiles for short panels (a sparse envelope leaves a few dozen block rows per column): twice the
 // workgroups again, each with half the rows to fetch; these kernels are bound by the latency of one workgroup.
 __global__ __launch_bounds__(256, 2) void gemm_update_thin_f64_kernel(double* C, long ldc, const double* A, long lda, const double* B,
                                                                       long ldb, int K, int tiles_m, int skip, int main_t, int jump_t) {
   __builtin_amdgcn_s_setprio(2);
-  gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(C, ldc, A, lda, B, ldb, K, tiles_m, skip, main_t, jump_t);
+  SK_GEMM_LDS(16, 32, 128)
+  gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(sh, C, ldc, A, lda, B, ldb, K, tiles_m, skip, main_t, jump_t);
 }
 __global__ __launch_bounds__(256, 2) void trsm_gemm_thin_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
                                                                     int tiles_m, int main_t, int jump_t) {
   __builtin_amdgcn_s_setprio(2);
-  gemm_nt_f64_body<1, 0, 16, 2, 32, 128>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0, main_t, jump_t);
+  SK_GEMM_LDS(16, 32, 128)
+  gemm_nt_f64_body<1, 0, 16, 2, 32, 128>(sh, C, ldc, A, lda, Linv, 128, 128, tiles_m, 0, main_t, jump_t);
 }
 // One 128 x 128 diagonal block, C -= A A^T, as 64 x 64 tiles (the upper one skipped): potrf128 waits on it.
 __global__ __launch_bounds__(256, 1) void gemm_diag_f64_kernel(double* C, long ldc, const double* A, long lda, int K) {
   __builtin_amdgcn_s_setprio(3);
-  gemm_nt_f64_body<0, 0, 32, 2, 64, 64>(C, ldc, A, lda, A, lda, K, 2, 4);
+  SK_GEMM_LDS(32, 64, 64)
+  gemm_nt_f64_body<0, 0, 32, 2, 64, 64>(sh, C, ldc, A, lda, A, lda, K, 2, 4);
 }
 // TRSM as a GEMM with the inverted diagonal block: C = A Linv^T (in place, C == A); 64 x 128 tiles.
 __global__ __launch_bounds__(256, 2) void trsm_gemm_f64_kernel(double* C, long ldc, const double* A, long lda, const double* Linv,
                                                                int tiles_m, int main_t, int jump_t) {
   __builtin_amdgcn_s_setprio(2);
-  gemm_nt_f64_body<1, 0, 16, 2, 64, 128>(C, ldc, A, lda, Linv, 128, 128, tiles_m, 0, main_t, jump_t);
+  SK_GEMM_LDS(16, 64, 128)
+  gemm_nt_f64_body<1, 0, 16, 2, 64, 128>(sh, C, ldc, A, lda, Linv, 128, 128, tiles_m, 0, main_t, jump_t);
 }
 
 // ---------------------------------------------------------------------------
@@ -491,8 +502,7 @@ __device__ long long g_potrf_stamps[4][16], g_potrf_clk[4][16];
 #define SK_STAMP(i)
 #endif
 
-__global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __forceinline__ void potrf128_body(double* lds, double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
   double* T = lds;                      // blocks 0..9: lower triangle of the tile (diagonal slots end as W_jj); 10..15: inverse, below the diagonal
   double* E = lds + 16 * kBlk;          // blocks 16, 17: staging of L_jj on its way to global memory (even / odd jb)
   double* colbuf = lds + 18 * kBlk;     // 3 x 64 doubles
@@ -709,6 +719,207 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 #undef SK_GI
 }
 
+__global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  potrf128_body(lds, A, ld, Linv, info);
+}
+
+// ---------------------------------------------------------------------------
+// The panel chain of an envelope factorisation (groups of one block column) without a kernel launch on
+// it.  Per block column j the serial dependence is
+//   potrf(j) -> X(j+1,j) = S(j+1,j) W_jj^T -> S(j+1,j+1) -= X X^T -> potrf(j+1)
+// and as four launches on one stream each arrow costs 8-10 us of dispatch and completion-signal latency
+// (tools/queue_overheads.hip), twice the arithmetic.  Here
+//   potrf_server_kernel   ONE workgroup, launched once per factorisation, factors the diagonal blocks one
+//                         after the other as their last update lands;
+//   chain_column_kernel   one launch per block column j, enqueued ahead of time: 32 x 128 tiles of the active
+//                         rows below the diagonal.  Its workgroups wait for potrf(j), form X(.,j) (the TRSM as a
+//                         GEMM with W_jj), wait for X(j+1,j) and for syrk(j-1) on the bulk stream, and apply
+//                         panel j to block column j+1 ("next(j)" of cholesky_factor);
+// hand over through counters in device memory (ChainSync): a producer's data is written back to memory
+// (device-scope release) before its counter moves, a consumer invalidates its caches (acquire) after it
+// saw the counter — the L2 caches of the 8 XCDs are not coherent with each other inside a kernel.
+// Launches of one stream still follow each other in order, so column j+1's workgroups start (and wait)
+// while potrf(j+1) runs, and their dispatch latency is off the chain.
+// No workgroup waits for a workgroup with a higher block index of its own launch, the server workgroup is
+// resident before the first column launch, and every wait gives up after kChainTimeoutTicks (then sets
+// the abort flag, which ends every other wait, and *info): the grid always drains.
+// ---------------------------------------------------------------------------
+enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncHeader = 8 };  // then diag_ready[maxblk], x_ready[maxblk]
+constexpr long long kChainTimeoutTicks = 300000000;  // 3 s of the 100 MHz wall clock
+
+// developer timeline (SK_CHAIN_STAMPS=<file>): wall-clock stamps of the server and of tile 0 of every column launch
+__device__ long long g_chain_stamps[1024][8];
+__device__ int g_chain_stamps_on;
+#define SK_CHAIN_STAMP(col, i) if (g_chain_stamps_on && threadIdx.x == 0 && (col) < 1024) g_chain_stamps[col][i] = wall_clock64();
+__device__ __forceinline__ int sync_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane: wait until *p >= target; false = aborted / timed out
+__device__ __forceinline__ bool chain_wait(const int* p, int target, int* abort_flag) {
+  if (sync_load(p) < target) {
+    const long long t0 = wall_clock64();
+    do {
+      __builtin_amdgcn_s_sleep(4);
+      if (sync_load(abort_flag) != 0) return false;
+      if (wall_clock64() - t0 > kChainTimeoutTicks) {
+        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    } while (sync_load(p) < target);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidation has completed before the barrier that releases the other waves
+  return true;
+}
+// every wave of a consumer invalidates after the workgroup barrier that follows the wait
+#ifdef SK_CHAIN_STRONG_FENCES
+#define SK_CHAIN_ACQUIRE_ALL __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+#define SK_CHAIN_ACQUIRE_ALL
+#endif
+// whole workgroup: every wave's stores have reached the L2, then one lane writes the L2 back and moves the counter
+__device__ __forceinline__ void chain_publish(int* p, int add) {
+#ifdef SK_CHAIN_STRONG_FENCES
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(p, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's stores are in the L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // one write-back of the L2 covers every wave's
+    __hip_atomic_fetch_add(p, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
+}
+
+__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, int first, int nblk, double* Linv, int* info, int* sync, int maxblk) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ int ok_s;
+  for (int j = first; j < nblk; ++j) {
+    if (j > 0) {
+      if (threadIdx.x == 0) ok_s = chain_wait(sync + kSyncHeader + j, 16, sync + kSyncAbort) ? 1 : 0;
+      __syncthreads();
+      if (!ok_s) {
+        if (threadIdx.x == 0) *info = 2;
+        return;
+      }
+      SK_CHAIN_ACQUIRE_ALL
+    }
+    SK_CHAIN_STAMP(j, 0)
+    potrf128_body(lds, S + (long)j * 128 * ld + (long)j * 128, ld, Linv + (long)j * 128 * 128, info);
+    chain_publish(sync + kSyncPotrfDone, j == first ? first + 1 : 1);  // the counter reads j + 1 after column j
+    SK_CHAIN_STAMP(j, 1)
+  }
+}
+
+// One 32 x 32 tile with K = 128 in a single memory round trip: C = A B^T (kMode 1) or C -= A B^T (kMode 0), A and B
+// 32 x 128 row slices.  Every load of the workgroup is in flight at once, then 32 MFMAs per wave (one 16 x 16
+// quadrant each): about 3 us against 9 us for the K-stepped 32 x 128 tile, whose eight steps each wait for a
+// round trip that nothing hides on the serial chain.  Same operation sequence per element as gemm_nt_f64_body
+// (k ascending, one accumulator).  shp: 2 * 32 * kCritLd doubles.
+constexpr int kCritLd = 130;
+__device__ __forceinline__ void crit_tile_load(double* shp, const double* A, long lda, const double* B, long ldb) {
+  const int t = threadIdx.x, row = t >> 3, c0 = (t & 7) * 16;
+  double2 va[8], vb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) va[i] = *reinterpret_cast<const double2*>(A + (long)row * lda + c0 + 2 * i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) vb[i] = *reinterpret_cast<const double2*>(B + (long)row * ldb + c0 + 2 * i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(shp + row * kCritLd + c0 + 2 * i) = va[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(shp + (32 + row) * kCritLd + c0 + 2 * i) = vb[i];
+}
+__device__ __forceinline__ d4 crit_tile_mma(const double* shp, d4 acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const double* sa = shp + ((wave >> 1) * 16 + l15) * kCritLd + l4;
+  const double* sb = shp + (32 + (wave & 1) * 16 + l15) * kCritLd + l4;
+#pragma unroll
+  for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk * 4], sb[kk * 4], acc, 0, 0, 0);
+  return acc;
+}
+// element i of a wave's accumulator: row (wave >> 1) * 16 + (lane >> 4) + 4 i, column (wave & 1) * 16 + (lane & 15) of the tile
+__device__ __forceinline__ long crit_tile_off(long ldc, int i) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  return (long)((wave >> 1) * 16 + (lane >> 4) + 4 * i) * ldc + (wave & 1) * 16 + (lane & 15);
+}
+
+// Workgroups [0, ncrit): the 16 tiles (32 x 32) of block row j+1, which the server waits for; the rest: 32 x 128 tiles
+// of the other active rows (thin tile 4 + (blockIdx.x - ncrit)).  ncrit == 0: block row j+1 is outside the envelope.
+// Xs: 128 x 128 scratch.  X(j+1,j) cannot be formed in place tile by tile (every column tile reads whole rows of
+// S(j+1,j)): the tiles go to Xs, which next(j) reads, and into S(j+1,j) once all 16 are known to have loaded theirs.
+__global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld, int j, const double* Linv_j, int tiles_m, int main_t, int jump_t,
+                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need) {
+  __shared__ __attribute__((aligned(16))) double sh[2 * 32 * kCritLd];
+  static_assert(2 * 32 * kCritLd >= gemm_lds_doubles(16, 32, 128), "LDS of the thin tiles");
+  __shared__ int ok_s;
+  __builtin_amdgcn_s_setprio(2);
+  double* A21 = S + (long)(j + 1) * 128 * ld + (long)j * 128;
+  int* x_ready = sync + kSyncHeader + maxblk + j;
+  int* diag_ready = sync + kSyncHeader + j + 1;
+  const int b = blockIdx.x;
+  const bool crit = b < ncrit;
+  const int ri = b >> 2, q = b & 3;        // critical tile: rows ri * 32, columns q * 32 of the block
+  const int thin_id = 4 + (b - ncrit);     // other workgroups (ncrit == 16), or every workgroup from 0 (ncrit == 0)
+  const int thin_bid = ncrit ? thin_id : b;
+  const bool stamp = b == 0;
+  if (stamp) SK_CHAIN_STAMP(j, 2)
+  if (threadIdx.x == 0) ok_s = chain_wait(sync + kSyncPotrfDone, j + 1, sync + kSyncAbort) ? 1 : 0;
+  __syncthreads();
+  if (!ok_s) return;
+  SK_CHAIN_ACQUIRE_ALL
+  if (stamp) SK_CHAIN_STAMP(j, 3)
+  // ---- X(r,j) = S(r,j) W_jj^T
+  d4 xacc = {0.0, 0.0, 0.0, 0.0};
+  if (crit) {
+    crit_tile_load(sh, A21 + (long)ri * 32 * ld, ld, Linv_j + (long)q * 32 * 128, 128);
+    __syncthreads();
+    xacc = crit_tile_mma(sh, xacc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Xs[(long)(ri * 32) * 128 + q * 32 + crit_tile_off(128, i)] = xacc[i];
+    chain_publish(x_ready, 1);
+  } else {
+    gemm_nt_f64_body<1, 0, 16, 2, 32, 128>(sh, A21, ld, A21, ld, Linv_j, 128, 128, tiles_m, 0, main_t, jump_t, 0x7fffffff, 0, thin_bid);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (stamp) SK_CHAIN_STAMP(j, 4)
+  if (threadIdx.x == 0)
+    ok_s = (chain_wait(x_ready, ncrit, sync + kSyncAbort) && chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort)) ? 1 : 0;
+  __syncthreads();
+  if (!ok_s) return;
+  SK_CHAIN_ACQUIRE_ALL
+  if (stamp) SK_CHAIN_STAMP(j, 5)
+  // ---- next(j): S(r,j+1) -= X(r,j) X(j+1,j)^T
+  if (crit) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A21[(long)(ri * 32) * ld + q * 32 + crit_tile_off(ld, i)] = xacc[i];  // every tile has read S(j+1,j) by now
+    if (q <= ri) {  // the server reads the lower 32-blocks only
+      double* Ct = A21 + 128 + (long)(ri * 32) * ld + q * 32;
+      d4 acc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = -Ct[crit_tile_off(ld, i)];
+      crit_tile_load(sh, Xs + (long)ri * 32 * 128, 128, Xs + (long)q * 32 * 128, 128);
+      __syncthreads();
+      acc = crit_tile_mma(sh, acc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Ct[crit_tile_off(ld, i)] = -acc[i];
+    }
+    chain_publish(diag_ready, 1);
+  } else {
+    const double* Bx = ncrit ? (const double*)Xs : (const double*)A21;
+    gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(sh, A21 + 128, ld, A21, ld, Bx, ncrit ? 128 : ld, 128, tiles_m, 1, main_t, jump_t, 0x7fffffff, 0, thin_bid);
+    if (ncrit == 0 && b == 0) chain_publish(diag_ready, 16);
+  }
+  if (stamp) SK_CHAIN_STAMP(j, 6)
+}
+
+// after a SYRK on its stream: the SYRK's completion (and its end-of-kernel write-back) as a counter the chain can poll
+__global__ void chain_marker_kernel(int* flag, int seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------
 // Backward substitution L^T y = z over 128-blocks, last block first; one
 // launch per block step kb:
@@ -774,6 +985,8 @@ size_t potrf128_lds_bytes() { return g_potrf_lds; }
 static int g_thin_grid = 512;  // panel launches of at most this many 32-row workgroups use the 32 x 128 kernels (developer knob SK_THIN_GRID)
 static int g_ext_events = 1;  // events on the producing kernel's own dispatch (developer knob SK_LA_EXT_EVENTS=0: separate records)
 static unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;  // developer knob SK_LA_SYSTEM_FENCE=1: default fences
+static int g_chain_server = 1;  // developer knob SK_CHOL_CHAIN_SERVER=0: the launch-per-step panel chain even where the resident one applies
+static int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see cholesky_plan (developer knobs SK_CHAIN_MAX_TRAILING, SK_CHAIN_PREFIX_GROUP)
 static int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK (developer knob SK_THIN_SYRK)
 static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
 hipError_t cholesky_init() {
@@ -783,17 +996,38 @@ hipError_t cholesky_init() {
   if (const char* e = getenv("SK_THIN_SYRK")) g_thin_syrk_tiles = atoi(e);
   if (const char* e = getenv("SK_LA_SYSTEM_FENCE")) { if (atoi(e)) g_event_flags = hipEventDisableTiming; }
   if (const char* e = getenv("SK_LA_EXT_EVENTS")) g_ext_events = atoi(e);
+  if (const char* e = getenv("SK_CHOL_CHAIN_SERVER")) g_chain_server = atoi(e);
+  if (const char* e = getenv("SK_CHAIN_MAX_TRAILING")) g_chain_max_trailing = atoi(e);
+  if (const char* e = getenv("SK_CHAIN_PREFIX_GROUP")) g_chain_prefix_group = atoi(e);
+  hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_server_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_potrf_lds);
+  if (rc != hipSuccess) return rc;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 CholeskyContext::~CholeskyContext() {
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
+  if (sync) (void)hipFree(sync);
+  if (xs) (void)hipFree(xs);
+}
+
+int* CholeskyContext::sync_for(int nblk) {
+  if (!xs && hipMalloc(reinterpret_cast<void**>(&xs), sizeof(double) * 128 * 128) != hipSuccess) { (void)hipGetLastError(); xs = nullptr; return nullptr; }
+  if (nblk > sync_blk) {
+    if (sync) (void)hipFree(sync);
+    sync = nullptr;
+    sync_blk = 0;
+    const int cap = (nblk + 255) / 256 * 256;
+    if (hipMalloc(reinterpret_cast<void**>(&sync), sizeof(int) * (size_t)(kSyncHeader + 2 * cap)) != hipSuccess) { (void)hipGetLastError(); sync = nullptr; return nullptr; }
+    sync_blk = cap;
+  }
+  return sync;
 }
 
 // The two streams are created once per process and shared by every context (one process drives one
 // GPU): creating a second CU-masked stream after destroying the first one hangs on this ROCm build.
-static hipStream_t g_panel_stream = nullptr, g_bulk_stream = nullptr, g_bulk_early_stream = nullptr;
+static hipStream_t g_panel_stream = nullptr, g_bulk_stream = nullptr, g_bulk_early_stream = nullptr, g_server_stream = nullptr;
 static int g_reserved_cus = 0, g_early_tiles = 0;
+
 
 // stream whose kernels stay off the first `per_xcd` CUs of every XCD (plain stream when per_xcd == 0 or masks are unavailable)
 static hipError_t create_bulk_stream(hipStream_t* out, int per_xcd, int ncu, int* reserved) {
@@ -829,16 +1063,38 @@ hipError_t CholeskyContext::init() {
       (void)hipStreamDestroy(p);
       return rc;
     }
+    // The resident potrf workgroup gets a CU of its own (XCD 0, CU 0 — the bulk masks exclude it already) and a
+    // hardware queue of its own: a CU-masked stream owns its queue, a plain one is mapped onto a small shared pool
+    // and could end up behind a stream it waits for.  The panel stream is masked to every other CU, so the
+    // workgroups that wait for the server can never occupy the CU it needs (150 KB of LDS).
+    hipStream_t sv = nullptr;
+    if (reserved > 0) {
+      std::vector<uint32_t> one((size_t)(ncu + 31) / 32, 0u), rest((size_t)(ncu + 31) / 32, 0u);
+      one[0] = 1u;
+      for (int i = 1; i < ncu; ++i) rest[(size_t)i / 32] |= 1u << (i % 32);
+      hipStream_t pm = nullptr;
+      if (hipExtStreamCreateWithCUMask(&sv, (uint32_t)one.size(), one.data()) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&pm, (uint32_t)rest.size(), rest.data()) == hipSuccess) {
+        (void)hipStreamDestroy(p);  // a plain stream: safe to destroy
+        p = pm;
+      } else {
+        (void)hipGetLastError();
+        sv = nullptr;  // (a masked stream that was created stays allocated: destroying one hangs the next creation on this ROCm build)
+      }
+    }
+    g_server_stream = sv;
     g_panel_stream = p; g_bulk_stream = b; g_bulk_early_stream = be; g_reserved_cus = reserved; g_early_tiles = early_tiles;
     // destroyed once, at process exit, before the HIP runtime's own teardown (handlers run in reverse order of registration)
     atexit([] {
       if (g_bulk_stream) (void)hipStreamDestroy(g_bulk_stream);
       if (g_bulk_early_stream) (void)hipStreamDestroy(g_bulk_early_stream);
       if (g_panel_stream) (void)hipStreamDestroy(g_panel_stream);
-      g_bulk_stream = g_bulk_early_stream = g_panel_stream = nullptr;
+      if (g_server_stream) (void)hipStreamDestroy(g_server_stream);
+      g_bulk_stream = g_bulk_early_stream = g_panel_stream = g_server_stream = nullptr;
     });
   }
   panel = g_panel_stream; bulk = g_bulk_stream; bulk_early = g_bulk_early_stream; reserved_cus = g_reserved_cus; early_tiles = g_early_tiles;
+  server = g_server_stream;
   return hipSuccess;
 }
 
@@ -871,6 +1127,51 @@ std::vector<int> cholesky_group_bounds(int nblk, int group) {
   return b;
 }
 
+// The groups actually used, and the block column from which the resident panel chain (potrf_server_kernel /
+// chain_column_kernel) takes over: the longest suffix of block columns whose trailing update is short (at most
+// g_chain_max_trailing tile rows: the serial chain, not the SYRK, decides there — measured on Ladybug-1723, a
+// column cycle is 44-50 us up to 13 trailing tile rows, 60 us at 20, 100 us at 30) and whose panels fit the 32-row
+// tiles.  Those columns are groups of one; the columns before them are factored launch by launch in groups of
+// `group` (of g_chain_prefix_group when the caller asked for 1: their SYRK is the long pole, and K = 128 leaves it
+// bound by the traffic of its C tiles).  chain == false: cholesky_group_bounds, no resident chain.
+CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain) {
+  CholeskyPlan plan;
+  plan.chain_from = nblk;
+  if (group < 1) group = 1;
+  if (!chain || !g_chain_server || nblk < 3) {
+    plan.bounds = cholesky_group_bounds(nblk, group);
+  } else {
+    auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
+    auto count = [&](int first_row, int last_row) {  // active block rows from first_row: the run up to last_row, and block row nblk-1
+      const int main_rows = last_row >= first_row ? last_row - first_row + 1 : 0;
+      return main_rows + ((first_row + main_rows <= nblk - 1 && last_row < nblk - 1) ? 1 : 0);
+    };
+    int c0 = nblk - 1;
+    for (int j = nblk - 2; j >= 0; --j) {
+      if (count(j + 2, last_main(j)) > g_chain_max_trailing || 4 * count(j + 1, last_main(j)) > g_thin_grid) break;
+      c0 = j;
+    }
+    if (c0 > nblk - 3) { plan.bounds = cholesky_group_bounds(nblk, group); return plan; }
+    const int pg = group == 1 ? g_chain_prefix_group : group;
+    int k = 0;
+    while (k < c0) {
+      plan.bounds.push_back(k);
+      int g = nblk - k <= g_tail_tiles ? g_tail_group : pg;
+      if (g < 1) g = 1;
+      k += g < c0 - k ? g : c0 - k;
+    }
+    for (; k < nblk; ++k) plan.bounds.push_back(k);
+    plan.bounds.push_back(nblk);
+    plan.chain_from = c0;
+  }
+  return plan;
+}
+int cholesky_plan_max_group(const CholeskyPlan& plan) {
+  int m = 1;
+  for (size_t g = 0; g + 1 < plan.bounds.size(); ++g) m = std::max(m, plan.bounds[g + 1] - plan.bounds[g]);
+  return m;
+}
+
 // Factor the lower triangle of S (npad x ld) in place.  Linv: nblk blocks of 128x128
 // (zero-initialised once).  Right-looking over groups of `group` block columns, lazy
 // left-looking inside a group.
@@ -893,7 +1194,7 @@ std::vector<int> cholesky_group_bounds(int nblk, int group) {
 // dense algorithm too (0 - 0 * x), so the result is bit-identical to last == nullptr; only the work differs
 // (Ladybug-1723-shaped S: 0.17 of 1.27 TFlop).
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt, const int* last) {
+                     KernelTimer* kt, const int* last, bool allow_chain) {
   const int nblk = npad / 128;
   const bool la = ctx != nullptr && ctx->panel != nullptr && ctx->bulk != nullptr;
   hipStream_t sp = la ? ctx->panel : s;
@@ -968,12 +1269,29 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       }
     }
   };
-  const std::vector<int> gb = cholesky_group_bounds(nblk, group);
+  // the resident panel chain from block column c0 on (cholesky_plan); not while every chain kernel is being timed
+  const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr && !(kt && kt->times_all()));
+  const std::vector<int>& gb = plan.bounds;
   const int ngroups = (int)gb.size() - 1;
+  int c0 = plan.chain_from;
+  int* sync = c0 < nblk ? ctx->sync_for(nblk) : nullptr;
+  if (!sync) c0 = nblk;  // (the same groups, launch by launch)
+  const bool chain = c0 < nblk;
+  const int maxblk = chain ? ctx->sync_blk : 0;
+  const char* stamps_file = chain ? getenv("SK_CHAIN_STAMPS") : nullptr;
+  if (chain) {
+    const int stamps_on = stamps_file ? 1 : 0;
+    static int stamps_state = 0;
+    if (stamps_on != stamps_state) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamps_on), &stamps_on, sizeof(int)); stamps_state = stamps_on; }
+    (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * maxblk), s);
+    order(s, ctx->server);
+    hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), ctx->server, S, ld, c0, nblk, Linv, info, sync, maxblk);
+  }
   order(s, sp);
   if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }
-  panel(gb[0], gb[1]);
+  if (c0 > 0) panel(gb[0], gb[1]);
   hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
+  int seq = 0;                     // SYRK completions announced to the chain so far (chain_marker_kernel)
   for (int g = 0; g + 1 < ngroups; ++g) {
     const int k0 = gb[g], k1 = gb[g + 1];
     const int K = (k1 - k0) * 128;
@@ -984,15 +1302,26 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
     const int Tb = rs.main + rs.extra;
+    const bool resident = chain && k0 >= c0;  // potrf(k0) by the server; TRSM and next(g) by one column launch
     if (la) sb = Tb >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
     if (sb != sb_prev && syrk_done) (void)hipStreamWaitEvent(sb, syrk_done, 0);  // syrk(g) after syrk(g-1) across the two bulk streams
     sb_prev = sb;
-    // panel(g) is final: syrk(g) may start (after syrk(g-1))
-    if (panel_done) (void)hipStreamWaitEvent(sb, panel_done, 0);
-    else order(sp, sb);
-    // next(g): active rows x na tiles, above-diagonal tiles skipped; on the panel stream, after syrk(g-1)
-    if (la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
-    update(sp, "gemm_syrk_next", A22, P, P, K, rn, na, 1);
+    if (resident) {
+      const int T = rn.main + rn.extra;  // rows of X(.,k0) == rows that next(g) updates (K = 128, na == 1)
+      // block row k0+1 is active as the start of the main run, or as the last block row itself
+      const int ncrit = (rn.main > 0 || rn.jump == 0) ? 16 : 0;
+      hipEvent_t col_done = Tb > 0 ? ctx->event(ev++) : nullptr;
+      hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, col_done, 0, S, ld, k0,
+                            (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq);
+      if (col_done) (void)hipStreamWaitEvent(sb, col_done, 0);
+    } else {
+      // panel(g) is final: syrk(g) may start (after syrk(g-1))
+      if (panel_done) (void)hipStreamWaitEvent(sb, panel_done, 0);
+      else order(sp, sb);
+      // next(g): active rows x na tiles, above-diagonal tiles skipped; on the panel stream, after syrk(g-1)
+      if (la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
+      update(sp, "gemm_syrk_next", A22, P, P, K, rn, na, 1);
+    }
     // syrk(g): everything right of them, lower triangle over the active rows
     syrk_done = nullptr;
     if (Tb > 0) {
@@ -1005,12 +1334,38 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       else
         hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
       if (kt) kt->end("gemm_syrk", sb);
-      if (la) { syrk_done = ctx->event(ev++); (void)hipEventRecord(syrk_done, sb); }
+      if (chain && k1 >= c0) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, ++seq);
+      // the launch-by-launch next(g+1) waits for this SYRK as an event; so does a SYRK that follows on the other bulk stream
+      bool record = la && !(chain && k1 >= c0);
+      if (la && !record && g + 3 < (int)gb.size()) {
+        const Rows rs1 = rows_from(gb[g + 3], last_main(gb[g + 2] - 1));
+        record = (rs1.main + rs1.extra >= ctx->early_tiles) != (sb == ctx->bulk_early);
+      }
+      if (record) { syrk_done = ctx->event(ev++); (void)hipEventRecord(syrk_done, sb); }
     }
-    panel(k1, k1 + na);
+    if (resident) continue;
+    if (chain && k1 == c0)  // hand-over: block (c0, c0) has its last launch-by-launch update; the server takes it from here
+      hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sp, sync + kSyncHeader + c0, 16);
+    else
+      panel(k1, k1 + na);
   }
   order(sp, s);
   if (la) { order(ctx->bulk, s); order(ctx->bulk_early, s); }
+  if (chain) order(ctx->server, s);
+  if (stamps_file) {
+    (void)hipStreamSynchronize(s);
+    std::vector<long long> st((size_t)1024 * 8);
+    (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_chain_stamps), st.size() * sizeof(long long));
+    if (FILE* f = fopen(stamps_file, "w")) {
+      for (int j = c0; j < nblk && j < 1024; ++j) {
+        fprintf(f, "%d ", j);
+        for (int i = 0; i < 7; ++i) fprintf(f, "%lld ", st[(size_t)j * 8 + i]);
+        const Rows rs = rows_from(j + 2, last_main(j));
+        fprintf(f, "%d\n", rs.main + rs.extra);
+      }
+      fclose(f);
+    }
+  }
 }
 
 // y (npad) <- solution of L^T y = z, with z^T = row rhs_row of L (first n entries).  w: scratch (npad).
@@ -1049,9 +1404,9 @@ void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, in
 
 // Algorithmic flops of the dominant kernel's launches (part (b) of each trailing SYRK:
 // lower-triangular 128x128 tiles incl. the diagonal tiles, 2*128*128*K each).
-double cholesky_syrk_flops(int npad, int group, const int* last) {
+double cholesky_syrk_flops(int npad, int group, const int* last, bool chain) {
   const int nblk = npad / 128;
-  const std::vector<int> gb = cholesky_group_bounds(nblk, group);
+  const std::vector<int> gb = cholesky_plan(nblk, group, last, chain).bounds;
   double f = 0.0;
   for (size_t g = 0; g + 2 < gb.size(); ++g) {
     const int k0 = gb[g], k1 = gb[g + 1], na = gb[g + 2] - k1;

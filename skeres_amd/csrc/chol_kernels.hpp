@@ -19,6 +19,7 @@ class KernelTimer {
   // small kernel of the panel chain would slow the chain it measures.
   void only(const std::string& name) { only_ = name; }
   bool enabled() const { return enabled_; }
+  bool times_all() const { return enabled_ && only_.empty(); }
   void begin(const char* name, hipStream_t s) {
     if (!enabled_) return;
     if (!only_.empty() && only_ != name) { skip_ = true; return; }
@@ -83,6 +84,11 @@ struct CholeskyContext {
   hipStream_t bulk_early = nullptr;  // SYRK of the early groups (long SYRK hides a slow chain: fewer CUs kept free)
   int early_tiles = 0;               // groups with at least this many trailing tile rows use bulk_early
   int reserved_cus = 0;              // CUs kept free of the SYRK on `bulk` (0: ordinary stream)
+  hipStream_t server = nullptr;      // the resident potrf workgroup of the chain-server factorisation (own hardware queue)
+  int* sync = nullptr;               // its counters (device memory), sized for sync_blk block columns
+  int sync_blk = 0;
+  double* xs = nullptr;              // 128 x 128 scratch: X(j+1,j) of the column in flight
+  int* sync_for(int nblk);
   std::vector<hipEvent_t> events;
   hipError_t init();
   hipEvent_t event(size_t i);
@@ -94,11 +100,18 @@ size_t potrf128_lds_bytes();
 // Factor the lower triangle of S (npad x ld, npad % 128 == 0) in place.
 // Linv: (npad/128) blocks of 128x128, zero-initialised once by the caller.
 // ctx == nullptr: everything on `s`; otherwise the panel chain overlaps the trailing SYRK.
+// allow_chain: the grouping is the library's to choose (cholesky_plan): resident panel chain for the chain-bound columns.
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt, const int* last = nullptr);
+                     KernelTimer* kt, const int* last = nullptr, bool allow_chain = false);
+struct CholeskyPlan {
+  std::vector<int> bounds;  // group start columns + nblk
+  int chain_from = 0;       // first block column of the resident panel chain (nblk: none)
+};
+CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain);
+int cholesky_plan_max_group(const CholeskyPlan& plan);
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
                         hipStream_t s, KernelTimer* kt, const int* last = nullptr);
-double cholesky_syrk_flops(int npad, int group, const int* last = nullptr);
+double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false);
 std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col);
 std::vector<int> cholesky_group_bounds(int nblk, int group);
 void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,

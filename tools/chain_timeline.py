@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Developer tool: timeline of the resident panel chain (SK_CHAIN_STAMPS) on the Ladybug-1723-shaped solve.
+Per block column: when the server started / finished potrf, and when tile 0 of the column launch started, saw potrf,
+finished the TRSM, saw X(j+1,j) and syrk(j-1), finished next(j) — microseconds relative to the server's start."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import skeres_amd as sk  # noqa: E402
+from skeres_amd import bal  # noqa: E402
+
+
+def main():
+    path = os.path.join(tempfile.gettempdir(), "sk_chain_stamps.txt")
+    os.environ["SK_CHAIN_STAMPS"] = path
+    prob = bal.generate_named(sys.argv[1] if len(sys.argv) > 1 else "ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1))
+    params = sk.RichDoubleArray.fromArray(prob.parameters)
+    problem = sk.Problem()
+    offs = np.stack([9 * prob.camera_index.astype(np.int64), 9 * prob.num_cameras + 3 * prob.point_index.astype(np.int64)], axis=1)
+    problem.addResidualBlocks(1, prob.observations, None, params, offs)
+    o = sk.Solver.Options()
+    o.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    o.setMaxNumIterations(1000)
+    o.setFunctionTolerance(0.0)
+    o.setGradientTolerance(0.0)
+    o.setParameterTolerance(0.0)
+    s = sk.StepSolver(o, problem)
+    for _ in range(4):
+        s.step()
+    raw = np.loadtxt(path)
+    cols, st = raw[:, 0].astype(int), raw[:, 1:]
+    t0 = st[0, 0]
+    us = (st - t0) * 0.01
+    names = ["potrf start", "potrf done", "col start", "saw potrf", "trsm done", "saw X+syrk", "next done"]
+    print("col  " + "  ".join("%11s" % n for n in names) + "   cycle  trailing rows")
+    for j in range(len(us)):
+        cyc = us[j, 0] - us[j - 1, 0] if j else 0.0
+        print("%3d  " % cols[j] + "  ".join("%11.1f" % us[j, i] for i in range(7)) + "   %6.1f  %4d" % (cyc, int(st[j, 7])))
+    print("total %.1f us, mean cycle %.1f us" % (us[-1, 1], (us[-1, 0] - us[0, 0]) / (len(us) - 1)))
+
+
+if __name__ == "__main__":
+    main()

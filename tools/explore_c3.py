@@ -55,6 +55,9 @@ def main():
                                                                                        1e6 * sec / max(1, n)))
     summ = sk.Solver.Summary()
     s.finish(summ)
+    n_it = max(1, len(summ.iterations()) - 1)
+    print("device ms per iteration: " + ", ".join("%s %.2f" % (n, 1e3 * summ.phaseSeconds(k) / n_it) for k, n in enumerate(
+        ["jacobian", "assembly (incl. jacobian)", "factor + solve", "back-substitution", "cost", "all-reduce"])))
     for i, it in enumerate(summ.iterations()):
         print("%3d cost %.6e  ok %d  rho %.3f  radius %.2e  |g| %.2e" % (i, it["cost"], it["step_is_successful"], it["relative_decrease"],
                                                                         it["trust_region_radius"], it["gradient_max_norm"]))
