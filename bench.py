@@ -73,7 +73,8 @@ def pmc_traffic():
     if not files:
         return None
     try:
-        k = json.load(open(files[-1]))["kernels"]["sk::syrk_trailing_f64_kernel"]
+        kernels = json.load(open(files[-1]))["kernels"]
+        k = kernels.get("syrk_trailing (both tilings)") or kernels["sk::syrk_trailing_f64_kernel"]
         return k["hbm_bytes_per_launch_corrected"]
     except (KeyError, ValueError, OSError):
         return None
@@ -180,6 +181,7 @@ def main():
 
     syrk_s, syrk_n = solver.kernelSeconds("gemm_syrk")
     syrk_flops = solver.syrkFlopsPerSolve()
+    syrk_c_bytes = solver.syrkCBytesPerSolve()
     summary = sk.Solver.Summary()
     solver.finish(summary)
     # Untimed side measurement: the same kernel with the look-ahead off, i.e. alone on the chip.  In the
@@ -237,19 +239,23 @@ def main():
                                 "replicated x%d: the solver measured %.1f ms for the all-reduce of the reduced system against %.1f ms of "
                                 "per-iteration work sharding would remove, and did not shard" % (world, 1e3 * t_allreduce, 1e3 * t_saved)),
                 "cost_first_timed": timed[0]["cost"] if timed else None, "cost_last_timed": timed[-1]["cost"] if timed else None},
-            "roofline": {"bound": "mfma", "kernel": "sk::syrk_trailing_f64_kernel (Cholesky trailing SYRK, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "sk::syrk_trailing_f64_kernel / sk::syrk_trailing_thin_f64_kernel (Cholesky trailing SYRK, one GEMM "
+                                                     "body in 128x128 and 32x128 tiles, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic() if (args.workload == "ladybug-1723-156502" and args.group <= 0 and not args.full_factorisation) else None,
                          "traffic_note": "bytes/launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled, gfx950; "
-                                         "includes Infinity-Cache hits); algorithmic C-tile bytes/launch (read + write, K = 128 per launch with the "
-                                         "envelope's automatic group of 1) = %.3e" % (
-                                             (syrk_flops / max(1, syrk_n // max(1, args.steps))) / (2.0 * 128 * 128 * 128) * 2 * 131072),
+                                         "includes Infinity-Cache hits; SK_CHOL_CHAIN_SERVER=0: the same launches with no resident kernel, "
+                                         "which counter collection would serialise); algorithmic C-tile bytes/launch (each 128x128 tile of "
+                                         "the trailing matrix read and written once per launch; K = 256 per launch where the SYRK is the "
+                                         "long pole, 128 under the resident panel chain) = %.3e" % (
+                                             syrk_c_bytes / max(1, syrk_n // max(1, args.steps))),
                          "launches": syrk_n, "avg_launch_ms": 1e3 * syrk_s / max(1, syrk_n),
                          "flops_per_solve": syrk_flops,
                          "achieved_alone": alone, "frac_alone": (alone / FP64_MFMA_PEAK_TFLOPS) if alone else None,
                          "note": "achieved/frac: live, inside the timed region, where the SYRK shares the chip with the look-ahead "
-                                 "panel chain (masked off 16-32 CUs); *_alone: same kernel, look-ahead off, 3 untimed steps; "
+                                 "panel chain (masked off 16-32 CUs) and most launches are a few dozen tile rows (a sparse envelope); "
+                                 "*_alone: same kernel, look-ahead off, 3 untimed steps; "
                                  "flops_per_solve counts the blocks inside the envelope only"},
             "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(
                 ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"])},

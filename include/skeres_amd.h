@@ -325,6 +325,10 @@ double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launc
 /* Algorithmic flop count of the dense Cholesky's trailing updates per linear
  * solve (what roofline.achieved is computed from). */
 double sk_solver_syrk_flops_per_solve(const sk_solver* s);
+/* Bytes of the C tiles those launches read and write per linear solve (each 128 x 128 tile once in, once out per
+ * launch): the algorithmic memory traffic of the trailing updates, next to which bench.py reports the measured one.
+ * 0 for solvers that do not report it. */
+double sk_solver_syrk_c_bytes_per_solve(const sk_solver* s);
 /* SK_DISTRIBUTION_SHARDED or _REPLICATED as decided at sk_solver_create; with AUTO, *allreduce_seconds is the
  * measured all-reduce of the reduced system and *saved_seconds the estimated per-iteration work sharding removes
  * (either pointer may be NULL). */

@@ -119,6 +119,7 @@ _SIGS = {
     "sk_solver_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_solver_kernel_seconds": (C.c_double, [C.c_void_p, C.c_char_p, _ip]),
     "sk_solver_syrk_flops_per_solve": (C.c_double, [C.c_void_p]),
+    "sk_solver_syrk_c_bytes_per_solve": (C.c_double, [C.c_void_p]),
     "sk_solver_distribution": (C.c_int, [C.c_void_p, _dp, _dp]),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
@@ -892,6 +893,9 @@ class StepSolver:
 
     def syrkFlopsPerSolve(self):
         return lib().sk_solver_syrk_flops_per_solve(self._h)
+
+    def syrkCBytesPerSolve(self):
+        return lib().sk_solver_syrk_c_bytes_per_solve(self._h)
 
     def distribution(self):
         """("sharded" | "replicated", measured all-reduce seconds, estimated seconds of work sharding removes per iteration)."""

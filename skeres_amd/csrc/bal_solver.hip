@@ -71,6 +71,11 @@ class BalSolver : public SolverBase {
  public:
   BalSolver(const Options& o, Problem* p) : SolverBase(o, p) {}
   double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, group_, env_last_.empty() ? nullptr : env_last_.data(), chain_ok()); }
+  double syrk_c_bytes_per_solve() const override {
+    double tiles = 0.0;
+    (void)cholesky_syrk_flops(npad_, group_, env_last_.empty() ? nullptr : env_last_.data(), chain_ok(), &tiles);
+    return tiles * 2.0 * 128.0 * 128.0 * sizeof(double);
+  }
   // the grouping is the library's choice (Options::cholesky_group == 0) and the masked streams of the resident panel chain exist
   bool chain_ok() const { return opt_.cholesky_group == 0 && opt_.lookahead && chol_ctx_.server != nullptr; }
   int distribution(double* allreduce_s, double* saved_s) const override {
@@ -364,6 +369,7 @@ int BalSolver::setup() {
     (void)hipGetLastError();
     opt_.lookahead = false;
   }
+  if (chain_ok()) cholesky_prepare(&chol_ctx_, s);  // (once per process: which queues the resident panel chain uses)
   SK_HIP_TRY(b_S_.zero(s));  // once: the blocks outside the envelope are never touched again
   {
     // first block column each block row is zeroed from: the row envelope, widened by the SYRK depth - 1 (inside a

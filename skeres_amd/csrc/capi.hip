@@ -464,6 +464,7 @@ double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launc
   return st.seconds;
 }
 double sk_solver_syrk_flops_per_solve(const sk_solver* s) { return s->impl->syrk_flops_per_solve(); }
+double sk_solver_syrk_c_bytes_per_solve(const sk_solver* s) { return s->impl->syrk_c_bytes_per_solve(); }
 int sk_solver_distribution(const sk_solver* s, double* allreduce_seconds, double* saved_seconds) { return s->impl->distribution(allreduce_seconds, saved_seconds); }
 
 int sk_solve(const sk_options* options, sk_problem* problem, sk_summary* summary) {

@@ -15,6 +15,8 @@
 // the trailing matrix.  (1), (3) and the SYRK are one kernel:
 //   gemm_nt_f64_kernel : C (-)= A B^T, 128x128 tile, v_mfma_f64_16x16x4_f64.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
 #include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
@@ -1042,12 +1044,27 @@ static hipError_t create_bulk_stream(hipStream_t* out, int per_xcd, int ncu, int
   return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
 
+// The queues of the panel stream and of the resident potrf workgroup are chosen by measurement.  With some
+// assignments of the process's queues to the command processor's pipes every launch on the panel and bulk streams
+// takes 30-50 us longer for as long as the server is resident — the whole factorisation twice as long.  Which
+// assignment a process gets follows from the order in which it (this library, PyTorch, RCCL) created its queues: one
+// more queue created first flips it (measured: 10.4 / 16.0 / 10.4 / 16.1 ms per iteration with 0 / 1 / 2 / 3 extra
+// queues; over the runs, fast exactly when the panel queue had one parity of creation index and the server queue
+// the other).  Probes with a spinning kernel and event-ordered empty launches do not show the effect, so two
+// queues are created for the bulk streams and three each for the panel stream and the server, and the first
+// factorisation with a resident chain first runs a small synthetic one (identity matrix, banded envelope, 1 ms) with
+// each of the 18 combinations and keeps the fastest (tune_chain_queues: 0.1 s, once per process; developer knob
+// SK_CHAIN_QUEUES=<n> fixes the combination).
+constexpr int kBulkCand = 2, kPanelCand = 3, kServerCand = 3;
+static hipStream_t g_bulk_candidates[kBulkCand] = {}, g_bulk_early_candidates[kBulkCand] = {}, g_panel_candidates[kPanelCand] = {},
+                   g_server_candidates[kServerCand] = {};
+static std::vector<hipStream_t> g_all_streams;  // destroyed at exit
+static int g_queue_choice = -1;  // -1: not measured yet; else (bulk * kPanelCand + panel) * kServerCand + server
+static bool g_tuning = false;
+
 hipError_t CholeskyContext::init() {
   if (panel) return hipSuccess;
   if (!g_panel_stream) {
-    hipStream_t p = nullptr, b = nullptr, be = nullptr;
-    hipError_t rc = hipStreamCreateWithFlags(&p, hipStreamNonBlocking);
-    if (rc != hipSuccess) return rc;
     int dev = 0, ncu = 0, reserved = 0, reserved_early = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1056,40 +1073,70 @@ hipError_t CholeskyContext::init() {
     if (const char* e = getenv("SK_LA_RESERVED_PER_XCD")) per_xcd = atoi(e);
     if (const char* e = getenv("SK_LA_RESERVED_EARLY")) per_xcd_early = atoi(e);
     if (const char* e = getenv("SK_LA_EARLY_TILES")) early_tiles = atoi(e);
-    rc = create_bulk_stream(&b, per_xcd, ncu, &reserved);
+    if (const char* e = getenv("SK_QUEUE_SHIFT")) {  // developer knob: extra queues first, as another library in the process would create them
+      std::vector<uint32_t> all((size_t)(ncu + 31) / 32, 0xffffffffu);
+      for (int k = 0; k < atoi(e); ++k) { hipStream_t d = nullptr; if (hipExtStreamCreateWithCUMask(&d, (uint32_t)all.size(), all.data()) != hipSuccess) (void)hipGetLastError(); }
+    }
+    hipStream_t b = nullptr, be = nullptr;
+    hipError_t rc = create_bulk_stream(&b, per_xcd, ncu, &reserved);
     if (rc == hipSuccess) rc = create_bulk_stream(&be, per_xcd_early, ncu, &reserved_early);
     if (rc != hipSuccess) {
       if (b) (void)hipStreamDestroy(b);
-      (void)hipStreamDestroy(p);
       return rc;
     }
-    // The resident potrf workgroup gets a CU of its own (XCD 0, CU 0 — the bulk masks exclude it already) and a
-    // hardware queue of its own: a CU-masked stream owns its queue, a plain one is mapped onto a small shared pool
-    // and could end up behind a stream it waits for.  The panel stream is masked to every other CU, so the
-    // workgroups that wait for the server can never occupy the CU it needs (150 KB of LDS).
-    hipStream_t sv = nullptr;
+    g_all_streams.push_back(b); g_all_streams.push_back(be);
+    g_bulk_candidates[0] = b; g_bulk_early_candidates[0] = be;
+    // The resident potrf workgroup gets a CU to itself — CU 0 of whichever XCD its launch lands on: the bulk masks
+    // exclude the first CUs of every XCD, the panel mask below CU 0 of every XCD (mask bit i <-> XCD i % 8, CU i / 8; an
+    // XCD without any bit would be unrestricted, so a mask cannot choose the XCD) — and a hardware queue to itself: a
+    // CU-masked stream owns its queue, a plain one is mapped onto a small shared pool and could end up behind a stream
+    // it waits for.  The workgroups that wait for the server can then never occupy the CU it needs (150 KB of LDS).
+    hipStream_t p = nullptr, sv = nullptr;
     if (reserved > 0) {
-      std::vector<uint32_t> one((size_t)(ncu + 31) / 32, 0u), rest((size_t)(ncu + 31) / 32, 0u);
-      one[0] = 1u;
-      for (int i = 1; i < ncu; ++i) rest[(size_t)i / 32] |= 1u << (i % 32);
-      hipStream_t pm = nullptr;
-      if (hipExtStreamCreateWithCUMask(&sv, (uint32_t)one.size(), one.data()) == hipSuccess &&
-          hipExtStreamCreateWithCUMask(&pm, (uint32_t)rest.size(), rest.data()) == hipSuccess) {
-        (void)hipStreamDestroy(p);  // a plain stream: safe to destroy
-        p = pm;
-      } else {
-        (void)hipGetLastError();
-        sv = nullptr;  // (a masked stream that was created stays allocated: destroying one hangs the next creation on this ROCm build)
+      const size_t words = (size_t)(ncu + 31) / 32;
+      std::vector<uint32_t> cu0(words, 0u), rest(words, 0u);
+      cu0[0] = 0xffu;
+      for (int i = 8; i < ncu; ++i) rest[(size_t)i / 32] |= 1u << (i % 32);
+      bool ok = true;
+      auto masked = [&](hipStream_t* out, const std::vector<uint32_t>& m) {
+        if (!ok) return;
+        if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, m.data()) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; ok = false; return; }
+        g_all_streams.push_back(*out);
+      };
+      // (a masked stream that was created stays allocated until exit: destroying one hangs the next creation on this ROCm build)
+      for (int k = 1; k < kBulkCand && ok; ++k) {
+        int r = 0;
+        if (create_bulk_stream(&g_bulk_candidates[k], per_xcd, ncu, &r) != hipSuccess || create_bulk_stream(&g_bulk_early_candidates[k], per_xcd_early, ncu, &r) != hipSuccess) {
+          (void)hipGetLastError();
+          ok = false;
+        }
+        if (g_bulk_candidates[k]) g_all_streams.push_back(g_bulk_candidates[k]);
+        if (g_bulk_early_candidates[k]) g_all_streams.push_back(g_bulk_early_candidates[k]);
       }
+      for (int k = 0; k < kPanelCand; ++k) masked(&g_panel_candidates[k], rest);
+      for (int k = 0; k < kServerCand; ++k) masked(&g_server_candidates[k], cu0);
+      p = g_panel_candidates[0];
+      sv = p ? g_server_candidates[0] : nullptr;
+      if (!ok) g_queue_choice = 0;  // no choice to make
+      if (const char* e = getenv("SK_CHAIN_QUEUES")) g_queue_choice = atoi(e) % (kBulkCand * kPanelCand * kServerCand);
+      if (ok && g_queue_choice >= 0) {
+        b = g_bulk_candidates[g_queue_choice / (kPanelCand * kServerCand)];
+        be = g_bulk_early_candidates[g_queue_choice / (kPanelCand * kServerCand)];
+        p = g_panel_candidates[g_queue_choice / kServerCand % kPanelCand];
+        sv = g_server_candidates[g_queue_choice % kServerCand];
+      }
+    }
+    if (!p) {
+      rc = hipStreamCreateWithFlags(&p, hipStreamNonBlocking);
+      if (rc != hipSuccess) return rc;
+      g_all_streams.push_back(p);
     }
     g_server_stream = sv;
     g_panel_stream = p; g_bulk_stream = b; g_bulk_early_stream = be; g_reserved_cus = reserved; g_early_tiles = early_tiles;
     // destroyed once, at process exit, before the HIP runtime's own teardown (handlers run in reverse order of registration)
     atexit([] {
-      if (g_bulk_stream) (void)hipStreamDestroy(g_bulk_stream);
-      if (g_bulk_early_stream) (void)hipStreamDestroy(g_bulk_early_stream);
-      if (g_panel_stream) (void)hipStreamDestroy(g_panel_stream);
-      if (g_server_stream) (void)hipStreamDestroy(g_server_stream);
+      for (hipStream_t st : g_all_streams) (void)hipStreamDestroy(st);
+      g_all_streams.clear();
       g_bulk_stream = g_bulk_early_stream = g_panel_stream = g_server_stream = nullptr;
     });
   }
@@ -1138,7 +1185,7 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain) {
   CholeskyPlan plan;
   plan.chain_from = nblk;
   if (group < 1) group = 1;
-  if (!chain || !g_chain_server || nblk < 3) {
+  if (!chain || nblk < 3) {
     plan.bounds = cholesky_group_bounds(nblk, group);
   } else {
     auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
@@ -1193,9 +1240,80 @@ int cholesky_plan_max_group(const CholeskyPlan& plan) {
 // a contiguous run plus that last row (main_t / jump_t of the GEMM body).  Blocks outside are exact zeros in the
 // dense algorithm too (0 - 0 * x), so the result is bit-identical to last == nullptr; only the work differs
 // (Ladybug-1723-shaped S: 0.17 of 1.27 TFlop).
+__global__ void set_identity_kernel(double* A, long ld, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[(long)i * ld + i] = 1.0;
+}
+
+// See g_queue_choice: a small synthetic factorisation (identity matrix — the launches do not depend on the values —, an
+// envelope four blocks high, every column under the resident chain) with each pair of candidate queues, on the
+// caller's stream: its queue is part of the assignment being measured.
+static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
+  g_queue_choice = 0;
+  const int nblk = 26, n = nblk * 128;
+  double *A = nullptr, *Linv = nullptr;
+  int* info = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&A), sizeof(double) * (size_t)n * n) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&Linv), sizeof(double) * (size_t)n * 128) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&info), sizeof(int)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (A) (void)hipFree(A);
+    if (Linv) (void)hipFree(Linv);
+    return;
+  }
+  (void)hipMemsetAsync(A, 0, sizeof(double) * (size_t)n * n, s);
+  (void)hipMemsetAsync(Linv, 0, sizeof(double) * (size_t)n * 128, s);
+  (void)hipMemsetAsync(info, 0, sizeof(int), s);
+  hipLaunchKernelGGL(set_identity_kernel, dim3((n + 255) / 256), dim3(256), 0, s, A, (long)n, n);
+  std::vector<int> last(nblk);
+  for (int c = 0; c < nblk; ++c) last[c] = std::min(c + 4, nblk - 2);
+  last[nblk - 1] = nblk - 1;
+  g_tuning = true;
+  const int ncomb = kBulkCand * kPanelCand * kServerCand;
+  std::vector<double> ms((size_t)ncomb, 1e30);
+  auto select = [&](int c) {
+    ctx->bulk = g_bulk_candidates[c / (kPanelCand * kServerCand)];
+    ctx->bulk_early = g_bulk_early_candidates[c / (kPanelCand * kServerCand)];
+    ctx->panel = g_panel_candidates[c / kServerCand % kPanelCand];
+    ctx->server = g_server_candidates[c % kServerCand];
+  };
+  for (int c = 0; c < ncomb; ++c) {
+    select(c);
+    for (int rep = 0; rep < 3; ++rep) {  // (the first one also pages the kernels in)
+      (void)hipStreamSynchronize(s);
+      const auto t0 = std::chrono::steady_clock::now();
+      cholesky_factor(A, n, n, Linv, info, 1, s, ctx, nullptr, last.data(), true);
+      (void)hipStreamSynchronize(s);
+      const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (rep > 0 && t < ms[c]) ms[c] = t;
+    }
+  }
+  g_tuning = false;
+  for (int c = 1; c < ncomb; ++c) if (ms[c] < ms[g_queue_choice]) g_queue_choice = c;
+  if (getenv("SK_DEBUG_QUEUES")) {
+    std::fprintf(stderr, "[skeres_amd] synthetic factorisation (ms) per (bulk, panel, server) queue candidates:");
+    for (int c = 0; c < ncomb; ++c) std::fprintf(stderr, "%s%.2f", c % kServerCand == 0 ? "  " : " ", ms[c]);
+    std::fprintf(stderr, ": combination %d\n", g_queue_choice);
+  }
+  select(g_queue_choice);
+  g_bulk_stream = ctx->bulk; g_bulk_early_stream = ctx->bulk_early; g_panel_stream = ctx->panel; g_server_stream = ctx->server;
+  (void)hipFree(A);
+  (void)hipFree(Linv);
+  (void)hipFree(info);
+}
+
+// Before the first factorisation with allow_chain on stream s (cholesky_factor does it otherwise): choose the queues.
+void cholesky_prepare(CholeskyContext* ctx, hipStream_t s) {
+  if (!ctx || !ctx->server || !g_chain_server || g_tuning) return;
+  if (g_queue_choice < 0) tune_chain_queues(ctx, s);
+  ctx->panel = g_panel_stream;  // (every context of the process: the choice is the process's)
+  ctx->server = g_server_stream; ctx->bulk = g_bulk_stream; ctx->bulk_early = g_bulk_early_stream;
+}
+
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
                      KernelTimer* kt, const int* last, bool allow_chain) {
   const int nblk = npad / 128;
+  if (allow_chain) cholesky_prepare(ctx, s);
   const bool la = ctx != nullptr && ctx->panel != nullptr && ctx->bulk != nullptr;
   hipStream_t sp = la ? ctx->panel : s;
   hipStream_t sb = la ? ctx->bulk : s;  // of the current group (chosen below)
@@ -1270,22 +1388,26 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     }
   };
   // the resident panel chain from block column c0 on (cholesky_plan); not while every chain kernel is being timed
-  const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr && !(kt && kt->times_all()));
+  const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr);
   const std::vector<int>& gb = plan.bounds;
   const int ngroups = (int)gb.size() - 1;
-  int c0 = plan.chain_from;
+  // the same groups launch by launch: while every chain kernel is being timed, and with SK_CHOL_CHAIN_SERVER=0 (PMC
+  // passes serialise the kernels of a process: a resident kernel that waits for another one would time out)
+  int c0 = (!g_chain_server || (kt && kt->times_all())) ? nblk : plan.chain_from;
   int* sync = c0 < nblk ? ctx->sync_for(nblk) : nullptr;
   if (!sync) c0 = nblk;  // (the same groups, launch by launch)
   const bool chain = c0 < nblk;
   const int maxblk = chain ? ctx->sync_blk : 0;
   const char* stamps_file = chain ? getenv("SK_CHAIN_STAMPS") : nullptr;
+  hipStream_t srv = nullptr;
   if (chain) {
     const int stamps_on = stamps_file ? 1 : 0;
     static int stamps_state = 0;
     if (stamps_on != stamps_state) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamps_on), &stamps_on, sizeof(int)); stamps_state = stamps_on; }
+    srv = ctx->server;
     (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * maxblk), s);
-    order(s, ctx->server);
-    hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), ctx->server, S, ld, c0, nblk, Linv, info, sync, maxblk);
+    order(s, srv);
+    hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, c0, nblk, Linv, info, sync, maxblk);
   }
   order(s, sp);
   if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }
@@ -1351,7 +1473,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   }
   order(sp, s);
   if (la) { order(ctx->bulk, s); order(ctx->bulk_early, s); }
-  if (chain) order(ctx->server, s);
+  if (chain) order(srv, s);
   if (stamps_file) {
     (void)hipStreamSynchronize(s);
     std::vector<long long> st((size_t)1024 * 8);
@@ -1404,10 +1526,10 @@ void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, in
 
 // Algorithmic flops of the dominant kernel's launches (part (b) of each trailing SYRK:
 // lower-triangular 128x128 tiles incl. the diagonal tiles, 2*128*128*K each).
-double cholesky_syrk_flops(int npad, int group, const int* last, bool chain) {
+double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, double* c_tiles) {
   const int nblk = npad / 128;
   const std::vector<int> gb = cholesky_plan(nblk, group, last, chain).bounds;
-  double f = 0.0;
+  double f = 0.0, tiles = 0.0;
   for (size_t g = 0; g + 2 < gb.size(); ++g) {
     const int k0 = gb[g], k1 = gb[g + 1], na = gb[g + 2] - k1;
     const int Lg = last ? (last[k1 - 1] < nblk - 1 ? last[k1 - 1] : nblk - 1) : nblk - 1;
@@ -1415,7 +1537,9 @@ double cholesky_syrk_flops(int npad, int group, const int* last, bool chain) {
     const int main_rows = Lg >= first_row ? Lg - first_row + 1 : 0;
     const int Tb = main_rows + ((first_row + main_rows <= nblk - 1 && Lg < nblk - 1) ? 1 : 0);
     f += 0.5 * Tb * (Tb + 1.0) * 2.0 * 128.0 * 128.0 * (double)((k1 - k0) * 128);
+    tiles += 0.5 * Tb * (Tb + 1.0);
   }
+  if (c_tiles) *c_tiles = tiles;  // 128 x 128 tiles of C read and written once per launch, summed over the launches
   return f;
 }
 

@@ -103,6 +103,7 @@ size_t potrf128_lds_bytes();
 // allow_chain: the grouping is the library's to choose (cholesky_plan): resident panel chain for the chain-bound columns.
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
                      KernelTimer* kt, const int* last = nullptr, bool allow_chain = false);
+void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
 struct CholeskyPlan {
   std::vector<int> bounds;  // group start columns + nblk
   int chain_from = 0;       // first block column of the resident panel chain (nblk: none)
@@ -111,7 +112,7 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain);
 int cholesky_plan_max_group(const CholeskyPlan& plan);
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
                         hipStream_t s, KernelTimer* kt, const int* last = nullptr);
-double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false);
+double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false, double* c_tiles = nullptr);
 std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col);
 std::vector<int> cholesky_group_bounds(int nblk, int group);
 void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,
