@@ -213,7 +213,7 @@ def main():
             del solver2
             return rate, dt, flops2
         alone, _, _ = side_run(False, not args.full_factorisation)
-        # ... and the factorisation of EVERY block (no envelope): same numbers out (bit-identical), more work in
+        # ... and the factorisation of EVERY block (no envelope): the same arithmetic (other SYRK grouping), more work in
         if not args.full_factorisation:
             _, full_dt, full_flops = side_run(True, False)
             full_ms = 1e3 * full_dt
@@ -232,7 +232,9 @@ def main():
                 "linear_solver": "DENSE_SCHUR", "reduced_system_n": 9 * prob.num_cameras,
                 "cholesky": ("full: every 128-block of the reduced system" if args.full_factorisation else
                              "block envelope: cameras ordered for a banded reduced system, the structurally zero 128-blocks outside the envelope "
-                             "skipped; bit-identical to the full factorisation (tests/test_gpu_parity.py::test_envelope_*)"),
+                             "skipped — the same arithmetic as the full factorisation (bit-identical at equal SYRK depth: "
+                             "tests/test_gpu_parity.py::test_envelope_*); SYRK depth 2 and launch-by-launch look-ahead where the trailing SYRK "
+                             "is the long pole, a resident panel chain (potrf server workgroup + per-column launches) where the serial chain is"),
                 "ms_per_step_full_factorisation": full_ms,
                 "successful_steps_in_timed_region": n_success, "parallelism": ("one GPU" if world == 1 else
                                 "points sharded x%d, reduced system all-reduced, Cholesky replicated" % world if dist_mode == "sharded" else

@@ -251,15 +251,21 @@ int sk_options_set_max_num_consecutive_invalid_steps(sk_options* o, int n);
 /* MI355X-side knobs (no reference counterpart) */
 int sk_options_set_device(sk_options* o, int hip_device);             /* default: current device */
 int sk_options_set_stream(sk_options* o, void* hip_stream);           /* default: a private stream */
-/* Tuning of the dense Cholesky: `group` = depth of the trailing SYRK in 128-column blocks (K = 128*group;
- * <= 0 keeps the automatic choice: 3 for a full factorisation, 1 when the block envelope makes the serial panel
- * chain the long pole); `lookahead` != 0 factors the next block-column group on its own stream next to the
- * trailing SYRK of the current one. */
+/* Tuning of the dense Cholesky: `group` = depth of the trailing SYRK in 128-column blocks (K = 128*group).
+ * <= 0 (default) leaves the plan to the library: groups of 3 for a full factorisation; with a sparse block
+ * envelope, groups of 2 while the trailing SYRK is the long pole and single columns under a resident panel chain
+ * (one workgroup that factors the diagonal blocks, per-column launches that hand it its operands through device
+ * counters) where the serial chain is — DESIGN.md section 4.  The first solver of a process then spends about
+ * 0.1 s choosing hardware queues for that chain.  An explicit `group` is used for every column, launch by launch
+ * (then the envelope factorisation is bit-identical to the full one at the same `group`).
+ * `lookahead` != 0 factors the next block-column group on its own stream next to the trailing SYRK of the
+ * current one. */
 int sk_options_set_cholesky_tuning(sk_options* o, int group, int lookahead);
 /* DENSE_SCHUR: the reduced camera system of a bundle-adjustment problem is block-banded (cameras that share no
  * point give a zero block, and the Cholesky factor keeps the block envelope).  on != 0 (default): the dense
  * factorisation touches only the 128-blocks inside the envelope; the blocks it leaves out are exact zeros in the
- * full computation too, so the result is bit-identical to on == 0, which factors every block. */
+ * full computation too, so at equal SYRK depth (sk_options_set_cholesky_tuning) the result is bit-identical to
+ * on == 0, which factors every block. */
 int sk_options_set_cholesky_envelope(sk_options* o, int on);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,
  * one per GPU.  Points (e-blocks) are partitioned over ranks; the
