@@ -20,6 +20,7 @@ from .api import (  # noqa: F401
     DoubleArray, RichDoubleArray, RichDoubleMatrix, StdVectorDoublePointer,
     CostFunction, SizedCostFunction, CostFunctor, AutoDiffCostFunctor, AutoDiffCostFunction,
     NumericDiffCostFunctor, NumericDiffCostFunction, NumericDiffMethodType, NumericDiffOptions,
+    HostAutoDiffCostFunctor, HostAutoDiffCostFunction, CostFunctorAdapter, CostFunctionToFunctor, DynamicCostFunctionToFunctor,
     SnavelyReprojectionError, ExponentialResidual, PowellF1, PowellF2, PowellF3, PowellF4,
     BinaryScalarCost, BinaryVector3Cost, TenParameterCost, HelloCostFunctor,
     PredefinedLossFunctions, LossFunction, Problem, Solver, LinearSolverType, MinimizerType, TerminationType,

@@ -535,6 +535,101 @@ class AutoDiffCostFunction(SizedCostFunction):
         return bool(rc)
 
 
+class HostAutoDiffCostFunctor(CostFunctor):
+    """A generic functor whose body is host code (CORE/CostFunctor.scala:31-38, the reference's only kind: its functors
+    run on the JVM).  Override ``apply(*x)``: x[i] is the list of block i's values, floats or ``Jet``s (rotation.Jet
+    has the arithmetic and ``skeres_amd.rotation.sqrt / exp / sin / ...`` the functions); return the residuals, or an
+    empty sequence to signal failure.  Functors with a body in the device registry (``AutoDiffCostFunctor``) are
+    evaluated on the GPU; this one reaches the solver through the director path, like any host ``CostFunction``."""
+
+    def toAutoDiffCostFunction(self):
+        return HostAutoDiffCostFunction(self)
+
+    def apply(self, *x):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def __call__(self, *x):
+        return self.apply(*x)
+
+
+class HostAutoDiffCostFunction(SizedCostFunction):
+    """CORE/AutodiffCostFunction.scala:69-135 on the host: residuals from the functor over doubles; Jacobians from
+    one evaluation over Jets of dimension sum(N), block i's k-th value seeded with e_(offset_i + k)."""
+
+    def __init__(self, costFunctor):
+        super().__init__(costFunctor.kNumResiduals, *costFunctor.N)
+        self.costFunctor = costFunctor
+
+    def evaluate(self, parameters, residuals, jacobians):
+        from .rotation import Jet
+        p, r, j = _host_views(self, parameters, residuals, jacobians)
+        f, N, nres = self.costFunctor, self.costFunctor.N, self.kNumResiduals
+        if j is None:
+            y = f(*[[float(v) for v in p[i]] for i in range(len(N))])
+            if len(y) == 0:
+                return False
+            r[:] = [float(v) for v in y]
+            return True
+        dim, x, off = int(sum(N)), [], 0
+        for i in range(len(N)):
+            x.append([Jet(p[i][k], off + k, dim) for k in range(N[i])])
+            off += N[i]
+        y = f(*x)
+        if len(y) == 0:
+            return False
+        off = 0
+        for i in range(len(N)):
+            if j[i] is not None:
+                for row in range(nres):
+                    j[i][row, :] = y[row].infinitesimal[off:off + N[i]] if isinstance(y[row], Jet) else 0.0
+            off += N[i]
+        r[:] = [float(v) for v in y]
+        return True
+
+
+class CostFunctorAdapter(HostAutoDiffCostFunctor):
+    """CORE/CostFunctionToFunctor.scala:50-123: a CostFunction as a generic functor, so that it can be called from
+    inside another functor.  Over doubles it evaluates the cost function's residuals (:66-77); over Jets it evaluates
+    residuals and Jacobians at the real parts and applies the chain rule, output[i] = residual[i] +
+    sum_j J[i][j] * infinitesimal(input[j]) (:79-122).  An evaluation that fails gives an empty result, as there."""
+
+    def __init__(self, cost):
+        super().__init__(cost.numResiduals(), *cost.parameterBlockSizes())
+        self.cost = cost
+
+    def apply(self, *x):
+        from .rotation import Jet
+        N, nres = self.N, self.kNumResiduals
+        if len(x) != len(N) or any(len(x[i]) != N[i] for i in range(len(N))):
+            raise ValueError("Invalid sizes for x")
+        jets = any(isinstance(v, Jet) for xi in x for v in xi)
+        p = [np.array([float(v) for v in xi], dtype=np.float64) for xi in x]
+        r = np.zeros(nres)
+        if not jets:
+            return list(r) if self.cost.evaluate(p, r, None) else []
+        J = [np.zeros((nres, n)) for n in N]
+        if not self.cost.evaluate(p, r, J):
+            return []
+        dim = max(len(v.infinitesimal) for xi in x for v in xi if isinstance(v, Jet))
+        out = []
+        for i in range(nres):
+            inf = np.zeros(dim)
+            for b in range(len(N)):
+                for k in range(N[b]):
+                    if isinstance(x[b][k], Jet):
+                        inf += J[b][i, k] * x[b][k].infinitesimal
+            out.append(Jet(r[i], inf))
+        return out
+
+
+def CostFunctionToFunctor(cost):
+    """CORE/CostFunctionToFunctor.scala:13-15."""
+    return CostFunctorAdapter(cost)
+
+
+DynamicCostFunctionToFunctor = CostFunctionToFunctor  # :18-20: "only to preserve the ceres-solver class names"
+
+
 class SnavelyReprojectionError(AutoDiffCostFunctor):  # EX/SimpleBundleAdjuster.scala:79-119
     FUNCTOR_ID = 1
 

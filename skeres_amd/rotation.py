@@ -27,7 +27,11 @@ OUT_LEN = (4, 3, 4, 3, 9, 9, 9, 9, 3, 3, 4, 3, 1, 3)
 
 
 class Jet:
-    """spire.math.Jet[Double]: ``Jet(x, k)`` = x + e_k (needs a dimension), ``Jet(x, [..])`` explicit."""
+    """spire.math.Jet[Double]: ``Jet(x, k)`` = x + e_k (needs a dimension), ``Jet(x, [..])`` explicit.
+
+    Arithmetic and the elementary functions below follow spire's Jet (Jet.scala [ext]; the rules are the chain rule):
+    enough to write a generic functor on the host — ``HostAutoDiffCostFunctor`` in api.py — as the reference writes
+    them over ``T: Field: Trig: NRoot``.  Comparisons look at the real part only, as spire's ``Order[Jet]`` does."""
 
     __slots__ = ("real", "infinitesimal")
 
@@ -44,6 +48,102 @@ class Jet:
 
     def __repr__(self):
         return "Jet(%r, %r)" % (self.real, self.infinitesimal.tolist())
+
+    def __float__(self):
+        return self.real
+
+    @staticmethod
+    def _split(other):
+        return (other.real, other.infinitesimal) if isinstance(other, Jet) else (float(other), 0.0)
+
+    def __neg__(self):
+        return Jet(-self.real, -self.infinitesimal)
+
+    def __pos__(self):
+        return self
+
+    def __add__(self, other):
+        r, v = Jet._split(other)
+        return Jet(self.real + r, self.infinitesimal + v)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        r, v = Jet._split(other)
+        return Jet(self.real - r, self.infinitesimal - v)
+
+    def __rsub__(self, other):
+        r, v = Jet._split(other)
+        return Jet(r - self.real, v - self.infinitesimal)
+
+    def __mul__(self, other):
+        r, v = Jet._split(other)
+        return Jet(self.real * r, self.infinitesimal * r + v * self.real)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        r, v = Jet._split(other)
+        inv = 1.0 / r
+        q = self.real * inv
+        return Jet(q, (self.infinitesimal - v * q) * inv)
+
+    def __rtruediv__(self, other):
+        r, v = Jet._split(other)
+        inv = 1.0 / self.real
+        q = r * inv
+        return Jet(q, (v - self.infinitesimal * q) * inv)
+
+    def __pow__(self, p):
+        if isinstance(p, Jet):
+            return exp(p * log(self))
+        return Jet(self.real ** p, self.infinitesimal * (p * self.real ** (p - 1)))
+
+    def __lt__(self, other):
+        return self.real < Jet._split(other)[0]
+
+    def __le__(self, other):
+        return self.real <= Jet._split(other)[0]
+
+    def __gt__(self, other):
+        return self.real > Jet._split(other)[0]
+
+    def __ge__(self, other):
+        return self.real >= Jet._split(other)[0]
+
+    def __abs__(self):
+        return -self if self.real < 0.0 else self
+
+    # spire-style method names, as generic reference code calls them
+    def sqrt(self):
+        return sqrt(self)
+
+
+def _unary(f, df):
+    def g(x):
+        if isinstance(x, Jet):
+            return Jet(f(x.real), x.infinitesimal * df(x.real))
+        return f(float(x))
+    return g
+
+
+sqrt = _unary(np.sqrt, lambda x: 0.5 / np.sqrt(x))
+exp = _unary(np.exp, np.exp)
+log = _unary(np.log, lambda x: 1.0 / x)
+sin = _unary(np.sin, np.cos)
+cos = _unary(np.cos, lambda x: -np.sin(x))
+tan = _unary(np.tan, lambda x: 1.0 / np.cos(x) ** 2)
+asin = _unary(np.arcsin, lambda x: 1.0 / np.sqrt(1.0 - x * x))
+acos = _unary(np.arccos, lambda x: -1.0 / np.sqrt(1.0 - x * x))
+atan = _unary(np.arctan, lambda x: 1.0 / (1.0 + x * x))
+
+
+def atan2(y, x):
+    if not isinstance(y, Jet) and not isinstance(x, Jet):
+        return float(np.arctan2(y, x))
+    (yr, yv), (xr, xv) = Jet._split(y), Jet._split(x)
+    d = xr * xr + yr * yr
+    return Jet(np.arctan2(yr, xr), (yv * xr - xv * yr) / d)
 
 
 class Quaternion:

@@ -305,6 +305,81 @@ def test_host_callback_cost_function_director_path():
         assert abs(g[k] - so.iterations[k].cost) <= 1e-9 * max(so.iterations[k].cost, 1e-30)
 
 
+@pytest.mark.gpu
+def test_host_generic_functors_and_cost_function_to_functor_through_the_solver():
+    # Powell (EX/Powell.scala:14-53) with the four functor bodies as HOST generic code (HostAutoDiffCostFunctor: the
+    # reference's functors run on the JVM), F4 written as a call of a wrapped analytic cost function
+    # (CORE/CostFunctionToFunctor.scala): same trajectory as the device functors' / the oracle's Jet autodiff.
+    from skeres_amd import rotation as R
+
+    class F1(sk.HostAutoDiffCostFunctor):
+        def __init__(self):
+            super().__init__(1, 1, 1)
+
+        def apply(self, x1, x2):
+            return [x1[0] + 10.0 * x2[0]]
+
+    class F2(sk.HostAutoDiffCostFunctor):
+        def __init__(self):
+            super().__init__(1, 1, 1)
+
+        def apply(self, x3, x4):
+            return [R.sqrt(5.0) * x3[0] - x4[0]]
+
+    class F3(sk.HostAutoDiffCostFunctor):
+        def __init__(self):
+            super().__init__(1, 1, 1)
+
+        def apply(self, x2, x3):
+            d = x2[0] - 2.0 * x3[0]
+            return [d * d]
+
+    class F4Analytic(sk.SizedCostFunction):  # PowellAnalytic.scala:62-81
+        def __init__(self):
+            super().__init__(1, 1, 1)
+
+        def evaluate(self, parameters, residuals, jacobians):
+            d = parameters[0][0] - parameters[1][0]
+            residuals[0] = np.sqrt(10.0) * d * d
+            if jacobians is not None:
+                if jacobians[0] is not None:
+                    jacobians[0][0, 0] = 2 * np.sqrt(10.0) * d
+                if jacobians[1] is not None:
+                    jacobians[1][0, 0] = -2 * np.sqrt(10.0) * d
+            return True
+
+    class F4(sk.HostAutoDiffCostFunctor):
+        def __init__(self):
+            super().__init__(1, 1, 1)
+            self.inner = sk.CostFunctionToFunctor(F4Analytic())
+
+        def apply(self, x1, x4):
+            return [1.0 * self.inner(x1, x4)[0]]
+
+    xs = [sk.DoubleArray(1) for _ in range(4)]
+    for a, v in zip(xs, [3.0, -1.0, 0.0, 1.0]):
+        a.set(0, v)
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    problem = sk.Problem()
+    costs = [F1().toAutoDiffCostFunction(), F2().toAutoDiffCostFunction(), F3().toAutoDiffCostFunction(), F4().toAutoDiffCostFunction()]
+    for cf, (i, j) in zip(costs, [(0, 1), (2, 3), (1, 2), (0, 3)]):
+        problem.addResidualBlock(cf, loss, xs[i], xs[j])
+    options = sk.Solver.Options()
+    options.setMaxNumIterations(100)
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_QR)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    blocks = [(oracle.POWELL_F1, [], [0, 1]), (oracle.POWELL_F2, [], [2, 3]), (oracle.POWELL_F3, [], [1, 2]),
+              (oracle.POWELL_F4, [], [0, 3])]
+    xo, so = oracle.solve([1, 1, 1, 1], [3.0, -1.0, 0.0, 1.0], blocks,
+                          oracle.default_options(linear_solver_type=oracle.DENSE_QR, max_num_iterations=100))
+    g = [it["cost"] for it in summary.iterations()]
+    for k in range(min(8, len(g), so.num_logged)):
+        assert abs(g[k] - so.iterations[k].cost) <= 1e-9 * max(so.iterations[k].cost, 1e-30)
+    assert summary.finalCost() <= 1e-10
+    np.testing.assert_allclose([a.get(0) for a in xs], xo, atol=1e-5)
+
+
 def test_numeric_diff_cost_function_through_the_solver_vs_oracle_autodiff():
     # CurveFitting with every residual block numerically differentiated on the host (central differences):
     # same optimum and, to the differencing error, the same trajectory as the oracle's Jet autodiff
