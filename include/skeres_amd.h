@@ -88,12 +88,15 @@ typedef enum sk_functor_id {
    * device from a counter-based generator; consts (seed, row index, y).  Added with
    * sk_problem_add_dense_rows. */
   SK_FUNCTOR_SYNTH_TANH_ROW = 10,
-  SK_FUNCTOR_HELLO_WORLD = 11             /* EX/HelloWorld.scala:11-14: r = 10 - x */
+  SK_FUNCTOR_HELLO_WORLD = 11,            /* EX/HelloWorld.scala:11-14: r = 10 - x */
+  SK_FUNCTOR_QUATERNION_ROTATION = 12     /* r = R(q) p - t, q = (w, x, y, z) normalised; consts (p[3], t[3]); no reference
+                                           * counterpart: a 4-parameter block for the local parameterizations */
 } sk_functor_id;
 
 typedef struct sk_ptrvec sk_ptrvec;
 typedef struct sk_loss_function sk_loss_function;
 typedef struct sk_cost_function sk_cost_function;
+typedef struct sk_local_parameterization sk_local_parameterization;
 typedef struct sk_problem sk_problem;
 typedef struct sk_options sk_options;
 typedef struct sk_summary sk_summary;
@@ -178,6 +181,24 @@ sk_loss_function* sk_loss_scaled(const sk_loss_function* rho, double a);
 int sk_loss_evaluate(const sk_loss_function* loss, const double* sq_norm, int n, double* rho);
 void sk_loss_free(sk_loss_function* loss);
 
+/* ---- LocalParameterization: PredefinedLocalParameterizations, ceres.i:186-210 -------------
+ * identity(size), subset(size, constant_parameters), quaternion(), homogeneousVector(size) — the Ceres 1.x classes
+ * the reference creates through SWIG for ceres::Problem::AddParameterBlock / SetParameterization, which its Problem
+ * inherits (CORE/Problem.scala:16).  Global size at most 16.  Creation returns NULL (sk_last_error) on the argument
+ * errors Ceres checks: subset indices out of range or duplicated, a homogeneous vector of size < 2.  The objects
+ * are copied into a problem when set; free them any time after.
+ * Plus(x, delta) and ComputeJacobian(x) (global x local, row-major) are evaluated ON THE DEVICE — the code the solver
+ * runs — for n points at once: x [n][global], delta [n][local] (one unused value per point when local is 0). */
+sk_local_parameterization* sk_local_parameterization_identity(int size);
+sk_local_parameterization* sk_local_parameterization_subset(int size, const int* constant_parameters, int num_constant);
+sk_local_parameterization* sk_local_parameterization_quaternion(void);          /* (w, x, y, z) */
+sk_local_parameterization* sk_local_parameterization_homogeneous_vector(int size);
+void sk_local_parameterization_free(sk_local_parameterization* p);
+int sk_local_parameterization_global_size(const sk_local_parameterization* p);  /* LocalParameterization::GlobalSize */
+int sk_local_parameterization_local_size(const sk_local_parameterization* p);   /* LocalParameterization::LocalSize */
+int sk_local_parameterization_plus(const sk_local_parameterization* p, const double* x, const double* delta, int n, double* x_plus);
+int sk_local_parameterization_compute_jacobian(const sk_local_parameterization* p, const double* x, int n, double* jacobian);
+
 /* ---- CostFunction -------------------------------------------------------- */
 /* AutoDiffCostFunctor.toAutoDiffCostFunction (CORE/CostFunctor.scala:44) for a
  * functor with a device body.  Validates like CostFunctor / SizedCostFunction
@@ -225,6 +246,16 @@ int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const d
  * depend on the single parameter block x[0..n).  consts is num_rows x 3 row-major. */
 int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const double* consts,
                               const sk_loss_function* loss, double* x, int n);
+/* ceres::Problem::AddParameterBlock(values, size[, local_parameterization]), SetParameterization,
+ * SetParameterBlockConstant / SetParameterBlockVariable (inherited by CORE/Problem.scala:16 from the SWIG-wrapped
+ * ceres::Problem).  `parameterization` may be NULL (none / remove).  The minimiser then works in the tangent
+ * space: Jacobian columns J * dPlus/ddelta, steps applied through Plus; a constant block takes no step.
+ * Implemented for DENSE_QR / DENSE_NORMAL_CHOLESKY over residual blocks; sk_solve reports SK_ERR_UNSUPPORTED for
+ * DENSE_SCHUR and dense-row problems that use them. */
+int sk_problem_add_parameter_block(sk_problem* p, double* values, int size, const sk_local_parameterization* parameterization);
+int sk_problem_set_parameterization(sk_problem* p, double* values, const sk_local_parameterization* parameterization);
+int sk_problem_set_parameter_block_constant(sk_problem* p, double* values);
+int sk_problem_set_parameter_block_variable(sk_problem* p, double* values);
 int sk_problem_num_residual_blocks(const sk_problem* p);   /* Problem::NumResidualBlocks */
 int sk_problem_num_parameter_blocks(const sk_problem* p);  /* Problem::NumParameterBlocks */
 int sk_problem_num_parameters(const sk_problem* p);        /* Problem::NumParameters */

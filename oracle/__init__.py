@@ -25,6 +25,7 @@ MAX_LOG = 256
 SNAVELY, EXPONENTIAL, POWELL_F1, POWELL_F2, POWELL_F3, POWELL_F4 = 1, 2, 3, 4, 5, 6
 BINARY_SCALAR, BINARY_VECTOR3, TEN_PARAMETER = 7, 8, 9
 HELLO_WORLD = 11  # EX/HelloWorld.scala:11-14
+QUATERNION_ROTATION = 12  # r = R(q) p - t (no reference counterpart; local-parameterization tests)
 SYNTH_TANH_ROW = 10  # BASELINE.json config 5 (dense rows over one block of any size)
 
 
@@ -97,6 +98,11 @@ def lib():
                                     C.POINTER(Options), C.POINTER(Summary)]
         L.or_solve_bal_loss.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, C.c_int, dp,
                                         C.POINTER(Options), C.POINTER(Summary)]
+        L.or_solve_param.argtypes = [C.c_int, ip, dp, C.c_int, ip, dp, ip, ip, ip, dp, ip, ip, ip, ip,
+                                     C.POINTER(Options), C.POINTER(Summary)]
+        L.or_parameterization_local_size.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.or_parameterization_plus.argtypes = [C.c_int, C.c_int, ip, C.c_int, dp, dp, dp]
+        L.or_parameterization_jacobian.argtypes = [C.c_int, C.c_int, ip, C.c_int, dp, dp]
         L.or_cholesky_lower.argtypes = [dp, C.c_int, C.c_int]
         L.or_cholesky_solve.argtypes = [dp, C.c_int, dp]
         _lib = L
@@ -222,6 +228,77 @@ def solve(block_sizes, x0, residual_blocks, options=None):
                         _ip(pidx), _ip(poff), C.byref(o), C.byref(s))
     if rc != 0:
         raise RuntimeError("or_solve failed: %d" % rc)
+    return x, s
+
+
+P_IDENTITY, P_SUBSET, P_QUATERNION, P_HOMOGENEOUS_VECTOR, P_CONSTANT = range(5)  # oracle/parameterization.hpp
+
+
+def _param_args(p):
+    """p: None | ("identity",) | ("subset", [constant indices]) | ("quaternion",) | ("homogeneous",) | ("constant",)"""
+    if p is None:
+        return -1, []
+    kind = {"identity": P_IDENTITY, "subset": P_SUBSET, "quaternion": P_QUATERNION, "homogeneous": P_HOMOGENEOUS_VECTOR,
+            "constant": P_CONSTANT}[p[0]]
+    return kind, list(p[1]) if kind == P_SUBSET else []
+
+
+def parameterization_local_size(p, size):
+    kind, const = _param_args(p)
+    return lib().or_parameterization_local_size(kind, size, len(const))
+
+
+def parameterization_plus(p, x, delta):
+    kind, const = _param_args(p)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    d = np.ascontiguousarray(list(delta) + [0.0], dtype=np.float64)
+    c = np.asarray(const + [0], dtype=np.int32)
+    out = np.zeros_like(x)
+    lib().or_parameterization_plus(kind, len(x), _ip(c), len(const), _dp(x), _dp(d), _dp(out))
+    return out
+
+
+def parameterization_jacobian(p, x):
+    kind, const = _param_args(p)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    c = np.asarray(const + [0], dtype=np.int32)
+    ls = parameterization_local_size(p, len(x))
+    J = np.zeros((len(x), max(ls, 1)))
+    lib().or_parameterization_jacobian(kind, len(x), _ip(c), len(const), _dp(x), _dp(J))
+    return J[:, :ls]
+
+
+def solve_param(block_sizes, x0, residual_blocks, parameterizations, options=None):
+    """As solve(), with one parameterization (see _param_args) or None per parameter block."""
+    o = options or default_options()
+    bs = np.asarray(block_sizes, dtype=np.int32)
+    x = np.array(x0, dtype=np.float64).copy()
+    fids = np.asarray([rb[0] for rb in residual_blocks], dtype=np.int32)
+    consts, coff, pidx, poff, nodes, roots, seen = [], [], [], [0], [], [], {}
+    for rb in residual_blocks:
+        coff.append(len(consts))
+        consts.extend(rb[1])
+        pidx.extend(rb[2])
+        poff.append(len(pidx))
+        loss = rb[3] if len(rb) > 3 else None
+        key = repr(loss)
+        if key not in seen:
+            seen[key] = _flatten_loss(loss, nodes)
+        roots.append(seen[key])
+    ptype, pcoff, pconst = [], [0], []
+    for p in parameterizations:
+        kind, const = _param_args(p)
+        ptype.append(kind)
+        pconst.extend(const)
+        pcoff.append(len(pconst))
+    consts = np.asarray(consts + [0.0], dtype=np.float64)
+    nodes = np.asarray(nodes if nodes else [[0.0] * 5], dtype=np.float64)
+    arrs = [np.asarray(a, dtype=np.int32) for a in (coff, pidx, poff, roots, ptype, pcoff, pconst + [0])]
+    s = Summary()
+    rc = lib().or_solve_param(len(bs), _ip(bs), _dp(x), len(fids), _ip(fids), _dp(consts), _ip(arrs[0]), _ip(arrs[1]), _ip(arrs[2]),
+                              _dp(nodes), _ip(arrs[3]), _ip(arrs[4]), _ip(arrs[5]), _ip(arrs[6]), C.byref(o), C.byref(s))
+    if rc != 0:
+        raise RuntimeError("or_solve_param failed: %d" % rc)
     return x, s
 
 

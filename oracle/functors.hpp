@@ -27,6 +27,7 @@ enum FunctorId {
   kBinaryVector3Cost = 8,         // TEST/AutodiffCostFuntionSpec.scala:55-69
   kTenParameterCost = 9,          // TEST/AutodiffCostFuntionSpec.scala:111-119
   kHelloCostFunctor = 11,         // EX/HelloWorld.scala:11-14
+  kQuaternionRotationError = 12,  // no reference counterpart: a 4-parameter block for the local-parameterization tests
 };
 
 // ulp(1.0) == 2^-52  (CORE/package.scala:15, CORE/Rotation.scala:457)
@@ -216,6 +217,25 @@ struct HelloCostFunctor {  // EX/HelloWorld.scala:11-14
   template <class T>
   static bool apply(const double*, const T* const* p, T* out) {
     out[0] = 10.0 - p[0][0];
+    return true;
+  }
+};
+
+// r = R(q) p - t for a quaternion block q = (w, x, y, z) (normalised first: Rotation.quaternionRotatePoint,
+// CORE/Rotation.scala:393-430, spelled out); consts = (p[3], t[3]).  Exists so that the quaternion / homogeneous-vector
+// parameterizations have a registered functor with a block of size 4 to be tested on.
+struct QuaternionRotationError {
+  static constexpr int kNumResiduals = 3, kNumBlocks = 1, kNumConsts = 6;
+  static constexpr int N[1] = {4};
+  template <class T>
+  static bool apply(const double* c, const T* const* p, T* out) {
+    const T* q = p[0];
+    const T scale = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const T a = q[0] * scale, b = q[1] * scale, cc = q[2] * scale, d = q[3] * scale;
+    const T t2 = a * b, t3 = a * cc, t4 = a * d, t5 = -(b * b), t6 = b * cc, t7 = b * d, t8 = -(cc * cc), t9 = cc * d, t1 = -(d * d);
+    out[0] = 2.0 * ((t8 + t1) * c[0] + (t6 - t4) * c[1] + (t3 + t7) * c[2]) + c[0] - c[3];
+    out[1] = 2.0 * ((t4 + t6) * c[0] + (t5 + t1) * c[1] + (t9 - t2) * c[2]) + c[1] - c[4];
+    out[2] = 2.0 * ((t7 - t3) * c[0] + (t2 + t9) * c[1] + (t5 + t8) * c[2]) + c[2] - c[5];
     return true;
   }
 };

@@ -39,6 +39,7 @@
 #endif
 #include "functors.hpp"
 #include "loss.hpp"
+#include "parameterization.hpp"
 #include "rotation.hpp"
 #include "oracle.h"
 
@@ -75,6 +76,7 @@ static bool functor_info(int id, FunctorInfo* fi) {
     case kBinaryVector3Cost: *fi = info_of<BinaryVector3Cost>(); return true;
     case kTenParameterCost: *fi = info_of<TenParameterCost>(); return true;
     case kHelloCostFunctor: *fi = info_of<HelloCostFunctor>(); return true;
+    case kQuaternionRotationError: *fi = info_of<QuaternionRotationError>(); return true;
   }
   return false;
 }
@@ -92,6 +94,7 @@ static bool evaluate_block(int id, const double* consts, double const* const* pa
     case kBinaryVector3Cost: return AutoDiff<BinaryVector3Cost>::evaluate(consts, params, residuals, jacobians);
     case kTenParameterCost: return AutoDiff<TenParameterCost>::evaluate(consts, params, residuals, jacobians);
     case kHelloCostFunctor: return AutoDiff<HelloCostFunctor>::evaluate(consts, params, residuals, jacobians);
+    case kQuaternionRotationError: return AutoDiff<QuaternionRotationError>::evaluate(consts, params, residuals, jacobians);
   }
   return false;
 }
@@ -139,6 +142,10 @@ struct Problem {
   int num_residuals = 0;
   const double* loss_nodes = nullptr;  // oracle/loss.hpp; block_loss[b] = root node or -1
   std::vector<int> block_loss;
+  // oracle/parameterization.hpp: one per parameter block when any block has one (identity otherwise)
+  std::vector<Parameterization> params;
+  std::vector<int> local_off;
+  int num_local = 0;
 };
 
 struct DenseEval {  // dense Jacobian, row-major m x n
@@ -367,6 +374,8 @@ struct Model {
   // evaluate at x: cost (+ residuals/Jacobian kept inside when want_jac)
   virtual bool evaluate(const double* x, bool want_jac, double* cost) = 0;
   virtual int num_params() const = 0;
+  virtual int num_local() const { return num_params(); }  // size of the tangent space (local parameterizations)
+  virtual void plus(const double* x, const double* delta, double* out) const { for (int j = 0; j < num_params(); ++j) out[j] = x[j] + delta[j]; }
   virtual void column_sq_norms(double* out) = 0;      // of the CURRENT (possibly scaled) Jacobian
   virtual void scale_columns(const double* s) = 0;    // J <- J diag(s)
   virtual void gradient(double* g) = 0;               // J^T r of the CURRENT Jacobian
@@ -379,25 +388,48 @@ struct DenseModel : Model {
   const Problem& P; int solver; DenseEval cur, cand;
   DenseModel(const Problem& p, int s) : P(p), solver(s) {}
   int num_params() const override { return P.num_params; }
+  int num_local() const override { return P.params.empty() ? P.num_params : P.num_local; }
+  void plus(const double* x, const double* delta, double* out) const override {
+    if (P.params.empty()) { Model::plus(x, delta, out); return; }
+    for (int b = 0; b < P.num_blocks; ++b) parameterization_plus(P.params[b], x + P.block_off[b], delta + P.local_off[b], out + P.block_off[b]);
+  }
   bool evaluate(const double* x, bool want_jac, double* cost) override {
-    return evaluate_dense(P, x, want_jac, want_jac ? &cur : &cand, cost) && std::isfinite(*cost);
+    if (!(evaluate_dense(P, x, want_jac, want_jac ? &cur : &cand, cost) && std::isfinite(*cost))) return false;
+    if (want_jac && !P.params.empty()) {
+      // the Jacobian the minimiser sees is w.r.t. the tangent vector: J_local = J_global * blockdiag(d Plus / d delta)
+      const int m = P.num_residuals, ng = P.num_params, nl = P.num_local;
+      std::vector<double> Jl((size_t)m * nl, 0.0), pj;
+      for (int b = 0; b < P.num_blocks; ++b) {
+        const int gs = P.block_size[b], ls = P.params[b].local_size();
+        pj.assign((size_t)gs * std::max(ls, 1), 0.0);
+        parameterization_jacobian(P.params[b], x + P.block_off[b], pj.data());
+        for (int i = 0; i < m; ++i)
+          for (int c = 0; c < ls; ++c) {
+            double acc = 0.0;
+            for (int g = 0; g < gs; ++g) acc += cur.J[(size_t)i * ng + P.block_off[b] + g] * pj[(size_t)g * ls + c];
+            Jl[(size_t)i * nl + P.local_off[b] + c] = acc;
+          }
+      }
+      cur.J.swap(Jl);
+    }
+    return true;
   }
   void column_sq_norms(double* out) override {
-    const int m = P.num_residuals, n = P.num_params;
+    const int m = P.num_residuals, n = num_local();
     for (int j = 0; j < n; ++j) out[j] = 0.0;
     for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) out[j] += cur.J[(size_t)i * n + j] * cur.J[(size_t)i * n + j];
   }
   void scale_columns(const double* s) override {
-    const int m = P.num_residuals, n = P.num_params;
+    const int m = P.num_residuals, n = num_local();
     for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) cur.J[(size_t)i * n + j] *= s[j];
   }
   void gradient(double* g) override {
-    const int m = P.num_residuals, n = P.num_params;
+    const int m = P.num_residuals, n = num_local();
     for (int j = 0; j < n; ++j) g[j] = 0.0;
     for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) g[j] += cur.J[(size_t)i * n + j] * cur.r[i];
   }
   bool solve(const double* D, double* y) override {
-    const int m = P.num_residuals, n = P.num_params;
+    const int m = P.num_residuals, n = num_local();
     if (solver == OR_DENSE_QR) {
       const int rows = m + n;
       std::vector<double> A((size_t)rows * n, 0.0), b(rows, 0.0);
@@ -417,7 +449,7 @@ struct DenseModel : Model {
     return true;
   }
   double model_cost_change(const double* step) override {
-    const int m = P.num_residuals, n = P.num_params; double acc = 0.0;
+    const int m = P.num_residuals, n = num_local(); double acc = 0.0;
     for (int i = 0; i < m; ++i) {
       double mr = 0.0; for (int j = 0; j < n; ++j) mr += cur.J[(size_t)i * n + j] * step[j];
       acc += mr * (cur.r[i] + mr / 2.0);
@@ -505,8 +537,8 @@ static void log_iter(or_summary* S, int it, double cost, double cost_change, dou
 }
 
 static void minimize(Model& M, const or_options& O, double* x, or_summary* S) {
-  const int n = M.num_params();
-  std::vector<double> scale(n, 1.0), diag(n), D(n), y(n), step(n), delta(n), xc(n), g(n), gs(n);
+  const int n = M.num_local(), ng = M.num_params();  // tangent / ambient sizes (equal without local parameterizations)
+  std::vector<double> scale(n, 1.0), diag(n), D(n), y(n), step(n), delta(n), xc(ng), g(n), gs(n);
   double cost = 0.0;
   std::memset(S, 0, sizeof(*S));
   double t_begin = now_s();
@@ -520,7 +552,7 @@ static void minimize(Model& M, const or_options& O, double* x, or_summary* S) {
     M.scale_columns(scale.data());
   }
   double radius = O.initial_trust_region_radius, decrease_factor = 2.0;
-  double x_norm = norm2(x, n);
+  double x_norm = norm2(x, ng);
   int iteration = 0, invalid = 0, n_success = 0, n_unsuccess = 0;
   log_iter(S, 0, cost, 0.0, gmax, 0.0, 0.0, radius, 1, 1);
   S->termination_type = OR_NO_CONVERGENCE;
@@ -548,10 +580,11 @@ static void minimize(Model& M, const or_options& O, double* x, or_summary* S) {
       continue;
     }
     invalid = 0;
-    for (int j = 0; j < n; ++j) { delta[j] = step[j] * scale[j]; xc[j] = x[j] + delta[j]; }
+    for (int j = 0; j < n; ++j) delta[j] = step[j] * scale[j];
+    M.plus(x, delta.data(), xc.data());
     double new_cost = std::numeric_limits<double>::max();
     if (!M.evaluate(xc.data(), false, &new_cost)) new_cost = std::numeric_limits<double>::max();
-    double sn = 0.0; for (int j = 0; j < n; ++j) { const double d = x[j] - xc[j]; sn += d * d; } sn = std::sqrt(sn);
+    double sn = 0.0; for (int j = 0; j < ng; ++j) { const double d = x[j] - xc[j]; sn += d * d; } sn = std::sqrt(sn);
     const double cost_change = cost - new_cost;
     if (sn <= O.parameter_tolerance * (x_norm + O.parameter_tolerance)) {
       S->termination_type = OR_CONVERGENCE; std::snprintf(S->message, sizeof(S->message), "Parameter tolerance reached. Relative step_norm: %e <= %e.", sn / (x_norm + O.parameter_tolerance), O.parameter_tolerance);
@@ -563,8 +596,8 @@ static void minimize(Model& M, const or_options& O, double* x, or_summary* S) {
     }
     const double rho = cost_change / mcc;
     if (rho > O.min_relative_decrease) {
-      for (int j = 0; j < n; ++j) x[j] = xc[j];
-      x_norm = norm2(x, n);
+      for (int j = 0; j < ng; ++j) x[j] = xc[j];
+      x_norm = norm2(x, ng);
       if (!M.evaluate(x, true, &cost)) { S->termination_type = OR_FAILURE; std::snprintf(S->message, sizeof(S->message), "Residual and Jacobian evaluation failed."); break; }
       M.gradient(g.data()); gmax = max_abs(g.data(), n);
       if (O.jacobi_scaling) M.scale_columns(scale.data());
@@ -628,15 +661,64 @@ int or_solve(int num_blocks, const int* block_sizes, double* x, int num_res_bloc
 }
 
 // The same with robust losses: loss_nodes as in oracle/loss.hpp, block_loss[b] = root node of block b's loss or -1.
+static int solve_dense(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
+                       const int* functor_ids, const double* consts, const int* const_off,
+                       const int* pidx, const int* pidx_off, const double* loss_nodes, const int* block_loss,
+                       const int* param_type, const int* param_const_off, const int* param_const,
+                       const or_options* opt, or_summary* summary);
+
 int or_solve_loss(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
                   const int* functor_ids, const double* consts, const int* const_off,
                   const int* pidx, const int* pidx_off, const double* loss_nodes, const int* block_loss,
                   const or_options* opt, or_summary* summary) {
+  return solve_dense(num_blocks, block_sizes, x, num_res_blocks, functor_ids, consts, const_off, pidx, pidx_off, loss_nodes, block_loss,
+                     nullptr, nullptr, nullptr, opt, summary);
+}
+
+// ... and with local parameterizations (oracle/parameterization.hpp): param_type[b] = P_* or -1 (none) per parameter
+// block; the indices a subset parameterization holds constant are param_const[param_const_off[b] .. param_const_off[b+1]).
+int or_solve_param(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
+                   const int* functor_ids, const double* consts, const int* const_off,
+                   const int* pidx, const int* pidx_off, const double* loss_nodes, const int* block_loss,
+                   const int* param_type, const int* param_const_off, const int* param_const,
+                   const or_options* opt, or_summary* summary) {
+  return solve_dense(num_blocks, block_sizes, x, num_res_blocks, functor_ids, consts, const_off, pidx, pidx_off, loss_nodes, block_loss,
+                     param_type, param_const_off, param_const, opt, summary);
+}
+
+static Parameterization make_parameterization(int type, int size, const int* constant, int nconst) {
+  Parameterization p; p.type = type < 0 ? P_IDENTITY : type; p.global_size = size;
+  if (p.type == P_SUBSET) p.constant.assign(constant, constant + nconst);
+  return p;
+}
+int or_parameterization_local_size(int type, int size, int nconst) { return make_parameterization(type, size, nullptr, 0).type == P_SUBSET ? size - nconst : make_parameterization(type, size, nullptr, 0).local_size(); }
+void or_parameterization_plus(int type, int size, const int* constant, int nconst, const double* x, const double* delta, double* x_plus) {
+  parameterization_plus(make_parameterization(type, size, constant, nconst), x, delta, x_plus);
+}
+void or_parameterization_jacobian(int type, int size, const int* constant, int nconst, const double* x, double* J) {
+  parameterization_jacobian(make_parameterization(type, size, constant, nconst), x, J);
+}
+
+static int solve_dense(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
+                       const int* functor_ids, const double* consts, const int* const_off,
+                       const int* pidx, const int* pidx_off, const double* loss_nodes, const int* block_loss,
+                       const int* param_type, const int* param_const_off, const int* param_const,
+                       const or_options* opt, or_summary* summary) {
   Problem P; P.num_blocks = num_blocks;
   if (loss_nodes && block_loss) { P.loss_nodes = loss_nodes; P.block_loss.assign(block_loss, block_loss + num_res_blocks); } P.block_size.assign(block_sizes, block_sizes + num_blocks);
   P.block_off.resize(num_blocks); int off = 0;
   for (int b = 0; b < num_blocks; ++b) { P.block_off[b] = off; off += block_sizes[b]; }
   P.num_params = off; P.num_res_blocks = num_res_blocks;
+  if (param_type) {
+    P.params.resize(num_blocks); P.local_off.resize(num_blocks); int loff = 0;
+    for (int b = 0; b < num_blocks; ++b) {
+      const int c0 = param_const_off ? param_const_off[b] : 0, c1 = param_const_off ? param_const_off[b + 1] : 0;
+      P.params[b] = make_parameterization(param_type[b], block_sizes[b], param_const ? param_const + c0 : nullptr, c1 - c0);
+      P.local_off[b] = loff; loff += P.params[b].local_size();
+    }
+    P.num_local = loff;
+    if (loff == 0) return -5;
+  }
   P.functor.assign(functor_ids, functor_ids + num_res_blocks);
   P.const_off.assign(const_off, const_off + num_res_blocks);
   P.pidx_off.assign(pidx_off, pidx_off + num_res_blocks + 1);

@@ -59,6 +59,16 @@ int or_solve_loss(int num_blocks, const int* block_sizes, double* x, int num_res
                   const int* functor_ids, const double* consts, const int* const_off, const int* pidx,
                   const int* pidx_off, const double* loss_nodes, const int* block_loss,
                   const or_options* opt, or_summary* summary);
+/* local parameterizations (oracle/parameterization.hpp): type 0 identity, 1 subset, 2 quaternion, 3 homogeneous vector,
+ * 4 constant; -1 = none */
+int or_solve_param(int num_blocks, const int* block_sizes, double* x, int num_res_blocks,
+                   const int* functor_ids, const double* consts, const int* const_off, const int* pidx,
+                   const int* pidx_off, const double* loss_nodes, const int* block_loss,
+                   const int* param_type, const int* param_const_off, const int* param_const,
+                   const or_options* opt, or_summary* summary);
+int or_parameterization_local_size(int type, int size, int nconst);
+void or_parameterization_plus(int type, int size, const int* constant, int nconst, const double* x, const double* delta, double* x_plus);
+void or_parameterization_jacobian(int type, int size, const int* constant, int nconst, const double* x, double* J);
 int or_solve_bal_loss(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                       const double* loss_nodes, int loss_root, double* x, const or_options* opt, or_summary* summary);
 int or_bal_evaluate(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,

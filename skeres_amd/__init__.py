@@ -22,7 +22,8 @@ from .api import (  # noqa: F401
     NumericDiffCostFunctor, NumericDiffCostFunction, NumericDiffMethodType, NumericDiffOptions,
     HostAutoDiffCostFunctor, HostAutoDiffCostFunction, CostFunctorAdapter, CostFunctionToFunctor, DynamicCostFunctionToFunctor,
     SnavelyReprojectionError, ExponentialResidual, PowellF1, PowellF2, PowellF3, PowellF4,
-    BinaryScalarCost, BinaryVector3Cost, TenParameterCost, HelloCostFunctor,
+    BinaryScalarCost, BinaryVector3Cost, TenParameterCost, HelloCostFunctor, QuaternionRotationError,
+    LocalParameterization, PredefinedLocalParameterizations,
     PredefinedLossFunctions, LossFunction, Problem, Solver, LinearSolverType, MinimizerType, TerminationType,
     ceres, StepSolver,
 )

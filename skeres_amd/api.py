@@ -50,6 +50,19 @@ _SIGS = {
     "sk_rotation_apply": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp]),
     "sk_loss_trivial": (C.c_void_p, []),
     "sk_loss_huber": (C.c_void_p, [C.c_double]),
+    "sk_local_parameterization_identity": (C.c_void_p, [C.c_int]),
+    "sk_local_parameterization_subset": (C.c_void_p, [C.c_int, _ip, C.c_int]),
+    "sk_local_parameterization_quaternion": (C.c_void_p, []),
+    "sk_local_parameterization_homogeneous_vector": (C.c_void_p, [C.c_int]),
+    "sk_local_parameterization_free": (None, [C.c_void_p]),
+    "sk_local_parameterization_global_size": (C.c_int, [C.c_void_p]),
+    "sk_local_parameterization_local_size": (C.c_int, [C.c_void_p]),
+    "sk_local_parameterization_plus": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, _dp]),
+    "sk_local_parameterization_compute_jacobian": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
+    "sk_problem_add_parameter_block": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_void_p]),
+    "sk_problem_set_parameterization": (C.c_int, [C.c_void_p, _dp, C.c_void_p]),
+    "sk_problem_set_parameter_block_constant": (C.c_int, [C.c_void_p, _dp]),
+    "sk_problem_set_parameter_block_variable": (C.c_int, [C.c_void_p, _dp]),
     "sk_loss_soft_l_one": (C.c_void_p, [C.c_double]),
     "sk_loss_cauchy": (C.c_void_p, [C.c_double]),
     "sk_loss_tukey": (C.c_void_p, [C.c_double]),
@@ -693,6 +706,15 @@ class TenParameterCost(AutoDiffCostFunctor):  # TEST/AutodiffCostFuntionSpec.sca
         super().__init__(1, *([1] * 10))
 
 
+class QuaternionRotationError(AutoDiffCostFunctor):
+    """r = R(q) p - t for a quaternion block q = (w, x, y, z), normalised first (no reference counterpart: a registered
+    functor with a block of size 4 for the local parameterizations to act on)."""
+    FUNCTOR_ID = 12
+
+    def __init__(self, p, t):
+        super().__init__(3, 4, consts=tuple(p) + tuple(t))
+
+
 class HelloCostFunctor(AutoDiffCostFunctor):  # EX/HelloWorld.scala:11-14
     FUNCTOR_ID = 11
 
@@ -758,6 +780,63 @@ class PredefinedLossFunctions:  # ceres.i:168-184
         return LossFunction(lib().sk_loss_scaled(rho._h if rho is not None else None, a))
 
 
+class LocalParameterization:
+    """com.google.ceres.LocalParameterization as built by PredefinedLocalParameterizations (ceres.i:186-210)."""
+
+    def __init__(self, h):
+        if not h:
+            raise ValueError(lib().sk_last_error().decode())
+        self._h = h
+
+    def globalSize(self):
+        return lib().sk_local_parameterization_global_size(self._h)
+
+    def localSize(self):
+        return lib().sk_local_parameterization_local_size(self._h)
+
+    def plus(self, x, delta):
+        """LocalParameterization::Plus on the device; x [global] or [n, global], delta [local] or [n, local]."""
+        x2 = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        d2 = np.ascontiguousarray(np.atleast_2d(delta), dtype=np.float64).reshape(len(x2), -1)
+        if d2.shape[1] == 0:
+            d2 = np.zeros((len(x2), 1))
+        out = np.zeros_like(x2)
+        _check(lib().sk_local_parameterization_plus(self._h, x2.ctypes.data_as(_dp), d2.ctypes.data_as(_dp), len(x2), out.ctypes.data_as(_dp)))
+        return out if np.ndim(x) == 2 else out[0]
+
+    def computeJacobian(self, x):
+        """LocalParameterization::ComputeJacobian on the device: [global, local] (or [n, global, local])."""
+        x2 = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        J = np.zeros((len(x2), self.globalSize(), self.localSize()))
+        if J.size:
+            _check(lib().sk_local_parameterization_compute_jacobian(self._h, x2.ctypes.data_as(_dp), len(x2), J.ctypes.data_as(_dp)))
+        return J if np.ndim(x) == 2 else J[0]
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.sk_local_parameterization_free(self._h)
+            self._h = None
+
+
+class PredefinedLocalParameterizations:  # ceres.i:186-210
+    @staticmethod
+    def identity(size):
+        return LocalParameterization(lib().sk_local_parameterization_identity(int(size)))
+
+    @staticmethod
+    def subset(size, constant_parameters):
+        c = np.ascontiguousarray(list(constant_parameters), dtype=np.int32)
+        return LocalParameterization(lib().sk_local_parameterization_subset(int(size), c.ctypes.data_as(_ip) if c.size else _ip(), c.size))
+
+    @staticmethod
+    def quaternion():
+        return LocalParameterization(lib().sk_local_parameterization_quaternion())
+
+    @staticmethod
+    def homogeneousVector(size):
+        return LocalParameterization(lib().sk_local_parameterization_homogeneous_vector(int(size)))
+
+
 # ---------------------------------------------------------------------------
 # Problem / Solver
 # ---------------------------------------------------------------------------
@@ -798,6 +877,32 @@ class Problem:
             raise ValueError(lib().sk_last_error().decode())
         _check(rc)
         return rid.value
+
+    # ceres::Problem members the reference's Problem inherits from the SWIG-wrapped class (CORE/Problem.scala:16)
+    def addParameterBlock(self, values, size, parameterization=None):
+        self._arrays.append(values)
+        rc = lib().sk_problem_add_parameter_block(self._h, values.cast(), int(size), parameterization._h if parameterization is not None else None)
+        if rc == 1:
+            raise ValueError(lib().sk_last_error().decode())
+        _check(rc)
+
+    def setParameterization(self, values, parameterization):
+        rc = lib().sk_problem_set_parameterization(self._h, values.cast(), parameterization._h if parameterization is not None else None)
+        if rc == 1:
+            raise ValueError(lib().sk_last_error().decode())
+        _check(rc)
+
+    def setParameterBlockConstant(self, values):
+        rc = lib().sk_problem_set_parameter_block_constant(self._h, values.cast())
+        if rc == 1:
+            raise ValueError(lib().sk_last_error().decode())
+        _check(rc)
+
+    def setParameterBlockVariable(self, values):
+        rc = lib().sk_problem_set_parameter_block_variable(self._h, values.cast())
+        if rc == 1:
+            raise ValueError(lib().sk_last_error().decode())
+        _check(rc)
 
     def addResidualBlocks(self, functor_id, consts, loss, base, offsets):
         """Bulk form of the loop at EX/SimpleBundleAdjuster.scala:139-145.

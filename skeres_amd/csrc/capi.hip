@@ -15,6 +15,7 @@ struct sk_ptrvec { std::vector<double*> v; };
 struct sk_loss_function { LossFunction l; };
 struct sk_cost_function { CostFunction c; };
 struct sk_problem { Problem p; };
+struct sk_local_parameterization { LocalParameterization p; };
 struct sk_options { Options o; };
 struct sk_summary { Summary s; };
 struct sk_solver { std::unique_ptr<SolverBase> impl; };
@@ -172,6 +173,80 @@ int sk_loss_evaluate(const sk_loss_function* loss, const double* sq_norm, int n,
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }
 
+// ---- PredefinedLocalParameterizations (ceres.i:186-210) ----------------------------
+static sk_local_parameterization* param_new(int type, int global_size, int local_size, unsigned mask) {
+  if (global_size < 1 || global_size > kParamMaxSize) { set_error("local parameterization: size %d outside 1..%d", global_size, kParamMaxSize); return nullptr; }
+  sk_local_parameterization* h = new (std::nothrow) sk_local_parameterization();
+  if (!h) { set_error("out of host memory"); return nullptr; }
+  h->p.type = type; h->p.global_size = global_size; h->p.local_size = local_size; h->p.constant_mask = mask;
+  return h;
+}
+sk_local_parameterization* sk_local_parameterization_identity(int size) { return param_new(kParamIdentity, size, size, 0u); }
+sk_local_parameterization* sk_local_parameterization_subset(int size, const int* constant_parameters, int num_constant) {
+  if (num_constant < 0 || (num_constant > 0 && !constant_parameters)) { set_error("subset parameterization: bad arguments"); return nullptr; }
+  unsigned mask = 0;
+  for (int i = 0; i < num_constant; ++i) {
+    const int c = constant_parameters[i];
+    if (c < 0 || c >= size) { set_error("subset parameterization: constant index %d outside [0, %d)", c, size); return nullptr; }  // ceres: "Indices indicating constant parameter must be ... "
+    if ((mask >> c) & 1u) { set_error("subset parameterization: the set of constant parameters cannot contain duplicates"); return nullptr; }
+    mask |= 1u << c;
+  }
+  return param_new(kParamSubset, size, size - num_constant, mask);
+}
+sk_local_parameterization* sk_local_parameterization_quaternion(void) { return param_new(kParamQuaternion, 4, 3, 0u); }
+sk_local_parameterization* sk_local_parameterization_homogeneous_vector(int size) {
+  if (size < 2) { set_error("homogeneous vector parameterization: the size of the homogeneous vector needs to be greater than 1"); return nullptr; }
+  return param_new(kParamHomogeneousVector, size, size - 1, 0u);
+}
+void sk_local_parameterization_free(sk_local_parameterization* p) { delete p; }
+int sk_local_parameterization_global_size(const sk_local_parameterization* p) { return p ? p->p.global_size : -1; }
+int sk_local_parameterization_local_size(const sk_local_parameterization* p) { return p ? p->p.local_size : -1; }
+
+__global__ void param_apply_kernel(ParamBlock pb, const double* x, const double* delta, int n, double* x_plus, double* jac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (x_plus) param_plus(pb, x + (size_t)i * pb.global_size, delta + (size_t)i * (pb.local_size > 0 ? pb.local_size : 1), x_plus + (size_t)i * pb.global_size);
+  if (jac) param_jacobian(pb, x + (size_t)i * pb.global_size, jac + (size_t)i * pb.global_size * pb.local_size);
+}
+static ParamBlock param_block_of(const LocalParameterization& lp) {
+  ParamBlock pb; pb.type = lp.type; pb.global_size = lp.global_size; pb.local_size = lp.local_size; pb.constant_mask = lp.constant_mask;
+  pb.global_off = pb.local_off = 0;
+  return pb;
+}
+// n points at once, ON THE DEVICE (the code the solver runs): x [n][global], delta [n][local] -> x_plus [n][global]
+int sk_local_parameterization_plus(const sk_local_parameterization* p, const double* x, const double* delta, int n, double* x_plus) {
+  SK_GUARD_BEGIN
+  if (!p || n < 0 || (n > 0 && (!x || !delta || !x_plus))) { set_error("sk_local_parameterization_plus: bad arguments"); return SK_ERR_INVALID_ARGUMENT; }
+  if (n == 0) return SK_OK;
+  if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
+  const int gs = p->p.global_size, ls = std::max(p->p.local_size, 1);
+  DevBuf<double> dx, dd, dout;
+  SK_HIP_TRY(dx.upload(std::vector<double>(x, x + (size_t)n * gs), nullptr));
+  SK_HIP_TRY(dd.upload(std::vector<double>(delta, delta + (size_t)n * ls), nullptr));
+  SK_HIP_TRY(dout.alloc((size_t)n * gs));
+  hipLaunchKernelGGL(param_apply_kernel, dim3((n + 127) / 128), dim3(128), 0, nullptr, param_block_of(p->p), (const double*)dx.p, (const double*)dd.p, n, dout.p, (double*)nullptr);
+  SK_HIP_TRY(hipGetLastError());
+  SK_HIP_TRY(hipMemcpy(x_plus, dout.p, (size_t)n * gs * sizeof(double), hipMemcpyDeviceToHost));
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+// jacobian [n][global x local], row-major
+int sk_local_parameterization_compute_jacobian(const sk_local_parameterization* p, const double* x, int n, double* jacobian) {
+  SK_GUARD_BEGIN
+  if (!p || n < 0 || (n > 0 && (!x || !jacobian))) { set_error("sk_local_parameterization_compute_jacobian: bad arguments"); return SK_ERR_INVALID_ARGUMENT; }
+  if (n == 0 || p->p.local_size == 0) return SK_OK;
+  if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
+  const int gs = p->p.global_size, ls = p->p.local_size;
+  DevBuf<double> dx, dj;
+  SK_HIP_TRY(dx.upload(std::vector<double>(x, x + (size_t)n * gs), nullptr));
+  SK_HIP_TRY(dj.alloc((size_t)n * gs * ls));
+  hipLaunchKernelGGL(param_apply_kernel, dim3((n + 127) / 128), dim3(128), 0, nullptr, param_block_of(p->p), (const double*)dx.p, (const double*)nullptr, n, (double*)nullptr, dj.p);
+  SK_HIP_TRY(hipGetLastError());
+  SK_HIP_TRY(hipMemcpy(jacobian, dj.p, (size_t)n * gs * ls * sizeof(double), hipMemcpyDeviceToHost));
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
 // ---- CostFunction -----------------------------------------------------------------
 sk_cost_function* sk_cost_function_new_autodiff(int functor_id, const double* consts, int num_consts) {
   FunctorDesc d;
@@ -249,6 +324,50 @@ static int register_block(Problem& P, double* ptr, int size) {
   P.block_of.emplace(ptr, id); P.block_ptr.push_back(ptr); P.block_size.push_back(size);
   return id;
 }
+
+// ceres::Problem::AddParameterBlock / SetParameterization / SetParameterBlockConstant / SetParameterBlockVariable,
+// which the reference's Problem inherits (CORE/Problem.scala:16)
+static int set_block_param(Problem& P, int id, const sk_local_parameterization* lp) {
+  P.block_param.resize(P.block_ptr.size(), -1);
+  if (!lp) { P.block_param[id] = -1; return SK_OK; }
+  if (lp->p.global_size != P.block_size[id]) {
+    set_error("local parameterization of global size %d set on a parameter block of size %d", lp->p.global_size, P.block_size[id]);
+    return SK_ERR_INVALID_ARGUMENT;
+  }
+  P.params.push_back(lp->p);
+  P.block_param[id] = (int)P.params.size() - 1;
+  return SK_OK;
+}
+int sk_problem_add_parameter_block(sk_problem* p, double* values, int size, const sk_local_parameterization* parameterization) {
+  SK_GUARD_BEGIN
+  if (!p || size < 1) { set_error("sk_problem_add_parameter_block: bad arguments"); return SK_ERR_INVALID_ARGUMENT; }
+  const int id = register_block(p->p, values, size);
+  if (id < 0) return SK_ERR_INVALID_ARGUMENT;
+  return parameterization ? set_block_param(p->p, id, parameterization) : SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+static int find_block(Problem& P, double* values) {
+  auto it = P.block_of.find(values);
+  if (it == P.block_of.end()) { set_error("parameter block %p is not part of the problem", (void*)values); return -1; }
+  return it->second;
+}
+int sk_problem_set_parameterization(sk_problem* p, double* values, const sk_local_parameterization* parameterization) {
+  SK_GUARD_BEGIN
+  if (!p) { set_error("null problem"); return SK_ERR_INVALID_ARGUMENT; }
+  const int id = find_block(p->p, values);
+  return id < 0 ? SK_ERR_INVALID_ARGUMENT : set_block_param(p->p, id, parameterization);
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+static int set_block_constant(sk_problem* p, double* values, char constant) {
+  if (!p) { set_error("null problem"); return SK_ERR_INVALID_ARGUMENT; }
+  const int id = find_block(p->p, values);
+  if (id < 0) return SK_ERR_INVALID_ARGUMENT;
+  p->p.block_constant.resize(p->p.block_ptr.size(), 0);
+  p->p.block_constant[id] = constant;
+  return SK_OK;
+}
+int sk_problem_set_parameter_block_constant(sk_problem* p, double* values) { return set_block_constant(p, values, 1); }
+int sk_problem_set_parameter_block_variable(sk_problem* p, double* values) { return set_block_constant(p, values, 0); }
 
 int sk_problem_add_residual_block(sk_problem* p, const sk_cost_function* cost, const sk_loss_function* loss, double* const* parameter_blocks,
                                   int num_parameter_blocks, sk_residual_block_id* id_out) {
@@ -410,6 +529,10 @@ double sk_summary_phase_seconds(const sk_summary* s, int phase) { return (phase 
 // ---- solve ------------------------------------------------------------------------------
 static std::unique_ptr<SolverBase> make_solver(const Options& o, Problem* p, int* rc) {
   *rc = SK_OK;
+  if (p->has_parameterization() && (o.linear_solver_type == SK_DENSE_SCHUR || problem_is_dense_rows(*p))) {
+    set_error("local parameterizations and constant parameter blocks are implemented for DENSE_QR / DENSE_NORMAL_CHOLESKY over residual blocks (not supported here)");
+    *rc = SK_ERR_UNSUPPORTED; return nullptr;
+  }
   if (o.linear_solver_type == SK_DENSE_SCHUR) {
     std::string why;
     if (!problem_is_bal_shaped(*p, &why)) { set_error("%s", why.c_str()); *rc = SK_ERR_UNSUPPORTED; return nullptr; }

@@ -13,6 +13,7 @@
 #include "../../include/skeres_amd.h"
 #include "functors.hpp"
 #include "loss.hpp"
+#include "parameterization.hpp"
 
 namespace sk {
 
@@ -72,6 +73,12 @@ struct LossFunction {
   int root() const { return nodes.empty() ? -1 : (int)nodes.size() - 1; }
 };
 
+// PredefinedLocalParameterizations (ceres.i:186-210)
+struct LocalParameterization {
+  int type = kParamIdentity, global_size = 0, local_size = 0;
+  unsigned constant_mask = 0;  // subset: bit i = coordinate i held constant
+};
+
 struct Problem {  // CeresProblem; parameter blocks identified by pointer value
   std::unordered_map<double*, int> block_of;
   std::vector<double*> block_ptr;
@@ -91,6 +98,16 @@ struct Problem {  // CeresProblem; parameter blocks identified by pointer value
   std::unordered_map<std::string, int> loss_root_of;
   bool has_loss = false;
   int intern_loss(const LossFunction* l);
+  // local parameterizations: block_param[b] = index into params (copied: the caller may free its object), -1 = none;
+  // block_constant[b]: Problem::SetParameterBlockConstant
+  std::vector<LocalParameterization> params;
+  std::vector<int> block_param;
+  std::vector<char> block_constant;
+  bool has_parameterization() const {
+    for (size_t b = 0; b < block_ptr.size(); ++b)
+      if ((b < block_param.size() && block_param[b] >= 0) || (b < block_constant.size() && block_constant[b])) return true;
+    return false;
+  }
   long num_residuals = 0;
   bool has_callbacks = false;
   Problem() { rb_pidx_off.push_back(0); }

@@ -4,6 +4,7 @@
 // J is row-major m x n in HBM with the Jacobi column scaling folded in.
 #include <hip/hip_runtime.h>
 #include "dense_kernels.hpp"
+#include "parameterization.hpp"
 #include "functors.hpp"
 
 namespace sk {
@@ -310,6 +311,65 @@ __global__ __launch_bounds__(256) void dense_qr_solve_kernel(double* A, double* 
 }
 
 void launch_dense_col_reduce(const double* J, const double* r, int m, int n, double* colsq, double* gs, hipStream_t s) { hipLaunchKernelGGL(dense_col_reduce_kernel, dim3((n + 127) / 128), dim3(128), 0, s, J, r, m, n, colsq, gs); }
+// ---------------------------------------------------------------------------
+// Local parameterizations (parameterization.hpp): the minimiser works in the tangent space.
+// ---------------------------------------------------------------------------
+// Jl (m x nl) = Jg (m x ng) blockdiag(dPlus/ddelta at x) diag(scale): one lane per (row, parameter block)
+__global__ __launch_bounds__(256) void dense_project_kernel(const double* Jg, int m, int ng, const ParamBlock* blocks, int nblocks, const double* x,
+                                                           const double* scale, double* Jl, int nl) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)m * nblocks) return;
+  const int row = (int)(e / nblocks);
+  const ParamBlock pb = blocks[e % nblocks];
+  if (pb.local_size == 0) return;
+  const double* g = Jg + (size_t)row * ng + pb.global_off;
+  bool any = false;
+  for (int i = 0; i < pb.global_size; ++i) any = any || g[i] != 0.0;
+  double* out = Jl + (size_t)row * nl + pb.local_off;
+  if (!any) { for (int c = 0; c < pb.local_size; ++c) out[c] = 0.0; return; }
+  double P[kParamMaxSize * kParamMaxSize];
+  param_jacobian(pb, x + pb.global_off, P);
+  for (int c = 0; c < pb.local_size; ++c) {
+    double acc = 0.0;
+    for (int i = 0; i < pb.global_size; ++i) acc += g[i] * P[i * pb.local_size + c];
+    out[c] = acc * scale[pb.local_off + c];
+  }
+}
+// step = -y (tangent, scaled); x_new = Plus(x, step * scale) block by block; out[0] = |x - x_new|^2
+__global__ __launch_bounds__(256) void dense_plus_kernel(const double* y, const double* scale, const double* x, double* step, double* x_new,
+                                                        const ParamBlock* blocks, int nblocks, double* out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    const ParamBlock pb = blocks[b];
+    double delta[kParamMaxSize], xp[kParamMaxSize];
+    for (int c = 0; c < pb.local_size; ++c) {
+      const double st = -y[pb.local_off + c];
+      step[pb.local_off + c] = st;
+      delta[c] = st * scale[pb.local_off + c];
+    }
+    param_plus(pb, x + pb.global_off, delta, xp);
+    for (int i = 0; i < pb.global_size; ++i) {
+      x_new[pb.global_off + i] = xp[i];
+      const double d = x[pb.global_off + i] - xp[i];
+      s += d * d;
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+void launch_dense_project(const double* Jg, int m, int ng, const ParamBlock* blocks, int nblocks, const double* x, const double* scale, double* Jl, int nl,
+                          hipStream_t s) {
+  const long e = (long)m * nblocks;
+  hipLaunchKernelGGL(dense_project_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, s, Jg, m, ng, blocks, nblocks, x, scale, Jl, nl);
+}
+void launch_dense_plus(const double* y, const double* scale, const double* x, double* step, double* x_new, const ParamBlock* blocks, int nblocks, double* out,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(dense_plus_kernel, dim3(1), dim3(256), 0, s, y, scale, x, step, x_new, blocks, nblocks, out);
+}
+
 void launch_dense_scale(double* J, const double* scale, int m, int n, hipStream_t s) { const size_t e = (size_t)m * n; hipLaunchKernelGGL(dense_scale_kernel, dim3((unsigned)((e + 255) / 256)), dim3(256), 0, s, J, scale, m, n); }
 void launch_dense_sumsq(const double* r, int m, double* out, hipStream_t s) { hipLaunchKernelGGL(dense_sumsq_kernel, dim3(1), dim3(256), 0, s, r, m, out); }
 void launch_dense_normal(const double* J, const double* r, int m, int n, double* H, int ld, int rhs_row, hipStream_t s) { const int e = n * (n + 1); hipLaunchKernelGGL(dense_normal_kernel, dim3((e + 255) / 256), dim3(256), 0, s, J, r, m, n, H, ld, rhs_row); }

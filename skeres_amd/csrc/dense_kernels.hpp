@@ -42,6 +42,11 @@ void launch_dense_sum(const double* v, int m, double* out, hipStream_t s);
 void launch_single_eval(int functor_id, const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
                         const int* jac_off, int want_jac, unsigned jac_mask, int* ok, hipStream_t s);
 void launch_dense_col_reduce(const double* J, const double* r, int m, int n, double* colsq, double* gs, hipStream_t s);
+struct ParamBlock;
+void launch_dense_project(const double* Jg, int m, int ng, const ParamBlock* blocks, int nblocks, const double* x, const double* scale, double* Jl, int nl,
+                          hipStream_t s);
+void launch_dense_plus(const double* y, const double* scale, const double* x, double* step, double* x_new, const ParamBlock* blocks, int nblocks, double* out,
+                       hipStream_t s);
 void launch_dense_scale(double* J, const double* scale, int m, int n, hipStream_t s);
 void launch_dense_sumsq(const double* r, int m, double* out, hipStream_t s);
 void launch_dense_normal(const double* J, const double* r, int m, int n, double* H, int ld, int rhs_row, hipStream_t s);

@@ -30,14 +30,21 @@ class DenseSolver : public SolverBase {
   int write_back() override;
   void describe(Summary* s) override {
     s->num_parameter_blocks = (int)problem_->block_size.size();
-    s->num_parameters = n_; s->num_residual_blocks = (int)problem_->rb_functor.size(); s->num_residuals = m_;
+    s->num_parameters = ng_; s->num_residual_blocks = (int)problem_->rb_functor.size(); s->num_residuals = m_;
   }
 
  private:
   int evaluate(const double* x_dev, bool jac);
   int host_callbacks(const double* x_dev, bool jac);
 
-  int n_ = 0, m_ = 0, npad_ = 0, rhs_row_ = 0;
+  // n_: columns of the Jacobian the minimiser works with = size of the tangent space; ng_: size of x.  Equal unless
+  // the problem has local parameterizations or constant blocks (tangent_): then the functors fill the global Jacobian
+  // b_Jg_ unscaled, and dense_project_kernel forms b_J_ = b_Jg_ blockdiag(dPlus/ddelta) diag(scale).
+  int n_ = 0, ng_ = 0, m_ = 0, npad_ = 0, rhs_row_ = 0;
+  bool tangent_ = false;
+  DevBuf<double> b_Jg_, b_ones_;
+  DevBuf<ParamBlock> b_pblocks_;
+  int num_pblocks_ = 0;
   std::vector<int> block_off_;
   std::map<int, std::vector<int>> by_functor_;  // functor id -> residual block ids
   std::map<int, DevBuf<int>> by_functor_dev_;
@@ -63,8 +70,34 @@ int DenseSolver::setup() {
   const int nb = (int)p.rb_functor.size();
   if (nb == 0) { set_error("problem has no residual blocks"); return SK_ERR_INVALID_ARGUMENT; }
   block_off_.resize(p.block_size.size());
-  n_ = 0;
-  for (size_t b = 0; b < p.block_size.size(); ++b) { block_off_[b] = n_; n_ += p.block_size[b]; }
+  ng_ = 0;
+  for (size_t b = 0; b < p.block_size.size(); ++b) { block_off_[b] = ng_; ng_ += p.block_size[b]; }
+  n_ = ng_;
+  tangent_ = p.has_parameterization();
+  std::vector<ParamBlock> pblocks;
+  if (tangent_) {
+    n_ = 0;
+    for (size_t b = 0; b < p.block_size.size(); ++b) {
+      ParamBlock pb; pb.type = kParamIdentity; pb.global_size = pb.local_size = p.block_size[b]; pb.constant_mask = 0u;
+      if (b < p.block_param.size() && p.block_param[b] >= 0) {
+        const LocalParameterization& lp = p.params[p.block_param[b]];
+        pb.type = lp.type; pb.local_size = lp.local_size; pb.constant_mask = lp.constant_mask;
+      }
+      if (b < p.block_constant.size() && p.block_constant[b]) { pb.type = kParamConstant; pb.local_size = 0; }
+      if (pb.type != kParamIdentity && pb.global_size > kParamMaxSize) { set_error("parameterized block of size %d (max %d)", pb.global_size, kParamMaxSize); return SK_ERR_UNSUPPORTED; }
+      if (pb.type == kParamIdentity && pb.global_size > kParamMaxSize) {  // a plain large block next to parameterized ones: as pieces
+        for (int o = 0; o < p.block_size[b]; o += kParamMaxSize) {
+          ParamBlock piece = pb; piece.global_size = piece.local_size = std::min(kParamMaxSize, p.block_size[b] - o);
+          piece.global_off = block_off_[b] + o; piece.local_off = n_; n_ += piece.local_size; pblocks.push_back(piece);
+        }
+        continue;
+      }
+      pb.global_off = block_off_[b]; pb.local_off = n_; n_ += pb.local_size;
+      pblocks.push_back(pb);
+    }
+    num_pblocks_ = (int)pblocks.size();
+    if (n_ == 0) { set_error("every parameter block is constant: nothing to optimise"); return SK_ERR_INVALID_ARGUMENT; }
+  }
   m_ = (int)p.num_residuals;
   if ((double)m_ * n_ > 2e9) { set_error("dense Jacobian of %d x %d is too large for this build", m_, n_); return SK_ERR_UNSUPPORTED; }
   res_off_h_.resize(nb + 1);
@@ -88,9 +121,14 @@ int DenseSolver::setup() {
   SK_HIP_TRY(b_consts_.upload(consts, s)); SK_HIP_TRY(b_const_off_.upload(p.rb_const_off, s));
   SK_HIP_TRY(b_pidx_off_.upload(p.rb_pidx_off, s)); SK_HIP_TRY(b_pidx_.upload(pidx, s)); SK_HIP_TRY(b_res_off_.upload(res_off_h_, s));
   for (auto& kv : by_functor_) SK_HIP_TRY(by_functor_dev_[kv.first].upload(kv.second, s));
-  std::vector<double> x(n_);
+  std::vector<double> x(ng_);
   for (size_t b = 0; b < p.block_size.size(); ++b) std::memcpy(&x[block_off_[b]], p.block_ptr[b], p.block_size[b] * sizeof(double));
-  SK_HIP_TRY(b_xa_.upload(x, s)); SK_HIP_TRY(b_xb_.alloc(n_));
+  SK_HIP_TRY(b_xa_.upload(x, s)); SK_HIP_TRY(b_xb_.alloc(ng_));
+  if (tangent_) {
+    SK_HIP_TRY(b_pblocks_.upload(pblocks, s));
+    SK_HIP_TRY(b_ones_.upload(std::vector<double>(ng_, 1.0), s));
+    SK_HIP_TRY(b_Jg_.alloc((size_t)m_ * ng_)); SK_HIP_TRY(b_Jg_.zero(s));
+  }
   x_ = b_xa_.p; x_new_ = b_xb_.p;
   SK_HIP_TRY(b_scale_.alloc(n_)); SK_HIP_TRY(b_colsq_.alloc(n_)); SK_HIP_TRY(b_gs_.alloc(n_)); SK_HIP_TRY(b_D_.alloc(n_)); SK_HIP_TRY(b_step_.alloc(n_));
   { std::vector<double> ones(n_, 1.0); SK_HIP_TRY(hipMemcpyAsync(b_scale_.p, ones.data(), n_ * sizeof(double), hipMemcpyHostToDevice, s)); SK_HIP_TRY(hipStreamSynchronize(s)); }
@@ -113,9 +151,10 @@ int DenseSolver::setup() {
 int DenseSolver::host_callbacks(const double* x_dev, bool jac) {
   if (cb_blocks_.empty()) return SK_OK;
   const Problem& p = *problem_;
-  std::vector<double> x(n_), scale(n_);
-  SK_HIP_TRY(hipMemcpyAsync(x.data(), x_dev, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-  SK_HIP_TRY(hipMemcpyAsync(scale.data(), b_scale_.p, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  std::vector<double> x(ng_), scale(ng_, 1.0);
+  SK_HIP_TRY(hipMemcpyAsync(x.data(), x_dev, ng_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  if (!tangent_) SK_HIP_TRY(hipMemcpyAsync(scale.data(), b_scale_.p, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  double* Jrows = tangent_ ? b_Jg_.p : b_J_.p;
   SK_HIP_TRY(hipStreamSynchronize(stream_));
   double* r_dev = jac ? b_r_.p : b_rc_.p;
   for (int b : cb_blocks_) {
@@ -139,7 +178,7 @@ int DenseSolver::host_callbacks(const double* x_dev, bool jac) {
         for (int r = 0; r < nres; ++r) {
           rowbuf.resize(nq);
           for (int j = 0; j < nq; ++j) rowbuf[j] = jbuf[q][(size_t)r * nq + j] * scale[off + j];
-          SK_HIP_TRY(hipMemcpy(b_J_.p + (size_t)(res_off_h_[b] + r) * n_ + off, rowbuf.data(), nq * sizeof(double), hipMemcpyHostToDevice));
+          SK_HIP_TRY(hipMemcpy(Jrows + (size_t)(res_off_h_[b] + r) * ng_ + off, rowbuf.data(), nq * sizeof(double), hipMemcpyHostToDevice));
         }
       }
     }
@@ -152,14 +191,15 @@ int DenseSolver::host_callbacks(const double* x_dev, bool jac) {
 void DenseSolver::apply_loss(double* r, bool jac) {
   DenseLossArgs a;
   a.num_blocks = (int)problem_->rb_functor.size(); a.res_off = b_res_off_.p; a.rb_loss = b_rb_loss_.p; a.nodes = b_loss_nodes_.p;
-  a.pidx = b_pidx_.p; a.psize = b_psize_.p; a.pidx_off = b_pidx_off_.p; a.r = r; a.J = jac ? b_J_.p : nullptr; a.cterm = b_cterm_.p; a.n = n_;
+  a.pidx = b_pidx_.p; a.psize = b_psize_.p; a.pidx_off = b_pidx_off_.p; a.r = r; a.J = jac ? (tangent_ ? b_Jg_.p : b_J_.p) : nullptr; a.cterm = b_cterm_.p;
+  a.n = ng_;
   launch_dense_loss(a, stream_);
 }
 
 int DenseSolver::evaluate(const double* x_dev, bool jac) {
   DenseEvalArgs a;
   a.consts = b_consts_.p; a.const_off = b_const_off_.p; a.pidx = b_pidx_.p; a.pidx_off = b_pidx_off_.p; a.res_off = b_res_off_.p;
-  a.x = x_dev; a.scale = b_scale_.p; a.r = jac ? b_r_.p : b_rc_.p; a.J = b_J_.p; a.n = n_; a.fail_flag = b_fail_.p;
+  a.x = x_dev; a.scale = tangent_ ? b_ones_.p : b_scale_.p; a.r = jac ? b_r_.p : b_rc_.p; a.J = tangent_ ? b_Jg_.p : b_J_.p; a.n = ng_; a.fail_flag = b_fail_.p;
   for (auto& kv : by_functor_) {
     a.count = (int)kv.second.size(); a.blocks = by_functor_dev_[kv.first].p;
     launch_dense_eval(kv.first, jac, a, stream_);
@@ -174,6 +214,7 @@ int DenseSolver::evaluate_with_jacobian(bool first) {
   int rc = evaluate(x_, true);
   if (rc) return rc;
   if (has_loss_) apply_loss(b_r_.p, true);  // before the column norms: the Jacobi scaling is that of the corrected Jacobian
+  if (tangent_) launch_dense_project(b_Jg_.p, m_, ng_, b_pblocks_.p, num_pblocks_, x_, b_scale_.p, b_J_.p, n_, s);
   launch_dense_col_reduce(b_J_.p, b_r_.p, m_, n_, b_colsq_.p, b_gs_.p, s);
   if (first && opt_.jacobi_scaling) {
     launch_jacobi_scale(b_colsq_.p, b_scale_.p, n_, s);
@@ -182,6 +223,7 @@ int DenseSolver::evaluate_with_jacobian(bool first) {
   }
   if (has_loss_) launch_dense_sum(b_cterm_.p, m_, b_scal_.p, s); else launch_dense_sumsq(b_r_.p, m_, b_scal_.p, s);
   launch_dense_gmax(b_gs_.p, b_scale_.p, x_, n_, b_scal_.p + 1, s);
+  if (tangent_) launch_dense_sumsq(x_, ng_, b_scal_.p + 2, s);  // |x|^2 over the ambient vector
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 16, b_fail_.p, sizeof(int), hipMemcpyDeviceToHost, s));
   SK_HIP_TRY(hipEventRecord(ev_[kEvJac], s));
@@ -214,7 +256,8 @@ int DenseSolver::try_step(double radius, bool* valid, double* mcc, double* new_c
     launch_dense_qr(b_J_.p, b_r_.p, b_D_.p, m_, n_, b_A_.p, b_b_.p, b_y_.p, b_ok_.p, s);
   }
   SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
-  launch_dense_step(b_y_.p, b_scale_.p, x_, b_step_.p, x_new_, n_, b_scal_.p, s);
+  if (tangent_) launch_dense_plus(b_y_.p, b_scale_.p, x_, b_step_.p, x_new_, b_pblocks_.p, num_pblocks_, b_scal_.p, s);
+  else launch_dense_step(b_y_.p, b_scale_.p, x_, b_step_.p, x_new_, n_, b_scal_.p, s);
   launch_dense_model(b_J_.p, b_r_.p, b_step_.p, m_, n_, b_scal_.p + 1, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvBacksub], s));
   int rc = evaluate(x_new_, false);
@@ -244,8 +287,8 @@ int DenseSolver::try_step(double radius, bool* valid, double* mcc, double* new_c
 }
 
 int DenseSolver::write_back() {
-  std::vector<double> x(n_);
-  SK_HIP_TRY(hipMemcpyAsync(x.data(), x_, n_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  std::vector<double> x(ng_);
+  SK_HIP_TRY(hipMemcpyAsync(x.data(), x_, ng_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
   SK_HIP_TRY(hipStreamSynchronize(stream_));
   for (size_t b = 0; b < problem_->block_size.size(); ++b) std::memcpy(problem_->block_ptr[b], &x[block_off_[b]], problem_->block_size[b] * sizeof(double));
   return SK_OK;

@@ -160,6 +160,25 @@ struct HelloCostFunctor {  // EX/HelloWorld.scala:11-14: 10 - x
   }
 };
 
+// r = R(q) p - t for a quaternion block q = (w, x, y, z), normalised first (Rotation.quaternionRotatePoint,
+// CORE/Rotation.scala:393-430, spelled out); c = (p[3], t[3]).  No reference counterpart: a registered functor
+// with a block of size 4, for the local parameterizations (quaternion, homogeneous vector) to act on.
+struct QuaternionRotationError {
+  static constexpr int kRes = 3, kBlocks = 1, kConsts = 6, kDim = 4;
+  static SK_HD int N(int) { return 4; }
+  template <class T>
+  static SK_HD bool apply(const double* c, const T* const* p, T* out) {
+    const T* q = p[0];
+    const T scale = 1.0 / jsqrt(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    const T a = q[0] * scale, b = q[1] * scale, cc = q[2] * scale, d = q[3] * scale;
+    const T t2 = a * b, t3 = a * cc, t4 = a * d, t5 = -(b * b), t6 = b * cc, t7 = b * d, t8 = -(cc * cc), t9 = cc * d, t1 = -(d * d);
+    out[0] = (2.0 * (((t8 + t1) * c[0] + (t6 - t4) * c[1]) + (t3 + t7) * c[2]) + c[0]) - c[3];
+    out[1] = (2.0 * (((t4 + t6) * c[0] + (t5 + t1) * c[1]) + (t9 - t2) * c[2]) + c[1]) - c[4];
+    out[2] = (2.0 * (((t7 - t3) * c[0] + (t2 + t9) * c[1]) + (t5 + t8) * c[2]) + c[2]) - c[5];
+    return true;
+  }
+};
+
 // Static description usable on the host (sizes for validation).
 struct FunctorDesc {
   int id, num_residuals, num_blocks, num_consts;
@@ -183,6 +202,7 @@ inline bool functor_desc(int id, FunctorDesc* d) {
     SK_DESC(8, BinaryVector3Cost)
     SK_DESC(9, TenParameterCost)
     SK_DESC(11, HelloCostFunctor)
+    SK_DESC(12, QuaternionRotationError)
   }
 #undef SK_DESC
   return false;
@@ -201,6 +221,7 @@ inline bool functor_desc(int id, FunctorDesc* d) {
     case 8: MACRO(sk::BinaryVector3Cost); break;        \
     case 9: MACRO(sk::TenParameterCost); break;         \
     case 11: MACRO(sk::HelloCostFunctor); break;        \
+    case 12: MACRO(sk::QuaternionRotationError); break; \
     default: break;                               \
   }
 

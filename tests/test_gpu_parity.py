@@ -838,3 +838,181 @@ def test_example_programs_end_to_end(tmp_path, capfd):  # capfd: the progress ta
     np.testing.assert_allclose(powell_analytic.main(), 0.0, atol=1e-3)
     out = capfd.readouterr().out
     assert out.count("Ceres Solver Report") == 3 and "Initial: x1 = 3.0, x2 = -1.0, x3 = 0.0, x4 = 1.0" in out
+
+
+# ---------------------------------------------------------------------------
+# Local parameterizations (PredefinedLocalParameterizations, ceres.i:186-210)
+# ---------------------------------------------------------------------------
+def _param_pairs():
+    P = sk.PredefinedLocalParameterizations
+    return [(P.identity(3), ("identity",), 3), (P.subset(5, [0, 3]), ("subset", [0, 3]), 5), (P.quaternion(), ("quaternion",), 4),
+            (P.homogeneousVector(2), ("homogeneous",), 2), (P.homogeneousVector(4), ("homogeneous",), 4), (P.homogeneousVector(9), ("homogeneous",), 9)]
+
+
+def test_local_parameterizations_device_vs_oracle():
+    rng = np.random.default_rng(5)
+    for dev, spec, size in _param_pairs():
+        ls = dev.localSize()
+        xs = rng.normal(size=(40, size))
+        xs[0, :-1] = 0.0  # x = +-|x| e_n: the degenerate Householder branches
+        xs[1, :-1] = 0.0
+        xs[1, -1] = -abs(xs[1, -1])
+        ds = rng.normal(size=(40, ls)) * rng.choice([1e-8, 1e-2, 1.0], size=(40, 1))
+        ds[2] = 0.0
+        got = dev.plus(xs, ds)
+        J = dev.computeJacobian(xs)
+        for k in range(len(xs)):
+            # floating point, two routes (explicit Householder matrix / in-register loops; device sin, cos): a few ulp of |x|
+            tol = 1e-14 * max(1.0, np.abs(xs[k]).max())
+            np.testing.assert_allclose(got[k], oracle.parameterization_plus(spec, xs[k], ds[k]), rtol=0, atol=tol)
+            np.testing.assert_allclose(J[k], oracle.parameterization_jacobian(spec, xs[k]), rtol=0, atol=tol)
+
+
+def _solve_both(build, block_sizes, x0, blocks, params, lst=None, iters=50):
+    """build(problem, arrays) adds blocks / parameterizations on the GPU side; the same structure goes to the oracle."""
+    lst = sk.LinearSolverType.DENSE_QR if lst is None else lst
+    arrays = []
+    off = 0
+    for n in block_sizes:
+        a = sk.DoubleArray(n)
+        for i in range(n):
+            a.set(i, float(x0[off + i]))
+        arrays.append(a)
+        off += n
+    problem = sk.Problem()
+    keep = build(problem, arrays)
+    options = sk.Solver.Options()
+    options.setMaxNumIterations(iters)
+    options.setLinearSolverType(lst)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    xg = np.concatenate([[a.get(i) for i in range(n)] for a, n in zip(arrays, block_sizes)])
+    o = oracle.default_options(linear_solver_type=oracle.DENSE_QR if lst == sk.LinearSolverType.DENSE_QR else oracle.DENSE_NORMAL_CHOLESKY,
+                               max_num_iterations=iters)
+    xo, so = oracle.solve_param(block_sizes, x0, blocks, params, o)
+    del keep
+    return xg, summary, xo, so
+
+
+def _check_trajectory(summary, so, n=8, rel=1e-9):
+    g = [it["cost"] for it in summary.iterations()]
+    assert len(g) >= 2
+    floor = 1e-10 * g[0]  # costs that small are rounding noise of residuals that cancel (noise-free targets)
+    for k in range(min(n, len(g), so.num_logged)):
+        assert abs(g[k] - so.iterations[k].cost) <= rel * max(so.iterations[k].cost, floor)
+
+
+@pytest.mark.parametrize("lst", [sk.LinearSolverType.DENSE_QR, sk.LinearSolverType.DENSE_NORMAL_CHOLESKY])
+def test_quaternion_parameterization_solve_vs_oracle(lst):
+    # fit a rotation to three point pairs: q stays on the unit sphere, the minimiser works in its 3-d tangent space
+    rng = np.random.default_rng(3)
+    q_true = np.array([0.8, -0.3, 0.4, 0.33])
+    q_true /= np.linalg.norm(q_true)
+    pts = rng.normal(size=(3, 3))
+    tgt = oracle.rotation_apply(9, np.concatenate([np.tile(q_true, (3, 1)), pts], axis=1)) + 0.01 * rng.normal(size=(3, 3))
+    x0 = np.array([0.9, 0.1, -0.2, 0.3])
+    x0 /= np.linalg.norm(x0)
+    blocks = [(oracle.QUATERNION_ROTATION, list(p) + list(t), [0]) for p, t in zip(pts, tgt)]
+
+    def build(problem, arrays):
+        keep = [sk.QuaternionRotationError(p, t).toAutoDiffCostFunction() for p, t in zip(pts, tgt)]
+        problem.addParameterBlock(arrays[0], 4, sk.PredefinedLocalParameterizations.quaternion())
+        for cf in keep:
+            problem.addResidualBlock(cf, None, arrays[0])
+        return keep
+    xg, summary, xo, so = _solve_both(build, [4], x0, blocks, [("quaternion",)], lst)
+    _check_trajectory(summary, so)
+    assert abs(np.linalg.norm(xg) - 1.0) < 1e-13
+    np.testing.assert_allclose(xg, xo, atol=1e-7)
+    assert summary.finalCost() < 1e-3
+
+
+def test_homogeneous_vector_subset_and_constant_blocks_vs_oracle():
+    # (a) the same residuals with q as a homogeneous 4-vector: the norm (here 2) is kept, the direction is optimised
+    rng = np.random.default_rng(9)
+    pts = rng.normal(size=(4, 3))
+    q_true = np.array([0.5, 0.5, -0.5, 0.5])
+    tgt = oracle.rotation_apply(9, np.concatenate([np.tile(q_true, (4, 1)), pts], axis=1))
+    x0 = 2.0 * np.array([0.6, 0.4, -0.3, 0.62]) / np.linalg.norm([0.6, 0.4, -0.3, 0.62])
+    blocks = [(oracle.QUATERNION_ROTATION, list(p) + list(t), [0]) for p, t in zip(pts, tgt)]
+
+    def build_h(problem, arrays):
+        keep = [sk.QuaternionRotationError(p, t).toAutoDiffCostFunction() for p, t in zip(pts, tgt)]
+        for cf in keep:
+            problem.addResidualBlock(cf, None, arrays[0])
+        problem.setParameterization(arrays[0], sk.PredefinedLocalParameterizations.homogeneousVector(4))
+        return keep
+    xg, summary, xo, so = _solve_both(build_h, [4], x0, blocks, [("homogeneous",)])
+    _check_trajectory(summary, so)
+    assert abs(np.linalg.norm(xg) - 2.0) < 1e-12
+    np.testing.assert_allclose(xg, xo, atol=1e-7)
+    np.testing.assert_allclose(np.abs(xg) / 2.0, np.abs(q_true), atol=1e-6)
+
+    # (b) BinaryVector3Cost blocks (TEST/AutodiffCostFuntionSpec.scala:55-69) with x[1] held by a subset parameterization
+    # and y constant altogether; Powell's x4 constant
+    blocks = [(oracle.BINARY_VECTOR3, [0.5], [0, 1]), (oracle.BINARY_VECTOR3, [1.5], [0, 1])]
+
+    def build_s(problem, arrays):
+        keep = [sk.BinaryVector3Cost(0.5).toAutoDiffCostFunction(), sk.BinaryVector3Cost(1.5).toAutoDiffCostFunction()]
+        for cf in keep:
+            problem.addResidualBlock(cf, None, arrays[0], arrays[1])
+        problem.setParameterization(arrays[0], sk.PredefinedLocalParameterizations.subset(2, [1]))
+        problem.setParameterBlockConstant(arrays[1])
+        return keep
+    x0 = [1.0, 2.0, 3.0, 4.0]
+    xg, summary, xo, so = _solve_both(build_s, [2, 2], x0, blocks, [("subset", [1]), ("constant",)])
+    _check_trajectory(summary, so)
+    assert list(xg[1:]) == [2.0, 3.0, 4.0]  # untouched, bit for bit
+    np.testing.assert_allclose(xg, xo, atol=1e-9)
+
+    blocks = [(oracle.POWELL_F1, [], [0, 1]), (oracle.POWELL_F2, [], [2, 3]), (oracle.POWELL_F3, [], [1, 2]), (oracle.POWELL_F4, [], [0, 3])]
+
+    def build_p(problem, arrays):
+        keep = [sk.PowellF1().toAutoDiffCostFunction(), sk.PowellF2().toAutoDiffCostFunction(), sk.PowellF3().toAutoDiffCostFunction(),
+                sk.PowellF4().toAutoDiffCostFunction()]
+        for cf, (i, j) in zip(keep, [(0, 1), (2, 3), (1, 2), (0, 3)]):
+            problem.addResidualBlock(cf, None, arrays[i], arrays[j])
+        problem.setParameterBlockConstant(arrays[3])
+        return keep
+    xg, summary, xo, so = _solve_both(build_p, [1, 1, 1, 1], [3.0, -1.0, 0.0, 1.0], blocks, [None, None, None, ("constant",)], iters=100)
+    _check_trajectory(summary, so)
+    assert xg[3] == 1.0
+    np.testing.assert_allclose(xg, xo, atol=1e-6)
+
+
+def test_parameterization_with_host_callback_and_unsupported_solvers():
+    # a host cost function on a quaternion block: the director path fills the global Jacobian, the projection is the GPU's
+    class Norm(sk.SizedCostFunction):  # r = q - q0 (4 residuals), J = I
+        def __init__(self, q0):
+            super().__init__(4, 4)
+            self.q0 = np.asarray(q0)
+
+        def evaluate(self, parameters, residuals, jacobians):
+            residuals[:] = parameters[0] - self.q0
+            if jacobians is not None and jacobians[0] is not None:
+                jacobians[0][:, :] = np.eye(4)
+            return True
+    q0 = np.array([0.3, 0.9, 0.1, -0.2])
+    q = sk.DoubleArray(4)
+    for i, v in enumerate([1.0, 0.0, 0.0, 0.0]):
+        q.set(i, v)
+    problem = sk.Problem()
+    cf = Norm(q0)
+    problem.addResidualBlock(cf, None, q)
+    problem.setParameterization(q, sk.PredefinedLocalParameterizations.quaternion())
+    options = sk.Solver.Options()
+    options.setMaxNumIterations(50)
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_QR)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    got = np.array([q.get(i) for i in range(4)])
+    np.testing.assert_allclose(got, q0 / np.linalg.norm(q0), atol=1e-4)  # the closest unit quaternion to q0 (default tolerances)
+    assert abs(np.linalg.norm(got) - 1.0) < 1e-13
+    # DENSE_SCHUR with a parameterization is refused, not solved another way
+    prob = bal.generate(4, 20, 60, seed=2)
+    problem, params, loss = bal_problem_to_sk(prob)
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    problem.setParameterBlockConstant(params)  # the first camera block starts where the parameter array does
+    with pytest.raises(sk.SkeresError):
+        sk.ceres.solve(options, problem, sk.Solver.Summary())
