@@ -504,44 +504,58 @@ __device__ long long g_potrf_stamps[4][16], g_potrf_clk[4][16];
 #define SK_STAMP(i)
 #endif
 
-__device__ __forceinline__ void potrf128_body(double* lds, double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
+__device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
+  // Inlined into the server's loop, everything below that does not depend on the column — LDS addresses, lane-derived
+  // offsets — is loop-invariant, gets hoisted, and the 256-register body spills (384-716 bytes of scratch).  Opaque
+  // copies of the three roots keep the arithmetic where it is used.
+  double* lds = lds_in;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid), "+s"(ld));
   double* T = lds;                      // blocks 0..9: lower triangle of the tile (diagonal slots end as W_jj); 10..15: inverse, below the diagonal
   double* E = lds + 16 * kBlk;          // blocks 16, 17: staging of L_jj on its way to global memory (even / odd jb)
   double* colbuf = lds + 18 * kBlk;     // 3 x 64 doubles
   volatile int* flags = reinterpret_cast<volatile int*>(colbuf + 192);  // 4 hand-over flags of waves 1..3
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int t = tid, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   __builtin_amdgcn_s_setprio(3);
   SK_STAMP(0)
-  // load the lower blocks: all 40 loads of a lane are issued before the first LDS write (one HBM round trip)
+  // Load the lower blocks.  Block (0,0) by all four waves, so that wave 0 starts the first diagonal factorisation after one
+  // short round trip; the other nine blocks by waves 1..3 (three blocks each, 48 loads per lane, issued before anything
+  // is waited for): they are first read after P(0), behind the barrier that ends it.
   {
-    long goff[4];
-    int loff[4];
+    double v0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = t + 256 * i;
-      goff[i] = (long)(e >> 5) * ld + (e & 31);
-      loff[i] = (e >> 5) * kBs + (e & 31);
+      v0[i] = A[(long)(e >> 5) * ld + (e & 31)];
     }
-    double v[10][4];
-    int b = 0;
+    if (wave == 0) {
 #pragma unroll
-    for (int bi = 0; bi < 4; ++bi)
+      for (int i = 0; i < 4; ++i) { const int e = t + 256 * i; T[blk_off(0, 0) + (e >> 5) * kBs + (e & 31)] = v0[i]; }
+      if (t < 4) flags[t] = 0;
+      __syncthreads();
+    } else {
+      double v[3][16];
+      const int first = 3 * (wave - 1) + 1;  // index in the lower-triangular enumeration (bi (bi + 1) / 2 + bj)
+      const long lo = (long)(lane >> 5) * ld + (lane & 31);
 #pragma unroll
-      for (int bj = 0; bj <= bi; ++bj, ++b) {
-        const double* Ab = A + ((long)bi * kB * ld + bj * kB);
+      for (int k = 0; k < 3; ++k) {
+        const int idx = first + k, bi = idx >= 6 ? 3 : (idx >= 3 ? 2 : 1), bj = idx - bi * (bi + 1) / 2;
+        const double* Ab = A + ((long)bi * kB * ld + bj * kB) + lo;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[b][i] = Ab[goff[i]];
+        for (int i = 0; i < 16; ++i) v[k][i] = Ab[(long)(2 * i) * ld];
       }
-    b = 0;
 #pragma unroll
-    for (int bi = 0; bi < 4; ++bi)
+      for (int i = 0; i < 4; ++i) { const int e = t + 256 * i; T[blk_off(0, 0) + (e >> 5) * kBs + (e & 31)] = v0[i]; }
+      __syncthreads();
+      const int ll = (lane >> 5) * kBs + (lane & 31);
 #pragma unroll
-      for (int bj = 0; bj <= bi; ++bj, ++b)
+      for (int k = 0; k < 3; ++k) {
+        const int idx = first + k, bi = idx >= 6 ? 3 : (idx >= 3 ? 2 : 1), bj = idx - bi * (bi + 1) / 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) T[blk_off(bi, bj) + loff[i]] = v[b][i];
+        for (int i = 0; i < 16; ++i) T[blk_off(bi, bj) + ll + 2 * i * kBs] = v[k][i];
+      }
+    }
   }
-  if (t < 4) flags[t] = 0;
-  __syncthreads();
   SK_STAMP(1)
   const unsigned uld = (unsigned)ld;
   const unsigned go_a = (unsigned)(lane >> 5) * uld + (lane & 31), go_i = (unsigned)(lane >> 5) * 128u + (lane & 31);
@@ -725,7 +739,6 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
   extern __shared__ __attribute__((aligned(16))) double lds[];
   potrf128_body(lds, A, ld, Linv, info);
 }
-
 // ---------------------------------------------------------------------------
 // The panel chain of an envelope factorisation (groups of one block column) without a kernel launch on
 // it.  Per block column j the serial dependence is
