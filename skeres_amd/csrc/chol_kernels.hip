@@ -829,9 +829,9 @@ __global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld
 
 // One 32 x 32 tile with K = 128 in a single memory round trip: C = A B^T (kMode 1) or C -= A B^T (kMode 0), A and B
 // 32 x 128 row slices.  Every load of the workgroup is in flight at once, then 32 MFMAs per wave (one 16 x 16
-// quadrant each): about 3 us against 9 us for the K-stepped 32 x 128 tile, whose eight steps each wait for a
-// round trip that nothing hides on the serial chain.  Same operation sequence per element as gemm_nt_f64_body
-// (k ascending, one accumulator).  shp: 2 * 32 * kCritLd doubles.
+// quadrant each): about 5 us with the hand-over against 9 us for the K-stepped 32 x 128 tile, whose eight steps each wait
+// for a round trip that nothing hides on the serial chain.  The time is the round trip and the publication, not the
+// MFMAs (two accumulators instead of one changed nothing).  shp: 2 * 32 * kCritLd doubles.
 constexpr int kCritLd = 130;
 __device__ __forceinline__ void crit_tile_load(double* shp, const double* A, long lda, const double* B, long ldb) {
   const int t = threadIdx.x, row = t >> 3, c0 = (t & 7) * 16;
@@ -850,9 +850,14 @@ __device__ __forceinline__ d4 crit_tile_mma(const double* shp, d4 acc) {
   const int l15 = lane & 15, l4 = lane >> 4;
   const double* sa = shp + ((wave >> 1) * 16 + l15) * kCritLd + l4;
   const double* sb = shp + (32 + (wave & 1) * 16 + l15) * kCritLd + l4;
+  // two accumulators (even / odd K-steps): a wave alone on its SIMD issues dependent fp64 MFMAs at half rate
+  d4 acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int kk = 0; kk < 32; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk * 4], sb[kk * 4], acc, 0, 0, 0);
-  return acc;
+  for (int kk = 0; kk < 32; kk += 2) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk * 4], sb[kk * 4], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk * 4 + 4], sb[kk * 4 + 4], acc1, 0, 0, 0);
+  }
+  return acc + acc1;
 }
 // element i of a wave's accumulator: row (wave >> 1) * 16 + (lane >> 4) + 4 i, column (wave & 1) * 16 + (lane & 15) of the tile
 __device__ __forceinline__ long crit_tile_off(long ldc, int i) {
@@ -1302,7 +1307,9 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
     }
   }
   g_tuning = false;
-  for (int c = 1; c < ncomb; ++c) if (ms[c] < ms[g_queue_choice]) g_queue_choice = c;
+  double best = ms[0];
+  for (int c = 1; c < ncomb; ++c) best = std::min(best, ms[c]);
+  for (int c = ncomb - 1; c >= 0; --c) if (ms[c] <= 1.04 * best) g_queue_choice = c;  // the first of those within noise of the best: the same choice run after run
   if (getenv("SK_DEBUG_QUEUES")) {
     std::fprintf(stderr, "[skeres_amd] synthetic factorisation (ms) per (bulk, panel, server) queue candidates:");
     for (int c = 0; c < ncomb; ++c) std::fprintf(stderr, "%s%.2f", c % kServerCand == 0 ? "  " : " ", ms[c]);
