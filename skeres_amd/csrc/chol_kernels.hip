@@ -608,12 +608,14 @@ __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict
       if (!ok && lane == 0) *info = 1;
       {
         // lanes 0..31: row of L_jj -> staging block E[jb & 1] (written to global by wave 3 during the next diagonal
-        // factorisation); lanes 32..63: column k of W_jj -> the slot of D (zeros above the diagonal in both)
+        // factorisation); lanes 32..63: column k of W_jj -> the slot of D.  W has its zeros above the diagonal (they
+        // are computed); the row of L is stored as it stands, with whatever the elimination left right of the diagonal:
+        // nothing reads the upper triangle of a diagonal block of the factor (sk_cholesky_solve returns tril).
         const int row = lane & 31;
         double* dst = lane < 32 ? E + (jb & 1) * kBlk + row * kBs : D + row;
         const int step = lane < 32 ? 1 : kBs;
 #pragma unroll
-        for (int c = 0; c < 32; ++c) dst[c * step] = (lane >= 32 || c <= row) ? a[c] : 0.0;
+        for (int c = 0; c < 32; ++c) dst[c * step] = a[c];
       }
       SK_STAMP(2 + 2 * jb)
       __syncthreads();
