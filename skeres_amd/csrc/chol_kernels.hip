@@ -1471,13 +1471,13 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     if (Tb > 0) {
       double* Cb = S + (long)(k1 + na) * 128 * ld + (long)(k1 + na) * 128;
       const double* Pb = S + (long)(k1 + na) * 128 * ld + (long)k0 * 128;
-      if (kt) kt->begin("gemm_syrk", sb);
+      hipEvent_t t_start = nullptr, t_stop = nullptr;
+      if (kt) kt->pair("gemm_syrk", &t_start, &t_stop);
       if (Tb <= g_thin_syrk_tiles)
-        hipLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(4 * Tb * Tb), dim3(256), 0, sb, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main, 4 * rs.jump, rs.main,
-                           rs.jump);
+        hipExtLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(4 * Tb * Tb), dim3(256), 0, sb, t_start, t_stop, 0, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main,
+                              4 * rs.jump, rs.main, rs.jump);
       else
-        hipLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
-      if (kt) kt->end("gemm_syrk", sb);
+        hipExtLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, t_start, t_stop, 0, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
       if (chain && k1 >= c0) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, ++seq);
       // the launch-by-launch next(g+1) waits for this SYRK as an event; so does a SYRK that follows on the other bulk stream
       bool record = la && !(chain && k1 >= c0);

@@ -28,6 +28,15 @@ class KernelTimer {
     hipEventRecord(e, s);
     pending_.push_back({name, e, nullptr});
   }
+  // The two events of one launch, to ride on its own dispatch (hipExtLaunchKernelGGL start / stop): the kernel's begin
+  // and end timestamps with no record packets around it in the queue (which delay whatever follows by 3-6 us each —
+  // on the panel chain that is the measurement changing the thing it measures).  Null when this name is not timed.
+  void pair(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    if (!enabled_ || (!only_.empty() && only_ != name)) return;
+    *start = get(); *stop = get();
+    pending_.push_back({name, *start, *stop});
+  }
   void end(const char* name, hipStream_t s) {
     if (!enabled_ || skip_ || pending_.empty()) return;
     hipEvent_t e = get();
