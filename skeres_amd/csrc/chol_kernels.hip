@@ -953,34 +953,45 @@ __global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict_
                                                         double* __restrict__ w, double* __restrict__ yout, int kb, int col0, int ncols) {
   __shared__ double wk[128], ykb[128], part[8][128];
   const int t = threadIdx.x;
-  if (t < 128) wk[t] = w[kb * 128 + t];
+  // every global load of the step is issued before anything is waited for (w_kb, this lane's 16 entries of Linv and its 8
+  // entries of the block row of L): one memory round trip per step instead of three dependent ones
+  const int c = t & 127, g = t >> 7;
+  const int cl = t & 63, rg = t >> 6;
+  const int col = col0 + blockIdx.x * 64 + cl;  // columns left of col0 are structurally zero in this block row
+  double wv = 0.0, li[16], lr[8];
+  if (t < 128) wv = w[kb * 128 + t];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) li[i] = Linv[(long)(g * 16 + i) * 128 + c];
+  if (col < ncols) {
+    const double* p = Lrow + (long)(rg * 8) * ld + col;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lr[i] = p[(long)i * ld];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lr[i] = 0.0;
+  }
+  if (t < 128) wk[t] = wv;
   __syncthreads();
   {
-    const int c = t & 127, g = t >> 7;
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int r = g * 16 + i; s += Linv[(long)r * 128 + c] * wk[r]; }
+    for (int i = 0; i < 16; ++i) s += li[i] * wk[g * 16 + i];
     part[g][c] = s;
   }
   __syncthreads();
   if (t < 128) {
     double s = 0.0;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s += part[g][t];
+    for (int q = 0; q < 8; ++q) s += part[q][t];
     ykb[t] = s;
     if (blockIdx.x == 0) yout[kb * 128 + t] = s;
   }
   __syncthreads();
   // 64 columns per workgroup (512-B row segments), 16 row groups of 8 rows: four times the workgroups of
   // a 256-column split — the grid is what limits this HBM-bound phase (<= 244 workgroups on 256 CUs)
-  const int cl = t & 63, rg = t >> 6;
-  const int col = col0 + blockIdx.x * 64 + cl;  // columns left of col0 are structurally zero in this block row
   double s = 0.0;
-  if (col < ncols) {
-    const double* p = Lrow + (long)(rg * 8) * ld + col;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += p[(long)i * ld] * ykb[rg * 8 + i];
-  }
+  for (int i = 0; i < 8; ++i) s += lr[i] * ykb[rg * 8 + i];
   double* red = &part[0][0];  // part[][] is free again: its readers finished before the barrier above
   red[rg * 64 + cl] = s;
   __syncthreads();
