@@ -284,7 +284,7 @@ int sk_options_set_device(sk_options* o, int hip_device);             /* default
 int sk_options_set_stream(sk_options* o, void* hip_stream);           /* default: a private stream */
 /* Tuning of the dense Cholesky: `group` = depth of the trailing SYRK in 128-column blocks (K = 128*group).
  * <= 0 (default) leaves the plan to the library: groups of 3 for a full factorisation; with a sparse block
- * envelope, groups of 2 while the trailing SYRK is the long pole and single columns under a resident panel chain
+ * envelope, groups of 2 where the trailing SYRK is the long pole and single columns under a resident panel chain
  * (one workgroup that factors the diagonal blocks, per-column launches that hand it its operands through device
  * counters) where the serial chain is — DESIGN.md section 4.  The first solver of a process then spends about
  * 0.1 s choosing hardware queues for that chain.  An explicit `group` is used for every column, launch by launch

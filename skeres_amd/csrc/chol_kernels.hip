@@ -809,24 +809,29 @@ __device__ __forceinline__ void chain_publish(int* p, int add) {
 #endif
 }
 
-__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, int first, int nblk, double* Linv, int* info, int* sync, int maxblk) {
+struct ChainRanges { int n; int begin[8], end[8]; };  // the resident runs of block columns, [begin, end)
+
+__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ int ok_s;
-  for (int j = first; j < nblk; ++j) {
-    if (j > 0) {
-      if (threadIdx.x == 0) ok_s = chain_wait(sync + kSyncHeader + j, 16, sync + kSyncAbort) ? 1 : 0;
-      __syncthreads();
-      if (!ok_s) {
-        if (threadIdx.x == 0) *info = 2;
-        return;
+  int done = 0;  // value of the potrf counter
+  for (int r = 0; r < ranges.n; ++r)
+    for (int j = ranges.begin[r]; j < ranges.end[r]; ++j) {
+      if (j > 0) {  // the first column of a run: set by the launch-by-launch part before it; the others: by column launch j-1
+        if (threadIdx.x == 0) ok_s = chain_wait(sync + kSyncHeader + j, 16, sync + kSyncAbort) ? 1 : 0;
+        __syncthreads();
+        if (!ok_s) {
+          if (threadIdx.x == 0) *info = 2;
+          return;
+        }
+        SK_CHAIN_ACQUIRE_ALL
       }
-      SK_CHAIN_ACQUIRE_ALL
+      SK_CHAIN_STAMP(j, 0)
+      potrf128_body(lds, S + (long)j * 128 * ld + (long)j * 128, ld, Linv + (long)j * 128 * 128, info);
+      chain_publish(sync + kSyncPotrfDone, j + 1 - done);  // the counter reads j + 1 after column j
+      done = j + 1;
+      SK_CHAIN_STAMP(j, 1)
     }
-    SK_CHAIN_STAMP(j, 0)
-    potrf128_body(lds, S + (long)j * 128 * ld + (long)j * 128, ld, Linv + (long)j * 128 * 128, info);
-    chain_publish(sync + kSyncPotrfDone, j == first ? first + 1 : 1);  // the counter reads j + 1 after column j
-    SK_CHAIN_STAMP(j, 1)
-  }
 }
 
 // One 32 x 32 tile with K = 128 in a single memory round trip: C = A B^T (kMode 1) or C -= A B^T (kMode 0), A and B
@@ -1205,43 +1210,52 @@ std::vector<int> cholesky_group_bounds(int nblk, int group) {
   return b;
 }
 
-// The groups actually used, and the block column from which the resident panel chain (potrf_server_kernel /
-// chain_column_kernel) takes over: the longest suffix of block columns whose trailing update is short (at most
+// The groups actually used, and the block columns under the resident panel chain (potrf_server_kernel /
+// chain_column_kernel): the runs of at least kMinChainRun block columns whose trailing update is short (at most
 // g_chain_max_trailing tile rows: the serial chain, not the SYRK, decides there — measured on Ladybug-1723, a
-// column cycle is 44-50 us up to 13 trailing tile rows, 60 us at 20, 100 us at 30) and whose panels fit the 32-row
-// tiles.  Those columns are groups of one; the columns before them are factored launch by launch in groups of
-// `group` (of g_chain_prefix_group when the caller asked for 1: their SYRK is the long pole, and K = 128 leaves it
-// bound by the traffic of its C tiles).  chain == false: cholesky_group_bounds, no resident chain.
+// column cycle is 40-50 us up to 13 trailing tile rows, 60 us at 20, 100 us at 30) and whose panels fit the 32-row
+// tiles — on Ladybug-1723 the first 8 block columns and the last 77.  Those columns are groups of one; the columns
+// between the runs are factored launch by launch in groups of `group` (of g_chain_prefix_group when the caller
+// asked for 1: their SYRK is the long pole, and K = 128 leaves it bound by the traffic of its C tiles).
+// chain == false: cholesky_group_bounds, no resident chain.
+constexpr int kMinChainRun = 4;
 CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain) {
   CholeskyPlan plan;
-  plan.chain_from = nblk;
+  plan.resident.assign(nblk, 0);
   if (group < 1) group = 1;
   if (!chain || nblk < 3) {
     plan.bounds = cholesky_group_bounds(nblk, group);
-  } else {
-    auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
-    auto count = [&](int first_row, int last_row) {  // active block rows from first_row: the run up to last_row, and block row nblk-1
-      const int main_rows = last_row >= first_row ? last_row - first_row + 1 : 0;
-      return main_rows + ((first_row + main_rows <= nblk - 1 && last_row < nblk - 1) ? 1 : 0);
-    };
-    int c0 = nblk - 1;
-    for (int j = nblk - 2; j >= 0; --j) {
-      if (count(j + 2, last_main(j)) > g_chain_max_trailing || 4 * count(j + 1, last_main(j)) > g_thin_grid) break;
-      c0 = j;
-    }
-    if (c0 > nblk - 3) { plan.bounds = cholesky_group_bounds(nblk, group); return plan; }
-    const int pg = group == 1 ? g_chain_prefix_group : group;
-    int k = 0;
-    while (k < c0) {
-      plan.bounds.push_back(k);
-      int g = nblk - k <= g_tail_tiles ? g_tail_group : pg;
-      if (g < 1) g = 1;
-      k += g < c0 - k ? g : c0 - k;
-    }
-    for (; k < nblk; ++k) plan.bounds.push_back(k);
-    plan.bounds.push_back(nblk);
-    plan.chain_from = c0;
+    return plan;
   }
+  auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
+  auto count = [&](int first_row, int last_row) {  // active block rows from first_row: the run up to last_row, and block row nblk-1
+    const int main_rows = last_row >= first_row ? last_row - first_row + 1 : 0;
+    return main_rows + ((first_row + main_rows <= nblk - 1 && last_row < nblk - 1) ? 1 : 0);
+  };
+  for (int j = 0; j + 1 < nblk; ++j)
+    plan.resident[j] = count(j + 2, last_main(j)) <= g_chain_max_trailing && 4 * count(j + 1, last_main(j)) <= g_thin_grid;
+  for (int j = 0; j + 1 < nblk;) {  // drop the short runs: a hand-over costs more than a few columns gain
+    if (!plan.resident[j]) { ++j; continue; }
+    int e = j;
+    while (e + 1 < nblk && plan.resident[e]) ++e;
+    if (e - j < kMinChainRun) for (int i = j; i < e; ++i) plan.resident[i] = 0;
+    j = e;
+  }
+  plan.resident[nblk - 1] = plan.resident[nblk - 2];  // the server factors the last diagonal block too when it has the column before it
+  bool any = false;
+  for (int j = 0; j < nblk; ++j) any = any || plan.resident[j];
+  if (!any) { plan.bounds = cholesky_group_bounds(nblk, group); return plan; }
+  const int pg = group == 1 ? g_chain_prefix_group : group;
+  for (int k = 0; k < nblk;) {
+    plan.bounds.push_back(k);
+    if (plan.resident[k]) { ++k; continue; }
+    int stop = k;
+    while (stop < nblk && !plan.resident[stop]) ++stop;
+    int g = nblk - k <= g_tail_tiles ? g_tail_group : pg;
+    if (g < 1) g = 1;
+    k += std::min(g, stop - k);
+  }
+  plan.bounds.push_back(nblk);
   return plan;
 }
 int cholesky_plan_max_group(const CholeskyPlan& plan) {
@@ -1420,16 +1434,25 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       }
     }
   };
-  // the resident panel chain from block column c0 on (cholesky_plan); not while every chain kernel is being timed
+  // the block columns under the resident panel chain (cholesky_plan)
   const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr);
   const std::vector<int>& gb = plan.bounds;
   const int ngroups = (int)gb.size() - 1;
+  ChainRanges ranges;
+  ranges.n = 0;
+  for (int j = 0; j < nblk; ++j)
+    if (plan.resident[j] && (j == 0 || !plan.resident[j - 1])) {
+      if (ranges.n == 8) { ranges.n = 0; break; }  // (more runs than the server takes: launch by launch)
+      int e = j;
+      while (e < nblk && plan.resident[e]) ++e;
+      ranges.begin[ranges.n] = j; ranges.end[ranges.n] = e; ++ranges.n;
+    }
   // the same groups launch by launch: while every chain kernel is being timed, and with SK_CHOL_CHAIN_SERVER=0 (PMC
   // passes serialise the kernels of a process: a resident kernel that waits for another one would time out)
-  int c0 = (!g_chain_server || (kt && kt->times_all())) ? nblk : plan.chain_from;
-  int* sync = c0 < nblk ? ctx->sync_for(nblk) : nullptr;
-  if (!sync) c0 = nblk;  // (the same groups, launch by launch)
-  const bool chain = c0 < nblk;
+  bool chain = ranges.n > 0 && g_chain_server && !(kt && kt->times_all());
+  int* sync = chain ? ctx->sync_for(nblk) : nullptr;
+  if (!sync) chain = false;  // (the same groups, launch by launch)
+  auto is_resident = [&](int k) { return chain && k < nblk && plan.resident[k]; };
   const int maxblk = chain ? ctx->sync_blk : 0;
   const char* stamps_file = chain ? getenv("SK_CHAIN_STAMPS") : nullptr;
   hipStream_t srv = nullptr;
@@ -1440,11 +1463,11 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     srv = ctx->server;
     (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * maxblk), s);
     order(s, srv);
-    hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, c0, nblk, Linv, info, sync, maxblk);
+    hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk);
   }
   order(s, sp);
   if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }
-  if (c0 > 0) panel(gb[0], gb[1]);
+  if (!is_resident(0)) panel(gb[0], gb[1]);
   hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
   int seq = 0;                     // SYRK completions announced to the chain so far (chain_marker_kernel)
   for (int g = 0; g + 1 < ngroups; ++g) {
@@ -1457,7 +1480,8 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
     const int Tb = rs.main + rs.extra;
-    const bool resident = chain && k0 >= c0;  // potrf(k0) by the server; TRSM and next(g) by one column launch
+    const bool resident = is_resident(k0);        // potrf(k0) by the server; TRSM and next(g) by one column launch
+    const bool next_resident = is_resident(k1);   // ... and the same for the next group
     if (la) sb = Tb >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
     if (sb != sb_prev && syrk_done) (void)hipStreamWaitEvent(sb, syrk_done, 0);  // syrk(g) after syrk(g-1) across the two bulk streams
     sb_prev = sb;
@@ -1482,27 +1506,32 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     if (Tb > 0) {
       double* Cb = S + (long)(k1 + na) * 128 * ld + (long)(k1 + na) * 128;
       const double* Pb = S + (long)(k1 + na) * 128 * ld + (long)k0 * 128;
-      hipEvent_t t_start = nullptr, t_stop = nullptr;
-      if (kt) kt->pair("gemm_syrk", &t_start, &t_stop);
-      if (Tb <= g_thin_syrk_tiles)
-        hipExtLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(4 * Tb * Tb), dim3(256), 0, sb, t_start, t_stop, 0, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main,
-                              4 * rs.jump, rs.main, rs.jump);
-      else
-        hipExtLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, t_start, t_stop, 0, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
-      if (chain && k1 >= c0) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, ++seq);
       // the launch-by-launch next(g+1) waits for this SYRK as an event; so does a SYRK that follows on the other bulk stream
-      bool record = la && !(chain && k1 >= c0);
+      bool record = la && !next_resident;
       if (la && !record && g + 3 < (int)gb.size()) {
         const Rows rs1 = rows_from(gb[g + 3], last_main(gb[g + 2] - 1));
         record = (rs1.main + rs1.extra >= ctx->early_tiles) != (sb == ctx->bulk_early);
       }
-      if (record) { syrk_done = ctx->event(ev++); (void)hipEventRecord(syrk_done, sb); }
+      // ... an event that rides on the SYRK's own dispatch (as do the two of the kernel timer): a separate record is a
+      // packet of its own behind the SYRK, in front of the next one
+      hipEvent_t t_start = nullptr, t_stop = nullptr;
+      if (kt) kt->pair("gemm_syrk", &t_start, &t_stop);
+      hipEvent_t stop_ev = t_stop ? t_stop : (record ? ctx->event(ev++) : nullptr);
+      if (Tb <= g_thin_syrk_tiles)
+        hipExtLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(4 * Tb * Tb), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main,
+                              4 * rs.jump, rs.main, rs.jump);
+      else
+        hipExtLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
+      if (next_resident) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, ++seq);
+      if (record) syrk_done = stop_ev;
     }
-    if (resident) continue;
-    if (chain && k1 == c0)  // hand-over: block (c0, c0) has its last launch-by-launch update; the server takes it from here
-      hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sp, sync + kSyncHeader + c0, 16);
-    else
-      panel(k1, k1 + na);
+    if (next_resident) {
+      // hand-over: block column k1 has its last launch-by-launch update; the server takes it from here (a column launch
+      // has told it already)
+      if (!resident) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sp, sync + kSyncHeader + k1, 16);
+    } else {
+      panel(k1, k1 + na);  // (after a resident column: hand-back, in stream order behind its column launch)
+    }
   }
   order(sp, s);
   if (la) { order(ctx->bulk, s); order(ctx->bulk_early, s); }
@@ -1512,7 +1541,8 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     std::vector<long long> st((size_t)1024 * 8);
     (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_chain_stamps), st.size() * sizeof(long long));
     if (FILE* f = fopen(stamps_file, "w")) {
-      for (int j = c0; j < nblk && j < 1024; ++j) {
+      for (int j = 0; j < nblk && j < 1024; ++j) {
+        if (!plan.resident[j]) continue;
         fprintf(f, "%d ", j);
         for (int i = 0; i < 7; ++i) fprintf(f, "%lld ", st[(size_t)j * 8 + i]);
         const Rows rs = rows_from(j + 2, last_main(j));

@@ -115,7 +115,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
 struct CholeskyPlan {
   std::vector<int> bounds;  // group start columns + nblk
-  int chain_from = 0;       // first block column of the resident panel chain (nblk: none)
+  std::vector<char> resident;  // per block column: under the resident panel chain
 };
 CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain);
 int cholesky_plan_max_group(const CholeskyPlan& plan);
