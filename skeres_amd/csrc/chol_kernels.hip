@@ -1322,7 +1322,8 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
     ctx->panel = g_panel_candidates[c / kServerCand % kPanelCand];
     ctx->server = g_server_candidates[c % kServerCand];
   };
-  for (int c = 0; c < ncomb; ++c) {
+  bool serialised = false;
+  for (int c = 0; c < ncomb && !serialised; ++c) {
     select(c);
     for (int rep = 0; rep < 3; ++rep) {  // (the first one also pages the kernels in)
       (void)hipStreamSynchronize(s);
@@ -1331,9 +1332,27 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
       (void)hipStreamSynchronize(s);
       const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (rep > 0 && t < ms[c]) ms[c] = t;
+      if (c == 0 && rep == 0) {
+        // A tool that serialises the kernels of the process (counter collection does) lets the server run alone: it
+        // waits for a column launch that cannot start, gives up (kChainTimeoutTicks) and sets info.  Then every
+        // block column is factored launch by launch for the rest of the process — the same plan, the same launches.
+        int h = 0;
+        (void)hipMemcpy(&h, info, sizeof(int), hipMemcpyDeviceToHost);
+        if (h != 0) { serialised = true; break; }
+      }
     }
   }
   g_tuning = false;
+  if (serialised) {
+    g_chain_server = 0;
+    std::fprintf(stderr, "[skeres_amd] the resident panel chain timed out in its trial run (are kernels being serialised, e.g. by counter "
+                         "collection?): block columns are factored launch by launch in this process\n");
+    select(0);
+    g_queue_choice = 0;
+    g_bulk_stream = ctx->bulk; g_bulk_early_stream = ctx->bulk_early; g_panel_stream = ctx->panel; g_server_stream = ctx->server;
+    (void)hipFree(A); (void)hipFree(Linv); (void)hipFree(info);
+    return;
+  }
   double best = ms[0];
   for (int c = 1; c < ncomb; ++c) best = std::min(best, ms[c]);
   for (int c = ncomb - 1; c >= 0; --c) if (ms[c] <= 1.04 * best) g_queue_choice = c;  // the first of those within noise of the best: the same choice run after run
