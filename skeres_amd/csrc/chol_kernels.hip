@@ -809,6 +809,15 @@ __device__ __forceinline__ void chain_publish(int* p, int add) {
 #endif
 }
 
+// For a payload of a few values per lane: the values themselves written through to memory (device-scope stores), so
+// that the hand-over needs no write-back of the whole L2 — s_waitcnt vmcnt(0) per wave, then the counter.
+__device__ __forceinline__ void store_through(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void chain_publish_through(int* p, int add) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(p, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct ChainRanges { int n; int begin[8], end[8]; };  // the resident runs of block columns, [begin, end)
 
 __global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk) {
@@ -904,8 +913,8 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
     __syncthreads();
     xacc = crit_tile_mma(sh, xacc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Xs[(long)(ri * 32) * 128 + q * 32 + crit_tile_off(128, i)] = xacc[i];
-    chain_publish(x_ready, 1);
+    for (int i = 0; i < 4; ++i) store_through(Xs + (long)(ri * 32) * 128 + q * 32 + crit_tile_off(128, i), xacc[i]);
+    chain_publish_through(x_ready, 1);
   } else {
     gemm_nt_f64_body<1, 0, 16, 2, 32, 128>(sh, A21, ld, A21, ld, Linv_j, 128, 128, tiles_m, 0, main_t, jump_t, 0x7fffffff, 0, thin_bid);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -931,9 +940,9 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
       __syncthreads();
       acc = crit_tile_mma(sh, acc);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) Ct[crit_tile_off(ld, i)] = -acc[i];
+      for (int i = 0; i < 4; ++i) store_through(Ct + crit_tile_off(ld, i), -acc[i]);
     }
-    chain_publish(diag_ready, 1);
+    chain_publish_through(diag_ready, 1);  // (the copy of X into S(j+1,j) above is for after the factorisation: the end of the launch writes it back)
   } else {
     const double* Bx = ncrit ? (const double*)Xs : (const double*)A21;
     gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(sh, A21 + 128, ld, A21, ld, Bx, ncrit ? 128 : ld, 128, tiles_m, 1, main_t, jump_t, 0x7fffffff, 0, thin_bid);
