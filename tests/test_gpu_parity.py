@@ -1016,3 +1016,10 @@ def test_parameterization_with_host_callback_and_unsupported_solvers():
     problem.setParameterBlockConstant(params)  # the first camera block starts where the parameter array does
     with pytest.raises(sk.SkeresError):
         sk.ceres.solve(options, problem, sk.Solver.Summary())
+
+
+def test_example_rotation_fit_with_a_quaternion_parameterization():
+    from skeres_amd.examples import rotation_fit
+    got, truth = rotation_fit.main()
+    assert abs(np.linalg.norm(got) - 1.0) < 1e-13
+    np.testing.assert_allclose(got, truth, atol=0.02)  # 12 point pairs with noise 0.02
