@@ -529,6 +529,7 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
   if (hipEventElapsedTime(&ms, ev_[kEvBacksub], ev_[kEvCost]) == hipSuccess) phase_[4] += 1e-3 * ms;
   int fail = 0, info = 0;
   std::memcpy(&fail, h_scal_ + 16, sizeof(int)); std::memcpy(&info, h_scal_ + 17, sizeof(int));
+  cholesky_note_info(info);  // (a time-out of the resident panel chain: this step is invalid, the next ones are factored launch by launch)
   double loc[4] = {h_scal_[0], h_scal_[1], h_scal_[9], (double)(fail | info)};  // sum r_new^2, model term, |delta_p|^2, failure
   const int ops4[4] = {0, 0, 0, 1};
   int rc = gather_rank_scalars(loc, 4, ops4);

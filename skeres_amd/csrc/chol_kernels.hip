@@ -1364,6 +1364,13 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
   }
   double best = ms[0];
   for (int c = 1; c < ncomb; ++c) best = std::min(best, ms[c]);
+  if (best > 8.0) {
+    // 26 block columns take 1.1 ms.  Several times that with every combination: the device is being time-sliced with
+    // another process, and kernels that wait for each other lose whole slices: launch by launch for this process.
+    g_chain_server = 0;
+    std::fprintf(stderr, "[skeres_amd] the resident panel chain ran %.0f times slower than it should in its trial run (is the device shared with "
+                         "another process?): block columns are factored launch by launch in this process\n", best / 1.1);
+  }
   for (int c = ncomb - 1; c >= 0; --c) if (ms[c] <= 1.04 * best) g_queue_choice = c;  // the first of those within noise of the best: the same choice run after run
   if (getenv("SK_DEBUG_QUEUES")) {
     std::fprintf(stderr, "[skeres_amd] synthetic factorisation (ms) per (bulk, panel, server) queue candidates:");
@@ -1375,6 +1382,18 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
   (void)hipFree(A);
   (void)hipFree(Linv);
   (void)hipFree(info);
+}
+
+// What a caller read back from `info` after a factorisation.  2 is the resident panel chain giving up on a wait
+// (kChainTimeoutTicks): the device is shared or its kernels are being serialised — that factorisation is lost (the
+// caller treats it as it treats a matrix that is not positive definite: an invalid step), and the process factors
+// launch by launch from here on.
+void cholesky_note_info(int info) {
+  if (info == 2 && g_chain_server) {
+    g_chain_server = 0;
+    std::fprintf(stderr, "[skeres_amd] the resident panel chain timed out (is the device shared with another process, or are kernels being "
+                         "serialised?): block columns are factored launch by launch in this process from now on\n");
+  }
 }
 
 // Before the first factorisation with allow_chain on stream s (cholesky_factor does it otherwise): choose the queues.

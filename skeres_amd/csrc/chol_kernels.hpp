@@ -113,6 +113,7 @@ size_t potrf128_lds_bytes();
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
                      KernelTimer* kt, const int* last = nullptr, bool allow_chain = false);
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
+void cholesky_note_info(int info);
 struct CholeskyPlan {
   std::vector<int> bounds;  // group start columns + nblk
   std::vector<char> resident;  // per block column: under the resident panel chain
