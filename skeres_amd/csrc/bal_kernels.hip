@@ -28,6 +28,16 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // Block-level sum of up to 4 values; result valid in thread 0.
+// The per-point kernels give a point kPointLanes adjacent lanes, which take its observations in turn and are summed
+// in a fixed tree: with a lane per point, the points seen by a hundred cameras set the length of the whole launch
+// (a wave runs its longest lane's loop; Ladybug-shaped: 141 / 120 / 177 us for the three kernels, most of it that tail).
+constexpr int kPointLanes = 8;
+__device__ __forceinline__ double point_lanes_sum(double v) {
+#pragma unroll
+  for (int off = 1; off < kPointLanes; off <<= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 template <int K>
 __device__ __forceinline__ void block_sum(double (&v)[K], double* out_partial, int nblocks_stride) {
   __shared__ double sh[K][kBlock / 64];
@@ -197,10 +207,11 @@ __global__ __launch_bounds__(kBlock) void bal_cam_reduce_kernel(BalDev d) {
 }
 
 __global__ __launch_bounds__(kBlock) void bal_pt_reduce_kernel(BalDev d) {
-  const int p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= d.P) return;
+  const int gid = blockIdx.x * kBlock + threadIdx.x, sub = gid % kPointLanes;
+  const int p = gid / kPointLanes;
+  if (p >= d.P) return;  // (whole lane groups: kBlock is a multiple of kPointLanes)
   double sq[3] = {0, 0, 0}, g[3] = {0, 0, 0};
-  for (int o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
+  for (int o = d.pt_start[p] + sub; o < d.pt_start[p + 1]; o += kPointLanes) {
     const double r0 = d.r[o], r1 = d.r[(size_t)d.N + o];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -210,7 +221,11 @@ __global__ __launch_bounds__(kBlock) void bal_pt_reduce_kernel(BalDev d) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { d.colsq_p[3 * (size_t)p + k] = sq[k]; d.gs_p[3 * (size_t)p + k] = g[k]; }
+  for (int k = 0; k < 3; ++k) { sq[k] = point_lanes_sum(sq[k]); g[k] = point_lanes_sum(g[k]); }
+  if (sub == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { d.colsq_p[3 * (size_t)p + k] = sq[k]; d.gs_p[3 * (size_t)p + k] = g[k]; }
+  }
 }
 
 // Generic small vector kernels -------------------------------------------------
@@ -274,15 +289,19 @@ __global__ __launch_bounds__(kBlock) void final_reduce_kernel(const double* part
 //   T_p = sum E^T E + D_p^2 ; M = chol(T)^-1 (lower) so T^-1 = M^T M ; q = T^-1 g
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void bal_point_block_kernel(BalDev d) {
-  const int p = blockIdx.x * kBlock + threadIdx.x;
+  const int gid = blockIdx.x * kBlock + threadIdx.x, sub = gid % kPointLanes;
+  const int p = gid / kPointLanes;
   if (p >= d.P) return;
   double t00 = 0, t10 = 0, t11 = 0, t20 = 0, t21 = 0, t22 = 0;
-  for (int o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
+  for (int o = d.pt_start[p] + sub; o < d.pt_start[p + 1]; o += kPointLanes) {
     const double a0 = d.E[o], a1 = d.E[(size_t)d.N + o], a2 = d.E[2 * (size_t)d.N + o];
     const double b0 = d.E[3 * (size_t)d.N + o], b1 = d.E[4 * (size_t)d.N + o], b2 = d.E[5 * (size_t)d.N + o];
     t00 += a0 * a0 + b0 * b0; t10 += a1 * a0 + b1 * b0; t11 += a1 * a1 + b1 * b1;
     t20 += a2 * a0 + b2 * b0; t21 += a2 * a1 + b2 * b1; t22 += a2 * a2 + b2 * b2;
   }
+  t00 = point_lanes_sum(t00); t10 = point_lanes_sum(t10); t11 = point_lanes_sum(t11);
+  t20 = point_lanes_sum(t20); t21 = point_lanes_sum(t21); t22 = point_lanes_sum(t22);
+  if (sub != 0) return;
   const double d0 = d.D_p[3 * (size_t)p], d1 = d.D_p[3 * (size_t)p + 1], d2 = d.D_p[3 * (size_t)p + 2];
   t00 += d0 * d0; t11 += d1 * d1; t22 += d2 * d2;
   // Cholesky T = L L^T
@@ -482,16 +501,21 @@ __global__ __launch_bounds__(kBlock) void bal_obs_backsub_kernel(BalDev d) {
 }
 
 __global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
-  const int p = blockIdx.x * kBlock + threadIdx.x;
+  const int gid = blockIdx.x * kBlock + threadIdx.x, sub = gid % kPointLanes;
+  const int p = gid / kPointLanes;
   double acc[1] = {0.0};
+  double w0 = 0.0, w1 = 0.0, w2 = 0.0;
   if (p < d.P) {
-    const size_t N = d.N, P = d.P;
-    double t0 = d.gs_p[3 * (size_t)p], t1 = d.gs_p[3 * (size_t)p + 1], t2 = d.gs_p[3 * (size_t)p + 2];
-    for (int o = d.pt_start[p]; o < d.pt_start[p + 1]; ++o) {
-      t0 -= d.What[(size_t)o * kWs];
-      t1 -= d.What[(size_t)o * kWs + 1];
-      t2 -= d.What[(size_t)o * kWs + 2];
+    for (int o = d.pt_start[p] + sub; o < d.pt_start[p + 1]; o += kPointLanes) {
+      w0 += d.What[(size_t)o * kWs];
+      w1 += d.What[(size_t)o * kWs + 1];
+      w2 += d.What[(size_t)o * kWs + 2];
     }
+  }
+  w0 = point_lanes_sum(w0); w1 = point_lanes_sum(w1); w2 = point_lanes_sum(w2);
+  if (p < d.P && sub == 0) {
+    const size_t P = d.P;
+    const double t0 = d.gs_p[3 * (size_t)p] - w0, t1 = d.gs_p[3 * (size_t)p + 1] - w1, t2 = d.gs_p[3 * (size_t)p + 2] - w2;
     const double m00 = d.M[p], m10 = d.M[P + p], m11 = d.M[2 * P + p], m20 = d.M[3 * P + p], m21 = d.M[4 * P + p], m22 = d.M[5 * P + p];
     const double u0 = m00 * t0, u1 = m10 * t0 + m11 * t1, u2 = m20 * t0 + m21 * t1 + m22 * t2;
     const double y[3] = {m00 * u0 + m10 * u1 + m20 * u2, m11 * u1 + m21 * u2, m22 * u2};
@@ -584,7 +608,9 @@ void launch_bal_eval_cost(const BalDev& d, hipStream_t s) {
 }
 void launch_bal_scale_jac(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_scale_jac_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_reduce(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_reduce_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
-void launch_bal_pt_reduce(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_pt_reduce_kernel, dim3((d.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+static int point_grid(int P) { return (int)(((long)P * kPointLanes + kBlock - 1) / kBlock); }
+int bal_point_blocks(int P) { return P > 0 ? point_grid(P) : 1; }
+void launch_bal_pt_reduce(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_pt_reduce_kernel, dim3(point_grid(d.P)), dim3(kBlock), 0, s, d); }
 void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(jacobi_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, scale, n); }
 void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(apply_scale_to_reductions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, gs, scale, n); }
 void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(lm_diagonal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, D, n, lo, hi, radius); }
@@ -594,7 +620,7 @@ int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x
   return g;
 }
 void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s) { hipLaunchKernelGGL(final_reduce_kernel, dim3(K), dim3(kBlock), 0, s, partial, stride, count, K, maxmask, out); }
-void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_point_block_kernel, dim3((d.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_point_block_kernel, dim3(point_grid(d.P)), dim3(kBlock), 0, s, d); }
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_pair(const BalDev& d, hipStream_t s) {
@@ -607,7 +633,7 @@ void launch_bal_pair(const BalDev& d, hipStream_t s) {
 }
 void launch_bal_finish_S(double* S, int ld, int n, int npad, int rhs_row, const double* D_c, hipStream_t s) { hipLaunchKernelGGL(bal_finish_S_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, n, npad, rhs_row, D_c); }
 int launch_bal_point_backsub(const BalDev& d, hipStream_t s) {
-  const int g = d.P > 0 ? (d.P + kBlock - 1) / kBlock : 1;
+  const int g = bal_point_blocks(d.P);
   hipLaunchKernelGGL(bal_obs_backsub_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
   hipLaunchKernelGGL(bal_point_backsub_kernel, dim3(g), dim3(kBlock), 0, s, d);
   return g;

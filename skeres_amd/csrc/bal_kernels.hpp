@@ -51,6 +51,7 @@ struct BalDev {
 };
 
 int bal_partial_blocks(int N);
+int bal_point_blocks(int P);  // workgroups of the per-point kernels (bal_point_backsub writes one partial sum each)
 // lower block triangle of S (nblk x nblk blocks of 128) as one contiguous run: block row kb holds its
 // 128 rows x (kb+1)*128 columns row-major; this is what travels in the all-reduce
 void launch_zero_envelope(double* S, int ld, const int* col0, int nblk, hipStream_t s);

@@ -389,7 +389,7 @@ int BalSolver::setup() {
     SK_HIP_TRY(b_zero_col0_.upload(col0, s));
   }
   SK_HIP_TRY(b_Linv_.alloc((size_t)npad_ * 128)); SK_HIP_TRY(b_Linv_.zero(s));
-  partial_stride_ = std::max(std::max(bal_partial_blocks(N_), (P_ + 255) / 256), 256);
+  partial_stride_ = std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_)), 256);
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
   SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
   SK_HIP_TRY(b_fail_.alloc(1)); SK_HIP_TRY(b_fail_.zero(s)); SK_HIP_TRY(b_info_.alloc(1)); SK_HIP_TRY(b_info_.zero(s));
