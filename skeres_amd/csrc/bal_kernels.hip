@@ -326,28 +326,51 @@ __global__ __launch_bounds__(kBlock) void bal_point_block_kernel(BalDev d) {
   if (!(l00 > 0.0) || !(l11 > 0.0) || !(l22 > 0.0)) *d.fail_flag = 1;  // not positive definite
 }
 
-// Per observation: Ehat = E M^T (2x3), What = F^T Ehat (9x3), rt = r - E q
+// Per observation: Ehat = E M^T (2x3), What = F^T Ehat (9x3), rt = r - E q.
+// What is an array of records ([N][kWs], what the pair kernels gather): a lane storing its own record writes 27 doubles
+// 224 bytes apart from its neighbour's — 64 cache lines per store instruction.  The wave's 64 records are contiguous,
+// so they go through LDS and out as 28 fully coalesced stores (184 -> about 65 us on the Ladybug-shaped problem).
 __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
+  constexpr int kLs = kWs + 1;  // odd record stride in LDS: lane l's k-th value in bank pair (29 l + k) mod 32, conflict-free
+  __shared__ double stage[kBlock / 64][64 * kLs];
   const size_t N = d.N, P = d.P;
-  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
-    const int p = d.pt[o];
-    const double m00 = d.M[p], m10 = d.M[P + p], m11 = d.M[2 * P + p], m20 = d.M[3 * P + p], m21 = d.M[4 * P + p], m22 = d.M[5 * P + p];
-    const double q0 = d.q[p], q1 = d.q[P + p], q2 = d.q[2 * P + p];
-    double eh[2][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* mine = &stage[wave][0];
+  // whole waves walk the observations: a wave's 64 records are consecutive (the last wave may be partly out of range)
+  for (long base = (long)(blockIdx.x * kBlock + wave * 64); base < (long)d.N; base += (long)gridDim.x * kBlock) {
+    const long o = base + lane;
+    if (o < (long)d.N) {
+      const int p = d.pt[o];
+      const double m00 = d.M[p], m10 = d.M[P + p], m11 = d.M[2 * P + p], m20 = d.M[3 * P + p], m21 = d.M[4 * P + p], m22 = d.M[5 * P + p];
+      const double q0 = d.q[p], q1 = d.q[P + p], q2 = d.q[2 * P + p];
+      double eh[2][3];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const double e0 = d.E[(3 * r) * N + o], e1 = d.E[(3 * r + 1) * N + o], e2 = d.E[(3 * r + 2) * N + o];
-      eh[r][0] = e0 * m00;
-      eh[r][1] = e0 * m10 + e1 * m11;
-      eh[r][2] = e0 * m20 + e1 * m21 + e2 * m22;
-      d.rt[r * N + o] = d.r[r * N + o] - (e0 * q0 + e1 * q1 + e2 * q2);
+      for (int r = 0; r < 2; ++r) {
+        const double e0 = d.E[(3 * r) * N + o], e1 = d.E[(3 * r + 1) * N + o], e2 = d.E[(3 * r + 2) * N + o];
+        eh[r][0] = e0 * m00;
+        eh[r][1] = e0 * m10 + e1 * m11;
+        eh[r][2] = e0 * m20 + e1 * m21 + e2 * m22;
+        d.rt[r * N + o] = d.r[r * N + o] - (e0 * q0 + e1 * q1 + e2 * q2);
+      }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const double f0 = d.F[c * N + o], f1 = d.F[(9 + c) * N + o];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) mine[lane * kLs + 3 * c + a] = f0 * eh[0][a] + f1 * eh[1][a];
+      }
+      mine[lane * kLs + 27] = 0.0;  // (the record's padding)
     }
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      const double f0 = d.F[c * N + o], f1 = d.F[(9 + c) * N + o];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) d.What[(size_t)o * kWs + 3 * c + a] = f0 * eh[0][a] + f1 * eh[1][a];
+    __builtin_amdgcn_wave_barrier();  // LDS writes of a wave are in order with its reads; keep the compiler from mixing them
+    const long count = ((long)d.N - base < 64 ? (long)d.N - base : 64) * kWs;
+    double* out = d.What + (size_t)base * kWs;
+    int rec = lane / kWs, idx = lane % kWs;  // element k = lane + 64 i of the wave's 64 x kWs doubles: record k / kWs, entry k % kWs
+#pragma unroll 4
+    for (int k = lane; k < 64 * kWs; k += 64) {
+      if (k < count) out[k] = mine[rec * kLs + idx];
+      rec += 64 / kWs; idx += 64 % kWs;
+      if (idx >= kWs) { idx -= kWs; ++rec; }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
