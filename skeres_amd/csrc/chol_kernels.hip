@@ -326,6 +326,13 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
     a[c] = unit ? (c == row ? 1.0 : 0.0) : d;
   }
   colbuf[lane] = a[0];  // lanes 32..63 write slots nobody reads (no branch in the chain)
+  // The broadcast reads of the column buffer below are at wave-uniform constant addresses, which the compiler moves from
+  // an SGPR into a VGPR one by one (ds_read needs a VGPR address): 8 v_mov per column step on average, in a loop whose
+  // length is its instruction count.  One opaque VGPR base and immediate offsets instead.
+  typedef __attribute__((address_space(3))) const double* lds_cdp;
+  unsigned cb_base = (unsigned)(unsigned long)(lds_cdp)colbuf;
+  asm volatile("" : "+v"(cb_base));
+  const lds_cdp cb3 = (lds_cdp)(unsigned long)cb_base;
   double cbp[32], cbn[32];  // column j-1 (in use) and column j (in flight) of A', c-indexed; SSA after unrolling
   double m_prev = 0.0, d_prev = 1.0;
   int sgn = 0;  // sign bits of the pivots
@@ -344,7 +351,7 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
   for (int j = 0; j < 32; ++j) {
     // prefetch: column j of A' for the late updates of the NEXT step
     {
-      const double* cbj = colbuf + (j % 3) * 64;
+      const lds_cdp cbj = cb3 + (j % 3) * 64;
 #pragma unroll
       for (int c = j + 2; c < 32; ++c) cbn[c] = SK_PROBE_VARIANT == 2 ? a[c] * 0.5 : cbj[c];
     }
