@@ -335,6 +335,7 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
   const lds_cdp cb3 = (lds_cdp)(unsigned long)cb_base;
   double cbp[32], cbn[32];  // column j-1 (in use) and column j (in flight) of A', c-indexed; SSA after unrolling
   double m_prev = 0.0, d_prev = 1.0;
+  int dv_lo = 0, dv_hi = 0x3ff00000;  // 1.0 in every lane until its pivot arrives (lanes 32..63 keep it)
   int sgn = 0;  // sign bits of the pivots
   // keeps a filler value where it is written: pure arithmetic otherwise sinks to its use after the
   // loop, where the 32 refinements of 1/sqrt(d) ran back to back (measured 1.3 us per block)
@@ -356,41 +357,32 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
       for (int c = j + 2; c < 32; ++c) cbn[c] = SK_PROBE_VARIANT == 2 ? a[c] * 0.5 : cbj[c];
     }
     // ---- chain 0
-    const double d = lane_bcast(a[j], j);
+    const int d_lo = __builtin_amdgcn_readlane(__double2loint(a[j]), j), d_hi = __builtin_amdgcn_readlane(__double2hiint(a[j]), j);
+    const double d = __hiloint2double(d_hi, d_lo);
     const double y = __builtin_amdgcn_rcp(d);
     const double l1 = lane_bcast(a[j], j + 1 < 32 ? j + 1 : j);
     const double m0 = a[j] * y;
     __builtin_amdgcn_sched_barrier(0);
-    sgn |= __double2hiint(d);  // scalar: d is wave-uniform
+    sgn |= d_hi;  // scalar: d is wave-uniform
     asm volatile("" : "+s"(sgn));
-    double ry = __builtin_amdgcn_rsq(d_prev);
-    double rh = 0.5 * d_prev;
-    SK_PIN(ry) SK_PIN(rh)
+    // the pivot goes to lane j of dv: the 32 factors 1 / sqrt(d_j) are formed once, after the loop, in one vector pass
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dv_lo) : "s"(d_lo), "n"(j));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dv_hi) : "s"(d_hi), "n"(j));
     SK_FILL(0)
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 1
     const double e = __builtin_fma(-d, y, 1.0);
     __builtin_amdgcn_sched_barrier(0);
-    double t = rh * ry;
-    SK_PIN(t)
     SK_FILL(1)
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 2
     const double q = __builtin_fma(e, e, e);
     __builtin_amdgcn_sched_barrier(0);
-    t = __builtin_fma(-t, ry, 1.5);
-    SK_PIN(t)
-    ry = ry * t;
-    SK_PIN(ry)
     SK_FILL(2)
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 3
     const double m = __builtin_fma(m0, q, m0);
     __builtin_amdgcn_sched_barrier(0);
-    t = rh * ry;
-    SK_PIN(t)
-    t = __builtin_fma(-t, ry, 1.5);
-    SK_PIN(t)
     SK_FILL(3)
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 4
@@ -399,9 +391,6 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
       colbuf[((j + 1) % 3) * 64 + lane] = a[j + 1];
     }
     __builtin_amdgcn_sched_barrier(0);
-    ry = ry * t;
-    SK_PIN(ry)
-    if (j >= 1) { a[j - 1] = a[j - 1] * ry; SK_PIN(a[j - 1]) }
     SK_FILL(4)
     __builtin_amdgcn_sched_barrier(0);
     m_prev = m;
@@ -411,7 +400,14 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
   }
 #undef SK_FILL
 #undef SK_PIN
-  a[31] = a[31] * fast_rsqrt(d_prev);
+  // column c of L (and of W) is what the elimination left, times 1 / sqrt(d_c): lane c of r holds that factor.  (Inside
+  // the loop the same scaling cost eight fp64 instructions per column on wave-uniform values, in a loop whose length is
+  // its fp64 instruction count: 0.6 us per 32 columns.)
+  {
+    const double r = fast_rsqrt(__hiloint2double(dv_hi, dv_lo));
+#pragma unroll
+    for (int c = 0; c < 32; ++c) a[c] = a[c] * lane_bcast(r, c);
+  }
   // a zero or NaN pivot poisons every later one, so the last pivot speaks for them
   return sgn >= 0 && d_prev > 0.0;
 }
