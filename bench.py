@@ -80,22 +80,73 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(prob, iters):
-    """The oracle (CPU restatement, kind "port") on the same problem: `iters` LM
-    iterations on all host cores, wall-clock of the steady-state iterations."""
+def cpu_baseline(prob, iters, envelope=True, full_iters=1):
+    """The oracle (CPU restatement, kind "port") on the same problem and — like for like — the same plan: the
+    Cholesky of the reduced camera system skips the structural zeros outside its envelope exactly as the GPU
+    factorisation does (oracle/chol.cpp: bit-identical to factoring everything).  `iters` LM iterations on all host
+    cores, value = 1 / median iteration time; the full factorisation (no envelope) is timed beside it on `full_iters`
+    iterations (it costs ~7x the work)."""
     import oracle
     nthreads = available_cpus()
-    o = oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=nthreads, max_num_iterations=iters,
-                               function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
-    t0 = time.time()
-    _, s = oracle.solve_bal(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index,
-                            prob.observations, prob.parameters, o)
-    wall = time.time() - t0
-    it = max(1, s.num_iterations)
-    return {"value": it / s.total_time_s, "unit": "LM iterations/s", "cores": int(s.num_threads_used), "kind": "port",
-            "sample": "%d LM iterations of the same %s-shaped problem (CPU restatement, not Ceres; %.1f s wall; "
-                      "cholesky %.1f s, schur assembly %.1f s)" % (it, "bundle-adjustment", wall, s.t_linear_cholesky_s,
-                                                                    s.t_linear_assemble_s)}
+
+    def run(n_it, env):
+        o = oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=nthreads, max_num_iterations=n_it,
+                                   function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0,
+                                   cholesky_envelope=1 if env else 0)
+        t0 = time.time()
+        _, s = oracle.solve_bal(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index,
+                                prob.observations, prob.parameters, o)
+        return s, time.time() - t0
+    s, wall = run(iters, envelope)
+    times = sorted(s.iteration_seconds())
+    med = times[len(times) // 2] if times else float("nan")
+    out = {"value": 1.0 / med, "unit": "LM iterations/s", "cores": int(s.num_threads_used), "kind": "port",
+           "plan": "block envelope of the reduced camera system (as the GPU run)" if envelope else "full factorisation (as the GPU run)",
+           "sample": "median of %d LM iterations of the same bundle-adjustment-shaped problem (CPU restatement, not Ceres; %.1f s wall; "
+                     "cholesky %.1f s, schur assembly %.1f s in total)" % (len(times), wall, s.t_linear_cholesky_s, s.t_linear_assemble_s)}
+    if envelope and full_iters > 0:
+        sf, wall_f = run(full_iters, False)
+        tf = sorted(sf.iteration_seconds())
+        out["value_full_factorisation"] = 1.0 / tf[len(tf) // 2]
+        out["sample_full_factorisation"] = "%d iteration(s), %.1f s wall (cholesky %.1f s)" % (len(tf), wall_f, sf.t_linear_cholesky_s)
+    return out
+
+
+def c5_record(sk, m=1000000, n=10000, iters=2, seed=5):
+    """BASELINE.json config 5 (dense rows: m residuals x n parameters, DENSE_NORMAL_CHOLESKY) in the same run: the J^T J
+    formation (syrk_gram_f64_kernel, fp64 MFMA) timed by HIP events around its launches, priced with the ALGORITHMIC
+    flop count m n (n + 1) of SURVEY.md section 8(d) (not the padded tiles the launch computes)."""
+    rng = np.random.default_rng(seed)
+    x_star = rng.normal(size=n)
+    y = sk.api.synth_dense_targets(seed, m, n, x_star) + rng.normal(0, 1e-3, m)
+    consts = np.stack([np.full(m, float(seed)), np.arange(m, dtype=np.float64), y], axis=1)
+    x = sk.DoubleArray(n)
+    problem = sk.Problem()
+    problem.addDenseRows(10, consts, None, x, n)
+    o = sk.Solver.Options()
+    o.setLinearSolverType(sk.LinearSolverType.DENSE_NORMAL_CHOLESKY)
+    o.setMaxNumIterations(1000)
+    o.setFunctionTolerance(0.0)
+    o.setGradientTolerance(0.0)
+    o.setParameterTolerance(0.0)
+    s = sk.StepSolver(o, problem)
+    s.setKernelTiming(1)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        s.step()
+    dt = (time.perf_counter() - t0) / iters
+    sec, launches = s.kernelSeconds("syrk_gram")
+    flops_alg = s.stat("jtj_flops_algorithmic")
+    flops_tiles = s.syrkFlopsPerSolve()
+    summ = sk.Solver.Summary()
+    s.finish(summ)
+    rate = flops_alg * launches / sec * 1e-12 if sec > 0 else None
+    return {"workload": "synthetic dense NLLS, %d residuals x %d parameters, DENSE_NORMAL_CHOLESKY (BASELINE.json configs[4])" % (m, n),
+            "iterations_per_second": 1.0 / dt, "seconds_per_iteration": dt,
+            "jtj": {"bound": "mfma", "kernel": "sk::syrk_gram_f64_kernel", "achieved": rate, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": rate / FP64_MFMA_PEAK_TFLOPS if rate else None, "flops_per_launch": flops_alg,
+                    "flops_per_launch_padded_tiles": flops_tiles, "launches": launches, "avg_launch_ms": 1e3 * sec / max(1, launches)},
+            "costs": [it["cost"] for it in summ.iterations()]}
 
 
 def main():
@@ -104,7 +155,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="ladybug-1723-156502")
-    ap.add_argument("--cpu-iters", type=int, default=2, help="LM iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=5, help="LM iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-full-iters", type=int, default=1, help="... and of the same baseline factoring every block (0 = skip)")
+    ap.add_argument("--long-range", type=float, default=0.0, help="fraction of the tracks seen from two distant windows (loop closures)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the BASELINE.json config-5 (dense rows) record")
     ap.add_argument("--group", type=int, default=0, help="(tuning) SYRK depth in 128-column blocks")
     ap.add_argument("--no-lookahead", action="store_true", help="(tuning) single-stream Cholesky")
     ap.add_argument("--no-alone", action="store_true", help="skip the untimed side measurements (profiling runs)")
@@ -135,7 +189,7 @@ def main():
     from skeres_amd import bal
     sk.lib()  # fail loudly if the HIP library is missing
 
-    prob = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB)
+    prob = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB, long_range_fraction=args.long_range)
     problem, params, loss = build_problem(sk, prob)
     options = sk.Solver.Options()
     options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
@@ -182,6 +236,7 @@ def main():
     syrk_s, syrk_n = solver.kernelSeconds("gemm_syrk")
     syrk_flops = solver.syrkFlopsPerSolve()
     syrk_c_bytes = solver.syrkCBytesPerSolve()
+    plan = {k: solver.stat(k) for k in ("envelope_fill", "camera_order", "cholesky_flops_full", "cholesky_flops_plan", "cholesky_columns_resident")}
     summary = sk.Solver.Summary()
     solver.finish(summary)
     # Untimed side measurement: the same kernel with the look-ahead off, i.e. alone on the chip.  In the
@@ -189,11 +244,12 @@ def main():
     # stream is masked off a few CUs per XCD), so its per-launch time there is longer by design.
     alone = None
     full_ms = None
+    full_chol_s = None
     if world == 1 and not args.no_lookahead and not args.no_alone:
         del solver
 
         def side_run(lookahead, envelope):
-            prob2 = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB)
+            prob2 = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB, long_range_fraction=args.long_range)
             problem2, params2, loss2 = build_problem(sk, prob2)
             options.setCholeskyTuning(args.group, lookahead)
             options.setCholeskyEnvelope(envelope)
@@ -209,13 +265,15 @@ def main():
             s2, n2 = solver2.kernelSeconds("gemm_syrk")
             rate = (solver2.syrkFlopsPerSolve() * 3) / s2 * 1e-12 if s2 > 0 else None
             flops2 = solver2.syrkFlopsPerSolve()
-            solver2.finish(sk.Solver.Summary())
+            summ2 = sk.Solver.Summary()
+            solver2.finish(summ2)
+            chol_s = summ2.phaseSeconds(2) / max(1, len(summ2.iterations()) - 1)  # Cholesky phase, seconds per iteration
             del solver2
-            return rate, dt, flops2
-        alone, _, _ = side_run(False, not args.full_factorisation)
+            return rate, dt, flops2, chol_s
+        alone, _, _, _ = side_run(False, not args.full_factorisation)
         # ... and the factorisation of EVERY block (no envelope): the same arithmetic (other SYRK grouping), more work in
         if not args.full_factorisation:
-            _, full_dt, full_flops = side_run(True, False)
+            _, full_dt, full_flops, full_chol_s = side_run(True, False)
             full_ms = 1e3 * full_dt
     its = summary.iterations()
     timed = its[1 + args.warmup: 1 + args.warmup + args.steps]
@@ -236,6 +294,10 @@ def main():
                              "tests/test_gpu_parity.py::test_envelope_*); SYRK depth 2 and launch-by-launch look-ahead where the trailing SYRK "
                              "is the long pole, a resident panel chain (potrf server workgroup + per-column launches) where the serial chain is"),
                 "ms_per_step_full_factorisation": full_ms,
+                "envelope_fill": plan["envelope_fill"],  # fraction of the lower-triangular 128-blocks of the reduced system that is factored
+                "camera_order": {0: "first appearance", 1: "memory order of the camera blocks", 2: "reverse Cuthill-McKee"}.get(int(plan["camera_order"])),
+                "cholesky_block_columns_resident": int(plan["cholesky_columns_resident"]),
+                "long_range_fraction": args.long_range,
                 "successful_steps_in_timed_region": n_success, "parallelism": ("one GPU" if world == 1 else
                                 "points sharded x%d, reduced system all-reduced, Cholesky replicated" % world if dist_mode == "sharded" else
                                 "replicated x%d: the solver measured %.1f ms for the all-reduce of the reduced system against %.1f ms of "
@@ -262,10 +324,34 @@ def main():
             "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(
                 ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"])},
         }
+        # The whole Cholesky phase (factorisation + triangular solves, every kernel of it) against the MFMA peak.  The
+        # timed region factors the blocks inside the envelope (cholesky_flops_plan); the structure-independent figure
+        # is the FULL factorisation — SURVEY.md section 8(d)'s n^3 / 3 over the measured Cholesky phase of the side run
+        # that factors every block.
+        chol_live_s = summary.phaseSeconds(2) / max(1, len(its) - 1)
+        line["roofline_cholesky_phase"] = {
+            "bound": "mfma", "flops": plan["cholesky_flops_plan"], "ms": 1e3 * chol_live_s,
+            "achieved": plan["cholesky_flops_plan"] / chol_live_s * 1e-12 if chol_live_s > 0 else None, "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": plan["cholesky_flops_plan"] / chol_live_s * 1e-12 / FP64_MFMA_PEAK_TFLOPS if chol_live_s > 0 else None,
+            "note": "all kernels of phase C (potrf, TRSM, updates, back-substitution) of the run above; flops of the blocks inside the envelope"}
+        if full_chol_s:
+            f_full = plan["cholesky_flops_full"]
+            line["roofline_full"] = {
+                "bound": "mfma", "flops": f_full, "cholesky_ms": 1e3 * full_chol_s, "ms_per_step": full_ms,
+                "iterations_per_second": 1e3 / full_ms if full_ms else None,
+                "achieved": f_full / full_chol_s * 1e-12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": f_full / full_chol_s * 1e-12 / FP64_MFMA_PEAK_TFLOPS,
+                "note": "every 128-block factored (sk_options_set_cholesky_envelope(o, 0)): (9C)^3 / 3 flops over the measured Cholesky "
+                        "phase, 3 untimed steps — what the iteration costs when the camera graph has no band to exploit"}
         if args.cpu_iters > 0 and world == 1:
-            line["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters)
+            line["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, envelope=not args.full_factorisation, full_iters=args.cpu_full_iters)
         elif world == 1:
             line["cpu_baseline"] = None
+        if world == 1 and not args.no_c5 and not args.no_alone:
+            try:
+                line["c5"] = c5_record(sk)
+            except sk.SkeresError as e:  # e.g. not enough free HBM for the 80 GB Jacobian on a shared device
+                line["c5"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

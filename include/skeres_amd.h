@@ -370,6 +370,19 @@ double sk_solver_syrk_c_bytes_per_solve(const sk_solver* s);
  * measured all-reduce of the reduced system and *saved_seconds the estimated per-iteration work sharding removes
  * (either pointer may be NULL). */
 int sk_solver_distribution(const sk_solver* s, double* allreduce_seconds, double* saved_seconds);
+/* Named figures of the solver's plan, for benchmarks and reports (no reference counterpart: Ceres prints the like in
+ * Summary::FullReport).  Returns SK_OK and sets *value, or SK_ERR_INVALID_ARGUMENT for a name this solver does not
+ * report.  DENSE_SCHUR:
+ *   "envelope_fill"         fraction of the lower-triangular 128-blocks of the reduced camera system inside the block
+ *                           envelope that is factored (1 with sk_options_set_cholesky_envelope(o, 0))
+ *   "camera_order"          0 first appearance, 1 memory order of the camera blocks, 2 reverse Cuthill-McKee
+ *   "cholesky_flops_full"   n^3 / 3, n = 9 * cameras: SURVEY.md section 8(d)'s figure for phase C
+ *   "cholesky_flops_plan"   flops of the factorisation as planned (potrf + TRSM + updates of the blocks inside the envelope)
+ *   "cholesky_columns_resident"  block columns factored under the resident panel chain
+ * dense rows (DENSE_NORMAL_CHOLESKY over one parameter block):
+ *   "jtj_flops_algorithmic" m n (n + 1): SURVEY.md section 8(d)'s figure for J^T J (sk_solver_syrk_flops_per_solve counts
+ *                           the padded 128 x 128 tiles the launch computes) */
+int sk_solver_stat(const sk_solver* s, const char* name, double* value);
 
 /* ---- multi-GPU sharding (host logic, no device needed) -----------------------
  * How sk_solve splits a bundle-adjustment-shaped problem over `world` ranks

@@ -38,6 +38,7 @@ class Options(C.Structure):
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double), ("jacobi_scaling", C.c_int),
         ("max_num_consecutive_invalid_steps", C.c_int), ("num_threads", C.c_int),
+        ("cholesky_envelope", C.c_int),
     ]
 
 
@@ -46,7 +47,7 @@ class Iteration(C.Structure):
         ("iteration", C.c_int), ("cost", C.c_double), ("cost_change", C.c_double),
         ("gradient_max_norm", C.c_double), ("step_norm", C.c_double),
         ("relative_decrease", C.c_double), ("trust_region_radius", C.c_double),
-        ("step_is_valid", C.c_int), ("step_is_successful", C.c_int),
+        ("step_is_valid", C.c_int), ("step_is_successful", C.c_int), ("time_s", C.c_double),
     ]
 
 
@@ -63,6 +64,11 @@ class Summary(C.Structure):
 
     def costs(self):
         return [self.iterations[i].cost for i in range(self.num_logged)]
+
+    def iteration_seconds(self):
+        """Wall-clock seconds of iterations 1 .. num_logged-1 (iteration 0 is the initial evaluation)."""
+        t = [self.iterations[i].time_s for i in range(self.num_logged)]
+        return [b - a for a, b in zip(t[:-1], t[1:])]
 
 
 _lib = None
@@ -105,6 +111,8 @@ def lib():
         L.or_parameterization_jacobian.argtypes = [C.c_int, C.c_int, ip, C.c_int, dp, dp]
         L.or_cholesky_lower.argtypes = [dp, C.c_int, C.c_int]
         L.or_cholesky_solve.argtypes = [dp, C.c_int, dp]
+        L.or_cholesky_lower_envelope.argtypes = [dp, C.c_int, C.c_int, ip]
+        L.or_cholesky_solve_envelope.argtypes = [dp, C.c_int, dp, ip]
         _lib = L
     return _lib
 
@@ -369,10 +377,27 @@ def bal_evaluate(C_, P_, cam_idx, pt_idx, obs, x, jacobians=True):
     return r.reshape(n, 2), None, None, cost.value
 
 
-def cholesky_lower(A, num_threads=1):
+def cholesky_lower(A, num_threads=1, last_row=None):
+    """last_row: column envelope (n ints, non-decreasing, last_row[j] >= j): the entries below it are structural zeros."""
     L = np.array(A, dtype=np.float64, order="C").copy()
-    info = lib().or_cholesky_lower(_dp(L), L.shape[0], num_threads)
+    if last_row is None:
+        info = lib().or_cholesky_lower(_dp(L), L.shape[0], num_threads)
+    else:
+        lr = np.ascontiguousarray(last_row, dtype=np.int32)
+        info = lib().or_cholesky_lower_envelope(_dp(L), L.shape[0], num_threads, _ip(lr))
     return info, np.tril(L)
+
+
+def cholesky_solve(L, b, last_row=None):
+    """Solve L L^T y = b (L lower, row-major); with last_row the structural zeros left of each row's envelope are skipped."""
+    L = np.ascontiguousarray(L, dtype=np.float64)
+    y = np.array(b, dtype=np.float64).copy()
+    if last_row is None:
+        lib().or_cholesky_solve(_dp(L), L.shape[0], _dp(y))
+    else:
+        lr = np.ascontiguousarray(last_row, dtype=np.int32)
+        lib().or_cholesky_solve_envelope(_dp(L), L.shape[0], _dp(y), _ip(lr))
+    return y
 
 
 def bal_reduced_system(C_, P_, cam_idx, pt_idx, obs, x, D, add_Dc=True):

@@ -8,6 +8,7 @@
 // a fair multi-core CPU implementation rather than a naive triple loop.
 #include <cmath>
 #include <cstring>
+#include <vector>
 #include <algorithm>
 #ifdef _OPENMP
 #include <omp.h>
@@ -77,7 +78,12 @@ static int potrf_unblocked(double* A, int n, int ld) {
 }
 
 // In place; only the lower triangle (incl. diagonal) is referenced / written.
-int cholesky_lower_inplace(double* A, int n, int ld, int num_threads) {
+// last_row (optional, n entries, non-decreasing, last_row[j] >= j): the column envelope of the matrix — rows below
+// last_row[j] are structurally zero in column j, and a Cholesky factor keeps the envelope of the matrix it factors.
+// The panel and trailing updates then stop at the panel's last envelope row.  What is left out is 0 - 0 * x in the
+// full algorithm, so the factor is bit-identical to last_row == nullptr (tests/test_oracle_kat.py); this is the CPU
+// counterpart of the block envelope the GPU factorisation uses, so that the timed CPU baseline does the same work.
+int cholesky_lower_inplace(double* A, int n, int ld, int num_threads, const int* last_row) {
   const int NB = 96, TB = 192;
   if (num_threads <= 0) num_threads = 1;
   for (int k = 0; k < n; k += NB) {
@@ -85,8 +91,8 @@ int cholesky_lower_inplace(double* A, int n, int ld, int num_threads) {
     double* Akk = A + (size_t)k * ld + k;
     const int info = potrf_unblocked(Akk, nb, ld);
     if (info) return k + info;
-    const int rem = n - k - nb;
-    if (rem <= 0) break;
+    const int rem = (last_row ? std::min(n, last_row[k + nb - 1] + 1) : n) - k - nb;
+    if (rem <= 0) continue;
     double* A21 = A + (size_t)(k + nb) * ld + k;
     // TRSM: X L11^T = A21, row by row
 #pragma omp parallel for num_threads(num_threads) schedule(static)
@@ -117,11 +123,14 @@ int cholesky_lower_inplace(double* A, int n, int ld, int num_threads) {
   return 0;
 }
 
-// Solve L L^T y = b in place (L row-major lower).
-void cholesky_solve_lower(const double* L, int n, int ld, double* b) {
+// Solve L L^T y = b in place (L row-major lower).  last_row as above: row i of L starts at the first column j with
+// last_row[j] >= i (the entries left of it are structural zeros; skipping them changes no sum).
+void cholesky_solve_lower(const double* L, int n, int ld, double* b, const int* last_row) {
+  std::vector<int> first(n, 0);
+  if (last_row) { int c = 0; for (int i = 0; i < n; ++i) { while (c < i && last_row[c] < i) ++c; first[i] = c; } }
   for (int i = 0; i < n; ++i) {
     double s = b[i]; const double* l = L + (size_t)i * ld;
-    for (int t = 0; t < i; ++t) s -= l[t] * b[t];
+    for (int t = first[i]; t < i; ++t) s = __builtin_fma(-l[t], b[t], s);  // explicit: one rounding per term wherever the loop starts
     b[i] = s / l[i];
   }
   // back substitution with L^T: column-oriented sweep keeps row-major access
@@ -129,7 +138,7 @@ void cholesky_solve_lower(const double* L, int n, int ld, double* b) {
     const double* l = L + (size_t)i * ld;
     const double yi = b[i] / l[i];
     b[i] = yi;
-    for (int t = 0; t < i; ++t) b[t] -= l[t] * yi;
+    for (int t = first[i]; t < i; ++t) b[t] = __builtin_fma(-l[t], yi, b[t]);
   }
 }
 

@@ -46,8 +46,8 @@
 namespace oracle {
 
 // dense Cholesky (chol.cpp; compiled with vectorisation flags)
-int cholesky_lower_inplace(double* A, int n, int ld, int num_threads);
-void cholesky_solve_lower(const double* L, int n, int ld, double* b);
+int cholesky_lower_inplace(double* A, int n, int ld, int num_threads, const int* last_row = nullptr);
+void cholesky_solve_lower(const double* L, int n, int ld, double* b, const int* last_row = nullptr);
 
 static double now_s() {
   using namespace std::chrono;
@@ -243,6 +243,22 @@ struct Bal {
   const double* consts = nullptr;            // 2 per observation
   std::vector<double> r, F, E;               // 2N, 18N, 6N
   const double* loss_nodes = nullptr; int loss_root = -1;  // one loss for all blocks (oracle/loss.hpp)
+  // or_options::cholesky_envelope: column envelope of the reduced camera system in the caller's camera numbering
+  // (last_row[j] >= j, non-decreasing; empty = factor every entry).  Camera c shares a point with no camera beyond
+  // the last camera of any of its points, so rows below 9 * that + 8 are structural zeros in S and in its factor.
+  std::vector<int> last_row;
+  void build_envelope() {
+    std::vector<int> last_cam(C);
+    for (int c = 0; c < C; ++c) last_cam[c] = c;
+    for (int p = 0; p < P; ++p) {
+      if (pt_start[p] == pt_start[p + 1]) continue;
+      const int cmax = cam[pt_obs[pt_start[p + 1] - 1]];  // pt_obs is sorted by camera
+      for (int k = pt_start[p]; k < pt_start[p + 1]; ++k) { int& l = last_cam[cam[pt_obs[k]]]; if (cmax > l) l = cmax; }
+    }
+    for (int c = 1; c < C; ++c) if (last_cam[c] < last_cam[c - 1]) last_cam[c] = last_cam[c - 1];
+    last_row.resize(9 * (size_t)C);
+    for (int j = 0; j < 9 * C; ++j) last_row[j] = 9 * last_cam[j / 9] + 8;
+  }
 };
 
 static bool bal_evaluate(Bal& B, const double* x, bool want_jac, double* cost, int nthreads) {
@@ -345,9 +361,10 @@ static bool bal_schur_solve(const Bal& B, const double* D, double* y, SchurWork&
   const int C = B.C, P = B.P; const int n = 9 * C;
   if (!bal_schur_assemble(B, D, w, nthreads, true)) return false;
   double t1 = now_s();
-  if (cholesky_lower_inplace(w.S.data(), n, n, nthreads) != 0) return false;
+  const int* env = B.last_row.empty() ? nullptr : B.last_row.data();
+  if (cholesky_lower_inplace(w.S.data(), n, n, nthreads, env) != 0) return false;
   std::vector<double> yc(w.rhs);
-  cholesky_solve_lower(w.S.data(), n, n, yc.data());
+  cholesky_solve_lower(w.S.data(), n, n, yc.data(), env);
   double t2 = now_s(); w.t_chol += t2 - t1;
   for (int i = 0; i < n; ++i) y[i] = yc[i];
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 256)
@@ -532,6 +549,7 @@ static void log_iter(or_summary* S, int it, double cost, double cost_change, dou
     L.iteration = it; L.cost = cost; L.cost_change = cost_change; L.gradient_max_norm = gmax;
     L.step_norm = step_norm; L.relative_decrease = rho; L.trust_region_radius = radius;
     L.step_is_valid = valid; L.step_is_successful = success;
+    L.time_s = now_s();  // wall clock at the end of the iteration (differences = iteration times; bench.py's CPU baseline)
     S->num_logged = it + 1;
   }
 }
@@ -631,6 +649,7 @@ void or_options_default(or_options* o) {
   o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
   o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
   o->jacobi_scaling = 1; o->max_num_consecutive_invalid_steps = 5; o->num_threads = 1;
+  o->cholesky_envelope = 0;
 }
 
 int or_functor_info(int id, int* num_residuals, int* num_blocks, int* num_consts, int* block_sizes) {
@@ -789,6 +808,7 @@ int or_solve_bal_loss(int C, int P, int N, const int* cam_idx, const int* pt_idx
   Bal B;
   if (int rc = bal_build(B, C, P, N, cam_idx, pt_idx, obs)) return rc;
   B.loss_nodes = loss_nodes; B.loss_root = loss_nodes ? loss_root : -1;
+  if (opt->cholesky_envelope) B.build_envelope();
   int nt = opt->num_threads;
 #ifdef _OPENMP
   if (nt <= 0) nt = omp_get_max_threads();
@@ -833,6 +853,8 @@ int or_bal_reduced_system(int C, int P, int N, const int* cam_idx, const int* pt
 }
 
 int or_cholesky_lower(double* A, int n, int num_threads) { return cholesky_lower_inplace(A, n, n, num_threads); }
+int or_cholesky_lower_envelope(double* A, int n, int num_threads, const int* last_row) { return cholesky_lower_inplace(A, n, n, num_threads, last_row); }
+void or_cholesky_solve_envelope(const double* L, int n, double* b, const int* last_row) { cholesky_solve_lower(L, n, n, b, last_row); }
 void or_cholesky_solve(const double* L, int n, double* b) { cholesky_solve_lower(L, n, n, b); }
 
 }  // extern "C"

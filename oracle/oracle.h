@@ -23,12 +23,15 @@ typedef struct or_options {
   int jacobi_scaling;
   int max_num_consecutive_invalid_steps;
   int num_threads; /* <=0: all cores */
+  int cholesky_envelope; /* DENSE_SCHUR: skip the structural zeros outside the column envelope of the reduced system
+                            (bit-identical factor; the like-for-like CPU baseline of the GPU's block envelope) */
 } or_options;
 
 typedef struct or_iteration {
   int iteration;
   double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius;
   int step_is_valid, step_is_successful;
+  double time_s; /* wall clock when the iteration was logged */
 } or_iteration;
 
 typedef struct or_summary {
@@ -77,6 +80,9 @@ int or_bal_reduced_system(int C, int P, int N, const int* cam_idx, const int* pt
                           const double* x, const double* D, int add_Dc, double* S, double* rhs);
 int or_cholesky_lower(double* A, int n, int num_threads);
 void or_cholesky_solve(const double* L, int n, double* b);
+/* last_row: n entries, non-decreasing, last_row[j] >= j (column envelope) */
+int or_cholesky_lower_envelope(double* A, int n, int num_threads, const int* last_row);
+void or_cholesky_solve_envelope(const double* L, int n, double* b, const int* last_row);
 
 #ifdef __cplusplus
 }

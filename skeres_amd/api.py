@@ -134,6 +134,7 @@ _SIGS = {
     "sk_solver_syrk_flops_per_solve": (C.c_double, [C.c_void_p]),
     "sk_solver_syrk_c_bytes_per_solve": (C.c_double, [C.c_void_p]),
     "sk_solver_distribution": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "sk_solver_stat": (C.c_int, [C.c_void_p, C.c_char_p, _dp]),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
@@ -1096,6 +1097,12 @@ class StepSolver:
 
     def syrkCBytesPerSolve(self):
         return lib().sk_solver_syrk_c_bytes_per_solve(self._h)
+
+    def stat(self, name):
+        """A named figure of the solver's plan (sk_solver_stat), e.g. "envelope_fill", "cholesky_flops_full"."""
+        v = C.c_double()
+        _check(lib().sk_solver_stat(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def distribution(self):
         """("sharded" | "replicated", measured all-reduce seconds, estimated seconds of work sharding removes per iteration)."""

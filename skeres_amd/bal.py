@@ -88,7 +88,7 @@ def snavely_project(cameras, points):
 
 
 def generate(num_cameras, num_points, num_observations, seed=1723, sigma_px=0.5,
-             perturb=(1e-2, 1e-1, 1e-1)):
+             perturb=(1e-2, 1e-1, 1e-1), long_range_fraction=0.0):
     """Seeded synthetic BAL problem with exactly the requested shape.
 
     Cameras sit on a noisy trajectory along +x looking down -z at a slab of
@@ -97,6 +97,13 @@ def generate(num_cameras, num_points, num_observations, seed=1723, sigma_px=0.5,
     heavy tail (up to C/4) and adjusted so that sum k_p == N; its cameras are
     a spatially local, strictly increasing run around the point's position on
     the trajectory, so the reduced camera matrix has BAL-like band + fill.
+
+    ``long_range_fraction`` (loop closures): that fraction of the points is seen from TWO distant windows of the
+    trajectory instead of one — the second half of the point's camera run is moved to a window drawn uniformly from
+    the part of the trajectory the first half does not cover (a street revisited).  Every such track couples two
+    far-apart groups of cameras, which is what widens the envelope of the reduced camera system; the sensitivity of
+    the factorisation to it is reported in profiles/ (tools/envelope_sensitivity.py).  0 leaves the problem exactly
+    as it was (the extra draws come from a generator of their own).
     """
     C, P, N = int(num_cameras), int(num_points), int(num_observations)
     if N < 2 * P:
@@ -160,6 +167,24 @@ def generate(num_cameras, num_points, num_observations, seed=1723, sigma_px=0.5,
         for p in bad_pts:
             kp = int(k[p])
             cam_idx[pt_start[p]:pt_start[p + 1]] = np.sort(rng.choice(C, size=kp, replace=False))
+    if long_range_fraction > 0.0:
+        rng_lr = np.random.default_rng([seed, 0x10c5])
+        chosen = np.flatnonzero(rng_lr.uniform(0, 1, P) < long_range_fraction)
+        u = rng_lr.uniform(0, 1, P)
+        for p in chosen:
+            a, b = int(pt_start[p]), int(pt_start[p + 1])
+            h = a + (b - a) // 2                     # second half: observations [h, b)
+            first = cam_idx[a:h]
+            off = cam_idx[h:b] - cam_idx[h]          # offsets inside the second window
+            span2 = int(off[-1])
+            lo, hi = int(first[0]), int(first[-1])
+            len_l = max(0, lo - span2)               # window start positions left of the first half: [0, lo - span2)
+            len_r = max(0, (C - span2) - (hi + 1))   # ... and right of it: [hi + 1, C - span2)
+            if len_l + len_r <= 0:
+                continue                             # the first half leaves no room: the track stays local
+            t = int(u[p] * (len_l + len_r))
+            base2 = t if t < len_l else hi + 1 + (t - len_l)
+            cam_idx[h:b] = base2 + off
     pt_idx = np.repeat(np.arange(P, dtype=np.int64), k)
 
     # points near the centroid of their cameras' x positions

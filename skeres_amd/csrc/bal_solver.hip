@@ -76,6 +76,30 @@ class BalSolver : public SolverBase {
     (void)cholesky_syrk_flops(npad_, group_, env_last_.empty() ? nullptr : env_last_.data(), chain_ok(), &tiles);
     return tiles * 2.0 * 128.0 * 128.0 * sizeof(double);
   }
+  bool stat(const std::string& name, double* value) const override {
+    const int nblk = npad_ / 128;
+    const int* env = env_last_.empty() ? nullptr : env_last_.data();
+    if (name == "envelope_fill") {
+      double in = 0.0;
+      for (int c = 0; c < nblk; ++c) {
+        const int lm = env ? std::min(env[c], nblk - 1) : nblk - 1;
+        in += (lm - c + 1) + (lm < nblk - 1 ? 1 : 0);  // the run from the diagonal block down, and the right-hand-side row
+      }
+      *value = in / (0.5 * nblk * (nblk + 1.0));
+      return true;
+    }
+    if (name == "camera_order") { *value = camera_order_; return true; }
+    if (name == "cholesky_flops_full") { const double n = 9.0 * C_; *value = n * n * n / 3.0; return true; }
+    if (name == "cholesky_flops_plan") { *value = cholesky_plan_flops(nblk, env); return true; }
+    if (name == "cholesky_columns_resident") {
+      const CholeskyPlan plan = cholesky_plan(nblk, group_, env, chain_ok());
+      int r = 0;
+      for (char c : plan.resident) r += c ? 1 : 0;
+      *value = r;
+      return true;
+    }
+    return false;
+  }
   // the grouping is the library's choice (Options::cholesky_group == 0) and the masked streams of the resident panel chain exist
   bool chain_ok() const { return opt_.cholesky_group == 0 && opt_.lookahead && chol_ctx_.server != nullptr; }
   int distribution(double* allreduce_s, double* saved_s) const override {
@@ -112,6 +136,7 @@ class BalSolver : public SolverBase {
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
+  int camera_order_ = 0;       // which candidate order of the cameras was kept (0 first appearance, 1 memory, 2 RCM)
   int group_ = 3;              // SYRK depth actually used (Options::cholesky_group, or chosen from the envelope)
   DevBuf<double> b_w_, b_pack_;
   size_t packed_elems_ = 0;
@@ -259,6 +284,7 @@ int BalSolver::setup() {
       if (best < 0.0 || f < best * (1.0 - 1e-9)) { best = f; best_k = (int)k; best_env.swap(env); }
     }
     const std::vector<int>& id = cand[best_k];
+    camera_order_ = best_k;
     std::vector<int> cb(C_);
     for (int c = 0; c < C_; ++c) cb[id[c]] = cam_block_[c];
     cam_block_.swap(cb);

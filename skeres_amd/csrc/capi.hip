@@ -589,6 +589,13 @@ double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launc
 double sk_solver_syrk_flops_per_solve(const sk_solver* s) { return s->impl->syrk_flops_per_solve(); }
 double sk_solver_syrk_c_bytes_per_solve(const sk_solver* s) { return s->impl->syrk_c_bytes_per_solve(); }
 int sk_solver_distribution(const sk_solver* s, double* allreduce_seconds, double* saved_seconds) { return s->impl->distribution(allreduce_seconds, saved_seconds); }
+int sk_solver_stat(const sk_solver* s, const char* name, double* value) {
+  SK_GUARD_BEGIN
+  if (!s || !name || !value) { set_error("null argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (!s->impl->stat(name, value)) { set_error("this solver reports no figure named '%s'", name); return SK_ERR_INVALID_ARGUMENT; }
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
 
 int sk_solve(const sk_options* options, sk_problem* problem, sk_summary* summary) {
   SK_GUARD_BEGIN

@@ -1656,6 +1656,20 @@ double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, dou
   return f;
 }
 
+// Algorithmic flops of factoring the blocks inside the envelope (last == nullptr: every block): per block column with
+// h active block rows below it, 128^3 (1/3 + h + h^2) — diagonal factorisation, triangular solve of h blocks, symmetric
+// update of h (h + 1) / 2 blocks with its diagonal blocks counted once.  Sums to n^3 / 3 for a full matrix.
+double cholesky_plan_flops(int nblk, const int* last) {
+  double f = 0.0;
+  for (int c = 0; c < nblk; ++c) {
+    const int lm = last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1;
+    const int main_rows = lm >= c + 1 ? lm - c : 0;
+    const double h = main_rows + ((c + 1 + main_rows <= nblk - 1 && lm < nblk - 1) ? 1 : 0);
+    f += 128.0 * 128.0 * 128.0 * (1.0 / 3.0 + h + h * h);
+  }
+  return f;
+}
+
 // Envelope from the block rows' first non-zero block columns (first_col[i] <= i for i < nblk-1; the entry of the
 // last block row is ignored: that row is always active): last[c] = max{ i <= nblk-2 : first_col[i] <= c }.
 std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col) {

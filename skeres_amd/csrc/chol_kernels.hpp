@@ -123,6 +123,7 @@ int cholesky_plan_max_group(const CholeskyPlan& plan);
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
                         hipStream_t s, KernelTimer* kt, const int* last = nullptr);
 double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false, double* c_tiles = nullptr);
+double cholesky_plan_flops(int nblk, const int* last);
 std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col);
 std::vector<int> cholesky_group_bounds(int nblk, int group);
 void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,

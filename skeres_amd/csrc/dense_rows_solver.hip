@@ -26,6 +26,10 @@ class DenseRowsSolver : public SolverBase {
   ~DenseRowsSolver() override { if (h_scal_) (void)hipHostFree(h_scal_); }
   // algorithmic flops of J^T J (lower-triangular 128x128 tiles, 2*128*128*K each)
   double syrk_flops_per_solve() const override { return 0.5 * (npad_ / 128) * (npad_ / 128 + 1.0) * 2.0 * 128.0 * 128.0 * (double)m_pad_; }
+  bool stat(const std::string& name, double* value) const override {
+    if (name == "jtj_flops_algorithmic") { *value = (double)m_ * (double)n_ * ((double)n_ + 1.0); return true; }
+    return false;
+  }
 
  protected:
   int setup() override;

@@ -22,6 +22,7 @@ class SolverBase {
   KernelTimer& kernel_timer() { return kt_; }
   virtual double syrk_flops_per_solve() const { return 0.0; }
   virtual double syrk_c_bytes_per_solve() const { return 0.0; }  // C tiles read + written by those launches
+  virtual bool stat(const std::string& name, double* value) const { (void)name; (void)value; return false; }  // sk_solver_stat
   // how a world > 1 is used (SK_DISTRIBUTION_*), with the estimates behind an automatic choice
   virtual int distribution(double* allreduce_s, double* saved_s) const {
     if (allreduce_s) *allreduce_s = 0.0;

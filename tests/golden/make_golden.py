@@ -10,6 +10,12 @@ come from tools that share no code with either the oracle or the product:
   optima.json              SciPy least_squares (trf, exact Jacobians from SymPy /
                            analytic formulas) minimisers of CurveFitting, Powell
                            and a tiny bundle-adjustment problem
+  lm_step.json             ONE Levenberg-Marquardt step of a 16-camera bundle-adjustment problem, computed with none of
+                           the oracle's or the product's code: residuals and Jacobians from the SymPy closed form
+                           evaluated with 40-digit mpmath, Jacobi scaling, LM diagonal and the damped normal
+                           equations (J^T J + D^2) y = J^T r formed in extended precision and solved with NumPy +
+                           iterative refinement; candidate cost again from the closed form.  Pins the linear
+                           algebra of one iteration (oracle: tests/test_oracle_kat.py; GPU: tests/test_gpu_parity.py)
   robust_optima.json       SciPy least_squares with loss = 'cauchy' / 'huber' / 'soft_l1'
                            (the same rho as Ceres' CauchyLoss / HuberLoss / SoftLOneLoss with
                            f_scale = a) on the RobustCurveFitting samples and on a tiny
@@ -163,8 +169,75 @@ def make_robust_optima():
         json.dump({"source": "scipy.optimize.least_squares (robust losses)", **out}, f, indent=1)
 
 
+def make_lm_step():
+    """One LM step as Ceres 1.x defines it (constants: initial radius 1e4, LM diagonal
+    clamp [1e-6, 1e32], Jacobi scaling 1 / (1 + |J_j|)) on bal.generate(16, 60, 300, seed=8)."""
+    mp.mp.dps = 40
+    C, P, N, seed = 16, 60, 300, 8
+    prob = bal.generate(C, P, N, seed=seed)
+    syms, res, J = snavely_symbolic()
+    f_res = sym.lambdify(syms, res, "mpmath")
+    f_jac = sym.lambdify(syms, J, "mpmath")
+    n = 9 * C + 3 * P
+
+    def evaluate(x, want_jac):
+        r = np.zeros(2 * N, dtype=np.longdouble)
+        Jd = np.zeros((2 * N, n), dtype=np.longdouble) if want_jac else None
+        cost = mp.mpf(0)
+        for o in range(N):
+            c, q = int(prob.camera_index[o]), int(prob.point_index[o])
+            args = [mp.mpf(float(v)) for v in list(x[9 * c:9 * c + 9]) + list(x[9 * C + 3 * q:9 * C + 3 * q + 3]) + list(prob.observations[o])]
+            rv = f_res(*args)
+            cost += rv[0] * rv[0] + rv[1] * rv[1]
+            r[2 * o], r[2 * o + 1] = np.longdouble(str(rv[0])), np.longdouble(str(rv[1]))
+            if want_jac:
+                Jm = f_jac(*args)
+                for i in range(2):
+                    for j in range(9):
+                        Jd[2 * o + i, 9 * c + j] = np.longdouble(str(Jm[i, j]))
+                    for j in range(3):
+                        Jd[2 * o + i, 9 * C + 3 * q + j] = np.longdouble(str(Jm[i, 9 + j]))
+        return float(cost / 2), r, Jd
+
+    x0 = prob.parameters.astype(np.float64)
+    cost0, r, Jd = evaluate(x0, True)
+    g = Jd.T @ r
+    scale = 1.0 / (1.0 + np.sqrt(np.sum(Jd * Jd, axis=0)))
+    Js = Jd * scale
+    diag = np.sum(Js * Js, axis=0)
+    radius = np.longdouble(1e4)
+    D2 = np.minimum(np.maximum(diag, np.longdouble(1e-6)), np.longdouble(1e32)) / radius
+    A = Js.T @ Js + np.diag(D2)
+    b = Js.T @ r
+    A64 = A.astype(np.float64)
+    y = np.linalg.solve(A64, b.astype(np.float64)).astype(np.longdouble)
+    for _ in range(6):  # iterative refinement against the extended-precision system
+        y = y + np.linalg.solve(A64, (b - A @ y).astype(np.float64)).astype(np.longdouble)
+    step_scaled = -y
+    mr = Js @ step_scaled
+    mcc = float(-np.dot(mr, r + mr / 2))
+    delta = (step_scaled * scale).astype(np.float64)
+    x1 = x0 + delta
+    cost1, _, _ = evaluate(x1, False)
+    rho = (cost0 - cost1) / mcc
+    out = {"source": "sympy closed form + mpmath 40 digits; numpy extended precision + iterative refinement",
+           "shape": [C, P, N], "seed": seed, "camera_index": prob.camera_index.tolist(), "point_index": prob.point_index.tolist(),
+           "observations": prob.observations.tolist(), "x0": x0.tolist(),
+           "initial_cost": cost0, "gradient_max_norm": float(np.max(np.abs(g))), "initial_radius": 1e4,
+           "delta": delta.tolist(), "step_norm": float(np.sqrt(np.sum((x1 - x0) ** 2))), "model_cost_change": mcc,
+           "candidate_cost": cost1, "relative_decrease": rho,
+           "radius_after": float(1e4 / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)),
+           "refinement_residual": float(np.max(np.abs(b - A @ y)) / np.max(np.abs(b)))}
+    with open(os.path.join(HERE, "lm_step.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "lm_step":
+        make_lm_step()
+        sys.exit(0)
     make_snavely()
     make_optima()
     make_robust_optima()
+    make_lm_step()
     print("golden fixtures written to", HERE)

@@ -219,3 +219,24 @@ def test_generator_shapes_are_exact_and_visible():
         assert np.unique(key).size == N
         _, depth = bal.snavely_project(prob.cameras()[prob.camera_index], prob.points()[prob.point_index])
         assert (depth < 0).all()  # in front of the camera (Snavely sign convention)
+
+
+def test_header_is_valid_c99_and_the_signatures_link(tmp_path):
+    """tests/abi_smoke.c: include/skeres_amd.h compiled as C99 (-pedantic -Werror) and linked against libskeres_amd.so;
+    memory helpers, Problem bookkeeping, option validation, and sk_solve -> SK_ERR_NO_DEVICE without a GPU (with one,
+    the tiny problem is solved).  What a JNI shim generated from the header would bind (ceres.i:95-125)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "skeres_amd")
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_smoke.c"), "-o", exe, "-L" + libdir, "-lskeres_amd",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath-link," + rocm_lib])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = rocm_lib + ":" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_smoke ok" in out.stdout

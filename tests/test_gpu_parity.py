@@ -491,6 +491,67 @@ def test_envelope_factorisation_is_bit_identical_to_the_full_one():
         assert [a["step_norm"] for a in s_env.iterations()] == [b["step_norm"] for b in s_full.iterations()]
 
 
+def test_default_plan_matches_explicit_grouping_at_full_size():
+    """The plan the bench times — automatic grouping, resident panel chain (potrf_server_kernel / chain_column_kernel) —
+    against the same factorisation with an explicit SYRK depth, launch by launch, no resident kernel, on Ladybug-1723
+    at full size: two LM iterations, every logged figure and the parameters.  The two differ in how the trailing
+    updates are grouped (different rounding), not in the algorithm: 1e-10."""
+    prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1))
+
+    def run(group):
+        problem, params, loss = bal_problem_to_sk(prob)
+        options = sk.Solver.Options()
+        options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+        options.setMaxNumIterations(2)
+        if group:
+            options.setCholeskyTuning(group, True)
+        solver = sk.StepSolver(options, problem)
+        resident = solver.stat("cholesky_columns_resident")
+        while not solver.step():
+            pass
+        summary = sk.Solver.Summary()
+        solver.finish(summary)
+        return params.toArray(prob.num_parameters), summary, resident
+    x_auto, s_auto, resident = run(0)
+    x_g, s_g, resident_g = run(2)
+    assert resident >= 60 and resident_g == 0  # the automatic plan really ran the resident chain; the explicit one did not
+    a, b = s_auto.iterations(), s_g.iterations()
+    assert len(a) == len(b) == 3
+    for u, v in zip(a, b):
+        for k in ("cost", "step_norm", "relative_decrease", "trust_region_radius", "gradient_max_norm"):
+            assert abs(u[k] - v[k]) <= 1e-10 * max(abs(v[k]), 1e-300), (k, u[k], v[k])
+    assert np.linalg.norm(x_auto - x_g) <= 1e-10 * np.linalg.norm(x_g - prob.parameters)
+    # ... and the explicit grouping is what the oracle-compared small problems run too: same check at a size the oracle solves
+    small = bal.generate(150, 3000, 14000, seed=5)
+    x_cpu, so = oracle.solve_bal(150, 3000, small.camera_index, small.point_index, small.observations, small.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=4, max_num_iterations=2))
+    for kw in ({}, {"setCholeskyTuning": 2}):
+        x_gpu, sg = solve_bal_gpu(small, setMaxNumIterations=2, **kw)
+        assert np.linalg.norm(x_gpu - x_cpu) <= 1e-9 * np.linalg.norm(x_cpu - small.parameters)
+
+
+def test_one_lm_step_vs_the_independent_fixture():
+    """tests/golden/lm_step.json: one Levenberg-Marquardt step of a 16-camera problem computed with none of the oracle's
+    or the product's code (SymPy closed-form Jacobians at 40 digits, extended-precision normal equations, NumPy solve
+    with iterative refinement; tests/golden/make_golden.py).  DENSE_SCHUR on the device must take that very step."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lm_step.json")))
+    C, P, N = g["shape"]
+    prob = bal.BalProblem(C, P, np.array(g["camera_index"], dtype=np.int32), np.array(g["point_index"], dtype=np.int32),
+                          np.array(g["observations"]), np.array(g["x0"]))
+    x, summary = solve_bal_gpu(prob, setMaxNumIterations=1)
+    its = summary.iterations()
+    assert abs(its[0]["cost"] - g["initial_cost"]) <= 1e-13 * g["initial_cost"]
+    assert abs(its[0]["gradient_max_norm"] - g["gradient_max_norm"]) <= 1e-12 * g["gradient_max_norm"]
+    assert abs(its[1]["cost"] - g["candidate_cost"]) <= 1e-10 * g["candidate_cost"]
+    assert abs(its[1]["step_norm"] - g["step_norm"]) <= 1e-9 * g["step_norm"]
+    assert abs(its[1]["relative_decrease"] - g["relative_decrease"]) <= 1e-12
+    assert abs(its[1]["trust_region_radius"] - g["radius_after"]) <= 1e-9 * g["radius_after"]
+    d, e = x - prob.parameters, np.array(g["delta"])
+    assert np.linalg.norm(d - e) <= 1e-8 * np.linalg.norm(e)
+
+
 def test_camera_order_follows_the_band_even_when_the_blocks_are_added_in_scrambled_order():
     # residual blocks added in random order (first-appearance order of the cameras is then random): the solver still
     # finds the banded order (memory order of the camera blocks / RCM) and the result matches the oracle

@@ -46,7 +46,7 @@ def main():
         s.step()
     dt = (time.time() - t0) / args.iters
     sec, launches = s.kernelSeconds("syrk_gram")
-    flops = s.syrkFlopsPerSolve()
+    flops = s.stat("jtj_flops_algorithmic")  # m n (n + 1), SURVEY.md section 8(d) — not the padded tiles (syrkFlopsPerSolve)
     summ = sk.Solver.Summary()
     s.finish(summ)
     out = {"config": "synthetic dense NLLS m=%d n=%d DENSE_NORMAL_CHOLESKY" % (m, n), "seconds_per_iteration": dt,
