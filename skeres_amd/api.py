@@ -135,6 +135,7 @@ _SIGS = {
     "sk_solver_syrk_c_bytes_per_solve": (C.c_double, [C.c_void_p]),
     "sk_solver_distribution": (C.c_int, [C.c_void_p, _dp, _dp]),
     "sk_solver_stat": (C.c_int, [C.c_void_p, C.c_char_p, _dp]),
+    "sk_last_status": (C.c_int, []),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
@@ -1068,7 +1069,7 @@ class StepSolver:
         self._keep = (options, problem)
         self._h = lib().sk_solver_create(options._h, problem._h)
         if not self._h:
-            raise SkeresError(lib().sk_last_error().decode())
+            raise SkeresError("status %d: %s" % (lib().sk_last_status(), lib().sk_last_error().decode()))
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:

@@ -101,7 +101,7 @@ class BalSolver : public SolverBase {
     return false;
   }
   // the grouping is the library's choice (Options::cholesky_group == 0) and the masked streams of the resident panel chain exist
-  bool chain_ok() const { return opt_.cholesky_group == 0 && opt_.lookahead && chol_ctx_.server != nullptr; }
+  bool chain_ok() const { return opt_.cholesky_group == 0 && opt_.lookahead && cholesky_chain_enabled(&chol_ctx_); }
   int distribution(double* allreduce_s, double* saved_s) const override {
     if (allreduce_s) *allreduce_s = est_allreduce_s_;
     if (saved_s) *saved_s = est_saved_s_;
@@ -112,6 +112,7 @@ class BalSolver : public SolverBase {
   int setup() override;
   int evaluate_with_jacobian(bool first) override;
   int try_step(double radius, bool* valid, double* mcc, double* new_cost, double* step_norm) override;
+  int try_step_once(double radius, bool* valid, double* mcc, double* new_cost, double* step_norm, bool* chain_lost);
   void accept_candidate() override { std::swap(d_.xc, d_.xc_new); std::swap(d_.xp, d_.xp_new); }
   int write_back() override;
   void describe(Summary* s) override {
@@ -124,6 +125,7 @@ class BalSolver : public SolverBase {
 
  private:
   int gather_rank_scalars(double* vals, int K, const int* ops);
+  int gather_rank_scalars_signed(double* vals, int K);
 
   int C_ = 0, P_total_ = 0, P_ = 0, N_ = 0;   // cameras, all points, local points, local observations
   int n_ = 0, npad_ = 0, rhs_row_ = 0;
@@ -136,6 +138,7 @@ class BalSolver : public SolverBase {
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
+  double order_hash_ = 0.0;    // of the camera order and the envelope: equal on every rank, or setup() fails
   int camera_order_ = 0;       // which candidate order of the cameras was kept (0 first appearance, 1 memory, 2 RCM)
   int group_ = 3;              // SYRK depth actually used (Options::cholesky_group, or chosen from the envelope)
   DevBuf<double> b_w_, b_pack_;
@@ -273,9 +276,15 @@ int BalSolver::setup() {
     const int nblk = npad_ / 128;
     std::vector<std::vector<int>> cand;
     { std::vector<int> id(C_); std::iota(id.begin(), id.end(), 0); cand.push_back(id); }  // first appearance
-    { std::vector<int> by_addr(C_); std::iota(by_addr.begin(), by_addr.end(), 0);
+    // (memory order: host addresses are this process's own — with separately allocated camera blocks the order could
+    // differ from rank to rank, and the ranks must build the same reduced system: one process only)
+    if (!opt_.allreduce) {
+      std::vector<int> by_addr(C_); std::iota(by_addr.begin(), by_addr.end(), 0);
       std::sort(by_addr.begin(), by_addr.end(), [&](int a, int b) { return p.block_ptr[cam_block_[a]] < p.block_ptr[cam_block_[b]]; });
-      std::vector<int> id(C_); for (int k = 0; k < C_; ++k) id[by_addr[k]] = k; cand.push_back(id); }
+      std::vector<int> id(C_); for (int k = 0; k < C_; ++k) id[by_addr[k]] = k; cand.push_back(id);
+    } else {
+      cand.push_back(cand[0]);  // keeps the candidate numbering of sk_solver_stat("camera_order")
+    }
     cand.push_back(rcm_order(ocam, opt, C_, P_total_));
     double best = -1.0; int best_k = 0; std::vector<int> best_env;
     for (size_t k = 0; k < cand.size(); ++k) {
@@ -285,6 +294,12 @@ int BalSolver::setup() {
     }
     const std::vector<int>& id = cand[best_k];
     camera_order_ = best_k;
+    {  // what every rank must agree on: the order and the envelope (checked below, once the exchange buffers exist)
+      unsigned long long h = 1469598103934665603ull;
+      for (int v : id) { h ^= (unsigned)v; h *= 1099511628211ull; }
+      for (int v : best_env) { h ^= (unsigned)v; h *= 1099511628211ull; }
+      order_hash_ = (double)(h >> 12);  // 52 bits: exact in a double
+    }
     std::vector<int> cb(C_);
     for (int c = 0; c < C_; ++c) cb[id[c]] = cam_block_[c];
     cam_block_.swap(cb);
@@ -435,6 +450,38 @@ int BalSolver::setup() {
   d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0];
   if (d_.loss_root >= 0) { SK_HIP_TRY(b_loss_nodes_.upload(p.loss_nodes, s)); d_.loss_nodes = b_loss_nodes_.p; }
   SK_HIP_TRY(hipStreamSynchronize(s));
+  if (opt_.allreduce) {
+    // every rank derived the camera order and the envelope for itself (from rank-invariant data): they must be the same
+    // reduced system, or the all-reduce would sum mismatched matrices
+    double v[2] = {order_hash_, -order_hash_};
+    const int ops[2] = {1, 1};
+    int rc = gather_rank_scalars_signed(v, 2);
+    if (rc) return rc;
+    if (v[0] != order_hash_ || v[1] != -order_hash_) {
+      set_error("the ranks derived different camera orders for the reduced system (are the residual blocks added in the same order on every rank?)");
+      return SK_ERR_COMM;
+    }
+    (void)ops;
+  }
+  return SK_OK;
+}
+
+// max over ranks of each value (values of either sign)
+int BalSolver::gather_rank_scalars_signed(double* vals, int K) {
+  const int W = opt_.world;
+  std::vector<double> table((size_t)W * K, 0.0);
+  for (int k = 0; k < K; ++k) table[(size_t)opt_.rank * K + k] = vals[k];
+  double* dev = b_small_.p + 2 * 9 * (size_t)C_ + 64;
+  SK_HIP_TRY(hipMemcpyAsync(dev, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  int rc = allreduce(dev, table.size());
+  if (rc) return rc;
+  SK_HIP_TRY(hipMemcpyAsync(table.data(), dev, table.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  SK_HIP_TRY(hipStreamSynchronize(stream_));
+  for (int k = 0; k < K; ++k) {
+    double a = table[k];
+    for (int r = 1; r < W; ++r) a = std::max(a, table[(size_t)r * K + k]);
+    vals[k] = a;
+  }
   return SK_OK;
 }
 
@@ -506,8 +553,19 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   return SK_OK;
 }
 
+// A time-out of the resident panel chain (info == 2: the device is shared, or its kernels are being serialised) loses
+// that factorisation, not the step: the chain is switched off for the device and the same linear system is assembled
+// and factored again, launch by launch, in the same iteration — the trajectory does not change.
 int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cost, double* step_norm) {
+  bool chain_lost = false;
+  int rc = try_step_once(radius, valid, mcc, new_cost, step_norm, &chain_lost);
+  if (rc == SK_OK && chain_lost) rc = try_step_once(radius, valid, mcc, new_cost, step_norm, &chain_lost);
+  return rc;
+}
+
+int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* new_cost, double* step_norm, bool* chain_lost) {
   hipStream_t s = stream_;
+  *chain_lost = false;
   const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_;
   *valid = false;
   SK_HIP_TRY(hipEventRecord(ev_[kEvBegin], s));
@@ -555,7 +613,7 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
   if (hipEventElapsedTime(&ms, ev_[kEvBacksub], ev_[kEvCost]) == hipSuccess) phase_[4] += 1e-3 * ms;
   int fail = 0, info = 0;
   std::memcpy(&fail, h_scal_ + 16, sizeof(int)); std::memcpy(&info, h_scal_ + 17, sizeof(int));
-  cholesky_note_info(info);  // (a time-out of the resident panel chain: this step is invalid, the next ones are factored launch by launch)
+  if (cholesky_note_info(&chol_ctx_, info) && !opt_.allreduce) { *chain_lost = true; return SK_OK; }  // factor again, launch by launch
   double loc[4] = {h_scal_[0], h_scal_[1], h_scal_[9], (double)(fail | info)};  // sum r_new^2, model term, |delta_p|^2, failure
   const int ops4[4] = {0, 0, 0, 1};
   int rc = gather_rank_scalars(loc, 4, ops4);

@@ -548,17 +548,19 @@ static std::unique_ptr<SolverBase> make_solver(const Options& o, Problem* p, int
 
 sk_solver* sk_solver_create(const sk_options* options, sk_problem* problem) {
   SK_GUARD_BEGIN
-  if (!options || !problem) { set_error("null argument"); return nullptr; }
+  set_status(SK_OK);
+  if (!options || !problem) { set_error("null argument"); set_status(SK_ERR_INVALID_ARGUMENT); return nullptr; }
   int rc;
   std::unique_ptr<SolverBase> impl = make_solver(options->o, &problem->p, &rc);
-  if (!impl) return nullptr;
+  if (!impl) { set_status(rc ? rc : SK_ERR_INVALID_ARGUMENT); return nullptr; }
   rc = impl->create();
-  if (rc) return nullptr;
+  if (rc) { set_status(rc); return nullptr; }
   sk_solver* s = new sk_solver();
   s->impl = std::move(impl);
   return s;
   SK_GUARD_END(nullptr)
 }
+int sk_last_status(void) { return get_status(); }
 void sk_solver_free(sk_solver* s) { delete s; }
 int sk_solver_step(sk_solver* s, int* done) {
   SK_GUARD_BEGIN
@@ -600,14 +602,7 @@ int sk_solver_stat(const sk_solver* s, const char* name, double* value) {
 int sk_solve(const sk_options* options, sk_problem* problem, sk_summary* summary) {
   SK_GUARD_BEGIN
   sk_solver* s = sk_solver_create(options, problem);
-  if (!s) {
-    // map the recorded reason to a status
-    const std::string e = get_error();
-    if (e.find("no HIP device") != std::string::npos) return SK_ERR_NO_DEVICE;
-    if (e.find("not implemented") != std::string::npos || e.find("implemented for") != std::string::npos || e.find("not supported") != std::string::npos) return SK_ERR_UNSUPPORTED;
-    if (e.find("failed:") != std::string::npos) return SK_ERR_HIP;
-    return SK_ERR_INVALID_ARGUMENT;
-  }
+  if (!s) return get_status() != SK_OK ? get_status() : SK_ERR_INVALID_ARGUMENT;  // the status sk_solver_create recorded (sk_last_status)
   int rc = SK_OK, done = 0;
   while (!done) { rc = sk_solver_step(s, &done); if (rc) break; }
   if (rc == SK_OK) rc = sk_solver_finish(s, summary);

@@ -20,7 +20,9 @@
 #include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
+#include <memory>
 #include "chol_kernels.hpp"
+#include "device_table.hpp"
 
 namespace sk {
 
@@ -889,7 +891,7 @@ __device__ __forceinline__ long crit_tile_off(long ldc, int i) {
 // Xs: 128 x 128 scratch.  X(j+1,j) cannot be formed in place tile by tile (every column tile reads whole rows of
 // S(j+1,j)): the tiles go to Xs, which next(j) reads, and into S(j+1,j) once all 16 are known to have loaded theirs.
 __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld, int j, const double* Linv_j, int tiles_m, int main_t, int jump_t,
-                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need) {
+                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int* info) {
   __shared__ __attribute__((aligned(16))) double sh[2 * 32 * kCritLd];
   static_assert(2 * 32 * kCritLd >= gemm_lds_doubles(16, 32, 128), "LDS of the thin tiles");
   __shared__ int ok_s;
@@ -904,9 +906,12 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
   const int thin_bid = ncrit ? thin_id : b;
   const bool stamp = b == 0;
   if (stamp) SK_CHAIN_STAMP(j, 2)
+  // A wait that gave up (its own time-out, or the abort flag another wait raised): this column was NOT computed.  The
+  // host must hear of it from whichever kernel noticed — the server may have nothing left to wait for (the last
+  // column of a resident run hands back to launch-by-launch kernels, which would factor stale data): *info = 2.
   if (threadIdx.x == 0) ok_s = chain_wait(sync + kSyncPotrfDone, j + 1, sync + kSyncAbort) ? 1 : 0;
   __syncthreads();
-  if (!ok_s) return;
+  if (!ok_s) { if (threadIdx.x == 0) *info = 2; return; }
   SK_CHAIN_ACQUIRE_ALL
   if (stamp) SK_CHAIN_STAMP(j, 3)
   // ---- X(r,j) = S(r,j) W_jj^T
@@ -927,7 +932,7 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
   if (threadIdx.x == 0)
     ok_s = (chain_wait(x_ready, ncrit, sync + kSyncAbort) && chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort)) ? 1 : 0;
   __syncthreads();
-  if (!ok_s) return;
+  if (!ok_s) { if (threadIdx.x == 0) *info = 2; return; }
   SK_CHAIN_ACQUIRE_ALL
   if (stamp) SK_CHAIN_STAMP(j, 5)
   // ---- next(j): S(r,j+1) -= X(r,j) X(j+1,j)^T
@@ -1032,10 +1037,11 @@ __global__ void copy_row_kernel(const double* __restrict__ src, double* __restri
 static const size_t g_potrf_lds = (size_t)(18 * kBlk + 192 + 4) * sizeof(double);
 size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
+static std::vector<hipStream_t> g_orphan_streams;  // streams of a device whose queue set could not be completed: kept, never destroyed
 static int g_thin_grid = 512;  // panel launches of at most this many 32-row workgroups use the 32 x 128 kernels (developer knob SK_THIN_GRID)
 static int g_ext_events = 1;  // events on the producing kernel's own dispatch (developer knob SK_LA_EXT_EVENTS=0: separate records)
 static unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;  // developer knob SK_LA_SYSTEM_FENCE=1: default fences
-static int g_chain_server = 1;  // developer knob SK_CHOL_CHAIN_SERVER=0: the launch-per-step panel chain even where the resident one applies
+static int g_chain_server = 1;  // developer knob SK_CHOL_CHAIN_SERVER=0: the launch-per-step panel chain even where the resident one applies (initial value of every device's DeviceQueues::chain_server)
 static int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see cholesky_plan (developer knobs SK_CHAIN_MAX_TRAILING, SK_CHAIN_PREFIX_GROUP)
 static int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK (developer knob SK_THIN_SYRK)
 static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
@@ -1073,11 +1079,36 @@ int* CholeskyContext::sync_for(int nblk) {
   return sync;
 }
 
-// The two streams are created once per process and shared by every context (one process drives one
-// GPU): creating a second CU-masked stream after destroying the first one hangs on this ROCm build.
-static hipStream_t g_panel_stream = nullptr, g_bulk_stream = nullptr, g_bulk_early_stream = nullptr, g_server_stream = nullptr;
-static int g_reserved_cus = 0, g_early_tiles = 0;
-
+// The queues of the look-ahead factorisation exist once per DEVICE (device_table.hpp) and are shared by every
+// context on that device; they live until process exit (creating a second CU-masked stream after destroying the
+// first one hangs on this ROCm build — see DESIGN.md section 4 for what is known about that).  A process may drive
+// several devices, one solver handle each: a context's queues are those of the device that was current when it was
+// initialised, created under that device.
+//
+// The queues of the panel stream and of the resident potrf workgroup are chosen by measurement.  With some
+// assignments of the process's queues to the command processor's pipes every launch on the panel and bulk streams
+// takes 30-50 us longer for as long as the server is resident — the whole factorisation twice as long.  Which
+// assignment a process gets follows from the order in which it (this library, PyTorch, RCCL) created its queues: one
+// more queue created first flips it (measured: 10.4 / 16.0 / 10.4 / 16.1 ms per iteration with 0 / 1 / 2 / 3 extra
+// queues; over the runs, fast exactly when the panel queue had one parity of creation index and the server queue
+// the other).  Probes with a spinning kernel and event-ordered empty launches do not show the effect, so two
+// queues are created for the bulk streams and three each for the panel stream and the server, and the first
+// factorisation with a resident chain first runs a small synthetic one (identity matrix, banded envelope, 1 ms) with
+// each of the 18 combinations and keeps the fastest (tune_chain_queues: 0.1 s, once per device; developer knob
+// SK_CHAIN_QUEUES=<n> fixes the combination).
+constexpr int kBulkCand = 2, kPanelCand = 3, kServerCand = 3;
+struct DeviceQueues {
+  int device = -1;
+  hipStream_t panel = nullptr, bulk = nullptr, bulk_early = nullptr, server = nullptr;  // the combination in use
+  int reserved_cus = 0, early_tiles = 0;
+  hipStream_t bulk_candidates[kBulkCand] = {}, bulk_early_candidates[kBulkCand] = {}, panel_candidates[kPanelCand] = {},
+              server_candidates[kServerCand] = {};
+  std::vector<hipStream_t> all_streams;  // destroyed at exit
+  int queue_choice = -1;  // -1: not measured yet; else (bulk * kPanelCand + panel) * kServerCand + server
+  bool tuning = false;
+  int chain_server = 1;   // 0: block columns are factored launch by launch on this device (knob, or a time-out happened)
+};
+static PerDeviceTable<DeviceQueues> g_device_queues;
 
 // stream whose kernels stay off the first `per_xcd` CUs of every XCD (plain stream when per_xcd == 0 or masks are unavailable)
 static hipError_t create_bulk_stream(hipStream_t* out, int per_xcd, int ncu, int* reserved) {
@@ -1092,104 +1123,115 @@ static hipError_t create_bulk_stream(hipStream_t* out, int per_xcd, int ncu, int
   return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
 
-// The queues of the panel stream and of the resident potrf workgroup are chosen by measurement.  With some
-// assignments of the process's queues to the command processor's pipes every launch on the panel and bulk streams
-// takes 30-50 us longer for as long as the server is resident — the whole factorisation twice as long.  Which
-// assignment a process gets follows from the order in which it (this library, PyTorch, RCCL) created its queues: one
-// more queue created first flips it (measured: 10.4 / 16.0 / 10.4 / 16.1 ms per iteration with 0 / 1 / 2 / 3 extra
-// queues; over the runs, fast exactly when the panel queue had one parity of creation index and the server queue
-// the other).  Probes with a spinning kernel and event-ordered empty launches do not show the effect, so two
-// queues are created for the bulk streams and three each for the panel stream and the server, and the first
-// factorisation with a resident chain first runs a small synthetic one (identity matrix, banded envelope, 1 ms) with
-// each of the 18 combinations and keeps the fastest (tune_chain_queues: 0.1 s, once per process; developer knob
-// SK_CHAIN_QUEUES=<n> fixes the combination).
-constexpr int kBulkCand = 2, kPanelCand = 3, kServerCand = 3;
-static hipStream_t g_bulk_candidates[kBulkCand] = {}, g_bulk_early_candidates[kBulkCand] = {}, g_panel_candidates[kPanelCand] = {},
-                   g_server_candidates[kServerCand] = {};
-static std::vector<hipStream_t> g_all_streams;  // destroyed at exit
-static int g_queue_choice = -1;  // -1: not measured yet; else (bulk * kPanelCand + panel) * kServerCand + server
-static bool g_tuning = false;
+// Creates the queues of device `dev`, which the caller has made current.  nullptr: the streams could not be created.
+static DeviceQueues* create_device_queues(int dev) {
+  std::unique_ptr<DeviceQueues> q(new DeviceQueues());
+  q->device = dev;
+  q->chain_server = g_chain_server;
+  int ncu = 0, reserved = 0, reserved_early = 0;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  // CUs per XCD kept free of the SYRK; developer knobs (0 = no mask)
+  int per_xcd = 4, per_xcd_early = 2, early_tiles = 72;
+  if (const char* e = getenv("SK_LA_RESERVED_PER_XCD")) per_xcd = atoi(e);
+  if (const char* e = getenv("SK_LA_RESERVED_EARLY")) per_xcd_early = atoi(e);
+  if (const char* e = getenv("SK_LA_EARLY_TILES")) early_tiles = atoi(e);
+  if (const char* e = getenv("SK_QUEUE_SHIFT")) {  // developer knob: extra queues first, as another library in the process would create them
+    std::vector<uint32_t> all((size_t)(ncu + 31) / 32, 0xffffffffu);
+    for (int k = 0; k < atoi(e); ++k) {
+      hipStream_t d = nullptr;
+      if (hipExtStreamCreateWithCUMask(&d, (uint32_t)all.size(), all.data()) != hipSuccess) (void)hipGetLastError();
+      else q->all_streams.push_back(d);
+    }
+  }
+  auto fail = [&]() -> DeviceQueues* {
+    // (streams that were created stay allocated until exit, like every other: see above)
+    for (hipStream_t st : q->all_streams) g_orphan_streams.push_back(st);
+    return nullptr;
+  };
+  hipStream_t b = nullptr, be = nullptr;
+  if (create_bulk_stream(&b, per_xcd, ncu, &reserved) != hipSuccess) { (void)hipGetLastError(); return fail(); }
+  q->all_streams.push_back(b);
+  if (create_bulk_stream(&be, per_xcd_early, ncu, &reserved_early) != hipSuccess) { (void)hipGetLastError(); return fail(); }
+  q->all_streams.push_back(be);
+  q->bulk_candidates[0] = b; q->bulk_early_candidates[0] = be;
+  // The resident potrf workgroup gets a CU to itself — CU 0 of whichever XCD its launch lands on: the bulk masks
+  // exclude the first CUs of every XCD, the panel mask below CU 0 of every XCD (mask bit i <-> XCD i % 8, CU i / 8; an
+  // XCD without any bit would be unrestricted, so a mask cannot choose the XCD) — and a hardware queue to itself: a
+  // CU-masked stream owns its queue, a plain one is mapped onto a small shared pool and could end up behind a stream
+  // it waits for.  The workgroups that wait for the server can then never occupy the CU it needs (150 KB of LDS).
+  hipStream_t p = nullptr, sv = nullptr;
+  if (reserved > 0) {
+    const size_t words = (size_t)(ncu + 31) / 32;
+    std::vector<uint32_t> cu0(words, 0u), rest(words, 0u);
+    cu0[0] = 0xffu;
+    for (int i = 8; i < ncu; ++i) rest[(size_t)i / 32] |= 1u << (i % 32);
+    bool ok = true;
+    auto masked = [&](hipStream_t* out, const std::vector<uint32_t>& m) {
+      if (!ok) return;
+      if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, m.data()) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; ok = false; return; }
+      q->all_streams.push_back(*out);
+    };
+    for (int k = 1; k < kBulkCand && ok; ++k) {
+      int r = 0;
+      if (create_bulk_stream(&q->bulk_candidates[k], per_xcd, ncu, &r) != hipSuccess || create_bulk_stream(&q->bulk_early_candidates[k], per_xcd_early, ncu, &r) != hipSuccess) {
+        (void)hipGetLastError();
+        ok = false;
+      }
+      if (q->bulk_candidates[k]) q->all_streams.push_back(q->bulk_candidates[k]);
+      if (q->bulk_early_candidates[k]) q->all_streams.push_back(q->bulk_early_candidates[k]);
+    }
+    for (int k = 0; k < kPanelCand; ++k) masked(&q->panel_candidates[k], rest);
+    for (int k = 0; k < kServerCand; ++k) masked(&q->server_candidates[k], cu0);
+    p = q->panel_candidates[0];
+    sv = p ? q->server_candidates[0] : nullptr;
+    if (!ok) q->queue_choice = 0;  // no choice to make
+    if (const char* e = getenv("SK_CHAIN_QUEUES")) q->queue_choice = atoi(e) % (kBulkCand * kPanelCand * kServerCand);
+    if (ok && q->queue_choice >= 0) {
+      b = q->bulk_candidates[q->queue_choice / (kPanelCand * kServerCand)];
+      be = q->bulk_early_candidates[q->queue_choice / (kPanelCand * kServerCand)];
+      p = q->panel_candidates[q->queue_choice / kServerCand % kPanelCand];
+      sv = q->server_candidates[q->queue_choice % kServerCand];
+    }
+  }
+  if (!p) {
+    if (hipStreamCreateWithFlags(&p, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return fail(); }
+    q->all_streams.push_back(p);
+  }
+  q->server = sv; q->panel = p; q->bulk = b; q->bulk_early = be; q->reserved_cus = reserved; q->early_tiles = early_tiles;
+  // destroyed once, at process exit, before the HIP runtime's own teardown (handlers run in reverse order of registration)
+  static bool registered = false;
+  if (!registered) {
+    registered = true;
+    atexit([] {
+      int cur = 0;
+      (void)hipGetDevice(&cur);
+      g_device_queues.for_each([](int dev, DeviceQueues& dq) {
+        (void)hipSetDevice(dev);
+        for (hipStream_t st : dq.all_streams) (void)hipStreamDestroy(st);
+        dq.all_streams.clear();
+        dq.panel = dq.bulk = dq.bulk_early = dq.server = nullptr;
+      });
+      (void)hipSetDevice(cur);
+    });
+  }
+  return q.release();
+}
+
+void CholeskyContext::use(DeviceQueues* q) {
+  dq = q;
+  panel = q->panel; bulk = q->bulk; bulk_early = q->bulk_early; server = q->server;
+  reserved_cus = q->reserved_cus; early_tiles = q->early_tiles;
+}
 
 hipError_t CholeskyContext::init() {
   if (panel) return hipSuccess;
-  if (!g_panel_stream) {
-    int dev = 0, ncu = 0, reserved = 0, reserved_early = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    // CUs per XCD kept free of the SYRK; developer knobs (0 = no mask)
-    int per_xcd = 4, per_xcd_early = 2, early_tiles = 72;
-    if (const char* e = getenv("SK_LA_RESERVED_PER_XCD")) per_xcd = atoi(e);
-    if (const char* e = getenv("SK_LA_RESERVED_EARLY")) per_xcd_early = atoi(e);
-    if (const char* e = getenv("SK_LA_EARLY_TILES")) early_tiles = atoi(e);
-    if (const char* e = getenv("SK_QUEUE_SHIFT")) {  // developer knob: extra queues first, as another library in the process would create them
-      std::vector<uint32_t> all((size_t)(ncu + 31) / 32, 0xffffffffu);
-      for (int k = 0; k < atoi(e); ++k) { hipStream_t d = nullptr; if (hipExtStreamCreateWithCUMask(&d, (uint32_t)all.size(), all.data()) != hipSuccess) (void)hipGetLastError(); }
-    }
-    hipStream_t b = nullptr, be = nullptr;
-    hipError_t rc = create_bulk_stream(&b, per_xcd, ncu, &reserved);
-    if (rc == hipSuccess) rc = create_bulk_stream(&be, per_xcd_early, ncu, &reserved_early);
-    if (rc != hipSuccess) {
-      if (b) (void)hipStreamDestroy(b);
-      return rc;
-    }
-    g_all_streams.push_back(b); g_all_streams.push_back(be);
-    g_bulk_candidates[0] = b; g_bulk_early_candidates[0] = be;
-    // The resident potrf workgroup gets a CU to itself — CU 0 of whichever XCD its launch lands on: the bulk masks
-    // exclude the first CUs of every XCD, the panel mask below CU 0 of every XCD (mask bit i <-> XCD i % 8, CU i / 8; an
-    // XCD without any bit would be unrestricted, so a mask cannot choose the XCD) — and a hardware queue to itself: a
-    // CU-masked stream owns its queue, a plain one is mapped onto a small shared pool and could end up behind a stream
-    // it waits for.  The workgroups that wait for the server can then never occupy the CU it needs (150 KB of LDS).
-    hipStream_t p = nullptr, sv = nullptr;
-    if (reserved > 0) {
-      const size_t words = (size_t)(ncu + 31) / 32;
-      std::vector<uint32_t> cu0(words, 0u), rest(words, 0u);
-      cu0[0] = 0xffu;
-      for (int i = 8; i < ncu; ++i) rest[(size_t)i / 32] |= 1u << (i % 32);
-      bool ok = true;
-      auto masked = [&](hipStream_t* out, const std::vector<uint32_t>& m) {
-        if (!ok) return;
-        if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, m.data()) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; ok = false; return; }
-        g_all_streams.push_back(*out);
-      };
-      // (a masked stream that was created stays allocated until exit: destroying one hangs the next creation on this ROCm build)
-      for (int k = 1; k < kBulkCand && ok; ++k) {
-        int r = 0;
-        if (create_bulk_stream(&g_bulk_candidates[k], per_xcd, ncu, &r) != hipSuccess || create_bulk_stream(&g_bulk_early_candidates[k], per_xcd_early, ncu, &r) != hipSuccess) {
-          (void)hipGetLastError();
-          ok = false;
-        }
-        if (g_bulk_candidates[k]) g_all_streams.push_back(g_bulk_candidates[k]);
-        if (g_bulk_early_candidates[k]) g_all_streams.push_back(g_bulk_early_candidates[k]);
-      }
-      for (int k = 0; k < kPanelCand; ++k) masked(&g_panel_candidates[k], rest);
-      for (int k = 0; k < kServerCand; ++k) masked(&g_server_candidates[k], cu0);
-      p = g_panel_candidates[0];
-      sv = p ? g_server_candidates[0] : nullptr;
-      if (!ok) g_queue_choice = 0;  // no choice to make
-      if (const char* e = getenv("SK_CHAIN_QUEUES")) g_queue_choice = atoi(e) % (kBulkCand * kPanelCand * kServerCand);
-      if (ok && g_queue_choice >= 0) {
-        b = g_bulk_candidates[g_queue_choice / (kPanelCand * kServerCand)];
-        be = g_bulk_early_candidates[g_queue_choice / (kPanelCand * kServerCand)];
-        p = g_panel_candidates[g_queue_choice / kServerCand % kPanelCand];
-        sv = g_server_candidates[g_queue_choice % kServerCand];
-      }
-    }
-    if (!p) {
-      rc = hipStreamCreateWithFlags(&p, hipStreamNonBlocking);
-      if (rc != hipSuccess) return rc;
-      g_all_streams.push_back(p);
-    }
-    g_server_stream = sv;
-    g_panel_stream = p; g_bulk_stream = b; g_bulk_early_stream = be; g_reserved_cus = reserved; g_early_tiles = early_tiles;
-    // destroyed once, at process exit, before the HIP runtime's own teardown (handlers run in reverse order of registration)
-    atexit([] {
-      for (hipStream_t st : g_all_streams) (void)hipStreamDestroy(st);
-      g_all_streams.clear();
-      g_bulk_stream = g_bulk_early_stream = g_panel_stream = g_server_stream = nullptr;
-    });
-  }
-  panel = g_panel_stream; bulk = g_bulk_stream; bulk_early = g_bulk_early_stream; reserved_cus = g_reserved_cus; early_tiles = g_early_tiles;
-  server = g_server_stream;
+  int dev = 0;
+  hipError_t rc = hipGetDevice(&dev);
+  if (rc != hipSuccess) return rc;
+  DeviceQueues* q = g_device_queues.get_or_create(dev, create_device_queues);
+  if (!q) return hipErrorOutOfMemory;
+  device = dev;
+  use(q);
   return hipSuccess;
 }
 
@@ -1302,11 +1344,12 @@ __global__ void set_identity_kernel(double* A, long ld, int n) {
   if (i < n) A[(long)i * ld + i] = 1.0;
 }
 
-// See g_queue_choice: a small synthetic factorisation (identity matrix — the launches do not depend on the values —, an
+// See DeviceQueues::queue_choice: a small synthetic factorisation (identity matrix — the launches do not depend on the values —, an
 // envelope four blocks high, every column under the resident chain) with each pair of candidate queues, on the
 // caller's stream: its queue is part of the assignment being measured.
 static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
-  g_queue_choice = 0;
+  DeviceQueues& q = *ctx->dq;
+  q.queue_choice = 0;
   const int nblk = 26, n = nblk * 128;
   double *A = nullptr, *Linv = nullptr;
   int* info = nullptr;
@@ -1325,14 +1368,15 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
   std::vector<int> last(nblk);
   for (int c = 0; c < nblk; ++c) last[c] = std::min(c + 4, nblk - 2);
   last[nblk - 1] = nblk - 1;
-  g_tuning = true;
+  q.tuning = true;
   const int ncomb = kBulkCand * kPanelCand * kServerCand;
   std::vector<double> ms((size_t)ncomb, 1e30);
   auto select = [&](int c) {
-    ctx->bulk = g_bulk_candidates[c / (kPanelCand * kServerCand)];
-    ctx->bulk_early = g_bulk_early_candidates[c / (kPanelCand * kServerCand)];
-    ctx->panel = g_panel_candidates[c / kServerCand % kPanelCand];
-    ctx->server = g_server_candidates[c % kServerCand];
+    q.bulk = q.bulk_candidates[c / (kPanelCand * kServerCand)];
+    q.bulk_early = q.bulk_early_candidates[c / (kPanelCand * kServerCand)];
+    q.panel = q.panel_candidates[c / kServerCand % kPanelCand];
+    q.server = q.server_candidates[c % kServerCand];
+    ctx->use(&q);
   };
   bool serialised = false;
   for (int c = 0; c < ncomb && !serialised; ++c) {
@@ -1354,14 +1398,13 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
       }
     }
   }
-  g_tuning = false;
+  q.tuning = false;
   if (serialised) {
-    g_chain_server = 0;
+    q.chain_server = 0;
     std::fprintf(stderr, "[skeres_amd] the resident panel chain timed out in its trial run (are kernels being serialised, e.g. by counter "
                          "collection?): block columns are factored launch by launch in this process\n");
     select(0);
-    g_queue_choice = 0;
-    g_bulk_stream = ctx->bulk; g_bulk_early_stream = ctx->bulk_early; g_panel_stream = ctx->panel; g_server_stream = ctx->server;
+    q.queue_choice = 0;
     (void)hipFree(A); (void)hipFree(Linv); (void)hipFree(info);
     return;
   }
@@ -1370,47 +1413,53 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
   if (best > 8.0) {
     // 26 block columns take 1.1 ms.  Several times that with every combination: the device is being time-sliced with
     // another process, and kernels that wait for each other lose whole slices: launch by launch for this process.
-    g_chain_server = 0;
+    q.chain_server = 0;
     std::fprintf(stderr, "[skeres_amd] the resident panel chain ran %.0f times slower than it should in its trial run (is the device shared with "
                          "another process?): block columns are factored launch by launch in this process\n", best / 1.1);
   }
-  for (int c = ncomb - 1; c >= 0; --c) if (ms[c] <= 1.04 * best) g_queue_choice = c;  // the first of those within noise of the best: the same choice run after run
+  for (int c = ncomb - 1; c >= 0; --c) if (ms[c] <= 1.04 * best) q.queue_choice = c;  // the first of those within noise of the best: the same choice run after run
   if (getenv("SK_DEBUG_QUEUES")) {
     std::fprintf(stderr, "[skeres_amd] synthetic factorisation (ms) per (bulk, panel, server) queue candidates:");
     for (int c = 0; c < ncomb; ++c) std::fprintf(stderr, "%s%.2f", c % kServerCand == 0 ? "  " : " ", ms[c]);
-    std::fprintf(stderr, ": combination %d\n", g_queue_choice);
+    std::fprintf(stderr, ": combination %d (device %d)\n", q.queue_choice, q.device);
   }
-  select(g_queue_choice);
-  g_bulk_stream = ctx->bulk; g_bulk_early_stream = ctx->bulk_early; g_panel_stream = ctx->panel; g_server_stream = ctx->server;
+  select(q.queue_choice);
   (void)hipFree(A);
   (void)hipFree(Linv);
   (void)hipFree(info);
 }
 
 // What a caller read back from `info` after a factorisation.  2 is the resident panel chain giving up on a wait
-// (kChainTimeoutTicks): the device is shared or its kernels are being serialised — that factorisation is lost (the
-// caller treats it as it treats a matrix that is not positive definite: an invalid step), and the process factors
-// launch by launch from here on.
-void cholesky_note_info(int info) {
-  if (info == 2 && g_chain_server) {
-    g_chain_server = 0;
-    std::fprintf(stderr, "[skeres_amd] the resident panel chain timed out (is the device shared with another process, or are kernels being "
-                         "serialised?): block columns are factored launch by launch in this process from now on\n");
+// (kChainTimeoutTicks): the device is shared or its kernels are being serialised.  That factorisation is lost; the
+// device factors launch by launch from here on, and the caller factors the same matrix again that way (BalSolver::try_step).
+// Returns true when the caller should do that.
+bool cholesky_note_info(CholeskyContext* ctx, int info) {
+  if (info != 2 || !ctx || !ctx->dq) return false;
+  std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());
+  if (ctx->dq->chain_server) {
+    ctx->dq->chain_server = 0;
+    std::fprintf(stderr, "[skeres_amd] the resident panel chain timed out on device %d (is the device shared with another process, or are "
+                         "kernels being serialised?): block columns are factored launch by launch on it from now on\n", ctx->dq->device);
   }
+  return true;
 }
+bool cholesky_chain_enabled(const CholeskyContext* ctx) { return ctx && ctx->dq && ctx->server && ctx->dq->chain_server; }
 
 // Before the first factorisation with allow_chain on stream s (cholesky_factor does it otherwise): choose the queues.
+// One trial per device, one at a time (two solvers on two threads would otherwise measure each other).
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s) {
-  if (!ctx || !ctx->server || !g_chain_server || g_tuning) return;
-  if (g_queue_choice < 0) tune_chain_queues(ctx, s);
-  ctx->panel = g_panel_stream;  // (every context of the process: the choice is the process's)
-  ctx->server = g_server_stream; ctx->bulk = g_bulk_stream; ctx->bulk_early = g_bulk_early_stream;
+  if (!ctx || !ctx->dq || !ctx->server) return;
+  std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());
+  DeviceQueues& q = *ctx->dq;
+  if (!q.chain_server || q.tuning) return;
+  if (q.queue_choice < 0) tune_chain_queues(ctx, s);
+  ctx->use(&q);  // (every context of the device: the choice is the device's)
 }
 
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
                      KernelTimer* kt, const int* last, bool allow_chain) {
   const int nblk = npad / 128;
-  if (allow_chain) cholesky_prepare(ctx, s);
+  if (allow_chain && !(ctx && ctx->dq && ctx->dq->tuning)) cholesky_prepare(ctx, s);
   const bool la = ctx != nullptr && ctx->panel != nullptr && ctx->bulk != nullptr;
   hipStream_t sp = la ? ctx->panel : s;
   hipStream_t sb = la ? ctx->bulk : s;  // of the current group (chosen below)
@@ -1499,7 +1548,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     }
   // the same groups launch by launch: while every chain kernel is being timed, and with SK_CHOL_CHAIN_SERVER=0 (PMC
   // passes serialise the kernels of a process: a resident kernel that waits for another one would time out)
-  bool chain = ranges.n > 0 && g_chain_server && !(kt && kt->times_all());
+  bool chain = ranges.n > 0 && ctx->dq && ctx->dq->chain_server && !(kt && kt->times_all());
   int* sync = chain ? ctx->sync_for(nblk) : nullptr;
   if (!sync) chain = false;  // (the same groups, launch by launch)
   auto is_resident = [&](int k) { return chain && k < nblk && plan.resident[k]; };
@@ -1541,7 +1590,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       const int ncrit = (rn.main > 0 || rn.jump == 0) ? 16 : 0;
       hipEvent_t col_done = Tb > 0 ? ctx->event(ev++) : nullptr;
       hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, col_done, 0, S, ld, k0,
-                            (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq);
+                            (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, info);
       if (col_done) (void)hipStreamWaitEvent(sb, col_done, 0);
     } else {
       // panel(g) is final: syrk(g) may start (after syrk(g-1))
@@ -1572,7 +1621,14 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
                               4 * rs.jump, rs.main, rs.jump);
       else
         hipExtLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
-      if (next_resident) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, ++seq);
+      if (next_resident) {
+        ++seq;
+        // (fault injection for tests: SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds the marker that column's launch
+        // waits for, once per process — the wait times out, and the factorisation must be reported as lost: info = 2)
+        static int withhold = getenv("SK_CHAIN_TEST_WITHHOLD_MARKER") ? atoi(getenv("SK_CHAIN_TEST_WITHHOLD_MARKER")) : -1;
+        if (withhold >= 0 && k1 == withhold && !ctx->dq->tuning) withhold = -1;
+        else hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, seq);
+      }
       if (record) syrk_done = stop_ev;
     }
     if (next_resident) {

@@ -87,7 +87,11 @@ class KernelTimer {
 // Streams + events of the look-ahead factorisation: the panel chain of the next block-column group
 // runs on `panel` while the trailing SYRK of the current group runs on `bulk`, whose CU mask leaves
 // a few CUs per XCD free so that the panel kernels are never queued behind a 6000-workgroup grid.
+struct DeviceQueues;  // chol_kernels.hip: the queues of one device, shared by its contexts, alive until process exit
 struct CholeskyContext {
+  DeviceQueues* dq = nullptr;        // the device's queue set this context uses (init(): the device current at that time)
+  int device = -1;
+  void use(DeviceQueues* q);
   hipStream_t panel = nullptr;
   hipStream_t bulk = nullptr;        // SYRK of the late groups (short SYRK, the panel chain decides: more CUs kept free)
   hipStream_t bulk_early = nullptr;  // SYRK of the early groups (long SYRK hides a slow chain: fewer CUs kept free)
@@ -113,7 +117,8 @@ size_t potrf128_lds_bytes();
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
                      KernelTimer* kt, const int* last = nullptr, bool allow_chain = false);
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
-void cholesky_note_info(int info);
+bool cholesky_note_info(CholeskyContext* ctx, int info);
+bool cholesky_chain_enabled(const CholeskyContext* ctx);
 struct CholeskyPlan {
   std::vector<int> bounds;  // group start columns + nblk
   std::vector<char> resident;  // per block column: under the resident panel chain

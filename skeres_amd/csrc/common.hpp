@@ -19,6 +19,8 @@ namespace sk {
 
 void set_error(const char* fmt, ...);
 const char* get_error();
+void set_status(int status);  // status of the last failure that could only be reported as a null handle (sk_last_status)
+int get_status();
 
 #define SK_HIP_TRY(expr)                                                                 \
   do {                                                                                   \

@@ -16,6 +16,10 @@ void set_error(const char* fmt, ...) {
   g_error = buf;
 }
 const char* get_error() { return g_error.c_str(); }
+// the status that goes with a failure reported through a null handle (sk_solver_create): typed, not parsed from the text
+static thread_local int g_status = SK_OK;
+void set_status(int status) { g_status = status; }
+int get_status() { return g_status; }
 
 const char* linear_solver_name(int t) {
   switch (t) {

@@ -28,26 +28,40 @@ class TorchAllReduce:
         self.hip.hipMemcpyAsync.restype = ctypes.c_int
 
     def __call__(self, ptr, count, stream):
+        """In-place sum of `count` doubles at device address `ptr`, ordered with the work already enqueued on the
+        solver's `stream` and before what the solver enqueues next: the collective is issued under that very stream
+        (torch.cuda.ExternalStream), whatever torch's current stream happens to be — a solver left on its private
+        stream (no options.setStream) would otherwise race with the copies and pack kernels around the collective."""
         torch, dist = self.torch, self.dist
         self.calls += 1
-        if self.base and self.base <= ptr and ptr + 8 * count <= self.base + self.nbytes:
-            off = (ptr - self.base) // 8
-            dist.all_reduce(self.big[off:off + count])
-            return
-        if self.stage is None or self.stage.numel() < count:
-            self.stage = torch.empty(max(count, 1 << 16), dtype=torch.float64, device="cuda")
-        st = self.stage[:count]
-        if self.hip.hipMemcpyAsync(st.data_ptr(), ptr, 8 * count, 3, stream) != 0:  # 3 == hipMemcpyDeviceToDevice
-            raise RuntimeError("hipMemcpyAsync D2D failed")
-        dist.all_reduce(st)
-        if self.hip.hipMemcpyAsync(ptr, st.data_ptr(), 8 * count, 3, stream) != 0:
-            raise RuntimeError("hipMemcpyAsync D2D failed")
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream else _NullContext()
+        with ctx:
+            if self.base and self.base <= ptr and ptr + 8 * count <= self.base + self.nbytes:
+                off = (ptr - self.base) // 8
+                dist.all_reduce(self.big[off:off + count])
+                return
+            if self.stage is None or self.stage.numel() < count:
+                self.stage = torch.empty(max(count, 1 << 16), dtype=torch.float64, device="cuda")
+            st = self.stage[:count]
+            if self.hip.hipMemcpyAsync(st.data_ptr(), ptr, 8 * count, 3, stream) != 0:  # 3 == hipMemcpyDeviceToDevice
+                raise RuntimeError("hipMemcpyAsync D2D failed")
+            dist.all_reduce(st)
+            if self.hip.hipMemcpyAsync(ptr, st.data_ptr(), 8 * count, 3, stream) != 0:
+                raise RuntimeError("hipMemcpyAsync D2D failed")
+
+
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def attach(options, problem, rank, world):
     """Allocate the reduce buffer with torch, register it and the hook on `options`.
-    The solver must run on torch's current stream (options.setStream).  Returns the
-    hook (keep it alive as long as the solver)."""
+    The hook issues its collectives on the stream the solver hands it, so the solver may run on any stream
+    (options.setStream or its private one).  Returns the hook (keep it alive as long as the solver)."""
     import torch
     from . import api
     nbytes = api.lib().sk_reduce_buffer_bytes(options._h, problem._h)

@@ -6,9 +6,8 @@ import numpy as np
 
 import skeres_amd as sk
 
-# (x, y) samples: the data table of the reference example (CurveFitting.scala:22-90) as a fixture
-_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden",
-                     "curve_fitting_data.txt")
+# (x, y) samples: the data table of the reference example (CurveFitting.scala:22-90) shipped with the example (the reference embeds it in the source)
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "curve_fitting_data.txt")
 
 
 def main(argv=()):

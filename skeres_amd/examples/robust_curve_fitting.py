@@ -7,9 +7,8 @@ import numpy as np
 
 import skeres_amd as sk
 
-# (x, y) samples: the data table of the reference example (RobustCurveFitting.scala:21-90) as a fixture
-_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden",
-                     "robust_curve_fitting_data.txt")
+# (x, y) samples: the data table of the reference example (RobustCurveFitting.scala:21-90) shipped with the example (the reference embeds it in the source)
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "robust_curve_fitting_data.txt")
 
 
 def main(argv=()):

@@ -240,3 +240,51 @@ def test_header_is_valid_c99_and_the_signatures_link(tmp_path):
     out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi_smoke ok" in out.stdout
+
+
+def test_per_device_queue_table_logic(tmp_path):
+    """tests/device_table_test.cpp: the table that owns the factorisation's queues per device (csrc/device_table.hpp) —
+    one entry per device, created once under concurrent requests, stable addresses, failed creations retried."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "device_table_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(ROOT, "tests", "device_table_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "device_table_test ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_failures_through_a_null_handle_carry_a_typed_status():
+    # sk_solver_create can only return NULL; the status is recorded (sk_last_status), never parsed from the message
+    prob = bal.generate(4, 20, 80, seed=1)
+    problem, params, loss = bal_problem_to_sk(prob)
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    if sk.device_count() == 0:
+        with pytest.raises(sk.SkeresError, match="status 2"):  # SK_ERR_NO_DEVICE
+            sk.StepSolver(options, problem)
+        assert sk.lib().sk_last_status() == 2
+    # a configuration that is refused before any device is touched: dense rows under DENSE_QR
+    x = sk.DoubleArray(4)
+    p2 = sk.Problem()
+    p2.addDenseRows(10, np.zeros((8, 3)), None, x, 4)
+    o2 = sk.Solver.Options()
+    o2.setLinearSolverType(sk.LinearSolverType.DENSE_QR)
+    with pytest.raises(sk.SkeresError, match="status 4"):  # SK_ERR_UNSUPPORTED
+        sk.StepSolver(o2, p2)
+    assert sk.lib().sk_last_status() == 4
+    summary = sk.Solver.Summary()
+    with pytest.raises(sk.SkeresError, match="status 4"):
+        sk.ceres.solve(o2, p2, summary)
+
+
+def test_example_data_tables_are_the_fixture_tables():
+    # the examples ship their own copy of the reference's sample tables (CurveFitting.scala:22-90,
+    # RobustCurveFitting.scala:21-90); product code does not reach into tests/
+    for name in ("curve_fitting_data.txt", "robust_curve_fitting_data.txt"):
+        a = open(os.path.join(ROOT, "tests", "golden", name)).read()
+        b = open(os.path.join(ROOT, "skeres_amd", "examples", "data", name)).read()
+        assert a == b
+    for f in ("curve_fitting.py", "robust_curve_fitting.py"):
+        assert "tests" not in open(os.path.join(ROOT, "skeres_amd", "examples", f)).read().split("_DATA")[1].split("\n")[0]

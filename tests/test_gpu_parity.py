@@ -552,6 +552,62 @@ def test_one_lm_step_vs_the_independent_fixture():
     assert np.linalg.norm(d - e) <= 1e-8 * np.linalg.norm(e)
 
 
+def test_resident_chain_timeout_is_reported_and_refactored():
+    """a wait of the resident panel chain that gives up must never go unnoticed, and must cost the
+    factorisation, not the LM step.  tests/chain_abort_worker.py withholds the marker that the last column of the first
+    resident run (block column 7 of Ladybug-1723: columns 0-7 are resident, 8-44 launch by launch) waits for: only the
+    column launch can notice.  Compared with an undisturbed run of the same worker."""
+    import json
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "chain_abort_worker.py")
+
+    def run(env_extra):
+        env = dict(os.environ)
+        env.update(env_extra)
+        out = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout + out.stderr
+        return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
+    clean, err_clean = run({})
+    hit, err_hit = run({"SK_CHAIN_TEST_WITHHOLD_MARKER": "7"})
+    assert "timed out" not in err_clean and clean["resident_after"] == clean["resident_before"] >= 60
+    assert "the resident panel chain timed out" in err_hit          # loud
+    assert hit["resident_before"] >= 60 and hit["resident_after"] == 0   # launch by launch from then on
+    assert hit["seconds"] > clean["seconds"] + 2.0                   # the 3 s time-out really happened
+    assert hit["valid"] == clean["valid"] == [1, 1, 1, 1]           # no LM step was lost ...
+    for a, b in zip(hit["costs"], clean["costs"]):                   # ... and the trajectory is the undisturbed one
+        assert abs(a - b) <= 1e-10 * abs(b)
+    for a, b in zip(hit["step_norms"], clean["step_norms"]):
+        assert abs(a - b) <= 1e-9 * max(abs(b), 1e-300)
+
+
+def test_two_solvers_share_the_queues_of_their_device():
+    """the factorisation's queues belong to the DEVICE (csrc/device_table.hpp), not to the process or
+    the solver.  Two solvers created with setDevice(0), alive at the same time and stepped alternately, give the
+    trajectories of two separate solves."""
+    probs = [bal.generate(150, 3000, 14000, seed=5), bal.generate(400, 30000, 140000, seed=77)]
+    ref = [solve_bal_gpu(p, setMaxNumIterations=4, setDevice=0) for p in probs]
+    built = []
+    for p in probs:
+        problem, params, loss = bal_problem_to_sk(p)
+        options = sk.Solver.Options()
+        options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+        options.setMaxNumIterations(4)
+        options.setDevice(0)
+        built.append((sk.StepSolver(options, problem), params, problem, loss))
+    done = [False, False]
+    while not all(done):
+        for k, (solver, _, _, _) in enumerate(built):
+            if not done[k]:
+                done[k] = solver.step()
+    for k, (solver, params, _, _) in enumerate(built):
+        summary = sk.Solver.Summary()
+        solver.finish(summary)
+        assert [it["cost"] for it in summary.iterations()] == [it["cost"] for it in ref[k][1].iterations()]
+        assert np.array_equal(params.toArray(probs[k].num_parameters), ref[k][0])
+
+
 def test_camera_order_follows_the_band_even_when_the_blocks_are_added_in_scrambled_order():
     # residual blocks added in random order (first-appearance order of the cameras is then random): the solver still
     # finds the banded order (memory order of the camera blocks / RCM) and the result matches the oracle
