@@ -412,6 +412,15 @@ int sk_synth_dense_targets(double seed, int m, int n, const double* x_star, doub
  * zero).  `group` is the SYRK depth in 128-column blocks (0 = default).
  * Returns SK_ERR_EVALUATION_FAILED when A is not positive definite. */
 int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double* L, int group);
+/* The same with what sk_solve adds for a block-banded reduced camera system.  `last` (optional): the block envelope,
+ * one entry per 128-block column of the padded matrix (ceil((n + 1) / 128) of them): last[c] >= c is the last block
+ * row in which block column c of the FACTOR can be non-zero (non-decreasing; the final block row, which carries the
+ * right-hand side, is always active) — blocks outside are neither read nor written, so A must be zero there.
+ * automatic_plan != 0: the grouping is the library's (DENSE_SCHUR's default: resident panel chain where the serial
+ * chain decides, launch-by-launch groups where the trailing SYRK does) and `group` <= 0 means 1; otherwise the
+ * explicit `group`, launch by launch.  Known-answer tests of the plans sk_solve runs at full size. */
+int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, double* L, int group, const int* last,
+                         int automatic_plan);
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,7 @@ _SIGS = {
     "sk_solver_distribution": (C.c_int, [C.c_void_p, _dp, _dp]),
     "sk_solver_stat": (C.c_int, [C.c_void_p, C.c_char_p, _dp]),
     "sk_last_status": (C.c_int, []),
+    "sk_cholesky_solve_ex": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, C.c_int]),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
@@ -1112,15 +1113,22 @@ class StepSolver:
         return {1: "sharded", 2: "replicated"}.get(mode, "sharded"), a.value, b.value
 
 
-def cholesky_solve(A, b, want_L=False, group=0):
-    """Dense SPD solve on the GPU (sk_cholesky_solve)."""
+def cholesky_solve(A, b, want_L=False, group=0, last=None, automatic_plan=False):
+    """Dense SPD solve on the GPU (sk_cholesky_solve / sk_cholesky_solve_ex): `last` = block envelope (one entry per
+    128-block column of the padded matrix), automatic_plan = the grouping DENSE_SCHUR uses by default."""
     A = np.ascontiguousarray(A, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     n = A.shape[0]
     x = np.empty(n)
     L = np.empty((n, n)) if want_L else None
-    _check(lib().sk_cholesky_solve(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp),
-                                   L.ctypes.data_as(_dp) if want_L else _dp(), int(group)))
+    lp = _ip()
+    if last is not None:
+        last = np.ascontiguousarray(last, dtype=np.int32)
+        if last.shape[0] != (n + 1 + 127) // 128:
+            raise ValueError("last needs one entry per 128-block column of the padded matrix")
+        lp = last.ctypes.data_as(_ip)
+    _check(lib().sk_cholesky_solve_ex(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp),
+                                      L.ctypes.data_as(_dp) if want_L else _dp(), int(group), lp, int(bool(automatic_plan))))
     return (x, L) if want_L else x
 
 

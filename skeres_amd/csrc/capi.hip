@@ -645,11 +645,21 @@ int sk_synth_dense_targets(double seed, int m, int n, const double* x_star, doub
 }
 
 int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double* L, int group) {
+  return sk_cholesky_solve_ex(n, A, b, x, L, group, nullptr, 0);
+}
+
+int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, double* L, int group, const int* last, int automatic_plan) {
   SK_GUARD_BEGIN
   if (n <= 0 || !A || !b || !x) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
   if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
-  if (group <= 0) group = 3;
-  const int rhs_row = n, npad = ((n + 1 + 127) / 128) * 128;
+  if (group <= 0) group = automatic_plan ? 1 : 3;
+  const int rhs_row = n, npad = ((n + 1 + 127) / 128) * 128, nblk = npad / 128;
+  if (last) {
+    for (int c = 0; c < nblk; ++c) {
+      const bool ok = last[c] >= std::min(c, nblk - 2) && last[c] <= nblk - 1 && (c == 0 || last[c] >= last[c - 1]);
+      if (!ok) { set_error("invalid block envelope at block column %d", c); return SK_ERR_INVALID_ARGUMENT; }
+    }
+  }
   std::vector<double> S((size_t)npad * npad, 0.0);
   for (int i = 0; i < n; ++i) std::memcpy(&S[(size_t)i * npad], A + (size_t)i * n, (size_t)(i + 1) * sizeof(double));
   std::memcpy(&S[(size_t)rhs_row * npad], b, (size_t)n * sizeof(double));
@@ -666,14 +676,16 @@ int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double
   if (!la) (void)hipGetLastError();
   SK_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   SK_HIP_TRY(hipDeviceSynchronize());  // uploads above ran on the null stream
-  cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr);
-  cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dw.p, dy.p, s, nullptr);
+  const bool chain = automatic_plan != 0 && la && cholesky_chain_enabled(&ctx);
+  cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr, last, chain);
+  cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dw.p, dy.p, s, nullptr, last);
   SK_HIP_TRY(hipStreamSynchronize(s));
   SK_HIP_TRY(hipStreamDestroy(s));
   s = nullptr;
   SK_HIP_TRY(hipStreamSynchronize(s));
   int info = 0;
   SK_HIP_TRY(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (info == 2) { (void)cholesky_note_info(&ctx, info); set_error("the resident panel chain timed out"); return SK_ERR_HIP; }
   if (info) { set_error("matrix is not positive definite"); return SK_ERR_EVALUATION_FAILED; }
   std::vector<double> y(npad);
   SK_HIP_TRY(hipMemcpy(y.data(), dy.p, npad * sizeof(double), hipMemcpyDeviceToHost));
