@@ -1572,15 +1572,21 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   for (int g = 0; g + 1 < ngroups; ++g) {
     const int k0 = gb[g], k1 = gb[g + 1];
     const int K = (k1 - k0) * 128;
-    const int na = gb[g + 2] - k1;  // tile columns of the next group
+    const bool resident = is_resident(k0);        // potrf(k0) by the server; TRSM and next(g) by one column launch
+    const bool next_resident = is_resident(k1);   // ... and the same for the next group
+    // tile columns that next(g) updates: those of the next group — but a resident column's launch applies its panel to
+    // block column k1 alone (chain_column_kernel), whatever the width of the group that follows: where a resident run
+    // hands back to launch-by-launch groups of two, the SYRK takes everything from k1 + 1.  (Round 1 split at the next
+    // group's width there: block column k1 + 1 never received this panel's update — a wrong factor that the
+    // full-size property tests could not see; tests/test_gpu_parity.py::test_default_plan_matches_explicit_grouping_at_full_size
+    // and test_factorisation_plans_vs_numpy now do.)
+    const int na = resident ? 1 : gb[g + 2] - k1;
     const int Lg = last_main(k1 - 1);  // rows below Lg (other than nblk-1) are zero in every column of this group
     const Rows rn = rows_from(k1, Lg);       // rows that next(g) updates
     const Rows rs = rows_from(k1 + na, Lg);  // rows (and columns) that syrk(g) updates
     double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
     const int Tb = rs.main + rs.extra;
-    const bool resident = is_resident(k0);        // potrf(k0) by the server; TRSM and next(g) by one column launch
-    const bool next_resident = is_resident(k1);   // ... and the same for the next group
     if (la) sb = Tb >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
     if (sb != sb_prev && syrk_done) (void)hipStreamWaitEvent(sb, syrk_done, 0);  // syrk(g) after syrk(g-1) across the two bulk streams
     sb_prev = sb;
@@ -1636,7 +1642,11 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       // has told it already)
       if (!resident) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sp, sync + kSyncHeader + k1, 16);
     } else {
-      panel(k1, k1 + na);  // (after a resident column: hand-back, in stream order behind its column launch)
+      // (after a resident column: hand-back, in stream order behind its column launch; the columns after k1 of a wider
+      // group take this panel's update from syrk(g), on the bulk stream)
+      const int k2 = gb[g + 2];
+      if (resident && k2 - k1 > 1 && la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
+      panel(k1, k2);
     }
   }
   order(sp, s);
@@ -1697,10 +1707,11 @@ void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, in
 // lower-triangular 128x128 tiles incl. the diagonal tiles, 2*128*128*K each).
 double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, double* c_tiles) {
   const int nblk = npad / 128;
-  const std::vector<int> gb = cholesky_plan(nblk, group, last, chain).bounds;
+  const CholeskyPlan plan = cholesky_plan(nblk, group, last, chain);
+  const std::vector<int>& gb = plan.bounds;
   double f = 0.0, tiles = 0.0;
   for (size_t g = 0; g + 2 < gb.size(); ++g) {
-    const int k0 = gb[g], k1 = gb[g + 1], na = gb[g + 2] - k1;
+    const int k0 = gb[g], k1 = gb[g + 1], na = plan.resident[k0] ? 1 : gb[g + 2] - k1;  // as cholesky_factor splits next(g) / syrk(g)
     const int Lg = last ? (last[k1 - 1] < nblk - 1 ? last[k1 - 1] : nblk - 1) : nblk - 1;
     const int first_row = k1 + na;
     const int main_rows = Lg >= first_row ? Lg - first_row + 1 : 0;

@@ -123,6 +123,67 @@ def test_cholesky_solve_vs_numpy(n, group):
     np.testing.assert_allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
 
 
+def _envelope_last(first_col):
+    nblk = len(first_col)
+    last = np.arange(nblk)
+    for i in range(nblk - 1):
+        c = min(first_col[i], i)
+        last[c] = max(last[c], i)
+    last = np.maximum.accumulate(last)
+    last[nblk - 2] = min(last[nblk - 2], nblk - 2)
+    last[nblk - 1] = nblk - 1
+    return last.astype(np.int32)
+
+
+def _banded_spd(n, last, seed):
+    rng = np.random.default_rng(seed)
+    nblk = len(last)
+    A = np.zeros((n, n))
+    for c in range(nblk):
+        c0, c1 = 128 * c, min(n, 128 * (c + 1))
+        r1 = min(n, 128 * (min(last[c], nblk - 2) + 1))
+        if c0 < n:
+            A[c0:r1, c0:c1] = rng.normal(0, 1.0, (r1 - c0, c1 - c0))
+    A = np.tril(A)
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(axis=1) + np.abs(A).sum(axis=0) + 1.0 + rng.uniform(0, 1, n)
+    return A
+
+
+# heights (active block rows below the diagonal) per block column: every regime of cholesky_plan and every hand-over
+# between them — resident run -> launch-by-launch groups of two (odd and even run lengths) -> resident run -> tail
+_PLAN_SHAPES = {
+    "band": [6] * 40,
+    "resident-then-wide-then-resident": [7] * 8 + [40 - i for i in range(30)] + [9] * 24,
+    "odd-resident-run": [5] * 7 + [36 - i for i in range(27)] + [8] * 13,
+    "two-wide-parts": [6] * 6 + [30 - i for i in range(20)] + [7] * 9 + [28 - i for i in range(19)] + [6] * 10,
+}
+
+
+@pytest.mark.parametrize("shape", sorted(_PLAN_SHAPES))
+def test_factorisation_plans_vs_numpy(shape):
+    """The plans sk_solve factors the reduced camera system with, on block-banded SPD matrices whose envelopes exercise
+    every regime of cholesky_plan and every hand-over between them: the automatic plan (resident panel chain + groups of
+    two, as timed by bench.py) and explicit groups against numpy's Cholesky factor and against each other."""
+    heights = _PLAN_SHAPES[shape]
+    nblk = len(heights) + 1
+    first_col = np.arange(nblk)
+    for c, h in enumerate(heights):
+        for r in range(c, min(nblk - 1, c + h + 1)):
+            first_col[r] = min(first_col[r], c)
+    last = _envelope_last(first_col)
+    n = 128 * nblk - 70
+    A = _banded_spd(n, last, seed=len(shape))
+    b = np.random.default_rng(3).normal(size=n)
+    Af = A + np.tril(A, -1).T
+    Lnp = np.linalg.cholesky(Af)
+    xnp = np.linalg.solve(Af, b)
+    scale = np.abs(Lnp).max()
+    for kw in ({"group": 2, "automatic_plan": False}, {"group": 1, "automatic_plan": False}, {"group": 0, "automatic_plan": True}):
+        x, L = sk.api.cholesky_solve(A, b, want_L=True, last=last, **kw)
+        assert np.abs(L - Lnp).max() <= 1e-11 * scale, (shape, kw, np.abs(L - Lnp).max())
+        assert np.linalg.norm(x - xnp) <= 1e-11 * np.linalg.norm(xnp), (shape, kw)
+
+
 def test_cholesky_mfma_layout_asymmetric():
     # A = L0 L0^T with an asymmetric integer-valued L0: a swapped row/col map in the
     # MFMA C/D layout cannot reproduce L0.
