@@ -250,8 +250,10 @@ int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const
  * SetParameterBlockConstant / SetParameterBlockVariable (inherited by CORE/Problem.scala:16 from the SWIG-wrapped
  * ceres::Problem).  `parameterization` may be NULL (none / remove).  The minimiser then works in the tangent
  * space: Jacobian columns J * dPlus/ddelta, steps applied through Plus; a constant block takes no step.
- * Implemented for DENSE_QR / DENSE_NORMAL_CHOLESKY over residual blocks; sk_solve reports SK_ERR_UNSUPPORTED for
- * DENSE_SCHUR and dense-row problems that use them. */
+ * Implemented for DENSE_QR / DENSE_NORMAL_CHOLESKY over residual blocks (every type), and under DENSE_SCHUR for what
+ * bundle adjustment uses: constant camera / point blocks, identity, and subset (e.g. fixed intrinsics on the 9-block) —
+ * a coordinate that is held constant has a zero Jacobian column and takes no step.  sk_solve reports
+ * SK_ERR_UNSUPPORTED for quaternion / homogeneous-vector blocks under DENSE_SCHUR and for dense-row problems. */
 int sk_problem_add_parameter_block(sk_problem* p, double* values, int size, const sk_local_parameterization* parameterization);
 int sk_problem_set_parameterization(sk_problem* p, double* values, const sk_local_parameterization* parameterization);
 int sk_problem_set_parameter_block_constant(sk_problem* p, double* values);

@@ -104,6 +104,8 @@ def lib():
                                     C.POINTER(Options), C.POINTER(Summary)]
         L.or_solve_bal_loss.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, C.c_int, dp,
                                         C.POINTER(Options), C.POINTER(Summary)]
+        L.or_solve_bal_masks.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, C.c_int, ip, ip, dp,
+                                         C.POINTER(Options), C.POINTER(Summary)]
         L.or_solve_param.argtypes = [C.c_int, ip, dp, C.c_int, ip, dp, ip, ip, ip, dp, ip, ip, ip, ip,
                                      C.POINTER(Options), C.POINTER(Summary)]
         L.or_parameterization_local_size.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -340,7 +342,8 @@ def _solve_loss(block_sizes, x0, residual_blocks, options=None):
     return x, s
 
 
-def solve_bal(C_, P_, cam_idx, pt_idx, obs, x0, options=None, loss=None):
+def solve_bal(C_, P_, cam_idx, pt_idx, obs, x0, options=None, loss=None, cam_mask=None, pt_mask=None):
+    """cam_mask / pt_mask: per camera / point, bit k set = coordinate k held constant (0x1ff / 0x7: a constant block)."""
     o = options or default_options(linear_solver_type=DENSE_SCHUR)
     cam = np.ascontiguousarray(cam_idx, dtype=np.int32)
     pt = np.ascontiguousarray(pt_idx, dtype=np.int32)
@@ -350,7 +353,11 @@ def solve_bal(C_, P_, cam_idx, pt_idx, obs, x0, options=None, loss=None):
     nodes = []
     root = _flatten_loss(loss, nodes)
     arr = np.asarray(nodes if nodes else [[0.0] * 5], dtype=np.float64)
-    rc = lib().or_solve_bal_loss(C_, P_, len(cam), _ip(cam), _ip(pt), _dp(ob), _dp(arr), root, _dp(x), C.byref(o), C.byref(s))
+    null = C.POINTER(C.c_int)()
+    cm = np.ascontiguousarray(cam_mask, dtype=np.int32) if cam_mask is not None else None
+    pm = np.ascontiguousarray(pt_mask, dtype=np.int32) if pt_mask is not None else None
+    rc = lib().or_solve_bal_masks(C_, P_, len(cam), _ip(cam), _ip(pt), _dp(ob), _dp(arr), root, _ip(cm) if cm is not None else null,
+                                  _ip(pm) if pm is not None else null, _dp(x), C.byref(o), C.byref(s))
     if rc != 0:
         raise RuntimeError("or_solve_bal failed: %d" % rc)
     return x, s

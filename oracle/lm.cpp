@@ -246,6 +246,14 @@ struct Bal {
   // or_options::cholesky_envelope: column envelope of the reduced camera system in the caller's camera numbering
   // (last_row[j] >= j, non-decreasing; empty = factor every entry).  Camera c shares a point with no camera beyond
   // the last camera of any of its points, so rows below 9 * that + 8 are structural zeros in S and in its factor.
+  // Parameter-block state on the Schur path: bit k of cam_mask[i] / pt_mask[p] = coordinate k of camera i / point p is
+  // held constant — SetParameterBlockConstant (all bits) or a SubsetParameterization (ceres.i:186-210; oracle/parameterization.hpp
+  // P_SUBSET / P_CONSTANT).  For both the tangent-space Jacobian is the ambient one without the constant columns and Plus
+  // adds the step to the free coordinates; here the constant columns are ZEROED instead of removed (the blocks keep their
+  // 9 / 3 columns): a zero column gets Jacobi scale 1, LM diagonal min_lm_diagonal / radius, no coupling and a zero
+  // right-hand side, so its step is exactly 0 and every other entry of the system is the reduced one's.  The dense path
+  // (or_solve_param) removes the columns for real: tests/test_oracle_kat.py holds the two against each other.
+  std::vector<int> cam_mask, pt_mask;  // empty = everything free
   std::vector<int> last_row;
   void build_envelope() {
     std::vector<int> last_cam(C);
@@ -276,6 +284,11 @@ static bool bal_evaluate(Bal& B, const double* x, bool want_jac, double* cost, i
     if (B.loss_root >= 0) {
       static const int kN[2] = {9, 3};
       term[o] = oracle::loss_correct(B.loss_nodes, B.loss_root, 2, &B.r[2 * (size_t)o], 2, kN, want_jac ? jac : nullptr);
+    }
+    if (want_jac && !B.cam_mask.empty()) {
+      const int mc = B.cam_mask[B.cam[o]], mp = B.pt_mask[B.pt[o]];
+      for (int c = 0; c < 9; ++c) if ((mc >> c) & 1) { jac[0][c] = 0.0; jac[0][9 + c] = 0.0; }
+      for (int a = 0; a < 3; ++a) if ((mp >> a) & 1) { jac[1][a] = 0.0; jac[1][3 + a] = 0.0; }
     }
   }
   if (bad) return false;
@@ -805,9 +818,20 @@ void or_loss_evaluate(const double* loss_nodes, int root, double s, double* rho)
 
 int or_solve_bal_loss(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                       const double* loss_nodes, int loss_root, double* x, const or_options* opt, or_summary* summary) {
+  return or_solve_bal_masks(C, P, N, cam_idx, pt_idx, obs, loss_nodes, loss_root, nullptr, nullptr, x, opt, summary);
+}
+
+int or_solve_bal_masks(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                       const double* loss_nodes, int loss_root, const int* cam_mask, const int* pt_mask, double* x,
+                       const or_options* opt, or_summary* summary) {
   Bal B;
   if (int rc = bal_build(B, C, P, N, cam_idx, pt_idx, obs)) return rc;
   B.loss_nodes = loss_nodes; B.loss_root = loss_nodes ? loss_root : -1;
+  if (cam_mask || pt_mask) {
+    B.cam_mask.assign(C, 0); B.pt_mask.assign(P, 0);
+    if (cam_mask) for (int i = 0; i < C; ++i) B.cam_mask[i] = cam_mask[i] & 0x1ff;
+    if (pt_mask) for (int p = 0; p < P; ++p) B.pt_mask[p] = pt_mask[p] & 0x7;
+  }
   if (opt->cholesky_envelope) B.build_envelope();
   int nt = opt->num_threads;
 #ifdef _OPENMP

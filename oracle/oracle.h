@@ -74,6 +74,12 @@ void or_parameterization_plus(int type, int size, const int* constant, int ncons
 void or_parameterization_jacobian(int type, int size, const int* constant, int nconst, const double* x, double* J);
 int or_solve_bal_loss(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                       const double* loss_nodes, int loss_root, double* x, const or_options* opt, or_summary* summary);
+/* ... with parameter-block state (ceres::Problem::SetParameterBlockConstant, SubsetParameterization): bit k of
+ * cam_mask[i] / pt_mask[p] holds coordinate k of camera i / point p constant (all 9 / 3 bits: a constant block).
+ * Either array may be NULL. */
+int or_solve_bal_masks(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
+                       const double* loss_nodes, int loss_root, const int* cam_mask, const int* pt_mask, double* x,
+                       const or_options* opt, or_summary* summary);
 int or_bal_evaluate(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                     const double* x, double* r, double* F, double* E, double* cost);
 int or_bal_reduced_system(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,

@@ -69,6 +69,7 @@ template <bool kLoss>
 __global__ __launch_bounds__(kBlock) void bal_eval_jac_kernel(BalDev d) {
   double acc[1] = {0.0};
   for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    if (d.is_host && d.is_host[o]) continue;  // the caller's host code evaluates this one (bal_host_jac_kernel)
     const int ci = d.cam[o], pi = d.pt[o];
     typedef Jet<12> J;
     J cam[9], X[3], out[2];
@@ -123,6 +124,7 @@ template <bool kLoss>
 __global__ __launch_bounds__(kBlock) void bal_eval_cost_kernel(BalDev d) {
   double acc[2] = {0.0, 0.0};
   for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    if (d.is_host && d.is_host[o]) continue;  // (bal_host_cost_kernel)
     const int ci = d.cam[o], pi = d.pt[o];
     double cam[9], X[3], out[2];
 #pragma unroll
@@ -155,6 +157,90 @@ __global__ __launch_bounds__(kBlock) void bal_eval_cost_kernel(BalDev d) {
     acc[1] += m0 * (d.r[o] + m0 / 2.0) + m1 * (d.r[(size_t)d.N + o] + m1 / 2.0);
   }
   block_sum<2>(acc, d.partial, d.partial_stride);
+}
+
+// Host-evaluated observations (director path): what the caller's Evaluate wrote — residuals and the two row-major
+// Jacobian blocks, CORE/AutodiffCostFunction.scala:113-130 — goes through the same loss correction and column scaling
+// as the device functors' output and into the same planes; everything downstream cannot tell the difference.
+template <bool kLoss>
+__global__ __launch_bounds__(kBlock) void bal_host_jac_kernel(BalDev d, int partial_off) {
+  double acc[1] = {0.0};
+  for (int h = blockIdx.x * kBlock + threadIdx.x; h < d.num_host; h += gridDim.x * kBlock) {
+    const int o = d.host_obs[h];
+    const int ci = d.cam[o], pi = d.pt[o];
+    const double* row = d.host_rows + (size_t)h * kHostRow;
+    const double r0 = row[0], r1 = row[1];
+    double j0[12], j1[12];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { j0[k] = row[2 + k]; j1[k] = row[11 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { j0[9 + k] = row[20 + k]; j1[9 + k] = row[23 + k]; }
+    if (kLoss) {
+      const double sq = r0 * r0 + r1 * r1;
+      double rho[3];
+      loss_evaluate(d.loss_nodes, d.loss_root, sq, rho);
+      const LossCorrector lc(sq, rho);
+      acc[0] += rho[0];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const double a = j0[k], b = j1[k];
+        const double rtj = lc.alpha_sq_norm * (r0 * a + r1 * b);
+        j0[k] = lc.sqrt_rho1 * (a - r0 * rtj);
+        j1[k] = lc.sqrt_rho1 * (b - r1 * rtj);
+      }
+      d.r[o] = r0 * lc.residual_scaling;
+      d.r[(size_t)d.N + o] = r1 * lc.residual_scaling;
+    } else {
+      d.r[o] = r0;
+      d.r[(size_t)d.N + o] = r1;
+      acc[0] += r0 * r0 + r1 * r1;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double s = d.scale_c[9 * (size_t)ci + k];
+      d.F[(size_t)k * d.N + o] = j0[k] * s;
+      d.F[(size_t)(9 + k) * d.N + o] = j1[k] * s;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double s = d.scale_p[3 * (size_t)pi + k];
+      d.E[(size_t)k * d.N + o] = j0[9 + k] * s;
+      d.E[(size_t)(3 + k) * d.N + o] = j1[9 + k] * s;
+    }
+  }
+  block_sum<1>(acc, d.partial + partial_off, d.partial_stride);
+}
+
+template <bool kLoss>
+__global__ __launch_bounds__(kBlock) void bal_host_cost_kernel(BalDev d, int partial_off) {
+  double acc[2] = {0.0, 0.0};
+  for (int h = blockIdx.x * kBlock + threadIdx.x; h < d.num_host; h += gridDim.x * kBlock) {
+    const int o = d.host_obs[h];
+    const int ci = d.cam[o], pi = d.pt[o];
+    const double n0 = d.host_rows[(size_t)h * kHostRow], n1 = d.host_rows[(size_t)h * kHostRow + 1];  // residuals at the candidate point
+    if (kLoss) {
+      double rho[3];
+      loss_evaluate(d.loss_nodes, d.loss_root, n0 * n0 + n1 * n1, rho);
+      acc[0] += rho[0];
+    } else {
+      acc[0] += n0 * n0 + n1 * n1;
+    }
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double s = d.step_c[9 * (size_t)ci + k];
+      m0 += d.F[(size_t)k * d.N + o] * s;
+      m1 += d.F[(size_t)(9 + k) * d.N + o] * s;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double s = d.step_p[3 * (size_t)pi + k];
+      m0 += d.E[(size_t)k * d.N + o] * s;
+      m1 += d.E[(size_t)(3 + k) * d.N + o] * s;
+    }
+    acc[1] += m0 * (d.r[o] + m0 / 2.0) + m1 * (d.r[(size_t)d.N + o] + m1 / 2.0);
+  }
+  block_sum<2>(acc, d.partial + partial_off, d.partial_stride);
 }
 
 // In-place column scaling of F / E (only at iteration 0, when the Jacobi
@@ -230,9 +316,13 @@ __global__ __launch_bounds__(kBlock) void bal_pt_reduce_kernel(BalDev d) {
 
 // Generic small vector kernels -------------------------------------------------
 // scale_j = 1 / (1 + sqrt(colsq_j))   (Jacobi scaling, fixed at iteration 0)
+// A coordinate that is held constant (SetParameterBlockConstant, SubsetParameterization) carries scale 0 from set-up on:
+// its Jacobian column is written as zeros and the step applied to it is step * 0 — the parameter keeps its bits.  Its
+// row of the normal equations is min_lm_diagonal / radius on the diagonal and zero elsewhere: the reduced program's
+// system with an inert extra unknown (oracle/lm.cpp, Bal::cam_mask).
 __global__ void jacobi_scale_kernel(const double* colsq, double* scale, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) scale[j] = 1.0 / (1.0 + sqrt(colsq[j]));
+  if (j < n) scale[j] = scale[j] == 0.0 ? 0.0 : 1.0 / (1.0 + sqrt(colsq[j]));
 }
 // After scaling J in place, colsq and the scaled gradient follow algebraically.
 __global__ void apply_scale_to_reductions_kernel(double* colsq, double* gs, const double* scale, int n) {
@@ -249,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void grad_max_xnorm_kernel(const double* gs
                                                                 int n, double* partial, int stride) {
   double m = 0.0, s = 0.0;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-    m = fmax(m, fabs(gs[j] / scale[j]));
+    if (scale[j] != 0.0) m = fmax(m, fabs(gs[j] / scale[j]));  // (a constant coordinate has no gradient entry)
     s += x[j] * x[j];
   }
   __shared__ double shm[kBlock / 64], shs[kBlock / 64];
@@ -628,6 +718,20 @@ void launch_bal_eval_jac(const BalDev& d, hipStream_t s) {
 void launch_bal_eval_cost(const BalDev& d, hipStream_t s) {
   if (d.loss_root >= 0) hipLaunchKernelGGL(bal_eval_cost_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
   else hipLaunchKernelGGL(bal_eval_cost_kernel<false>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
+}
+int launch_bal_host_jac(const BalDev& d, int partial_off, hipStream_t s) {
+  if (d.num_host <= 0) return 0;
+  const int g = grid_for(d.num_host);
+  if (d.loss_root >= 0) hipLaunchKernelGGL(bal_host_jac_kernel<true>, dim3(g), dim3(kBlock), 0, s, d, partial_off);
+  else hipLaunchKernelGGL(bal_host_jac_kernel<false>, dim3(g), dim3(kBlock), 0, s, d, partial_off);
+  return g;
+}
+int launch_bal_host_cost(const BalDev& d, int partial_off, hipStream_t s) {
+  if (d.num_host <= 0) return 0;
+  const int g = grid_for(d.num_host);
+  if (d.loss_root >= 0) hipLaunchKernelGGL(bal_host_cost_kernel<true>, dim3(g), dim3(kBlock), 0, s, d, partial_off);
+  else hipLaunchKernelGGL(bal_host_cost_kernel<false>, dim3(g), dim3(kBlock), 0, s, d, partial_off);
+  return g;
 }
 void launch_bal_scale_jac(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_scale_jac_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_reduce(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_reduce_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }

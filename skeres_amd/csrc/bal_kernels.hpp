@@ -48,7 +48,14 @@ struct BalDev {
   int* fail_flag;
   // robust loss shared by every residual block (loss.hpp); loss_root < 0 = trivial
   const LossNode* loss_nodes;  int loss_root;
+  // residual blocks whose cost function is the caller's host code (the reference's director path, ceres.i:48:
+  // sk_cost_function_new_callback with 2 residuals over a 9- and a 3-block): evaluated on the host, their rows uploaded
+  const unsigned char* is_host;  // [N] 1 = host-evaluated observation; nullptr when there is none
+  int num_host;
+  const int* host_obs;           // [num_host] observation index
+  const double* host_rows;       // [num_host][kHostRow]: r (2), d r / d camera (2 x 9 row-major), d r / d point (2 x 3 row-major)
 };
+constexpr int kHostRow = 26;
 
 int bal_partial_blocks(int N);
 int bal_point_blocks(int P);  // workgroups of the per-point kernels (bal_point_backsub writes one partial sum each)
@@ -59,6 +66,11 @@ size_t tri_packed_elems(int nblk);
 void launch_tri_pack(double* S, int ld, double* packed, int nblk, bool to_packed, hipStream_t s);
 void launch_bal_eval_jac(const BalDev& d, hipStream_t s);
 void launch_bal_eval_cost(const BalDev& d, hipStream_t s);
+// the uploaded rows of the host-evaluated observations -> r / F / E planes (loss correction and column scaling as the
+// device functors' kernel applies them); cost partial sums from slot `partial_off` on.  Returns the number of slots.
+int launch_bal_host_jac(const BalDev& d, int partial_off, hipStream_t s);
+// candidate cost and model term of the host-evaluated observations from their uploaded residuals at the candidate point
+int launch_bal_host_cost(const BalDev& d, int partial_off, hipStream_t s);
 void launch_bal_scale_jac(const BalDev& d, hipStream_t s);
 void launch_bal_cam_reduce(const BalDev& d, hipStream_t s);
 void launch_bal_pt_reduce(const BalDev& d, hipStream_t s);

@@ -7,6 +7,7 @@
 // is summed with one all-reduce per linear solve.
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <numeric>
 
 #include "bal_kernels.hpp"
@@ -17,11 +18,18 @@ namespace sk {
 bool problem_is_bal_shaped(const Problem& p, std::string* why) {
   const size_t nb = p.rb_functor.size();
   if (nb == 0) { *why = "problem has no residual blocks"; return false; }
-  for (size_t b = 0; b < nb; ++b)
-    if (p.rb_functor[b] != SK_FUNCTOR_SNAVELY_REPROJECTION) {
-      *why = "DENSE_SCHUR is implemented for SnavelyReprojectionError residual blocks (2 residuals; 9- and 3-parameter blocks) only";
+  // the registered device functor of that shape, or ANY cost function of that shape through the director path
+  // (sk_cost_function_new_callback: the caller's Evaluate, run on the host — CORE/CostFunctor.scala:40-51, ceres.i:48)
+  for (size_t b = 0; b < nb; ++b) {
+    const CostFunction* cf = b < p.rb_cost.size() ? p.rb_cost[b] : nullptr;
+    const bool host_ok = p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK && cf && cf->callback && cf->num_residuals == 2 && cf->block_sizes.size() == 2 &&
+                         cf->block_sizes[0] == 9 && cf->block_sizes[1] == 3;
+    if (p.rb_functor[b] != SK_FUNCTOR_SNAVELY_REPROJECTION && !host_ok) {
+      *why = "DENSE_SCHUR is implemented for residual blocks with 2 residuals over a 9- and a 3-parameter block (SnavelyReprojectionError on the "
+             "device, or any host-callback cost function of that shape); not supported: another shape";
       return false;
     }
+  }
   for (size_t b = 1; b < nb && b < p.rb_loss.size(); ++b)
     if (p.rb_loss[b] != p.rb_loss[0]) { *why = "DENSE_SCHUR takes one loss function for all residual blocks"; return false; }
   std::vector<char> role(p.block_size.size(), 0);
@@ -125,6 +133,15 @@ class BalSolver : public SolverBase {
 
  private:
   int gather_rank_scalars(double* vals, int K, const int* ops);
+  // director path: the host-evaluated observations at the point held in x_dev ([cameras | points]); jac: with Jacobians
+  int host_callbacks(const double* x_dev, bool jac, bool* failed);
+  std::vector<int> host_obs_;                 // local observation index of every host-evaluated residual block
+  std::vector<const CostFunction*> host_cf_;  // ... and its cost function
+  std::vector<double> host_x_, host_rows_h_;
+  DevBuf<unsigned char> b_is_host_;
+  DevBuf<int> b_host_obs_;
+  DevBuf<double> b_host_rows_;
+  std::vector<int> h_cam_, h_pt_;             // camera / local point of every local observation (host copy, for the callbacks)
   int gather_rank_scalars_signed(double* vals, int K);
 
   int C_ = 0, P_total_ = 0, P_ = 0, N_ = 0;   // cameras, all points, local points, local observations
@@ -264,6 +281,14 @@ int BalSolver::setup() {
   std::string why;
   if (!problem_is_bal_shaped(*problem_, &why)) { set_error("%s", why.c_str()); return SK_ERR_UNSUPPORTED; }
   const Problem& p = *problem_;
+  for (size_t b = 0; b < p.block_param.size(); ++b)
+    if (p.block_param[b] >= 0) {
+      const int t = p.params[p.block_param[b]].type;
+      if (t != kParamIdentity && t != kParamSubset) {
+        set_error("DENSE_SCHUR takes identity and subset parameterizations and constant parameter blocks (quaternion / homogeneous-vector blocks are implemented for DENSE_QR / DENSE_NORMAL_CHOLESKY; not supported here)");
+        return SK_ERR_UNSUPPORTED;
+      }
+    }
   const int Nall = (int)p.rb_functor.size();
   std::vector<int> ocam, opt;
   bal_index_problem(p, &cam_block_, &pt_block_, &ocam, &opt);
@@ -350,7 +375,11 @@ int BalSolver::setup() {
   for (int o = 0; o < N_; ++o) {
     const int b = order[o];
     cam[o] = ocam[b]; pt[o] = opt[b] - p_lo;
-    obs[o] = p.consts[p.rb_const_off[b]]; obs[(size_t)N_ + o] = p.consts[p.rb_const_off[b] + 1];
+    if (p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK) {  // no captured doubles on the device: the caller's object holds them
+      host_obs_.push_back(o); host_cf_.push_back(p.rb_cost[b]);
+    } else {
+      obs[o] = p.consts[p.rb_const_off[b]]; obs[(size_t)N_ + o] = p.consts[p.rb_const_off[b] + 1];
+    }
     if (o > 0 && pt[o] == pt[o - 1] && cam[o] == cam[o - 1]) { set_error("two residual blocks share the same (camera, point) pair: not supported by the Schur path"); return SK_ERR_UNSUPPORTED; }
   }
   // camera CSR (ascending point because observation order is point-major)
@@ -399,7 +428,23 @@ int BalSolver::setup() {
   // x vectors are stored [cameras | points] so whole-vector kernels run once
   SK_HIP_TRY(b_xc_.upload(x, s)); SK_HIP_TRY(b_xc_new_.alloc(nx));
   SK_HIP_TRY(b_scale_.alloc(nx)); SK_HIP_TRY(b_colsq_.alloc(nx)); SK_HIP_TRY(b_gs_.alloc(nx)); SK_HIP_TRY(b_D_.alloc(nx)); SK_HIP_TRY(b_step_.alloc(nx));
-  { std::vector<double> ones(nx, 1.0); SK_HIP_TRY(hipMemcpyAsync(b_scale_.p, ones.data(), nx * sizeof(double), hipMemcpyHostToDevice, s)); SK_HIP_TRY(hipStreamSynchronize(s)); }
+  {
+    // scale starts as the mask of free coordinates: 1, or 0 for a coordinate that is held constant — a constant parameter
+    // block (Problem::SetParameterBlockConstant) or the constant coordinates of a SubsetParameterization (ceres.i:186-210);
+    // an IdentityParameterization changes nothing.  See jacobi_scale_kernel.
+    std::vector<double> free_mask(nx, 1.0);
+    auto mask_block = [&](int block, size_t off, int size) {
+      if ((size_t)block < p.block_constant.size() && p.block_constant[block]) { for (int k = 0; k < size; ++k) free_mask[off + k] = 0.0; return; }
+      const int pi = (size_t)block < p.block_param.size() ? p.block_param[block] : -1;
+      if (pi < 0) return;
+      const LocalParameterization& lp = p.params[pi];
+      if (lp.type == kParamSubset) for (int k = 0; k < size; ++k) if ((lp.constant_mask >> k) & 1u) free_mask[off + k] = 0.0;
+    };
+    for (int i = 0; i < C_; ++i) mask_block(cam_block_[i], 9 * (size_t)i, 9);
+    for (int q = 0; q < P_; ++q) mask_block(pt_block_[local_pt_[q]], nc + 3 * (size_t)q, 3);
+    SK_HIP_TRY(hipMemcpyAsync(b_scale_.p, free_mask.data(), nx * sizeof(double), hipMemcpyHostToDevice, s));
+    SK_HIP_TRY(hipStreamSynchronize(s));
+  }
   SK_HIP_TRY(b_y_.alloc(npad_));
   SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
   SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
@@ -430,7 +475,7 @@ int BalSolver::setup() {
     SK_HIP_TRY(b_zero_col0_.upload(col0, s));
   }
   SK_HIP_TRY(b_Linv_.alloc((size_t)npad_ * 128)); SK_HIP_TRY(b_Linv_.zero(s));
-  partial_stride_ = std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_)), 256);
+  partial_stride_ = std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_)), 256) + bal_partial_blocks((int)host_obs_.size());
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
   SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
   SK_HIP_TRY(b_fail_.alloc(1)); SK_HIP_TRY(b_fail_.zero(s)); SK_HIP_TRY(b_info_.alloc(1)); SK_HIP_TRY(b_info_.zero(s));
@@ -449,6 +494,16 @@ int BalSolver::setup() {
   d_.S = b_S_.p; d_.ld = npad_; d_.rhs_row = rhs_row_; d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = b_fail_.p;
   d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0];
   if (d_.loss_root >= 0) { SK_HIP_TRY(b_loss_nodes_.upload(p.loss_nodes, s)); d_.loss_nodes = b_loss_nodes_.p; }
+  d_.is_host = nullptr; d_.num_host = (int)host_obs_.size(); d_.host_obs = nullptr; d_.host_rows = nullptr;
+  if (!host_obs_.empty()) {
+    std::vector<unsigned char> flag(N_, 0);
+    for (int o : host_obs_) flag[o] = 1;
+    SK_HIP_TRY(b_is_host_.upload(flag, s)); SK_HIP_TRY(b_host_obs_.upload(host_obs_, s));
+    SK_HIP_TRY(b_host_rows_.alloc(host_obs_.size() * (size_t)kHostRow));
+    d_.is_host = b_is_host_.p; d_.host_obs = b_host_obs_.p; d_.host_rows = b_host_rows_.p;
+    h_cam_ = cam; h_pt_ = pt;
+    host_x_.resize(nx); host_rows_h_.resize(host_obs_.size() * (size_t)kHostRow);
+  }
   SK_HIP_TRY(hipStreamSynchronize(s));
   if (opt_.allreduce) {
     // every rank derived the camera order and the envelope for itself (from rank-invariant data): they must be the same
@@ -512,7 +567,14 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_;
   SK_HIP_TRY(hipEventRecord(ev_[kEvBegin], s));
   kt_.begin("bal_eval_jac", s); launch_bal_eval_jac(d_, s); kt_.end("bal_eval_jac", s);
-  const int nb = bal_partial_blocks(N_);
+  int nb = bal_partial_blocks(N_);
+  if (d_.num_host > 0) {
+    bool failed = false;
+    int rc = host_callbacks(d_.xc, true, &failed);
+    if (rc) return rc;
+    if (failed) return SK_ERR_EVALUATION_FAILED;
+    nb += launch_bal_host_jac(d_, nb, s);
+  }
   launch_bal_cam_reduce(d_, s);
   launch_bal_pt_reduce(d_, s);
   if (opt_.allreduce) {  // camera columns are summed over all ranks' observations
@@ -600,7 +662,14 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   launch_final_reduce(b_partial_.p, partial_stride_, P_ > 0 ? gb : 0, 1, 0, b_scal_.p + 9, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvBacksub], s));
   kt_.begin("bal_eval_cost", s); launch_bal_eval_cost(d_, s); kt_.end("bal_eval_cost", s);
-  launch_final_reduce(b_partial_.p, partial_stride_, bal_partial_blocks(N_), 2, 0, b_scal_.p, s);
+  int nb_cost = bal_partial_blocks(N_);
+  bool candidate_failed = false;  // a cost function that cannot be evaluated at the candidate: the step is rejected (cost = max)
+  if (d_.num_host > 0) {
+    int rc = host_callbacks(d_.xc_new, false, &candidate_failed);
+    if (rc) return rc;
+    nb_cost += launch_bal_host_cost(d_, nb_cost, s);
+  }
+  launch_final_reduce(b_partial_.p, partial_stride_, nb_cost, 2, 0, b_scal_.p, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 16, b_fail_.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -622,8 +691,31 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   if (loc[3] != 0.0 || !std::isfinite(step_sq) || !std::isfinite(loc[1])) return SK_OK;  // invalid step
   *valid = true;
   *mcc = -loc[1];
-  *new_cost = 0.5 * loc[0];
+  *new_cost = candidate_failed ? std::numeric_limits<double>::max() : 0.5 * loc[0];
   *step_norm = std::sqrt(step_sq);
+  return SK_OK;
+}
+
+// The reference's director upcall (ceres.i:48; CORE/AutodiffCostFunction.scala:74-78) for the residual blocks whose cost
+// function has no device body: parameters down to the host, the caller's Evaluate once per block with the exact native
+// signature (jacobians == nullptr on the cost-only branch), the rows back up.  Slow by construction — one PCIe round
+// trip per evaluation and host arithmetic — but any generic (9, 3) -> 2 functor can enter DENSE_SCHUR this way.
+int BalSolver::host_callbacks(const double* x_dev, bool jac, bool* failed) {
+  *failed = false;
+  const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_;
+  SK_HIP_TRY(hipMemcpyAsync(host_x_.data(), x_dev, (nc + np) * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  SK_HIP_TRY(hipStreamSynchronize(stream_));
+  for (size_t h = 0; h < host_obs_.size(); ++h) {
+    const int o = host_obs_[h];
+    const CostFunction* cf = host_cf_[h];
+    const double* params[2] = {&host_x_[9 * (size_t)h_cam_[o]], &host_x_[nc + 3 * (size_t)h_pt_[o]]};
+    double* row = &host_rows_h_[h * (size_t)kHostRow];
+    for (int k = 0; k < kHostRow; ++k) row[k] = 0.0;
+    double* jptr[2] = {row + 2, row + 20};
+    if (!cf->callback(cf->user, params, row, jac ? jptr : nullptr)) { *failed = true; return SK_OK; }
+  }
+  SK_HIP_TRY(hipMemcpyAsync(b_host_rows_.p, host_rows_h_.data(), host_rows_h_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  SK_HIP_TRY(hipStreamSynchronize(stream_));  // (host_rows_h_ is pageable and reused by the next evaluation)
   return SK_OK;
 }
 

@@ -529,8 +529,8 @@ double sk_summary_phase_seconds(const sk_summary* s, int phase) { return (phase 
 // ---- solve ------------------------------------------------------------------------------
 static std::unique_ptr<SolverBase> make_solver(const Options& o, Problem* p, int* rc) {
   *rc = SK_OK;
-  if (p->has_parameterization() && (o.linear_solver_type == SK_DENSE_SCHUR || problem_is_dense_rows(*p))) {
-    set_error("local parameterizations and constant parameter blocks are implemented for DENSE_QR / DENSE_NORMAL_CHOLESKY over residual blocks (not supported here)");
+  if (p->has_parameterization() && o.linear_solver_type != SK_DENSE_SCHUR && problem_is_dense_rows(*p)) {
+    set_error("local parameterizations and constant parameter blocks are implemented for residual-block problems (DENSE_QR / DENSE_NORMAL_CHOLESKY; identity, subset and constant blocks under DENSE_SCHUR), not for dense rows (not supported here)");
     *rc = SK_ERR_UNSUPPORTED; return nullptr;
   }
   if (o.linear_solver_type == SK_DENSE_SCHUR) {
