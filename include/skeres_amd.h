@@ -424,6 +424,14 @@ int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double
 int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, double* L, int group, const int* last,
                          int automatic_plan);
 
+/* The same system solved by two-way dissection (what DENSE_SCHUR does with the reduced camera system of a camera
+ * sequence when that pays — DESIGN.md section 4): rows [0, head) are eliminated front to back, rows [tail_begin, n) back
+ * to front, side by side, each leaving its Schur complement on the separator [head, tail_begin), which is factored
+ * last.  A(tail, head) must be zero (SK_ERR_INVALID_ARGUMENT otherwise).  The block envelopes of the three fronts are
+ * derived from the non-zeros of A.  Known-answer tests of the dissected factorisation against a plain one. */
+int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double* x, int head, int tail_begin, int group,
+                                int automatic_plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,7 @@ _SIGS = {
     "sk_solver_distribution": (C.c_int, [C.c_void_p, _dp, _dp]),
     "sk_solver_stat": (C.c_int, [C.c_void_p, C.c_char_p, _dp]),
     "sk_last_status": (C.c_int, []),
+    "sk_cholesky_solve_dissected": (C.c_int, [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sk_cholesky_solve_ex": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, C.c_int]),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
@@ -1130,6 +1131,18 @@ def cholesky_solve(A, b, want_L=False, group=0, last=None, automatic_plan=False)
     _check(lib().sk_cholesky_solve_ex(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp),
                                       L.ctypes.data_as(_dp) if want_L else _dp(), int(group), lp, int(bool(automatic_plan))))
     return (x, L) if want_L else x
+
+
+def cholesky_solve_dissected(A, b, head, tail_begin, group=0, automatic_plan=False):
+    """A x = b by two-way dissection on the GPU (sk_cholesky_solve_dissected): rows [0, head) and [tail_begin, n) are
+    eliminated side by side (the tail back to front), the separator in between last."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    n = A.shape[0]
+    x = np.empty(n)
+    _check(lib().sk_cholesky_solve_dissected(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp), int(head), int(tail_begin),
+                                             int(group), int(bool(automatic_plan))))
+    return x
 
 
 def synth_dense_targets(seed, m, n, x_star):

@@ -698,4 +698,93 @@ int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, dou
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }
 
+// Block envelope of a front held on the host (lower triangle, row-major, ld): first non-zero block column per block row.
+static std::vector<int> host_block_envelope(const std::vector<double>& M, size_t ld, int nblk) {
+  std::vector<int> first_col(nblk);
+  for (int i = 0; i < nblk; ++i) {
+    first_col[i] = i;
+    for (int j = 0; j < i && first_col[i] == i; ++j) {
+      bool nz = false;
+      for (int r = 0; r < 128 && !nz; ++r) {
+        const double* row = &M[((size_t)i * 128 + r) * ld + (size_t)j * 128];
+        for (int c = 0; c < 128; ++c) if (row[c] != 0.0) { nz = true; break; }
+      }
+      if (nz) first_col[i] = j;
+    }
+  }
+  return cholesky_envelope_last(first_col);
+}
+
+int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double* x, int head, int tail_begin, int group, int automatic_plan) {
+  SK_GUARD_BEGIN
+  if (n <= 0 || !A || !b || !x || head < 0 || tail_begin < head || tail_begin > n) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
+  const int ra = head, rb = tail_begin, nt = n - rb, msep = rb - ra;
+  for (int i = rb; i < n; ++i)
+    for (int j = 0; j < ra; ++j)
+      if (A[(size_t)i * n + j] != 0.0) { set_error("the tail couples with the head at (%d, %d): not a separator", i, j); return SK_ERR_INVALID_ARGUMENT; }
+  if (group <= 0) group = automatic_plan ? 1 : 3;
+  const int nA = (ra + 127) / 128, nB = (nt + 127) / 128, E = (msep + 1 + 127) / 128;
+  const size_t dA = (size_t)(nA + E) * 128, dB = (size_t)(nB + E) * 128, dR = (size_t)E * 128;
+  std::vector<double> FA(dA * dA, 0.0), FB(dB * dB, 0.0), FR(dR * dR, 0.0);
+  // head: interior in order, border = separator in order, then the right-hand side
+  for (int i = 0; i < ra; ++i) std::memcpy(&FA[(size_t)i * dA], A + (size_t)i * n, (size_t)(i + 1) * sizeof(double));
+  for (int i = ra; i < nA * 128; ++i) FA[(size_t)i * dA + i] = 1.0;
+  for (int k = 0; k < msep; ++k) std::memcpy(&FA[((size_t)nA * 128 + k) * dA], A + (size_t)(ra + k) * n, (size_t)ra * sizeof(double));
+  std::memcpy(&FA[((size_t)nA * 128 + msep) * dA], b, (size_t)ra * sizeof(double));
+  // tail: interior in REVERSE order (t <-> global n - 1 - t), border = separator in reverse order, then the right-hand side
+  for (int t1 = 0; t1 < nt; ++t1)
+    for (int t2 = 0; t2 <= t1; ++t2) FB[(size_t)t1 * dB + t2] = A[(size_t)(n - 1 - t2) * n + (n - 1 - t1)];
+  for (int i = nt; i < nB * 128; ++i) FB[(size_t)i * dB + i] = 1.0;
+  for (int k = 0; k < msep; ++k)
+    for (int t = 0; t < nt; ++t) FB[((size_t)nB * 128 + k) * dB + t] = A[(size_t)(n - 1 - t) * n + (ra + msep - 1 - k)];
+  for (int t = 0; t < nt; ++t) FB[((size_t)nB * 128 + msep) * dB + t] = b[n - 1 - t];
+  // root: the separator's own block and right-hand side
+  for (int i = 0; i < msep; ++i) std::memcpy(&FR[(size_t)i * dR], A + (size_t)(ra + i) * n + ra, (size_t)(i + 1) * sizeof(double));
+  std::memcpy(&FR[(size_t)msep * dR], b + ra, (size_t)msep * sizeof(double));
+  FR[(size_t)msep * dR + msep] = 1e300;
+  for (size_t j = (size_t)msep + 1; j < dR; ++j) FR[j * dR + j] = 1.0;
+  std::vector<int> mapB(dR, -1);
+  for (int k = 0; k < msep; ++k) mapB[k] = msep - 1 - k;
+  mapB[msep] = msep;
+  const std::vector<int> lastA = host_block_envelope(FA, dA, nA + E), lastB = host_block_envelope(FB, dB, nB + E);
+  DevBuf<double> dFA, dFB, dFR, dLinv, dw, dy; DevBuf<int> dinfo, dmap;
+  hipStream_t s = nullptr;
+  SK_HIP_TRY(dFA.upload(FA, s)); SK_HIP_TRY(dFB.upload(FB, s)); SK_HIP_TRY(dFR.upload(FR, s)); SK_HIP_TRY(dmap.upload(mapB, s));
+  SK_HIP_TRY(dLinv.alloc((size_t)(nA + nB + E) * 128 * 128)); SK_HIP_TRY(dLinv.zero(s));
+  SK_HIP_TRY(dw.alloc(dA + dB + 2 * dR)); SK_HIP_TRY(dy.alloc(dA + dB + dR)); SK_HIP_TRY(dy.zero(s)); SK_HIP_TRY(dinfo.alloc(1)); SK_HIP_TRY(dinfo.zero(s));
+  SK_HIP_TRY(cholesky_init());
+  CholeskyContext ctx, ctxB;
+  const bool la = ctx.init() == hipSuccess;
+  if (!la) (void)hipGetLastError();
+  const bool side = la && ctxB.init_secondary(ctx) == hipSuccess;
+  if (la && !side) (void)hipGetLastError();
+  SK_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  SK_HIP_TRY(hipDeviceSynchronize());
+  DissectedSystem d;
+  d.A.S = dFA.p; d.A.ld = (long)dA; d.A.nblk = nA + E; d.A.ncols = nA; d.A.last = lastA.data(); d.A.Linv = dLinv.p; d.A.rhs_row = nA * 128 + msep;
+  d.B.S = dFB.p; d.B.ld = (long)dB; d.B.nblk = nB + E; d.B.ncols = nB; d.B.last = lastB.data(); d.B.Linv = dLinv.p + (size_t)nA * 128 * 128; d.B.rhs_row = nB * 128 + msep;
+  d.R.S = dFR.p; d.R.ld = (long)dR; d.R.nblk = E; d.R.ncols = E; d.R.last = nullptr; d.R.Linv = dLinv.p + (size_t)(nA + nB) * 128 * 128; d.R.rhs_row = msep;
+  d.border_blocks = E; d.mapB = dmap.p;
+  const bool chain = automatic_plan != 0 && la && cholesky_chain_enabled(&ctx);
+  if (chain) cholesky_prepare(&ctx, s);
+  cholesky_dissected_factor(d, dinfo.p, group, s, la ? &ctx : nullptr, side ? &ctxB : nullptr, nullptr, chain);
+  double *wA = dw.p, *wB = dw.p + dA, *wR = dw.p + dA + dB, *ybB = dw.p + dA + dB + dR;
+  double *yA = dy.p, *yB = dy.p + dA, *yR = dy.p + dA + dB;
+  cholesky_dissected_backsolve(d, msep, wR, yR, wA, yA, wB, yB, ybB, s, side ? &ctxB : nullptr, nullptr);
+  SK_HIP_TRY(hipStreamSynchronize(s));
+  SK_HIP_TRY(hipStreamDestroy(s));
+  int info = 0;
+  SK_HIP_TRY(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (info == 2) { (void)cholesky_note_info(&ctx, info); set_error("the resident panel chain timed out"); return SK_ERR_HIP; }
+  if (info) { set_error("matrix is not positive definite"); return SK_ERR_EVALUATION_FAILED; }
+  std::vector<double> y(dA + dB + dR);
+  SK_HIP_TRY(hipMemcpy(y.data(), dy.p, y.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < ra; ++i) x[i] = y[i];
+  for (int t = 0; t < nt; ++t) x[n - 1 - t] = y[dA + t];
+  for (int k = 0; k < msep; ++k) x[ra + k] = y[dA + dB + k];
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
 }  // extern "C"

@@ -1062,6 +1062,8 @@ hipError_t cholesky_init() {
 
 CholeskyContext::~CholeskyContext() {
   for (hipEvent_t e : events) (void)hipEventDestroy(e);
+  if (fork_ev) (void)hipEventDestroy(fork_ev);
+  if (join_ev) (void)hipEventDestroy(join_ev);
   if (sync) (void)hipFree(sync);
   if (xs) (void)hipFree(xs);
 }
@@ -1107,6 +1109,7 @@ struct DeviceQueues {
   int queue_choice = -1;  // -1: not measured yet; else (bulk * kPanelCand + panel) * kServerCand + server
   bool tuning = false;
   int chain_server = 1;   // 0: block columns are factored launch by launch on this device (knob, or a time-out happened)
+  hipStream_t fork = nullptr;  // stands in for the caller's stream in a secondary context (CholeskyContext::init_secondary)
 };
 static PerDeviceTable<DeviceQueues> g_device_queues;
 
@@ -1235,6 +1238,24 @@ hipError_t CholeskyContext::init() {
   return hipSuccess;
 }
 
+hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
+  if (panel) return hipSuccess;
+  if (!primary.dq) return hipErrorInvalidValue;
+  DeviceQueues* q = primary.dq;
+  dq = q; device = primary.device;
+  server = nullptr;
+  reserved_cus = q->reserved_cus; early_tiles = q->early_tiles;
+  for (int k = 0; k < kPanelCand; ++k) if (q->panel_candidates[k] && q->panel_candidates[k] != primary.panel) { panel = q->panel_candidates[k]; break; }
+  for (int k = 0; k < kBulkCand; ++k) if (q->bulk_candidates[k] && q->bulk_candidates[k] != primary.bulk) { bulk = q->bulk_candidates[k]; bulk_early = q->bulk_early_candidates[k]; break; }
+  if (!panel || !bulk) { panel = bulk = bulk_early = nullptr; return hipErrorNotSupported; }  // (no CU-masked candidates on this device)
+  if (!q->fork) {
+    if (hipStreamCreateWithFlags(&q->fork, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); panel = bulk = bulk_early = nullptr; return hipErrorOutOfMemory; }
+    q->all_streams.push_back(q->fork);
+  }
+  fork = q->fork;
+  return hipSuccess;
+}
+
 hipEvent_t CholeskyContext::event(size_t i) {
   while (events.size() <= i) {
     hipEvent_t e = nullptr;
@@ -1273,12 +1294,33 @@ std::vector<int> cholesky_group_bounds(int nblk, int group) {
 // asked for 1: their SYRK is the long pole, and K = 128 leaves it bound by the traffic of its C tiles).
 // chain == false: cholesky_group_bounds, no resident chain.
 constexpr int kMinChainRun = 4;
-CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain) {
+// ncols < nblk (a PARTIAL factorisation: a leaf front of the dissected reduced system, cholesky_dissected_*): only the
+// first ncols block columns are factored; the trailing block rows — the front's border — receive their updates and are
+// left holding the Schur complement.  The groups then cover [0, ncols), followed by [ncols, ncols + 1) and
+// [ncols + 1, nblk), which cholesky_factor never factors: they only tell the last real group where next(g) (one block
+// column, as after a resident column) ends and syrk(g) begins.
+static void plan_close_partial(CholeskyPlan* plan, int nblk, int ncols) {
+  std::vector<int>& b = plan->bounds;
+  while (!b.empty() && b.back() >= ncols) b.pop_back();
+  b.push_back(ncols);
+  if (ncols + 1 < nblk) b.push_back(ncols + 1);
+  if (ncols < nblk) b.push_back(nblk);
+}
+CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols) {
   CholeskyPlan plan;
   plan.resident.assign(nblk, 0);
   if (group < 1) group = 1;
+  if (ncols < 0 || ncols > nblk) ncols = nblk;
+  const bool partial = ncols < nblk;
   if (!chain || nblk < 3) {
     plan.bounds = cholesky_group_bounds(nblk, group);
+    if (partial) {
+      // group boundaries of [0, ncols) (a group never straddles the border), then the border's pseudo-groups
+      std::vector<int> b;
+      for (int k : plan.bounds) if (k < ncols) b.push_back(k);
+      plan.bounds.swap(b);
+      plan_close_partial(&plan, nblk, ncols);
+    }
     return plan;
   }
   auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
@@ -1286,30 +1328,32 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain) {
     const int main_rows = last_row >= first_row ? last_row - first_row + 1 : 0;
     return main_rows + ((first_row + main_rows <= nblk - 1 && last_row < nblk - 1) ? 1 : 0);
   };
-  for (int j = 0; j + 1 < nblk; ++j)
+  const int jend = partial ? ncols : nblk - 1;  // block columns that have a column launch of their own
+  for (int j = 0; j < jend; ++j)
     plan.resident[j] = count(j + 2, last_main(j)) <= g_chain_max_trailing && 4 * count(j + 1, last_main(j)) <= g_thin_grid;
-  for (int j = 0; j + 1 < nblk;) {  // drop the short runs: a hand-over costs more than a few columns gain
+  for (int j = 0; j < jend;) {  // drop the short runs: a hand-over costs more than a few columns gain
     if (!plan.resident[j]) { ++j; continue; }
     int e = j;
-    while (e + 1 < nblk && plan.resident[e]) ++e;
+    while (e < jend && plan.resident[e]) ++e;
     if (e - j < kMinChainRun) for (int i = j; i < e; ++i) plan.resident[i] = 0;
     j = e;
   }
-  plan.resident[nblk - 1] = plan.resident[nblk - 2];  // the server factors the last diagonal block too when it has the column before it
+  if (!partial) plan.resident[nblk - 1] = plan.resident[nblk - 2];  // the server factors the last diagonal block too when it has the column before it
   bool any = false;
   for (int j = 0; j < nblk; ++j) any = any || plan.resident[j];
-  if (!any) { plan.bounds = cholesky_group_bounds(nblk, group); return plan; }
+  if (!any) return cholesky_plan(nblk, group, last, false, ncols);
   const int pg = group == 1 ? g_chain_prefix_group : group;
-  for (int k = 0; k < nblk;) {
+  for (int k = 0; k < ncols;) {
     plan.bounds.push_back(k);
     if (plan.resident[k]) { ++k; continue; }
     int stop = k;
-    while (stop < nblk && !plan.resident[stop]) ++stop;
+    while (stop < ncols && !plan.resident[stop]) ++stop;
     int g = nblk - k <= g_tail_tiles ? g_tail_group : pg;
     if (g < 1) g = 1;
     k += std::min(g, stop - k);
   }
-  plan.bounds.push_back(nblk);
+  if (partial) plan_close_partial(&plan, nblk, ncols);
+  else plan.bounds.push_back(nblk);
   return plan;
 }
 int cholesky_plan_max_group(const CholeskyPlan& plan) {
@@ -1457,8 +1501,9 @@ void cholesky_prepare(CholeskyContext* ctx, hipStream_t s) {
 }
 
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt, const int* last, bool allow_chain) {
+                     KernelTimer* kt, const int* last, bool allow_chain, int ncols) {
   const int nblk = npad / 128;
+  if (ncols < 0 || ncols > nblk) ncols = nblk;
   if (allow_chain && !(ctx && ctx->dq && ctx->dq->tuning)) cholesky_prepare(ctx, s);
   const bool la = ctx != nullptr && ctx->panel != nullptr && ctx->bulk != nullptr;
   hipStream_t sp = la ? ctx->panel : s;
@@ -1534,7 +1579,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     }
   };
   // the block columns under the resident panel chain (cholesky_plan)
-  const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr);
+  const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr, ncols);
   const std::vector<int>& gb = plan.bounds;
   const int ngroups = (int)gb.size() - 1;
   ChainRanges ranges;
@@ -1566,11 +1611,12 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   }
   order(s, sp);
   if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }
-  if (!is_resident(0)) panel(gb[0], gb[1]);
+  if (!is_resident(0) && ncols > 0) panel(gb[0], gb[1]);
   hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
   int seq = 0;                     // SYRK completions announced to the chain so far (chain_marker_kernel)
   for (int g = 0; g + 1 < ngroups; ++g) {
     const int k0 = gb[g], k1 = gb[g + 1];
+    if (k0 >= ncols) break;  // (a partial factorisation: the border's pseudo-groups)
     const int K = (k1 - k0) * 128;
     const bool resident = is_resident(k0);        // potrf(k0) by the server; TRSM and next(g) by one column launch
     const bool next_resident = is_resident(k1);   // ... and the same for the next group
@@ -1645,8 +1691,10 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       // (after a resident column: hand-back, in stream order behind its column launch; the columns after k1 of a wider
       // group take this panel's update from syrk(g), on the bulk stream)
       const int k2 = gb[g + 2];
-      if (resident && k2 - k1 > 1 && la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
-      panel(k1, k2);
+      if (k1 < ncols) {
+        if (resident && k2 - k1 > 1 && la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
+        panel(k1, k2);
+      }
     }
   }
   order(sp, s);
@@ -1691,6 +1739,159 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
   if (kt) kt->end("backsolve", s);
 }
 
+// ---------------------------------------------------------------------------
+// Two-way dissection of a block-banded system ("Dissection").
+//
+// The reduced camera system of a camera sequence is block-banded, and a banded Cholesky is a serial chain of one
+// block column after the other: 122 of them at C = 1723, each 40-60 us of latency however idle the chip is.  The
+// cameras are therefore split into a head A, a separator and a tail B such that no point is seen from both A and B;
+// A is eliminated front to back and B BACK TO FRONT, concurrently — two chains of half the length — each leaving its
+// Schur complement on the separator, which is then factored: the chain is ~(n + separator) / 2 block columns long
+// instead of n.  The same arithmetic as the banded factorisation in another elimination order (a "twisted" / "burn at
+// both ends" factorisation); no flops are added, B's are the mirror image of what they were.
+//
+// Storage: three dense matrices ("fronts").  A leaf front holds its interior block columns [0, ncols) followed by a
+// BORDER of E block rows: the separator's unknowns and, in the last block, the right-hand-side row, exactly as a whole
+// system holds it.  Ordered so that the separator unknowns a leaf's last columns couple with come FIRST in its border
+// (A: separator in camera order; B: in reverse camera order), a leaf front is an ordinary envelope matrix — a contiguous
+// run of active rows plus the last block row — of which cholesky_factor factors the first ncols block columns
+// (cholesky_plan, partial).  The root front is the separator's own system (E blocks, right-hand side in its last row),
+// to which the leaves' border blocks are added before it is factored.
+// ---------------------------------------------------------------------------
+// root (lower triangle, row-major, ld_r) += the lower triangle of a leaf's border x border block, border index i going to
+// root index map[i] (< 0: an unused padding row).  map == nullptr: identity.  One thread per element of the border block.
+__global__ __launch_bounds__(256) void border_add_kernel(double* __restrict__ root, long ld_r, const double* __restrict__ border, long ld_f, int m,
+                                                         const int* __restrict__ map) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)m * m) return;
+  const int i = (int)(e / m), j = (int)(e % m);
+  if (j > i) return;
+  int ri = i, rj = j;
+  if (map) { ri = map[i]; rj = map[j]; }
+  if (ri < 0 || rj < 0) return;
+  const double v = border[(long)i * ld_f + j];
+  if (v == 0.0) return;
+  if (ri >= rj) root[(long)ri * ld_r + rj] += v;
+  else root[(long)rj * ld_r + ri] += v;
+}
+
+// w[c] -= sum_r L[border row r][c] * yb[r] for the interior columns c in [col0, ncols) of a leaf front: the border
+// unknowns (the separator's solution, in the leaf's border order) are known; this is their part of L^T y = z.
+// Lb: first border row of the front.  64 columns per workgroup, 16 row groups.
+__global__ __launch_bounds__(1024) void bs_border_kernel(const double* __restrict__ Lb, long ld, int m, const double* __restrict__ yb, double* __restrict__ w,
+                                                          int col0, int ncols) {
+  __shared__ double red[16 * 64];
+  const int t = threadIdx.x, cl = t & 63, rg = t >> 6;
+  const int col = col0 + blockIdx.x * 64 + cl;
+  double acc = 0.0;
+  if (col < ncols)
+    for (int r = rg; r < m; r += 16) acc += Lb[(long)r * ld + col] * yb[r];
+  red[rg * 64 + cl] = acc;
+  __syncthreads();
+  if (t < 64 && col < ncols) {
+    double u = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) u += red[g * 64 + t];
+    w[col] -= u;
+  }
+}
+
+// dst[i] = map[i] >= 0 ? src[map[i]] : 0   (a leaf's border unknowns from the root's solution)
+__global__ void gather_map_kernel(const double* __restrict__ src, const int* __restrict__ map, double* __restrict__ dst, int m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) dst[i] = map ? (map[i] >= 0 ? src[map[i]] : 0.0) : src[i];
+}
+
+void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s) {
+  const int m = border_blocks * 128;
+  const long total = (long)m * m;
+  hipLaunchKernelGGL(border_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, root, ld_r, front + (long)ncols * 128 * ld_f + (long)ncols * 128, ld_f, m, map);
+}
+
+// Interior part of L^T y = z for a leaf front whose border unknowns are known.  yb: border unknowns (border_blocks * 128
+// values, zero where the border has padding or its right-hand-side row).  w: scratch (ncols * 128); y: interior solution.
+void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
+                              hipStream_t s, const int* last) {
+  const int ni = ncols * 128, m = (nblk - ncols) * 128;
+  if (ncols <= 0) return;
+  hipLaunchKernelGGL(copy_row_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, ni, ni);
+  // block rows' first non-zero block columns (the border rows: from the first interior column that reaches the border)
+  std::vector<int> first(nblk, 0);
+  int c0 = 0;
+  if (last)
+    for (int kb = 0; kb < nblk - 1; ++kb) {
+      while (c0 < kb && last[c0] < kb) ++c0;
+      first[kb] = c0;
+    }
+  const int bcol0 = std::min(first[ncols < nblk - 1 ? ncols : nblk - 1], ncols) * 128;
+  if (ni > bcol0)
+    hipLaunchKernelGGL(bs_border_kernel, dim3((ni - bcol0 + 63) / 64), dim3(1024), 0, s, S + (long)ncols * 128 * ld, ld, m, yb, w, bcol0, ni);
+  for (int kb = ncols - 1; kb >= 0; --kb) {
+    const int nc = kb * 128, col0 = first[kb] * 128;
+    const int grid = nc > col0 ? (nc - col0 + 63) / 64 : 1;
+    hipLaunchKernelGGL(bs_step_kernel, dim3(grid), dim3(1024), 0, s, Linv + (long)kb * 128 * 128, S + (long)kb * 128 * ld, ld, w, y, kb, col0, nc);
+  }
+}
+
+static void fork_join_events(CholeskyContext* c) {
+  if (!c->fork_ev) (void)hipEventCreateWithFlags(&c->fork_ev, g_event_flags);
+  if (!c->join_ev) (void)hipEventCreateWithFlags(&c->join_ev, g_event_flags);
+}
+
+void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, hipStream_t s, CholeskyContext* ctxA, CholeskyContext* ctxB,
+                               KernelTimer* kt, bool allow_chain) {
+  const bool side = d.B.ncols > 0 && ctxB && ctxB->fork;
+  if (d.B.ncols > 0) {
+    // the tail first: its launches are enqueued (and start) while the host is still enqueueing the head's
+    hipStream_t sB = s;
+    if (side) {
+      fork_join_events(ctxB);
+      (void)hipEventRecord(ctxB->fork_ev, s);
+      (void)hipStreamWaitEvent(ctxB->fork, ctxB->fork_ev, 0);
+      sB = ctxB->fork;
+    }
+    cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, sB, side ? ctxB : ctxA, kt, d.B.last, false, d.B.ncols);
+  }
+  if (d.A.ncols > 0) cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols);
+  if (side) {
+    (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
+    (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);
+  }
+  if (d.A.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.A.S, d.A.ld, d.A.ncols, d.border_blocks, nullptr, s);
+  if (d.B.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.B.S, d.B.ld, d.B.ncols, d.border_blocks, d.mapB, s);
+  cholesky_factor(d.R.S, d.R.ld, d.R.nblk * 128, d.R.Linv, info, group, s, ctxA, kt, d.R.last, allow_chain);
+}
+
+void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,
+                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt) {
+  cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last);
+  if (kt) kt->begin("backsolve", s);
+  const int m = d.border_blocks * 128;
+  const bool side = d.B.ncols > 0 && d.A.ncols > 0 && ctxB && ctxB->fork;
+  hipStream_t sB = s;
+  if (d.B.ncols > 0) {
+    if (side) {
+      fork_join_events(ctxB);
+      (void)hipEventRecord(ctxB->fork_ev, s);
+      (void)hipStreamWaitEvent(ctxB->fork, ctxB->fork_ev, 0);
+      sB = ctxB->fork;
+    }
+    cholesky_gather_map(yR, d.mapB, ybB, m, sB);
+    cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, ybB, wB, yB, sB, d.B.last);
+  }
+  // (yR is zero in the root's padding rows and in its right-hand-side row: it serves as A's border unknowns as it stands)
+  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last);
+  if (side) {
+    (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
+    (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);
+  }
+  if (kt) kt->end("backsolve", s);
+}
+
+void cholesky_gather_map(const double* src, const int* map, double* dst, int m, hipStream_t s) {
+  hipLaunchKernelGGL(gather_map_kernel, dim3((m + 255) / 256), dim3(256), 0, s, src, map, dst, m);
+}
+
 // H (tiles x tiles blocks of 128, lower) = A A^T, A row-major (tiles*128) x K, K a multiple of 16.
 // K = nslabs * Kc; slabs: nslabs x (tiles*128 x ldh) scratch (may be null when nslabs == 1: H is written directly).
 void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,
@@ -1705,12 +1906,14 @@ void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, in
 
 // Algorithmic flops of the dominant kernel's launches (part (b) of each trailing SYRK:
 // lower-triangular 128x128 tiles incl. the diagonal tiles, 2*128*128*K each).
-double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, double* c_tiles) {
+double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, double* c_tiles, int ncols) {
   const int nblk = npad / 128;
-  const CholeskyPlan plan = cholesky_plan(nblk, group, last, chain);
+  if (ncols < 0 || ncols > nblk) ncols = nblk;
+  const CholeskyPlan plan = cholesky_plan(nblk, group, last, chain, ncols);
   const std::vector<int>& gb = plan.bounds;
   double f = 0.0, tiles = 0.0;
   for (size_t g = 0; g + 2 < gb.size(); ++g) {
+    if (gb[g] >= ncols) break;
     const int k0 = gb[g], k1 = gb[g + 1], na = plan.resident[k0] ? 1 : gb[g + 2] - k1;  // as cholesky_factor splits next(g) / syrk(g)
     const int Lg = last ? (last[k1 - 1] < nblk - 1 ? last[k1 - 1] : nblk - 1) : nblk - 1;
     const int first_row = k1 + na;
@@ -1726,9 +1929,10 @@ double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, dou
 // Algorithmic flops of factoring the blocks inside the envelope (last == nullptr: every block): per block column with
 // h active block rows below it, 128^3 (1/3 + h + h^2) — diagonal factorisation, triangular solve of h blocks, symmetric
 // update of h (h + 1) / 2 blocks with its diagonal blocks counted once.  Sums to n^3 / 3 for a full matrix.
-double cholesky_plan_flops(int nblk, const int* last) {
+double cholesky_plan_flops(int nblk, const int* last, int ncols) {
   double f = 0.0;
-  for (int c = 0; c < nblk; ++c) {
+  if (ncols < 0 || ncols > nblk) ncols = nblk;
+  for (int c = 0; c < ncols; ++c) {
     const int lm = last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1;
     const int main_rows = lm >= c + 1 ? lm - c : 0;
     const double h = main_rows + ((c + 1 + main_rows <= nblk - 1 && lm < nblk - 1) ? 1 : 0);

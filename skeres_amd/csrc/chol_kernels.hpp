@@ -104,6 +104,12 @@ struct CholeskyContext {
   int* sync_for(int nblk);
   std::vector<hipEvent_t> events;
   hipError_t init();
+  // A second set of streams on the same device, for a factorisation that runs NEXT TO the primary context's (the tail
+  // front of a dissected system): the panel / bulk queues of the device's candidates that `primary` does not use, no
+  // resident server, and `fork`, a plain stream that stands in for the caller's stream.
+  hipError_t init_secondary(const CholeskyContext& primary);
+  hipStream_t fork = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   hipEvent_t event(size_t i);
   ~CholeskyContext();
 };
@@ -115,7 +121,7 @@ size_t potrf128_lds_bytes();
 // ctx == nullptr: everything on `s`; otherwise the panel chain overlaps the trailing SYRK.
 // allow_chain: the grouping is the library's to choose (cholesky_plan): resident panel chain for the chain-bound columns.
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt, const int* last = nullptr, bool allow_chain = false);
+                     KernelTimer* kt, const int* last = nullptr, bool allow_chain = false, int ncols = -1);
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
 bool cholesky_note_info(CholeskyContext* ctx, int info);
 bool cholesky_chain_enabled(const CholeskyContext* ctx);
@@ -123,12 +129,38 @@ struct CholeskyPlan {
   std::vector<int> bounds;  // group start columns + nblk
   std::vector<char> resident;  // per block column: under the resident panel chain
 };
-CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain);
+CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols = -1);
 int cholesky_plan_max_group(const CholeskyPlan& plan);
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
                         hipStream_t s, KernelTimer* kt, const int* last = nullptr);
-double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false, double* c_tiles = nullptr);
-double cholesky_plan_flops(int nblk, const int* last);
+// --- dissected factorisation (chol_kernels.hip, "Two-way dissection") ---
+struct FrontView {
+  double* S = nullptr; long ld = 0;   // row-major, lower triangle
+  int nblk = 0, ncols = 0;            // block rows; block columns that are factored (leaf: the interior; root: all)
+  const int* last = nullptr;          // block envelope (nblk entries) or nullptr
+  double* Linv = nullptr;             // ncols inverted diagonal blocks
+  int rhs_row = 0;                    // row that carries the right-hand side
+};
+struct DissectedSystem {
+  FrontView A, B, R;                  // head, tail (B.ncols == 0: none), root
+  int border_blocks = 0;              // block rows of the leaves' borders == R.nblk
+  const int* mapB = nullptr;          // device: B's border index -> root index (< 0: padding)
+};
+// Factor A and B side by side (B on ctxB's streams, launch by launch), add their Schur complements to the root, factor it.
+void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, hipStream_t s, CholeskyContext* ctxA, CholeskyContext* ctxB,
+                               KernelTimer* kt, bool allow_chain);
+// Solve: root, then the two interiors side by side.  yR / yA / yB: solutions in each front's own order; w*: scratch of the
+// fronts' sizes; ybB: scratch of border size.  The right-hand sides are the fronts' rhs rows after the factorisation.
+void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,
+                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt);
+// root += border x border block of a leaf front (front: ncols interior block columns, then border_blocks block rows);
+// map: root index of each border index (nullptr: identity; < 0: skip)
+void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s);
+void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
+                              hipStream_t s, const int* last);
+void cholesky_gather_map(const double* src, const int* map, double* dst, int m, hipStream_t s);
+double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false, double* c_tiles = nullptr, int ncols = -1);
+double cholesky_plan_flops(int nblk, const int* last, int ncols = -1);
 std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col);
 std::vector<int> cholesky_group_bounds(int nblk, int group);
 void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,

@@ -184,6 +184,35 @@ def test_factorisation_plans_vs_numpy(shape):
         assert np.linalg.norm(x - xnp) <= 1e-11 * np.linalg.norm(xnp), (shape, kw)
 
 
+@pytest.mark.parametrize("shape,head_block,automatic", [("band", 17, True), ("band", 17, False), ("band", 0, True), ("band", 33, True),
+                                                        ("resident-then-wide-then-resident", 45, True), ("odd-resident-run", 36, True),
+                                                        ("two-wide-parts", 29, True), ("two-wide-parts", 29, False)])
+def test_dissected_factorisation_vs_numpy(shape, head_block, automatic):
+    """Two-way dissection (chol_kernels.hip; sk_cholesky_solve_dissected): the head of a block-banded system eliminated
+    front to back and its tail back to front, side by side, the separator last — against numpy's solution of the whole
+    system.  Split points off the block grid, an empty head, and envelopes that take every regime of the plan."""
+    heights = _PLAN_SHAPES[shape]
+    nblk = len(heights) + 1
+    first_col = np.arange(nblk)
+    for c, h in enumerate(heights):
+        for r in range(c, min(nblk - 1, c + h + 1)):
+            first_col[r] = min(first_col[r], c)
+    last = _envelope_last(first_col)
+    n = 128 * nblk - 70
+    A = _banded_spd(n, last, seed=len(shape) + head_block)
+    b = np.random.default_rng(5).normal(size=n)
+    Af = A + np.tril(A, -1).T
+    xnp = np.linalg.solve(Af, b)
+    head = max(0, 128 * head_block - 37)
+    reach = int(np.max(np.nonzero(np.abs(A[:, :head]).sum(axis=1))[0])) if head > 0 else -1   # last row coupled with the head
+    for tail_begin in sorted({max(head, reach + 1), min(n, max(head, reach + 1) + 200), n}):
+        x = sk.api.cholesky_solve_dissected(A, b, head, tail_begin, group=0 if automatic else 2, automatic_plan=automatic)
+        assert np.linalg.norm(x - xnp) <= 1e-11 * np.linalg.norm(xnp), (shape, head, tail_begin, np.linalg.norm(x - xnp) / np.linalg.norm(xnp))
+    if head > 0 and reach + 1 < n:
+        with pytest.raises(sk.SkeresError):  # not a separator: the tail would couple with the head
+            sk.api.cholesky_solve_dissected(A, b, head, reach, group=2)
+
+
 def test_cholesky_mfma_layout_asymmetric():
     # A = L0 L0^T with an asymmetric integer-valued L0: a swapped row/col map in the
     # MFMA C/D layout cannot reproduce L0.
