@@ -300,6 +300,16 @@ int sk_options_set_cholesky_tuning(sk_options* o, int group, int lookahead);
  * full computation too, so at equal SYRK depth (sk_options_set_cholesky_tuning) the result is bit-identical to
  * on == 0, which factors every block. */
 int sk_options_set_cholesky_envelope(sk_options* o, int on);
+/* DENSE_SCHUR: two-way dissection of the camera sequence.  The block-banded reduced system of a camera sequence is a
+ * serial chain of one 128-block column after the other; the cameras are split into a head, a separator and a tail (no
+ * point seen from both head and tail), the head is eliminated front to back and the tail back to front, side by side
+ * on two sets of queues, and the separator's system — plus both Schur complements — is factored last: the same
+ * arithmetic in another elimination order (results agree with the undissected factorisation to rounding, not bit for
+ * bit), with a chain about half as long.  AUTO (default): when a model of the two chains predicts at least 10 % less
+ * time, with the library's own plan (no explicit `group`), the envelope on and one process; ON: whenever a separator
+ * exists (tests); OFF: never. */
+enum { SK_DISSECTION_AUTO = 0, SK_DISSECTION_ON = 1, SK_DISSECTION_OFF = 2 };
+int sk_options_set_cholesky_dissection(sk_options* o, int mode);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,
  * one per GPU.  Points (e-blocks) are partitioned over ranks; the
  * normal-equation terms are summed with `allreduce` once per linear solve.
@@ -384,6 +394,9 @@ int sk_solver_distribution(const sk_solver* s, double* allreduce_seconds, double
  *   "cholesky_flops_full"   n^3 / 3, n = 9 * cameras: SURVEY.md section 8(d)'s figure for phase C
  *   "cholesky_flops_plan"   flops of the factorisation as planned (potrf + TRSM + updates of the blocks inside the envelope)
  *   "cholesky_columns_resident"  block columns factored under the resident panel chain
+ *   "dissected"             1 when the camera sequence is dissected (sk_options_set_cholesky_dissection), with
+ *   "dissection_head_cameras" / "dissection_separator_cameras" / "dissection_tail_cameras" and the model's
+ *   "dissection_model_us_plain" / "dissection_model_us" (microseconds of factorisation it predicted either way)
  * dense rows (DENSE_NORMAL_CHOLESKY over one parameter block):
  *   "jtj_flops_algorithmic" m n (n + 1): SURVEY.md section 8(d)'s figure for J^T J (sk_solver_syrk_flops_per_solve counts
  *                           the padded 128 x 128 tiles the launch computes) */

@@ -140,6 +140,7 @@ _SIGS = {
     "sk_cholesky_solve_ex": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, C.c_int]),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_cholesky_dissection": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
     "sk_synth_dense_targets": (C.c_int, [C.c_double, C.c_int, C.c_int, _dp, _dp]),
     "sk_problem_point_partition": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip]),
@@ -1017,6 +1018,11 @@ class Solver:
         def setCholeskyEnvelope(self, on):
             """DENSE_SCHUR: factor only the blocks inside the reduced system's block envelope (default on; bit-identical)."""
             _check(lib().sk_options_set_cholesky_envelope(self._h, int(bool(on))))
+
+        def setCholeskyDissection(self, mode):
+            """DENSE_SCHUR: two-way dissection of the camera sequence: "auto" (default) / "on" / "off" (or 0 / 1 / 2)."""
+            mode = {"auto": 0, "on": 1, "off": 2}.get(mode, mode)
+            _check(lib().sk_options_set_cholesky_dissection(self._h, int(mode)))
 
         def setDistributionMode(self, mode):
             """0 auto (default), 1 sharded, 2 replicated: what a world > 1 does (include/skeres_amd.h)."""

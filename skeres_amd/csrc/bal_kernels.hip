@@ -27,6 +27,23 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Where the reduced camera system keeps block (camera i rows, camera j columns), i >= j, and the right-hand side of
+// camera i (BalDev::front).
+__device__ __forceinline__ int bal_part(const BalDev& d, int i) { return i < d.cam_a ? 0 : (i < d.cam_b ? 1 : 2); }
+__device__ __forceinline__ int bal_pos(const BalDev& d, int i, int part) { return 9 * (i - (part == 0 ? 0 : (part == 1 ? d.cam_a : d.cam_b))); }
+__device__ __forceinline__ double* bal_block(const BalDev& d, int i, int j, int* ld) {
+  const int pj = bal_part(d, j), pi = bal_part(d, i);
+  const BalDev::Front& f = d.front[pj];
+  const int row = pi == pj ? bal_pos(d, i, pi) : f.interior + (pj == 1 ? 9 * (d.C - 1 - i) : 9 * (i - d.cam_b));
+  *ld = f.ld;
+  return f.S + (size_t)row * f.ld + bal_pos(d, j, pj);
+}
+__device__ __forceinline__ double* bal_rhs(const BalDev& d, int i) {
+  const int pi = bal_part(d, i);
+  const BalDev::Front& f = d.front[pi];
+  return f.S + (size_t)((pi == 2 ? 0 : f.interior) + d.rhs_off) * f.ld + bal_pos(d, i, pi);
+}
+
 // Block-level sum of up to 4 values; result valid in thread 0.
 // The per-point kernels give a point kPointLanes adjacent lanes, which take its observations in turn and are summed
 // in a fixed tree: with a lane per point, the points seen by a hundred cameras set the length of the whole launch
@@ -499,12 +516,14 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) rh[k] = wave_sum(rh[k]);
   if (lane == 0) {
-    int k = 0;
+    int k = 0, ld;
+    double* blk = bal_block(d, i, i, &ld);
+    double* rhs = bal_rhs(d, i);
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      d.S[(size_t)d.rhs_row * d.ld + 9 * i + c] = rh[c];
+      rhs[c] = rh[c];
 #pragma unroll
-      for (int e2 = 0; e2 <= c; ++e2, ++k) d.S[(size_t)(9 * i + c) * d.ld + 9 * i + e2] = acc[k];
+      for (int e2 = 0; e2 <= c; ++e2, ++k) blk[(size_t)c * ld + e2] = acc[k];
     }
   }
 }
@@ -544,7 +563,8 @@ __global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d) {
   for (int k = 0; k < 9; ++k) acc[k] = 0.0;
   pair_accumulate(d, d.seg_start[seg], d.seg_start[seg + 1], 1, c, acc);
   const int i = d.seg_row[seg], j = d.seg_col[seg];
-  double* out = d.S + (size_t)(9 * i + c) * d.ld + 9 * j;
+  int ld;
+  double* out = bal_block(d, i, j, &ld) + (size_t)c * ld;
 #pragma unroll
   for (int k = 0; k < 9; ++k) out[k] = -acc[k];
 }
@@ -572,23 +592,45 @@ __global__ __launch_bounds__(kBlock) void bal_pair_long_kernel(BalDev d) {
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
   __builtin_amdgcn_wave_barrier();
   const int i = d.seg_row[seg], j = d.seg_col[seg];
+  int ld;
+  double* blk = bal_block(d, i, j, &ld);
   for (int e = lane; e < 81; e += 64) {
     double s = 0.0;
 #pragma unroll
     for (int g = 0; g < 7; ++g) s += red[w][g][e];
-    d.S[(size_t)(9 * i + e / 9) * d.ld + 9 * j + e % 9] = -s;
+    blk[(size_t)(e / 9) * ld + e % 9] = -s;
   }
 }
 
 // After the (optional) all-reduce: add D_c^2 on the diagonal, make the padded
 // tail of S an identity and give the augmented rhs row a huge diagonal so the
 // factorisation stays positive definite (its own diagonal entry is unused).
-__global__ void bal_finish_S_kernel(double* S, int ld, int n, int npad, int rhs_row, const double* D_c) {
+// the same for a single dense normal matrix (dense paths): D^2 on the diagonal, identity on the padded tail, a huge
+// diagonal for the augmented right-hand-side row
+__global__ void finish_normal_matrix_kernel(double* S, int ld, int n, int npad, int rhs_row, const double* D) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= npad) return;
-  if (j < n) S[(size_t)j * ld + j] += D_c[j] * D_c[j];
+  if (j < n) S[(size_t)j * ld + j] += D[j] * D[j];
   else if (j == rhs_row) S[(size_t)j * ld + j] = 1e300;
   else S[(size_t)j * ld + j] = 1.0;
+}
+__global__ void bal_finish_S_kernel(BalDev d) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 9 * d.C) return;
+  const int i = j / 9, c = j - 9 * i;
+  int ld;
+  double* blk = bal_block(d, i, i, &ld);
+  blk[(size_t)c * ld + c] += d.D_c[j] * d.D_c[j];
+}
+__global__ void set_diagonal_kernel(double* S, int ld, int from, int to, double value) {
+  const int j = from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < to) S[(size_t)j * ld + j] = value;
+}
+__global__ void bal_gather_y_kernel(BalDev d) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 9 * d.C) return;
+  const int i = j / 9, c = j - 9 * i, part = bal_part(d, i);
+  d.y_c[j] = d.y_front[part][bal_pos(d, i, part) + c];
 }
 
 // ---------------------------------------------------------------------------
@@ -758,7 +800,12 @@ void launch_bal_pair(const BalDev& d, hipStream_t s) {
     hipLaunchKernelGGL(bal_pair_kernel, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
   }
 }
-void launch_bal_finish_S(double* S, int ld, int n, int npad, int rhs_row, const double* D_c, hipStream_t s) { hipLaunchKernelGGL(bal_finish_S_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, n, npad, rhs_row, D_c); }
+void launch_finish_normal_matrix(double* S, int ld, int n, int npad, int rhs_row, const double* D, hipStream_t s) { hipLaunchKernelGGL(finish_normal_matrix_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, n, npad, rhs_row, D); }
+void launch_bal_finish_S(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_finish_S_kernel, dim3((9 * d.C + 255) / 256), dim3(256), 0, s, d); }
+void launch_set_diagonal(double* S, int ld, int from, int to, double value, hipStream_t s) {
+  if (to > from) hipLaunchKernelGGL(set_diagonal_kernel, dim3((to - from + 255) / 256), dim3(256), 0, s, S, ld, from, to, value);
+}
+void launch_bal_gather_y(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_gather_y_kernel, dim3((9 * d.C + 255) / 256), dim3(256), 0, s, d); }
 int launch_bal_point_backsub(const BalDev& d, hipStream_t s) {
   const int g = bal_point_blocks(d.P);
   hipLaunchKernelGGL(bal_obs_backsub_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);

@@ -41,8 +41,19 @@ struct BalDev {
   double* r;  double* F;  double* E;  double* What;  double* rt;
   // per-point
   double* M;  double* q;
-  // reduced camera system, row-major npad x ld, lower triangle; rhs in row rhs_row
-  double* S;  int ld;  int rhs_row;
+  // Reduced camera system: up to three dense row-major matrices ("fronts", chol_kernels.hip "Two-way dissection"), lower
+  // triangles.  Cameras are numbered head [0, cam_a), tail [cam_a, cam_b) (in ITS elimination order: back to front along
+  // the sequence), separator [cam_b, C).  Block (i, j), i >= j, lives in the front of camera j's part — head 0, tail 1,
+  // separator 2 (the root) — at column 9 (j - first camera of the part); its rows are camera i's interior rows when i is in
+  // the same part, else (i in the separator) rows of the leaf's border: interior + 9 (i - cam_b) in the head's front,
+  // interior + 9 (C - 1 - i) in the tail's (border in reverse camera order).  The right-hand side of a part's cameras is
+  // the row `rhs_off` of the border (of the root itself for the separator).  Without dissection cam_a == cam_b == 0:
+  // every camera is "separator", front[2] is the whole system and rhs_off == 9 C.
+  struct Front { double* S; int ld; int interior; };
+  Front front[3];
+  int cam_a, cam_b, rhs_off;
+  const double* y_front[3];  // the fronts' solutions (interior order) -> y_c (bal_gather_y)
+  double* S;  int ld;  int rhs_row;  // == front[2] when the system is not dissected (the all-reduce packs this one)
   // reductions
   double* partial;  int partial_stride;
   int* fail_flag;
@@ -83,7 +94,10 @@ void launch_bal_point_block(const BalDev& d, hipStream_t s);
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s);
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s);
 void launch_bal_pair(const BalDev& d, hipStream_t s);
-void launch_bal_finish_S(double* S, int ld, int n, int npad, int rhs_row, const double* D_c, hipStream_t s);
+void launch_finish_normal_matrix(double* S, int ld, int n, int npad, int rhs_row, const double* D, hipStream_t s);
+void launch_bal_finish_S(const BalDev& d, hipStream_t s);  // D_c^2 onto the cameras' diagonal entries
+void launch_set_diagonal(double* S, int ld, int from, int to, double value, hipStream_t s);  // S[j][j] = value, from <= j < to
+void launch_bal_gather_y(const BalDev& d, hipStream_t s);  // y_c[9 i + k] from the fronts' solutions
 int launch_bal_point_backsub(const BalDev& d, hipStream_t s);
 void launch_bal_cam_step(const BalDev& d, double* out, hipStream_t s);
 

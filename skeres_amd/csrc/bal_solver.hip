@@ -78,34 +78,60 @@ namespace {
 class BalSolver : public SolverBase {
  public:
   BalSolver(const Options& o, Problem* p) : SolverBase(o, p) {}
-  double syrk_flops_per_solve() const override { return cholesky_syrk_flops(npad_, group_, env_last_.empty() ? nullptr : env_last_.data(), chain_ok()); }
+  // over the fronts of the reduced system (one when it is not dissected); the tail front is factored launch by launch
+  double syrk_flops_per_solve() const override {
+    double f = 0.0;
+    for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && k != 1, nullptr, fr_[k].ncols);
+    return f;
+  }
   double syrk_c_bytes_per_solve() const override {
     double tiles = 0.0;
-    (void)cholesky_syrk_flops(npad_, group_, env_last_.empty() ? nullptr : env_last_.data(), chain_ok(), &tiles);
+    for (int k = 0; k < 3; ++k) {
+      double t = 0.0;
+      if (fr_[k].nblk > 0) (void)cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && k != 1, &t, fr_[k].ncols);
+      tiles += t;
+    }
     return tiles * 2.0 * 128.0 * 128.0 * sizeof(double);
   }
   bool stat(const std::string& name, double* value) const override {
     const int nblk = npad_ / 128;
-    const int* env = env_last_.empty() ? nullptr : env_last_.data();
-    if (name == "envelope_fill") {
+    if (name == "envelope_fill") {  // 128-blocks that are factored or updated, over the lower triangle of the undissected system
       double in = 0.0;
-      for (int c = 0; c < nblk; ++c) {
-        const int lm = env ? std::min(env[c], nblk - 1) : nblk - 1;
-        in += (lm - c + 1) + (lm < nblk - 1 ? 1 : 0);  // the run from the diagonal block down, and the right-hand-side row
+      for (int k = 0; k < 3; ++k) {
+        const FrontHost& F = fr_[k];
+        const int* env = F.env();
+        for (int c = 0; c < F.ncols; ++c) {
+          const int lm = env ? std::min(env[c], F.nblk - 1) : F.nblk - 1;
+          in += (lm - c + 1) + (lm < F.nblk - 1 ? 1 : 0);  // the run from the diagonal block down, and the right-hand-side row
+        }
       }
       *value = in / (0.5 * nblk * (nblk + 1.0));
       return true;
     }
     if (name == "camera_order") { *value = camera_order_; return true; }
     if (name == "cholesky_flops_full") { const double n = 9.0 * C_; *value = n * n * n / 3.0; return true; }
-    if (name == "cholesky_flops_plan") { *value = cholesky_plan_flops(nblk, env); return true; }
+    if (name == "cholesky_flops_plan") {
+      double f = 0.0;
+      for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_plan_flops(fr_[k].nblk, fr_[k].env(), fr_[k].ncols);
+      *value = f;
+      return true;
+    }
     if (name == "cholesky_columns_resident") {
-      const CholeskyPlan plan = cholesky_plan(nblk, group_, env, chain_ok());
       int r = 0;
-      for (char c : plan.resident) r += c ? 1 : 0;
+      for (int k = 0; k < 3; ++k) {
+        if (fr_[k].nblk == 0) continue;
+        const CholeskyPlan plan = cholesky_plan(fr_[k].nblk, group_, fr_[k].env(), chain_ok() && k != 1, fr_[k].ncols);
+        for (char c : plan.resident) r += c ? 1 : 0;
+      }
       *value = r;
       return true;
     }
+    if (name == "dissected") { *value = dissected_ ? 1.0 : 0.0; return true; }
+    if (name == "dissection_head_cameras") { *value = cam_a_; return true; }
+    if (name == "dissection_tail_cameras") { *value = cam_b_ - cam_a_; return true; }
+    if (name == "dissection_separator_cameras") { *value = dissected_ ? C_ - cam_b_ : 0; return true; }
+    if (name == "dissection_model_us_plain") { *value = dissect_t_plain_; return true; }
+    if (name == "dissection_model_us") { *value = dissect_t_model_; return true; }
     return false;
   }
   // the grouping is the library's choice (Options::cholesky_group == 0) and the masked streams of the resident panel chain exist
@@ -150,15 +176,31 @@ class BalSolver : public SolverBase {
   std::vector<int> local_pt_;                 // global point id of local point
   BalDev d_{};
   DevBuf<LossNode> b_loss_nodes_;
-  DevBuf<int> b_zero_col0_;
   DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_, b_fail_, b_info_;
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
+  // The reduced camera system as fronts (BalDev::front): 0 head, 1 tail, 2 root.  Not dissected: only the root, which is
+  // then the whole system.  Each front is a dense dim x dim matrix inside b_S_.
+  struct FrontHost {
+    int nblk = 0, ncols = 0, cams = 0;   // block rows; block columns factored here; cameras eliminated here
+    size_t dim = 0, s_off = 0, linv_off = 0, y_off = 0;
+    int rhs_row = 0;
+    std::vector<int> last;               // block envelope (empty: dense)
+    const int* env() const { return last.empty() ? nullptr : last.data(); }
+  };
+  FrontHost fr_[3];
+  bool dissected_ = false;
+  int cam_a_ = 0, cam_b_ = 0, border_blocks_ = 0;
+  double dissect_t_plain_ = 0.0, dissect_t_model_ = 0.0;
+  DissectedSystem ds_;
+  CholeskyContext chol_ctx_b_;
+  DevBuf<int> b_zero_col0_f_[3], b_mapB_;
+  DevBuf<double> b_yf_, b_wf_, b_ybB_;
   double order_hash_ = 0.0;    // of the camera order and the envelope: equal on every rank, or setup() fails
   int camera_order_ = 0;       // which candidate order of the cameras was kept (0 first appearance, 1 memory, 2 RCM)
   int group_ = 3;              // SYRK depth actually used (Options::cholesky_group, or chosen from the envelope)
-  DevBuf<double> b_w_, b_pack_;
+  DevBuf<double> b_pack_;
   size_t packed_elems_ = 0;
   int distribution_ = SK_DISTRIBUTION_SHARDED;
   double est_allreduce_s_ = 0.0, est_saved_s_ = 0.0;
@@ -178,7 +220,7 @@ class BalSolver : public SolverBase {
 // caller uses the reference's layout, EX/SimpleBundleAdjuster.scala:18-34), and reverse Cuthill-McKee on the
 // co-visibility graph.  The one with the fewest trailing-update flops wins; ties keep the earlier candidate.
 static std::vector<int> envelope_of_order(const std::vector<int>& ocam, const std::vector<int>& opt, const std::vector<int>& new_id, int C, int P,
-                                          int nblk) {
+                                          int nblk, std::vector<int>* first_col_out = nullptr) {
   std::vector<int> cmin(P, C);
   for (size_t b = 0; b < ocam.size(); ++b) cmin[opt[b]] = std::min(cmin[opt[b]], new_id[ocam[b]]);
   std::vector<int> first_col(nblk);
@@ -186,6 +228,75 @@ static std::vector<int> envelope_of_order(const std::vector<int>& ocam, const st
   for (size_t b = 0; b < ocam.size(); ++b) {  // camera c shares point opt[b] with camera cmin: block (rows of c, columns of cmin)
     const int c = new_id[ocam[b]], col = (9 * cmin[opt[b]]) / 128;
     for (int row = (9 * c) / 128; row <= (9 * c + 8) / 128; ++row) first_col[row] = std::min(first_col[row], col);
+  }
+  if (first_col_out) *first_col_out = first_col;
+  return cholesky_envelope_last(first_col);
+}
+
+// ---- two-way dissection of the camera sequence (chol_kernels.hip, "Two-way dissection") ---------------------------------
+// Cameras in the chosen (banded) order: head [0, a), separator [a, b), tail [b, C), with no point seen from both the head
+// and the tail: b = 1 + the last camera that shares a point with a camera before a.  The head is eliminated front to back
+// and the tail back to front, side by side, so the serial panel chain is about half as long.  Where to cut is decided
+// by a model of the two chains (microseconds per block column; constants measured on MI355X, profiles/r02_*): a block
+// column costs the larger of its panel chain and its trailing update.
+struct Dissection { int a = 0, b = 0; double t_plain = 0.0, t_dissected = 0.0; };
+static double column_cost_us(int h, bool resident_capable) {
+  const double update_us = 128.0 * 128.0 * 128.0 * ((double)h * h + h) / 35e6 + (h > 24 ? 20.0 : 0.0);  // 35 TFLOP/s, launch gaps of the wide columns
+  const double chain_us = (resident_capable && h <= 24) ? 42.0 : 70.0;
+  return std::max(update_us, chain_us);
+}
+static Dissection choose_dissection(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
+                                    const std::vector<int>& first_col) {
+  Dissection d;
+  if (C < 64 || nblk < 24) return d;
+  // reach[c]: the last camera that shares a point with any camera <= c (cameras in the chosen order)
+  std::vector<int> cmin(P, C), cmax(P, -1), reach(C);
+  for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); }
+  for (int c = 0; c < C; ++c) reach[c] = c;
+  for (int q = 0; q < P; ++q) if (cmax[q] >= 0) reach[cmin[q]] = std::max(reach[cmin[q]], cmax[q]);
+  for (int c = 1; c < C; ++c) reach[c] = std::max(reach[c], reach[c - 1]);
+  // per block column: height forward (rows below, as the envelope has it) and backward (rows above: the tail's view)
+  std::vector<double> fwd(nblk), bwd(nblk), fwd_sum(nblk + 1, 0.0), bwd_sum(nblk + 1, 0.0);
+  std::vector<int> fc(first_col);
+  for (int i = nblk - 2; i >= 0; --i) fc[i] = std::min(fc[i], fc[i + 1] < i + 1 ? fc[i + 1] : i);  // (monotone, as the backward envelope is)
+  for (int c = 0; c < nblk; ++c) {
+    const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0);
+    fwd[c] = column_cost_us(hf, true);
+    bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1, false);
+    d.t_plain += fwd[c];
+  }
+  for (int c = 0; c < nblk; ++c) { fwd_sum[c + 1] = fwd_sum[c] + fwd[c]; bwd_sum[c + 1] = bwd_sum[c] + bwd[c]; }
+  double best = d.t_plain;
+  for (int a = 14; a + 14 < C; a += 7) {
+    const int b = reach[a - 1] + 1;
+    if (b >= C - 14) break;
+    const int ca = (9 * a + 127) / 128, cb = (9 * b) / 128, E = (9 * (b - a) + 1 + 127) / 128;
+    if (E > 40) continue;  // a separator that wide is no separator
+    double root = 0.0;
+    for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i, true);
+    const double t = std::max(fwd_sum[ca], bwd_sum[nblk] - bwd_sum[cb]) + root + 120.0;  // + fork, join, border add
+    if (t < best) { best = t; d.a = a; d.b = b; }
+  }
+  d.t_dissected = best;
+  if (best > 0.9 * d.t_plain) { d.a = d.b = 0; }
+  return d;
+}
+
+// Block envelope of one front: `pos[c]` is camera c's first row in the front (interior or border), -1 when the camera has
+// no rows in it; `interior[c]` whether its columns are eliminated in this front.  Only points that touch an interior
+// camera shape the envelope (the border x border block is the Schur complement's, covered by the last columns' reach).
+static std::vector<int> front_envelope(const std::vector<int>& ocam, const std::vector<int>& opt, const std::vector<int>& pos, const std::vector<char>& interior,
+                                       int P, int nblk) {
+  const int kNone = 1 << 30;
+  std::vector<int> minpos(P, kNone);
+  for (size_t b = 0; b < ocam.size(); ++b) if (interior[ocam[b]]) minpos[opt[b]] = std::min(minpos[opt[b]], pos[ocam[b]]);
+  std::vector<int> first_col(nblk);
+  for (int i = 0; i < nblk; ++i) first_col[i] = i;
+  for (size_t b = 0; b < ocam.size(); ++b) {
+    const int c = ocam[b];
+    if (pos[c] < 0 || minpos[opt[b]] == kNone) continue;
+    const int col = minpos[opt[b]] / 128;
+    for (int row = pos[c] / 128; row <= (pos[c] + 8) / 128; ++row) first_col[row] = std::min(first_col[row], std::min(col, row));
   }
   return cholesky_envelope_last(first_col);
 }
@@ -294,6 +405,25 @@ int BalSolver::setup() {
   bal_index_problem(p, &cam_block_, &pt_block_, &ocam, &opt);
   C_ = (int)cam_block_.size(); P_total_ = (int)pt_block_.size();
   n_ = 9 * C_; rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
+  SK_HIP_TRY(cholesky_init());
+  if (opt_.lookahead && chol_ctx_.init() != hipSuccess) {  // CU-masked streams unavailable: plain in-order factorisation
+    (void)hipGetLastError();
+    opt_.lookahead = false;
+  }
+  // ---- multi-GPU: shard the points, or replicate? (before the camera order: a replicated world is
+  // world-many single-GPU solves, each free to order and dissect for itself) ----
+  packed_elems_ = tri_packed_elems(npad_ / 128);
+  if (opt_.allreduce) {
+    if (opt_.reduce_buffer) {
+      if (opt_.reduce_buffer_bytes < packed_elems_ * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", packed_elems_ * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
+      b_pack_.adopt(static_cast<double*>(opt_.reduce_buffer), packed_elems_);
+    } else {
+      SK_HIP_TRY(b_pack_.alloc(packed_elems_));
+    }
+    SK_HIP_TRY(b_pack_.zero(stream_));
+    int rc = choose_distribution(opt);
+    if (rc) return rc;
+  }
   // ---- camera order + block envelope of the reduced system (all ranks' observations: the all-reduced S has the union structure).
   // The order is chosen the same way whether or not the envelope is then used (opt_.envelope), so that the two
   // settings differ in nothing but the blocks they skip and give bit-identical results. ----
@@ -331,6 +461,48 @@ int BalSolver::setup() {
     for (int& c : ocam) c = id[c];
     const double full = cholesky_syrk_flops(npad_, 1, nullptr);
     group_ = opt_.group_or(opt_.envelope && best < 0.5 * full ? 1 : 3);
+    // ---- dissect? (one process, library's own plan, CU-masked stream sets available) ----
+    const bool may_dissect = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && !opt_.allreduce && opt_.lookahead && opt_.cholesky_group == 0 &&
+                             chol_ctx_b_.init_secondary(chol_ctx_) == hipSuccess;
+    if (!may_dissect) (void)hipGetLastError();
+    if (may_dissect) {
+      std::vector<int> first_col;
+      (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
+      Dissection ds = choose_dissection(ocam, opt, C_, P_total_, nblk, best_env, first_col);
+      if (opt_.dissection == SK_DISSECTION_ON && ds.a == 0 && C_ >= 6) {
+        // forced (tests): cut at the middle camera wherever that leaves a tail
+        std::vector<int> cmin(P_total_, C_), cmax(P_total_, -1);
+        for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); }
+        for (int a = C_ / 2; a >= 1 && ds.a == 0; --a) {
+          int b = a;
+          for (int q = 0; q < P_total_; ++q) if (cmin[q] < a) b = std::max(b, cmax[q] + 1);
+          if (b < C_) { ds.a = a; ds.b = b; }
+        }
+      }
+      if (const char* e = getenv("SK_DISSECT_AT")) {  // developer knob: head size in cameras (0: no dissection)
+        ds.a = atoi(e); ds.b = 0;
+        if (ds.a > 0 && ds.a < C_) {
+          ds.b = ds.a;
+          std::vector<int> cmin(P_total_, C_);
+          for (size_t b = 0; b < ocam.size(); ++b) cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]);
+          for (size_t b = 0; b < ocam.size(); ++b) if (cmin[opt[b]] < ds.a) ds.b = std::max(ds.b, ocam[b] + 1);
+          if (ds.b >= C_) ds.a = ds.b = 0;
+        } else ds.a = 0;
+      }
+      dissect_t_plain_ = ds.t_plain; dissect_t_model_ = ds.t_dissected;
+      if (ds.a > 0 && ds.b < C_) {
+        dissected_ = true;
+        // final numbering: head [0, a) as it is, tail [b, C) REVERSED to [a, a + C - b), separator [a, b) last
+        const int a = ds.a, b = ds.b, nt = C_ - b;
+        std::vector<int> fin(C_);
+        for (int c = 0; c < C_; ++c) fin[c] = c < a ? c : (c >= b ? a + (C_ - 1 - c) : a + nt + (c - a));
+        std::vector<int> cb2(C_);
+        for (int c = 0; c < C_; ++c) cb2[fin[c]] = cam_block_[c];
+        cam_block_.swap(cb2);
+        for (int& c : ocam) c = fin[c];
+        cam_a_ = a; cam_b_ = a + nt;
+      }
+    }
     if (opt_.envelope) env_last_.swap(best_env);
     if (getenv("SK_DEBUG_ENVELOPE") && opt_.envelope) {
       long h = 0;
@@ -338,19 +510,6 @@ int BalSolver::setup() {
       std::fprintf(stderr, "[skeres_amd] camera order %d (0 first appearance, 1 memory, 2 RCM); envelope: %d block columns, mean height %.1f; "
                    "trailing-update flops %.3e (full %.3e)\n", best_k, nblk, (double)h / nblk, best, full);
     }
-  }
-  // ---- multi-GPU: shard the points, or replicate? ----
-  packed_elems_ = tri_packed_elems(npad_ / 128);
-  if (opt_.allreduce) {
-    if (opt_.reduce_buffer) {
-      if (opt_.reduce_buffer_bytes < packed_elems_ * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", packed_elems_ * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
-      b_pack_.adopt(static_cast<double*>(opt_.reduce_buffer), packed_elems_);
-    } else {
-      SK_HIP_TRY(b_pack_.alloc(packed_elems_));
-    }
-    SK_HIP_TRY(b_pack_.zero(stream_));
-    int rc = choose_distribution(opt);
-    if (rc) return rc;
   }
   int p_lo = 0, p_hi = P_total_;
   if (opt_.world > 1) {
@@ -445,42 +604,77 @@ int BalSolver::setup() {
     SK_HIP_TRY(hipMemcpyAsync(b_scale_.p, free_mask.data(), nx * sizeof(double), hipMemcpyHostToDevice, s));
     SK_HIP_TRY(hipStreamSynchronize(s));
   }
-  SK_HIP_TRY(b_y_.alloc(npad_));
+  SK_HIP_TRY(b_y_.alloc(npad_ + 128));
   SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
   SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
-  SK_HIP_TRY(b_S_.alloc((size_t)npad_ * npad_));
-  SK_HIP_TRY(cholesky_init());
-  if (opt_.lookahead && chol_ctx_.init() != hipSuccess) {  // CU-masked streams unavailable: plain in-order factorisation
-    (void)hipGetLastError();
-    opt_.lookahead = false;
+  // ---- the fronts of the reduced camera system ----
+  if (!dissected_) {
+    FrontHost& r = fr_[2];
+    r.nblk = r.ncols = npad_ / 128; r.cams = C_; r.dim = (size_t)npad_; r.rhs_row = rhs_row_; r.last = env_last_;
+    border_blocks_ = 0;
+  } else {
+    const int nsep = C_ - cam_b_, ncam[2] = {cam_a_, cam_b_ - cam_a_};
+    border_blocks_ = (9 * nsep + 1 + 127) / 128;
+    for (int f = 0; f < 2; ++f) {
+      FrontHost& L = fr_[f];
+      L.cams = ncam[f]; L.ncols = (9 * ncam[f] + 127) / 128; L.nblk = L.ncols + border_blocks_; L.dim = (size_t)L.nblk * 128;
+      L.rhs_row = L.ncols * 128 + 9 * nsep;
+      // rows of every camera in this front: its own interior, or (separator) the border — in reverse camera order for the tail
+      std::vector<int> pos(C_, -1);
+      std::vector<char> interior(C_, 0);
+      const int base = f == 0 ? 0 : cam_a_;
+      for (int c = base; c < base + ncam[f]; ++c) { pos[c] = 9 * (c - base); interior[c] = 1; }
+      for (int c = cam_b_; c < C_; ++c) pos[c] = L.ncols * 128 + (f == 0 ? 9 * (c - cam_b_) : 9 * (C_ - 1 - c));
+      L.last = front_envelope(ocam, opt, pos, interior, P_total_, L.nblk);
+    }
+    FrontHost& r = fr_[2];
+    r.nblk = r.ncols = border_blocks_; r.cams = nsep; r.dim = (size_t)border_blocks_ * 128; r.rhs_row = 9 * nsep;  // dense
   }
-  if (chain_ok()) cholesky_prepare(&chol_ctx_, s);  // (once per process: which queues the resident panel chain uses)
-  SK_HIP_TRY(b_S_.zero(s));  // once: the blocks outside the envelope are never touched again
   {
+    size_t s_off = 0, linv_off = 0, y_off = 0;
+    for (int f = 0; f < 3; ++f) {
+      fr_[f].s_off = s_off; fr_[f].linv_off = linv_off; fr_[f].y_off = y_off;
+      s_off += fr_[f].dim * fr_[f].dim; linv_off += (size_t)fr_[f].ncols * 128 * 128; y_off += fr_[f].dim;
+    }
+    SK_HIP_TRY(b_S_.alloc(s_off));
+    SK_HIP_TRY(b_Linv_.alloc(linv_off)); SK_HIP_TRY(b_Linv_.zero(s));
+    SK_HIP_TRY(b_yf_.alloc(y_off)); SK_HIP_TRY(b_yf_.zero(s)); SK_HIP_TRY(b_wf_.alloc(y_off)); SK_HIP_TRY(b_ybB_.alloc((size_t)std::max(1, border_blocks_) * 128));
+  }
+  if (chain_ok()) cholesky_prepare(&chol_ctx_, s);  // (once per device: which queues the resident panel chain uses)
+  if (dissected_) SK_HIP_TRY(chol_ctx_b_.init_secondary(chol_ctx_));  // (again, now that the queue choice is made: the queues it left over)
+  SK_HIP_TRY(b_S_.zero(s));  // once: the blocks outside the envelopes are never touched again
+  for (int f = 0; f < 3; ++f) {
     // first block column each block row is zeroed from: the row envelope, widened by the SYRK depth - 1 (inside a
     // group, the lazy updates read every column of the group down to the LAST column's envelope) — and the whole
     // width for the last block row (right-hand side) and without an envelope
-    const int nblk = npad_ / 128;
-    std::vector<int> col0(nblk, 0);
+    const FrontHost& F = fr_[f];
+    if (F.nblk == 0) continue;
+    std::vector<int> col0(F.nblk, 0);
     // the widest group of either way to factor (with / without the resident chain, which a timing mode switches off)
-    const int widen = env_last_.empty() ? 1 : std::max(group_, cholesky_plan_max_group(cholesky_plan(nblk, group_, env_last_.data(), chain_ok())));
-    if (!env_last_.empty()) {
+    const bool chain_here = chain_ok() && f != 1;
+    const int widen = F.last.empty() ? 1 : std::max(group_, cholesky_plan_max_group(cholesky_plan(F.nblk, group_, F.last.data(), chain_here, F.ncols)));
+    if (!F.last.empty()) {
       int c = 0;
-      for (int i = 0; i + 1 < nblk; ++i) {
-        while (c < i && env_last_[c] < i) ++c;
+      for (int i = 0; i + 1 < F.nblk; ++i) {
+        while (c < i && F.last[c] < i) ++c;
         col0[i] = std::max(0, c - (widen - 1));
       }
     }
-    SK_HIP_TRY(b_zero_col0_.upload(col0, s));
+    SK_HIP_TRY(b_zero_col0_f_[f].upload(col0, s));
   }
-  SK_HIP_TRY(b_Linv_.alloc((size_t)npad_ * 128)); SK_HIP_TRY(b_Linv_.zero(s));
+  if (dissected_) {
+    const int nsep = C_ - cam_b_;
+    std::vector<int> mapB((size_t)border_blocks_ * 128, -1);
+    for (int k = 0; k < nsep; ++k) for (int c = 0; c < 9; ++c) mapB[9 * k + c] = 9 * (nsep - 1 - k) + c;  // camera order reversed, coordinates in order
+    mapB[9 * nsep] = 9 * nsep;  // right-hand-side row
+    SK_HIP_TRY(b_mapB_.upload(mapB, s));
+  }
   partial_stride_ = std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_)), 256) + bal_partial_blocks((int)host_obs_.size());
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
   SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
   SK_HIP_TRY(b_fail_.alloc(1)); SK_HIP_TRY(b_fail_.zero(s)); SK_HIP_TRY(b_info_.alloc(1)); SK_HIP_TRY(b_info_.zero(s));
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
-  SK_HIP_TRY(b_w_.alloc(npad_));
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p;
@@ -491,7 +685,22 @@ int BalSolver::setup() {
   d_.scale_c = b_scale_.p; d_.scale_p = b_scale_.p + nc; d_.colsq_c = b_colsq_.p; d_.colsq_p = b_colsq_.p + nc;
   d_.gs_c = b_gs_.p; d_.gs_p = b_gs_.p + nc; d_.D_c = b_D_.p; d_.D_p = b_D_.p + nc; d_.step_c = b_step_.p; d_.step_p = b_step_.p + nc;
   d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.rt = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
-  d_.S = b_S_.p; d_.ld = npad_; d_.rhs_row = rhs_row_; d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = b_fail_.p;
+  for (int f = 0; f < 3; ++f) {
+    d_.front[f].S = b_S_.p + fr_[f].s_off; d_.front[f].ld = (int)fr_[f].dim; d_.front[f].interior = fr_[f].ncols * 128;
+    d_.y_front[f] = b_yf_.p + fr_[f].y_off;
+  }
+  d_.cam_a = cam_a_; d_.cam_b = cam_b_; d_.rhs_off = fr_[2].rhs_row;
+  d_.S = d_.front[2].S; d_.ld = d_.front[2].ld; d_.rhs_row = fr_[2].rhs_row;
+  if (dissected_) {
+    auto view = [&](int f) {
+      FrontView v;
+      v.S = d_.front[f].S; v.ld = (long)fr_[f].dim; v.nblk = fr_[f].nblk; v.ncols = fr_[f].ncols; v.last = fr_[f].env();
+      v.Linv = b_Linv_.p + fr_[f].linv_off; v.rhs_row = fr_[f].rhs_row;
+      return v;
+    };
+    ds_.A = view(0); ds_.B = view(1); ds_.R = view(2); ds_.border_blocks = border_blocks_; ds_.mapB = b_mapB_.p;
+  }
+  d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = b_fail_.p;
   d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0];
   if (d_.loss_root >= 0) { SK_HIP_TRY(b_loss_nodes_.upload(p.loss_nodes, s)); d_.loss_nodes = b_loss_nodes_.p; }
   d_.is_host = nullptr; d_.num_host = (int)host_obs_.size(); d_.host_obs = nullptr; d_.host_rows = nullptr;
@@ -634,7 +843,8 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   launch_lm_diagonal(b_colsq_.p, b_D_.p, (int)(nc + np), opt_.min_lm_diagonal, opt_.max_lm_diagonal, radius, s);
   // ---- B. Schur complement assembly ----
   kt_.begin("memset_S", s);
-  launch_zero_envelope(b_S_.p, npad_, b_zero_col0_.p, npad_ / 128, s);  // only what the factorisation can read
+  for (int f = 0; f < 3; ++f)  // only what the factorisations can read
+    if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, b_zero_col0_f_[f].p, fr_[f].nblk, s);
   kt_.end("memset_S", s);
   SK_HIP_TRY(hipMemsetAsync(b_fail_.p, 0, sizeof(int), s));
   SK_HIP_TRY(hipMemsetAsync(b_info_.p, 0, sizeof(int), s));
@@ -644,17 +854,33 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   kt_.begin("bal_pair", s); launch_bal_pair(d_, s); kt_.end("bal_pair", s);
   if (opt_.allreduce) {
     // sum S (with the rhs row) over ranks: only its lower block triangle travels (half the bytes)
-    launch_tri_pack(b_S_.p, npad_, b_pack_.p, npad_ / 128, true, s);
+    launch_tri_pack(d_.S, npad_, b_pack_.p, npad_ / 128, true, s);  // (never dissected here: front[2] is the whole system)
     int rc = allreduce(b_pack_.p, packed_elems_);
     if (rc) return rc;
-    launch_tri_pack(b_S_.p, npad_, b_pack_.p, npad_ / 128, false, s);
+    launch_tri_pack(d_.S, npad_, b_pack_.p, npad_ / 128, false, s);
   }
-  launch_bal_finish_S(b_S_.p, npad_, n_, npad_, rhs_row_, d_.D_c, s);
+  // D_c^2 onto the cameras' diagonal entries; the padded tails of the interiors and of the root are identities, and the
+  // augmented right-hand-side row of the root gets a huge diagonal so that its factorisation stays positive definite (the
+  // entry itself is unused; in a leaf's border that diagonal stays zero: it is ADDED to the root's)
+  launch_bal_finish_S(d_, s);
+  for (int f = 0; f < 2; ++f)
+    if (fr_[f].nblk > 0) launch_set_diagonal(d_.front[f].S, (int)fr_[f].dim, 9 * fr_[f].cams, fr_[f].ncols * 128, 1.0, s);
+  launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row, fr_[2].rhs_row + 1, 1e300, s);
+  launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row + 1, (int)fr_[2].dim, 1.0, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
-  const int* env = env_last_.empty() ? nullptr : env_last_.data();
-  cholesky_factor(b_S_.p, npad_, npad_, b_Linv_.p, b_info_.p, group_, s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_, env, chain_ok());
-  cholesky_backsolve(b_S_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_, env);
+  CholeskyContext* ctx = opt_.lookahead ? &chol_ctx_ : nullptr;
+  double* yf[3] = {b_yf_.p + fr_[0].y_off, b_yf_.p + fr_[1].y_off, b_yf_.p + fr_[2].y_off};
+  double* wf[3] = {b_wf_.p + fr_[0].y_off, b_wf_.p + fr_[1].y_off, b_wf_.p + fr_[2].y_off};
+  if (dissected_) {
+    cholesky_dissected_factor(ds_, b_info_.p, group_, s, ctx, &chol_ctx_b_, &kt_, chain_ok());
+    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_);
+  } else {
+    const FrontHost& R = fr_[2];
+    cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, b_info_.p, group_, s, ctx, &kt_, R.env(), chain_ok());
+    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env());
+  }
+  launch_bal_gather_y(d_, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----
   launch_bal_cam_step(d_, b_scal_.p + 8, s);

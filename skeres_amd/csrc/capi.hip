@@ -487,6 +487,10 @@ int sk_options_set_distributed(sk_options* o, int rank, int world, sk_allreduce_
   o->o.rank = rank; o->o.world = world; o->o.allreduce = fn; o->o.allreduce_user = user; return SK_OK;
 }
 int sk_options_set_cholesky_envelope(sk_options* o, int on) { o->o.envelope = on != 0; return SK_OK; }
+int sk_options_set_cholesky_dissection(sk_options* o, int mode) {
+  if (mode != SK_DISSECTION_AUTO && mode != SK_DISSECTION_ON && mode != SK_DISSECTION_OFF) { set_error("invalid dissection mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
+  o->o.dissection = mode; return SK_OK;
+}
 int sk_options_set_distribution_mode(sk_options* o, int mode) {
   if (mode != SK_DISTRIBUTION_AUTO && mode != SK_DISTRIBUTION_SHARDED && mode != SK_DISTRIBUTION_REPLICATED) { set_error("invalid distribution mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
   o->o.distribution_mode = mode; return SK_OK;

@@ -141,6 +141,7 @@ struct Options {  // Solver.Options; Ceres 1.x defaults
   int cholesky_group = 0;
   int group_or(int automatic) const { return cholesky_group > 0 ? cholesky_group : automatic; }
   bool lookahead = true;   // potrf128 on a second stream, off the critical path
+  int dissection = SK_DISSECTION_AUTO;  // DENSE_SCHUR: eliminate the head and the tail of a camera sequence side by side (sk_options_set_cholesky_dissection)
   bool envelope = true;    // DENSE_SCHUR: skip the blocks of the reduced system outside its block envelope (bit-identical result)
 };
 

@@ -125,7 +125,7 @@ int DenseRowsSolver::try_step(double radius, bool* valid, double* mcc, double* n
   // J^T J: one long-K MFMA SYRK over the transposed Jacobian (every lower tile is overwritten)
   launch_syrk_gram(b_H_.p, npad_, b_Jt_.p, (long)m_pad_, (int)(m_pad_ / nslabs_), nslabs_, b_slabs_.p, npad_ / 128, s, &kt_);
   launch_rows_set_rhs(b_H_.p, npad_, rhs_row_, b_gs_.p, n_, s);
-  launch_bal_finish_S(b_H_.p, npad_, n_, npad_, rhs_row_, b_D_.p, s);
+  launch_finish_normal_matrix(b_H_.p, npad_, n_, npad_, rhs_row_, b_D_.p, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   cholesky_factor(b_H_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.group_or(3), s, opt_.lookahead ? &chol_ctx_ : nullptr, &kt_);
   cholesky_backsolve(b_H_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_);

@@ -247,7 +247,7 @@ int DenseSolver::try_step(double radius, bool* valid, double* mcc, double* new_c
   if (opt_.linear_solver_type == SK_DENSE_NORMAL_CHOLESKY) {
     SK_HIP_TRY(hipMemsetAsync(b_H_.p, 0, (size_t)npad_ * npad_ * sizeof(double), s));
     launch_dense_normal(b_J_.p, b_r_.p, m_, n_, b_H_.p, npad_, rhs_row_, s);
-    launch_bal_finish_S(b_H_.p, npad_, n_, npad_, rhs_row_, b_D_.p, s);
+    launch_finish_normal_matrix(b_H_.p, npad_, n_, npad_, rhs_row_, b_D_.p, s);
     SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
     cholesky_factor(b_H_.p, npad_, npad_, b_Linv_.p, b_info_.p, opt_.group_or(3), s, nullptr, &kt_);
     cholesky_backsolve(b_H_.p, npad_, n_, npad_, rhs_row_, b_Linv_.p, b_w_.p, b_y_.p, s, &kt_);
