@@ -709,9 +709,10 @@ def test_resident_chain_timeout_is_reported_and_refactored():
         return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
     clean, err_clean = run({})
     hit, err_hit = run({"SK_CHAIN_TEST_WITHHOLD_MARKER": "7"})
-    assert "timed out" not in err_clean and clean["resident_after"] == clean["resident_before"] >= 60
+    # (resident columns: the head front's and the root's — the tail of the dissected system is factored launch by launch)
+    assert "timed out" not in err_clean and clean["resident_after"] == clean["resident_before"] >= 15
     assert "the resident panel chain timed out" in err_hit          # loud
-    assert hit["resident_before"] >= 60 and hit["resident_after"] == 0   # launch by launch from then on
+    assert hit["resident_before"] >= 15 and hit["resident_after"] == 0   # launch by launch from then on
     assert hit["seconds"] > clean["seconds"] + 2.0                   # the 3 s time-out really happened
     assert hit["valid"] == clean["valid"] == [1, 1, 1, 1]           # no LM step was lost ...
     for a, b in zip(hit["costs"], clean["costs"]):                   # ... and the trajectory is the undisturbed one
