@@ -20,6 +20,7 @@
 #include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <memory>
 #include "chol_kernels.hpp"
 #include "device_table.hpp"
@@ -1110,6 +1111,7 @@ struct DeviceQueues {
   bool tuning = false;
   int chain_server = 1;   // 0: block columns are factored launch by launch on this device (knob, or a time-out happened)
   hipStream_t fork = nullptr;  // stands in for the caller's stream in a secondary context (CholeskyContext::init_secondary)
+  hipStream_t plain[2] = {nullptr, nullptr};
 };
 static PerDeviceTable<DeviceQueues> g_device_queues;
 
@@ -1245,8 +1247,18 @@ hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
   dq = q; device = primary.device;
   server = nullptr;
   reserved_cus = q->reserved_cus; early_tiles = q->early_tiles;
-  for (int k = 0; k < kPanelCand; ++k) if (q->panel_candidates[k] && q->panel_candidates[k] != primary.panel) { panel = q->panel_candidates[k]; break; }
-  for (int k = 0; k < kBulkCand; ++k) if (q->bulk_candidates[k] && q->bulk_candidates[k] != primary.bulk) { bulk = q->bulk_candidates[k]; bulk_early = q->bulk_early_candidates[k]; break; }
+  const char* mode = getenv("SK_DISSECT_B_STREAMS");  // developer knob: "plain" = ordinary streams instead of the left-over CU-masked candidates
+  if (mode && !strcmp(mode, "plain")) {
+    for (int k = 0; k < 2; ++k)
+      if (!q->plain[k]) {
+        if (hipStreamCreateWithFlags(&q->plain[k], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+        q->all_streams.push_back(q->plain[k]);
+      }
+    panel = q->plain[0]; bulk = bulk_early = q->plain[1];
+  } else {
+    for (int k = 0; k < kPanelCand; ++k) if (q->panel_candidates[k] && q->panel_candidates[k] != primary.panel) { panel = q->panel_candidates[k]; break; }
+    for (int k = 0; k < kBulkCand; ++k) if (q->bulk_candidates[k] && q->bulk_candidates[k] != primary.bulk) { bulk = q->bulk_candidates[k]; bulk_early = q->bulk_early_candidates[k]; break; }
+  }
   if (!panel || !bulk) { panel = bulk = bulk_early = nullptr; return hipErrorNotSupported; }  // (no CU-masked candidates on this device)
   if (!q->fork) {
     if (hipStreamCreateWithFlags(&q->fork, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); panel = bulk = bulk_early = nullptr; return hipErrorOutOfMemory; }
@@ -1840,9 +1852,11 @@ static void fork_join_events(CholeskyContext* c) {
 
 void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, hipStream_t s, CholeskyContext* ctxA, CholeskyContext* ctxB,
                                KernelTimer* kt, bool allow_chain) {
-  const bool side = d.B.ncols > 0 && ctxB && ctxB->fork;
-  if (d.B.ncols > 0) {
-    // the tail first: its launches are enqueued (and start) while the host is still enqueueing the head's
+  static const int serial = getenv("SK_DISSECT_SERIAL") ? atoi(getenv("SK_DISSECT_SERIAL")) : 0;       // developer knobs
+  static const int head_first = getenv("SK_DISSECT_HEAD_FIRST") ? atoi(getenv("SK_DISSECT_HEAD_FIRST")) : 0;
+  const bool side = d.B.ncols > 0 && ctxB && ctxB->fork && !serial;
+  auto tail = [&]() {
+    if (d.B.ncols <= 0) return;
     hipStream_t sB = s;
     if (side) {
       fork_join_events(ctxB);
@@ -1851,8 +1865,14 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
       sB = ctxB->fork;
     }
     cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, sB, side ? ctxB : ctxA, kt, d.B.last, false, d.B.ncols);
-  }
+  };
+  // the tail first: its launches are enqueued (and start) while the host is still enqueueing the head's
+  if (!head_first) tail();
   if (d.A.ncols > 0) cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols);
+  if (head_first) {
+    if (side) { fork_join_events(ctxB); }
+    tail();
+  }
   if (side) {
     (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);
