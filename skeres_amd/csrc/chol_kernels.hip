@@ -1241,7 +1241,7 @@ hipError_t CholeskyContext::init() {
 }
 
 hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
-  if (panel) return hipSuccess;
+  panel = bulk = bulk_early = nullptr;  // (called again after the queue choice: the queues the primary context does NOT use now)
   if (!primary.dq) return hipErrorInvalidValue;
   DeviceQueues* q = primary.dq;
   dq = q; device = primary.device;
@@ -1852,6 +1852,23 @@ static void fork_join_events(CholeskyContext* c) {
 
 void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, hipStream_t s, CholeskyContext* ctxA, CholeskyContext* ctxB,
                                KernelTimer* kt, bool allow_chain) {
+  // developer knob SK_DISSECT_TIMING=1: HIP events on the caller's stream around the parts (printed by the NEXT call, when
+  // they have completed): with SK_DISSECT_SERIAL=1 the tail, the head and the root one after the other
+  static const int timing = getenv("SK_DISSECT_TIMING") ? atoi(getenv("SK_DISSECT_TIMING")) : 0;
+  static hipEvent_t tev[5] = {};
+  static int tcalls = 0;
+  if (timing) {
+    if (!tev[0]) for (auto& e : tev) (void)hipEventCreate(&e);
+    else if (tcalls < 40) {
+      (void)hipEventSynchronize(tev[4]);
+      float a = 0, b = 0, c = 0, dd = 0;
+      (void)hipEventElapsedTime(&a, tev[0], tev[1]); (void)hipEventElapsedTime(&b, tev[1], tev[2]);
+      (void)hipEventElapsedTime(&c, tev[2], tev[3]); (void)hipEventElapsedTime(&dd, tev[3], tev[4]);
+      std::fprintf(stderr, "[skeres_amd] dissected factorisation: first part %.2f ms, second part (+ join) %.2f ms, border add %.2f ms, root %.2f ms\n", a, b, c, dd);
+    }
+    ++tcalls;
+    (void)hipEventRecord(tev[0], s);
+  }
   static const int serial = getenv("SK_DISSECT_SERIAL") ? atoi(getenv("SK_DISSECT_SERIAL")) : 0;       // developer knobs
   static const int head_first = getenv("SK_DISSECT_HEAD_FIRST") ? atoi(getenv("SK_DISSECT_HEAD_FIRST")) : 0;
   const bool side = d.B.ncols > 0 && ctxB && ctxB->fork && !serial;
@@ -1868,18 +1885,20 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
   };
   // the tail first: its launches are enqueued (and start) while the host is still enqueueing the head's
   if (!head_first) tail();
+  if (timing && !head_first) (void)hipEventRecord(tev[1], s);
   if (d.A.ncols > 0) cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols);
-  if (head_first) {
-    if (side) { fork_join_events(ctxB); }
-    tail();
-  }
+  if (timing && head_first) (void)hipEventRecord(tev[1], s);
+  if (head_first) tail();
   if (side) {
     (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);
   }
+  if (timing) (void)hipEventRecord(tev[2], s);
   if (d.A.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.A.S, d.A.ld, d.A.ncols, d.border_blocks, nullptr, s);
   if (d.B.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.B.S, d.B.ld, d.B.ncols, d.border_blocks, d.mapB, s);
+  if (timing) (void)hipEventRecord(tev[3], s);
   cholesky_factor(d.R.S, d.R.ld, d.R.nblk * 128, d.R.Linv, info, group, s, ctxA, kt, d.R.last, allow_chain);
+  if (timing) (void)hipEventRecord(tev[4], s);
 }
 
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,

@@ -1,11 +1,9 @@
 #!/bin/bash
 # Developer tool: ms per LM iteration of the Ladybug-1723 solve under the knobs of the dissected factorisation.
-run() { echo "== $*"; env "$@" timeout -k 10 120 python tools/explore_c3.py --timing 0 --iters 12 --perturb 1e-2 1e-1 1e-1 2>&1 | grep -E "iterations:|device ms|dissect|timed out" ; }
+run() { echo "== $*"; env "$@" timeout -k 10 120 python tools/explore_c3.py --timing 0 --iters 8 --perturb 1e-2 1e-1 1e-1 2>&1 | grep -E "iterations:|device ms|dissect|timed out" | tail -6 ; }
 run SK_DISSECT_AT=0
-run SK_X=1
-run SK_DISSECT_SERIAL=1
-run SK_DISSECT_HEAD_FIRST=1
-run SK_DISSECT_B_STREAMS=plain
-run SK_DISSECT_B_STREAMS=plain SK_DISSECT_HEAD_FIRST=1
-run SK_DISSECT_AT=600
-run SK_DISSECT_AT=900
+run SK_DISSECT_TIMING=1
+run SK_DISSECT_SERIAL=1 SK_DISSECT_TIMING=1
+run SK_DISSECT_SERIAL=1 SK_DISSECT_TIMING=1 SK_CHOL_CHAIN_SERVER=0
+run SK_DISSECT_TIMING=1 SK_CHOL_CHAIN_SERVER=0
+run SK_DISSECT_B_STREAMS=plain SK_DISSECT_TIMING=1
