@@ -93,6 +93,15 @@ class BalSolver : public SolverBase {
     }
     return tiles * 2.0 * 128.0 * 128.0 * sizeof(double);
   }
+  void set_kernel_timing(int on) override {
+    SolverBase::set_kernel_timing(on);
+    kt_b_.only(on == 2 ? "gemm_syrk" : ""); kt_b_.enable(on != 0);
+  }
+  KernelTimer::Stat kernel_stat(const std::string& name) override {
+    KernelTimer::Stat a = kt_.get_stat(name), b = kt_b_.get_stat(name);
+    a.seconds += b.seconds; a.launches += b.launches;
+    return a;
+  }
   bool stat(const std::string& name, double* value) const override {
     const int nblk = npad_ / 128;
     if (name == "envelope_fill") {  // 128-blocks that are factored or updated, over the lower triangle of the undissected system
@@ -195,6 +204,7 @@ class BalSolver : public SolverBase {
   double dissect_t_plain_ = 0.0, dissect_t_model_ = 0.0;
   DissectedSystem ds_;
   CholeskyContext chol_ctx_b_;
+  KernelTimer kt_b_;  // launches enqueued by the tail front's own thread
   DevBuf<int> b_zero_col0_f_[3], b_mapB_;
   DevBuf<double> b_yf_, b_wf_, b_ybB_;
   double order_hash_ = 0.0;    // of the camera order and the envelope: equal on every rank, or setup() fails
@@ -241,8 +251,10 @@ static std::vector<int> envelope_of_order(const std::vector<int>& ocam, const st
 // column costs the larger of its panel chain and its trailing update.
 struct Dissection { int a = 0, b = 0; double t_plain = 0.0, t_dissected = 0.0; };
 static double column_cost_us(int h, bool resident_capable) {
-  const double update_us = 128.0 * 128.0 * 128.0 * ((double)h * h + h) / 35e6 + (h > 24 ? 20.0 : 0.0);  // 35 TFLOP/s, launch gaps of the wide columns
-  const double chain_us = (resident_capable && h <= 24) ? 42.0 : 70.0;
+  // trailing update: 14 TFLOP/s where it is a few dozen thin tiles, 32 TFLOP/s (+ 20 us between launches) where it is wide
+  const double flops = 128.0 * 128.0 * 128.0 * ((double)h * h + h);
+  const double update_us = h > 24 ? flops / 32e6 + 20.0 : flops / 14e6;
+  const double chain_us = (resident_capable && h <= 24) ? 42.0 : 70.0;  // resident panel chain / four launches per column
   return std::max(update_us, chain_us);
 }
 static Dissection choose_dissection(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
@@ -271,7 +283,7 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
     const int b = reach[a - 1] + 1;
     if (b >= C - 14) break;
     const int ca = (9 * a + 127) / 128, cb = (9 * b) / 128, E = (9 * (b - a) + 1 + 127) / 128;
-    if (E > 40) continue;  // a separator that wide is no separator
+    if (E > 24) continue;  // a separator that wide is no separator: its dense system is factored after both chains, alone
     double root = 0.0;
     for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i, true);
     const double t = std::max(fwd_sum[ca], bwd_sum[nblk] - bwd_sum[cb]) + root + 120.0;  // + fork, join, border add
@@ -873,7 +885,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   double* yf[3] = {b_yf_.p + fr_[0].y_off, b_yf_.p + fr_[1].y_off, b_yf_.p + fr_[2].y_off};
   double* wf[3] = {b_wf_.p + fr_[0].y_off, b_wf_.p + fr_[1].y_off, b_wf_.p + fr_[2].y_off};
   if (dissected_) {
-    cholesky_dissected_factor(ds_, b_info_.p, group_, s, ctx, &chol_ctx_b_, &kt_, chain_ok());
+    cholesky_dissected_factor(ds_, b_info_.p, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
     cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_);
   } else {
     const FrontHost& R = fr_[2];

@@ -583,12 +583,11 @@ int sk_solver_finish(sk_solver* s, sk_summary* summary) {
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }
 int sk_solver_set_kernel_timing(sk_solver* s, int on) {
-  s->impl->kernel_timer().only(on == 2 ? "gemm_syrk" : "");
-  s->impl->kernel_timer().enable(on != 0);
+  s->impl->set_kernel_timing(on);
   return SK_OK;
 }
 double sk_solver_kernel_seconds(const sk_solver* s, const char* name, int* launches) {
-  KernelTimer::Stat st = s->impl->kernel_timer().get_stat(name);
+  KernelTimer::Stat st = s->impl->kernel_stat(name);
   if (launches) *launches = st.launches;
   return st.seconds;
 }
@@ -772,7 +771,7 @@ int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double*
   d.border_blocks = E; d.mapB = dmap.p;
   const bool chain = automatic_plan != 0 && la && cholesky_chain_enabled(&ctx);
   if (chain) cholesky_prepare(&ctx, s);
-  cholesky_dissected_factor(d, dinfo.p, group, s, la ? &ctx : nullptr, side ? &ctxB : nullptr, nullptr, chain);
+  cholesky_dissected_factor(d, dinfo.p, group, s, la ? &ctx : nullptr, side ? &ctxB : nullptr, nullptr, nullptr, chain);
   double *wA = dw.p, *wB = dw.p + dA, *wR = dw.p + dA + dB, *ybB = dw.p + dA + dB + dR;
   double *yA = dy.p, *yB = dy.p + dA, *yR = dy.p + dA + dB;
   cholesky_dissected_backsolve(d, msep, wR, yR, wA, yA, wB, yB, ybB, s, side ? &ctxB : nullptr, nullptr);

@@ -1851,7 +1851,7 @@ static void fork_join_events(CholeskyContext* c) {
 }
 
 void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, hipStream_t s, CholeskyContext* ctxA, CholeskyContext* ctxB,
-                               KernelTimer* kt, bool allow_chain) {
+                               KernelTimer* kt, KernelTimer* ktB, bool allow_chain) {
   // developer knob SK_DISSECT_TIMING=1: HIP events on the caller's stream around the parts (printed by the NEXT call, when
   // they have completed): with SK_DISSECT_SERIAL=1 the tail, the head and the root one after the other
   static const int timing = getenv("SK_DISSECT_TIMING") ? atoi(getenv("SK_DISSECT_TIMING")) : 0;
@@ -1872,16 +1872,27 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
   static const int serial = getenv("SK_DISSECT_SERIAL") ? atoi(getenv("SK_DISSECT_SERIAL")) : 0;       // developer knobs
   static const int head_first = getenv("SK_DISSECT_HEAD_FIRST") ? atoi(getenv("SK_DISSECT_HEAD_FIRST")) : 0;
   const bool side = d.B.ncols > 0 && ctxB && ctxB->fork && !serial;
+  static const int threaded = getenv("SK_DISSECT_THREAD") ? atoi(getenv("SK_DISSECT_THREAD")) : 1;
+  bool tail_async = false;
   auto tail = [&]() {
     if (d.B.ncols <= 0) return;
-    hipStream_t sB = s;
-    if (side) {
-      fork_join_events(ctxB);
-      (void)hipEventRecord(ctxB->fork_ev, s);
-      (void)hipStreamWaitEvent(ctxB->fork, ctxB->fork_ev, 0);
-      sB = ctxB->fork;
+    if (!side) { cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, false, d.B.ncols); return; }
+    fork_join_events(ctxB);
+    (void)hipEventRecord(ctxB->fork_ev, s);
+    (void)hipStreamWaitEvent(ctxB->fork, ctxB->fork_ev, 0);
+    // the tail's launches (and the event that says they are all enqueued behind `fork`) from ctxB's own thread: the
+    // head's are enqueued by this one meanwhile
+    auto job = [&d, info, group, ctxB, ktB] {
+      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, ctxB->fork, ctxB, ktB, d.B.last, false, d.B.ncols);
+      (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
+    };
+    if (threaded) {
+      if (!ctxB->runner) ctxB->runner.reset(new AsyncRunner(ctxB->device));
+      ctxB->runner->run(job);
+      tail_async = true;
+    } else {
+      job();
     }
-    cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, sB, side ? ctxB : ctxA, kt, d.B.last, false, d.B.ncols);
   };
   // the tail first: its launches are enqueued (and start) while the host is still enqueueing the head's
   if (!head_first) tail();
@@ -1890,7 +1901,7 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
   if (timing && head_first) (void)hipEventRecord(tev[1], s);
   if (head_first) tail();
   if (side) {
-    (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
+    if (tail_async) ctxB->runner->wait();  // (the join event has been recorded)
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);
   }
   if (timing) (void)hipEventRecord(tev[2], s);

@@ -1,8 +1,13 @@
 // Dense fp64 Cholesky on gfx950 matrix cores — host entry points (chol_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <condition_variable>
 #include <cstdint>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -84,6 +89,52 @@ class KernelTimer {
   std::map<std::string, Stat> stats_;
 };
 
+// One helper thread that runs host-side jobs (enqueueing a factorisation's launches) next to the caller's thread.
+// A launch-by-launch factorisation costs the host about as much time to enqueue as it costs the GPU to run (four launches
+// and as many event operations per block column): two of them side by side on the GPU need two enqueueing threads.
+class AsyncRunner {
+ public:
+  explicit AsyncRunner(int device) : device_(device) {}
+  ~AsyncRunner() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+  }
+  void run(std::function<void()> job) {
+    wait();
+    { std::lock_guard<std::mutex> l(m_); job_ = std::move(job); busy_ = true; }
+    if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+    cv_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> l(m_);
+    cv_.wait(l, [this] { return !busy_; });
+  }
+
+ private:
+  void loop() {
+    (void)hipSetDevice(device_);
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return stop_ || (busy_ && job_); });
+        if (stop_) return;
+        job = std::move(job_); job_ = nullptr;
+      }
+      job();
+      { std::lock_guard<std::mutex> l(m_); busy_ = false; }
+      cv_.notify_all();
+    }
+  }
+  int device_;
+  std::thread th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> job_;
+  bool busy_ = false, stop_ = false;
+};
+
 // Streams + events of the look-ahead factorisation: the panel chain of the next block-column group
 // runs on `panel` while the trailing SYRK of the current group runs on `bulk`, whose CU mask leaves
 // a few CUs per XCD free so that the panel kernels are never queued behind a 6000-workgroup grid.
@@ -110,6 +161,7 @@ struct CholeskyContext {
   hipError_t init_secondary(const CholeskyContext& primary);
   hipStream_t fork = nullptr;
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  std::unique_ptr<AsyncRunner> runner;   // enqueues this context's factorisation from a thread of its own
   hipEvent_t event(size_t i);
   ~CholeskyContext();
 };
@@ -147,8 +199,9 @@ struct DissectedSystem {
   const int* mapB = nullptr;          // device: B's border index -> root index (< 0: padding)
 };
 // Factor A and B side by side (B on ctxB's streams, launch by launch), add their Schur complements to the root, factor it.
+// ktB: the timer of the tail's launches (they are enqueued by ctxB's own thread: a KernelTimer belongs to one thread).
 void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, hipStream_t s, CholeskyContext* ctxA, CholeskyContext* ctxB,
-                               KernelTimer* kt, bool allow_chain);
+                               KernelTimer* kt, KernelTimer* ktB, bool allow_chain);
 // Solve: root, then the two interiors side by side.  yR / yA / yB: solutions in each front's own order; w*: scratch of the
 // fronts' sizes; ybB: scratch of border size.  The right-hand sides are the fronts' rhs rows after the factorisation.
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,

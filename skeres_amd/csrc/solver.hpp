@@ -20,6 +20,9 @@ class SolverBase {
   int step(bool* done);         // one trust-region iteration
   int finish(Summary* s);       // parameters back to caller memory + summary
   KernelTimer& kernel_timer() { return kt_; }
+  // sk_solver_set_kernel_timing / sk_solver_kernel_seconds (a solver may keep more than one timer: one per enqueueing thread)
+  virtual void set_kernel_timing(int on) { kt_.only(on == 2 ? "gemm_syrk" : ""); kt_.enable(on != 0); }
+  virtual KernelTimer::Stat kernel_stat(const std::string& name) { return kt_.get_stat(name); }
   virtual double syrk_flops_per_solve() const { return 0.0; }
   virtual double syrk_c_bytes_per_solve() const { return 0.0; }  // C tiles read + written by those launches
   virtual bool stat(const std::string& name, double* value) const { (void)name; (void)value; return false; }  // sk_solver_stat

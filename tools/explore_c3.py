@@ -42,6 +42,8 @@ def main():
     t0 = time.time()
     s = sk.StepSolver(o, problem)
     print("setup + iteration 0: %.2f s" % (time.time() - t0))
+    print("plan: " + ", ".join("%s %g" % (k, s.stat(k)) for k in ("dissected", "dissection_head_cameras", "dissection_separator_cameras", "dissection_tail_cameras",
+                                                                 "dissection_model_us_plain", "dissection_model_us", "cholesky_columns_resident", "envelope_fill")))
     s.step()
     s.setKernelTiming(args.timing)
     t0 = time.time()
