@@ -1099,7 +1099,7 @@ int* CholeskyContext::sync_for(int nblk) {
 // factorisation with a resident chain first runs a small synthetic one (identity matrix, banded envelope, 1 ms) with
 // each of the 18 combinations and keeps the fastest (tune_chain_queues: 0.1 s, once per device; developer knob
 // SK_CHAIN_QUEUES=<n> fixes the combination).
-constexpr int kBulkCand = 2, kPanelCand = 3, kServerCand = 3;
+constexpr int kBulkCand = 2, kPanelCand = 4, kServerCand = 3;
 struct DeviceQueues {
   int device = -1;
   hipStream_t panel = nullptr, bulk = nullptr, bulk_early = nullptr, server = nullptr;  // the combination in use
@@ -1256,8 +1256,21 @@ hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
       }
     panel = q->plain[0]; bulk = bulk_early = q->plain[1];
   } else {
-    for (int k = 0; k < kPanelCand; ++k) if (q->panel_candidates[k] && q->panel_candidates[k] != primary.panel) { panel = q->panel_candidates[k]; break; }
-    for (int k = 0; k < kBulkCand; ++k) if (q->bulk_candidates[k] && q->bulk_candidates[k] != primary.bulk) { bulk = q->bulk_candidates[k]; bulk_early = q->bulk_early_candidates[k]; break; }
+    // The queues the primary context does not use — of the same creation parity as the ones it does: which queues suffer
+    // from a resident kernel on the server's queue goes by that parity (tune_chain_queues), and the primary's were
+    // measured to be on the good side.  (Developer knobs SK_DISSECT_B_PANEL / SK_DISSECT_B_BULK: candidate indices.)
+    int kp = -1, kb = -1;
+    for (int k = 0; k < kPanelCand; ++k) if (q->panel_candidates[k] == primary.panel) kp = k;
+    for (int k = 0; k < kBulkCand; ++k) if (q->bulk_candidates[k] == primary.bulk) kb = k;
+    int bp = -1, bb = -1;
+    for (int k = 0; k < kPanelCand; ++k) if (k != kp && q->panel_candidates[k] && (kp < 0 || (k - kp) % 2 == 0)) { bp = k; break; }
+    if (bp < 0) for (int k = 0; k < kPanelCand; ++k) if (k != kp && q->panel_candidates[k]) { bp = k; break; }
+    for (int k = 0; k < kBulkCand; ++k) if (k != kb && q->bulk_candidates[k]) { bb = k; break; }
+    if (const char* e = getenv("SK_DISSECT_B_PANEL")) bp = atoi(e) % kPanelCand;
+    if (const char* e = getenv("SK_DISSECT_B_BULK")) bb = atoi(e) % kBulkCand;
+    if (bp >= 0) panel = q->panel_candidates[bp];
+    if (bb >= 0) { bulk = q->bulk_candidates[bb]; bulk_early = q->bulk_early_candidates[bb]; }
+    if (getenv("SK_DEBUG_QUEUES")) std::fprintf(stderr, "[skeres_amd] secondary context: panel candidate %d (primary %d), bulk candidate %d (primary %d)\n", bp, kp, bb, kb);
   }
   if (!panel || !bulk) { panel = bulk = bulk_early = nullptr; return hipErrorNotSupported; }  // (no CU-masked candidates on this device)
   if (!q->fork) {
