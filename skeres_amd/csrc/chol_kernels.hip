@@ -1896,8 +1896,10 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
     // the tail's launches (and the event that says they are all enqueued behind `fork`) from ctxB's own thread: the
     // head's are enqueued by this one meanwhile
     auto job = [&d, info, group, ctxB, ktB] {
+      const auto h0 = std::chrono::steady_clock::now();
       cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, ctxB->fork, ctxB, ktB, d.B.last, false, d.B.ncols);
       (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
+      if (timing) std::fprintf(stderr, "[skeres_amd]   host: tail enqueued in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count());
     };
     if (threaded) {
       if (!ctxB->runner) ctxB->runner.reset(new AsyncRunner(ctxB->device));
@@ -1910,7 +1912,9 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
   // the tail first: its launches are enqueued (and start) while the host is still enqueueing the head's
   if (!head_first) tail();
   if (timing && !head_first) (void)hipEventRecord(tev[1], s);
+  const auto hA = std::chrono::steady_clock::now();
   if (d.A.ncols > 0) cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols);
+  if (timing) std::fprintf(stderr, "[skeres_amd]   host: head enqueued in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hA).count());
   if (timing && head_first) (void)hipEventRecord(tev[1], s);
   if (head_first) tail();
   if (side) {
