@@ -1273,6 +1273,7 @@ hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
     if (getenv("SK_DEBUG_QUEUES")) std::fprintf(stderr, "[skeres_amd] secondary context: panel candidate %d (primary %d), bulk candidate %d (primary %d)\n", bp, kp, bb, kb);
   }
   if (!panel || !bulk) { panel = bulk = bulk_early = nullptr; return hipErrorNotSupported; }  // (no CU-masked candidates on this device)
+  if (const char* e = getenv("SK_DISSECT_B_SINGLE")) if (atoi(e)) bulk = bulk_early = panel;  // developer knob: the whole tail on ONE in-order queue
   if (!q->fork) {
     if (hipStreamCreateWithFlags(&q->fork, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); panel = bulk = bulk_early = nullptr; return hipErrorOutOfMemory; }
     q->all_streams.push_back(q->fork);
@@ -1724,7 +1725,8 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   }
   order(sp, s);
   if (la) { order(ctx->bulk, s); order(ctx->bulk_early, s); }
-  if (chain) order(srv, s);
+  static const int no_server_join = getenv("SK_CHAIN_NO_SERVER_JOIN") ? atoi(getenv("SK_CHAIN_NO_SERVER_JOIN")) : 0;  // developer knob
+  if (chain && !no_server_join) order(srv, s);
   if (stamps_file) {
     (void)hipStreamSynchronize(s);
     std::vector<long long> st((size_t)1024 * 8);
@@ -1891,14 +1893,16 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
     if (d.B.ncols <= 0) return;
     if (!side) { cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, false, d.B.ncols); return; }
     fork_join_events(ctxB);
+    static const int no_fork = getenv("SK_DISSECT_NO_FORK") ? atoi(getenv("SK_DISSECT_NO_FORK")) : 0;  // developer knob: the tail's panel queue stands in for its caller's stream
+    hipStream_t sB = no_fork ? ctxB->panel : ctxB->fork;
     (void)hipEventRecord(ctxB->fork_ev, s);
-    (void)hipStreamWaitEvent(ctxB->fork, ctxB->fork_ev, 0);
+    (void)hipStreamWaitEvent(sB, ctxB->fork_ev, 0);
     // the tail's launches (and the event that says they are all enqueued behind `fork`) from ctxB's own thread: the
     // head's are enqueued by this one meanwhile
-    auto job = [&d, info, group, ctxB, ktB] {
+    auto job = [&d, info, group, ctxB, ktB, sB] {
       const auto h0 = std::chrono::steady_clock::now();
-      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, ctxB->fork, ctxB, ktB, d.B.last, false, d.B.ncols);
-      (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
+      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, sB, ctxB, ktB, d.B.last, false, d.B.ncols);
+      (void)hipEventRecord(ctxB->join_ev, sB);
       if (timing) std::fprintf(stderr, "[skeres_amd]   host: tail enqueued in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count());
     };
     if (threaded) {
