@@ -305,9 +305,10 @@ int sk_options_set_cholesky_envelope(sk_options* o, int on);
  * point seen from both head and tail), the head is eliminated front to back and the tail back to front, side by side
  * on two sets of queues, and the separator's system — plus both Schur complements — is factored last: the same
  * arithmetic in another elimination order (results agree with the undissected factorisation to rounding, not bit for
- * bit), with a chain about half as long.  AUTO (default): when a model of the two chains predicts at least 10 % less
- * time, with the library's own plan (no explicit `group`), the envelope on and one process; ON: whenever a separator
- * exists (tests); OFF: never. */
+ * bit), with a chain about half as long.  ON: whenever a separator exists, with the library's own plan (no explicit
+ * `group`), the envelope on and one process; OFF: never; AUTO (default): as OFF on one device — measured on MI355X the
+ * two chains disturb each other on one chip more than the shorter chain gains — the model's
+ * prediction is reported by sk_solver_stat. */
 enum { SK_DISSECTION_AUTO = 0, SK_DISSECTION_ON = 1, SK_DISSECTION_OFF = 2 };
 int sk_options_set_cholesky_dissection(sk_options* o, int mode);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,

@@ -481,6 +481,11 @@ int BalSolver::setup() {
       std::vector<int> first_col;
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
       Dissection ds = choose_dissection(ocam, opt, C_, P_total_, nblk, best_env, first_col);
+      // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
+      // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
+      // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon.  ON forces it;
+      // the fronts are what a two-device split of the factorisation is made of.
+      if (opt_.dissection == SK_DISSECTION_AUTO && !getenv("SK_DISSECT_AT")) { ds.a = ds.b = 0; }
       if (opt_.dissection == SK_DISSECTION_ON && ds.a == 0 && C_ >= 6) {
         // forced (tests): cut at the middle camera wherever that leaves a tail
         std::vector<int> cmin(P_total_, C_), cmax(P_total_, -1);
