@@ -327,7 +327,8 @@ enum { SK_DISTRIBUTION_AUTO = 0, SK_DISTRIBUTION_SHARDED = 1, SK_DISTRIBUTION_RE
 int sk_options_set_distribution_mode(sk_options* o, int mode);
 /* The caller may hand the solver the buffer the big all-reduce runs on (so a
  * torch.distributed / RCCL communicator can register it).  bytes must be >=
- * sk_reduce_buffer_bytes(problem, options). */
+ * sk_reduce_buffer_bytes(problem, options): the whole lower block triangle, an upper bound — the solver packs and
+ * reduces only the blocks inside the envelope (sk_solver_stat "allreduce_bytes"), at the start of the buffer. */
 int sk_options_set_reduce_buffer(sk_options* o, void* device_ptr, size_t bytes);
 size_t sk_reduce_buffer_bytes(const sk_options* o, const sk_problem* p);
 
@@ -395,6 +396,8 @@ int sk_solver_distribution(const sk_solver* s, double* allreduce_seconds, double
  *   "cholesky_flops_full"   n^3 / 3, n = 9 * cameras: SURVEY.md section 8(d)'s figure for phase C
  *   "cholesky_flops_plan"   flops of the factorisation as planned (potrf + TRSM + updates of the blocks inside the envelope)
  *   "cholesky_columns_resident"  block columns factored under the resident panel chain
+ *   "allreduce_bytes"       bytes of the reduced system that travel in the per-iteration all-reduce of the sharded mode (the
+ *                           lower block triangle inside the envelope), "allreduce_bytes_full_triangle" beside it
  *   "dissected"             1 when the camera sequence is dissected (sk_options_set_cholesky_dissection), with
  *   "dissection_head_cameras" / "dissection_separator_cameras" / "dissection_tail_cameras" and the model's
  *   "dissection_model_us_plain" / "dissection_model_us" (microseconds of factorisation it predicted either way)

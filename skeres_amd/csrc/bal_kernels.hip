@@ -710,14 +710,16 @@ __global__ __launch_bounds__(kBlock) void bal_cam_step_kernel(BalDev d, double* 
 }
 
 // Lower block triangle of S <-> packed buffer (see bal_kernels.hpp), 16 bytes per lane.
-__global__ __launch_bounds__(256) void tri_pack_kernel(double* S, int ld, double* packed, int to_packed) {
+// Block row kb travels from block column col0[kb] to its diagonal block; off[kb] = where it starts in the packed buffer.
+__global__ __launch_bounds__(256) void tri_pack_kernel(double* S, int ld, double* packed, const int* __restrict__ col0, const long long* __restrict__ off,
+                                                       int to_packed) {
   const int kb = blockIdx.y;
-  const size_t width = (size_t)(kb + 1) * 128;
-  double* pk = packed + (size_t)128 * 128 * ((size_t)kb * (kb + 1) / 2);
+  const size_t c0 = (size_t)col0[kb] * 128, width = (size_t)(kb + 1) * 128 - c0;
+  double* pk = packed + off[kb];
   const size_t n2 = 128 * width / 2;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
     const size_t e = 2 * i, r = e / width, c = e % width;
-    double2* a = reinterpret_cast<double2*>(S + ((size_t)kb * 128 + r) * ld + c);
+    double2* a = reinterpret_cast<double2*>(S + ((size_t)kb * 128 + r) * ld + c0 + c);
     double2* b = reinterpret_cast<double2*>(pk + e);
     if (to_packed) *b = *a; else *a = *b;
   }
@@ -749,8 +751,8 @@ void launch_zero_envelope(double* S, int ld, const int* col0, int nblk, hipStrea
 
 int bal_partial_blocks(int N) { return grid_for(N); }
 size_t tri_packed_elems(int nblk) { return (size_t)128 * 128 * ((size_t)nblk * (nblk + 1) / 2); }
-void launch_tri_pack(double* S, int ld, double* packed, int nblk, bool to_packed, hipStream_t s) {
-  if (nblk > 0) hipLaunchKernelGGL(tri_pack_kernel, dim3(64, nblk), dim3(256), 0, s, S, ld, packed, to_packed ? 1 : 0);
+void launch_tri_pack(double* S, int ld, double* packed, int nblk, const int* col0, const long long* off, bool to_packed, hipStream_t s) {
+  if (nblk > 0) hipLaunchKernelGGL(tri_pack_kernel, dim3(64, nblk), dim3(256), 0, s, S, ld, packed, col0, off, to_packed ? 1 : 0);
 }
 
 void launch_bal_eval_jac(const BalDev& d, hipStream_t s) {

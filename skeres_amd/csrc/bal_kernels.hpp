@@ -70,11 +70,12 @@ constexpr int kHostRow = 26;
 
 int bal_partial_blocks(int N);
 int bal_point_blocks(int P);  // workgroups of the per-point kernels (bal_point_backsub writes one partial sum each)
-// lower block triangle of S (nblk x nblk blocks of 128) as one contiguous run: block row kb holds its
-// 128 rows x (kb+1)*128 columns row-major; this is what travels in the all-reduce
+// the part of the lower block triangle of S inside its block envelope as one contiguous run: block row kb holds its
+// 128 rows x (kb + 1 - col0[kb]) * 128 columns row-major; this is what travels in the all-reduce
 void launch_zero_envelope(double* S, int ld, const int* col0, int nblk, hipStream_t s);
 size_t tri_packed_elems(int nblk);
-void launch_tri_pack(double* S, int ld, double* packed, int nblk, bool to_packed, hipStream_t s);
+// col0[kb]: first block column of block row kb that travels; off[kb]: where the row starts in the packed buffer (elements)
+void launch_tri_pack(double* S, int ld, double* packed, int nblk, const int* col0, const long long* off, bool to_packed, hipStream_t s);
 void launch_bal_eval_jac(const BalDev& d, hipStream_t s);
 void launch_bal_eval_cost(const BalDev& d, hipStream_t s);
 // the uploaded rows of the host-evaluated observations -> r / F / E planes (loss correction and column scaling as the

@@ -135,6 +135,8 @@ class BalSolver : public SolverBase {
       *value = r;
       return true;
     }
+    if (name == "allreduce_bytes") { *value = (double)packed_elems_ * sizeof(double); return true; }
+    if (name == "allreduce_bytes_full_triangle") { *value = (double)tri_packed_elems(nblk) * sizeof(double); return true; }
     if (name == "dissected") { *value = dissected_ ? 1.0 : 0.0; return true; }
     if (name == "dissection_head_cameras") { *value = cam_a_; return true; }
     if (name == "dissection_tail_cameras") { *value = cam_b_ - cam_a_; return true; }
@@ -212,6 +214,10 @@ class BalSolver : public SolverBase {
   int group_ = 3;              // SYRK depth actually used (Options::cholesky_group, or chosen from the envelope)
   DevBuf<double> b_pack_;
   size_t packed_elems_ = 0;
+  std::vector<int> pack_col0_h_;            // all-reduce packing: first block column of every block row that travels
+  std::vector<long long> pack_off_h_;       // ... and where the row starts in the packed buffer
+  DevBuf<int> b_pack_col0_;
+  DevBuf<long long> b_pack_off_;
   int distribution_ = SK_DISTRIBUTION_SHARDED;
   double est_allreduce_s_ = 0.0, est_saved_s_ = 0.0;
   int choose_distribution(const std::vector<int>& opt);
@@ -422,20 +428,7 @@ int BalSolver::setup() {
     (void)hipGetLastError();
     opt_.lookahead = false;
   }
-  // ---- multi-GPU: shard the points, or replicate? (before the camera order: a replicated world is
-  // world-many single-GPU solves, each free to order and dissect for itself) ----
-  packed_elems_ = tri_packed_elems(npad_ / 128);
-  if (opt_.allreduce) {
-    if (opt_.reduce_buffer) {
-      if (opt_.reduce_buffer_bytes < packed_elems_ * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", packed_elems_ * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
-      b_pack_.adopt(static_cast<double*>(opt_.reduce_buffer), packed_elems_);
-    } else {
-      SK_HIP_TRY(b_pack_.alloc(packed_elems_));
-    }
-    SK_HIP_TRY(b_pack_.zero(stream_));
-    int rc = choose_distribution(opt);
-    if (rc) return rc;
-  }
+  std::vector<int> env_for_model;  // the envelope of the chosen order (whether or not it is then used)
   // ---- camera order + block envelope of the reduced system (all ranks' observations: the all-reduced S has the union structure).
   // The order is chosen the same way whether or not the envelope is then used (opt_.envelope), so that the two
   // settings differ in nothing but the blocks they skip and give bit-identical results. ----
@@ -473,6 +466,44 @@ int BalSolver::setup() {
     for (int& c : ocam) c = id[c];
     const double full = cholesky_syrk_flops(npad_, 1, nullptr);
     group_ = opt_.group_or(opt_.envelope && best < 0.5 * full ? 1 : 3);
+    env_for_model = best_env;
+    if (opt_.envelope) env_last_.swap(best_env);
+    if (getenv("SK_DEBUG_ENVELOPE") && opt_.envelope) {
+      long h = 0;
+      for (int c = 0; c < nblk; ++c) h += env_last_[c] - c;
+      std::fprintf(stderr, "[skeres_amd] camera order %d (0 first appearance, 1 memory, 2 RCM); envelope: %d block columns, mean height %.1f; "
+                   "trailing-update flops %.3e (full %.3e)\n", best_k, nblk, (double)h / nblk, best, full);
+    }
+  }
+  // ---- multi-GPU: shard the points, or replicate? ----
+  // What travels in the all-reduce of the reduced system is the part of its lower block triangle INSIDE the envelope:
+  // block row kb from the first block column that reaches it (the right-hand-side row whole) — 0.36 GB instead of 0.98 GB
+  // on the Ladybug-1723-shaped system, exactly the blocks the assembly can write.
+  {
+    const int nblk = npad_ / 128;
+    std::vector<int> pack_col0(nblk, 0);
+    std::vector<long long> pack_off(nblk + 1, 0);
+    if (!env_last_.empty()) {
+      int c = 0;
+      for (int i = 0; i + 1 < nblk; ++i) { while (c < i && env_last_[c] < i) ++c; pack_col0[i] = c; }
+    }
+    for (int kb = 0; kb < nblk; ++kb) pack_off[kb + 1] = pack_off[kb] + (long long)128 * 128 * (kb + 1 - pack_col0[kb]);
+    packed_elems_ = (size_t)pack_off[nblk];
+    pack_col0_h_ = pack_col0; pack_off_h_ = pack_off;
+  }
+  if (opt_.allreduce) {
+    if (opt_.reduce_buffer) {
+      if (opt_.reduce_buffer_bytes < packed_elems_ * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", packed_elems_ * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
+      b_pack_.adopt(static_cast<double*>(opt_.reduce_buffer), packed_elems_);
+    } else {
+      SK_HIP_TRY(b_pack_.alloc(packed_elems_));
+    }
+    SK_HIP_TRY(b_pack_.zero(stream_));
+    int rc = choose_distribution(opt);
+    if (rc) return rc;
+  }
+  {
+    const int nblk = npad_ / 128;
     // ---- dissect? (one process, library's own plan, CU-masked stream sets available) ----
     const bool may_dissect = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && !opt_.allreduce && opt_.lookahead && opt_.cholesky_group == 0 &&
                              chol_ctx_b_.init_secondary(chol_ctx_) == hipSuccess;
@@ -480,7 +511,7 @@ int BalSolver::setup() {
     if (may_dissect) {
       std::vector<int> first_col;
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
-      Dissection ds = choose_dissection(ocam, opt, C_, P_total_, nblk, best_env, first_col);
+      Dissection ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col);
       // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
       // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon.  ON forces it;
@@ -519,13 +550,6 @@ int BalSolver::setup() {
         for (int& c : ocam) c = fin[c];
         cam_a_ = a; cam_b_ = a + nt;
       }
-    }
-    if (opt_.envelope) env_last_.swap(best_env);
-    if (getenv("SK_DEBUG_ENVELOPE") && opt_.envelope) {
-      long h = 0;
-      for (int c = 0; c < nblk; ++c) h += env_last_[c] - c;
-      std::fprintf(stderr, "[skeres_amd] camera order %d (0 first appearance, 1 memory, 2 RCM); envelope: %d block columns, mean height %.1f; "
-                   "trailing-update flops %.3e (full %.3e)\n", best_k, nblk, (double)h / nblk, best, full);
     }
   }
   int p_lo = 0, p_hi = P_total_;
@@ -658,6 +682,7 @@ int BalSolver::setup() {
     SK_HIP_TRY(b_Linv_.alloc(linv_off)); SK_HIP_TRY(b_Linv_.zero(s));
     SK_HIP_TRY(b_yf_.alloc(y_off)); SK_HIP_TRY(b_yf_.zero(s)); SK_HIP_TRY(b_wf_.alloc(y_off)); SK_HIP_TRY(b_ybB_.alloc((size_t)std::max(1, border_blocks_) * 128));
   }
+  if (opt_.allreduce) { SK_HIP_TRY(b_pack_col0_.upload(pack_col0_h_, s)); SK_HIP_TRY(b_pack_off_.upload(pack_off_h_, s)); }
   if (chain_ok()) cholesky_prepare(&chol_ctx_, s);  // (once per device: which queues the resident panel chain uses)
   if (dissected_) SK_HIP_TRY(chol_ctx_b_.init_secondary(chol_ctx_));  // (again, now that the queue choice is made: the queues it left over)
   SK_HIP_TRY(b_S_.zero(s));  // once: the blocks outside the envelopes are never touched again
@@ -871,10 +896,10 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   kt_.begin("bal_pair", s); launch_bal_pair(d_, s); kt_.end("bal_pair", s);
   if (opt_.allreduce) {
     // sum S (with the rhs row) over ranks: only its lower block triangle travels (half the bytes)
-    launch_tri_pack(d_.S, npad_, b_pack_.p, npad_ / 128, true, s);  // (never dissected here: front[2] is the whole system)
+    launch_tri_pack(d_.S, npad_, b_pack_.p, npad_ / 128, b_pack_col0_.p, b_pack_off_.p, true, s);  // (never dissected here: front[2] is the whole system)
     int rc = allreduce(b_pack_.p, packed_elems_);
     if (rc) return rc;
-    launch_tri_pack(d_.S, npad_, b_pack_.p, npad_ / 128, false, s);
+    launch_tri_pack(d_.S, npad_, b_pack_.p, npad_ / 128, b_pack_col0_.p, b_pack_off_.p, false, s);
   }
   // D_c^2 onto the cameras' diagonal entries; the padded tails of the interiors and of the root are identities, and the
   // augmented right-hand-side row of the root gets a huge diagonal so that its factorisation stays positive definite (the
