@@ -44,7 +44,8 @@ def main():
     from helpers import bal_problem_to_sk, solve_bal_gpu
 
     mode = sys.argv[1] if len(sys.argv) > 1 else "auto"
-    prob = bal.generate(16, 600, 2600, seed=11)
+    shape = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [16, 600, 2600, 11]
+    prob = bal.generate(shape[0], shape[1], shape[2], seed=shape[3])
     x_plain, s_plain = solve_bal_gpu(prob)
     problem, params, loss = bal_problem_to_sk(prob)
     options = sk.Solver.Options()
@@ -55,6 +56,9 @@ def main():
     summary = sk.Solver.Summary()
     solver = sk.StepSolver(options, problem)
     used, t_allreduce, t_saved = solver.distribution()
+    if shape[0] >= 200 and mode == "sharded":
+        # a camera sequence long enough for a band: only the blocks inside the envelope travel
+        assert solver.stat("allreduce_bytes") < 0.7 * solver.stat("allreduce_bytes_full_triangle"), (solver.stat("allreduce_bytes"), solver.stat("allreduce_bytes_full_triangle"))
     while not solver.step():
         pass
     solver.finish(summary)

@@ -830,7 +830,7 @@ def test_distributed_hook_path_world_of_one_matches_plain_solve():
 
 
 @pytest.mark.parametrize("world,mode", [(2, "sharded"), (3, "sharded"), (2, "replicated"), (2, "auto")])
-def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode):
+def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode, shape=None):
     """tests/dist_gpu_worker2.py: `world` ranks share GPU 0 and exchange through gloo (host-staged hook)."""
     import os
     import subprocess
@@ -838,10 +838,18 @@ def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29900 + world + (os.getpid() % 60)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker2.py"), mode]
+           "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker2.py"), mode] + ([shape] if shape else [])
     out = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "DIST_GPU2_OK world=%d" % world in out.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_solve_sends_only_the_envelope(world):
+    """The same with a camera sequence long enough for a banded reduced system (400 cameras, 29 block columns): the
+    all-reduce carries the blocks inside the envelope only, and the sharded solve follows the
+    single-GPU trajectory to 1e-10."""
+    test_sharded_solve_on_one_gpu_with_a_real_exchange(world, "sharded", "400,12000,60000,3")
 
 
 # ---------------------------------------------------------------------------
