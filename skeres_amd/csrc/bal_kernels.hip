@@ -351,6 +351,11 @@ __global__ void lm_diagonal_kernel(const double* colsq, double* D, int n, double
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) D[j] = sqrt(fmin(fmax(colsq[j], lo), hi) / radius);
 }
+// the same with the radius in device memory: the launch is then identical from one iteration to the next (hipGraph replay)
+__global__ void lm_diagonal_dev_kernel(const double* colsq, double* D, int n, double lo, double hi, const double* radius) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) D[j] = sqrt(fmin(fmax(colsq[j], lo), hi) / radius[0]);
+}
 // partial[0] = max |gs_j / scale_j| , partial[1] = sum x_j^2 over this block
 __global__ __launch_bounds__(kBlock) void grad_max_xnorm_kernel(const double* gs, const double* scale, const double* x,
                                                                 int n, double* partial, int stride) {
@@ -785,6 +790,7 @@ void launch_bal_pt_reduce(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaun
 void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(jacobi_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, scale, n); }
 void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(apply_scale_to_reductions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, gs, scale, n); }
 void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(lm_diagonal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, D, n, lo, hi, radius); }
+void launch_lm_diagonal_dev(const double* colsq, double* D, int n, double lo, double hi, const double* radius, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(lm_diagonal_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, D, n, lo, hi, radius); }
 int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x, int n, double* partial, int stride, hipStream_t s) {
   const int g = grid_for(n, 256);
   hipLaunchKernelGGL(grad_max_xnorm_kernel, dim3(g), dim3(kBlock), 0, s, gs, scale, x, n, partial, stride);

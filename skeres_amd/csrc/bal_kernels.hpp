@@ -89,6 +89,7 @@ void launch_bal_pt_reduce(const BalDev& d, hipStream_t s);
 void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s);
 void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* scale, int n, hipStream_t s);
 void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s);
+void launch_lm_diagonal_dev(const double* colsq, double* D, int n, double lo, double hi, const double* radius, hipStream_t s);
 int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x, int n, double* partial, int stride, hipStream_t s);
 void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s);
 void launch_bal_point_block(const BalDev& d, hipStream_t s);

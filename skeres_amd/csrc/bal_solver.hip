@@ -158,7 +158,7 @@ class BalSolver : public SolverBase {
   int evaluate_with_jacobian(bool first) override;
   int try_step(double radius, bool* valid, double* mcc, double* new_cost, double* step_norm) override;
   int try_step_once(double radius, bool* valid, double* mcc, double* new_cost, double* step_norm, bool* chain_lost);
-  void accept_candidate() override { std::swap(d_.xc, d_.xc_new); std::swap(d_.xp, d_.xp_new); }
+  void accept_candidate() override { std::swap(d_.xc, d_.xc_new); std::swap(d_.xp, d_.xp_new); parity_ ^= 1; }
   int write_back() override;
   void describe(Summary* s) override {
     s->num_parameter_blocks = (int)problem_->block_size.size();
@@ -207,6 +207,16 @@ class BalSolver : public SolverBase {
   DissectedSystem ds_;
   CholeskyContext chol_ctx_b_;
   KernelTimer kt_b_;  // launches enqueued by the tail front's own thread
+  // Small problems (BASELINE.json configs[1], BAL-49: a reduced system of four 128-blocks) are bound by launch latency:
+  // ~60 launches of a few microseconds each per iteration.  Their two launch sequences — the linear solve with the
+  // candidate evaluation, and the Jacobian evaluation — are identical from iteration to iteration except for the trust
+  // region radius (read from device memory here) and for which of the two parameter buffers is current (`parity_`), so
+  // each is captured into a hipGraph once per parity and replayed.
+  bool graph_mode_ = false;
+  int parity_ = 0;
+  hipGraphExec_t g_step_[2] = {nullptr, nullptr}, g_eval_[2] = {nullptr, nullptr};
+  bool graph_ok() const { return graph_mode_ && !kt_.enabled(); }
+  int finish_capture(hipStream_t s, hipGraphExec_t* exec);
   DevBuf<int> b_zero_col0_f_[3], b_mapB_;
   DevBuf<double> b_yf_, b_wf_, b_ybB_;
   double order_hash_ = 0.0;    // of the camera order and the envelope: equal on every rank, or setup() fails
@@ -225,7 +235,10 @@ class BalSolver : public SolverBase {
   double* h_scal_ = nullptr;  // pinned
   int partial_stride_ = 0;
  public:
-  ~BalSolver() override { if (h_scal_) (void)hipHostFree(h_scal_); }
+  ~BalSolver() override {
+    for (hipGraphExec_t g : {g_step_[0], g_step_[1], g_eval_[0], g_eval_[1]}) if (g) (void)hipGraphExecDestroy(g);
+    if (h_scal_) (void)hipHostFree(h_scal_);
+  }
 };
 
 // ---- camera ordering for the reduced system --------------------------------------------------------------
@@ -755,6 +768,11 @@ int BalSolver::setup() {
     h_cam_ = cam; h_pt_ = pt;
     host_x_.resize(nx); host_rows_h_.resize(host_obs_.size() * (size_t)kHostRow);
   }
+  {
+    const char* e = getenv("SK_BAL_GRAPH");  // developer knob: 0 = never replay graphs
+    graph_mode_ = npad_ / 128 <= 8 && !opt_.allreduce && host_obs_.empty() && !dissected_ && !(e && !atoi(e));
+    if (graph_mode_) opt_.lookahead = false;  // one stream: the whole iteration is one in-order launch sequence
+  }
   SK_HIP_TRY(hipStreamSynchronize(s));
   if (opt_.allreduce) {
     // every rank derived the camera order and the envelope for itself (from rank-invariant data): they must be the same
@@ -817,6 +835,10 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   hipStream_t s = stream_;
   const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_;
   SK_HIP_TRY(hipEventRecord(ev_[kEvBegin], s));
+  const bool graph = graph_ok() && !first;  // (iteration 0 also derives the Jacobi scaling: its own sequence, run once)
+  const bool replay = graph && g_eval_[parity_] != nullptr;
+  if (graph && !replay && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graph_mode_ = false; return evaluate_with_jacobian(first); }
+  if (!replay) {
   kt_.begin("bal_eval_jac", s); launch_bal_eval_jac(d_, s); kt_.end("bal_eval_jac", s);
   int nb = bal_partial_blocks(N_);
   if (d_.num_host > 0) {
@@ -849,6 +871,11 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   const int gp = launch_grad_max_xnorm(d_.gs_p, d_.scale_p, d_.xp, (int)np, b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, s);
   launch_final_reduce(b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, np ? gp : 0, 2, 1, b_scal_.p + 2, s);
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  if (graph) {
+    if (!replay) { int rc = finish_capture(s, &g_eval_[parity_]); if (rc) return rc; if (!graph_mode_) return evaluate_with_jacobian(first); }
+    SK_HIP_TRY(hipGraphLaunch(g_eval_[parity_], s));
+  }
   SK_HIP_TRY(hipEventRecord(ev_[kEvJac], s));
   SK_HIP_TRY(hipStreamSynchronize(s));
   const double sumsq = h_scal_[4];
@@ -882,7 +909,20 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_;
   *valid = false;
   SK_HIP_TRY(hipEventRecord(ev_[kEvBegin], s));
-  launch_lm_diagonal(b_colsq_.p, b_D_.p, (int)(nc + np), opt_.min_lm_diagonal, opt_.max_lm_diagonal, radius, s);
+  const bool graph = graph_ok();
+  const bool replay = graph && g_step_[parity_] != nullptr;
+  bool candidate_failed = false;  // a cost function that cannot be evaluated at the candidate: the step is rejected (cost = max)
+  if (graph) {
+    h_scal_[32] = radius;  // pinned: the captured host-to-device copy reads it when the graph RUNS
+    if (!replay && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graph_mode_ = false; return try_step_once(radius, valid, mcc, new_cost, step_norm, chain_lost); }
+  }
+  if (!replay) {
+  if (graph) {
+    SK_HIP_TRY(hipMemcpyAsync(b_scal_.p + 12, h_scal_ + 32, sizeof(double), hipMemcpyHostToDevice, s));
+    launch_lm_diagonal_dev(b_colsq_.p, b_D_.p, (int)(nc + np), opt_.min_lm_diagonal, opt_.max_lm_diagonal, b_scal_.p + 12, s);
+  } else {
+    launch_lm_diagonal(b_colsq_.p, b_D_.p, (int)(nc + np), opt_.min_lm_diagonal, opt_.max_lm_diagonal, radius, s);
+  }
   // ---- B. Schur complement assembly ----
   kt_.begin("memset_S", s);
   for (int f = 0; f < 3; ++f)  // only what the factorisations can read
@@ -909,7 +949,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     if (fr_[f].nblk > 0) launch_set_diagonal(d_.front[f].S, (int)fr_[f].dim, 9 * fr_[f].cams, fr_[f].ncols * 128, 1.0, s);
   launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row, fr_[2].rhs_row + 1, 1e300, s);
   launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row + 1, (int)fr_[2].dim, 1.0, s);
-  SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
+  if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
   CholeskyContext* ctx = opt_.lookahead ? &chol_ctx_ : nullptr;
   double* yf[3] = {b_yf_.p + fr_[0].y_off, b_yf_.p + fr_[1].y_off, b_yf_.p + fr_[2].y_off};
@@ -923,31 +963,40 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env());
   }
   launch_bal_gather_y(d_, s);
-  SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
+  if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----
   launch_bal_cam_step(d_, b_scal_.p + 8, s);
   const int gb = launch_bal_point_backsub(d_, s);
   launch_final_reduce(b_partial_.p, partial_stride_, P_ > 0 ? gb : 0, 1, 0, b_scal_.p + 9, s);
-  SK_HIP_TRY(hipEventRecord(ev_[kEvBacksub], s));
+  if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvBacksub], s));
   kt_.begin("bal_eval_cost", s); launch_bal_eval_cost(d_, s); kt_.end("bal_eval_cost", s);
   int nb_cost = bal_partial_blocks(N_);
-  bool candidate_failed = false;  // a cost function that cannot be evaluated at the candidate: the step is rejected (cost = max)
   if (d_.num_host > 0) {
     int rc = host_callbacks(d_.xc_new, false, &candidate_failed);
     if (rc) return rc;
     nb_cost += launch_bal_host_cost(d_, nb_cost, s);
   }
   launch_final_reduce(b_partial_.p, partial_stride_, nb_cost, 2, 0, b_scal_.p, s);
-  SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
+  if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 16, b_fail_.p, sizeof(int), hipMemcpyDeviceToHost, s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 17, b_info_.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  }
+  if (graph) {
+    if (!replay) { int rc = finish_capture(s, &g_step_[parity_]); if (rc) return rc; if (!graph_mode_) return try_step_once(radius, valid, mcc, new_cost, step_norm, chain_lost); }
+    SK_HIP_TRY(hipGraphLaunch(g_step_[parity_], s));
+    SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
+  }
   SK_HIP_TRY(hipStreamSynchronize(s));
   float ms = 0.f;
-  if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvAssemble]) == hipSuccess) phase_[1] += 1e-3 * ms;
-  if (hipEventElapsedTime(&ms, ev_[kEvAssemble], ev_[kEvChol]) == hipSuccess) phase_[2] += 1e-3 * ms;
-  if (hipEventElapsedTime(&ms, ev_[kEvChol], ev_[kEvBacksub]) == hipSuccess) phase_[3] += 1e-3 * ms;
-  if (hipEventElapsedTime(&ms, ev_[kEvBacksub], ev_[kEvCost]) == hipSuccess) phase_[4] += 1e-3 * ms;
+  if (graph) {  // one replayed graph: no events inside it — the whole linear solve + candidate evaluation is reported as "factor"
+    if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvCost]) == hipSuccess) phase_[2] += 1e-3 * ms;
+  } else {
+    if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvAssemble]) == hipSuccess) phase_[1] += 1e-3 * ms;
+    if (hipEventElapsedTime(&ms, ev_[kEvAssemble], ev_[kEvChol]) == hipSuccess) phase_[2] += 1e-3 * ms;
+    if (hipEventElapsedTime(&ms, ev_[kEvChol], ev_[kEvBacksub]) == hipSuccess) phase_[3] += 1e-3 * ms;
+    if (hipEventElapsedTime(&ms, ev_[kEvBacksub], ev_[kEvCost]) == hipSuccess) phase_[4] += 1e-3 * ms;
+  }
   int fail = 0, info = 0;
   std::memcpy(&fail, h_scal_ + 16, sizeof(int)); std::memcpy(&info, h_scal_ + 17, sizeof(int));
   if (cholesky_note_info(&chol_ctx_, info) && !opt_.allreduce) { *chain_lost = true; return SK_OK; }  // factor again, launch by launch
@@ -961,6 +1010,22 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   *mcc = -loc[1];
   *new_cost = candidate_failed ? std::numeric_limits<double>::max() : 0.5 * loc[0];
   *step_norm = std::sqrt(step_sq);
+  return SK_OK;
+}
+
+// End the capture on `s` and instantiate what was captured.  A runtime that cannot capture this sequence switches the
+// replay off for good (graph_mode_ = false; the caller then enqueues the launches directly), with one line on stderr.
+int BalSolver::finish_capture(hipStream_t s, hipGraphExec_t* exec) {
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s, &g);
+  if (e == hipSuccess && g) e = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
+  if (g) (void)hipGraphDestroy(g);
+  if (e != hipSuccess || !*exec) {
+    (void)hipGetLastError();
+    *exec = nullptr;
+    graph_mode_ = false;
+    std::fprintf(stderr, "[skeres_amd] hipGraph capture of the iteration failed (%s): launches are enqueued one by one\n", hipGetErrorString(e));
+  }
   return SK_OK;
 }
 

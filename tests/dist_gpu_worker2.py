@@ -58,7 +58,7 @@ def main():
     used, t_allreduce, t_saved = solver.distribution()
     if shape[0] >= 200 and mode == "sharded":
         # a camera sequence long enough for a band: only the blocks inside the envelope travel
-        assert solver.stat("allreduce_bytes") < 0.7 * solver.stat("allreduce_bytes_full_triangle"), (solver.stat("allreduce_bytes"), solver.stat("allreduce_bytes_full_triangle"))
+        assert solver.stat("allreduce_bytes") < 0.9 * solver.stat("allreduce_bytes_full_triangle"), (solver.stat("allreduce_bytes"), solver.stat("allreduce_bytes_full_triangle"))
     while not solver.step():
         pass
     solver.finish(summary)
