@@ -319,11 +319,16 @@ int sk_options_set_cholesky_dissection(sk_options* o, int mode);
 typedef int (*sk_allreduce_fn)(void* user, double* device_buffer, size_t count, void* hip_stream);
 int sk_options_set_distributed(sk_options* o, int rank, int world, sk_allreduce_fn allreduce,
                                void* user);
-/* What a world > 1 does with its ranks.  SHARDED: points partitioned, one all-reduce of the reduced system
+/* SEGMENTED: the camera sequence is dissected (sk_options_set_cholesky_dissection): rank 0's device eliminates the head and
+ * its points, rank 1's the tail (further ranks replicate rank r mod 2 and add zeros to the sums); what is all-reduced per
+ * iteration is the separator's system with both Schur complements — a few MB instead of the reduced system — and the two
+ * serial chains run on two chips.  Chosen by AUTO when the model of the two chains predicts a gain; asked for explicitly it
+ * is SK_ERR_UNSUPPORTED for a problem without a separator or with an explicit Cholesky grouping.
+ * What a world > 1 does with its ranks.  SHARDED: points partitioned, one all-reduce of the reduced system
  * (its lower block triangle, packed) per linear solve.  REPLICATED: every rank solves the whole problem, no
  * collective.  AUTO (default): the solver times the all-reduce on the real buffer at set-up, estimates the
  * per-iteration work sharding would remove, and shards only when that pays (same decision on every rank). */
-enum { SK_DISTRIBUTION_AUTO = 0, SK_DISTRIBUTION_SHARDED = 1, SK_DISTRIBUTION_REPLICATED = 2 };
+enum { SK_DISTRIBUTION_AUTO = 0, SK_DISTRIBUTION_SHARDED = 1, SK_DISTRIBUTION_REPLICATED = 2, SK_DISTRIBUTION_SEGMENTED = 3 };
 int sk_options_set_distribution_mode(sk_options* o, int mode);
 /* The caller may hand the solver the buffer the big all-reduce runs on (so a
  * torch.distributed / RCCL communicator can register it).  bytes must be >=

@@ -1117,7 +1117,7 @@ class StepSolver:
         """("sharded" | "replicated", measured all-reduce seconds, estimated seconds of work sharding removes per iteration)."""
         a, b = C.c_double(), C.c_double()
         mode = lib().sk_solver_distribution(self._h, C.byref(a), C.byref(b))
-        return {1: "sharded", 2: "replicated"}.get(mode, "sharded"), a.value, b.value
+        return {1: "sharded", 2: "replicated", 3: "segmented"}.get(mode, "sharded"), a.value, b.value
 
 
 def cholesky_solve(A, b, want_L=False, group=0, last=None, automatic_plan=False):

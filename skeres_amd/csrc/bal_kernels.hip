@@ -520,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
   for (int k = 0; k < 45; ++k) acc[k] = wave_sum(acc[k]);
 #pragma unroll
   for (int k = 0; k < 9; ++k) rh[k] = wave_sum(rh[k]);
-  if (lane == 0) {
+  if (lane == 0 && d.front[bal_part(d, i)].S) {  // (a rank of a segmented world holds one leaf front and the root)
     int k = 0, ld;
     double* blk = bal_block(d, i, i, &ld);
     double* rhs = bal_rhs(d, i);
@@ -619,10 +619,12 @@ __global__ void finish_normal_matrix_kernel(double* S, int ld, int n, int npad, 
   else if (j == rhs_row) S[(size_t)j * ld + j] = 1e300;
   else S[(size_t)j * ld + j] = 1.0;
 }
-__global__ void bal_finish_S_kernel(BalDev d) {
+// parts: bit k set = the cameras of part k (0 head, 1 tail, 2 separator / everything when undissected)
+__global__ void bal_finish_S_kernel(BalDev d, int parts) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= 9 * d.C) return;
-  const int i = j / 9, c = j - 9 * i;
+  const int i = j / 9, c = j - 9 * i, part = bal_part(d, i);
+  if (!((parts >> part) & 1) || !d.front[part].S) return;
   int ld;
   double* blk = bal_block(d, i, i, &ld);
   blk[(size_t)c * ld + c] += d.D_c[j] * d.D_c[j];
@@ -635,7 +637,7 @@ __global__ void bal_gather_y_kernel(BalDev d) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= 9 * d.C) return;
   const int i = j / 9, c = j - 9 * i, part = bal_part(d, i);
-  d.y_c[j] = d.y_front[part][bal_pos(d, i, part) + c];
+  d.y_c[j] = d.front[part].S ? d.y_front[part][bal_pos(d, i, part) + c] : 0.0;  // (another rank's segment: no step here)
 }
 
 // ---------------------------------------------------------------------------
@@ -695,7 +697,9 @@ __global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
 }
 
 // cameras: step_c = -y_c ; xc_new = xc + step_c * scale_c ; out[0] = |delta_c|^2
-__global__ __launch_bounds__(kBlock) void bal_cam_step_kernel(BalDev d, double* out) {
+// (norm_lo, norm_hi: the coordinates whose step this rank accounts for — all of them, or in a segmented world its own
+// segment's, the separator's being counted by the head's rank alone)
+__global__ __launch_bounds__(kBlock) void bal_cam_step_kernel(BalDev d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2) {
   double acc = 0.0;
   const int n = 9 * d.C;
   for (int j = threadIdx.x; j < n; j += kBlock) {
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(kBlock) void bal_cam_step_kernel(BalDev d, double* 
     const double xn = xo + st * d.scale_c[j];
     d.xc_new[j] = xn;
     const double df = xo - xn;
-    acc += df * df;
+    if ((j >= norm_lo && j < norm_hi) || (j >= norm_lo2 && j < norm_hi2)) acc += df * df;
   }
   __shared__ double sh[kBlock / 64];
   acc = wave_sum(acc);
@@ -809,7 +813,7 @@ void launch_bal_pair(const BalDev& d, hipStream_t s) {
   }
 }
 void launch_finish_normal_matrix(double* S, int ld, int n, int npad, int rhs_row, const double* D, hipStream_t s) { hipLaunchKernelGGL(finish_normal_matrix_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, n, npad, rhs_row, D); }
-void launch_bal_finish_S(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_finish_S_kernel, dim3((9 * d.C + 255) / 256), dim3(256), 0, s, d); }
+void launch_bal_finish_S(const BalDev& d, int parts, hipStream_t s) { hipLaunchKernelGGL(bal_finish_S_kernel, dim3((9 * d.C + 255) / 256), dim3(256), 0, s, d, parts); }
 void launch_set_diagonal(double* S, int ld, int from, int to, double value, hipStream_t s) {
   if (to > from) hipLaunchKernelGGL(set_diagonal_kernel, dim3((to - from + 255) / 256), dim3(256), 0, s, S, ld, from, to, value);
 }
@@ -820,6 +824,8 @@ int launch_bal_point_backsub(const BalDev& d, hipStream_t s) {
   hipLaunchKernelGGL(bal_point_backsub_kernel, dim3(g), dim3(kBlock), 0, s, d);
   return g;
 }
-void launch_bal_cam_step(const BalDev& d, double* out, hipStream_t s) { hipLaunchKernelGGL(bal_cam_step_kernel, dim3(1), dim3(kBlock), 0, s, d, out); }
+void launch_bal_cam_step(const BalDev& d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2, hipStream_t s) {
+  hipLaunchKernelGGL(bal_cam_step_kernel, dim3(1), dim3(kBlock), 0, s, d, out, norm_lo, norm_hi, norm_lo2, norm_hi2);
+}
 
 }  // namespace sk

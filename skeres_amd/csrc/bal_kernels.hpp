@@ -97,10 +97,10 @@ void launch_bal_obs_precompute(const BalDev& d, hipStream_t s);
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s);
 void launch_bal_pair(const BalDev& d, hipStream_t s);
 void launch_finish_normal_matrix(double* S, int ld, int n, int npad, int rhs_row, const double* D, hipStream_t s);
-void launch_bal_finish_S(const BalDev& d, hipStream_t s);  // D_c^2 onto the cameras' diagonal entries
+void launch_bal_finish_S(const BalDev& d, int parts, hipStream_t s);  // D_c^2 onto the diagonal entries of the cameras of `parts` (bit mask)
 void launch_set_diagonal(double* S, int ld, int from, int to, double value, hipStream_t s);  // S[j][j] = value, from <= j < to
 void launch_bal_gather_y(const BalDev& d, hipStream_t s);  // y_c[9 i + k] from the fronts' solutions
 int launch_bal_point_backsub(const BalDev& d, hipStream_t s);
-void launch_bal_cam_step(const BalDev& d, double* out, hipStream_t s);
+void launch_bal_cam_step(const BalDev& d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2, hipStream_t s);
 
 }  // namespace sk

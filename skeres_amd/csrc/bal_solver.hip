@@ -202,6 +202,9 @@ class BalSolver : public SolverBase {
   };
   FrontHost fr_[3];
   bool dissected_ = false;
+  bool segmented_ = false;  // several ranks: this rank holds ONE leaf front (role_: 0 head, 1 tail) and the root
+  int role_ = 0;
+  int fold_world_ = 0;      // ranks whose contributions count in gather_rank_scalars (0: all; segmented: the first two)
   int cam_a_ = 0, cam_b_ = 0, border_blocks_ = 0;
   double dissect_t_plain_ = 0.0, dissect_t_model_ = 0.0;
   DissectedSystem ds_;
@@ -504,34 +507,32 @@ int BalSolver::setup() {
     packed_elems_ = (size_t)pack_off[nblk];
     pack_col0_h_ = pack_col0; pack_off_h_ = pack_off;
   }
-  if (opt_.allreduce) {
-    if (opt_.reduce_buffer) {
-      if (opt_.reduce_buffer_bytes < packed_elems_ * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", packed_elems_ * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
-      b_pack_.adopt(static_cast<double*>(opt_.reduce_buffer), packed_elems_);
-    } else {
-      SK_HIP_TRY(b_pack_.alloc(packed_elems_));
-    }
-    SK_HIP_TRY(b_pack_.zero(stream_));
-    int rc = choose_distribution(opt);
-    if (rc) return rc;
-  }
   {
     const int nblk = npad_ / 128;
-    // ---- dissect? (one process, library's own plan, CU-masked stream sets available) ----
-    const bool may_dissect = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && !opt_.allreduce && opt_.lookahead && opt_.cholesky_group == 0 &&
-                             chol_ctx_b_.init_secondary(chol_ctx_) == hipSuccess;
+    // ---- dissect?  One process: only when forced (measured not to pay on one chip).  Several ranks: the SEGMENTED
+    // distribution — the head's chain on the even ranks' devices, the tail's on the odd ranks' — when the model of the two
+    // chains predicts a gain (or when asked for). ----
+    const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0;
+    const bool multi = opt_.allreduce != nullptr && opt_.world >= 2;
+    bool may_dissect = plan_ok && (multi ? (opt_.distribution_mode == SK_DISTRIBUTION_AUTO || opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED)
+                                         : (!opt_.allreduce && chol_ctx_b_.init_secondary(chol_ctx_) == hipSuccess));
     if (!may_dissect) (void)hipGetLastError();
+    if (!plan_ok && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED) {
+      set_error("the segmented distribution needs the library's own factorisation plan (envelope, look-ahead, no explicit group); not supported with these options");
+      return SK_ERR_UNSUPPORTED;
+    }
+    Dissection ds;
     if (may_dissect) {
       std::vector<int> first_col;
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
-      Dissection ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col);
+      ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col);
       // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
-      // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon.  ON forces it;
-      // the fronts are what a two-device split of the factorisation is made of.
-      if (opt_.dissection == SK_DISSECTION_AUTO && !getenv("SK_DISSECT_AT")) { ds.a = ds.b = 0; }
-      if (opt_.dissection == SK_DISSECTION_ON && ds.a == 0 && C_ >= 6) {
-        // forced (tests): cut at the middle camera wherever that leaves a tail
+      // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon there.
+      if (!multi && opt_.dissection == SK_DISSECTION_AUTO && !getenv("SK_DISSECT_AT")) { ds.a = ds.b = 0; }
+      const bool forced = multi ? opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED : opt_.dissection == SK_DISSECTION_ON;
+      if (forced && ds.a == 0 && C_ >= 6) {
+        // forced (tests, small problems): cut at the middle camera wherever that leaves a tail
         std::vector<int> cmin(P_total_, C_), cmax(P_total_, -1);
         for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); }
         for (int a = C_ / 2; a >= 1 && ds.a == 0; --a) {
@@ -551,43 +552,88 @@ int BalSolver::setup() {
         } else ds.a = 0;
       }
       dissect_t_plain_ = ds.t_plain; dissect_t_model_ = ds.t_dissected;
-      if (ds.a > 0 && ds.b < C_) {
-        dissected_ = true;
-        // final numbering: head [0, a) as it is, tail [b, C) REVERSED to [a, a + C - b), separator [a, b) last
-        const int a = ds.a, b = ds.b, nt = C_ - b;
-        std::vector<int> fin(C_);
-        for (int c = 0; c < C_; ++c) fin[c] = c < a ? c : (c >= b ? a + (C_ - 1 - c) : a + nt + (c - a));
-        std::vector<int> cb2(C_);
-        for (int c = 0; c < C_; ++c) cb2[fin[c]] = cam_block_[c];
-        cam_block_.swap(cb2);
-        for (int& c : ocam) c = fin[c];
-        cam_a_ = a; cam_b_ = a + nt;
-      }
+    }
+    if (multi && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && !(ds.a > 0 && ds.b < C_)) {
+      set_error("the segmented distribution needs a separator in the camera sequence (no point seen from both ends); not supported for this problem");
+      return SK_ERR_UNSUPPORTED;
+    }
+    if (ds.a > 0 && ds.b < C_) {
+      dissected_ = true;
+      segmented_ = multi;
+      // final numbering: head [0, a) as it is, tail [b, C) REVERSED to [a, a + C - b), separator [a, b) last
+      const int a = ds.a, b = ds.b, nt = C_ - b;
+      std::vector<int> fin(C_);
+      for (int c = 0; c < C_; ++c) fin[c] = c < a ? c : (c >= b ? a + (C_ - 1 - c) : a + nt + (c - a));
+      std::vector<int> cb2(C_);
+      for (int c = 0; c < C_; ++c) cb2[fin[c]] = cam_block_[c];
+      cam_block_.swap(cb2);
+      for (int& c : ocam) c = fin[c];
+      cam_a_ = a; cam_b_ = a + nt;
     }
   }
-  int p_lo = 0, p_hi = P_total_;
-  if (opt_.world > 1) {
-    std::vector<int> cut;
-    bal_partition_points(opt, P_total_, opt_.world, &cut);
-    p_lo = cut[opt_.rank]; p_hi = cut[opt_.rank + 1];
+  if (segmented_) {
+    // Ranks 0 and 1 own the head and the tail; further ranks are replicas of rank (r mod 2): they do the same work and add
+    // zeros to every sum.  What is exchanged per iteration: the root front (the separator's system with both Schur
+    // complements), the separator cameras' column norms and gradient, and a handful of scalars.
+    distribution_ = SK_DISTRIBUTION_SEGMENTED;
+    role_ = opt_.rank % 2;
+    fold_world_ = 2;
+    const int nsep = C_ - cam_b_, E = (9 * nsep + 1 + 127) / 128;
+    packed_elems_ = tri_packed_elems(E);
+    pack_col0_h_.assign(E, 0);
+    pack_off_h_.assign(E + 1, 0);
+    for (int kb = 0; kb < E; ++kb) pack_off_h_[kb + 1] = pack_off_h_[kb] + (long long)128 * 128 * (kb + 1);
   }
-  P_ = p_hi - p_lo;
-  local_pt_.resize(P_); std::iota(local_pt_.begin(), local_pt_.end(), p_lo);
+  if (opt_.allreduce) {
+    if (opt_.reduce_buffer) {
+      if (opt_.reduce_buffer_bytes < packed_elems_ * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", packed_elems_ * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
+      b_pack_.adopt(static_cast<double*>(opt_.reduce_buffer), packed_elems_);
+    } else {
+      SK_HIP_TRY(b_pack_.alloc(packed_elems_));
+    }
+    SK_HIP_TRY(b_pack_.zero(stream_));
+    if (!segmented_) {
+      int rc = choose_distribution(opt);
+      if (rc) return rc;
+    }
+  }
+  // ---- this rank's points: a contiguous run of equal sum k^2 (sharded), or (segmented) the points that see a camera of
+  // its segment — each such point sees only that segment and the separator — plus every other of the points that see the
+  // separator alone ----
+  std::vector<int> local_of(P_total_, -1);
+  if (segmented_) {
+    std::vector<char> touches(P_total_, 0);  // bit 0 head, 1 tail, 2 separator
+    for (int b = 0; b < Nall; ++b) touches[opt[b]] |= (char)(ocam[b] < cam_a_ ? 1 : (ocam[b] < cam_b_ ? 2 : 4));
+    for (int q = 0; q < P_total_; ++q) {
+      const bool mine = (touches[q] & (role_ == 0 ? 1 : 2)) || (touches[q] == 4 && (q % 2) == role_);
+      if (mine) { local_of[q] = (int)local_pt_.size(); local_pt_.push_back(q); }
+    }
+  } else {
+    int p_lo = 0, p_hi = P_total_;
+    if (opt_.world > 1) {
+      std::vector<int> cut;
+      bal_partition_points(opt, P_total_, opt_.world, &cut);
+      p_lo = cut[opt_.rank]; p_hi = cut[opt_.rank + 1];
+    }
+    local_pt_.resize(p_hi - p_lo); std::iota(local_pt_.begin(), local_pt_.end(), p_lo);
+    for (int q = p_lo; q < p_hi; ++q) local_of[q] = q - p_lo;
+  }
+  P_ = (int)local_pt_.size();
   // local observations, point-major, ascending camera within a point
   std::vector<int> pt_start(P_ + 1, 0);
-  for (int b = 0; b < Nall; ++b) if (opt[b] >= p_lo && opt[b] < p_hi) pt_start[opt[b] - p_lo + 1]++;
+  for (int b = 0; b < Nall; ++b) if (local_of[opt[b]] >= 0) pt_start[local_of[opt[b]] + 1]++;
   for (int q = 0; q < P_; ++q) pt_start[q + 1] += pt_start[q];
   N_ = pt_start[P_];
   std::vector<int> order(N_);
   { std::vector<int> fill(pt_start.begin(), pt_start.end() - 1);
-    for (int b = 0; b < Nall; ++b) if (opt[b] >= p_lo && opt[b] < p_hi) order[fill[opt[b] - p_lo]++] = b; }
+    for (int b = 0; b < Nall; ++b) if (local_of[opt[b]] >= 0) order[fill[local_of[opt[b]]]++] = b; }
   for (int q = 0; q < P_; ++q)
     std::sort(order.begin() + pt_start[q], order.begin() + pt_start[q + 1], [&](int a, int b) { return ocam[a] != ocam[b] ? ocam[a] < ocam[b] : a < b; });
   std::vector<int> cam(N_), pt(N_);
   std::vector<double> obs(2 * (size_t)N_);
   for (int o = 0; o < N_; ++o) {
     const int b = order[o];
-    cam[o] = ocam[b]; pt[o] = opt[b] - p_lo;
+    cam[o] = ocam[b]; pt[o] = local_of[opt[b]];
     if (p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK) {  // no captured doubles on the device: the caller's object holds them
       host_obs_.push_back(o); host_cf_.push_back(p.rb_cost[b]);
     } else {
@@ -671,6 +717,7 @@ int BalSolver::setup() {
     const int nsep = C_ - cam_b_, ncam[2] = {cam_a_, cam_b_ - cam_a_};
     border_blocks_ = (9 * nsep + 1 + 127) / 128;
     for (int f = 0; f < 2; ++f) {
+      if (segmented_ && f != role_) continue;  // the other segment's front lives on the other rank's device
       FrontHost& L = fr_[f];
       L.cams = ncam[f]; L.ncols = (9 * ncam[f] + 127) / 128; L.nblk = L.ncols + border_blocks_; L.dim = (size_t)L.nblk * 128;
       L.rhs_row = L.ncols * 128 + 9 * nsep;
@@ -697,7 +744,7 @@ int BalSolver::setup() {
   }
   if (opt_.allreduce) { SK_HIP_TRY(b_pack_col0_.upload(pack_col0_h_, s)); SK_HIP_TRY(b_pack_off_.upload(pack_off_h_, s)); }
   if (chain_ok()) cholesky_prepare(&chol_ctx_, s);  // (once per device: which queues the resident panel chain uses)
-  if (dissected_) SK_HIP_TRY(chol_ctx_b_.init_secondary(chol_ctx_));  // (again, now that the queue choice is made: the queues it left over)
+  if (dissected_ && !segmented_) SK_HIP_TRY(chol_ctx_b_.init_secondary(chol_ctx_));  // (again, now that the queue choice is made: the queues it left over)
   SK_HIP_TRY(b_S_.zero(s));  // once: the blocks outside the envelopes are never touched again
   for (int f = 0; f < 3; ++f) {
     // first block column each block row is zeroed from: the row envelope, widened by the SYRK depth - 1 (inside a
@@ -741,7 +788,7 @@ int BalSolver::setup() {
   d_.gs_c = b_gs_.p; d_.gs_p = b_gs_.p + nc; d_.D_c = b_D_.p; d_.D_p = b_D_.p + nc; d_.step_c = b_step_.p; d_.step_p = b_step_.p + nc;
   d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.rt = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
   for (int f = 0; f < 3; ++f) {
-    d_.front[f].S = b_S_.p + fr_[f].s_off; d_.front[f].ld = (int)fr_[f].dim; d_.front[f].interior = fr_[f].ncols * 128;
+    d_.front[f].S = fr_[f].nblk > 0 ? b_S_.p + fr_[f].s_off : nullptr; d_.front[f].ld = (int)fr_[f].dim; d_.front[f].interior = fr_[f].ncols * 128;
     d_.y_front[f] = b_yf_.p + fr_[f].y_off;
   }
   d_.cam_a = cam_a_; d_.cam_b = cam_b_; d_.rhs_off = fr_[2].rhs_row;
@@ -754,6 +801,7 @@ int BalSolver::setup() {
       return v;
     };
     ds_.A = view(0); ds_.B = view(1); ds_.R = view(2); ds_.border_blocks = border_blocks_; ds_.mapB = b_mapB_.p;
+    if (segmented_) { if (role_ == 0) ds_.B = FrontView(); else ds_.A = FrontView(); }
   }
   d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = b_fail_.p;
   d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0];
@@ -823,9 +871,10 @@ int BalSolver::gather_rank_scalars(double* vals, int K, const int* ops) {
   if (rc) return rc;
   SK_HIP_TRY(hipMemcpyAsync(table.data(), dev, table.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
   SK_HIP_TRY(hipStreamSynchronize(stream_));
+  const int fold = fold_world_ > 0 ? std::min(fold_world_, W) : W;  // (segmented: ranks beyond the first two are replicas)
   for (int k = 0; k < K; ++k) {
     double a = 0.0;
-    for (int r = 0; r < W; ++r) a = ops[k] ? std::max(a, table[(size_t)r * K + k]) : a + table[(size_t)r * K + k];
+    for (int r = 0; r < fold; ++r) a = ops[k] ? std::max(a, table[(size_t)r * K + k]) : a + table[(size_t)r * K + k];
     vals[k] = a;
   }
   return SK_OK;
@@ -852,8 +901,12 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   launch_bal_pt_reduce(d_, s);
   if (opt_.allreduce) {  // camera columns are summed over all ranks' observations
     double* buf = b_small_.p;
-    SK_HIP_TRY(hipMemcpyAsync(buf, d_.colsq_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
-    SK_HIP_TRY(hipMemcpyAsync(buf + nc, d_.gs_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (segmented_ && opt_.rank >= 2) {  // a replica: its sums are rank (r mod 2)'s over again
+      SK_HIP_TRY(hipMemsetAsync(buf, 0, 2 * nc * sizeof(double), s));
+    } else {
+      SK_HIP_TRY(hipMemcpyAsync(buf, d_.colsq_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
+      SK_HIP_TRY(hipMemcpyAsync(buf + nc, d_.gs_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
     int rc = allreduce(buf, 2 * nc);
     if (rc) return rc;
     SK_HIP_TRY(hipMemcpyAsync(d_.colsq_c, buf, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -866,7 +919,15 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   }
   // scalars: sum r^2 (slot 4) ; gradient max-norm and |x|^2 (cameras once, points local)
   launch_final_reduce(b_partial_.p, partial_stride_, nb, 1, 0, b_scal_.p + 4, s);
-  const int gc = launch_grad_max_xnorm(d_.gs_c, d_.scale_c, d_.xc, (int)nc, b_partial_.p, partial_stride_, s);
+  // cameras: every rank holds all of them — but in a segmented world only its own segment's (and the separator's) are
+  // current, and the separator's |x|^2 must be counted once: the head's rank takes it
+  int c_lo = 0, c_n = (int)nc;
+  if (segmented_) { c_lo = role_ == 0 ? 0 : 9 * cam_a_; c_n = role_ == 0 ? 9 * cam_a_ : 9 * (cam_b_ - cam_a_); }
+  int gc = launch_grad_max_xnorm(d_.gs_c + c_lo, d_.scale_c + c_lo, d_.xc + c_lo, c_n, b_partial_.p, partial_stride_, s);
+  if (segmented_ && role_ == 0) {  // + the separator (slots behind the head's)
+    const int lo2 = 9 * cam_b_, n2 = (int)nc - lo2;
+    gc += launch_grad_max_xnorm(d_.gs_c + lo2, d_.scale_c + lo2, d_.xc + lo2, n2, b_partial_.p + gc, partial_stride_, s);
+  }
   launch_final_reduce(b_partial_.p, partial_stride_, gc, 2, 1, b_scal_.p, s);
   const int gp = launch_grad_max_xnorm(d_.gs_p, d_.scale_p, d_.xp, (int)np, b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, s);
   launch_final_reduce(b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, np ? gp : 0, 2, 1, b_scal_.p + 2, s);
@@ -880,15 +941,16 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   SK_HIP_TRY(hipStreamSynchronize(s));
   const double sumsq = h_scal_[4];
   const double gmax_c = h_scal_[0], x2_c = h_scal_[1];
-  double loc[3] = {sumsq, h_scal_[2], h_scal_[3]};  // local: sum r^2, max |g_p|, |x_p|^2
+  // local: sum r^2, max |g_p|, |x_p|^2 — and in a segmented world this rank's cameras' share of max |g_c| and |x_c|^2 too
+  double loc[3] = {sumsq, segmented_ ? std::max(h_scal_[2], gmax_c) : h_scal_[2], h_scal_[3] + (segmented_ ? x2_c : 0.0)};
   const int ops3[3] = {0, 1, 0};
   int rc = gather_rank_scalars(loc, 3, ops3);
   if (rc) return rc;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvJac]) == hipSuccess) phase_[0] += 1e-3 * ms;
   cost_ = 0.5 * loc[0];
-  gmax_ = std::max(gmax_c, loc[1]);
-  xnorm_ = std::sqrt(x2_c + loc[2]);
+  gmax_ = segmented_ ? loc[1] : std::max(gmax_c, loc[1]);
+  xnorm_ = std::sqrt((segmented_ ? 0.0 : x2_c) + loc[2]);
   if (!std::isfinite(cost_)) return SK_ERR_EVALUATION_FAILED;
   return SK_OK;
 }
@@ -944,17 +1006,37 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   // D_c^2 onto the cameras' diagonal entries; the padded tails of the interiors and of the root are identities, and the
   // augmented right-hand-side row of the root gets a huge diagonal so that its factorisation stays positive definite (the
   // entry itself is unused; in a leaf's border that diagonal stays zero: it is ADDED to the root's)
-  launch_bal_finish_S(d_, s);
+  auto finish_root = [&]() {
+    launch_bal_finish_S(d_, 4, s);
+    launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row, fr_[2].rhs_row + 1, 1e300, s);
+    launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row + 1, (int)fr_[2].dim, 1.0, s);
+  };
+  launch_bal_finish_S(d_, 3, s);
   for (int f = 0; f < 2; ++f)
     if (fr_[f].nblk > 0) launch_set_diagonal(d_.front[f].S, (int)fr_[f].dim, 9 * fr_[f].cams, fr_[f].ncols * 128, 1.0, s);
-  launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row, fr_[2].rhs_row + 1, 1e300, s);
-  launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row + 1, (int)fr_[2].dim, 1.0, s);
+  if (!segmented_) finish_root();  // (segmented: after the ranks' root fronts have been summed — D^2 and the diagonals are added once)
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
   CholeskyContext* ctx = opt_.lookahead ? &chol_ctx_ : nullptr;
   double* yf[3] = {b_yf_.p + fr_[0].y_off, b_yf_.p + fr_[1].y_off, b_yf_.p + fr_[2].y_off};
   double* wf[3] = {b_wf_.p + fr_[0].y_off, b_wf_.p + fr_[1].y_off, b_wf_.p + fr_[2].y_off};
-  if (dissected_) {
+  if (segmented_) {
+    // this rank's segment: factor its interior, leave its Schur complement on the separator; sum the root fronts over the
+    // ranks (the separator's own blocks come from whichever rank owns the point, the Schur complements from both segments);
+    // then every rank factors the same root and solves its own interior
+    const FrontView& L = role_ == 0 ? ds_.A : ds_.B;
+    cholesky_factor(L.S, L.ld, L.nblk * 128, L.Linv, b_info_.p, group_, s, ctx, &kt_, L.last, chain_ok(), L.ncols);
+    cholesky_border_add(ds_.R.S, ds_.R.ld, L.S, L.ld, L.ncols, border_blocks_, role_ == 0 ? nullptr : ds_.mapB, s);
+    if (opt_.rank >= 2) SK_HIP_TRY(hipMemsetAsync(b_pack_.p, 0, packed_elems_ * sizeof(double), s));  // a replica adds nothing
+    else launch_tri_pack(ds_.R.S, (int)ds_.R.ld, b_pack_.p, border_blocks_, b_pack_col0_.p, b_pack_off_.p, true, s);
+    int rc = allreduce(b_pack_.p, packed_elems_);
+    if (rc) return rc;
+    launch_tri_pack(ds_.R.S, (int)ds_.R.ld, b_pack_.p, border_blocks_, b_pack_col0_.p, b_pack_off_.p, false, s);
+    finish_root();
+    cholesky_factor(ds_.R.S, ds_.R.ld, ds_.R.nblk * 128, ds_.R.Linv, b_info_.p, group_, s, ctx, &kt_, ds_.R.last, chain_ok());
+    DissectedSystem mine = ds_;
+    cholesky_dissected_backsolve(mine, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, nullptr, &kt_);
+  } else if (dissected_) {
     cholesky_dissected_factor(ds_, b_info_.p, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
     cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_);
   } else {
@@ -965,7 +1047,15 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   launch_bal_gather_y(d_, s);
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----
-  launch_bal_cam_step(d_, b_scal_.p + 8, s);
+  {
+    // whose cameras' steps this rank accounts for in |step|^2: all, or (segmented) its segment's, + the separator's on the head's rank
+    int lo = 0, hi = (int)nc, lo2 = 0, hi2 = 0;
+    if (segmented_) {
+      if (role_ == 0) { lo = 0; hi = 9 * cam_a_; lo2 = 9 * cam_b_; hi2 = (int)nc; }
+      else { lo = 9 * cam_a_; hi = 9 * cam_b_; }
+    }
+    launch_bal_cam_step(d_, b_scal_.p + 8, lo, hi, lo2, hi2, s);
+  }
   const int gb = launch_bal_point_backsub(d_, s);
   launch_final_reduce(b_partial_.p, partial_stride_, P_ > 0 ? gb : 0, 1, 0, b_scal_.p + 9, s);
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvBacksub], s));
@@ -1000,11 +1090,12 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   int fail = 0, info = 0;
   std::memcpy(&fail, h_scal_ + 16, sizeof(int)); std::memcpy(&info, h_scal_ + 17, sizeof(int));
   if (cholesky_note_info(&chol_ctx_, info) && !opt_.allreduce) { *chain_lost = true; return SK_OK; }  // factor again, launch by launch
-  double loc[4] = {h_scal_[0], h_scal_[1], h_scal_[9], (double)(fail | info)};  // sum r_new^2, model term, |delta_p|^2, failure
+  // sum r_new^2, model term, |delta_p|^2 (segmented: + this rank's cameras' |delta_c|^2, which no other rank has), failure
+  double loc[4] = {h_scal_[0], h_scal_[1], h_scal_[9] + (segmented_ ? h_scal_[8] : 0.0), (double)(fail | info)};
   const int ops4[4] = {0, 0, 0, 1};
   int rc = gather_rank_scalars(loc, 4, ops4);
   if (rc) return rc;
-  const double step_sq = h_scal_[8] + loc[2];
+  const double step_sq = (segmented_ ? 0.0 : h_scal_[8]) + loc[2];
   if (loc[3] != 0.0 || !std::isfinite(step_sq) || !std::isfinite(loc[1])) return SK_OK;  // invalid step
   *valid = true;
   *mcc = -loc[1];
@@ -1057,6 +1148,22 @@ int BalSolver::write_back() {
   std::vector<double> x(nc + np);
   SK_HIP_TRY(hipMemcpyAsync(x.data(), d_.xc, (nc + np) * sizeof(double), hipMemcpyDeviceToHost, stream_));
   SK_HIP_TRY(hipStreamSynchronize(stream_));
+  if (segmented_) {
+    // a rank's cameras of the OTHER segment were never updated: every camera from the rank that owns it (the separator's
+    // from rank 0; replicas add zeros), summed into a zero-filled table
+    std::vector<double> cams(nc, 0.0);
+    if (opt_.rank < 2) {
+      const size_t lo = role_ == 0 ? 0 : 9 * (size_t)cam_a_, hi = role_ == 0 ? 9 * (size_t)cam_a_ : 9 * (size_t)cam_b_;
+      std::memcpy(&cams[lo], &x[lo], (hi - lo) * sizeof(double));
+      if (role_ == 0) std::memcpy(&cams[9 * (size_t)cam_b_], &x[9 * (size_t)cam_b_], (nc - 9 * (size_t)cam_b_) * sizeof(double));
+    }
+    DevBuf<double> tmpc;
+    SK_HIP_TRY(tmpc.upload(cams, stream_));
+    int rc = allreduce(tmpc.p, cams.size());
+    if (rc) return rc;
+    SK_HIP_TRY(hipMemcpyAsync(x.data(), tmpc.p, nc * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    SK_HIP_TRY(hipStreamSynchronize(stream_));
+  }
   for (int i = 0; i < C_; ++i) std::memcpy(problem_->block_ptr[cam_block_[i]], &x[9 * (size_t)i], 9 * sizeof(double));
   if (!opt_.allreduce) {
     for (int q = 0; q < P_; ++q) std::memcpy(problem_->block_ptr[pt_block_[local_pt_[q]]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
@@ -1064,7 +1171,8 @@ int BalSolver::write_back() {
   }
   // every rank returns ALL points: zero-filled table, own slice filled, sum-reduced
   std::vector<double> all(3 * (size_t)P_total_, 0.0);
-  for (int q = 0; q < P_; ++q) std::memcpy(&all[3 * (size_t)local_pt_[q]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
+  if (!(segmented_ && opt_.rank >= 2))  // (a replica adds zeros)
+    for (int q = 0; q < P_; ++q) std::memcpy(&all[3 * (size_t)local_pt_[q]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
   DevBuf<double> tmp;
   SK_HIP_TRY(tmp.upload(all, stream_));
   int rc = allreduce(tmp.p, all.size());

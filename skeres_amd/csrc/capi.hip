@@ -492,7 +492,7 @@ int sk_options_set_cholesky_dissection(sk_options* o, int mode) {
   o->o.dissection = mode; return SK_OK;
 }
 int sk_options_set_distribution_mode(sk_options* o, int mode) {
-  if (mode != SK_DISTRIBUTION_AUTO && mode != SK_DISTRIBUTION_SHARDED && mode != SK_DISTRIBUTION_REPLICATED) { set_error("invalid distribution mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
+  if (mode != SK_DISTRIBUTION_AUTO && mode != SK_DISTRIBUTION_SHARDED && mode != SK_DISTRIBUTION_REPLICATED && mode != SK_DISTRIBUTION_SEGMENTED) { set_error("invalid distribution mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
   o->o.distribution_mode = mode; return SK_OK;
 }
 int sk_options_set_reduce_buffer(sk_options* o, void* ptr, size_t bytes) { o->o.reduce_buffer = ptr; o->o.reduce_buffer_bytes = bytes; return SK_OK; }

@@ -852,6 +852,15 @@ def test_sharded_solve_sends_only_the_envelope(world):
     test_sharded_solve_on_one_gpu_with_a_real_exchange(world, "sharded", "400,12000,60000,3")
 
 
+@pytest.mark.parametrize("world,shape", [(2, "60,2500,12000,13"), (2, "400,12000,60000,3"), (3, "400,12000,60000,3")])
+def test_segmented_solve_on_one_gpu_with_a_real_exchange(world, shape):
+    """SK_DISTRIBUTION_SEGMENTED: the camera sequence dissected over the ranks — rank 0 eliminates the
+    head and its points, rank 1 the tail (rank 2, in the world of three, replicates rank 0 and adds zeros) — the separator's
+    system all-reduced, factored by everyone.  Same trajectory as the single-GPU solve (1e-10), every rank ends with all
+    parameters, bit for bit the same."""
+    test_sharded_solve_on_one_gpu_with_a_real_exchange(world, "segmented", shape)
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json config 5: dense rows over one block, DENSE_NORMAL_CHOLESKY with a long-K MFMA SYRK
 # ---------------------------------------------------------------------------
