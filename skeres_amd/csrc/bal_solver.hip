@@ -834,6 +834,13 @@ int BalSolver::setup() {
       return SK_ERR_COMM;
     }
     (void)ops;
+    // ... and the same factorisation plan: a rank whose device cannot run the resident panel chain (its queue trial said
+    // so: a shared or serialised device) takes every rank to the launch-by-launch plan — replicated factorisations must
+    // round alike, or the ranks' parameters drift apart
+    double off[1] = {opt_.cholesky_group == 0 && opt_.lookahead && !cholesky_chain_enabled(&chol_ctx_) ? 1.0 : 0.0};
+    rc = gather_rank_scalars_signed(off, 1);
+    if (rc) return rc;
+    if (off[0] > 0.0) cholesky_disable_chain(&chol_ctx_);
   }
   return SK_OK;
 }
@@ -1095,6 +1102,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   const int ops4[4] = {0, 0, 0, 1};
   int rc = gather_rank_scalars(loc, 4, ops4);
   if (rc) return rc;
+  if (opt_.allreduce && loc[3] >= 2.0) cholesky_disable_chain(&chol_ctx_);  // a rank's chain timed out (info == 2): launch by launch on every rank from here on
   const double step_sq = (segmented_ ? 0.0 : h_scal_[8]) + loc[2];
   if (loc[3] != 0.0 || !std::isfinite(step_sq) || !std::isfinite(loc[1])) return SK_OK;  // invalid step
   *valid = true;

@@ -1513,6 +1513,13 @@ bool cholesky_note_info(CholeskyContext* ctx, int info) {
   }
   return true;
 }
+// Another rank of the world lost its resident chain (or never had one): every rank must factor by the same plan, or the
+// replicated factorisations differ in rounding and the ranks' parameters drift apart bit by bit.
+void cholesky_disable_chain(CholeskyContext* ctx) {
+  if (!ctx || !ctx->dq) return;
+  std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());
+  ctx->dq->chain_server = 0;
+}
 bool cholesky_chain_enabled(const CholeskyContext* ctx) { return ctx && ctx->dq && ctx->server && ctx->dq->chain_server; }
 
 // Before the first factorisation with allow_chain on stream s (cholesky_factor does it otherwise): choose the queues.

@@ -177,6 +177,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
 bool cholesky_note_info(CholeskyContext* ctx, int info);
 bool cholesky_chain_enabled(const CholeskyContext* ctx);
+void cholesky_disable_chain(CholeskyContext* ctx);
 struct CholeskyPlan {
   std::vector<int> bounds;  // group start columns + nblk
   std::vector<char> resident;  // per block column: under the resident panel chain
