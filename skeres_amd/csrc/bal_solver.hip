@@ -1003,7 +1003,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   launch_bal_obs_precompute(d_, s);
   kt_.begin("bal_cam_diag", s); launch_bal_cam_diag(d_, s); kt_.end("bal_cam_diag", s);
   kt_.begin("bal_pair", s); launch_bal_pair(d_, s); kt_.end("bal_pair", s);
-  if (opt_.allreduce) {
+  if (opt_.allreduce && !segmented_) {  // (segmented: the root front is summed after the leaf has been factored, below)
     // sum S (with the rhs row) over ranks: only its lower block triangle travels (half the bytes)
     launch_tri_pack(d_.S, npad_, b_pack_.p, npad_ / 128, b_pack_col0_.p, b_pack_off_.p, true, s);  // (never dissected here: front[2] is the whole system)
     int rc = allreduce(b_pack_.p, packed_elems_);
