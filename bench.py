@@ -9,12 +9,13 @@ diagonal, Schur-complement assembly, dense fp64-MFMA Cholesky of the 9C x 9C
 reduced camera system, back-substitution, candidate cost, accept/reject and
 (on acceptance) the Jet-autodiff Jacobian evaluation at the new point.
 Termination tolerances are set to zero so exactly K iterations run in the timed
-region; the start is perturbed far enough that every one of them is a
-successful step of a real solve (the count is reported in config).
+region of a real solve; how many of them were successful steps (an unsuccessful one skips the Jacobian evaluation) is
+reported in config.
 
-Multi-GPU: points (and their observations) are sharded over ranks, cameras are
-replicated, the reduced system is summed with one RCCL all-reduce per
-iteration; the Cholesky runs replicated.  Total work is fixed => "strong".
+Multi-GPU (total work fixed => "strong"; the solver chooses, config.parallelism says what it chose): SEGMENTED — the
+camera sequence is dissected, rank 0's device eliminates the head and its points, rank 1's the tail, the separator's
+system is all-reduced (a few MB) and factored by every rank; or SHARDED — points sharded, the reduced system (its blocks
+inside the envelope) all-reduced, Cholesky replicated; or REPLICATED when neither pays.
 
 Rank 0 prints ONE JSON line.
 """
@@ -300,6 +301,9 @@ def main():
                 "cholesky_block_columns_resident": int(plan["cholesky_columns_resident"]),
                 "long_range_fraction": args.long_range,
                 "successful_steps_in_timed_region": n_success, "parallelism": ("one GPU" if world == 1 else
+                                "camera sequence dissected over the ranks (SK_DISTRIBUTION_SEGMENTED): the head and its points on rank 0's device, the tail "
+                                "on rank 1's, ranks beyond the second replicate rank r mod 2; per iteration the separator's system is all-reduced "
+                                "(%.1f MB) and factored by every rank" % allreduce_mb if dist_mode == "segmented" else
                                 "points sharded x%d, reduced system all-reduced (%.0f MB: the blocks inside the envelope), Cholesky replicated" % (world, allreduce_mb) if dist_mode == "sharded" else
                                 "replicated x%d: the solver measured %.1f ms for the all-reduce of the reduced system against %.1f ms of "
                                 "per-iteration work sharding would remove, and did not shard" % (world, 1e3 * t_allreduce, 1e3 * t_saved)),
