@@ -279,8 +279,10 @@ static double column_cost_us(int h, bool resident_capable) {
   const double chain_us = (resident_capable && h <= 24) ? 42.0 : 70.0;  // resident panel chain / four launches per column
   return std::max(update_us, chain_us);
 }
+// tail_resident: the tail has a device of its own (segmented world) and runs under a resident panel chain like the head;
+// on one device it is factored launch by launch next to the head's chain.
 static Dissection choose_dissection(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
-                                    const std::vector<int>& first_col) {
+                                    const std::vector<int>& first_col, bool tail_resident) {
   Dissection d;
   if (C < 64 || nblk < 24) return d;
   // reach[c]: the last camera that shares a point with any camera <= c (cameras in the chosen order)
@@ -296,7 +298,7 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
   for (int c = 0; c < nblk; ++c) {
     const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0);
     fwd[c] = column_cost_us(hf, true);
-    bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1, false);
+    bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1, tail_resident);
     d.t_plain += fwd[c];
   }
   for (int c = 0; c < nblk; ++c) { fwd_sum[c + 1] = fwd_sum[c] + fwd[c]; bwd_sum[c + 1] = bwd_sum[c] + bwd[c]; }
@@ -525,7 +527,7 @@ int BalSolver::setup() {
     if (may_dissect) {
       std::vector<int> first_col;
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
-      ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col);
+      ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, multi);
       // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
       // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon there.
