@@ -699,10 +699,11 @@ __global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
 // cameras: step_c = -y_c ; xc_new = xc + step_c * scale_c ; out[0] = |delta_c|^2
 // (norm_lo, norm_hi: the coordinates whose step this rank accounts for — all of them, or in a segmented world its own
 // segment's, the separator's being counted by the head's rank alone)
-__global__ __launch_bounds__(kBlock) void bal_cam_step_kernel(BalDev d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2) {
+__global__ __launch_bounds__(1024) void bal_cam_step_kernel(BalDev d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2) {
   double acc = 0.0;
   const int n = 9 * d.C;
-  for (int j = threadIdx.x; j < n; j += kBlock) {
+  // one workgroup (the sum's order is fixed), sixteen waves: 9 C values are a few loads per lane
+  for (int j = threadIdx.x; j < n; j += 1024) {
     const double st = -d.y_c[j];
     d.step_c[j] = st;
     const double xo = d.xc[j];
@@ -711,11 +712,11 @@ __global__ __launch_bounds__(kBlock) void bal_cam_step_kernel(BalDev d, double* 
     const double df = xo - xn;
     if ((j >= norm_lo && j < norm_hi) || (j >= norm_lo2 && j < norm_hi2)) acc += df * df;
   }
-  __shared__ double sh[kBlock / 64];
+  __shared__ double sh[16];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) { double s = 0.0; for (int i = 0; i < kBlock / 64; ++i) s += sh[i]; out[0] = s; }
+  if (threadIdx.x == 0) { double s = 0.0; for (int i = 0; i < 16; ++i) s += sh[i]; out[0] = s; }
 }
 
 // Lower block triangle of S <-> packed buffer (see bal_kernels.hpp), 16 bytes per lane.
@@ -825,7 +826,7 @@ int launch_bal_point_backsub(const BalDev& d, hipStream_t s) {
   return g;
 }
 void launch_bal_cam_step(const BalDev& d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2, hipStream_t s) {
-  hipLaunchKernelGGL(bal_cam_step_kernel, dim3(1), dim3(kBlock), 0, s, d, out, norm_lo, norm_hi, norm_lo2, norm_hi2);
+  hipLaunchKernelGGL(bal_cam_step_kernel, dim3(1), dim3(1024), 0, s, d, out, norm_lo, norm_hi, norm_lo2, norm_hi2);
 }
 
 }  // namespace sk
