@@ -66,7 +66,7 @@ def main():
         # the camera sequence is cut: rank 0's device eliminates the head, rank 1's the tail; what travels is the separator's system
         assert used == "segmented" and solver.stat("dissected") == 1
         if shape[0] >= 200:
-            assert solver.stat("allreduce_bytes") < 0.35 * solver.stat("allreduce_bytes_full_triangle")
+            assert solver.stat("allreduce_bytes") < 0.6 * solver.stat("allreduce_bytes_full_triangle")
     elif mode != "auto":
         assert used == mode, (used, mode)
     else:  # a 2600-observation problem: the host-staged all-reduce costs far more than sharding saves

@@ -50,7 +50,7 @@ def main():
     for _ in range(args.iters):
         s.step()
     dt = time.time() - t0
-    print("%d iterations: %.1f ms each" % (args.iters, 1e3 * dt / args.iters))
+    print("%d iterations: %.3f ms each" % (args.iters, 1e3 * dt / args.iters))
     for k in KERNELS:
         sec, n = s.kernelSeconds(k)
         print("  %-18s %6d launches  %9.3f ms total  %8.3f ms/iter  %8.1f us/launch" % (k, n, 1e3 * sec, 1e3 * sec / args.iters,
