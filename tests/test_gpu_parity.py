@@ -894,6 +894,22 @@ def test_dense_rows_vs_oracle(m, n):
     np.testing.assert_allclose(x_gpu, x_star, atol=5e-3)  # recovers the planted parameters
 
 
+@pytest.mark.parametrize("world,shape", [(2, "3000,200"), (3, "5000,300")])
+def test_dense_rows_sharded_over_ranks(world, shape):
+    """tests/dist_dense_rows_worker.py: the rows of the dense problem sharded over `world` ranks (SURVEY.md section 8e:
+    "C5: shard rows of J"), J^T J all-reduced, Cholesky replicated — the single-GPU trajectory to 1e-10."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29750 + world + (os.getpid() % 60)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_dense_rows_worker.py"), shape]
+    out = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "DIST_DENSE_ROWS_OK world=%d" % world in out.stdout
+
+
 def test_dense_rows_medium_properties():
     from skeres_amd import dense_synth
     m, n = 60000, 1000
