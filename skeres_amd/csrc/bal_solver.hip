@@ -129,7 +129,7 @@ class BalSolver : public SolverBase {
       int r = 0;
       for (int k = 0; k < 3; ++k) {
         if (fr_[k].nblk == 0) continue;
-        const CholeskyPlan plan = cholesky_plan(fr_[k].nblk, group_, fr_[k].env(), chain_ok() && k != 1, fr_[k].ncols);
+        const CholeskyPlan plan = cholesky_plan(fr_[k].nblk, group_, fr_[k].env(), chain_live() && k != 1, fr_[k].ncols);
         for (char c : plan.resident) r += c ? 1 : 0;
       }
       *value = r;
@@ -146,7 +146,10 @@ class BalSolver : public SolverBase {
     return false;
   }
   // the grouping is the library's choice (Options::cholesky_group == 0) and the masked streams of the resident panel chain exist
-  bool chain_ok() const { return opt_.cholesky_group == 0 && opt_.lookahead && cholesky_chain_enabled(&chol_ctx_); }
+  // ... (the PLAN is then the one with resident runs; whether they really run resident or, with the same grouping, launch
+  // by launch — SK_CHOL_CHAIN_SERVER=0, a time-out — is cholesky_factor's business: chain_live())
+  bool chain_ok() const { return opt_.cholesky_group == 0 && opt_.lookahead && chol_ctx_.server != nullptr; }
+  bool chain_live() const { return chain_ok() && cholesky_chain_enabled(&chol_ctx_); }
   int distribution(double* allreduce_s, double* saved_s) const override {
     if (allreduce_s) *allreduce_s = est_allreduce_s_;
     if (saved_s) *saved_s = est_saved_s_;
@@ -839,7 +842,7 @@ int BalSolver::setup() {
     // ... and the same factorisation plan: a rank whose device cannot run the resident panel chain (its queue trial said
     // so: a shared or serialised device) takes every rank to the launch-by-launch plan — replicated factorisations must
     // round alike, or the ranks' parameters drift apart
-    double off[1] = {opt_.cholesky_group == 0 && opt_.lookahead && !cholesky_chain_enabled(&chol_ctx_) ? 1.0 : 0.0};
+    double off[1] = {chain_ok() && !chain_live() ? 1.0 : 0.0};
     rc = gather_rank_scalars_signed(off, 1);
     if (rc) return rc;
     if (off[0] > 0.0) cholesky_disable_chain(&chol_ctx_);

@@ -679,7 +679,7 @@ int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, dou
   if (!la) (void)hipGetLastError();
   SK_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   SK_HIP_TRY(hipDeviceSynchronize());  // uploads above ran on the null stream
-  const bool chain = automatic_plan != 0 && la && cholesky_chain_enabled(&ctx);
+  const bool chain = automatic_plan != 0 && la && ctx.server != nullptr;  // (the plan; resident or not is the device's state)
   cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr, last, chain);
   cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dw.p, dy.p, s, nullptr, last);
   SK_HIP_TRY(hipStreamSynchronize(s));
@@ -769,7 +769,7 @@ int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double*
   d.B.S = dFB.p; d.B.ld = (long)dB; d.B.nblk = nB + E; d.B.ncols = nB; d.B.last = lastB.data(); d.B.Linv = dLinv.p + (size_t)nA * 128 * 128; d.B.rhs_row = nB * 128 + msep;
   d.R.S = dFR.p; d.R.ld = (long)dR; d.R.nblk = E; d.R.ncols = E; d.R.last = nullptr; d.R.Linv = dLinv.p + (size_t)(nA + nB) * 128 * 128; d.R.rhs_row = msep;
   d.border_blocks = E; d.mapB = dmap.p;
-  const bool chain = automatic_plan != 0 && la && cholesky_chain_enabled(&ctx);
+  const bool chain = automatic_plan != 0 && la && ctx.server != nullptr;
   if (chain) cholesky_prepare(&ctx, s);
   cholesky_dissected_factor(d, dinfo.p, group, s, la ? &ctx : nullptr, side ? &ctxB : nullptr, nullptr, nullptr, chain);
   double *wA = dw.p, *wB = dw.p + dA, *wR = dw.p + dA + dB, *ybB = dw.p + dA + dB + dR;
