@@ -1244,6 +1244,7 @@ hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
   panel = bulk = bulk_early = nullptr;  // (called again after the queue choice: the queues the primary context does NOT use now)
   if (!primary.dq) return hipErrorInvalidValue;
   DeviceQueues* q = primary.dq;
+  std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());  // (the device's entry may gain streams below)
   dq = q; device = primary.device;
   server = nullptr;
   reserved_cus = q->reserved_cus; early_tiles = q->early_tiles;
