@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 // the abort flag, which ends every other wait, and *info): the grid always drains.
 // ---------------------------------------------------------------------------
 enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncHeader = 8 };  // then diag_ready[maxblk], x_ready[maxblk]
-constexpr long long kChainTimeoutTicks = 300000000;  // 3 s of the 100 MHz wall clock
+constexpr long long kChainTimeoutTicks = 100000000;  // 1 s of the 100 MHz wall clock (a block column takes 40 us: 25 000 times that)
 
 // developer timeline (SK_CHAIN_STAMPS=<file>): wall-clock stamps of the server and of tile 0 of every column launch
 __device__ long long g_chain_stamps[1024][8];

@@ -735,7 +735,7 @@ def test_resident_chain_timeout_is_reported_and_refactored():
     assert "timed out" not in err_clean and clean["resident_after"] == clean["resident_before"] >= 60
     assert "the resident panel chain timed out" in err_hit          # loud
     assert hit["resident_before"] >= 60 and hit["resident_after"] == 0   # launch by launch from then on
-    assert hit["seconds"] > clean["seconds"] + 2.0                   # the 3 s time-out really happened
+    assert hit["seconds"] > clean["seconds"] + 0.7                   # the 1 s time-out really happened
     assert hit["valid"] == clean["valid"] == [1, 1, 1, 1]           # no LM step was lost ...
     for a, b in zip(hit["costs"], clean["costs"]):                   # ... and the trajectory is the undisturbed one
         assert abs(a - b) <= 1e-10 * abs(b)
