@@ -285,6 +285,34 @@ __global__ __launch_bounds__(kBlock) void bal_scale_jac_kernel(BalDev d) {
 // list (fixed lane assignment + fixed butterfly => run-to-run reproducible).
 //   colsq_c = sum F^2 (squared column norm), gs_c = sum F^T r (scaled gradient)
 // ---------------------------------------------------------------------------
+// F, r planes (point-major) -> camera-major records.  A wave takes 64 consecutive observations: coalesced plane reads,
+// the 64 records staged in LDS, then written 3.2 records per store instruction (each record's 160 bytes contiguous).
+__global__ __launch_bounds__(kBlock) void bal_cam_records_kernel(BalDev d) {
+  __shared__ double stage[kBlock / 64][64 * kFcam];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double* st = stage[w];
+  const size_t N = d.N;
+  for (long o0 = ((long)blockIdx.x * (kBlock / 64) + w) * 64; o0 < d.N; o0 += (long)gridDim.x * kBlock) {
+    const long o = o0 + lane;
+    if (o < d.N) {
+#pragma unroll
+      for (int k = 0; k < 18; ++k) st[lane * kFcam + k] = d.F[(size_t)k * N + o];
+      st[lane * kFcam + 18] = d.r[o];
+      st[lane * kFcam + 19] = d.r[N + o];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const int nrec = (int)((d.N - o0) < 64 ? (d.N - o0) : 64);
+#pragma unroll 4
+    for (int i = 0; i < kFcam; ++i) {
+      const int e = i * 64 + lane, rr = e / kFcam, f = e - rr * kFcam;
+      if (rr < nrec) d.Fcam[(size_t)d.obs_slot[o0 + rr] * kFcam + f] = st[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void bal_cam_reduce_kernel(BalDev d) {
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= d.C) return;
@@ -292,11 +320,15 @@ __global__ __launch_bounds__(kBlock) void bal_cam_reduce_kernel(BalDev d) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) { sq[k] = 0.0; g[k] = 0.0; }
   for (int e = d.cam_start[wave] + lane; e < d.cam_start[wave + 1]; e += 64) {
-    const int o = d.cam_obs[e];
-    const double r0 = d.r[o], r1 = d.r[(size_t)d.N + o];
+    // (the observations of a camera in CSR order, as before: the sums round as before)
+    const double2* rec = reinterpret_cast<const double2*>(d.Fcam + (size_t)e * kFcam);
+    double v[kFcam];
+#pragma unroll
+    for (int k = 0; k < kFcam / 2; ++k) { const double2 t = rec[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+    const double r0 = v[18], r1 = v[19];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const double f0 = d.F[(size_t)k * d.N + o], f1 = d.F[(size_t)(9 + k) * d.N + o];
+      const double f0 = v[k], f1 = v[9 + k];
       sq[k] += f0 * f0 + f1 * f1;
       g[k] += f0 * r0 + f1 * r1;
     }
@@ -502,8 +534,15 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
   for (int e = d.cam_start[i] + lane; e < d.cam_start[i + 1]; e += 64) {
     const int o = d.cam_obs[e];
     double f0[9], f1[9], w[27];
+    {
+      const double2* rec = reinterpret_cast<const double2*>(d.Fcam + (size_t)e * kFcam);  // camera-major: streamed
 #pragma unroll
-    for (int c = 0; c < 9; ++c) { f0[c] = d.F[c * N + o]; f1[c] = d.F[(9 + c) * N + o]; }
+      for (int k = 0; k < 9; ++k) {
+        const double2 t = rec[k];
+        if (2 * k < 9) f0[2 * k] = t.x; else f1[2 * k - 9] = t.x;
+        if (2 * k + 1 < 9) f0[2 * k + 1] = t.y; else f1[2 * k + 1 - 9] = t.y;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 27; ++k) w[k] = d.What[(size_t)o * kWs + k];
     const double r0 = d.rt[o], r1 = d.rt[N + o];
@@ -788,6 +827,7 @@ int launch_bal_host_cost(const BalDev& d, int partial_off, hipStream_t s) {
   return g;
 }
 void launch_bal_scale_jac(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_scale_jac_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
+void launch_bal_cam_records(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_records_kernel, dim3(grid_for((d.N + 63) / 64 * 64)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_reduce(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_reduce_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 static int point_grid(int P) { return (int)(((long)P * kPointLanes + kBlock - 1) / kBlock); }
 int bal_point_blocks(int P) { return P > 0 ? point_grid(P) : 1; }

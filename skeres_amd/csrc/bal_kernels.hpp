@@ -39,6 +39,11 @@ struct BalDev {
   double* y_c;                        // reduced-system solution
   // per-observation planes
   double* r;  double* F;  double* E;  double* What;  double* rt;
+  // CAMERA-major copy of what the per-camera kernels read of an observation: record e (the e-th entry of the camera CSR,
+  // i.e. observation cam_obs[e]) holds F row 0 (9), F row 1 (9), r (2).  The planes above are point-major — lane o streams —
+  // and a wave that walks a camera's observations through them fetches 20 scattered 64-byte sectors per observation for
+  // 160 bytes used; through the records it streams.  Written by bal_cam_records_kernel after every Jacobian evaluation.
+  double* Fcam;  const int* obs_slot;  // [N][kFcam]; slot of observation o in the camera CSR (the inverse of cam_obs)
   // per-point
   double* M;  double* q;
   // Reduced camera system: up to three dense row-major matrices ("fronts", chol_kernels.hip "Two-way dissection"), lower
@@ -67,6 +72,7 @@ struct BalDev {
   const double* host_rows;       // [num_host][kHostRow]: r (2), d r / d camera (2 x 9 row-major), d r / d point (2 x 3 row-major)
 };
 constexpr int kHostRow = 26;
+constexpr int kFcam = 20;
 
 int bal_partial_blocks(int N);
 int bal_point_blocks(int P);  // workgroups of the per-point kernels (bal_point_backsub writes one partial sum each)
@@ -84,6 +90,7 @@ int launch_bal_host_jac(const BalDev& d, int partial_off, hipStream_t s);
 // candidate cost and model term of the host-evaluated observations from their uploaded residuals at the candidate point
 int launch_bal_host_cost(const BalDev& d, int partial_off, hipStream_t s);
 void launch_bal_scale_jac(const BalDev& d, hipStream_t s);
+void launch_bal_cam_records(const BalDev& d, hipStream_t s);  // F, r planes -> camera-major records (Fcam)
 void launch_bal_cam_reduce(const BalDev& d, hipStream_t s);
 void launch_bal_pt_reduce(const BalDev& d, hipStream_t s);
 void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s);

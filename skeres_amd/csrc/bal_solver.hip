@@ -190,9 +190,9 @@ class BalSolver : public SolverBase {
   std::vector<int> local_pt_;                 // global point id of local point
   BalDev d_{};
   DevBuf<LossNode> b_loss_nodes_;
-  DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_, b_fail_, b_info_;
+  DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_obs_slot_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_, b_fail_, b_info_;
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
-      b_r_, b_F_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
+      b_r_, b_F_, b_Fcam_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
   // The reduced camera system as fronts (BalDev::front): 0 head, 1 tail, 2 root.  Not dissected: only the root, which is
   // then the whole system.  Each front is a dense dim x dim matrix inside b_S_.
@@ -677,6 +677,7 @@ int BalSolver::setup() {
   hipStream_t s = stream_;
   SK_HIP_TRY(b_cam_.upload(cam, s)); SK_HIP_TRY(b_pt_.upload(pt, s)); SK_HIP_TRY(b_obs_.upload(obs, s));
   SK_HIP_TRY(b_pt_start_.upload(pt_start, s)); SK_HIP_TRY(b_cam_start_.upload(cam_start, s)); SK_HIP_TRY(b_cam_obs_.upload(cam_obs, s));
+  { std::vector<int> slot(N_); for (int e = 0; e < N_; ++e) slot[cam_obs[e]] = e; SK_HIP_TRY(b_obs_slot_.upload(slot, s)); }
   SK_HIP_TRY(b_seg_start_.upload(seg_start, s)); SK_HIP_TRY(b_seg_row_.upload(seg_row, s)); SK_HIP_TRY(b_seg_col_.upload(seg_col, s));
   SK_HIP_TRY(b_pair_row_.upload(pair_row, s)); SK_HIP_TRY(b_pair_col_.upload(pair_col, s));
   std::vector<int> short_segs, long_segs;
@@ -710,7 +711,7 @@ int BalSolver::setup() {
     SK_HIP_TRY(hipStreamSynchronize(s));
   }
   SK_HIP_TRY(b_y_.alloc(npad_ + 128));
-  SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
+  SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_Fcam_.alloc(kFcam * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
   SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
   // ---- the fronts of the reduced camera system ----
@@ -784,14 +785,14 @@ int BalSolver::setup() {
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
-  d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p;
+  d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p; d_.obs_slot = b_obs_slot_.p;
   d_.num_segments = (int)seg_row.size(); d_.seg_start = b_seg_start_.p; d_.seg_row = b_seg_row_.p; d_.seg_col = b_seg_col_.p;
   d_.short_segments = b_short_segs_.p; d_.long_segments = b_long_segs_.p;
   d_.pair_row_obs = b_pair_row_.p; d_.pair_col_obs = b_pair_col_.p;
   d_.xc = b_xc_.p; d_.xp = b_xc_.p + nc; d_.xc_new = b_xc_new_.p; d_.xp_new = b_xc_new_.p + nc;
   d_.scale_c = b_scale_.p; d_.scale_p = b_scale_.p + nc; d_.colsq_c = b_colsq_.p; d_.colsq_p = b_colsq_.p + nc;
   d_.gs_c = b_gs_.p; d_.gs_p = b_gs_.p + nc; d_.D_c = b_D_.p; d_.D_p = b_D_.p + nc; d_.step_c = b_step_.p; d_.step_p = b_step_.p + nc;
-  d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.rt = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
+  d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.Fcam = b_Fcam_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.rt = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
   for (int f = 0; f < 3; ++f) {
     d_.front[f].S = fr_[f].nblk > 0 ? b_S_.p + fr_[f].s_off : nullptr; d_.front[f].ld = (int)fr_[f].dim; d_.front[f].interior = fr_[f].ncols * 128;
     d_.y_front[f] = b_yf_.p + fr_[f].y_off;
@@ -909,7 +910,8 @@ int BalSolver::evaluate_with_jacobian(bool first) {
     if (failed) return SK_ERR_EVALUATION_FAILED;
     nb += launch_bal_host_jac(d_, nb, s);
   }
-  launch_bal_cam_reduce(d_, s);
+  kt_.begin("bal_cam_records", s); launch_bal_cam_records(d_, s); kt_.end("bal_cam_records", s);
+  kt_.begin("bal_cam_reduce", s); launch_bal_cam_reduce(d_, s); kt_.end("bal_cam_reduce", s);
   launch_bal_pt_reduce(d_, s);
   if (opt_.allreduce) {  // camera columns are summed over all ranks' observations
     double* buf = b_small_.p;
@@ -927,6 +929,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   if (first && opt_.jacobi_scaling) {
     launch_jacobi_scale(b_colsq_.p, b_scale_.p, (int)(nc + np), s);
     launch_bal_scale_jac(d_, s);
+    launch_bal_cam_records(d_, s);  // F changed under the records
     launch_apply_scale_to_reductions(b_colsq_.p, b_gs_.p, b_scale_.p, (int)(nc + np), s);
   }
   // scalars: sum r^2 (slot 4) ; gradient max-norm and |x|^2 (cameras once, points local)

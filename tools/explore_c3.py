@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import skeres_amd as sk  # noqa: E402
 from skeres_amd import bal  # noqa: E402
 
-KERNELS = ["bal_eval_jac", "memset_S", "bal_cam_diag", "bal_pair", "gemm_diag_update", "gemm_panel_update", "potrf128", "gemm_trsm", "gemm_syrk_next",
+KERNELS = ["bal_eval_jac", "bal_cam_records", "bal_cam_reduce", "memset_S", "bal_cam_diag", "bal_pair", "gemm_diag_update", "gemm_panel_update", "potrf128", "gemm_trsm", "gemm_syrk_next",
            "gemm_syrk", "backsolve", "bal_eval_cost"]
 
 
