@@ -415,125 +415,6 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
   return sgn >= 0 && d_prev > 0.0;
 }
 
-// ---------------------------------------------------------------------------
-// The same 32 x 32 factorisation on FOUR waves (the P waves of potrf128_body, one per SIMD).
-//
-// wave_potrf32 costs 270 clocks per column of which the dependent chain is about 100: the rest is the column's
-// update of the 31 - j columns right of it (fma + LDS broadcast read each), which one wave has to issue between
-// the chain instructions.  Here wave W owns columns [8 W, 8 W + 8): lane = row as before (lanes 32..63 the unit
-// vectors, ending as W = L^-1), 8 registers per lane.  A wave
-//   1. applies the columns of the waves before it, in order, as they are PUBLISHED in LDS — column j as it stood
-//      when it was eliminated (64 lanes' values, pub[j][lane]) and y_j = 1 / d_j (pub_y[j]):
-//      a[c] -= (pub[j][lane] y_j) pub[j][c] for its eight c — in the shadow of the owners' chains;
-//   2. runs the chain over its own 8 columns exactly as wave_potrf32 does, with at most 6 late updates per column
-//      to place between the chain instructions, publishing each column;
-//   3. scales its columns by 1 / sqrt(d).
-// The chain hops from wave to wave three times per block (a publication, a poll, one column's update: ~300 clocks each).
-// `progress` counts published columns (jbase + j + 1 after column j); LDS operations of one wave execute in
-// order, so the count is written after the data without waiting for either.
-// ---------------------------------------------------------------------------
-constexpr int kCoopW = 8;               // columns per P wave
-constexpr int kPubY = 32 * 64;          // pub_y behind the 32 published columns
-constexpr int kPubDoubles = kPubY + 32;
-template <int W>
-__device__ __forceinline__ bool coop_potrf32(double (&a)[kCoopW], double* pub_in, __attribute__((address_space(3))) volatile int* prog, int jbase, int lane) {
-  constexpr int C0 = kCoopW * W;
-  typedef __attribute__((address_space(3))) double* lds_dp;
-  typedef __attribute__((address_space(3))) volatile double* lds_vdp;
-  unsigned pb = (unsigned)(unsigned long)(lds_dp)pub_in;
-  asm volatile("" : "+v"(pb));  // one VGPR base, immediate offsets (see wave_potrf32)
-  const lds_dp pub = (lds_dp)(unsigned long)pb;
-  const lds_dp publ = pub + lane;
-  const lds_vdp puby = (lds_vdp)(pub + kPubY);
-  // ---- 1. the columns before mine
-  if (W > 0) {
-    int j = 0;
-    while (j < C0) {
-      int have = __builtin_amdgcn_readfirstlane(*prog) - jbase;
-      if (have <= j) continue;
-      if (have > C0) have = C0;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll 2
-      for (; j < have; ++j) {
-        const lds_dp pc = pub + j * 64;
-        const double m = pc[lane] * pub[kPubY + j];
-#pragma unroll
-        for (int i = 0; i < kCoopW; ++i) a[i] = __builtin_fma(-m, pc[C0 + i], a[i]);
-      }
-    }
-  }
-  // ---- 2. my columns
-  double cbp[kCoopW], cbn[kCoopW];
-  double m_prev = 0.0, d_prev = 1.0;
-  int dv_lo = 0, dv_hi = 0x3ff00000;
-  int sgn = 0;
-  publ[C0 * 64] = a[0];
-#define SK_CFILL(k)                                                                                                   \
-  if (jl >= 1) {                                                                                                      \
-    _Pragma("unroll") for (int i = jl + 1 + ((k) * (kCoopW - 1 - jl) + 4) / 5; i < jl + 1 + (((k) + 1) * (kCoopW - 1 - jl) + 4) / 5; ++i) \
-      a[i] = __builtin_fma(-m_prev, cbp[i], a[i]);                                                                    \
-  }
-#pragma unroll
-  for (int jl = 0; jl < kCoopW; ++jl) {
-    const int j = C0 + jl;
-#pragma unroll
-    for (int i = jl + 2; i < kCoopW; ++i) cbn[i] = pub[j * 64 + C0 + i];  // column j, for the late updates of the next step
-    // ---- chain 0
-    const int d_lo = __builtin_amdgcn_readlane(__double2loint(a[jl]), j), d_hi = __builtin_amdgcn_readlane(__double2hiint(a[jl]), j);
-    const double d = __hiloint2double(d_hi, d_lo);
-    const double y = __builtin_amdgcn_rcp(d);
-    const double l1 = lane_bcast(a[jl], jl + 1 < kCoopW ? j + 1 : j);
-    const double m0 = a[jl] * y;
-    __builtin_amdgcn_sched_barrier(0);
-    sgn |= d_hi;
-    asm volatile("" : "+s"(sgn));
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dv_lo) : "s"(d_lo), "n"(j));
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(dv_hi) : "s"(d_hi), "n"(j));
-    SK_CFILL(0)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- chain 1
-    const double e = __builtin_fma(-d, y, 1.0);
-    __builtin_amdgcn_sched_barrier(0);
-    SK_CFILL(1)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- chain 2
-    const double q = __builtin_fma(e, e, e);
-    __builtin_amdgcn_sched_barrier(0);
-    SK_CFILL(2)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- chain 3 (and y_j to the waves behind: on THEIR chain when this is my last column)
-    const double m = __builtin_fma(m0, q, m0);
-    if (W < 3) {
-      puby[j] = __builtin_fma(y, q, y);
-      asm volatile("" ::: "memory");
-      *prog = jbase + j + 1;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    SK_CFILL(3)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- chain 4
-    if (jl + 1 < kCoopW) {
-      a[jl + 1] = __builtin_fma(-m, l1, a[jl + 1]);
-      publ[(j + 1) * 64] = a[jl + 1];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    SK_CFILL(4)
-    __builtin_amdgcn_sched_barrier(0);
-    m_prev = m;
-    d_prev = d;
-#pragma unroll
-    for (int i = jl + 2; i < kCoopW; ++i) cbp[i] = cbn[i];
-  }
-#undef SK_CFILL
-  // ---- 3. scaling: lane c of r holds 1 / sqrt(d_c) for my columns c
-  {
-    const double r = fast_rsqrt(__hiloint2double(dv_hi, dv_lo));
-#pragma unroll
-    for (int i = 0; i < kCoopW; ++i) a[i] = a[i] * lane_bcast(r, C0 + i);
-  }
-  return sgn >= 0 && d_prev > 0.0;
-}
-
 // acc(2x2 MFMA tiles of a 32x32 block) += P Q^T (kPlainB false) or P Q (true); P, Q 32x32 blocks in LDS (stride kBs)
 template <bool kPlainB>
 __device__ __forceinline__ void block_mma32(d4 (&acc)[2][2], const double* P, const double* Q, int lane) {
@@ -623,32 +504,65 @@ __device__ __forceinline__ void block_neg_left_mul32(double* dst, const double* 
 }
 
 #ifdef SK_POTRF_STAMPS
-__device__ long long g_potrf_stamps[8][16], g_potrf_clk[8][16];
+__device__ long long g_potrf_stamps[4][16], g_potrf_clk[4][16];
 #define SK_STAMP(i) if (lane == 0) { g_potrf_stamps[wave][i] = wall_clock64(); g_potrf_clk[wave][i] = clock64(); }
 #else
 #define SK_STAMP(i)
 #endif
 
-// potrf128: EIGHT waves, two per SIMD.  Waves 0..3 ("P waves") share each 32 x 32 diagonal factorisation
-// (coop_potrf32: vector instructions and LDS broadcasts) and the step between two of them; waves 4..6 ("MFMA waves")
-// do everything else next to it — the other panel blocks, the off-diagonal updates, the blocked inverse, the
-// write-backs: block products on the matrix pipe, which the SIMD runs between the P wave's instructions.
-constexpr int kPotrfThreads = 512;
 __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
   // Inlined into the server's loop, everything below that does not depend on the column — LDS addresses, lane-derived
-  // offsets — is loop-invariant and gets hoisted.  Opaque copies of the three roots keep the arithmetic where it is used.
+  // offsets — is loop-invariant, gets hoisted, and the 256-register body spills (384-716 bytes of scratch).  Opaque
+  // copies of the three roots keep the arithmetic where it is used.
   double* lds = lds_in;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid), "+s"(ld));
   double* T = lds;                      // blocks 0..9: lower triangle of the tile (diagonal slots end as W_jj); 10..15: inverse, below the diagonal
-  double* pub = lds + 16 * kBlk;        // (blocks 16, 17) the published columns of the diagonal factorisation in progress
-  static_assert(kPubDoubles <= 2 * kBlk, "published columns fit the two spare blocks");
-  typedef __attribute__((address_space(3))) volatile int* lds_vip;
-  const lds_vip flags = (lds_vip)reinterpret_cast<int*>(lds + 18 * kBlk);  // 4 hand-over flags of the MFMA waves, [4] progress, [5] loaded
+  double* E = lds + 16 * kBlk;          // blocks 16, 17: staging of L_jj on its way to global memory (even / odd jb)
+  double* colbuf = lds + 18 * kBlk;     // 3 x 64 doubles
+  volatile int* flags = reinterpret_cast<volatile int*>(colbuf + 192);  // 4 hand-over flags of waves 1..3
   const int t = tid, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  __builtin_amdgcn_s_setprio(3);
   SK_STAMP(0)
-  if (t < 8) flags[t] = 0;
-  __syncthreads();
+  // Load the lower blocks.  Block (0,0) by all four waves, so that wave 0 starts the first diagonal factorisation after one
+  // short round trip; the other nine blocks by waves 1..3 (three blocks each, 48 loads per lane, issued before anything
+  // is waited for): they are first read after P(0), behind the barrier that ends it.
+  {
+    double v0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t + 256 * i;
+      v0[i] = A[(long)(e >> 5) * ld + (e & 31)];
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int e = t + 256 * i; T[blk_off(0, 0) + (e >> 5) * kBs + (e & 31)] = v0[i]; }
+      if (t < 4) flags[t] = 0;
+      __syncthreads();
+    } else {
+      double v[3][16];
+      const int first = 3 * (wave - 1) + 1;  // index in the lower-triangular enumeration (bi (bi + 1) / 2 + bj)
+      const long lo = (long)(lane >> 5) * ld + (lane & 31);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = first + k, bi = idx >= 6 ? 3 : (idx >= 3 ? 2 : 1), bj = idx - bi * (bi + 1) / 2;
+        const double* Ab = A + ((long)bi * kB * ld + bj * kB) + lo;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[k][i] = Ab[(long)(2 * i) * ld];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int e = t + 256 * i; T[blk_off(0, 0) + (e >> 5) * kBs + (e & 31)] = v0[i]; }
+      __syncthreads();
+      const int ll = (lane >> 5) * kBs + (lane & 31);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = first + k, bi = idx >= 6 ? 3 : (idx >= 3 ? 2 : 1), bj = idx - bi * (bi + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[blk_off(bi, bj) + ll + 2 * i * kBs] = v[k][i];
+      }
+    }
+  }
+  SK_STAMP(1)
   const unsigned uld = (unsigned)ld;
   const unsigned go_a = (unsigned)(lane >> 5) * uld + (lane & 31), go_i = (unsigned)(lane >> 5) * 128u + (lane & 31);
   const int lo_w = (lane >> 5) * kBs + (lane & 31);
@@ -665,7 +579,7 @@ __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict
     block_store32(SK_L(bi, jb), acc, lane, 1.0); /* every read of the block feeds the MFMAs */  \
   }
   // the step between two diagonal factorisations, on the critical path: X(jb+1,jb) = T(jb+1,jb) W_jj^T and
-  // T(jb+1,jb+1) -= X X^T, each split into four 16x16 quadrants, one per P wave (8 MFMAs instead of 32)
+  // T(jb+1,jb+1) -= X X^T, each split into four 16x16 quadrants, one per wave (8 MFMAs instead of 32)
 #define SK_CRITICAL_B(jb)                                                                        \
   {                                                                                              \
     d4 xq;                                                                                       \
@@ -679,61 +593,35 @@ __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict
     quad_store16(SK_L((jb) + 1, (jb) + 1), uq, qi, qj, lane, -1.0);                              \
     __syncthreads();                                                                             \
   }
-#define SK_CRITICAL_B_OTHERS { __syncthreads(); __syncthreads(); __syncthreads(); }
 #define SK_WRITE_L(bi, bj) block_to_global(SK_GA(bi, bj), 2 * uld, go_a, SK_L(bi, bj), lo_w);
 #define SK_WRITE_W(bi) block_to_global(SK_GI(bi, bi), 256u, go_i, SK_L(bi, bi), lo_w);
 #define SK_WRITE_V(bi, bj) block_to_global(SK_GI(bi, bj), 256u, go_i, SK_V(bi, bj), lo_w);
-  // flags in LDS by which the MFMA waves pass blocks to each other while the P waves are inside a diagonal factorisation
-  // (a workgroup barrier would need them): the producer's LDS writes are complete (lgkmcnt) before the flag
+#define SK_WRITE_E(bi) block_to_global(SK_GA(bi, bi), 2 * uld, go_a, E + ((bi) & 1) * kBlk, lo_w);
+  // flags in LDS by which waves 1..3 pass blocks to each other while wave 0 is inside a diagonal factorisation
+  // (a workgroup barrier would need wave 0): the producer's LDS writes are complete (lgkmcnt) before the flag
 #define SK_FLAG_SET(i) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); if (lane == 0) flags[i] = 1; }
 #define SK_FLAG_WAIT(i) { while (__builtin_amdgcn_readfirstlane(flags[i]) == 0) __builtin_amdgcn_s_sleep(1); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-  if (wave < 4) {
-    // ---- the P waves
-    __builtin_amdgcn_s_setprio(3);
-    const int qi = wave >> 1, qj = wave & 1;
-    const int row = lane & 31, c0 = kCoopW * wave;
-    double a[kCoopW];
-    // block (0,0): my eight columns straight from global memory (lanes 32..63: the unit vectors)
-    {
-      double2 v[kCoopW / 2];
-      const double2* src = reinterpret_cast<const double2*>(A + (long)row * ld + c0);
-#pragma unroll
-      for (int i = 0; i < kCoopW / 2; ++i) v[i] = lane < 32 ? src[i] : double2{0.0, 0.0};
-#pragma unroll
-      for (int i = 0; i < kCoopW; ++i) a[i] = lane < 32 ? (i & 1 ? v[i >> 1].y : v[i >> 1].x) : (c0 + i == row ? 1.0 : 0.0);
-    }
-    SK_STAMP(1)
+  const int qi = wave >> 1, qj = wave & 1;
+  // Wave 0 runs a loop (one copy of the 32-column chain in the instruction cache); waves 1..3 run
+  // straight-line code with the same barriers.  `wave` is scalar: the branches are uniform.
+  if (wave == 0) {
 #pragma unroll 1
     for (int jb = 0; jb < 4; ++jb) {
       double* D = SK_L(jb, jb);
-      if (jb > 0) {
-#pragma unroll
-        for (int i = 0; i < kCoopW; ++i) {
-          const double d = D[row * kBs + c0 + i];
-          a[i] = lane < 32 ? d : (c0 + i == row ? 1.0 : 0.0);
-        }
-        // the slot of D becomes W_jj: not before every P wave has read its columns of D
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(flags + 5), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      bool ok;
-      if (wave == 0) ok = coop_potrf32<0>(a, pub, flags + 4, 32 * jb, lane);
-      else if (wave == 1) ok = coop_potrf32<1>(a, pub, flags + 4, 32 * jb, lane);
-      else if (wave == 2) ok = coop_potrf32<2>(a, pub, flags + 4, 32 * jb, lane);
-      else ok = coop_potrf32<3>(a, pub, flags + 4, 32 * jb, lane);
+      double a[32];
+      const bool ok = wave_potrf32(D, colbuf, a, lane);
       SK_STAMP(11 + jb)
       if (!ok && lane == 0) *info = 1;
-      if (jb > 0) while (__builtin_amdgcn_readfirstlane(flags[5]) < 4 * jb) {}
-      if (lane < 32) {
-        // row of L_jj, my columns: to global memory as it stands, with whatever the elimination left right of the
-        // diagonal — nothing reads the upper triangle of a diagonal block of the factor (sk_cholesky_solve returns tril)
-        double2* dst = reinterpret_cast<double2*>(A + (long)(jb * kB + row) * ld + jb * kB + c0);
+      {
+        // lanes 0..31: row of L_jj -> staging block E[jb & 1] (written to global by wave 3 during the next diagonal
+        // factorisation); lanes 32..63: column k of W_jj -> the slot of D.  W has its zeros above the diagonal (they
+        // are computed); the row of L is stored as it stands, with whatever the elimination left right of the diagonal:
+        // nothing reads the upper triangle of a diagonal block of the factor (sk_cholesky_solve returns tril).
+        const int row = lane & 31;
+        double* dst = lane < 32 ? E + (jb & 1) * kBlk + row * kBs : D + row;
+        const int step = lane < 32 ? 1 : kBs;
 #pragma unroll
-        for (int i = 0; i < kCoopW / 2; ++i) dst[i] = double2{a[2 * i], a[2 * i + 1]};
-      } else {
-        // column k = row of W_jj, my rows of it -> the slot of D (its zeros above the diagonal are computed)
-#pragma unroll
-        for (int i = 0; i < kCoopW; ++i) D[(c0 + i) * kBs + row] = a[i];
+        for (int c = 0; c < 32; ++c) dst[c * step] = a[c];
       }
       SK_STAMP(2 + 2 * jb)
       __syncthreads();
@@ -743,67 +631,43 @@ __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict
       SK_STAMP(3 + 2 * jb)
     }
   } else {
-    // ---- the MFMA waves: straight-line code with the same barriers
-    __builtin_amdgcn_s_setprio(1);
-    const int mw = wave - 3;  // 1, 2, 3 work; 4 only keeps the barriers
-    d4 accs[2][2];            // a partial sum S carried in registers
-    // Load the nine blocks below the diagonal of block column 0 .. (three each, 48 loads per lane, issued before
-    // anything is waited for): they are first read after P(0), behind the barrier that ends it.
-    if (mw < 4) {
-      double v[3][16];
-      const int first = 3 * (mw - 1) + 1;  // index in the lower-triangular enumeration (bi (bi + 1) / 2 + bj)
-      const long lo = (long)(lane >> 5) * ld + (lane & 31);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int idx = first + k, bi = idx >= 6 ? 3 : (idx >= 3 ? 2 : 1), bj = idx - bi * (bi + 1) / 2;
-        const double* Ab = A + ((long)bi * kB * ld + bj * kB) + lo;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[k][i] = Ab[(long)(2 * i) * ld];
-      }
-      const int ll = (lane >> 5) * kBs + (lane & 31);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int idx = first + k, bi = idx >= 6 ? 3 : (idx >= 3 ? 2 : 1), bj = idx - bi * (bi + 1) / 2;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) T[blk_off(bi, bj) + ll + 2 * i * kBs] = v[k][i];
-      }
-    }
+    d4 accs[2][2];  // a partial sum S carried in registers
     SK_STAMP(2)
     __syncthreads();
-    SK_CRITICAL_B_OTHERS
+    SK_CRITICAL_B(0)
     SK_STAMP(3)
     // ---- next to P(1): the rest of block column 0 and everything it updates
-    if (mw == 1) {
+    if (wave == 1) {
       SK_PANEL_ROW(0, 2)
       SK_FLAG_SET(0)
       block_update32(SK_L(2, 2), SK_L(2, 0), SK_L(2, 0), lane);
       block_update32(SK_L(2, 1), SK_L(2, 0), SK_L(1, 0), lane);
       SK_WRITE_L(2, 0)
     }
-    if (mw == 2) {
+    if (wave == 2) {
       SK_PANEL_ROW(0, 3)
       SK_FLAG_SET(1)
       block_update32(SK_L(3, 3), SK_L(3, 0), SK_L(3, 0), lane);
       block_update32(SK_L(3, 1), SK_L(3, 0), SK_L(1, 0), lane);
       SK_WRITE_L(3, 0)
     }
-    if (mw == 3) {
-      SK_WRITE_L(1, 0) SK_WRITE_W(0)
+    if (wave == 3) {
+      SK_WRITE_E(0) SK_WRITE_L(1, 0) SK_WRITE_W(0)
       SK_FLAG_WAIT(0) SK_FLAG_WAIT(1)
       block_update32(SK_L(3, 2), SK_L(3, 0), SK_L(2, 0), lane);
     }
     SK_STAMP(4)
     __syncthreads();
-    SK_CRITICAL_B_OTHERS
+    SK_CRITICAL_B(1)
     SK_STAMP(5)
     // ---- next to P(2): the rest of block column 1; Inv(1,0) = -W_1 (L_10 W_0); S(2,0) = L_20 W_0 + L_21 Inv(1,0)
-    if (mw == 1) {
+    if (wave == 1) {
       SK_PANEL_ROW(1, 3)
       block_update32(SK_L(3, 3), SK_L(3, 1), SK_L(3, 1), lane);
       block_update32(SK_L(3, 2), SK_L(3, 1), SK_L(2, 1), lane);
       SK_WRITE_L(3, 1) SK_WRITE_L(2, 1)
     }
-    if (mw == 2) {
+    if (wave == 2) {
       d4 acc[2][2];
       block_zero32(acc);
       block_mma32<true>(acc, SK_L(1, 0), SK_L(0, 0), lane);
@@ -815,8 +679,8 @@ __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict
       block_store32(SK_V(2, 1), acc, lane, 1.0);
       SK_WRITE_V(1, 0)
     }
-    if (mw == 3) {
-      SK_WRITE_W(1)
+    if (wave == 3) {
+      SK_WRITE_E(1) SK_WRITE_W(1)
       block_zero32(accs);
       block_mma32<true>(accs, SK_L(2, 0), SK_L(0, 0), lane);
       SK_FLAG_WAIT(2)
@@ -825,10 +689,10 @@ __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict
     }
     SK_STAMP(6)
     __syncthreads();
-    SK_CRITICAL_B_OTHERS
+    SK_CRITICAL_B(2)
     SK_STAMP(7)
     // ---- next to P(3): row 2 of the inverse, and the partial sums S(3,bj) = sum_{t<3} L(3,t) Inv(t,bj) of row 3
-    if (mw == 1) {  // S(3,0) = L_30 W_0 + L_31 Inv(1,0) + L_32 Inv(2,0)
+    if (wave == 1) {  // S(3,0) = L_30 W_0 + L_31 Inv(1,0) + L_32 Inv(2,0)
       block_zero32(accs);
       block_mma32<true>(accs, SK_L(3, 0), SK_L(0, 0), lane);
       block_mma32<true>(accs, SK_L(3, 1), SK_V(1, 0), lane);
@@ -838,7 +702,7 @@ __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict
       block_store32(SK_V(3, 0), accs, lane, 1.0);
       SK_WRITE_V(2, 0)
     }
-    if (mw == 2) {  // Inv(2,1) = -W_2 S(2,1);  S(3,1) = L_31 W_1 + L_32 Inv(2,1)
+    if (wave == 2) {  // Inv(2,1) = -W_2 S(2,1);  S(3,1) = L_31 W_1 + L_32 Inv(2,1)
       block_neg_left_mul32(SK_V(2, 1), SK_L(2, 2), lane);
       block_zero32(accs);
       block_mma32<true>(accs, SK_L(3, 1), SK_L(1, 1), lane);
@@ -846,40 +710,40 @@ __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict
       block_store32(SK_V(3, 1), accs, lane, 1.0);
       SK_WRITE_V(2, 1)
     }
-    if (mw == 3) {  // Inv(2,0) = -W_2 S(2,0);  S(3,2) = L_32 W_2
+    if (wave == 3) {  // Inv(2,0) = -W_2 S(2,0);  S(3,2) = L_32 W_2
       block_neg_left_mul32(SK_V(2, 0), SK_L(2, 2), lane);
       SK_FLAG_SET(3)
       block_zero32(accs);
       block_mma32<true>(accs, SK_L(3, 2), SK_L(2, 2), lane);
       block_store32(SK_V(3, 2), accs, lane, 1.0);
-      SK_WRITE_W(2)
+      SK_WRITE_E(2) SK_WRITE_W(2)
     }
     SK_STAMP(8)
     __syncthreads();
   }
   // row 3 of the inverse: Inv(3,bj) = -W_3 S(3,bj)
-  if (wave >= 4 && wave < 7) {
-    block_neg_left_mul32(SK_V(3, wave - 4), SK_L(3, 3), lane);
-    SK_WRITE_V(3, wave - 4)
-  } else if (wave == 7) {
-    SK_WRITE_W(3)
+  if (wave < 3) {
+    block_neg_left_mul32(SK_V(3, wave), SK_L(3, 3), lane);
+    SK_WRITE_V(3, wave)
+  } else {
+    SK_WRITE_E(3) SK_WRITE_W(3)
   }
   SK_STAMP(10)
 #undef SK_PANEL_ROW
 #undef SK_CRITICAL_B
-#undef SK_CRITICAL_B_OTHERS
 #undef SK_FLAG_SET
 #undef SK_FLAG_WAIT
 #undef SK_WRITE_L
 #undef SK_WRITE_W
 #undef SK_WRITE_V
+#undef SK_WRITE_E
 #undef SK_L
 #undef SK_V
 #undef SK_GA
 #undef SK_GI
 }
 
-__global__ __launch_bounds__(kPotrfThreads, 1) void potrf128_kernel(double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
+__global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   potrf128_body(lds, A, ld, Linv, info);
 }
@@ -962,7 +826,7 @@ __device__ __forceinline__ void chain_publish_through(int* p, int add) {
 
 struct ChainRanges { int n; int begin[8], end[8]; };  // the resident runs of block columns, [begin, end)
 
-__global__ __launch_bounds__(kPotrfThreads, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk) {
+__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ int ok_s;
   int done = 0;  // value of the potrf counter
@@ -1728,7 +1592,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       const int K = (kb - k0) * 128;
       if (kb > k0) update_diag(sp, "gemm_diag_update", Akk, P, K);  // lazy left-looking update from columns [k0, kb): diagonal tile ...
       if (kt) kt->begin("potrf128", sp);
-      hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(kPotrfThreads), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
+      hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), sp, Akk, ld, Linv + (long)kb * 128 * 128, info);
       if (kt) kt->end("potrf128", sp);
       if (below.main + below.extra > 0) {
         double* A21 = Akk + 128 * ld;
@@ -1777,7 +1641,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     srv = ctx->server;
     (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * maxblk), s);
     order(s, srv);
-    hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(kPotrfThreads), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk);
+    hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk);
   }
   order(s, sp);
   if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }

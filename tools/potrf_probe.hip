@@ -44,7 +44,7 @@ int main() {
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(sk::potrf128_kernel, dim3(1), dim3(sk::kPotrfThreads), sk::potrf128_lds_bytes(), 0, dA, (long)ld, dLinv, dinfo);
+    hipLaunchKernelGGL(sk::potrf128_kernel, dim3(1), dim3(256), sk::potrf128_lds_bytes(), 0, dA, (long)ld, dLinv, dinfo);
     hipEventRecord(e1, 0);
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
     float ms;
@@ -66,9 +66,9 @@ int main() {
       eI = std::fmax(eI, std::fabs(s - (i == j ? 1.0 : 0.0)));
     }
   printf("info %d  max|L - L_host| %.3e  max|Linv L - I| %.3e  best event time %.1f us\n", info, eL, eI, best * 1e3);
-  long long st[8][16];
+  long long st[4][16];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(sk::g_potrf_stamps), sizeof(st));
-  long long ck[8][16];
+  long long ck[4][16];
   hipMemcpyFromSymbol(ck, HIP_SYMBOL(sk::g_potrf_clk), sizeof(ck));
   printf("shader clock / 100 MHz wall clock over the kernel: %.2f  (=> %.0f MHz)\n", (double)(ck[0][10] - ck[0][0]) / (st[0][10] - st[0][0]),
          100.0 * (ck[0][10] - ck[0][0]) / (st[0][10] - st[0][0]));
@@ -76,7 +76,7 @@ int main() {
     printf("P(%d): chain %.2f us (%lld shader clocks), write-back %.2f us\n", jb, (st[0][11 + jb] - st[0][jb == 0 ? 1 : 1 + 2 * jb]) * 0.01,
            ck[0][11 + jb] - ck[0][jb == 0 ? 1 : 1 + 2 * jb], (st[0][2 + 2 * jb] - st[0][11 + jb]) * 0.01);
   const char* names[11] = {"start", "loaded", "A0", "B0", "A1", "B1", "A2", "B2", "A3", "B3", "end"};
-  for (int w = 0; w < 8; ++w) {
+  for (int w = 0; w < 4; ++w) {
     printf("wave %d:", w);
     for (int i = 1; i <= 10; ++i) if (i != 9) printf("  %s %+.2f", names[i], (st[w][i] - st[0][0]) * 0.01);  // 100 MHz counter -> us
     printf("\n");
