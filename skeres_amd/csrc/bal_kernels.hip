@@ -573,24 +573,36 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
 }
 
 // acc[k] += sum over entries e = e_begin, e_begin + stride, ... < e_end of  What[row obs][3c..3c+2] . What[col obs][3k..3k+2].
-// The indices of the next entry are fetched while the current one is being multiplied (one memory latency per
-// entry on the dependent chain instead of two).
-__device__ __forceinline__ void pair_accumulate(const BalDev& d, int e_begin, int e_end, int stride, int c, double (&acc)[9]) {
+// The nine lanes of a block need the same 27 values of the column observation's record: each lane fetches three of them
+// (as it does of the row observation's) and the group shares them through `slot` (its 27 doubles of LDS) — fourteen
+// 16-byte LDS broadcasts per entry where there were fourteen 16-byte global loads per lane (the texture path was the
+// limit: 17 load instructions per wave and entry group; 2.79 -> 2.12 ms on Venice-1778, 361 -> 264 us on Ladybug-1723).  The data of the next entry and the indices
+// of the one after it are in flight while the current one is multiplied.
+constexpr int kPairSlot = 34;  // doubles per nine-lane group: 272 bytes, so that the seven groups' 16-byte reads fall on disjoint banks
+__device__ __forceinline__ void pair_accumulate(const BalDev& d, int e_begin, int e_end, int stride, int c, double* slot, double (&acc)[9]) {
   if (e_begin >= e_end) return;
-  int ob = d.pair_row_obs[e_begin], oa = d.pair_col_obs[e_begin];
+  const int last = e_begin + (e_end - 1 - e_begin) / stride * stride;  // the last entry of this lane group
+  const double* wr = d.What + (size_t)d.pair_row_obs[e_begin] * kWs + 3 * c;
+  const double* wc = d.What + (size_t)d.pair_col_obs[e_begin] * kWs + 3 * c;
+  double y0 = wr[0], y1 = wr[1], y2 = wr[2], v0 = wc[0], v1 = wc[1], v2 = wc[2];
+  int e1 = e_begin + stride <= last ? e_begin + stride : last;
+  int ob1 = d.pair_row_obs[e1], oa1 = d.pair_col_obs[e1];
   for (int e = e_begin; e < e_end; e += stride) {
-    const int en = e + stride < e_end ? e + stride : e;
-    const int ob_next = d.pair_row_obs[en], oa_next = d.pair_col_obs[en];
-    const double* wr = d.What + (size_t)ob * kWs + 3 * c;
-    // the same 27 values for the nine lanes of a block: one 224-byte record, fetched as fourteen 16-byte loads
-    const double2* wc2 = reinterpret_cast<const double2*>(d.What + (size_t)oa * kWs);
-    double wc[kWs];
+    slot[3 * c] = v0; slot[3 * c + 1] = v1; slot[3 * c + 2] = v2;
+    __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave execute in order: no wait, only no reordering by the compiler)
+    double w[kWs];
 #pragma unroll
-    for (int k = 0; k < kWs / 2; ++k) { const double2 v = wc2[k]; wc[2 * k] = v.x; wc[2 * k + 1] = v.y; }
-    const double y0 = wr[0], y1 = wr[1], y2 = wr[2];
+    for (int k = 0; k < kWs / 2; ++k) { const double2 t = reinterpret_cast<const double2*>(slot)[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
+    __builtin_amdgcn_wave_barrier();
+    const double* wrn = d.What + (size_t)ob1 * kWs + 3 * c;
+    const double* wcn = d.What + (size_t)oa1 * kWs + 3 * c;
+    const double yn0 = wrn[0], yn1 = wrn[1], yn2 = wrn[2], vn0 = wcn[0], vn1 = wcn[1], vn2 = wcn[2];
+    const int e2 = e + 2 * stride <= last ? e + 2 * stride : last;
+    const int ob2 = d.pair_row_obs[e2], oa2 = d.pair_col_obs[e2];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] += y0 * wc[3 * k] + y1 * wc[3 * k + 1] + y2 * wc[3 * k + 2];
-    ob = ob_next; oa = oa_next;
+    for (int k = 0; k < 9; ++k) acc[k] += y0 * w[3 * k] + y1 * w[3 * k + 1] + y2 * w[3 * k + 2];
+    y0 = yn0; y1 = yn1; y2 = yn2; v0 = vn0; v1 = vn1; v2 = vn2;
+    ob1 = ob2; oa1 = oa2;
   }
 }
 
@@ -598,6 +610,7 @@ __device__ __forceinline__ void pair_accumulate(const BalDev& d, int e_begin, in
 __global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  __shared__ __attribute__((aligned(16))) double share[kBlock / 64][7][kPairSlot];
   const int sub = lane / 9, c = lane - 9 * sub;
   const int slot = wave * 7 + sub;
   if (sub >= 7 || slot >= d.num_short_segments) return;
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d) {
   double acc[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-  pair_accumulate(d, d.seg_start[seg], d.seg_start[seg + 1], 1, c, acc);
+  pair_accumulate(d, d.seg_start[seg], d.seg_start[seg + 1], 1, c, share[threadIdx.x >> 6][sub], acc);
   const int i = d.seg_row[seg], j = d.seg_col[seg];
   int ld;
   double* out = bal_block(d, i, j, &ld) + (size_t)c * ld;
@@ -619,6 +632,7 @@ __global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d) {
 // the short-segment kernel's list order: which kernel a segment goes to is fixed at set-up).
 __global__ __launch_bounds__(kBlock) void bal_pair_long_kernel(BalDev d) {
   __shared__ double red[kBlock / 64][7][81];
+  __shared__ __attribute__((aligned(16))) double share[kBlock / 64][7][kPairSlot];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int slot = (blockIdx.x * kBlock + threadIdx.x) >> 6;
   if (slot >= d.num_long_segments) return;  // wave-uniform
@@ -628,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void bal_pair_long_kernel(BalDev d) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.0;
   if (sub < 7) {
-    pair_accumulate(d, d.seg_start[seg] + sub, d.seg_start[seg + 1], 7, c, acc);
+    pair_accumulate(d, d.seg_start[seg] + sub, d.seg_start[seg + 1], 7, c, share[w][sub], acc);
 #pragma unroll
     for (int k = 0; k < 9; ++k) red[w][sub][9 * c + k] = acc[k];
   }

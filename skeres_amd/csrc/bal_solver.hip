@@ -749,7 +749,7 @@ int BalSolver::setup() {
     SK_HIP_TRY(b_yf_.alloc(y_off)); SK_HIP_TRY(b_yf_.zero(s)); SK_HIP_TRY(b_wf_.alloc(y_off)); SK_HIP_TRY(b_ybB_.alloc((size_t)std::max(1, border_blocks_) * 128));
   }
   if (opt_.allreduce) { SK_HIP_TRY(b_pack_col0_.upload(pack_col0_h_, s)); SK_HIP_TRY(b_pack_off_.upload(pack_off_h_, s)); }
-  if (chain_ok()) cholesky_prepare(&chol_ctx_, s);  // (once per device: which queues the resident panel chain uses)
+  cholesky_prepare(&chol_ctx_, s);  // (once per device: which queues the panel, bulk and server streams sit on; nothing without look-ahead)
   if (dissected_ && !segmented_) SK_HIP_TRY(chol_ctx_b_.init_secondary(chol_ctx_));  // (again, now that the queue choice is made: the queues it left over)
   SK_HIP_TRY(b_S_.zero(s));  // once: the blocks outside the envelopes are never touched again
   for (int f = 0; f < 3; ++f) {

@@ -760,17 +760,17 @@ int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double*
   CholeskyContext ctx, ctxB;
   const bool la = ctx.init() == hipSuccess;
   if (!la) (void)hipGetLastError();
-  const bool side = la && ctxB.init_secondary(ctx) == hipSuccess;
-  if (la && !side) (void)hipGetLastError();
   SK_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   SK_HIP_TRY(hipDeviceSynchronize());
+  if (la) cholesky_prepare(&ctx, s);  // the device's queue choice first: the second context takes the queues it leaves over
+  const bool side = la && ctxB.init_secondary(ctx) == hipSuccess;
+  if (la && !side) (void)hipGetLastError();
   DissectedSystem d;
   d.A.S = dFA.p; d.A.ld = (long)dA; d.A.nblk = nA + E; d.A.ncols = nA; d.A.last = lastA.data(); d.A.Linv = dLinv.p; d.A.rhs_row = nA * 128 + msep;
   d.B.S = dFB.p; d.B.ld = (long)dB; d.B.nblk = nB + E; d.B.ncols = nB; d.B.last = lastB.data(); d.B.Linv = dLinv.p + (size_t)nA * 128 * 128; d.B.rhs_row = nB * 128 + msep;
   d.R.S = dFR.p; d.R.ld = (long)dR; d.R.nblk = E; d.R.ncols = E; d.R.last = nullptr; d.R.Linv = dLinv.p + (size_t)(nA + nB) * 128 * 128; d.R.rhs_row = msep;
   d.border_blocks = E; d.mapB = dmap.p;
   const bool chain = automatic_plan != 0 && la && ctx.server != nullptr;
-  if (chain) cholesky_prepare(&ctx, s);
   cholesky_dissected_factor(d, dinfo.p, group, s, la ? &ctx : nullptr, side ? &ctxB : nullptr, nullptr, nullptr, chain);
   double *wA = dw.p, *wB = dw.p + dA, *wR = dw.p + dA + dB, *ybB = dw.p + dA + dB + dR;
   double *yA = dy.p, *yB = dy.p + dA, *yR = dy.p + dA + dB;

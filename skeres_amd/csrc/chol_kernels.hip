@@ -1538,7 +1538,10 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
                      KernelTimer* kt, const int* last, bool allow_chain, int ncols) {
   const int nblk = npad / 128;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
-  if (allow_chain && !(ctx && ctx->dq && ctx->dq->tuning)) cholesky_prepare(ctx, s);
+  // Which hardware queues the panel and bulk streams sit on decides how well their kernels overlap — with or without the
+  // resident chain (Venice-1778 in explicit groups of two: 30.6 ms per iteration on the first combination, 19.1 on the
+  // one the trial picks): every look-ahead factorisation asks for the trial, which runs once per device.
+  if (ctx && ctx->dq && !ctx->dq->tuning) cholesky_prepare(ctx, s);
   const bool la = ctx != nullptr && ctx->panel != nullptr && ctx->bulk != nullptr;
   hipStream_t sp = la ? ctx->panel : s;
   hipStream_t sb = la ? ctx->bulk : s;  // of the current group (chosen below)
