@@ -1421,7 +1421,7 @@ __global__ void set_identity_kernel(double* A, long ld, int n) {
 static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
   DeviceQueues& q = *ctx->dq;
   q.queue_choice = 0;
-  const int nblk = 26, n = nblk * 128;
+  const int nblk = 26, nblk2 = 32, n = nblk2 * 128;  // (stage 1 factors the leading 26 blocks of A, stage 2 all 32)
   double *A = nullptr, *Linv = nullptr;
   int* info = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&A), sizeof(double) * (size_t)n * n) != hipSuccess ||
@@ -1450,12 +1450,14 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
     ctx->use(&q);
   };
   bool serialised = false;
+  // Stage 1, every combination: the banded system above, all of it under the resident chain (the hand-overs between the
+  // server, the column launches and the SYRKs are what a bad combination delays: 1.0 ms against 1.5-4).
   for (int c = 0; c < ncomb && !serialised; ++c) {
     select(c);
     for (int rep = 0; rep < 3; ++rep) {  // (the first one also pages the kernels in)
       (void)hipStreamSynchronize(s);
       const auto t0 = std::chrono::steady_clock::now();
-      cholesky_factor(A, n, n, Linv, info, 1, s, ctx, nullptr, last.data(), true);
+      cholesky_factor(A, n, nblk * 128, Linv, info, 1, s, ctx, nullptr, last.data(), true);
       (void)hipStreamSynchronize(s);
       const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (rep > 0 && t < ms[c]) ms[c] = t;
@@ -1469,8 +1471,8 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
       }
     }
   }
-  q.tuning = false;
   if (serialised) {
+    q.tuning = false;
     q.chain_server = 0;
     std::fprintf(stderr, "[skeres_amd] the resident panel chain timed out in its trial run (are kernels being serialised, e.g. by counter "
                          "collection?): block columns are factored launch by launch in this process\n");
@@ -1488,12 +1490,37 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
     std::fprintf(stderr, "[skeres_amd] the resident panel chain ran %.0f times slower than it should in its trial run (is the device shared with "
                          "another process?): block columns are factored launch by launch in this process\n", best / 1.1);
   }
-  for (int c = ncomb - 1; c >= 0; --c) if (ms[c] <= 1.04 * best) q.queue_choice = c;  // the first of those within noise of the best: the same choice run after run
+  // Stage 2, the combinations within noise of the best: a dense system factored launch by launch in groups of two with
+  // every SYRK on the queue of the EARLY groups, which a banded system never uses and a dense one uses for most of its
+  // flops — a combination can be right for one and wrong for the other (Ladybug-1723: four combinations at 9.1 ms per
+  // iteration, of which one factors the dense system of the same size in 34.7 ms and the others in 29.2-29.6).
+  std::vector<double> ms2((size_t)ncomb, 1e30);
+  double best2 = 1e30;
+  for (int c = 0; c < ncomb; ++c) {
+    if (ms[c] > 1.08 * best) continue;
+    select(c);
+    ctx->early_tiles = 0;
+    double sum = 0.0;
+    for (int rep = 0; rep < 4; ++rep) {
+      (void)hipStreamSynchronize(s);
+      const auto t0 = std::chrono::steady_clock::now();
+      cholesky_factor(A, n, n, Linv, info, 2, s, ctx, nullptr, nullptr, false);
+      (void)hipStreamSynchronize(s);
+      if (rep > 0) sum += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    ms2[c] = sum / 3.0;  // (the mean: a conflict between two queues shows in some runs and not in others)
+    best2 = std::min(best2, ms2[c]);
+  }
+  for (int c = ncomb - 1; c >= 0; --c) if (ms2[c] <= 1.04 * best2) q.queue_choice = c;  // the first of those within noise of the best: the same choice run after run
   if (getenv("SK_DEBUG_QUEUES")) {
-    std::fprintf(stderr, "[skeres_amd] synthetic factorisation (ms) per (bulk, panel, server) queue candidates:");
-    for (int c = 0; c < ncomb; ++c) std::fprintf(stderr, "%s%.2f", c % kServerCand == 0 ? "  " : " ", ms[c]);
+    std::fprintf(stderr, "[skeres_amd] synthetic factorisations (ms: banded under the resident chain / dense on the early-group queue) per (bulk, panel, server) queue candidates:");
+    for (int c = 0; c < ncomb; ++c) {
+      std::fprintf(stderr, "%s%.2f", c % kServerCand == 0 ? "  " : " ", ms[c]);
+      if (ms2[c] < 1e29) std::fprintf(stderr, "/%.2f", ms2[c]);
+    }
     std::fprintf(stderr, ": combination %d (device %d)\n", q.queue_choice, q.device);
   }
+  q.tuning = false;
   select(q.queue_choice);
   (void)hipFree(A);
   (void)hipFree(Linv);
