@@ -76,6 +76,18 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ld
     ti = r; tj = b - r * (r + 1) / 2;
     if (ti >= main_t) ti += jump_t;
     if (tj >= main_t) tj += jump_t;
+  } else if (kShape == 2) {
+    // lower-triangular enumeration of 128-blocks, 128 / kTM row tiles each (kTN == 128): the small SYRK without the
+    // workgroups above the diagonal, which as a rectangle were half of the grid and left at once — at 10 ns of
+    // dispatcher time each
+    constexpr int kSub = 128 / kTM;
+    const int b = (int)blockIdx.x / kSub;
+    int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= b) ++r;
+    while (r * (r + 1) / 2 > b) --r;
+    ti = r * kSub + (int)blockIdx.x % kSub; tj = b - r * (r + 1) / 2;
+    if (ti >= main_t) ti += jump_t;
+    if (tj >= main_n) tj += jump_n;
   } else {
     const int bx = block_id >= 0 ? block_id : (int)blockIdx.x;  // (chain_column_kernel numbers its tiles itself)
     ti = bx % tiles_m; tj = bx / tiles_m;
@@ -190,14 +202,14 @@ __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, lo
   SK_GEMM_LDS(16, 128, 128)
   gemm_nt_f64_body<0, 1, 16, 1, 128, 128>(sh, C, ldc, A, lda, A, lda, K, 0, tile_off, main_t, jump_t);
 }
-// The same update for a SMALL trailing matrix (block envelope: a few dozen block rows): as a rectangle of 32 x 128
-// tiles with the tiles above the diagonal dropped.  A 128 x 128 tile with K = 128 is one workgroup-latency of
+// The same update for a SMALL trailing matrix (block envelope: a few dozen block rows): in 32 x 128 tiles, four to a
+// 128-block of the lower triangle (kShape 2).  A 128 x 128 tile with K = 128 is one workgroup-latency of
 // 30-50 us however few tiles there are (load 128 KB of C, eight K-steps, store 128 KB); 32-row tiles are four
 // times as many workgroups, each a quarter as long, and the whole launch fits in two rounds.
 __global__ __launch_bounds__(256, 2) void syrk_trailing_thin_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tiles_m, int main_t,
                                                                         int jump_t, int main_n, int jump_n) {
   SK_GEMM_LDS(16, 32, 128)
-  gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(sh, C, ldc, A, lda, A, lda, K, tiles_m, 1, main_t, jump_t, main_n, jump_n);
+  gemm_nt_f64_body<0, 2, 16, 2, 32, 128>(sh, C, ldc, A, lda, A, lda, K, tiles_m, 0, main_t, jump_t, main_n, jump_n);
 }
 // Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
 // transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
@@ -1733,7 +1745,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       if (kt) kt->pair("gemm_syrk", &t_start, &t_stop);
       hipEvent_t stop_ev = t_stop ? t_stop : (record ? ctx->event(ev++) : nullptr);
       if (Tb <= g_thin_syrk_tiles)
-        hipExtLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(4 * Tb * Tb), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main,
+        hipExtLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(2 * Tb * (Tb + 1)), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main,
                               4 * rs.jump, rs.main, rs.jump);
       else
         hipExtLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
