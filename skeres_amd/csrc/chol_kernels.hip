@@ -77,15 +77,21 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ld
     if (ti >= main_t) ti += jump_t;
     if (tj >= main_t) tj += jump_t;
   } else if (kShape == 2) {
-    // lower-triangular enumeration of 128-blocks, 128 / kTM row tiles each (kTN == 128): the small SYRK without the
-    // workgroups above the diagonal, which as a rectangle were half of the grid and left at once — at 10 ns of
-    // dispatcher time each
+    // lower-triangular enumeration of 128-blocks, 128 / kTM row tiles each (kTN == 128), COLUMN by column (the tiles of a
+    // block column follow each other, as in the rectangle this replaces: they share the 128 x K operand of their
+    // column — enumerated row by row the launch fetched 127 MB instead of 82): the small SYRK without the workgroups
+    // above the diagonal, which were half of the rectangle.  (An XCD-aware map on top — workgroup w, which goes to XCD
+    // w mod 8, taking the tiles of one contiguous eighth of either triangular enumeration — was measured and dropped:
+    // 102.1 MB per SYRK launch against 98.0, no difference in time; profiles/r02_d_pmc_traffic.json.)
     constexpr int kSub = 128 / kTM;
-    const int b = (int)blockIdx.x / kSub;
-    int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-    while ((r + 1) * (r + 2) / 2 <= b) ++r;
-    while (r * (r + 1) / 2 > b) --r;
-    ti = r * kSub + (int)blockIdx.x % kSub; tj = b - r * (r + 1) / 2;
+    const int T = tiles_m / kSub, nb = T * (T + 1) / 2;
+    const int w = (int)blockIdx.x;
+    const int k = nb - 1 - w / kSub;  // from the last (shortest) column backwards: the row-by-row enumeration of a triangle
+    int r = (int)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= k) ++r;
+    while (r * (r + 1) / 2 > k) --r;
+    tj = T - 1 - r;
+    ti = (T - 1 - (k - r * (r + 1) / 2)) * kSub + w % kSub;
     if (ti >= main_t) ti += jump_t;
     if (tj >= main_n) tj += jump_n;
   } else {
