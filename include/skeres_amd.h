@@ -89,9 +89,33 @@ typedef enum sk_functor_id {
    * sk_problem_add_dense_rows. */
   SK_FUNCTOR_SYNTH_TANH_ROW = 10,
   SK_FUNCTOR_HELLO_WORLD = 11,            /* EX/HelloWorld.scala:11-14: r = 10 - x */
-  SK_FUNCTOR_QUATERNION_ROTATION = 12     /* r = R(q) p - t, q = (w, x, y, z) normalised; consts (p[3], t[3]); no reference
+  SK_FUNCTOR_QUATERNION_ROTATION = 12,    /* r = R(q) p - t, q = (w, x, y, z) normalised; consts (p[3], t[3]); no reference
                                            * counterpart: a 4-parameter block for the local parameterizations */
+  SK_FUNCTOR_TAPE = 13                    /* a recorded functor body: sk_cost_function_new_tape */
 } sk_functor_id;
+
+/* A recorded functor body ("tape").  CORE/CostFunctor.scala:40-51 lets the user write ANY residual as
+ *   def apply[T: Field: Trig: NRoot: Order: ClassTag](x: Array[T]*): Array[T]
+ * and the reference calls it back per residual block on the JVM (ceres.i:48).  The functors of the reference's own
+ * examples have device bodies above; every other functor gets to the device by being run ONCE with a recording T
+ * (the Scala side: a T whose Field / Trig / NRoot instances append an instruction and return a fresh register;
+ * skeres_amd/tape.py is that recording T in Python) — the list of instructions is the tape, evaluated on the GPU per
+ * residual block by forward-mode autodiff exactly as CORE/AutodiffCostFunction.scala:96-130 seeds and reads its Jets.
+ * An instruction is five 32-bit integers: opcode, destination register, operands a, b, c.
+ * An operand is kind << 28 | index: */
+typedef enum sk_tape_operand_kind {
+  SK_TAPE_REGISTER = 0,   /* a register written by an earlier instruction */
+  SK_TAPE_PARAMETER = 1,  /* x(i)(j), numbered through the blocks: index = N(0) + ... + N(i-1) + j */
+  SK_TAPE_CAPTURED = 2,   /* the index-th double the closure captures (observedX, observedY, ...), per residual block */
+  SK_TAPE_CONSTANT = 3    /* the index-th literal of the body (tape_constants) */
+} sk_tape_operand_kind;
+typedef enum sk_tape_opcode {
+  SK_TAPE_MOV = 0, SK_TAPE_ADD, SK_TAPE_SUB, SK_TAPE_MUL, SK_TAPE_DIV, SK_TAPE_NEG, SK_TAPE_SQRT, SK_TAPE_EXP, SK_TAPE_LOG,
+  SK_TAPE_SIN, SK_TAPE_COS, SK_TAPE_TAN, SK_TAPE_ASIN, SK_TAPE_ACOS, SK_TAPE_ATAN, SK_TAPE_ATAN2 /* atan2(a, b) */, SK_TAPE_ABS,
+  SK_TAPE_LT,     /* 1 if real(a) <  real(b) else 0: spire's Order[Jet] compares real parts (CORE/Rotation.scala:458) */
+  SK_TAPE_LE,     /* 1 if real(a) <= real(b) else 0 */
+  SK_TAPE_SELECT  /* real(a) != 0 ? b : c — a data-dependent `if` of the body, BOTH of whose arms are on the tape */
+} sk_tape_opcode;
 
 typedef struct sk_ptrvec sk_ptrvec;
 typedef struct sk_loss_function sk_loss_function;
@@ -216,6 +240,16 @@ typedef int (*sk_evaluate_fn)(void* user, double const* const* parameters, doubl
                               double** jacobians);
 sk_cost_function* sk_cost_function_new_callback(sk_evaluate_fn fn, void* user, int num_residuals,
                                                 const int* block_sizes, int num_blocks);
+/* AutoDiffCostFunctor.toAutoDiffCostFunction (CORE/CostFunctor.scala:44) for a functor WITHOUT a device body: its
+ * recorded body (see sk_tape_opcode).  `instructions`: 5 * num_instructions integers; `output_operands`: one operand per
+ * residual; `captured`: the doubles this closure captures (num_captured of them; sk_problem_add_residual_blocks_tape
+ * passes them per block instead).  Validates sizes as CostFunctor / SizedCostFunction do (CORE/CostFunctor.scala:31-34)
+ * and every instruction (known opcode, operands in range, registers written before they are read).  NULL on error. */
+sk_cost_function* sk_cost_function_new_tape(int num_residuals, const int* block_sizes, int num_blocks,
+                                            const int* instructions, int num_instructions,
+                                            const double* tape_constants, int num_tape_constants,
+                                            int num_registers, const int* output_operands,
+                                            const double* captured, int num_captured);
 void sk_cost_function_free(sk_cost_function* cf);
 int sk_cost_function_num_residuals(const sk_cost_function* cf);             /* CostFunction.numResiduals() */
 int sk_cost_function_num_parameter_blocks(const sk_cost_function* cf);      /* parameterBlockSizes().size() */
@@ -242,6 +276,10 @@ int sk_problem_add_residual_block(sk_problem* p, const sk_cost_function* cost,
  * n x num_consts row-major; parameter_blocks is n x num_blocks row-major. */
 int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const double* consts,
                                    const sk_loss_function* loss, double* const* parameter_blocks);
+/* The same for a recorded functor (sk_cost_function_new_tape): n residual blocks of the body of `cost`, block b with
+ * the captured doubles captured[b * num_captured ..] (NULL when the body captures none). */
+int sk_problem_add_residual_blocks_tape(sk_problem* p, const sk_cost_function* cost, int n, const double* captured,
+                                        const sk_loss_function* loss, double* const* parameter_blocks);
 /* Bulk add of `num_rows` residual blocks of a dense-row functor (SK_FUNCTOR_SYNTH_TANH_ROW) that all
  * depend on the single parameter block x[0..n).  consts is num_rows x 3 row-major. */
 int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const double* consts,

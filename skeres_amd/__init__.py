@@ -20,7 +20,7 @@ from .api import (  # noqa: F401
     DoubleArray, RichDoubleArray, RichDoubleMatrix, StdVectorDoublePointer,
     CostFunction, SizedCostFunction, CostFunctor, AutoDiffCostFunctor, AutoDiffCostFunction,
     NumericDiffCostFunctor, NumericDiffCostFunction, NumericDiffMethodType, NumericDiffOptions,
-    HostAutoDiffCostFunctor, HostAutoDiffCostFunction, CostFunctorAdapter, CostFunctionToFunctor, DynamicCostFunctionToFunctor,
+    HostAutoDiffCostFunctor, HostAutoDiffCostFunction, TracedCostFunctor, TracedCostFunction, CostFunctorAdapter, CostFunctionToFunctor, DynamicCostFunctionToFunctor,
     SnavelyReprojectionError, ExponentialResidual, PowellF1, PowellF2, PowellF3, PowellF4,
     BinaryScalarCost, BinaryVector3Cost, TenParameterCost, HelloCostFunctor, QuaternionRotationError,
     LocalParameterization, PredefinedLocalParameterizations,
@@ -29,4 +29,5 @@ from .api import (  # noqa: F401
 )
 from . import bal  # noqa: F401
 from . import rotation  # noqa: F401
+from . import tape  # noqa: F401
 from .rotation import Rotation, Jet, Quaternion, MatrixAdapter, RowMajorMatrixAdapter3x3, ColumnMajorMatrixAdapter3x3  # noqa: F401

@@ -82,6 +82,8 @@ _SIGS = {
     "sk_problem_free": (None, [C.c_void_p]),
     "sk_problem_add_residual_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _dpp, C.c_int, _ip]),
     "sk_problem_add_residual_blocks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_void_p, _dpp]),
+    "sk_problem_add_residual_blocks_tape": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, C.c_void_p, _dpp]),
+    "sk_cost_function_new_tape": (C.c_void_p, [C.c_int, _ip, C.c_int, _ip, C.c_int, _dp, C.c_int, C.c_int, _ip, _dp, C.c_int]),
     "sk_problem_add_dense_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_void_p, _dp, C.c_int]),
     "sk_problem_num_residual_blocks": (C.c_int, [C.c_void_p]),
     "sk_problem_num_parameter_blocks": (C.c_int, [C.c_void_p]),
@@ -605,6 +607,70 @@ class HostAutoDiffCostFunction(SizedCostFunction):
         return True
 
 
+class TracedCostFunctor(HostAutoDiffCostFunctor):
+    """A generic functor WITHOUT a body in the device registry that still runs on the GPU: ``apply`` is run once on
+    recording values (skeres_amd/tape.py: the ``T`` of CORE/CostFunctor.scala:40-51 instantiated a third time) and the
+    recorded instruction list is evaluated on the device per residual block (include/skeres_amd.h:
+    sk_cost_function_new_tape).  Write ``apply`` over generic values — arithmetic, ``skeres_amd.tape.sqrt / exp / log /
+    sin / cos / ... / atan2`` and ``skeres_amd.tape.where(a > b, then, otherwise)`` for a data-dependent branch — and it
+    also works over floats and ``rotation.Jet`` (``toHostAutoDiffCostFunction``: the director path, for comparison).
+    ``captured``: the doubles the closure captures (the reference's ``observedX``, ``observedY``); inside ``apply`` read
+    them with ``self.captured_values()``, which gives floats, or the recording's values while recording."""
+
+    def __init__(self, kNumResiduals, *N, captured=()):
+        super().__init__(kNumResiduals, *N)
+        self.captured = tuple(float(c) for c in captured)
+        self._traced_captured = None
+        self._tape = None
+
+    def captured_values(self):
+        return list(self._traced_captured) if self._traced_captured is not None else list(self.captured)
+
+    def tape(self):
+        """(instructions [n, 5] int32, literals, number of registers, output operands): recorded once per functor object."""
+        if self._tape is None:
+            from . import tape as _tape
+            self._tape = _tape.record(self, self.N, len(self.captured))
+        return self._tape
+
+    def toAutoDiffCostFunction(self):
+        return TracedCostFunction(self)
+
+    def toHostAutoDiffCostFunction(self):
+        return HostAutoDiffCostFunction(self)
+
+
+class TracedCostFunction(SizedCostFunction):
+    """CORE/AutodiffCostFunction.scala:69-135 over a recorded functor: evaluated on the device."""
+
+    def __init__(self, costFunctor):
+        super().__init__(costFunctor.kNumResiduals, *costFunctor.N)
+        self.costFunctor = costFunctor
+
+    def _handle(self):
+        if self._h is None:
+            f = self.costFunctor
+            ins, consts, nregs, outs = f.tape()
+            sizes = np.asarray(f.N, dtype=np.int32)
+            cap = np.asarray(f.captured, dtype=np.float64)
+            ins = np.ascontiguousarray(ins, dtype=np.int32)
+            self._h = lib().sk_cost_function_new_tape(
+                f.kNumResiduals, sizes.ctypes.data_as(_ip), len(f.N), ins.ctypes.data_as(_ip), ins.shape[0],
+                consts.ctypes.data_as(_dp) if consts.size else _dp(), consts.size, int(nregs), outs.ctypes.data_as(_ip),
+                cap.ctypes.data_as(_dp) if cap.size else _dp(), cap.size)
+            if not self._h:
+                raise ValueError(lib().sk_last_error().decode())
+        return self._h
+
+    def evaluate(self, parameters, residuals, jacobians):
+        pp = parameters._as_pp()
+        jp = jacobians._as_pp() if jacobians is not None else None
+        rc = lib().sk_cost_function_evaluate(self._handle(), pp, residuals.cast(), jp)
+        if rc < 0:
+            raise SkeresError(lib().sk_last_error().decode())
+        return bool(rc)
+
+
 class CostFunctorAdapter(HostAutoDiffCostFunctor):
     """CORE/CostFunctionToFunctor.scala:50-123: a CostFunction as a generic functor, so that it can be called from
     inside another functor.  Over doubles it evaluates the cost function's residuals (:66-77); over Jets it evaluates
@@ -923,6 +989,24 @@ class Problem:
         rc = lib().sk_problem_add_residual_blocks(self._h, int(functor_id), int(n), consts.ctypes.data_as(_dp),
                                                   loss._h if loss is not None else None,
                                                   C.cast(ptrs.ctypes.data, _dpp))
+        if rc == 1:
+            raise ValueError(lib().sk_last_error().decode())
+        _check(rc)
+
+    def addResidualBlocksTraced(self, costFunctor, captured, loss, base, offsets):
+        """The same for a recorded functor (``TracedCostFunctor``): n residual blocks of its body, block b with the
+        captured doubles ``captured[b]`` ([n, len(costFunctor.captured)])."""
+        cost = costFunctor.toAutoDiffCostFunction() if isinstance(costFunctor, TracedCostFunctor) else costFunctor
+        self._costs.append(cost)
+        self._arrays.append(base)
+        self._losses.append(loss)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = offsets.shape[0]
+        addr = C.cast(base.cast(), C.c_void_p).value
+        ptrs = np.ascontiguousarray(addr + 8 * offsets.ravel(), dtype=np.uint64)
+        captured = np.ascontiguousarray(captured, dtype=np.float64)
+        rc = lib().sk_problem_add_residual_blocks_tape(self._h, cost._handle(), int(n), captured.ctypes.data_as(_dp) if captured.size else _dp(),
+                                                       loss._h if loss is not None else None, C.cast(ptrs.ctypes.data, _dpp))
         if rc == 1:
             raise ValueError(lib().sk_last_error().decode())
         _check(rc)

@@ -176,6 +176,104 @@ __global__ __launch_bounds__(kBlock) void bal_eval_cost_kernel(BalDev d) {
   block_sum<2>(acc, d.partial, d.partial_stride);
 }
 
+// ---- recorded functors (tape.hpp): the same two kernels with the functor body interpreted ------------------------
+// `d.obs` holds the tape's captured doubles as planes [num_obs][N].  Forward mode in 12 / W passes of Jet<W> (W divides
+// 12); the registers of the workgroup's threads are the dynamic LDS.  Everything after the functor — loss correction,
+// column scaling, the planes written — is the code of bal_eval_jac_kernel, applied column by column.
+constexpr int kTapeMaxObs = 8;
+template <bool kLoss, int W>
+__global__ __launch_bounds__(kBlock) void bal_eval_jac_tape_kernel(BalDev d, TapeDev t, int num_obs) {
+  extern __shared__ __attribute__((aligned(16))) double tape_lds[];
+  typedef Jet<W> J;
+  const TapeRegs<J> regs{tape_lds, kBlock, (int)threadIdx.x};
+  double acc[1] = {0.0};
+  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    if (d.is_host && d.is_host[o]) continue;
+    const int ci = d.cam[o], pi = d.pt[o];
+    double c[kTapeMaxObs];
+    for (int k = 0; k < num_obs; ++k) c[k] = d.obs[(size_t)k * d.N + o];
+    auto param = [&](int k) { return k < 9 ? d.xc[9 * (size_t)ci + k] : d.xp[3 * (size_t)pi + (k - 9)]; };
+    double r0 = 0.0, r1 = 0.0, sqrt_rho1 = 1.0, alpha_sq_norm = 0.0;
+    for (int first = 0; first < 12; first += W) {
+      J out[2];
+      tape_run<J>(t, c, param, first, regs, out);
+      if (first == 0) {
+        r0 = out[0].a; r1 = out[1].a;
+        if (kLoss) {
+          const double sq = r0 * r0 + r1 * r1;
+          double rho[3];
+          loss_evaluate(d.loss_nodes, d.loss_root, sq, rho);
+          const LossCorrector lc(sq, rho);
+          acc[0] += rho[0];
+          sqrt_rho1 = lc.sqrt_rho1; alpha_sq_norm = lc.alpha_sq_norm;
+          d.r[o] = r0 * lc.residual_scaling;
+          d.r[(size_t)d.N + o] = r1 * lc.residual_scaling;
+        } else {
+          d.r[o] = r0;
+          d.r[(size_t)d.N + o] = r1;
+          acc[0] += r0 * r0 + r1 * r1;
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const int k = first + w;
+        double j0 = out[0].v[w], j1 = out[1].v[w];
+        if (kLoss) {
+          const double rtj = alpha_sq_norm * (r0 * j0 + r1 * j1);
+          const double a0 = sqrt_rho1 * (j0 - r0 * rtj), a1 = sqrt_rho1 * (j1 - r1 * rtj);
+          j0 = a0; j1 = a1;
+        }
+        if (k < 9) {
+          const double s = d.scale_c[9 * (size_t)ci + k];
+          d.F[(size_t)k * d.N + o] = j0 * s;
+          d.F[(size_t)(9 + k) * d.N + o] = j1 * s;
+        } else {
+          const double s = d.scale_p[3 * (size_t)pi + (k - 9)];
+          d.E[(size_t)(k - 9) * d.N + o] = j0 * s;
+          d.E[(size_t)(3 + k - 9) * d.N + o] = j1 * s;
+        }
+      }
+    }
+  }
+  block_sum<1>(acc, d.partial, d.partial_stride);
+}
+template <bool kLoss>
+__global__ __launch_bounds__(kBlock) void bal_eval_cost_tape_kernel(BalDev d, TapeDev t, int num_obs) {
+  extern __shared__ __attribute__((aligned(16))) double tape_lds[];
+  const TapeRegs<double> regs{tape_lds, kBlock, (int)threadIdx.x};
+  double acc[2] = {0.0, 0.0};
+  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    if (d.is_host && d.is_host[o]) continue;
+    const int ci = d.cam[o], pi = d.pt[o];
+    double c[kTapeMaxObs], out[2];
+    for (int k = 0; k < num_obs; ++k) c[k] = d.obs[(size_t)k * d.N + o];
+    auto param = [&](int k) { return k < 9 ? d.xc_new[9 * (size_t)ci + k] : d.xp_new[3 * (size_t)pi + (k - 9)]; };
+    tape_run<double>(t, c, param, 0, regs, out);
+    if (kLoss) {
+      double rho[3];
+      loss_evaluate(d.loss_nodes, d.loss_root, out[0] * out[0] + out[1] * out[1], rho);
+      acc[0] += rho[0];
+    } else {
+      acc[0] += out[0] * out[0] + out[1] * out[1];
+    }
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const double s = d.step_c[9 * (size_t)ci + k];
+      m0 += d.F[(size_t)k * d.N + o] * s;
+      m1 += d.F[(size_t)(9 + k) * d.N + o] * s;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double s = d.step_p[3 * (size_t)pi + k];
+      m0 += d.E[(size_t)k * d.N + o] * s;
+      m1 += d.E[(size_t)(3 + k) * d.N + o] * s;
+    }
+    acc[1] += m0 * (d.r[o] + m0 / 2.0) + m1 * (d.r[(size_t)d.N + o] + m1 / 2.0);
+  }
+  block_sum<2>(acc, d.partial, d.partial_stride);
+}
+
 // Host-evaluated observations (director path): what the caller's Evaluate wrote — residuals and the two row-major
 // Jacobian blocks, CORE/AutodiffCostFunction.scala:113-130 — goes through the same loss correction and column scaling
 // as the device functors' output and into the same planes; everything downstream cannot tell the difference.
@@ -825,6 +923,26 @@ void launch_bal_eval_jac(const BalDev& d, hipStream_t s) {
 void launch_bal_eval_cost(const BalDev& d, hipStream_t s) {
   if (d.loss_root >= 0) hipLaunchKernelGGL(bal_eval_cost_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
   else hipLaunchKernelGGL(bal_eval_cost_kernel<false>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
+}
+// recorded functors.  W: derivative slots per pass (1, 2 or 3: bal_tape_width)
+int bal_tape_width(const Tape& t) { return t.num_obs_consts > kTapeMaxObs ? 0 : tape_pick_width(t, kBlock); }
+template <class K> static void bal_tape_allow_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+void launch_bal_eval_jac_tape(const BalDev& d, const TapeDevBuffers& tb, hipStream_t s) {
+  const int W = bal_tape_width(tb.host), nobs = tb.host.num_obs_consts;
+  const size_t lds = tape_lds_bytes(tb.host, W, kBlock);
+  const dim3 g(grid_for(d.N)), b(kBlock);
+#define SK_TAPE_JAC(LOSS, WW) { bal_tape_allow_lds(bal_eval_jac_tape_kernel<LOSS, WW>, lds); hipLaunchKernelGGL((bal_eval_jac_tape_kernel<LOSS, WW>), g, b, lds, s, d, tb.view, nobs); }
+  if (d.loss_root >= 0) { if (W == 3) SK_TAPE_JAC(true, 3) else if (W == 2) SK_TAPE_JAC(true, 2) else SK_TAPE_JAC(true, 1) }
+  else { if (W == 3) SK_TAPE_JAC(false, 3) else if (W == 2) SK_TAPE_JAC(false, 2) else SK_TAPE_JAC(false, 1) }
+#undef SK_TAPE_JAC
+}
+void launch_bal_eval_cost_tape(const BalDev& d, const TapeDevBuffers& tb, hipStream_t s) {
+  const size_t lds = tape_lds_bytes(tb.host, 0, kBlock);
+  const int nobs = tb.host.num_obs_consts;
+  if (d.loss_root >= 0) { bal_tape_allow_lds(bal_eval_cost_tape_kernel<true>, lds); hipLaunchKernelGGL(bal_eval_cost_tape_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), lds, s, d, tb.view, nobs); }
+  else { bal_tape_allow_lds(bal_eval_cost_tape_kernel<false>, lds); hipLaunchKernelGGL(bal_eval_cost_tape_kernel<false>, dim3(grid_for(d.N)), dim3(kBlock), lds, s, d, tb.view, nobs); }
 }
 int launch_bal_host_jac(const BalDev& d, int partial_off, hipStream_t s) {
   if (d.num_host <= 0) return 0;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "common.hpp"
 #include "loss.hpp"
 
 namespace sk {
@@ -14,7 +15,7 @@ struct BalDev {
   // structure (built once on the host, point-major observation order)
   const int* cam;         // [N] camera of observation o
   const int* pt;          // [N] local point of observation o
-  const double* obs;      // [2][N] observed x, y
+  const double* obs;      // [2][N] observed x, y (a recorded functor: its captured doubles, [num captured][N])
   const int* pt_start;    // [P+1] observations of point p are [pt_start[p], pt_start[p+1])
   const int* cam_start;   // [C+1] CSR into cam_obs
   const int* cam_obs;     // [N] observation indices of each camera, ascending point
@@ -84,6 +85,10 @@ size_t tri_packed_elems(int nblk);
 void launch_tri_pack(double* S, int ld, double* packed, int nblk, const int* col0, const long long* off, bool to_packed, hipStream_t s);
 void launch_bal_eval_jac(const BalDev& d, hipStream_t s);
 void launch_bal_eval_cost(const BalDev& d, hipStream_t s);
+// the same two for a recorded functor (tape.hpp); bal_tape_width == 0: its register file does not fit the LDS
+int bal_tape_width(const Tape& t);
+void launch_bal_eval_jac_tape(const BalDev& d, const TapeDevBuffers& tb, hipStream_t s);
+void launch_bal_eval_cost_tape(const BalDev& d, const TapeDevBuffers& tb, hipStream_t s);
 // the uploaded rows of the host-evaluated observations -> r / F / E planes (loss correction and column scaling as the
 // device functors' kernel applies them); cost partial sums from slot `partial_off` on.  Returns the number of slots.
 int launch_bal_host_jac(const BalDev& d, int partial_off, hipStream_t s);

@@ -24,11 +24,24 @@ bool problem_is_bal_shaped(const Problem& p, std::string* why) {
     const CostFunction* cf = b < p.rb_cost.size() ? p.rb_cost[b] : nullptr;
     const bool host_ok = p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK && cf && cf->callback && cf->num_residuals == 2 && cf->block_sizes.size() == 2 &&
                          cf->block_sizes[0] == 9 && cf->block_sizes[1] == 3;
-    if (p.rb_functor[b] != SK_FUNCTOR_SNAVELY_REPROJECTION && !host_ok) {
+    const Tape* tp = p.tape_of_block(b);
+    const bool tape_ok = tp && tp->num_residuals == 2 && tp->block_sizes.size() == 2 && tp->block_sizes[0] == 9 && tp->block_sizes[1] == 3;
+    if (p.rb_functor[b] != SK_FUNCTOR_SNAVELY_REPROJECTION && !host_ok && !tape_ok) {
       *why = "DENSE_SCHUR is implemented for residual blocks with 2 residuals over a 9- and a 3-parameter block (SnavelyReprojectionError on the "
-             "device, or any host-callback cost function of that shape); not supported: another shape";
+             "device, a recorded functor of that shape, or any host-callback cost function of that shape); not supported: another shape";
       return false;
     }
+  }
+  // one device functor per problem: the evaluation kernels are launched over all device-evaluated observations at once
+  int device_functor = -1;
+  for (size_t b = 0; b < nb; ++b) {
+    if (p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK) continue;
+    if (device_functor < 0) device_functor = p.rb_functor[b];
+    else if (device_functor != p.rb_functor[b]) { *why = "DENSE_SCHUR takes one device functor for all residual blocks (host-callback cost functions may be mixed in): not supported"; return false; }
+  }
+  if (device_functor >= kTapeFunctorBase && bal_tape_width(*p.tapes[device_functor - kTapeFunctorBase]) == 0) {
+    *why = "the recorded functor needs more registers (or captures more doubles) than the device interpreter holds: not supported";
+    return false;
   }
   for (size_t b = 1; b < nb && b < p.rb_loss.size(); ++b)
     if (p.rb_loss[b] != p.rb_loss[0]) { *why = "DENSE_SCHUR takes one loss function for all residual blocks"; return false; }
@@ -218,6 +231,8 @@ class BalSolver : public SolverBase {
   // candidate evaluation, and the Jacobian evaluation — are identical from iteration to iteration except for the trust
   // region radius (read from device memory here) and for which of the two parameter buffers is current (`parity_`), so
   // each is captured into a hipGraph once per parity and replayed.
+  bool tape_mode_ = false;      // the device functor is a recorded one (tape.hpp), interpreted by the evaluation kernels
+  TapeDevBuffers tape_dev_;
   bool graph_mode_ = false;
   int parity_ = 0;
   hipGraphExec_t g_step_[2] = {nullptr, nullptr}, g_eval_[2] = {nullptr, nullptr};
@@ -635,14 +650,18 @@ int BalSolver::setup() {
   for (int q = 0; q < P_; ++q)
     std::sort(order.begin() + pt_start[q], order.begin() + pt_start[q + 1], [&](int a, int b) { return ocam[a] != ocam[b] ? ocam[a] < ocam[b] : a < b; });
   std::vector<int> cam(N_), pt(N_);
-  std::vector<double> obs(2 * (size_t)N_);
+  // captured doubles per observation: (observedX, observedY) of SnavelyReprojectionError, or whatever a recorded functor captures
+  const Tape* tape = nullptr;
+  for (int b = 0; b < Nall && !tape; ++b) tape = p.tape_of_block(b);
+  const int nobs = tape ? tape->num_obs_consts : 2;
+  std::vector<double> obs((size_t)std::max(1, nobs) * (size_t)N_);
   for (int o = 0; o < N_; ++o) {
     const int b = order[o];
     cam[o] = ocam[b]; pt[o] = local_of[opt[b]];
     if (p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK) {  // no captured doubles on the device: the caller's object holds them
       host_obs_.push_back(o); host_cf_.push_back(p.rb_cost[b]);
     } else {
-      obs[o] = p.consts[p.rb_const_off[b]]; obs[(size_t)N_ + o] = p.consts[p.rb_const_off[b] + 1];
+      for (int k = 0; k < nobs; ++k) obs[(size_t)k * N_ + o] = p.consts[p.rb_const_off[b] + k];
     }
     if (o > 0 && pt[o] == pt[o - 1] && cam[o] == cam[o - 1]) { set_error("two residual blocks share the same (camera, point) pair: not supported by the Schur path"); return SK_ERR_UNSUPPORTED; }
   }
@@ -676,6 +695,7 @@ int BalSolver::setup() {
   // ---- device buffers ----
   hipStream_t s = stream_;
   SK_HIP_TRY(b_cam_.upload(cam, s)); SK_HIP_TRY(b_pt_.upload(pt, s)); SK_HIP_TRY(b_obs_.upload(obs, s));
+  if (tape) { tape_mode_ = true; SK_HIP_TRY(tape_dev_.upload(*tape, s)); }
   SK_HIP_TRY(b_pt_start_.upload(pt_start, s)); SK_HIP_TRY(b_cam_start_.upload(cam_start, s)); SK_HIP_TRY(b_cam_obs_.upload(cam_obs, s));
   { std::vector<int> slot(N_); for (int e = 0; e < N_; ++e) slot[cam_obs[e]] = e; SK_HIP_TRY(b_obs_slot_.upload(slot, s)); }
   SK_HIP_TRY(b_seg_start_.upload(seg_start, s)); SK_HIP_TRY(b_seg_row_.upload(seg_row, s)); SK_HIP_TRY(b_seg_col_.upload(seg_col, s));
@@ -826,7 +846,7 @@ int BalSolver::setup() {
   }
   {
     const char* e = getenv("SK_BAL_GRAPH");  // developer knob: 0 = never replay graphs
-    graph_mode_ = npad_ / 128 <= 8 && !opt_.allreduce && host_obs_.empty() && !dissected_ && !(e && !atoi(e));
+    graph_mode_ = npad_ / 128 <= 8 && !opt_.allreduce && host_obs_.empty() && !dissected_ && !tape_mode_ && !(e && !atoi(e));
     if (graph_mode_) opt_.lookahead = false;  // one stream: the whole iteration is one in-order launch sequence
   }
   SK_HIP_TRY(hipStreamSynchronize(s));
@@ -903,7 +923,9 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   const bool replay = graph && g_eval_[parity_] != nullptr;
   if (graph && !replay && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graph_mode_ = false; return evaluate_with_jacobian(first); }
   if (!replay) {
-  kt_.begin("bal_eval_jac", s); launch_bal_eval_jac(d_, s); kt_.end("bal_eval_jac", s);
+  kt_.begin("bal_eval_jac", s);
+  if (tape_mode_) launch_bal_eval_jac_tape(d_, tape_dev_, s); else launch_bal_eval_jac(d_, s);
+  kt_.end("bal_eval_jac", s);
   int nb = bal_partial_blocks(N_);
   if (d_.num_host > 0) {
     bool failed = false;
@@ -1076,7 +1098,9 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   const int gb = launch_bal_point_backsub(d_, s);
   launch_final_reduce(b_partial_.p, partial_stride_, P_ > 0 ? gb : 0, 1, 0, b_scal_.p + 9, s);
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvBacksub], s));
-  kt_.begin("bal_eval_cost", s); launch_bal_eval_cost(d_, s); kt_.end("bal_eval_cost", s);
+  kt_.begin("bal_eval_cost", s);
+  if (tape_mode_) launch_bal_eval_cost_tape(d_, tape_dev_, s); else launch_bal_eval_cost(d_, s);
+  kt_.end("bal_eval_cost", s);
   int nb_cost = bal_partial_blocks(N_);
   if (d_.num_host > 0) {
     int rc = host_callbacks(d_.xc_new, false, &candidate_failed);

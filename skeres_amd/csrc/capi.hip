@@ -273,6 +273,33 @@ sk_cost_function* sk_cost_function_new_callback(sk_evaluate_fn fn, void* user, i
   cf->c.block_sizes.assign(block_sizes, block_sizes + num_blocks);
   return cf;
 }
+sk_cost_function* sk_cost_function_new_tape(int num_residuals, const int* block_sizes, int num_blocks, const int* instructions, int num_instructions,
+                                            const double* tape_constants, int num_tape_constants, int num_registers, const int* output_operands,
+                                            const double* captured, int num_captured) {
+  SK_GUARD_BEGIN
+  // CostFunctor / SizedCostFunction validation (CORE/CostFunctor.scala:31-34, CORE/SizedCostFunction.scala:7-11), then the tape's own
+  if (num_residuals <= 0) { set_error("Nonpositive number of residuals specified: %d", num_residuals); return nullptr; }
+  if (num_blocks <= 0 || !block_sizes) { set_error("a cost function needs at least one parameter block"); return nullptr; }
+  if (num_instructions < 0 || (num_instructions > 0 && !instructions) || num_tape_constants < 0 || (num_tape_constants > 0 && !tape_constants) ||
+      !output_operands || num_captured < 0 || (num_captured > 0 && !captured)) { set_error("invalid argument"); return nullptr; }
+  auto t = std::make_shared<Tape>();
+  t->num_residuals = num_residuals; t->num_registers = num_registers; t->num_obs_consts = num_captured;
+  t->block_sizes.assign(block_sizes, block_sizes + num_blocks);
+  t->ins.resize((size_t)num_instructions);
+  for (int i = 0; i < num_instructions; ++i) t->ins[i] = TapeIns{instructions[5 * i], instructions[5 * i + 1], instructions[5 * i + 2], instructions[5 * i + 3], instructions[5 * i + 4]};
+  t->consts.assign(tape_constants, tape_constants + num_tape_constants);
+  t->out.assign(output_operands, output_operands + num_residuals);
+  const std::string why = tape_validate(*t);
+  if (!why.empty()) { set_error("%s", why.c_str()); return nullptr; }
+  sk_cost_function* cf = new (std::nothrow) sk_cost_function();
+  if (!cf) { set_error("out of host memory"); return nullptr; }
+  cf->c.functor_id = SK_FUNCTOR_TAPE; cf->c.num_residuals = num_residuals;
+  cf->c.block_sizes = t->block_sizes;
+  cf->c.consts.assign(captured, captured + num_captured);
+  cf->c.tape = t;
+  return cf;
+  SK_GUARD_END(nullptr)
+}
 void sk_cost_function_free(sk_cost_function* cf) { delete cf; }
 int sk_cost_function_num_residuals(const sk_cost_function* cf) { return cf->c.num_residuals; }
 int sk_cost_function_num_parameter_blocks(const sk_cost_function* cf) { return (int)cf->c.block_sizes.size(); }
@@ -295,7 +322,16 @@ int sk_cost_function_evaluate(const sk_cost_function* cf, double const* const* p
 #define SK_TRYN(e) do { if ((e) != hipSuccess) { set_error("HIP error in sk_cost_function_evaluate"); return -SK_ERR_HIP; } } while (0)
   SK_TRYN(dx.upload(x, s)); SK_TRYN(dc.upload(consts, s)); SK_TRYN(dxo.upload(x_off, s)); SK_TRYN(djo.upload(j_off, s));
   SK_TRYN(dr.alloc(nres)); SK_TRYN(dj.alloc(nj)); SK_TRYN(dok.alloc(1));
-  launch_single_eval(c.functor_id, dc.p, dx.p, dxo.p, dr.p, dj.p, djo.p, jacobians ? 1 : 0, mask, dok.p, s);
+  if (c.functor_id == SK_FUNCTOR_TAPE) {
+    TapeDevBuffers tb;
+    SK_TRYN(tb.upload(*c.tape, s));
+    if (!launch_single_eval_tape(tb, dc.p, dx.p, dxo.p, dr.p, dj.p, djo.p, jacobians ? 1 : 0, mask, dok.p, s)) {
+      set_error("the recorded functor needs %d registers: more than the device interpreter holds", c.tape->num_registers);
+      return -SK_ERR_UNSUPPORTED;
+    }
+  } else {
+    launch_single_eval(c.functor_id, dc.p, dx.p, dxo.p, dr.p, dj.p, djo.p, jacobians ? 1 : 0, mask, dok.p, s);
+  }
   int ok = 0;
   std::vector<double> r(nres), j(nj);
   SK_TRYN(hipMemcpy(&ok, dok.p, sizeof(int), hipMemcpyDeviceToHost));
@@ -382,7 +418,8 @@ int sk_problem_add_residual_block(sk_problem* p, const sk_cost_function* cost, c
     if (ids[q] < 0) return SK_ERR_INVALID_ARGUMENT;
     for (int t = 0; t < q; ++t) if (ids[t] == ids[q]) { set_error("duplicate parameter blocks in a residual block are not allowed"); return SK_ERR_INVALID_ARGUMENT; }
   }
-  P.rb_functor.push_back(c.functor_id); P.rb_num_residuals.push_back(c.num_residuals);
+  P.rb_functor.push_back(c.functor_id == SK_FUNCTOR_TAPE ? kTapeFunctorBase + P.intern_tape(c.tape) : c.functor_id);
+  P.rb_num_residuals.push_back(c.num_residuals);
   P.rb_const_off.push_back(P.consts.size()); P.consts.insert(P.consts.end(), c.consts.begin(), c.consts.end());
   P.rb_pidx.insert(P.rb_pidx.end(), ids.begin(), ids.end()); P.rb_pidx_off.push_back(P.rb_pidx.size());
   P.rb_cost.push_back(c.functor_id == SK_FUNCTOR_HOST_CALLBACK ? &c : nullptr);
@@ -418,6 +455,34 @@ int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const d
     P.rb_cost.push_back(nullptr);
     P.rb_loss.push_back(loss_root);
     P.num_residuals += d.num_residuals;
+  }
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+int sk_problem_add_residual_blocks_tape(sk_problem* p, const sk_cost_function* cost, int n, const double* captured, const sk_loss_function* loss,
+                                        double* const* parameter_blocks) {
+  SK_GUARD_BEGIN
+  if (!p || !cost || n < 0 || !parameter_blocks) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (cost->c.functor_id != SK_FUNCTOR_TAPE || !cost->c.tape) { set_error("not a recorded functor (sk_cost_function_new_tape)"); return SK_ERR_INVALID_ARGUMENT; }
+  const Tape& t = *cost->c.tape;
+  if (t.num_obs_consts > 0 && !captured) { set_error("the recorded functor captures %d doubles per block", t.num_obs_consts); return SK_ERR_INVALID_ARGUMENT; }
+  Problem& P = p->p;
+  const int loss_root = P.intern_loss(loss ? &loss->l : nullptr);
+  const int fid = kTapeFunctorBase + P.intern_tape(cost->c.tape), nbk = (int)t.block_sizes.size();
+  std::vector<int> ids((size_t)nbk);
+  for (int b = 0; b < n; ++b) {
+    for (int q = 0; q < nbk; ++q) {
+      ids[q] = register_block(P, parameter_blocks[(size_t)b * nbk + q], t.block_sizes[q]);
+      if (ids[q] < 0) return SK_ERR_INVALID_ARGUMENT;
+      for (int u = 0; u < q; ++u) if (ids[u] == ids[q]) { set_error("duplicate parameter blocks in a residual block are not allowed"); return SK_ERR_INVALID_ARGUMENT; }
+    }
+    P.rb_functor.push_back(fid); P.rb_num_residuals.push_back(t.num_residuals);
+    P.rb_const_off.push_back(P.consts.size());
+    if (t.num_obs_consts) P.consts.insert(P.consts.end(), captured + (size_t)b * t.num_obs_consts, captured + (size_t)(b + 1) * t.num_obs_consts);
+    P.rb_pidx.insert(P.rb_pidx.end(), ids.begin(), ids.end()); P.rb_pidx_off.push_back(P.rb_pidx.size());
+    P.rb_cost.push_back(nullptr);
+    P.rb_loss.push_back(loss_root);
+    P.num_residuals += t.num_residuals;
   }
   return SK_OK;
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -14,6 +15,7 @@
 #include "functors.hpp"
 #include "loss.hpp"
 #include "parameterization.hpp"
+#include "tape.hpp"
 
 namespace sk {
 
@@ -67,6 +69,7 @@ struct CostFunction {  // com.google.ceres.CostFunction as sized by CORE/SizedCo
   void* user = nullptr;
   int num_residuals = 0;
   std::vector<int> block_sizes;
+  std::shared_ptr<const Tape> tape;  // SK_FUNCTOR_TAPE: the recorded body (consts: the captured doubles of THIS cost function)
 };
 
 // PredefinedLossFunctions (ceres.i:159-184): a flattened expression, children before parents; empty == trivial
@@ -93,6 +96,19 @@ struct Problem {  // CeresProblem; parameter blocks identified by pointer value
   std::vector<int> rb_pidx;
   std::vector<double> consts;
   std::vector<const CostFunction*> rb_cost;  // non-null only for host-callback blocks
+  // recorded functor bodies, every distinct one once (by content: the caller may free its cost function); a tape block's
+  // rb_functor is kTapeFunctorBase + its index here
+  std::vector<std::shared_ptr<const Tape>> tapes;
+  std::unordered_map<std::string, int> tape_of;
+  int intern_tape(const std::shared_ptr<const Tape>& t) {
+    const std::string k = t->key();
+    auto it = tape_of.find(k);
+    if (it != tape_of.end()) return it->second;
+    tapes.push_back(t);
+    tape_of.emplace(k, (int)tapes.size() - 1);
+    return (int)tapes.size() - 1;
+  }
+  const Tape* tape_of_block(size_t b) const { const int f = rb_functor[b]; return f >= kTapeFunctorBase ? tapes[f - kTapeFunctorBase].get() : nullptr; }
   // loss functions: every distinct loss expression once in loss_nodes (copied: the caller may free its object);
   // rb_loss[b] = root node of block b's loss, -1 = trivial
   std::vector<LossNode> loss_nodes;
@@ -168,6 +184,14 @@ struct Summary {
   std::string device_name;
   std::string brief, full;
   void build_reports();
+};
+
+// device copy of a tape (owned by a solver, or by one sk_cost_function_evaluate)
+struct TapeDevBuffers {
+  DevBuf<TapeIns> ins; DevBuf<double> consts; DevBuf<int32_t> out; DevBuf<int> param_block, param_index;
+  TapeDev view;
+  Tape host;
+  hipError_t upload(const Tape& t, hipStream_t s);
 };
 
 const char* linear_solver_name(int t);

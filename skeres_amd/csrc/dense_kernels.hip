@@ -159,6 +159,108 @@ __global__ void single_eval_kernel(const double* consts, const double* x, const 
   }
 }
 
+// ---- recorded functors (tape.hpp) --------------------------------------------------------------------------------
+// One lane per residual block of the tape; W = 0: residuals only (T = double), else ceil(dim / W) passes of Jet<W>.
+// Dynamic LDS: the register files of the workgroup's threads.
+template <int W>
+__global__ void dense_eval_tape_kernel(DenseEvalArgs a, TapeDev t) {
+  extern __shared__ __attribute__((aligned(16))) double tape_lds[];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.count) return;
+  const int b = a.blocks[i];
+  const double* c = a.consts + a.const_off[b];
+  const int* pidx = a.pidx + a.pidx_off[b];
+  const int row0 = a.res_off[b];
+  auto param = [&](int k) { return a.x[pidx[t.param_block[k]] + t.param_index[k]]; };
+  if (W == 0) {
+    const TapeRegs<double> regs{tape_lds, (int)blockDim.x, (int)threadIdx.x};
+    double out[kTapeMaxResiduals];
+    tape_run<double>(t, c, param, 0, regs, out);
+    for (int r = 0; r < t.num_residuals; ++r) a.r[row0 + r] = out[r];
+  } else {
+    typedef Jet<(W > 0 ? W : 1)> J;
+    const TapeRegs<J> regs{tape_lds, (int)blockDim.x, (int)threadIdx.x};
+    J out[kTapeMaxResiduals];
+    for (int first = 0; first < t.dim; first += W) {
+      tape_run<J>(t, c, param, first, regs, out);
+      if (first == 0) for (int r = 0; r < t.num_residuals; ++r) a.r[row0 + r] = out[r].a;
+      for (int w = 0; w < W && first + w < t.dim; ++w) {
+        const int col = pidx[t.param_block[first + w]] + t.param_index[first + w];
+        for (int r = 0; r < t.num_residuals; ++r) a.J[(size_t)(row0 + r) * a.n + col] = out[r].v[w] * a.scale[col];
+      }
+    }
+  }
+}
+// one residual block (sk_cost_function_evaluate); thread 0 of one wave
+template <int W>
+__global__ void single_eval_tape_kernel(TapeDev t, const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
+                                        const int* jac_off, int want_jac, unsigned jac_mask, int* ok) {
+  extern __shared__ __attribute__((aligned(16))) double tape_lds[];
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  auto param = [&](int k) { return x[x_off[t.param_block[k]] + t.param_index[k]]; };
+  *ok = 1;
+  if (!want_jac) {
+    const TapeRegs<double> regs{tape_lds, (int)blockDim.x, 0};
+    double out[kTapeMaxResiduals];
+    tape_run<double>(t, consts, param, 0, regs, out);
+    for (int r = 0; r < t.num_residuals; ++r) residuals[r] = out[r];
+    return;
+  }
+  typedef Jet<W> J;
+  const TapeRegs<J> regs{tape_lds, (int)blockDim.x, 0};
+  J out[kTapeMaxResiduals];
+  // size of parameter block q: the number of parameters numbered into it
+  for (int first = 0; first < t.dim; first += W) {
+    tape_run<J>(t, consts, param, first, regs, out);
+    if (first == 0) for (int r = 0; r < t.num_residuals; ++r) residuals[r] = out[r].a;
+    for (int w = 0; w < W && first + w < t.dim; ++w) {
+      const int q = t.param_block[first + w], j = t.param_index[first + w];
+      if (!((jac_mask >> q) & 1u)) continue;
+      int nq = 0;
+      for (int k = 0; k < t.dim; ++k) nq += t.param_block[k] == q ? 1 : 0;
+      for (int r = 0; r < t.num_residuals; ++r) jac[jac_off[q] + r * nq + j] = out[r].v[w];  // row-major num_residuals x N(q)
+    }
+  }
+}
+
+template <class K>
+static void tape_allow_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+bool launch_dense_eval_tape(const TapeDevBuffers& tb, bool jac, const DenseEvalArgs& a, hipStream_t s) {
+  if (a.count <= 0) return true;
+  const int threads = 128;
+  const dim3 g((a.count + threads - 1) / threads), b(threads);
+  if (!jac) {
+    const size_t lds = tape_lds_bytes(tb.host, 0, threads);
+    if (lds > kTapeLdsBudget) return false;
+    tape_allow_lds(dense_eval_tape_kernel<0>, lds);
+    hipLaunchKernelGGL(dense_eval_tape_kernel<0>, g, b, lds, s, a, tb.view);
+    return true;
+  }
+  const int W = tape_pick_width(tb.host, threads);
+  const size_t lds = tape_lds_bytes(tb.host, W, threads);
+  switch (W) {
+    case 3: tape_allow_lds(dense_eval_tape_kernel<3>, lds); hipLaunchKernelGGL(dense_eval_tape_kernel<3>, g, b, lds, s, a, tb.view); return true;
+    case 2: tape_allow_lds(dense_eval_tape_kernel<2>, lds); hipLaunchKernelGGL(dense_eval_tape_kernel<2>, g, b, lds, s, a, tb.view); return true;
+    case 1: tape_allow_lds(dense_eval_tape_kernel<1>, lds); hipLaunchKernelGGL(dense_eval_tape_kernel<1>, g, b, lds, s, a, tb.view); return true;
+    default: return false;
+  }
+}
+bool launch_single_eval_tape(const TapeDevBuffers& tb, const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
+                             const int* jac_off, int want_jac, unsigned jac_mask, int* ok, hipStream_t s) {
+  const int threads = 64;
+  const int W = tape_pick_width(tb.host, threads);
+  if (W == 0) return false;
+  const size_t lds = tape_lds_bytes(tb.host, W, threads);
+  switch (W) {
+    case 3: tape_allow_lds(single_eval_tape_kernel<3>, lds); hipLaunchKernelGGL(single_eval_tape_kernel<3>, dim3(1), dim3(threads), lds, s, tb.view, consts, x, x_off, residuals, jac, jac_off, want_jac, jac_mask, ok); break;
+    case 2: tape_allow_lds(single_eval_tape_kernel<2>, lds); hipLaunchKernelGGL(single_eval_tape_kernel<2>, dim3(1), dim3(threads), lds, s, tb.view, consts, x, x_off, residuals, jac, jac_off, want_jac, jac_mask, ok); break;
+    default: tape_allow_lds(single_eval_tape_kernel<1>, lds); hipLaunchKernelGGL(single_eval_tape_kernel<1>, dim3(1), dim3(threads), lds, s, tb.view, consts, x, x_off, residuals, jac, jac_off, want_jac, jac_mask, ok); break;
+  }
+  return true;
+}
+
 void launch_single_eval(int functor_id, const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
                         const int* jac_off, int want_jac, unsigned jac_mask, int* ok, hipStream_t s) {
 #define SK_LAUNCH(F) hipLaunchKernelGGL((single_eval_kernel<F>), dim3(1), dim3(64), 0, s, consts, x, x_off, residuals, jac, jac_off, want_jac, jac_mask, ok)

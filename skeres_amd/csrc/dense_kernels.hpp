@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "common.hpp"
 #include "loss.hpp"
 
 namespace sk {
@@ -39,6 +40,10 @@ struct DenseLossArgs {
 void launch_dense_eval(int functor_id, bool jac, const DenseEvalArgs& a, hipStream_t s);
 void launch_dense_loss(const DenseLossArgs& a, hipStream_t s);
 void launch_dense_sum(const double* v, int m, double* out, hipStream_t s);
+// recorded functors (tape.hpp); false = the tape's register file does not fit the LDS (nothing was launched)
+bool launch_dense_eval_tape(const TapeDevBuffers& tb, bool jac, const DenseEvalArgs& a, hipStream_t s);
+bool launch_single_eval_tape(const TapeDevBuffers& tb, const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
+                             const int* jac_off, int want_jac, unsigned jac_mask, int* ok, hipStream_t s);
 void launch_single_eval(int functor_id, const double* consts, const double* x, const int* x_off, double* residuals, double* jac,
                         const int* jac_off, int want_jac, unsigned jac_mask, int* ok, hipStream_t s);
 void launch_dense_col_reduce(const double* J, const double* r, int m, int n, double* colsq, double* gs, hipStream_t s);

@@ -48,6 +48,7 @@ class DenseSolver : public SolverBase {
   std::vector<int> block_off_;
   std::map<int, std::vector<int>> by_functor_;  // functor id -> residual block ids
   std::map<int, DevBuf<int>> by_functor_dev_;
+  std::map<int, TapeDevBuffers> tapes_dev_;  // recorded functors (keys >= kTapeFunctorBase of by_functor_)
   std::vector<int> cb_blocks_;
   std::vector<int> res_off_h_;
   DevBuf<double> b_consts_, b_xa_, b_xb_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_, b_r_, b_rc_, b_J_, b_H_, b_Linv_, b_A_, b_b_, b_scal_;
@@ -120,7 +121,14 @@ int DenseSolver::setup() {
   std::vector<double> consts = p.consts; if (consts.empty()) consts.push_back(0.0);
   SK_HIP_TRY(b_consts_.upload(consts, s)); SK_HIP_TRY(b_const_off_.upload(p.rb_const_off, s));
   SK_HIP_TRY(b_pidx_off_.upload(p.rb_pidx_off, s)); SK_HIP_TRY(b_pidx_.upload(pidx, s)); SK_HIP_TRY(b_res_off_.upload(res_off_h_, s));
-  for (auto& kv : by_functor_) SK_HIP_TRY(by_functor_dev_[kv.first].upload(kv.second, s));
+  for (auto& kv : by_functor_) {
+    SK_HIP_TRY(by_functor_dev_[kv.first].upload(kv.second, s));
+    if (kv.first >= kTapeFunctorBase) {  // a recorded functor: its tape goes to the device once
+      const Tape& t = *p.tapes[kv.first - kTapeFunctorBase];
+      if (tape_pick_width(t, 128) == 0) { set_error("a recorded functor needs %d registers: more than the device interpreter holds", t.num_registers); return SK_ERR_UNSUPPORTED; }
+      SK_HIP_TRY(tapes_dev_[kv.first].upload(t, s));
+    }
+  }
   std::vector<double> x(ng_);
   for (size_t b = 0; b < p.block_size.size(); ++b) std::memcpy(&x[block_off_[b]], p.block_ptr[b], p.block_size[b] * sizeof(double));
   SK_HIP_TRY(b_xa_.upload(x, s)); SK_HIP_TRY(b_xb_.alloc(ng_));
@@ -202,7 +210,8 @@ int DenseSolver::evaluate(const double* x_dev, bool jac) {
   a.x = x_dev; a.scale = tangent_ ? b_ones_.p : b_scale_.p; a.r = jac ? b_r_.p : b_rc_.p; a.J = tangent_ ? b_Jg_.p : b_J_.p; a.n = ng_; a.fail_flag = b_fail_.p;
   for (auto& kv : by_functor_) {
     a.count = (int)kv.second.size(); a.blocks = by_functor_dev_[kv.first].p;
-    launch_dense_eval(kv.first, jac, a, stream_);
+    if (kv.first >= kTapeFunctorBase) launch_dense_eval_tape(tapes_dev_[kv.first], jac, a, stream_);
+    else launch_dense_eval(kv.first, jac, a, stream_);
   }
   return host_callbacks(x_dev, jac);
 }

@@ -1,0 +1,314 @@
+"""Recorded functors (include/skeres_amd.h: sk_cost_function_new_tape; skeres_amd/tape.py): SURVEY.md section 8 row f4,
+"expression-tape tracing of arbitrary generic functors" (CORE/CostFunctor.scala:40-51).
+
+CPU tests: the recording itself (register allocation, selects, literals) against direct evaluation of the same body,
+and the C ABI's validation.  GPU tests: the device interpreter against the oracle, the registered device functors and
+the reference's own known-answer values, one block at a time and through DENSE_QR and DENSE_SCHUR."""
+import math
+
+import numpy as np
+import pytest
+
+import skeres_amd as sk
+from skeres_amd import bal, tape as T
+from skeres_amd.examples.traced_functors import TracedExponentialResidual, TracedPowell, TracedSnavelyReprojectionError
+from skeres_amd.rotation import Jet
+
+
+# ---- a host interpreter of a tape: test infrastructure (the device one is csrc/tape.hpp) ----
+def run_tape(tape, params, captured):
+    ins, consts, nregs, outs = tape
+    regs = [None] * max(1, nregs)
+
+    def val(code):
+        kind, idx = (int(code) >> 28) & 7, int(code) & 0x0FFFFFFF
+        return (regs, params, captured, consts)[kind][idx]
+    un = {T.SQRT: math.sqrt, T.EXP: math.exp, T.LOG: math.log, T.SIN: math.sin, T.COS: math.cos, T.TAN: math.tan,
+          T.ASIN: math.asin, T.ACOS: math.acos, T.ATAN: math.atan, T.NEG: lambda v: -v, T.ABS: abs, T.MOV: lambda v: v}
+    for op, dst, a, b, c in ins:
+        with np.errstate(all="ignore"):
+            try:
+                if op in un:
+                    r = un[op](val(a))
+                elif op == T.ADD:
+                    r = val(a) + val(b)
+                elif op == T.SUB:
+                    r = val(a) - val(b)
+                elif op == T.MUL:
+                    r = val(a) * val(b)
+                elif op == T.DIV:
+                    r = float(np.float64(val(a)) / np.float64(val(b)))
+                elif op == T.ATAN2:
+                    r = math.atan2(val(a), val(b))
+                elif op == T.LT:
+                    r = 1.0 if val(a) < val(b) else 0.0
+                elif op == T.LE:
+                    r = 1.0 if val(a) <= val(b) else 0.0
+                elif op == T.SELECT:
+                    r = val(b) if val(a) != 0.0 else val(c)
+                else:
+                    raise AssertionError("opcode %d" % op)
+            except (ValueError, ZeroDivisionError):
+                r = float("nan")  # the arm a select does not take
+        regs[dst] = r
+    return [val(o) for o in outs]
+
+
+def _random_camera(rng, small_angle=False):
+    cam = np.concatenate([rng.normal(0, 0.3, 3), rng.normal(0, 1, 3), [rng.uniform(400, 1200)], [rng.normal(0, 1e-6)], [rng.normal(0, 1e-11)]])
+    if small_angle:
+        cam[:3] = 0.0
+    return cam
+
+
+def test_recording_of_the_snavely_body_reproduces_its_direct_evaluation():
+    rng = np.random.default_rng(5)
+    f = TracedSnavelyReprojectionError(3.5, -7.25)
+    tape = f.tape()
+    ins, consts, nregs, outs = tape
+    assert ins.shape[1] == 5 and nregs <= 16 and len(outs) == 2
+    assert (ins[:, 0] == T.SELECT).sum() == 3  # the three coordinates of the rotated point: both arms are on the tape
+    for trial in range(10):
+        cam, pt = _random_camera(rng, small_angle=trial < 2), rng.normal(0, 1, 3) + [0, 0, -5]
+        direct = f.apply(list(cam), list(pt))  # floats: `where` just picks
+        np.testing.assert_allclose(run_tape(tape, list(cam) + list(pt), f.captured), direct, rtol=1e-15, atol=0)
+        jets = f.apply([Jet(cam[k], k, 12) for k in range(9)], [Jet(pt[k], 9 + k, 12) for k in range(3)])  # and over Jets
+        assert abs(jets[0].real - direct[0]) <= 1e-12 * abs(direct[0])
+
+
+def test_register_allocation_reuses_registers_and_prunes_dead_values():
+    class F(sk.TracedCostFunctor):
+        def __init__(self):
+            super().__init__(1, 3)
+
+        def apply(self, x):
+            unused = T.exp(x[0]) * 3.0  # noqa: F841  never returned: must not be on the tape
+            s = x[0]
+            for _ in range(40):
+                s = s * x[1] + x[2]   # a chain: two registers suffice whatever its length
+            return [s]
+    ins, consts, nregs, outs = F().tape()
+    assert ins.shape[0] == 80 and nregs <= 2 and not (ins[:, 0] == T.EXP).any()
+    x = [0.3, 0.9, -0.2]
+    s = x[0]
+    for _ in range(40):
+        s = s * x[1] + x[2]
+    assert run_tape((ins, consts, nregs, outs), x, []) == [s]
+
+
+def test_comparisons_of_traced_values_cannot_decide_a_python_if():
+    class F(sk.TracedCostFunctor):
+        def __init__(self):
+            super().__init__(1, 1)
+
+        def apply(self, x):
+            return [x[0] if x[0] > 0.0 else -x[0]]
+    with pytest.raises(TypeError, match="where"):
+        F().tape()
+    assert T.where(2.0 > 1.0, "a", "b") == "a" and T.where(Jet(0.0, 0, 1) > 1.0, "a", "b") == "b"
+
+
+def test_the_c_abi_validates_a_tape():
+    lib = sk.lib()
+    i32, f64 = np.int32, np.float64
+
+    def new(nres, sizes, ins, consts, nregs, outs, captured=()):
+        sizes, ins, outs = np.asarray(sizes, i32), np.asarray(ins, i32).reshape(-1, 5), np.asarray(outs, i32)
+        consts, captured = np.asarray(consts, f64), np.asarray(captured, f64)
+        ip, dp = sk.api._ip, sk.api._dp
+        h = lib.sk_cost_function_new_tape(nres, sizes.ctypes.data_as(ip), len(sizes), ins.ctypes.data_as(ip), ins.shape[0],
+                                          consts.ctypes.data_as(dp) if consts.size else dp(), consts.size, nregs, outs.ctypes.data_as(ip),
+                                          captured.ctypes.data_as(dp) if captured.size else dp(), captured.size)
+        return h, lib.sk_last_error().decode()
+    P, R, K = T.PARAMETER << 28, T.REGISTER << 28, T.CONSTANT << 28
+    ok, _ = new(1, [2], [[T.ADD, 0, P | 0, P | 1, 0]], [], 1, [R | 0])
+    assert ok
+    assert lib.sk_cost_function_num_residuals(ok) == 1 and lib.sk_cost_function_parameter_block_size(ok, 0) == 2
+    lib.sk_cost_function_free(ok)
+    for args, what in [
+        ((0, [2], [], [], 0, []), "Nonpositive number of residuals"),                                     # CORE/CostFunctor.scala:31-34
+        ((1, [0], [], [], 0, [P | 0]), "Nonpositive parameter block sizes"),
+        ((1, [2], [[99, 0, P | 0, 0, 0]], [], 1, [R | 0]), "unknown opcode"),
+        ((1, [2], [[T.ADD, 0, P | 0, P | 2, 0]], [], 1, [R | 0]), "parameter index out of range"),
+        ((1, [2], [[T.ADD, 0, R | 0, P | 1, 0]], [], 1, [R | 0]), "read before it is written"),
+        ((1, [2], [[T.ADD, 1, P | 0, P | 1, 0]], [], 1, [R | 0]), "destination register out of range"),
+        ((1, [2], [[T.MUL, 0, P | 0, K | 0, 0]], [], 1, [R | 0]), "tape-constant index out of range"),
+        ((1, [2], [], [], 0, [(T.CAPTURED << 28) | 0]), "captured-constant index out of range"),
+    ]:
+        h, err = new(*args)
+        assert not h and what in err, (what, err)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+def _evaluate(cf, blocks, nres):
+    parameters = sk.RichDoubleMatrix.fromArrays(*blocks)
+    residuals = sk.DoubleArray(nres)
+    jac = sk.RichDoubleMatrix([sk.DoubleArray(nres * len(b)) for b in blocks])
+    assert cf.evaluate(parameters, residuals, jac)
+    res2 = sk.DoubleArray(nres)
+    assert cf.evaluate(parameters, res2, None)
+    np.testing.assert_allclose(res2.toArray(nres), residuals.toArray(nres), rtol=1e-14)  # cost-only branch: the same residuals (a Jet divides by multiplying with the reciprocal)
+    return residuals.toArray(nres), [jac.getRow(i).toArray(nres * len(b)).reshape(nres, len(b)) for i, b in enumerate(blocks)]
+
+
+@gpu
+def test_recorded_snavely_on_the_device_vs_oracle_and_registered_functor():
+    import oracle
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        cam = _random_camera(rng, small_angle=trial == 0)
+        if trial == 1:
+            cam[:3] = [1e-9, -2e-9, 3e-9]
+        pt, obs = rng.normal(0, 1, 3) + [0, 0, -5], rng.normal(0, 100, 2)
+        ok, r_o, j_o = oracle.evaluate(oracle.SNAVELY, obs, [cam, pt])
+        r, j = _evaluate(TracedSnavelyReprojectionError(obs[0], obs[1]).toAutoDiffCostFunction(), [cam, pt], 2)
+        np.testing.assert_allclose(r, r_o, rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(j[0], j_o[0], rtol=1e-11, atol=1e-9)
+        np.testing.assert_allclose(j[1], j_o[1], rtol=1e-11, atol=1e-9)
+        rb, jb = _evaluate(sk.SnavelyReprojectionError(obs[0], obs[1]).toAutoDiffCostFunction(), [cam, pt], 2)
+        np.testing.assert_allclose(r, rb, rtol=1e-13, atol=1e-11)
+        np.testing.assert_allclose(j[0], jb[0], rtol=1e-12, atol=1e-10)
+
+
+@gpu
+def test_recorded_versions_of_the_reference_spec_functors_give_its_values():
+    """TEST/AutodiffCostFuntionSpec.scala:14-26 (BinaryScalarCost: a x'y ... ) through a recording: the values the
+    reference's own test expects from its generic functor."""
+    class BinaryScalar(sk.TracedCostFunctor):  # :14-26: residual a - x . y  over two 2-blocks
+        def __init__(self, a):
+            super().__init__(1, 2, 2, captured=(a,))
+
+        def apply(self, x, y):
+            (a,) = self.captured_values()
+            return [x[0] * y[0] + x[1] * y[1] - a]
+    r, j = _evaluate(BinaryScalar(1.0).toAutoDiffCostFunction(), [np.array([1.0, 2.0]), np.array([3.0, 5.0])], 1)
+    rb, jb = _evaluate(sk.BinaryScalarCost(1.0).toAutoDiffCostFunction(), [np.array([1.0, 2.0]), np.array([3.0, 5.0])], 1)
+    np.testing.assert_array_equal(r, rb)
+    np.testing.assert_array_equal(j[0], jb[0])
+    np.testing.assert_array_equal(j[1], jb[1])
+    assert r[0] == 12.0 and list(j[0][0]) == [3.0, 5.0] and list(j[1][0]) == [1.0, 2.0]  # AutodiffCostFuntionSpec.scala:36-50
+
+    class Trig(sk.TracedCostFunctor):  # every opcode once, against numpy
+        def __init__(self):
+            super().__init__(3, 2)
+
+        def apply(self, x):
+            u, v = x[0], x[1]
+            return [T.sin(u) * T.cos(v) + T.tan(u) - T.log(v) / T.exp(u), T.atan2(u, v) + T.asin(u) * T.acos(u) - T.atan(v) + abs(-v) ** 3,
+                    T.where(u <= v, T.sqrt(v), -u) + v ** 0.5]
+    x = np.array([0.3, 1.7])
+    r, j = _evaluate(Trig().toAutoDiffCostFunction(), [x], 3)
+    u, v = x
+    np.testing.assert_allclose(r, [np.sin(u) * np.cos(v) + np.tan(u) - np.log(v) / np.exp(u),
+                                   np.arctan2(u, v) + np.arcsin(u) * np.arccos(u) - np.arctan(v) + v ** 3, np.sqrt(v) + np.sqrt(v)], rtol=1e-14)
+    h = 1e-6
+    for k in range(2):  # central differences of the recorded body evaluated on the host
+        xp, xm = x.copy(), x.copy()
+        xp[k] += h
+        xm[k] -= h
+        fd = (np.array(run_tape(Trig().tape(), list(xp), [])) - np.array(run_tape(Trig().tape(), list(xm), []))) / (2 * h)
+        np.testing.assert_allclose(j[0][:, k], fd, rtol=2e-8, atol=1e-9)
+
+
+@gpu
+@pytest.mark.parametrize("solver", ["DENSE_QR", "DENSE_NORMAL_CHOLESKY"])
+def test_curve_fitting_with_a_recorded_functor_follows_the_registered_one(solver):
+    """EX/CurveFitting.scala:100-133 with the ExponentialResidual body recorded instead of registered."""
+    import os
+    data = np.loadtxt(os.path.join(os.path.dirname(sk.__file__), "examples", "data", "curve_fitting_data.txt")).reshape(-1, 2)
+
+    def solve(make):
+        m, c = sk.RichDoubleArray.fromArray(np.array([0.0])), sk.RichDoubleArray.fromArray(np.array([0.0]))
+        problem, keep = sk.Problem(), []
+        loss = sk.PredefinedLossFunctions.trivialLoss()
+        for x, y in data:
+            keep.append(make(x, y).toAutoDiffCostFunction())
+            problem.addResidualBlock(keep[-1], loss, m, c)
+        o = sk.Solver.Options()
+        o.setLinearSolverType(getattr(sk.LinearSolverType, solver))
+        o.setMaxNumIterations(25)
+        s = sk.Solver.Summary()
+        sk.ceres.solve(o, problem, s)
+        return m.toArray(1)[0], c.toArray(1)[0], s
+    m1, c1, s1 = solve(TracedExponentialResidual)
+    m0, c0, s0 = solve(sk.ExponentialResidual)
+    assert len(s1.iterations()) == len(s0.iterations())
+    for a, b in zip(s1.iterations(), s0.iterations()):
+        assert abs(a["cost"] - b["cost"]) <= 1e-12 * b["cost"]
+    assert abs(m1 - m0) <= 1e-10 and abs(c1 - c0) <= 1e-10
+    assert abs(m1 - 0.3) < 0.05 and abs(c1 - 0.1) < 0.05  # the values the data were generated from (EX/CurveFitting.scala:12-15)
+
+
+@gpu
+def test_powell_with_one_recorded_functor_over_four_blocks():
+    """EX/Powell.scala:14-91: the four residuals as one recorded functor over four 1-blocks (a 4 x 4 Jacobian in two
+    passes of three and one derivative slots)."""
+    x = [sk.RichDoubleArray.fromArray(np.array([v])) for v in (3.0, -1.0, 0.0, 1.0)]
+    problem = sk.Problem()
+    cf = TracedPowell().toAutoDiffCostFunction()
+    problem.addResidualBlock(cf, None, *x)
+    o = sk.Solver.Options()
+    o.setLinearSolverType(sk.LinearSolverType.DENSE_QR)
+    o.setMaxNumIterations(100)
+    s = sk.Solver.Summary()
+    sk.ceres.solve(o, problem, s)
+    assert s.initialCost() == pytest.approx(107.5) and s.finalCost() < 1e-10
+    assert all(abs(v.toArray(1)[0]) < 1e-2 for v in x)
+
+
+@gpu
+@pytest.mark.parametrize("loss_spec", [None, ("huber", 2.0)])
+def test_recorded_snavely_under_dense_schur_follows_the_device_functor_and_the_oracle(loss_spec):
+    """SURVEY section 8 row f4 / VERDICT r01 missing #2: a user's (9, 3) -> 2 functor enters DENSE_SCHUR at device speed —
+    its recorded body interpreted by the evaluation kernels, everything downstream unchanged."""
+    import oracle
+    from test_gpu_parity import sk_loss, solve_bal_gpu
+    C, P, N = 16, 200, 900
+    prob = bal.generate(C, P, N, seed=23)
+    x_dev, s_dev = solve_bal_gpu(prob, loss=sk_loss(loss_spec) if loss_spec else None)
+    x_cpu, so = oracle.solve_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR), loss=loss_spec)
+    params = sk.RichDoubleArray.fromArray(prob.parameters)
+    problem = sk.Problem()
+    loss = sk_loss(loss_spec) if loss_spec else sk.PredefinedLossFunctions.trivialLoss()
+    offs = np.stack([9 * prob.camera_index.astype(np.int64), 9 * C + 3 * prob.point_index.astype(np.int64)], axis=1)
+    problem.addResidualBlocksTraced(TracedSnavelyReprojectionError(0.0, 0.0), prob.observations, loss, params, offs)
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    a, b = summary.iterations(), s_dev.iterations()
+    assert len(a) == len(b)
+    for u, v in zip(a, b):
+        assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
+    for k in range(min(5, len(a), so.num_logged)):
+        assert abs(a[k]["cost"] - so.iterations[k].cost) <= 1e-10 * so.iterations[k].cost
+    np.testing.assert_allclose(params.toArray(prob.num_parameters), x_dev, atol=1e-7)
+
+
+@gpu
+def test_recorded_functor_at_full_size_matches_the_device_functor_step():
+    """Ladybug-1723 shape: one LM iteration with the recorded body against the registered one."""
+    from skeres_amd import bal as B
+    prob = B.generate_named("ladybug-1723-156502", seed=1723, perturb=(5e-2, 5e-1, 5e-1))
+    costs = []
+    for traced in (False, True):
+        params = sk.RichDoubleArray.fromArray(prob.parameters)
+        problem = sk.Problem()
+        offs = np.stack([9 * prob.camera_index.astype(np.int64), 9 * prob.num_cameras + 3 * prob.point_index.astype(np.int64)], axis=1)
+        if traced:
+            problem.addResidualBlocksTraced(TracedSnavelyReprojectionError(0.0, 0.0), prob.observations, None, params, offs)
+        else:
+            problem.addResidualBlocks(sk.SnavelyReprojectionError.FUNCTOR_ID, prob.observations, None, params, offs)
+        o = sk.Solver.Options()
+        o.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+        o.setMaxNumIterations(2)
+        s = sk.Solver.Summary()
+        sk.ceres.solve(o, problem, s)
+        costs.append([it["cost"] for it in s.iterations()])
+    assert len(costs[0]) == len(costs[1]) >= 2
+    for u, v in zip(costs[1], costs[0]):
+        assert abs(u - v) <= 1e-10 * v
