@@ -633,6 +633,16 @@ class TracedCostFunctor(HostAutoDiffCostFunctor):
             self._tape = _tape.record(self, self.N, len(self.captured))
         return self._tape
 
+    def withCaptured(self, *captured):
+        """The same functor around other captured doubles (another observation): shares this one's recording."""
+        import copy
+        if len(captured) != len(self.captured):
+            raise ValueError("the functor captures %d doubles, %d given" % (len(self.captured), len(captured)))
+        self.tape()
+        g = copy.copy(self)
+        g.captured = tuple(float(c) for c in captured)
+        return g
+
     def toAutoDiffCostFunction(self):
         return TracedCostFunction(self)
 

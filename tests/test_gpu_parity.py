@@ -1142,6 +1142,10 @@ def test_example_programs_end_to_end(tmp_path, capfd):  # capfd: the progress ta
     out = capfd.readouterr().out
     assert "Loading BalProblem from" in out and " done" in out and "DENSE_SCHUR" in out and "Termination" in out
     assert simple_bundle_adjuster.main(["prog"]) == 1  # usage
+    assert simple_bundle_adjuster.main(["prog", str(path), "--recorded"]) == 0  # the same with the functor body recorded (tape.py)
+    rec = capfd.readouterr().out
+    final = [ln for ln in out.splitlines() if ln.startswith("Final   ")]  # the cost table of the full report
+    assert final and final[-1:] == [ln for ln in rec.splitlines() if ln.startswith("Final   ")]
     # the small examples: HelloWorld (autodiff on the device), HelloWorldNumericDiff and PowellAnalytic (host cost functions)
     from skeres_amd.examples import hello_world, hello_world_numeric_diff, powell_analytic
     assert hello_world.main() == pytest.approx(10.0, abs=1e-6)
