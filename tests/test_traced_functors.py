@@ -290,6 +290,47 @@ def test_recorded_snavely_under_dense_schur_follows_the_device_functor_and_the_o
 
 
 @gpu
+def test_recorded_and_host_callback_blocks_mix_under_dense_schur():
+    """Every third block through the director path (the caller's Evaluate on the host), the others through a recording:
+    the trajectory of the registered device functor."""
+    from test_gpu_parity import _host_snavely_functor, solve_bal_gpu
+    HostSnavely = _host_snavely_functor()
+    C, P, N = 8, 60, 260
+    prob = bal.generate(C, P, N, seed=17)
+    x_dev, s_dev = solve_bal_gpu(prob)
+    params = sk.RichDoubleArray.fromArray(prob.parameters)
+    problem, keep = sk.Problem(), []
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    recorded = TracedSnavelyReprojectionError(0.0, 0.0)
+    for i in range(N):
+        ox, oy = prob.observations[i]
+        keep.append((HostSnavely(ox, oy) if i % 3 == 0 else recorded.withCaptured(ox, oy)).toAutoDiffCostFunction())
+        problem.addResidualBlock(keep[-1], loss, params.slice(9 * int(prob.camera_index[i])), params.slice(9 * C + 3 * int(prob.point_index[i])))
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    a, b = summary.iterations(), s_dev.iterations()
+    assert len(a) == len(b)
+    for u, v in zip(a, b):
+        assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
+    np.testing.assert_allclose(params.toArray(prob.num_parameters), x_dev, atol=1e-7)
+    # two different recorded bodies in one DENSE_SCHUR problem are refused, not silently solved another way
+    class Other(sk.TracedCostFunctor):
+        def __init__(self):
+            super().__init__(2, 9, 3)
+
+        def apply(self, cam, X):
+            return [cam[0] * X[0] - 1.0, cam[1] * X[1] + 2.0]
+    problem2, p2 = sk.Problem(), sk.RichDoubleArray.fromArray(prob.parameters)
+    k1, k2 = recorded.withCaptured(0.1, 0.2).toAutoDiffCostFunction(), Other().toAutoDiffCostFunction()
+    problem2.addResidualBlock(k1, loss, p2.slice(0), p2.slice(9 * C))
+    problem2.addResidualBlock(k2, loss, p2.slice(9), p2.slice(9 * C + 3))
+    with pytest.raises(sk.SkeresError, match="one device functor"):
+        sk.ceres.solve(options, problem2, sk.Solver.Summary())
+
+
+@gpu
 def test_recorded_functor_at_full_size_matches_the_device_functor_step():
     """Ladybug-1723 shape: one LM iteration with the recorded body against the registered one."""
     from skeres_amd import bal as B
