@@ -90,10 +90,15 @@ hipError_t TapeDevBuffers::upload(const Tape& t, hipStream_t s) {
   return hipSuccess;
 }
 
-// W derivative slots per pass for a register file of `threads` threads: the widest of 3, 2, 1 that fits the LDS budget;
+// W derivative slots per pass for a register file of `threads` threads: the widest of 3, 2, 1 that leaves room for TWO
+// workgroups per CU (the interpreter is bound by LDS latency: Ladybug-1723, 11 registers, 256 threads — W = 3, one
+// workgroup per CU, 1.28 ms; W = 2, two, 1.08 ms; W = 1, three, 1.92 ms), else the widest that fits at all;
 // 0 = not even one slot fits (too many registers)
 int tape_pick_width(const Tape& t, int threads) {
-  for (int W = 3; W >= 1; --W) if (tape_lds_bytes(t, W, threads) <= kTapeLdsBudget) return W;
+  static const int cap = getenv("SK_TAPE_WIDTH") ? atoi(getenv("SK_TAPE_WIDTH")) : 3;  // developer knob
+  const int top = cap < 1 ? 1 : (cap > 3 ? 3 : cap);
+  for (int W = top; W >= 1; --W) if (tape_lds_bytes(t, W, threads) <= kTapeLdsBudget / 2) return W;
+  for (int W = top; W >= 1; --W) if (tape_lds_bytes(t, W, threads) <= kTapeLdsBudget) return W;
   return 0;
 }
 
