@@ -214,6 +214,34 @@ def test_recorded_versions_of_the_reference_spec_functors_give_its_values():
 
 
 @gpu
+def test_degenerate_recordings_and_partial_jacobian_requests():
+    """A body that returns its arguments, a literal and a captured double untouched records NO instruction; and
+    evaluate() with some Jacobian blocks not asked for (a null row, CORE/AutodiffCostFunction.scala:113-130) leaves them alone."""
+    class Passthrough(sk.TracedCostFunctor):
+        def __init__(self):
+            super().__init__(4, 2, 1, captured=(7.5,))
+
+        def apply(self, x, y):
+            (c,) = self.captured_values()
+            return [x[1], y[0], 3.25, c]
+    f = Passthrough()
+    ins, consts, nregs, outs = f.tape()
+    assert ins.shape[0] == 0 and nregs == 0 and list(consts) == [3.25]
+    cf = f.toAutoDiffCostFunction()
+    x, y = np.array([1.5, -2.0]), np.array([4.0])
+    r, j = _evaluate(cf, [x, y], 4)
+    assert list(r) == [-2.0, 4.0, 3.25, 7.5]
+    np.testing.assert_array_equal(j[0], [[0, 1], [0, 0], [0, 0], [0, 0]])
+    np.testing.assert_array_equal(j[1], [[0], [1], [0], [0]])
+    # only the second block's Jacobian is asked for
+    parameters = sk.RichDoubleMatrix.fromArrays(x, y)
+    residuals, j1 = sk.DoubleArray(4), sk.DoubleArray(4)
+    jac = sk.RichDoubleMatrix([None, j1])
+    assert cf.evaluate(parameters, residuals, jac)
+    assert list(j1.toArray(4)) == [0.0, 1.0, 0.0, 0.0] and list(residuals.toArray(4)) == [-2.0, 4.0, 3.25, 7.5]
+
+
+@gpu
 @pytest.mark.parametrize("solver", ["DENSE_QR", "DENSE_NORMAL_CHOLESKY"])
 def test_curve_fitting_with_a_recorded_functor_follows_the_registered_one(solver):
     """EX/CurveFitting.scala:100-133 with the ExponentialResidual body recorded instead of registered."""
