@@ -58,7 +58,7 @@ constexpr int gemm_lds_doubles(int kBKT, int kTM, int kTN) { return 2 * (kTM + k
 template <int kMode, int kShape, int kBKT, int kPF, int kTM, int kTN>
 __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
                                                  int tiles_m, int skip, int main_t = 0x7fffffff, int jump_t = 0, int main_n = 0x7fffffff,
-                                                 int jump_n = 0, int block_id = -1) {
+                                                 int jump_n = 0, int block_id = -1, int* first_column_done = nullptr) {
   constexpr int mode = kMode;
   constexpr int kLdT = kBKT + 2;            // LDS row stride in doubles
   constexpr int kChA = kTM * kBKT / 512;    // 16-byte chunks per thread and stage, A operand
@@ -68,6 +68,7 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ld
   static_assert(kChA >= 1 && kChB >= 1, "tile too small for 256 staging threads");
   constexpr int kShBuf = (kTM + kTN) * kLdT;  // shp: 2 * kShBuf doubles of LDS (gemm_lds_doubles), 16-byte aligned
   int ti, tj;
+  bool first_column = false;  // kShape 2: a tile of the first block column of the enumeration (see the epilogue)
   if (kShape == 1) {
     const int b = blockIdx.x + skip;  // lower-triangular enumeration
     int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
@@ -91,6 +92,7 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ld
     while ((r + 1) * (r + 2) / 2 <= k) ++r;
     while (r * (r + 1) / 2 > k) --r;
     tj = T - 1 - r;
+    first_column = tj == 0;
     ti = (T - 1 - (k - r * (r + 1) / 2)) * kSub + w % kSub;
     if (ti >= main_t) ti += jump_t;
     if (tj >= main_n) tj += jump_n;
@@ -191,6 +193,22 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ld
 #undef SK_LOAD_STAGE
 #undef SK_STORE_STAGE
   const double sgn = mode == 0 ? -1.0 : 1.0;
+  if (kShape == 2 && first_column_done && first_column) {
+    // The first block column of a trailing SYRK under the resident chain is all the NEXT column launch needs of it
+    // (next(j+1) updates block column j+2, the first one syrk(j) touches): its tiles are written through to memory and
+    // counted, and that launch waits for the count instead of the whole SYRK's completion (marker kernel and all).
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < kNT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __hip_atomic_store(&Cg[(long)(crow + mt * 16 + 4 * i) * ldc + ccol + nt * 16], sgn * acc[mt][nt][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(first_column_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
@@ -213,9 +231,9 @@ __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, lo
 // 30-50 us however few tiles there are (load 128 KB of C, eight K-steps, store 128 KB); 32-row tiles are four
 // times as many workgroups, each a quarter as long, and the whole launch fits in two rounds.
 __global__ __launch_bounds__(256, 2) void syrk_trailing_thin_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tiles_m, int main_t,
-                                                                        int jump_t, int main_n, int jump_n) {
+                                                                        int jump_t, int main_n, int jump_n, int* first_column_done) {
   SK_GEMM_LDS(16, 32, 128)
-  gemm_nt_f64_body<0, 2, 16, 2, 32, 128>(sh, C, ldc, A, lda, A, lda, K, tiles_m, 0, main_t, jump_t, main_n, jump_n);
+  gemm_nt_f64_body<0, 2, 16, 2, 32, 128>(sh, C, ldc, A, lda, A, lda, K, tiles_m, 0, main_t, jump_t, main_n, jump_n, -1, first_column_done);
 }
 // Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
 // transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
@@ -786,7 +804,7 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 // resident before the first column launch, and every wait gives up after kChainTimeoutTicks (then sets
 // the abort flag, which ends every other wait, and *info): the grid always drains.
 // ---------------------------------------------------------------------------
-enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncHeader = 8 };  // then diag_ready[maxblk], x_ready[maxblk]
+enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncSyrkColumn = 3, kSyncHeader = 8 };  // then diag_ready[maxblk], x_ready[maxblk]
 constexpr long long kChainTimeoutTicks = 100000000;  // 1 s of the 100 MHz wall clock (a block column takes 40 us: 25 000 times that)
 
 // developer timeline (SK_CHAIN_STAMPS=<file>): wall-clock stamps of the server and of tile 0 of every column launch
@@ -910,7 +928,7 @@ __device__ __forceinline__ long crit_tile_off(long ldc, int i) {
 // Xs: 128 x 128 scratch.  X(j+1,j) cannot be formed in place tile by tile (every column tile reads whole rows of
 // S(j+1,j)): the tiles go to Xs, which next(j) reads, and into S(j+1,j) once all 16 are known to have loaded theirs.
 __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld, int j, const double* Linv_j, int tiles_m, int main_t, int jump_t,
-                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int* info) {
+                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info) {
   __shared__ __attribute__((aligned(16))) double sh[2 * 32 * kCritLd];
   static_assert(2 * 32 * kCritLd >= gemm_lds_doubles(16, 32, 128), "LDS of the thin tiles");
   __shared__ int ok_s;
@@ -949,7 +967,8 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
   }
   if (stamp) SK_CHAIN_STAMP(j, 4)
   if (threadIdx.x == 0)
-    ok_s = (chain_wait(x_ready, ncrit, sync + kSyncAbort) && chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort)) ? 1 : 0;
+    ok_s = (chain_wait(x_ready, ncrit, sync + kSyncAbort) && chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort) &&
+            chain_wait(sync + kSyncSyrkColumn, column_need, sync + kSyncAbort)) ? 1 : 0;
   __syncthreads();
   if (!ok_s) { if (threadIdx.x == 0) *info = 2; return; }
   SK_CHAIN_ACQUIRE_ALL
@@ -1057,6 +1076,7 @@ static const size_t g_potrf_lds = (size_t)(18 * kBlk + 192 + 4) * sizeof(double)
 size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
 static std::vector<hipStream_t> g_orphan_streams;  // streams of a device whose queue set could not be completed: kept, never destroyed
+static int g_early_column = 1;  // developer knob SK_CHAIN_EARLY_COLUMN=0: a resident column launch waits for the whole SYRK before it (marker kernel)
 static int g_thin_grid = 512;  // panel launches of at most this many 32-row workgroups use the 32 x 128 kernels (developer knob SK_THIN_GRID)
 static int g_ext_events = 1;  // events on the producing kernel's own dispatch (developer knob SK_LA_EXT_EVENTS=0: separate records)
 static unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;  // developer knob SK_LA_SYSTEM_FENCE=1: default fences
@@ -1069,6 +1089,7 @@ hipError_t cholesky_init() {
   if (const char* e = getenv("SK_TAIL_GROUP")) g_tail_group = atoi(e);
   if (const char* e = getenv("SK_THIN_GRID")) g_thin_grid = atoi(e);
   if (const char* e = getenv("SK_THIN_SYRK")) g_thin_syrk_tiles = atoi(e);
+  if (const char* e = getenv("SK_CHAIN_EARLY_COLUMN")) g_early_column = atoi(e);
   if (const char* e = getenv("SK_LA_SYSTEM_FENCE")) { if (atoi(e)) g_event_flags = hipEventDisableTiming; }
   if (const char* e = getenv("SK_LA_EXT_EVENTS")) g_ext_events = atoi(e);
   if (const char* e = getenv("SK_CHOL_CHAIN_SERVER")) g_chain_server = atoi(e);
@@ -1696,6 +1717,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   if (!is_resident(0) && ncols > 0) panel(gb[0], gb[1]);
   hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
   int seq = 0;                     // SYRK completions announced to the chain so far (chain_marker_kernel)
+  int col_seq = 0;                 // ... and first-column workgroups of SYRKs that announce themselves (syrk_trailing_thin_f64_kernel)
   for (int g = 0; g + 1 < ngroups; ++g) {
     const int k0 = gb[g], k1 = gb[g + 1];
     if (k0 >= ncols) break;  // (a partial factorisation: the border's pseudo-groups)
@@ -1724,7 +1746,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       const int ncrit = (rn.main > 0 || rn.jump == 0) ? 16 : 0;
       hipEvent_t col_done = Tb > 0 ? ctx->event(ev++) : nullptr;
       hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, col_done, 0, S, ld, k0,
-                            (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, info);
+                            (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, info);
       if (col_done) (void)hipStreamWaitEvent(sb, col_done, 0);
     } else {
       // panel(g) is final: syrk(g) may start (after syrk(g-1))
@@ -1750,18 +1772,25 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       hipEvent_t t_start = nullptr, t_stop = nullptr;
       if (kt) kt->pair("gemm_syrk", &t_start, &t_stop);
       hipEvent_t stop_ev = t_stop ? t_stop : (record ? ctx->event(ev++) : nullptr);
-      if (Tb <= g_thin_syrk_tiles)
+      // What the next column launch waits for when it is resident: the FIRST block column of this SYRK, counted by its
+      // own workgroups as they finish (the 32-row tiling: 4 Tb of them, enumerated first) — or, with the 128-row tiling,
+      // the whole SYRK, announced by a marker kernel behind it.
+      // (fault injection for tests: SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds what that column's launch
+      // waits for, once per process — the wait times out, and the factorisation must be reported as lost: info = 2)
+      static int withhold = getenv("SK_CHAIN_TEST_WITHHOLD_MARKER") ? atoi(getenv("SK_CHAIN_TEST_WITHHOLD_MARKER")) : -1;
+      bool withheld = false;
+      if (next_resident && withhold >= 0 && k1 == withhold && !ctx->dq->tuning) { withhold = -1; withheld = true; }
+      const bool thin = Tb <= g_thin_syrk_tiles, by_column = next_resident && thin && g_early_column;
+      if (thin)
         hipExtLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(2 * Tb * (Tb + 1)), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main,
-                              4 * rs.jump, rs.main, rs.jump);
+                              4 * rs.jump, rs.main, rs.jump, by_column && !withheld ? sync + kSyncSyrkColumn : (int*)nullptr);
       else
         hipExtLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
-      if (next_resident) {
+      if (by_column) {
+        col_seq += 4 * Tb;
+      } else if (next_resident) {
         ++seq;
-        // (fault injection for tests: SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds the marker that column's launch
-        // waits for, once per process — the wait times out, and the factorisation must be reported as lost: info = 2)
-        static int withhold = getenv("SK_CHAIN_TEST_WITHHOLD_MARKER") ? atoi(getenv("SK_CHAIN_TEST_WITHHOLD_MARKER")) : -1;
-        if (withhold >= 0 && k1 == withhold && !ctx->dq->tuning) withhold = -1;
-        else hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, seq);
+        if (!withheld) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, seq);
       }
       if (record) syrk_done = stop_ev;
     }
