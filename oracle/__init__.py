@@ -111,6 +111,7 @@ def lib():
         L.or_parameterization_local_size.argtypes = [C.c_int, C.c_int, C.c_int]
         L.or_parameterization_plus.argtypes = [C.c_int, C.c_int, ip, C.c_int, dp, dp, dp]
         L.or_parameterization_jacobian.argtypes = [C.c_int, C.c_int, ip, C.c_int, dp, dp]
+        L.or_dense_rows_cost.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, dp]
         L.or_cholesky_lower.argtypes = [dp, C.c_int, C.c_int]
         L.or_cholesky_solve.argtypes = [dp, C.c_int, dp]
         L.or_cholesky_lower_envelope.argtypes = [dp, C.c_int, C.c_int, ip]
@@ -382,6 +383,17 @@ def bal_evaluate(C_, P_, cam_idx, pt_idx, obs, x, jacobians=True):
     if jacobians:
         return r.reshape(n, 2), F.reshape(n, 2, 9), E.reshape(n, 2, 3), cost.value
     return r.reshape(n, 2), None, None, cost.value
+
+
+def dense_rows_cost(consts, x, num_threads=0):
+    """1/2 sum r^2 of the dense rows (functor SYNTH_TANH_ROW; consts [m, 3]) at x — cost-only, threaded, no Jacobian."""
+    consts = np.ascontiguousarray(consts, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = C.c_double(0.0)
+    rc = lib().or_dense_rows_cost(_dp(consts), consts.shape[0], _dp(x), x.shape[0], num_threads, C.byref(out))
+    if rc:
+        raise RuntimeError("dense-row evaluation failed")
+    return out.value
 
 
 def cholesky_lower(A, num_threads=1, last_row=None):

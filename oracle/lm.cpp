@@ -876,6 +876,31 @@ int or_bal_reduced_system(int C, int P, int N, const int* cam_idx, const int* pt
   return 0;
 }
 
+// cost 1/2 sum r_i^2 of m dense rows (kSynthTanhRow; consts: m x 3) at x — the cost-only branch of
+// CORE/AutodiffCostFunction.scala:80-93 over every residual block, without the m x n Jacobian a solve would hold
+// (BASELINE.json config 5 at full size: 80 GB).  Rows in fixed chunks of 1024, chunk sums added in chunk order.
+int or_dense_rows_cost(const double* consts, int m, const double* x, int n, int num_threads, double* cost) {
+  int nt = num_threads;
+  if (nt <= 0) nt = omp_get_max_threads();
+  const int chunks = (m + 1023) / 1024;
+  std::vector<double> part((size_t)chunks, 0.0);
+  int bad = 0;
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 4) reduction(+ : bad)
+  for (int c = 0; c < chunks; ++c) {
+    double s = 0.0;
+    for (int i = c * 1024; i < m && i < (c + 1) * 1024; ++i) {
+      double r = 0.0;
+      if (!oracle::synth_tanh_row_evaluate(consts + 3 * (size_t)i, x, n, &r, nullptr)) ++bad;
+      s += r * r;
+    }
+    part[c] = s;
+  }
+  double total = 0.0;
+  for (int c = 0; c < chunks; ++c) total += part[c];
+  *cost = 0.5 * total;
+  return bad ? 1 : 0;
+}
+
 int or_cholesky_lower(double* A, int n, int num_threads) { return cholesky_lower_inplace(A, n, n, num_threads); }
 int or_cholesky_lower_envelope(double* A, int n, int num_threads, const int* last_row) { return cholesky_lower_inplace(A, n, n, num_threads, last_row); }
 void or_cholesky_solve_envelope(const double* L, int n, double* b, const int* last_row) { cholesky_solve_lower(L, n, n, b, last_row); }

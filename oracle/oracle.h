@@ -84,6 +84,8 @@ int or_bal_evaluate(int C, int P, int N, const int* cam_idx, const int* pt_idx, 
                     const double* x, double* r, double* F, double* E, double* cost);
 int or_bal_reduced_system(int C, int P, int N, const int* cam_idx, const int* pt_idx, const double* obs,
                           const double* x, const double* D, int add_Dc, double* S, double* rhs);
+/* cost of m dense rows (functor 10, consts m x 3 = seed, row, y) at x: cost-only evaluation, no Jacobian */
+int or_dense_rows_cost(const double* consts, int m, const double* x, int n, int num_threads, double* cost);
 int or_cholesky_lower(double* A, int n, int num_threads);
 void or_cholesky_solve(const double* L, int n, double* b);
 /* last_row: n entries, non-decreasing, last_row[j] >= j (column envelope) */

@@ -88,6 +88,22 @@ void bal_partition_points(const std::vector<int>& opt, int num_points, int world
 
 namespace {
 
+// A stream that is capturing when an error makes the enqueueing function return early would fail every later call with
+// a capture error instead of the real one: end and discard the capture, and stop replaying graphs for this solver.
+struct CaptureGuard {
+  hipStream_t s; bool active; bool* graph_mode;
+  CaptureGuard(hipStream_t st, bool on, bool* gm) : s(st), active(on), graph_mode(gm) {}
+  void release() { active = false; }
+  ~CaptureGuard() {
+    if (!active) return;
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(s, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    *graph_mode = false;
+  }
+};
+
 class BalSolver : public SolverBase {
  public:
   BalSolver(const Options& o, Problem* p) : SolverBase(o, p) {}
@@ -460,9 +476,27 @@ int BalSolver::setup() {
   C_ = (int)cam_block_.size(); P_total_ = (int)pt_block_.size();
   n_ = 9 * C_; rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
   SK_HIP_TRY(cholesky_init());
+  {
+    // Launch-bound problems replay their iteration as a hipGraph on ONE stream (below): decided before the look-ahead
+    // context exists, so that a reduced system of a few blocks pays neither the queue trial nor its 134 MB of scratch.
+    const char* e = getenv("SK_BAL_GRAPH");  // developer knob: 0 = never replay graphs
+    bool host_or_tape = false;
+    for (size_t b = 0; b < p.rb_functor.size() && !host_or_tape; ++b) host_or_tape = p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK || p.tape_of_block(b) != nullptr;
+    graph_mode_ = npad_ / 128 <= 8 && !opt_.allreduce && !host_or_tape && opt_.dissection != SK_DISSECTION_ON && !getenv("SK_DISSECT_AT") && !(e && !atoi(e));
+    if (graph_mode_) opt_.lookahead = false;  // one stream: the whole iteration is one in-order launch sequence
+  }
   if (opt_.lookahead && chol_ctx_.init() != hipSuccess) {  // CU-masked streams unavailable: plain in-order factorisation
     (void)hipGetLastError();
     opt_.lookahead = false;
+  }
+  if (opt_.allreduce && opt_.world > 1) {
+    // the ranks must factor by ONE plan and take ONE distribution decision: a rank without CU-masked streams (no
+    // look-ahead, hence no resident chain and no dissection) takes every rank there
+    SK_HIP_TRY(b_small_.alloc(2 * 9 * (size_t)C_ + 64 + 16 * (size_t)opt_.world));
+    double off[1] = {opt_.lookahead ? 0.0 : 1.0};
+    int rc = gather_rank_scalars_signed(off, 1);
+    if (rc) return rc;
+    if (off[0] > 0.0) opt_.lookahead = false;
   }
   std::vector<int> env_for_model;  // the envelope of the chosen order (whether or not it is then used)
   // ---- camera order + block envelope of the reduced system (all ranks' observations: the all-reduced S has the union structure).
@@ -844,11 +878,7 @@ int BalSolver::setup() {
     h_cam_ = cam; h_pt_ = pt;
     host_x_.resize(nx); host_rows_h_.resize(host_obs_.size() * (size_t)kHostRow);
   }
-  {
-    const char* e = getenv("SK_BAL_GRAPH");  // developer knob: 0 = never replay graphs
-    graph_mode_ = npad_ / 128 <= 8 && !opt_.allreduce && host_obs_.empty() && !dissected_ && !tape_mode_ && !(e && !atoi(e));
-    if (graph_mode_) opt_.lookahead = false;  // one stream: the whole iteration is one in-order launch sequence
-  }
+  graph_mode_ = graph_mode_ && host_obs_.empty() && !dissected_ && !tape_mode_;
   SK_HIP_TRY(hipStreamSynchronize(s));
   if (opt_.allreduce) {
     // every rank derived the camera order and the envelope for itself (from rank-invariant data): they must be the same
@@ -922,6 +952,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   const bool graph = graph_ok() && !first;  // (iteration 0 also derives the Jacobi scaling: its own sequence, run once)
   const bool replay = graph && g_eval_[parity_] != nullptr;
   if (graph && !replay && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graph_mode_ = false; return evaluate_with_jacobian(first); }
+  CaptureGuard capture(s, graph && !replay, &graph_mode_);  // an early return below must not leave the stream capturing
   if (!replay) {
   kt_.begin("bal_eval_jac", s);
   if (tape_mode_) launch_bal_eval_jac_tape(d_, tape_dev_, s); else launch_bal_eval_jac(d_, s);
@@ -973,7 +1004,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   if (graph) {
-    if (!replay) { int rc = finish_capture(s, &g_eval_[parity_]); if (rc) return rc; if (!graph_mode_) return evaluate_with_jacobian(first); }
+    if (!replay) { capture.release(); int rc = finish_capture(s, &g_eval_[parity_]); if (rc) return rc; if (!graph_mode_) return evaluate_with_jacobian(first); }
     SK_HIP_TRY(hipGraphLaunch(g_eval_[parity_], s));
   }
   SK_HIP_TRY(hipEventRecord(ev_[kEvJac], s));
@@ -1017,6 +1048,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     h_scal_[32] = radius;  // pinned: the captured host-to-device copy reads it when the graph RUNS
     if (!replay && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graph_mode_ = false; return try_step_once(radius, valid, mcc, new_cost, step_norm, chain_lost); }
   }
+  CaptureGuard capture(s, graph && !replay, &graph_mode_);
   if (!replay) {
   if (graph) {
     SK_HIP_TRY(hipMemcpyAsync(b_scal_.p + 12, h_scal_ + 32, sizeof(double), hipMemcpyHostToDevice, s));
@@ -1114,7 +1146,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 17, b_info_.p, sizeof(int), hipMemcpyDeviceToHost, s));
   }
   if (graph) {
-    if (!replay) { int rc = finish_capture(s, &g_step_[parity_]); if (rc) return rc; if (!graph_mode_) return try_step_once(radius, valid, mcc, new_cost, step_norm, chain_lost); }
+    if (!replay) { capture.release(); int rc = finish_capture(s, &g_step_[parity_]); if (rc) return rc; if (!graph_mode_) return try_step_once(radius, valid, mcc, new_cost, step_norm, chain_lost); }
     SK_HIP_TRY(hipGraphLaunch(g_step_[parity_], s));
     SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
   }

@@ -16,6 +16,7 @@
 //   gemm_nt_f64_kernel : C (-)= A B^T, 128x128 tile, v_mfma_f64_16x16x4_f64.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <hip/hip_ext.h>
 #include <math.h>
@@ -546,6 +547,11 @@ __device__ long long g_potrf_stamps[4][16], g_potrf_clk[4][16];
 #define SK_STAMP(i)
 #endif
 
+// `info` only ever rises: 0 ok, 1 a pivot was not positive, 2 a wait of the resident panel chain gave up.  After a
+// time-out the hand-back kernels still run, on a half-updated matrix that is easily indefinite; their 1 must not replace
+// the 2, or the host would count an invalid LM step instead of factoring the same system again (cholesky_note_info).
+__device__ __forceinline__ void info_raise(int* info, int v) { (void)__hip_atomic_fetch_max(info, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict__ A, long ld, double* __restrict__ Linv, int* info) {
   // Inlined into the server's loop, everything below that does not depend on the column — LDS addresses, lane-derived
   // offsets — is loop-invariant, gets hoisted, and the 256-register body spills (384-716 bytes of scratch).  Opaque
@@ -647,7 +653,7 @@ __device__ __forceinline__ void potrf128_body(double* lds_in, double* __restrict
       double a[32];
       const bool ok = wave_potrf32(D, colbuf, a, lane);
       SK_STAMP(11 + jb)
-      if (!ok && lane == 0) *info = 1;
+      if (!ok && lane == 0) info_raise(info, 1);
       {
         // lanes 0..31: row of L_jj -> staging block E[jb & 1] (written to global by wave 3 during the next diagonal
         // factorisation); lanes 32..63: column k of W_jj -> the slot of D.  W has its zeros above the diagonal (they
@@ -872,7 +878,7 @@ __global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld
         if (threadIdx.x == 0) ok_s = chain_wait(sync + kSyncHeader + j, 16, sync + kSyncAbort) ? 1 : 0;
         __syncthreads();
         if (!ok_s) {
-          if (threadIdx.x == 0) *info = 2;
+          if (threadIdx.x == 0) info_raise(info, 2);
           return;
         }
         SK_CHAIN_ACQUIRE_ALL
@@ -948,7 +954,7 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
   // column of a resident run hands back to launch-by-launch kernels, which would factor stale data): *info = 2.
   if (threadIdx.x == 0) ok_s = chain_wait(sync + kSyncPotrfDone, j + 1, sync + kSyncAbort) ? 1 : 0;
   __syncthreads();
-  if (!ok_s) { if (threadIdx.x == 0) *info = 2; return; }
+  if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
   SK_CHAIN_ACQUIRE_ALL
   if (stamp) SK_CHAIN_STAMP(j, 3)
   // ---- X(r,j) = S(r,j) W_jj^T
@@ -970,7 +976,7 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
     ok_s = (chain_wait(x_ready, ncrit, sync + kSyncAbort) && chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort) &&
             chain_wait(sync + kSyncSyrkColumn, column_need, sync + kSyncAbort)) ? 1 : 0;
   __syncthreads();
-  if (!ok_s) { if (threadIdx.x == 0) *info = 2; return; }
+  if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
   SK_CHAIN_ACQUIRE_ALL
   if (stamp) SK_CHAIN_STAMP(j, 5)
   // ---- next(j): S(r,j+1) -= X(r,j) X(j+1,j)^T
@@ -1084,7 +1090,16 @@ static int g_chain_server = 1;  // developer knob SK_CHOL_CHAIN_SERVER=0: the la
 static int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see cholesky_plan (developer knobs SK_CHAIN_MAX_TRAILING, SK_CHAIN_PREFIX_GROUP)
 static int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK (developer knob SK_THIN_SYRK)
 static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
+// Unsupported test hooks, read once in cholesky_init (cholesky_factor runs on two threads when a tail front has its own):
+// SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds, once per process, what that column's launch waits for (the wait
+// times out; tests/chain_abort_worker.py); SK_CHAIN_NO_SERVER_JOIN=1 leaves the server's stream unjoined (a probe).
+static std::atomic<int> g_test_withhold{-1}, g_no_server_join{0};
 hipError_t cholesky_init() {
+  static std::once_flag hooks;
+  std::call_once(hooks, [] {
+    if (const char* e = getenv("SK_CHAIN_TEST_WITHHOLD_MARKER")) g_test_withhold.store(atoi(e));
+    if (const char* e = getenv("SK_CHAIN_NO_SERVER_JOIN")) g_no_server_join.store(atoi(e));
+  });
   if (const char* e = getenv("SK_TAIL_TILES")) g_tail_tiles = atoi(e);  // developer knobs
   if (const char* e = getenv("SK_TAIL_GROUP")) g_tail_group = atoi(e);
   if (const char* e = getenv("SK_THIN_GRID")) g_thin_grid = atoi(e);
@@ -1134,9 +1149,9 @@ int* CholeskyContext::sync_for(int nblk) {
 // more queue created first flips it (measured: 10.4 / 16.0 / 10.4 / 16.1 ms per iteration with 0 / 1 / 2 / 3 extra
 // queues; over the runs, fast exactly when the panel queue had one parity of creation index and the server queue
 // the other).  Probes with a spinning kernel and event-ordered empty launches do not show the effect, so two
-// queues are created for the bulk streams and three each for the panel stream and the server, and the first
+// queues are created for the bulk streams, four for the panel stream and three for the server, and the first
 // factorisation with a resident chain first runs a small synthetic one (identity matrix, banded envelope, 1 ms) with
-// each of the 18 combinations and keeps the fastest (tune_chain_queues: 0.1 s, once per device; developer knob
+// each of the 24 combinations (kBulkCand x kPanelCand x kServerCand) and keeps the fastest (tune_chain_queues: 0.1 s, once per device; developer knob
 // SK_CHAIN_QUEUES=<n> fixes the combination).
 constexpr int kBulkCand = 2, kPanelCand = 4, kServerCand = 3;
 struct DeviceQueues {
@@ -1147,8 +1162,8 @@ struct DeviceQueues {
               server_candidates[kServerCand] = {};
   std::vector<hipStream_t> all_streams;  // destroyed at exit
   int queue_choice = -1;  // -1: not measured yet; else (bulk * kPanelCand + panel) * kServerCand + server
-  bool tuning = false;
-  int chain_server = 1;   // 0: block columns are factored launch by launch on this device (knob, or a time-out happened)
+  std::atomic<bool> tuning{false};  // the queue trial of this device is running (under the table's operation mutex)
+  std::atomic<int> chain_server{1};   // 0: block columns are factored launch by launch on this device (knob, or a time-out happened)
   hipStream_t fork = nullptr;  // stands in for the caller's stream in a secondary context (CholeskyContext::init_secondary)
   hipStream_t plain[2] = {nullptr, nullptr};
 };
@@ -1171,7 +1186,7 @@ static hipError_t create_bulk_stream(hipStream_t* out, int per_xcd, int ncu, int
 static DeviceQueues* create_device_queues(int dev) {
   std::unique_ptr<DeviceQueues> q(new DeviceQueues());
   q->device = dev;
-  q->chain_server = g_chain_server;
+  q->chain_server.store(g_chain_server);
   int ncu = 0, reserved = 0, reserved_early = 0;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   // CUs per XCD kept free of the SYRK; developer knobs (0 = no mask)
@@ -1479,6 +1494,7 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
   for (int c = 0; c < nblk; ++c) last[c] = std::min(c + 4, nblk - 2);
   last[nblk - 1] = nblk - 1;
   q.tuning = true;
+  ctx->in_trial = true;
   const int ncomb = kBulkCand * kPanelCand * kServerCand;
   std::vector<double> ms((size_t)ncomb, 1e30);
   auto select = [&](int c) {
@@ -1512,6 +1528,7 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
   }
   if (serialised) {
     q.tuning = false;
+    ctx->in_trial = false;
     q.chain_server = 0;
     std::fprintf(stderr, "[skeres_amd] the resident panel chain timed out in its trial run (are kernels being serialised, e.g. by counter "
                          "collection?): block columns are factored launch by launch in this process\n");
@@ -1560,6 +1577,7 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
     std::fprintf(stderr, ": combination %d (device %d)\n", q.queue_choice, q.device);
   }
   q.tuning = false;
+  ctx->in_trial = false;
   select(q.queue_choice);
   (void)hipFree(A);
   (void)hipFree(Linv);
@@ -1592,12 +1610,15 @@ bool cholesky_chain_enabled(const CholeskyContext* ctx) { return ctx && ctx->dq 
 // Before the first factorisation with allow_chain on stream s (cholesky_factor does it otherwise): choose the queues.
 // One trial per device, one at a time (two solvers on two threads would otherwise measure each other).
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s) {
-  if (!ctx || !ctx->dq || !ctx->server) return;
+  if (!ctx || !ctx->dq || !ctx->server || ctx->prepared) return;
+  // (a factorisation that finds the trial of its device running waits here for it to end, instead of running alongside
+  // it and skewing what it measures; the trial's own factorisations never get here: cholesky_factor checks `tuning`)
   std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());
   DeviceQueues& q = *ctx->dq;
-  if (!q.chain_server || q.tuning) return;
+  if (!q.chain_server) return;
   if (q.queue_choice < 0) tune_chain_queues(ctx, s);
   ctx->use(&q);  // (every context of the device: the choice is the device's)
+  ctx->prepared = q.queue_choice >= 0;  // the choice is final: later factorisations of this context take no lock
 }
 
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
@@ -1607,7 +1628,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   // Which hardware queues the panel and bulk streams sit on decides how well their kernels overlap — with or without the
   // resident chain (Venice-1778 in explicit groups of two: 30.6 ms per iteration on the first combination, 19.1 on the
   // one the trial picks): every look-ahead factorisation asks for the trial, which runs once per device.
-  if (ctx && ctx->dq && !ctx->dq->tuning) cholesky_prepare(ctx, s);
+  if (ctx && ctx->dq && !ctx->prepared && !(ctx->dq->tuning && ctx->in_trial)) cholesky_prepare(ctx, s);
   const bool la = ctx != nullptr && ctx->panel != nullptr && ctx->bulk != nullptr;
   hipStream_t sp = la ? ctx->panel : s;
   hipStream_t sb = la ? ctx->bulk : s;  // of the current group (chosen below)
@@ -1777,9 +1798,8 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       // the whole SYRK, announced by a marker kernel behind it.
       // (fault injection for tests: SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds what that column's launch
       // waits for, once per process — the wait times out, and the factorisation must be reported as lost: info = 2)
-      static int withhold = getenv("SK_CHAIN_TEST_WITHHOLD_MARKER") ? atoi(getenv("SK_CHAIN_TEST_WITHHOLD_MARKER")) : -1;
       bool withheld = false;
-      if (next_resident && withhold >= 0 && k1 == withhold && !ctx->dq->tuning) { withhold = -1; withheld = true; }
+      if (next_resident && !ctx->dq->tuning) { int want = k1; withheld = want >= 0 && g_test_withhold.compare_exchange_strong(want, -1); }
       const bool thin = Tb <= g_thin_syrk_tiles, by_column = next_resident && thin && g_early_column;
       if (thin)
         hipExtLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(2 * Tb * (Tb + 1)), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main,
@@ -1810,8 +1830,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   }
   order(sp, s);
   if (la) { order(ctx->bulk, s); order(ctx->bulk_early, s); }
-  static const int no_server_join = getenv("SK_CHAIN_NO_SERVER_JOIN") ? atoi(getenv("SK_CHAIN_NO_SERVER_JOIN")) : 0;  // developer knob
-  if (chain && !no_server_join) order(srv, s);
+  if (chain && !g_no_server_join.load(std::memory_order_relaxed)) order(srv, s);
   if (stamps_file) {
     (void)hipStreamSynchronize(s);
     std::vector<long long> st((size_t)1024 * 8);

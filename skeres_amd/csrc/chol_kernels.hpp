@@ -141,6 +141,8 @@ class AsyncRunner {
 struct DeviceQueues;  // chol_kernels.hip: the queues of one device, shared by its contexts, alive until process exit
 struct CholeskyContext {
   DeviceQueues* dq = nullptr;        // the device's queue set this context uses (init(): the device current at that time)
+  bool prepared = false;             // the device's queue choice has been made and adopted (cholesky_prepare)
+  bool in_trial = false;             // this context is the one running its device's queue trial
   int device = -1;
   void use(DeviceQueues* q);
   hipStream_t panel = nullptr;

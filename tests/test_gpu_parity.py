@@ -795,6 +795,90 @@ def test_full_size_venice_1778_properties():
     assert abs(c - s1.finalCost()) <= 1e-10 * c
 
 
+def _oracle_threads():
+    import os
+    return max(1, min(len(os.sched_getaffinity(0)), 32))
+
+
+def _compare_bal_trajectory_with_oracle(prob, iterations):
+    """The device trajectory against the oracle's on the SAME full-size problem: every logged figure of iterations
+    0 .. `iterations` and the parameters.  The oracle factors inside the column envelope of its reduced system
+    (or_options.cholesky_envelope: bit-identical to its full factorisation, oracle/chol.cpp) on all host cores."""
+    x_gpu, sg = solve_bal_gpu(prob, setMaxNumIterations=iterations)
+    o = oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=_oracle_threads(), max_num_iterations=iterations, cholesky_envelope=1)
+    x_cpu, so = oracle.solve_bal(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index, prob.observations, prob.parameters, o)
+    g = sg.iterations()
+    assert len(g) == so.num_logged == iterations + 1
+    for k in range(iterations + 1):
+        c = so.iterations[k]
+        assert abs(g[k]["cost"] - c.cost) <= 1e-10 * c.cost, (k, g[k]["cost"], c.cost)
+        assert g[k]["step_is_successful"] == c.step_is_successful or k == 0
+        for name, ref in (("step_norm", c.step_norm), ("gradient_max_norm", c.gradient_max_norm), ("trust_region_radius", c.trust_region_radius),
+                          ("relative_decrease", c.relative_decrease)):
+            assert abs(g[k][name] - ref) <= 1e-8 * max(abs(ref), 1e-300), (k, name, g[k][name], ref)
+    assert np.linalg.norm(x_gpu - x_cpu) <= 1e-8 * np.linalg.norm(x_cpu - prob.parameters)
+    return sg, so
+
+
+def test_full_size_ladybug_1723_trajectory_vs_oracle():
+    """BASELINE.json configs[2] at FULL size, iterations 0-2 against the oracle (cost 1e-10; step norm, gradient
+    max-norm, radius, gain ratio 1e-8; parameters 1e-8 of the distance moved).  The default plan — block envelope,
+    resident panel chain — is what runs: round 1's wrong factor in that plan passed every size-independent property
+    and moved the cost of iteration 1 by 2e-3; this is the test that would have caught it."""
+    prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1))
+    _compare_bal_trajectory_with_oracle(prob, 2)
+
+
+def test_full_size_venice_1778_first_iteration_vs_oracle():
+    """BASELINE.json configs[3] at FULL size (C = 1778, N = 5 001 946): iteration 0 and the first LM step against the oracle."""
+    prob = bal.generate_named("venice-1778-993923", seed=1778, perturb=(1e-2, 1e-1, 1e-1))
+    _compare_bal_trajectory_with_oracle(prob, 1)
+
+
+def test_full_size_dense_rows_1m_x_10k_vs_oracle_costs():
+    """BASELINE.json configs[4] at FULL size (10^6 residuals x 10^4 parameters, DENSE_NORMAL_CHOLESKY): two LM iterations.
+    The oracle cannot hold the 80 GB Jacobian a solve of that size needs, so: every logged cost equals the oracle's
+    cost-only evaluation (CORE/AutodiffCostFunction.scala:80-93 over all rows) of the parameters the device holds at
+    that point — start and end — to 1e-10; the cost decreases; a rerun is bitwise the same.  The trajectory itself is
+    held against the oracle's at the largest size it solves in seconds (below)."""
+    m, n, seed = 1000000, 10000, 5
+    rng = np.random.default_rng(seed)
+    x_star = rng.normal(size=n)
+    y = sk.api.synth_dense_targets(seed, m, n, x_star) + rng.normal(0, 1e-3, m)
+    consts = np.stack([np.full(m, float(seed)), np.arange(m, dtype=np.float64), y], axis=1)
+    try:
+        x1, s1 = _solve_dense_rows_gpu(consts, n, max_iter=2)
+    except sk.SkeresError as e:
+        if "memory" in str(e).lower():
+            pytest.skip("not enough free HBM for the 80 GB Jacobian on this device: %s" % e)
+        raise
+    its = s1.iterations()
+    assert len(its) == 3 and its[2]["cost"] < its[1]["cost"] < its[0]["cost"]
+    c0 = oracle.dense_rows_cost(consts, np.zeros(n), _oracle_threads())
+    c2 = oracle.dense_rows_cost(consts, x1, _oracle_threads())
+    assert abs(its[0]["cost"] - c0) <= 1e-10 * c0
+    assert abs(its[2]["cost"] - c2) <= 1e-10 * c2
+    x2, s2 = _solve_dense_rows_gpu(consts, n, max_iter=2)
+    assert np.array_equal(x1, x2) and [a["cost"] for a in s2.iterations()] == [a["cost"] for a in its]
+
+
+def test_dense_rows_trajectory_vs_oracle_at_the_largest_size_it_solves_in_seconds():
+    from skeres_amd import dense_synth
+    m, n = 30000, 600
+    consts, x_star = dense_synth.generate(m, n, seed=21)
+    x_gpu, summary = _solve_dense_rows_gpu(consts, n, max_iter=3)
+    blocks = [(oracle.SYNTH_TANH_ROW, list(consts[i]), [0]) for i in range(m)]
+    x_cpu, so = oracle.solve([n], np.zeros(n), blocks, oracle.default_options(linear_solver_type=oracle.DENSE_NORMAL_CHOLESKY, max_num_iterations=3))
+    g = summary.iterations()
+    assert len(g) == so.num_logged == 4
+    for k in range(4):
+        c = so.iterations[k]
+        assert abs(g[k]["cost"] - c.cost) <= 1e-10 * c.cost, (k, g[k]["cost"], c.cost)
+        assert abs(g[k]["step_norm"] - c.step_norm) <= 1e-8 * max(c.step_norm, 1e-300)
+        assert abs(g[k]["gradient_max_norm"] - c.gradient_max_norm) <= 1e-8 * c.gradient_max_norm
+    assert np.linalg.norm(x_gpu - x_cpu) <= 1e-9 * np.linalg.norm(x_cpu)
+
+
 def test_full_size_cholesky_15507_residual():
     """The dense fp64 MFMA Cholesky at the reduced-system size of Ladybug-1723, look-ahead path: solve A x = b and
     check the residual and a sample of L L^T = A in numpy."""
