@@ -492,6 +492,15 @@ int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, dou
 int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double* x, int head, int tail_begin, int group,
                                 int automatic_plan);
 
+/* ... and by multi-way dissection: num_segments >= 2 runs of rows separated by num_segments - 1 separators
+ * (cuts[2 (k - 1)], cuts[2 (k - 1) + 1]) = [begin, end) of separator k, ascending; rows behind a separator must not couple
+ * with rows before it).  Every segment leaves its Schur complement on the separators next to it — a segment between two
+ * separators as a partial factorisation whose border rows of the LEFT separator are active in every column (the spike) —
+ * and the separators' block-tridiagonal system is factored last.  This is the arithmetic of the segmented distribution
+ * over several GPUs (SK_DISTRIBUTION_SEGMENTED) run on one device: a known-answer test of it. */
+int sk_cholesky_solve_segments(int n, const double* A, const double* b, double* x, int num_segments, const int* cuts, int group,
+                               int automatic_plan);
+
 #ifdef __cplusplus
 }
 #endif

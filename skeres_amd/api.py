@@ -139,6 +139,7 @@ _SIGS = {
     "sk_solver_stat": (C.c_int, [C.c_void_p, C.c_char_p, _dp]),
     "sk_last_status": (C.c_int, []),
     "sk_cholesky_solve_dissected": (C.c_int, [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sk_cholesky_solve_segments": (C.c_int, [C.c_int, _dp, _dp, _dp, C.c_int, _ip, C.c_int, C.c_int]),
     "sk_cholesky_solve_ex": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, C.c_int]),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
@@ -1242,6 +1243,19 @@ def cholesky_solve_dissected(A, b, head, tail_begin, group=0, automatic_plan=Fal
     x = np.empty(n)
     _check(lib().sk_cholesky_solve_dissected(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp), int(head), int(tail_begin),
                                              int(group), int(bool(automatic_plan))))
+    return x
+
+
+def cholesky_solve_segments(A, b, cuts, group=0, automatic_plan=False):
+    """A x = b by multi-way dissection on the GPU (sk_cholesky_solve_segments): `cuts` = [(begin, end) of each separator],
+    ascending; len(cuts) + 1 segments, each eliminated on its own, the separators' system last."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    n = A.shape[0]
+    x = np.empty(n)
+    c = np.ascontiguousarray(np.asarray(cuts, dtype=np.int32).reshape(-1))
+    _check(lib().sk_cholesky_solve_segments(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp), len(cuts) + 1,
+                                            c.ctypes.data_as(_ip), int(group), int(bool(automatic_plan))))
     return x
 
 

@@ -767,7 +767,7 @@ int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, dou
 }
 
 // Block envelope of a front held on the host (lower triangle, row-major, ld): first non-zero block column per block row.
-static std::vector<int> host_block_envelope(const std::vector<double>& M, size_t ld, int nblk) {
+static std::vector<int> host_block_envelope(const std::vector<double>& M, size_t ld, int nblk, int tail_rows = 1) {
   std::vector<int> first_col(nblk);
   for (int i = 0; i < nblk; ++i) {
     first_col[i] = i;
@@ -780,7 +780,7 @@ static std::vector<int> host_block_envelope(const std::vector<double>& M, size_t
       if (nz) first_col[i] = j;
     }
   }
-  return cholesky_envelope_last(first_col);
+  return cholesky_envelope_last(first_col, tail_rows);
 }
 
 int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double* x, int head, int tail_begin, int group, int automatic_plan) {
@@ -851,6 +851,128 @@ int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double*
   for (int i = 0; i < ra; ++i) x[i] = y[i];
   for (int t = 0; t < nt; ++t) x[n - 1 - t] = y[dA + t];
   for (int k = 0; k < msep; ++k) x[ra + k] = y[dA + dB + k];
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
+int sk_cholesky_solve_segments(int n, const double* A, const double* b, double* x, int num_segments, const int* cuts, int group, int automatic_plan) {
+  SK_GUARD_BEGIN
+  const int R = num_segments;
+  if (n <= 0 || !A || !b || !x || R < 2 || !cuts) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
+  // separator k (1 <= k < R) = rows [sb[k], se[k]); segment k = rows [se[k], sb[k + 1]) with se[0] = 0, sb[R] = n
+  std::vector<int> sb(R + 1, 0), se(R + 1, 0);
+  sb[R] = n;
+  for (int k = 1; k < R; ++k) { sb[k] = cuts[2 * (k - 1)]; se[k] = cuts[2 * (k - 1) + 1]; }
+  for (int k = 1; k <= R; ++k)
+    if (sb[k] < se[k - 1] || (k < R && (se[k] < sb[k] || se[k] > n))) { set_error("invalid cuts"); return SK_ERR_INVALID_ARGUMENT; }
+  for (int k = 1; k < R; ++k)
+    for (int i = se[k]; i < n; ++i)
+      for (int j = 0; j < sb[k]; ++j)
+        if (A[(size_t)i * n + j] != 0.0) { set_error("rows behind separator %d couple with rows before it at (%d, %d): not a separator", k, i, j); return SK_ERR_INVALID_ARGUMENT; }
+  if (group <= 0) group = automatic_plan ? 1 : 3;
+  auto a = [&](int i, int j) { return i >= j ? A[(size_t)i * n + j] : A[(size_t)j * n + i]; };  // (lower triangle given)
+  // root: every separator in order, then the right-hand side
+  std::vector<int> sep_off(R, 0);
+  for (int k = 1; k < R; ++k) sep_off[k] = sep_off[k - 1] + (se[k] - sb[k]);  // sep_off[k - 1]: offset of separator k; sep_off[R - 1]: total
+  const int nroot = sep_off[R - 1], E = (nroot + 1 + 127) / 128;
+  const size_t dR = (size_t)E * 128;
+  auto root_index = [&](int row) {  // global row of a separator -> root index
+    for (int k = 1; k < R; ++k) if (row >= sb[k] && row < se[k]) return sep_off[k - 1] + (row - sb[k]);
+    return -1;
+  };
+  std::vector<double> FR(dR * dR, 0.0);
+  for (int k = 1; k < R; ++k)
+    for (int i = sb[k]; i < se[k]; ++i) {
+      const int ri = root_index(i);
+      for (int k2 = 1; k2 <= k; ++k2)
+        for (int j = sb[k2]; j < se[k2] && j <= i; ++j) FR[(size_t)ri * dR + root_index(j)] = a(i, j);
+      FR[(size_t)nroot * dR + ri] = b[i];
+    }
+  FR[(size_t)nroot * dR + nroot] = 1e300;
+  for (size_t j = (size_t)nroot + 1; j < dR; ++j) FR[j * dR + j] = 1.0;
+  const std::vector<int> lastR = root_envelope(std::vector<int>(sep_off.begin(), sep_off.end()));
+  SK_HIP_TRY(cholesky_init());
+  CholeskyContext ctx;
+  const bool la = ctx.init() == hipSuccess;
+  if (!la) (void)hipGetLastError();
+  hipStream_t s = nullptr;
+  SK_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  if (la) cholesky_prepare(&ctx, s);
+  const bool chain = automatic_plan != 0 && la && ctx.server != nullptr;
+  DevBuf<double> dFR; DevBuf<int> dinfo;
+  SK_HIP_TRY(dFR.upload(FR, s)); SK_HIP_TRY(dinfo.alloc(1)); SK_HIP_TRY(dinfo.zero(s));
+  struct Leaf { SegmentLayout L; std::vector<int> order, map, last; DevBuf<double> F, Linv, w, y, yb; DevBuf<int> dmap; size_t dim; };
+  std::vector<std::unique_ptr<Leaf>> leaves;
+  for (int k = 0; k < R; ++k) {
+    std::unique_ptr<Leaf> lf(new Leaf());
+    const int lo = se[k], hi = sb[k + 1], ni = hi - lo;
+    const int left_n = k > 0 ? se[k] - sb[k] : 0, right_n = k + 1 < R ? se[k + 1] - sb[k + 1] : 0;
+    lf->L = segment_layout(ni, left_n, right_n);
+    const SegmentLayout& L = lf->L;
+    lf->dim = (size_t)L.nblk * 128;
+    const size_t d = lf->dim;
+    // front row -> global row (-1: padding / right-hand side)
+    lf->order.assign(d, -1);
+    for (int t = 0; t < ni; ++t) lf->order[t] = L.reversed ? hi - 1 - t : lo + t;
+    const int bo = L.ncols * 128;
+    if (L.right_off >= 0) for (int t = 0; t < right_n; ++t) lf->order[bo + L.right_off + t] = sb[k + 1] + t;
+    if (L.left_off >= 0) for (int t = 0; t < left_n; ++t) lf->order[bo + L.left_off + t] = L.reversed ? se[k] - 1 - t : sb[k] + t;
+    std::vector<double> F(d * d, 0.0);
+    for (size_t i = 0; i < d; ++i) {
+      const int gi = lf->order[i];
+      if (gi < 0) continue;
+      const bool border_i = (int)i >= bo;
+      for (size_t j = 0; j <= i && j < (size_t)ni; ++j) F[i * d + j] = a(gi, lf->order[j]);  // interior columns only: the border x border block starts at zero
+      (void)border_i;
+    }
+    for (int t = 0; t < ni; ++t) F[(size_t)L.rhs_row * d + t] = b[lf->order[t]];
+    for (int i = ni; i < bo; ++i) F[(size_t)i * d + i] = 1.0;
+    lf->last = host_block_envelope(F, d, L.nblk, L.tail_rows);
+    lf->map.assign(d - bo, -1);
+    for (size_t i = bo; i < d; ++i) if (lf->order[i] >= 0) lf->map[i - bo] = root_index(lf->order[i]);
+    lf->map[L.rhs_row - bo] = nroot;
+    SK_HIP_TRY(lf->F.upload(F, s)); SK_HIP_TRY(lf->dmap.upload(lf->map, s));
+    SK_HIP_TRY(lf->Linv.alloc((size_t)L.ncols * 128 * 128)); SK_HIP_TRY(lf->Linv.zero(s));
+    SK_HIP_TRY(lf->w.alloc(d)); SK_HIP_TRY(lf->y.alloc(d)); SK_HIP_TRY(lf->y.zero(s)); SK_HIP_TRY(lf->yb.alloc(d - bo));
+    if (ni > 0) {
+      cholesky_factor(lf->F.p, (long)d, (int)d, lf->Linv.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr, lf->last.data(), chain, L.ncols, L.tail_rows);
+      cholesky_border_add(dFR.p, (long)dR, lf->F.p, (long)d, L.ncols, L.nblk - L.ncols, lf->dmap.p, s);
+    }
+    SK_HIP_TRY(hipStreamSynchronize(s));  // (F, the host copy, goes out of scope)
+    leaves.push_back(std::move(lf));
+  }
+  DevBuf<double> dLinvR, dwR, dyR;
+  SK_HIP_TRY(dLinvR.alloc(dR * 128)); SK_HIP_TRY(dLinvR.zero(s)); SK_HIP_TRY(dwR.alloc(dR)); SK_HIP_TRY(dyR.alloc(dR));
+  cholesky_factor(dFR.p, (long)dR, (int)dR, dLinvR.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr, lastR.empty() ? nullptr : lastR.data(), chain);
+  cholesky_backsolve(dFR.p, (long)dR, nroot, (int)dR, nroot, dLinvR.p, dwR.p, dyR.p, s, nullptr, lastR.empty() ? nullptr : lastR.data());
+  std::vector<double> y(dR);
+  for (auto& lf : leaves) {
+    const SegmentLayout& L = lf->L;
+    if (L.ncols == 0) continue;
+    const int m = (L.nblk - L.ncols) * 128;
+    // border unknowns in the leaf's border order (zero in padding rows and in the right-hand-side row)
+    std::vector<int> gmap(lf->map);
+    gmap[L.rhs_row - L.ncols * 128] = -1;
+    DevBuf<int> dg;
+    SK_HIP_TRY(dg.upload(gmap, s));
+    cholesky_gather_map(dyR.p, dg.p, lf->yb.p, m, s);
+    cholesky_backsolve_front(lf->F.p, (long)lf->dim, L.nblk, L.ncols, L.rhs_row, lf->Linv.p, lf->yb.p, lf->w.p, lf->y.p, s, lf->last.data(), L.tail_rows);
+    SK_HIP_TRY(hipStreamSynchronize(s));
+  }
+  SK_HIP_TRY(hipStreamSynchronize(s));
+  int info = 0;
+  SK_HIP_TRY(hipMemcpy(&info, dinfo.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (info == 2) { (void)cholesky_note_info(&ctx, info); (void)hipStreamDestroy(s); set_error("the resident panel chain timed out"); return SK_ERR_HIP; }
+  if (info) { (void)hipStreamDestroy(s); set_error("matrix is not positive definite"); return SK_ERR_EVALUATION_FAILED; }
+  SK_HIP_TRY(hipMemcpy(y.data(), dyR.p, dR * sizeof(double), hipMemcpyDeviceToHost));
+  for (int k = 1; k < R; ++k) for (int i = sb[k]; i < se[k]; ++i) x[i] = y[root_index(i)];
+  for (auto& lf : leaves) {
+    std::vector<double> yl(lf->dim);
+    SK_HIP_TRY(hipMemcpy(yl.data(), lf->y.p, lf->dim * sizeof(double), hipMemcpyDeviceToHost));
+    for (int t = 0; t < lf->L.ncols * 128; ++t) if (lf->order[t] >= 0) x[lf->order[t]] = yl[t];
+  }
+  SK_HIP_TRY(hipStreamDestroy(s));
   return SK_OK;
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }

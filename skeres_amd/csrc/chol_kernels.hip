@@ -1387,11 +1387,16 @@ static void plan_close_partial(CholeskyPlan* plan, int nblk, int ncols) {
   if (ncols + 1 < nblk) b.push_back(ncols + 1);
   if (ncols < nblk) b.push_back(nblk);
 }
-CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols) {
+// tail_rows: how many block rows at the end of the matrix are active in EVERY block column (1: the block row that carries
+// the right-hand side; more for a leaf front whose border has rows that the first columns of the interior couple with —
+// the "spike" of a segment between two separators); only a partial factorisation has more than one.
+CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols, int tail_rows) {
   CholeskyPlan plan;
   plan.resident.assign(nblk, 0);
   if (group < 1) group = 1;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
+  if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
+  const int tail0 = nblk - tail_rows;  // first block row of the tail
   const bool partial = ncols < nblk;
   if (!chain || nblk < 3) {
     plan.bounds = cholesky_group_bounds(nblk, group);
@@ -1405,9 +1410,9 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int
     return plan;
   }
   auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
-  auto count = [&](int first_row, int last_row) {  // active block rows from first_row: the run up to last_row, and block row nblk-1
+  auto count = [&](int first_row, int last_row) {  // active block rows from first_row: the run up to last_row, and the tail rows
     const int main_rows = last_row >= first_row ? last_row - first_row + 1 : 0;
-    return main_rows + ((first_row + main_rows <= nblk - 1 && last_row < nblk - 1) ? 1 : 0);
+    return main_rows + std::max(0, nblk - std::max(tail0, first_row + main_rows));
   };
   const int jend = partial ? ncols : nblk - 1;  // block columns that have a column launch of their own
   for (int j = 0; j < jend; ++j)
@@ -1422,7 +1427,7 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int
   if (!partial) plan.resident[nblk - 1] = plan.resident[nblk - 2];  // the server factors the last diagonal block too when it has the column before it
   bool any = false;
   for (int j = 0; j < nblk; ++j) any = any || plan.resident[j];
-  if (!any) return cholesky_plan(nblk, group, last, false, ncols);
+  if (!any) return cholesky_plan(nblk, group, last, false, ncols, tail_rows);
   const int pg = group == 1 ? g_chain_prefix_group : group;
   for (int k = 0; k < ncols;) {
     plan.bounds.push_back(k);
@@ -1622,9 +1627,11 @@ void cholesky_prepare(CholeskyContext* ctx, hipStream_t s) {
 }
 
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt, const int* last, bool allow_chain, int ncols) {
+                     KernelTimer* kt, const int* last, bool allow_chain, int ncols, int tail_rows) {
   const int nblk = npad / 128;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
+  if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
+  const int tail0 = nblk - tail_rows;
   // Which hardware queues the panel and bulk streams sit on decides how well their kernels overlap — with or without the
   // resident chain (Venice-1778 in explicit groups of two: 30.6 ms per iteration on the first combination, 19.1 on the
   // one the trial picks): every look-ahead factorisation asks for the trial, which runs once per device.
@@ -1642,12 +1649,13 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   };
   // last active main row of block column c, and whether block row nblk-1 comes on top of the run that ends there
   auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
-  struct Rows { int main, extra, jump; };  // `main` consecutive block rows from `first_row`, then `extra` (0/1) row nblk-1, `jump` blocks further
+  struct Rows { int main, extra, jump; };  // `main` consecutive block rows from `first_row`, then `extra` rows of the tail (what is left of it), `jump` blocks further
   auto rows_from = [&](int first_row, int last_row) {
     Rows r;
     r.main = last_row >= first_row ? last_row - first_row + 1 : 0;
-    r.extra = (first_row + r.main <= nblk - 1 && last_row < nblk - 1) ? 1 : 0;
-    r.jump = r.extra ? (nblk - 1) - (first_row + r.main) : 0;
+    const int t0 = std::max(tail0, first_row + r.main);
+    r.extra = std::max(0, nblk - t0);
+    r.jump = r.extra ? t0 - (first_row + r.main) : 0;
     return r;
   };
   // C[rows x tiles_n tiles of 128] -= A B^T; rows as above, 64-row tiles
@@ -1703,7 +1711,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     }
   };
   // the block columns under the resident panel chain (cholesky_plan)
-  const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr, ncols);
+  const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr, ncols, tail_rows);
   const std::vector<int>& gb = plan.bounds;
   const int ngroups = (int)gb.size() - 1;
   ChainRanges ranges;
@@ -1942,9 +1950,10 @@ void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f
 // Interior part of L^T y = z for a leaf front whose border unknowns are known.  yb: border unknowns (border_blocks * 128
 // values, zero where the border has padding or its right-hand-side row).  w: scratch (ncols * 128); y: interior solution.
 void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last) {
+                              hipStream_t s, const int* last, int tail_rows) {
   const int ni = ncols * 128, m = (nblk - ncols) * 128;
   if (ncols <= 0) return;
+  if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
   hipLaunchKernelGGL(copy_row_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, ni, ni);
   // block rows' first non-zero block columns (the border rows: from the first interior column that reaches the border)
   std::vector<int> first(nblk, 0);
@@ -1954,7 +1963,8 @@ void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int
       while (c0 < kb && last[c0] < kb) ++c0;
       first[kb] = c0;
     }
-  const int bcol0 = std::min(first[ncols < nblk - 1 ? ncols : nblk - 1], ncols) * 128;
+  // (border rows of the tail reach every interior column: a spike; first[] of the last block row is 0 anyway)
+  const int bcol0 = tail_rows > 1 ? 0 : std::min(first[ncols < nblk - 1 ? ncols : nblk - 1], ncols) * 128;
   if (ni > bcol0)
     hipLaunchKernelGGL(bs_border_kernel, dim3((ni - bcol0 + 63) / 64), dim3(1024), 0, s, S + (long)ncols * 128 * ld, ld, m, yb, w, bcol0, ni);
   for (int kb = ncols - 1; kb >= 0; --kb) {
@@ -2081,10 +2091,12 @@ void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, in
 
 // Algorithmic flops of the dominant kernel's launches (part (b) of each trailing SYRK:
 // lower-triangular 128x128 tiles incl. the diagonal tiles, 2*128*128*K each).
-double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, double* c_tiles, int ncols) {
+double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, double* c_tiles, int ncols, int tail_rows) {
   const int nblk = npad / 128;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
-  const CholeskyPlan plan = cholesky_plan(nblk, group, last, chain, ncols);
+  if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
+  const int tail0 = nblk - tail_rows;
+  const CholeskyPlan plan = cholesky_plan(nblk, group, last, chain, ncols, tail_rows);
   const std::vector<int>& gb = plan.bounds;
   double f = 0.0, tiles = 0.0;
   for (size_t g = 0; g + 2 < gb.size(); ++g) {
@@ -2093,7 +2105,7 @@ double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, dou
     const int Lg = last ? (last[k1 - 1] < nblk - 1 ? last[k1 - 1] : nblk - 1) : nblk - 1;
     const int first_row = k1 + na;
     const int main_rows = Lg >= first_row ? Lg - first_row + 1 : 0;
-    const int Tb = main_rows + ((first_row + main_rows <= nblk - 1 && Lg < nblk - 1) ? 1 : 0);
+    const int Tb = main_rows + std::max(0, nblk - std::max(tail0, first_row + main_rows));
     f += 0.5 * Tb * (Tb + 1.0) * 2.0 * 128.0 * 128.0 * (double)((k1 - k0) * 128);
     tiles += 0.5 * Tb * (Tb + 1.0);
   }
@@ -2104,25 +2116,41 @@ double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, dou
 // Algorithmic flops of factoring the blocks inside the envelope (last == nullptr: every block): per block column with
 // h active block rows below it, 128^3 (1/3 + h + h^2) — diagonal factorisation, triangular solve of h blocks, symmetric
 // update of h (h + 1) / 2 blocks with its diagonal blocks counted once.  Sums to n^3 / 3 for a full matrix.
-double cholesky_plan_flops(int nblk, const int* last, int ncols) {
+double cholesky_plan_flops(int nblk, const int* last, int ncols, int tail_rows) {
   double f = 0.0;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
+  if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
+  const int tail0 = nblk - tail_rows;
   for (int c = 0; c < ncols; ++c) {
     const int lm = last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1;
     const int main_rows = lm >= c + 1 ? lm - c : 0;
-    const double h = main_rows + ((c + 1 + main_rows <= nblk - 1 && lm < nblk - 1) ? 1 : 0);
+    const double h = main_rows + std::max(0, nblk - std::max(tail0, c + 1 + main_rows));
     f += 128.0 * 128.0 * 128.0 * (1.0 / 3.0 + h + h * h);
   }
   return f;
 }
 
+std::vector<int> root_envelope(const std::vector<int>& sep_off) {
+  const int nsep = (int)sep_off.size() - 1;
+  if (nsep <= 1) return {};
+  const int total = sep_off[nsep], nblk = (total + 1 + 127) / 128;
+  std::vector<int> first_col(nblk);
+  for (int i = 0; i < nblk; ++i) first_col[i] = i;
+  for (int k = 0; k < nsep; ++k) {
+    const int col = sep_off[k > 0 ? k - 1 : 0] / 128;
+    for (int r = sep_off[k] / 128; r <= (sep_off[k + 1] - 1) / 128 && r < nblk; ++r) first_col[r] = std::min(first_col[r], col);
+  }
+  return cholesky_envelope_last(first_col);
+}
+
 // Envelope from the block rows' first non-zero block columns (first_col[i] <= i for i < nblk-1; the entry of the
 // last block row is ignored: that row is always active): last[c] = max{ i <= nblk-2 : first_col[i] <= c }.
-std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col) {
+std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col, int tail_rows) {
   const int nblk = (int)first_col.size();
+  if (tail_rows < 1) tail_rows = 1;
   std::vector<int> last(nblk);
   for (int c = 0; c < nblk; ++c) last[c] = c < nblk - 1 ? c : nblk - 1;
-  for (int i = 0; i + 1 < nblk; ++i) { const int c = first_col[i] < i ? first_col[i] : i; if (c >= 0 && last[c] < i) last[c] = i; }
+  for (int i = 0; i + tail_rows < nblk; ++i) { const int c = first_col[i] < i ? first_col[i] : i; if (c >= 0 && last[c] < i) last[c] = i; }  // (the tail rows are active in every column anyway)
   for (int c = 1; c < nblk; ++c) if (last[c] < last[c - 1]) last[c] = last[c - 1];
   if (nblk >= 2 && last[nblk - 2] > nblk - 2) last[nblk - 2] = nblk - 2;
   return last;

@@ -175,7 +175,7 @@ size_t potrf128_lds_bytes();
 // ctx == nullptr: everything on `s`; otherwise the panel chain overlaps the trailing SYRK.
 // allow_chain: the grouping is the library's to choose (cholesky_plan): resident panel chain for the chain-bound columns.
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt, const int* last = nullptr, bool allow_chain = false, int ncols = -1);
+                     KernelTimer* kt, const int* last = nullptr, bool allow_chain = false, int ncols = -1, int tail_rows = 1);
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
 bool cholesky_note_info(CholeskyContext* ctx, int info);
 bool cholesky_chain_enabled(const CholeskyContext* ctx);
@@ -184,7 +184,7 @@ struct CholeskyPlan {
   std::vector<int> bounds;  // group start columns + nblk
   std::vector<char> resident;  // per block column: under the resident panel chain
 };
-CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols = -1);
+CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols = -1, int tail_rows = 1);
 int cholesky_plan_max_group(const CholeskyPlan& plan);
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
                         hipStream_t s, KernelTimer* kt, const int* last = nullptr);
@@ -195,6 +195,7 @@ struct FrontView {
   const int* last = nullptr;          // block envelope (nblk entries) or nullptr
   double* Linv = nullptr;             // ncols inverted diagonal blocks
   int rhs_row = 0;                    // row that carries the right-hand side
+  int tail_rows = 1;                  // block rows at the end that are active in every column (cholesky_plan)
 };
 struct DissectedSystem {
   FrontView A, B, R;                  // head, tail (B.ncols == 0: none), root
@@ -213,11 +214,50 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
 // map: root index of each border index (nullptr: identity; < 0: skip)
 void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s);
 void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last);
+                              hipStream_t s, const int* last, int tail_rows = 1);
 void cholesky_gather_map(const double* src, const int* map, double* dst, int m, hipStream_t s);
-double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false, double* c_tiles = nullptr, int ncols = -1);
-double cholesky_plan_flops(int nblk, const int* last, int ncols = -1);
-std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col);
+// --- multi-way dissection: R segments of a block-banded system with R - 1 separators between them ---
+// Leaf front of one segment, in scalar rows.  The interior is followed by a border:
+//   first segment    [right separator, forward | rhs]                         tail_rows 1 — the head of the two-way case
+//   last segment     [left separator, REVERSED | rhs], interior reversed too  tail_rows 1 — the tail of the two-way case
+//   between two      [right separator, forward, padded to whole blocks | left separator, forward | rhs]
+//                    eliminated front to back: its last columns reach the right separator as part of their contiguous run;
+//                    the left separator couples with the FIRST columns and fills in along the whole interior (the spike):
+//                    its block rows are the tail rows of the partial factorisation (cholesky_plan).
+struct SegmentLayout {
+  int ncols = 0, nblk = 0, tail_rows = 1;
+  int rhs_row = 0;                    // absolute row of the right-hand side in the front
+  int right_off = -1, left_off = -1;  // first border row (relative to the border) of the right / left separator; -1: none
+  bool reversed = false;
+};
+inline SegmentLayout segment_layout(int interior_n, int left_n, int right_n) {
+  SegmentLayout L;
+  L.ncols = (interior_n + 127) / 128;
+  if (left_n <= 0) {          // first segment (or the only one)
+    L.right_off = 0;
+    L.nblk = L.ncols + (right_n + 1 + 127) / 128;
+    L.rhs_row = L.ncols * 128 + right_n;
+  } else if (right_n <= 0) {  // last segment
+    L.left_off = 0; L.reversed = true;
+    L.nblk = L.ncols + (left_n + 1 + 127) / 128;
+    L.rhs_row = L.ncols * 128 + left_n;
+  } else {
+    const int rb = (right_n + 127) / 128;
+    L.right_off = 0; L.left_off = rb * 128;
+    L.tail_rows = (left_n + 1 + 127) / 128;
+    L.nblk = L.ncols + rb + L.tail_rows;
+    L.rhs_row = L.ncols * 128 + L.left_off + left_n;
+  }
+  return L;
+}
+// Block envelope of the root (every separator in sequence order, then the right-hand side): separator k couples with
+// separator k - 1 through the Schur complement of the segment between them.  sep_off: R entries, scalar offset of each
+// separator in the root and, last, their total.  Empty result: dense (one separator).
+std::vector<int> root_envelope(const std::vector<int>& sep_off);
+
+double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false, double* c_tiles = nullptr, int ncols = -1, int tail_rows = 1);
+double cholesky_plan_flops(int nblk, const int* last, int ncols = -1, int tail_rows = 1);
+std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col, int tail_rows = 1);
 std::vector<int> cholesky_group_bounds(int nblk, int group);
 void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,
                       KernelTimer* kt);

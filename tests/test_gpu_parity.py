@@ -213,6 +213,43 @@ def test_dissected_factorisation_vs_numpy(shape, head_block, automatic):
             sk.api.cholesky_solve_dissected(A, b, head, reach, group=2)
 
 
+@pytest.mark.parametrize("shape,starts,automatic", [("band", (9, 19, 30), True), ("band", (9, 19, 30), False), ("long-band", (6, 17, 28, 39, 50, 61, 72), True),
+                                                    ("two-wide-parts", (4, 30, 58), True), ("resident-then-wide-then-resident", (3, 45), True),
+                                                    ("band", (20,), True)])
+def test_multiway_dissected_factorisation_vs_numpy(shape, starts, automatic):
+    """Multi-way dissection (sk_cholesky_solve_segments — the arithmetic of the segmented distribution over 2, 4 and 8
+    devices, run on one): the band cut into len(starts) + 1 segments, every segment eliminated on its own — the ones
+    between two separators with the left separator's rows active in every column (the spike: cholesky_plan's tail rows)
+    — and the separators' block-tridiagonal system last, against numpy's solution of the whole system.  Cuts off the
+    block grid; separators of different widths; two, three, four and eight segments."""
+    heights = dict(_PLAN_SHAPES, **{"long-band": [4] * 84})[shape]
+    nblk = len(heights) + 1
+    first_col = np.arange(nblk)
+    for c, h in enumerate(heights):
+        for r in range(c, min(nblk - 1, c + h + 1)):
+            first_col[r] = min(first_col[r], c)
+    last = _envelope_last(first_col)
+    n = 128 * nblk - 70
+    A = _banded_spd(n, last, seed=len(shape) + len(starts))
+    b = np.random.default_rng(7).normal(size=n)
+    Af = A + np.tril(A, -1).T
+    xnp = np.linalg.solve(Af, b)
+    cuts, prev_end = [], 0
+    for k, blk in enumerate(starts):
+        begin = max(prev_end + 50, 128 * blk - 37 - 11 * k)
+        reach = int(np.max(np.nonzero(np.abs(A[:, :begin]).sum(axis=1))[0]))  # last row coupled with anything before the cut
+        end = max(begin, reach + 1)
+        cuts.append((begin, end))
+        prev_end = end
+    assert prev_end < n - 50
+    x = sk.api.cholesky_solve_segments(A, b, cuts, group=0 if automatic else 2, automatic_plan=automatic)
+    assert np.linalg.norm(x - xnp) <= 1e-11 * np.linalg.norm(xnp), (shape, cuts, np.linalg.norm(x - xnp) / np.linalg.norm(xnp))
+    with pytest.raises(sk.SkeresError):  # not a separator
+        bad = list(cuts)
+        bad[0] = (cuts[0][0], cuts[0][1] - 1)
+        sk.api.cholesky_solve_segments(A, b, bad, group=2)
+
+
 def test_cholesky_mfma_layout_asymmetric():
     # A = L0 L0^T with an asymmetric integer-valued L0: a swapped row/col map in the
     # MFMA C/D layout cannot reproduce L0.
