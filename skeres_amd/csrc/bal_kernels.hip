@@ -29,19 +29,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Where the reduced camera system keeps block (camera i rows, camera j columns), i >= j, and the right-hand side of
 // camera i (BalDev::front).
-__device__ __forceinline__ int bal_part(const BalDev& d, int i) { return i < d.cam_a ? 0 : (i < d.cam_b ? 1 : 2); }
-__device__ __forceinline__ int bal_pos(const BalDev& d, int i, int part) { return 9 * (i - (part == 0 ? 0 : (part == 1 ? d.cam_a : d.cam_b))); }
+__device__ __forceinline__ int bal_part(const BalDev& d, int i) { return i >= d.cam_b ? 2 : ((i >= d.seg_lo && i < d.cam_a) ? 0 : 1); }
+__device__ __forceinline__ int bal_pos(const BalDev& d, int i, int part) { return 9 * (i - (part == 0 ? d.seg_lo : (part == 1 ? d.cam_a : d.cam_b))); }
 __device__ __forceinline__ double* bal_block(const BalDev& d, int i, int j, int* ld) {
   const int pj = bal_part(d, j), pi = bal_part(d, i);
   const BalDev::Front& f = d.front[pj];
-  const int row = pi == pj ? bal_pos(d, i, pi) : f.interior + (pj == 1 ? 9 * (d.C - 1 - i) : 9 * (i - d.cam_b));
+  const int row = pi == pj ? bal_pos(d, i, pi) : f.border_row[i - d.cam_b];
   *ld = f.ld;
   return f.S + (size_t)row * f.ld + bal_pos(d, j, pj);
 }
 __device__ __forceinline__ double* bal_rhs(const BalDev& d, int i) {
   const int pi = bal_part(d, i);
   const BalDev::Front& f = d.front[pi];
-  return f.S + (size_t)((pi == 2 ? 0 : f.interior) + d.rhs_off) * f.ld + bal_pos(d, i, pi);
+  return f.S + (size_t)f.rhs_row * f.ld + bal_pos(d, i, pi);
 }
 
 // Block-level sum of up to 4 values; result valid in thread 0.

@@ -48,16 +48,17 @@ struct BalDev {
   // per-point
   double* M;  double* q;
   // Reduced camera system: up to three dense row-major matrices ("fronts", chol_kernels.hip "Two-way dissection"), lower
-  // triangles.  Cameras are numbered head [0, cam_a), tail [cam_a, cam_b) (in ITS elimination order: back to front along
-  // the sequence), separator [cam_b, C).  Block (i, j), i >= j, lives in the front of camera j's part — head 0, tail 1,
-  // separator 2 (the root) — at column 9 (j - first camera of the part); its rows are camera i's interior rows when i is in
-  // the same part, else (i in the separator) rows of the leaf's border: interior + 9 (i - cam_b) in the head's front,
-  // interior + 9 (C - 1 - i) in the tail's (border in reverse camera order).  The right-hand side of a part's cameras is
-  // the row `rhs_off` of the border (of the root itself for the separator).  Without dissection cam_a == cam_b == 0:
-  // every camera is "separator", front[2] is the whole system and rhs_off == 9 C.
-  struct Front { double* S; int ld; int interior; };
+  // triangles.  Part of camera i: 2 (separators, the root front) when i >= cam_b; 0 when seg_lo <= i < cam_a (one device:
+  // the head, seg_lo == 0; a rank of a segmented world: ITS segment); otherwise 1 — one device: the tail [cam_a, cam_b), in
+  // its elimination order, back to front along the sequence; a rank of a segmented world: the other ranks' segments, which
+  // have no front here (front[1].S == nullptr) and no observation among this rank's.  Block (i, j), i >= j, lives in the
+  // front of camera j's part at column 9 (j - first camera of the part); its rows are camera i's interior rows when i is in
+  // the same part, else (i is a separator camera) row border_row[i - cam_b] of that front — the leaf's border, laid out as
+  // chol_kernels.hpp's SegmentLayout says.  The right-hand side of a part's cameras is the front's row `rhs_row`.
+  // Without dissection seg_lo == cam_a == cam_b == 0: every camera is "separator" and front[2] is the whole system.
+  struct Front { double* S; int ld; int interior; int rhs_row; const int* border_row; };
   Front front[3];
-  int cam_a, cam_b, rhs_off;
+  int seg_lo, cam_a, cam_b;
   const double* y_front[3];  // the fronts' solutions (interior order) -> y_c (bal_gather_y)
   double* S;  int ld;  int rhs_row;  // == front[2] when the system is not dissected (the all-reduce packs this one)
   // reductions

@@ -110,14 +110,14 @@ class BalSolver : public SolverBase {
   // over the fronts of the reduced system (one when it is not dissected); the tail front is factored launch by launch
   double syrk_flops_per_solve() const override {
     double f = 0.0;
-    for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && k != 1, nullptr, fr_[k].ncols);
+    for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && k != 1, nullptr, fr_[k].ncols, fr_[k].tail_rows);
     return f;
   }
   double syrk_c_bytes_per_solve() const override {
     double tiles = 0.0;
     for (int k = 0; k < 3; ++k) {
       double t = 0.0;
-      if (fr_[k].nblk > 0) (void)cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && k != 1, &t, fr_[k].ncols);
+      if (fr_[k].nblk > 0) (void)cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && k != 1, &t, fr_[k].ncols, fr_[k].tail_rows);
       tiles += t;
     }
     return tiles * 2.0 * 128.0 * 128.0 * sizeof(double);
@@ -140,7 +140,7 @@ class BalSolver : public SolverBase {
         const int* env = F.env();
         for (int c = 0; c < F.ncols; ++c) {
           const int lm = env ? std::min(env[c], F.nblk - 1) : F.nblk - 1;
-          in += (lm - c + 1) + (lm < F.nblk - 1 ? 1 : 0);  // the run from the diagonal block down, and the right-hand-side row
+          in += (lm - c + 1) + std::max(0, F.nblk - std::max(F.nblk - F.tail_rows, lm + 1));  // the run from the diagonal block down, and the tail rows (right-hand side)
         }
       }
       *value = in / (0.5 * nblk * (nblk + 1.0));
@@ -150,7 +150,7 @@ class BalSolver : public SolverBase {
     if (name == "cholesky_flops_full") { const double n = 9.0 * C_; *value = n * n * n / 3.0; return true; }
     if (name == "cholesky_flops_plan") {
       double f = 0.0;
-      for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_plan_flops(fr_[k].nblk, fr_[k].env(), fr_[k].ncols);
+      for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_plan_flops(fr_[k].nblk, fr_[k].env(), fr_[k].ncols, fr_[k].tail_rows);
       *value = f;
       return true;
     }
@@ -158,7 +158,7 @@ class BalSolver : public SolverBase {
       int r = 0;
       for (int k = 0; k < 3; ++k) {
         if (fr_[k].nblk == 0) continue;
-        const CholeskyPlan plan = cholesky_plan(fr_[k].nblk, group_, fr_[k].env(), chain_live() && k != 1, fr_[k].ncols);
+        const CholeskyPlan plan = cholesky_plan(fr_[k].nblk, group_, fr_[k].env(), chain_live() && k != 1, fr_[k].ncols, fr_[k].tail_rows);
         for (char c : plan.resident) r += c ? 1 : 0;
       }
       *value = r;
@@ -167,6 +167,9 @@ class BalSolver : public SolverBase {
     if (name == "allreduce_bytes") { *value = (double)packed_elems_ * sizeof(double); return true; }
     if (name == "allreduce_bytes_full_triangle") { *value = (double)tri_packed_elems(nblk) * sizeof(double); return true; }
     if (name == "dissected") { *value = dissected_ ? 1.0 : 0.0; return true; }
+    if (name == "segments") { *value = segmented_ ? segments_ : (dissected_ ? 2 : 1); return true; }
+    if (name == "segment_cameras") { *value = segmented_ ? my_hi_ - my_lo_ : C_; return true; }
+    if (name.rfind("model_us_segments_", 0) == 0) { const int k = atoi(name.c_str() + 18); if (k < 1 || k > 8) return false; *value = model_us_[k]; return true; }
     if (name == "dissection_head_cameras") { *value = cam_a_; return true; }
     if (name == "dissection_tail_cameras") { *value = cam_b_ - cam_a_; return true; }
     if (name == "dissection_separator_cameras") { *value = dissected_ ? C_ - cam_b_ : 0; return true; }
@@ -229,15 +232,26 @@ class BalSolver : public SolverBase {
     int nblk = 0, ncols = 0, cams = 0;   // block rows; block columns factored here; cameras eliminated here
     size_t dim = 0, s_off = 0, linv_off = 0, y_off = 0;
     int rhs_row = 0;
+    int tail_rows = 1;                   // block rows at the end that every column reaches (cholesky_plan): > 1 for a segment between two separators
     std::vector<int> last;               // block envelope (empty: dense)
     const int* env() const { return last.empty() ? nullptr : last.data(); }
   };
   FrontHost fr_[3];
   bool dissected_ = false;
-  bool segmented_ = false;  // several ranks: this rank holds ONE leaf front (role_: 0 head, 1 tail) and the root
-  int role_ = 0;
-  int fold_world_ = 0;      // ranks whose contributions count in gather_rank_scalars (0: all; segmented: the first two)
+  // Several ranks (SK_DISTRIBUTION_SEGMENTED): the camera sequence is cut into segments_ segments with a separator between
+  // neighbours; this rank holds ONE leaf front (fr_[0]: segment role_, cameras [my_lo_, my_hi_) of the final numbering)
+  // and the root (every separator).  Ranks beyond segments_ replicate rank (r mod segments_) and add zeros to every sum.
+  bool segmented_ = false;
+  int segments_ = 0, role_ = 0, my_lo_ = 0, my_hi_ = 0;
+  bool replica_ = false;
+  int fold_world_ = 0;      // ranks whose contributions count in gather_rank_scalars (0: all; segmented: the first segments_)
   int cam_a_ = 0, cam_b_ = 0, border_blocks_ = 0;
+  std::vector<int> seg_off_;   // dissected: first camera of every segment in the final numbering, then cam_b_
+  std::vector<int> sep_first_; // ... and of every separator, then C_
+  std::vector<int> root_last_; // segmented: block envelope of the root (empty: dense — one separator)
+  FrontView leaf_;             // segmented: this rank's leaf front
+  DevBuf<int> b_border_row_[2], b_leaf_map_, b_leaf_gmap_;  // separator camera -> row of a leaf's border; border index -> root index (gmap: rhs row -> -1)
+  double model_us_[9] = {0};   // the chain model's prediction per number of segments (index: segments; [1] = undissected)
   double dissect_t_plain_ = 0.0, dissect_t_model_ = 0.0;
   DissectedSystem ds_;
   CholeskyContext chol_ctx_b_;
@@ -356,7 +370,7 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
 // no rows in it; `interior[c]` whether its columns are eliminated in this front.  Only points that touch an interior
 // camera shape the envelope (the border x border block is the Schur complement's, covered by the last columns' reach).
 static std::vector<int> front_envelope(const std::vector<int>& ocam, const std::vector<int>& opt, const std::vector<int>& pos, const std::vector<char>& interior,
-                                       int P, int nblk) {
+                                       int P, int nblk, int tail_rows = 1) {
   const int kNone = 1 << 30;
   std::vector<int> minpos(P, kNone);
   for (size_t b = 0; b < ocam.size(); ++b) if (interior[ocam[b]]) minpos[opt[b]] = std::min(minpos[opt[b]], pos[ocam[b]]);
@@ -368,7 +382,97 @@ static std::vector<int> front_envelope(const std::vector<int>& ocam, const std::
     const int col = minpos[opt[b]] / 128;
     for (int row = pos[c] / 128; row <= (pos[c] + 8) / 128; ++row) first_col[row] = std::min(first_col[row], std::min(col, row));
   }
-  return cholesky_envelope_last(first_col);
+  return cholesky_envelope_last(first_col, tail_rows);
+}
+
+// ---- multi-way dissection over the ranks of a world ---------------------------------------------------
+// R segments of the camera sequence with a separator between neighbours: separator k (1 <= k < R) = cameras [a[k-1], b[k-1])
+// of the banded numbering, b = 1 + the last camera that shares a point with a camera before a.  Every segment is
+// eliminated on a device of its own — the last one back to front, the others front to back — and the separators'
+// block-tridiagonal system by every rank.  The cuts balance the segments' chains under the same model of a block
+// column's cost as choose_dissection; the number of segments (at most max_segments) is the one with the shortest
+// predicted critical path.  forced: cut wherever separators exist (tests, small problems), as evenly as the sequence allows.
+struct Segments { std::vector<int> a, b; double t_plain = 0.0, t_model = 0.0; double model_us[9] = {0}; };
+static Segments choose_segments(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
+                                const std::vector<int>& first_col, int max_segments, bool forced) {
+  Segments out;
+  max_segments = std::min(max_segments, 8);
+  if (max_segments < 2 || C < 6) return out;
+  std::vector<int> cmin(P, C), cmax(P, -1), reach(C);
+  for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); }
+  for (int c = 0; c < C; ++c) reach[c] = c;
+  for (int q = 0; q < P; ++q) if (cmax[q] >= 0) reach[cmin[q]] = std::max(reach[cmin[q]], cmax[q]);
+  for (int c = 1; c < C; ++c) reach[c] = std::max(reach[c], reach[c - 1]);
+  if (C >= 64 && nblk >= 24) {
+    std::vector<double> fwd(nblk), bwd(nblk), fwd_sum(nblk + 1, 0.0), bwd_sum(nblk + 1, 0.0);
+    std::vector<int> fc(first_col);
+    for (int i = nblk - 2; i >= 0; --i) fc[i] = std::min(fc[i], fc[i + 1] < i + 1 ? fc[i + 1] : i);
+    for (int c = 0; c < nblk; ++c) {
+      const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0);
+      fwd[c] = column_cost_us(hf, true);
+      bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1, true);
+      out.t_plain += fwd[c];
+    }
+    for (int c = 0; c < nblk; ++c) { fwd_sum[c + 1] = fwd_sum[c] + fwd[c]; bwd_sum[c + 1] = bwd_sum[c] + bwd[c]; }
+    out.model_us[1] = out.t_plain;
+    auto sep_blocks = [&](int a) { return (9 * (reach[a - 1] + 1 - a) + 1 + 127) / 128; };
+    // can the sequence be cut into Rn segments none of whose chains is longer than T?  Greedy: every segment as long as T allows.
+    auto plan_for = [&](int Rn, double T, std::vector<int>* as) {
+      int pos = 0;
+      as->clear();
+      for (int sgm = 0; sgm + 1 < Rn; ++sgm) {
+        int best_a = -1;
+        for (int a = ((pos + 14 + 6) / 7) * 7; a + 14 < C; a += 7) {
+          const int b = reach[a - 1] + 1;
+          if (b >= C - 14 - 42 * (Rn - 2 - sgm)) break;  // (room for the cuts still to come: a generous T must not spend the whole sequence on this segment)
+          if (fwd_sum[(9 * a + 127) / 128] - fwd_sum[(9 * pos) / 128] > T) break;
+          if (sep_blocks(a) <= 24) best_a = a;
+        }
+        if (best_a < 0) return false;
+        as->push_back(best_a);
+        pos = reach[best_a - 1] + 1;
+      }
+      return bwd_sum[nblk] - bwd_sum[(9 * pos) / 128] <= T;
+    };
+    double best = out.t_plain;
+    std::vector<int> best_as;
+    for (int Rn = 2; Rn <= max_segments; ++Rn) {
+      std::vector<int> as;
+      if (!plan_for(Rn, out.t_plain, &as)) break;
+      double lo = 0.0, hi = out.t_plain;
+      for (int it = 0; it < 40; ++it) { const double mid = 0.5 * (lo + hi); if (plan_for(Rn, mid, &as)) hi = mid; else lo = mid; }
+      (void)plan_for(Rn, hi, &as);
+      double root = 0.0;  // the separators' block-tridiagonal system, one resident column after the other, on every rank
+      for (size_t k = 0; k < as.size(); ++k) {
+        const int E = sep_blocks(as[k]), Enext = k + 1 < as.size() ? sep_blocks(as[k + 1]) : 0;
+        for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i + Enext, true);
+      }
+      const double t = hi + root + 220.0;  // + fork, join, border add, the all-reduce of the root
+      out.model_us[Rn] = t;
+      if (forced ? true : t < best) { best = t; best_as = as; }  // (forced: a segment per rank, as far as the sequence can be cut)
+    }
+    out.t_model = best;
+    if (!best_as.empty() && (forced || best <= 0.9 * out.t_plain)) {
+      for (int a : best_as) { out.a.push_back(a); out.b.push_back(reach[a - 1] + 1); }
+      return out;
+    }
+  }
+  if (!forced) return out;
+  for (int Rn = max_segments; Rn >= 2 && out.a.empty(); --Rn) {
+    std::vector<int> as, bs;
+    int pos = 0;
+    bool ok = true;
+    for (int k = 1; k < Rn && ok; ++k) {
+      // the cut nearest to the k-th Rn-th of the sequence (from there towards the front) whose separator leaves room behind it
+      int a = std::min(C - 1, std::max(pos + 1, (int)((long)k * C / Rn)));
+      while (a > pos && reach[a - 1] + 1 >= C - (Rn - 1 - k)) --a;
+      if (a <= pos) { ok = false; break; }
+      as.push_back(a); bs.push_back(reach[a - 1] + 1);
+      pos = bs.back();
+    }
+    if (ok && pos < C) { out.a = as; out.b = bs; }
+  }
+  return out;
 }
 
 static std::vector<int> rcm_order(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P) {
@@ -564,8 +668,8 @@ int BalSolver::setup() {
   {
     const int nblk = npad_ / 128;
     // ---- dissect?  One process: only when forced (measured not to pay on one chip).  Several ranks: the SEGMENTED
-    // distribution — the head's chain on the even ranks' devices, the tail's on the odd ranks' — when the model of the two
-    // chains predicts a gain (or when asked for). ----
+    // distribution — every rank's device eliminates one segment of the camera sequence — when the model of the chains
+    // predicts a gain (or when asked for). ----
     const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0;
     const bool multi = opt_.allreduce != nullptr && opt_.world >= 2;
     bool may_dissect = plan_ok && (multi ? (opt_.distribution_mode == SK_DISTRIBUTION_AUTO || opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED)
@@ -575,17 +679,26 @@ int BalSolver::setup() {
       set_error("the segmented distribution needs the library's own factorisation plan (envelope, look-ahead, no explicit group); not supported with these options");
       return SK_ERR_UNSUPPORTED;
     }
-    Dissection ds;
-    if (may_dissect) {
+    std::vector<int> cut_a, cut_b;  // the separators [a, b) in the banded numbering, ascending
+    if (may_dissect && multi) {
       std::vector<int> first_col;
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
-      ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, multi);
+      int max_seg = opt_.world;
+      if (const char* e = getenv("SK_SEGMENTS")) max_seg = std::max(2, std::min(max_seg, atoi(e)));  // developer knob: at most that many segments
+      const Segments sg = choose_segments(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, max_seg, opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED);
+      cut_a = sg.a; cut_b = sg.b;
+      dissect_t_plain_ = sg.t_plain; dissect_t_model_ = sg.t_model;
+      for (int k = 0; k < 9; ++k) model_us_[k] = sg.model_us[k];
+    } else if (may_dissect) {
+      Dissection ds;
+      std::vector<int> first_col;
+      (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
+      ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, false);
       // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
       // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon there.
-      if (!multi && opt_.dissection == SK_DISSECTION_AUTO && !getenv("SK_DISSECT_AT")) { ds.a = ds.b = 0; }
-      const bool forced = multi ? opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED : opt_.dissection == SK_DISSECTION_ON;
-      if (forced && ds.a == 0 && C_ >= 6) {
+      if (opt_.dissection == SK_DISSECTION_AUTO && !getenv("SK_DISSECT_AT")) { ds.a = ds.b = 0; }
+      if (opt_.dissection == SK_DISSECTION_ON && ds.a == 0 && C_ >= 6) {
         // forced (tests, small problems): cut at the middle camera wherever that leaves a tail
         std::vector<int> cmin(P_total_, C_), cmax(P_total_, -1);
         for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); }
@@ -606,37 +719,62 @@ int BalSolver::setup() {
         } else ds.a = 0;
       }
       dissect_t_plain_ = ds.t_plain; dissect_t_model_ = ds.t_dissected;
+      model_us_[1] = ds.t_plain; model_us_[2] = ds.t_dissected;
+      if (ds.a > 0 && ds.b < C_) { cut_a.push_back(ds.a); cut_b.push_back(ds.b); }
     }
-    if (multi && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && !(ds.a > 0 && ds.b < C_)) {
+    if (multi && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && cut_a.empty()) {
       set_error("the segmented distribution needs a separator in the camera sequence (no point seen from both ends); not supported for this problem");
       return SK_ERR_UNSUPPORTED;
     }
-    if (ds.a > 0 && ds.b < C_) {
+    if (!cut_a.empty()) {
       dissected_ = true;
       segmented_ = multi;
-      // final numbering: head [0, a) as it is, tail [b, C) REVERSED to [a, a + C - b), separator [a, b) last
-      const int a = ds.a, b = ds.b, nt = C_ - b;
+      // final numbering: the segments one after the other — the last one REVERSED (it is eliminated back to front) —
+      // then the separators, in sequence order
+      const int R = (int)cut_a.size() + 1;
+      seg_off_.assign(R + 1, 0);
+      for (int sg = 0; sg < R; ++sg) {
+        const int lo = sg == 0 ? 0 : cut_b[sg - 1], hi = sg + 1 < R ? cut_a[sg] : C_;
+        seg_off_[sg + 1] = seg_off_[sg] + (hi - lo);
+      }
+      cam_b_ = seg_off_[R];
       std::vector<int> fin(C_);
-      for (int c = 0; c < C_; ++c) fin[c] = c < a ? c : (c >= b ? a + (C_ - 1 - c) : a + nt + (c - a));
+      int sep_pos = cam_b_;
+      for (int sg = 0; sg < R; ++sg) {
+        const int lo = sg == 0 ? 0 : cut_b[sg - 1], hi = sg + 1 < R ? cut_a[sg] : C_;
+        for (int c = lo; c < hi; ++c) fin[c] = sg + 1 < R ? seg_off_[sg] + (c - lo) : seg_off_[sg] + (hi - 1 - c);
+        if (sg + 1 < R) { sep_first_.push_back(sep_pos); for (int c = cut_a[sg]; c < cut_b[sg]; ++c) fin[c] = sep_pos++; }
+      }
+      sep_first_.push_back(C_);
       std::vector<int> cb2(C_);
       for (int c = 0; c < C_; ++c) cb2[fin[c]] = cam_block_[c];
       cam_block_.swap(cb2);
       for (int& c : ocam) c = fin[c];
-      cam_a_ = a; cam_b_ = a + nt;
+      cam_a_ = seg_off_[1];  // (one device: the head [0, cam_a_), the tail [cam_a_, cam_b_))
+      segments_ = R;
     }
   }
   if (segmented_) {
-    // Ranks 0 and 1 own the head and the tail; further ranks are replicas of rank (r mod 2): they do the same work and add
-    // zeros to every sum.  What is exchanged per iteration: the root front (the separator's system with both Schur
-    // complements), the separator cameras' column norms and gradient, and a handful of scalars.
+    // Rank r < segments_ owns segment r; further ranks are replicas of rank (r mod segments_): they do the same work and
+    // add zeros to every sum.  What is exchanged per iteration: the root front (the separators' block-tridiagonal system
+    // with the segments' Schur complements), the cameras' column norms and gradient, and a handful of scalars.
     distribution_ = SK_DISTRIBUTION_SEGMENTED;
-    role_ = opt_.rank % 2;
-    fold_world_ = 2;
-    const int nsep = C_ - cam_b_, E = (9 * nsep + 1 + 127) / 128;
-    packed_elems_ = tri_packed_elems(E);
+    role_ = opt_.rank % segments_;
+    replica_ = opt_.rank >= segments_;
+    fold_world_ = segments_;
+    my_lo_ = seg_off_[role_]; my_hi_ = seg_off_[role_ + 1];
+    std::vector<int> sep_off;  // scalar offsets of the separators in the root, then their total
+    for (int f : sep_first_) sep_off.push_back(9 * (f - cam_b_));
+    root_last_ = root_envelope(sep_off);
+    const int E = (9 * (C_ - cam_b_) + 1 + 127) / 128;
     pack_col0_h_.assign(E, 0);
     pack_off_h_.assign(E + 1, 0);
-    for (int kb = 0; kb < E; ++kb) pack_off_h_[kb + 1] = pack_off_h_[kb] + (long long)128 * 128 * (kb + 1);
+    if (!root_last_.empty()) {
+      int c = 0;
+      for (int i = 0; i + 1 < E; ++i) { while (c < i && root_last_[c] < i) ++c; pack_col0_h_[i] = c; }
+    }
+    for (int kb = 0; kb < E; ++kb) pack_off_h_[kb + 1] = pack_off_h_[kb] + (long long)128 * 128 * (kb + 1 - pack_col0_h_[kb]);
+    packed_elems_ = (size_t)pack_off_h_[E];
   }
   if (opt_.allreduce) {
     if (opt_.reduce_buffer) {
@@ -656,10 +794,17 @@ int BalSolver::setup() {
   // separator alone ----
   std::vector<int> local_of(P_total_, -1);
   if (segmented_) {
-    std::vector<char> touches(P_total_, 0);  // bit 0 head, 1 tail, 2 separator
-    for (int b = 0; b < Nall; ++b) touches[opt[b]] |= (char)(ocam[b] < cam_a_ ? 1 : (ocam[b] < cam_b_ ? 2 : 4));
+    std::vector<int> seg_of_cam(C_, -1);  // (separator cameras: -1)
+    for (int sg = 0; sg < segments_; ++sg) for (int c = seg_off_[sg]; c < seg_off_[sg + 1]; ++c) seg_of_cam[c] = sg;
+    std::vector<int> seg_of_pt(P_total_, -1);
+    for (int b = 0; b < Nall; ++b) {
+      const int sg = seg_of_cam[ocam[b]];
+      if (sg < 0) continue;
+      if (seg_of_pt[opt[b]] >= 0 && seg_of_pt[opt[b]] != sg) { set_error("internal: a point is seen from two segments of the camera sequence"); return SK_ERR_UNSUPPORTED; }
+      seg_of_pt[opt[b]] = sg;
+    }
     for (int q = 0; q < P_total_; ++q) {
-      const bool mine = (touches[q] & (role_ == 0 ? 1 : 2)) || (touches[q] == 4 && (q % 2) == role_);
+      const bool mine = seg_of_pt[q] == role_ || (seg_of_pt[q] < 0 && (q % segments_) == role_);
       if (mine) { local_of[q] = (int)local_pt_.size(); local_pt_.push_back(q); }
     }
   } else {
@@ -771,28 +916,46 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
   // ---- the fronts of the reduced camera system ----
+  std::vector<int> border_row_h[2], leaf_map_h, leaf_gmap_h;
   if (!dissected_) {
     FrontHost& r = fr_[2];
     r.nblk = r.ncols = npad_ / 128; r.cams = C_; r.dim = (size_t)npad_; r.rhs_row = rhs_row_; r.last = env_last_;
     border_blocks_ = 0;
   } else {
-    const int nsep = C_ - cam_b_, ncam[2] = {cam_a_, cam_b_ - cam_a_};
-    border_blocks_ = (9 * nsep + 1 + 127) / 128;
+    const int nsep = C_ - cam_b_;
+    // the leaf fronts this device holds: one device — the head (0) and the tail (1); a rank of a segmented world — its segment (0)
     for (int f = 0; f < 2; ++f) {
-      if (segmented_ && f != role_) continue;  // the other segment's front lives on the other rank's device
+      if (segmented_ && f != 0) continue;
+      const int seg = segmented_ ? role_ : f;
+      const int lo = seg_off_[seg], hi = seg_off_[seg + 1];
+      // the separators next to the segment (cameras of the final numbering): left [ll, lh), right [rl, rh)
+      const int ll = seg > 0 ? sep_first_[seg - 1] : 0, lh = seg > 0 ? sep_first_[seg] : 0;
+      const int rl = seg + 1 < segments_ ? sep_first_[seg] : 0, rh = seg + 1 < segments_ ? sep_first_[seg + 1] : 0;
+      const SegmentLayout lay = segment_layout(9 * (hi - lo), 9 * (lh - ll), 9 * (rh - rl));
       FrontHost& L = fr_[f];
-      L.cams = ncam[f]; L.ncols = (9 * ncam[f] + 127) / 128; L.nblk = L.ncols + border_blocks_; L.dim = (size_t)L.nblk * 128;
-      L.rhs_row = L.ncols * 128 + 9 * nsep;
-      // rows of every camera in this front: its own interior, or (separator) the border — in reverse camera order for the tail
+      L.cams = hi - lo; L.ncols = lay.ncols; L.nblk = lay.nblk; L.dim = (size_t)L.nblk * 128; L.rhs_row = lay.rhs_row; L.tail_rows = lay.tail_rows;
+      // rows of every camera in this front: its own interior, or (a separator next to it) the border
       std::vector<int> pos(C_, -1);
       std::vector<char> interior(C_, 0);
-      const int base = f == 0 ? 0 : cam_a_;
-      for (int c = base; c < base + ncam[f]; ++c) { pos[c] = 9 * (c - base); interior[c] = 1; }
-      for (int c = cam_b_; c < C_; ++c) pos[c] = L.ncols * 128 + (f == 0 ? 9 * (c - cam_b_) : 9 * (C_ - 1 - c));
-      L.last = front_envelope(ocam, opt, pos, interior, P_total_, L.nblk);
+      for (int c = lo; c < hi; ++c) { pos[c] = 9 * (c - lo); interior[c] = 1; }
+      const int bo = L.ncols * 128;
+      for (int c = rl; c < rh; ++c) pos[c] = bo + lay.right_off + 9 * (c - rl);
+      for (int c = ll; c < lh; ++c) pos[c] = bo + lay.left_off + (lay.reversed ? 9 * (lh - 1 - c) : 9 * (c - ll));
+      L.last = front_envelope(ocam, opt, pos, interior, P_total_, L.nblk, L.tail_rows);
+      border_row_h[f].assign(std::max(1, nsep), 0);
+      for (int c = cam_b_; c < C_; ++c) border_row_h[f][c - cam_b_] = pos[c] >= 0 ? pos[c] : 0;  // (a separator that is not next to the segment: no block of it here)
+      if (segmented_) {
+        // border index -> root index (cholesky_border_add, cholesky_gather_map): separator cameras, and the right-hand-side row
+        leaf_map_h.assign((size_t)(L.nblk - L.ncols) * 128, -1);
+        for (int c = cam_b_; c < C_; ++c) if (pos[c] >= 0) for (int k = 0; k < 9; ++k) leaf_map_h[pos[c] - bo + k] = 9 * (c - cam_b_) + k;
+        leaf_gmap_h = leaf_map_h;
+        leaf_map_h[L.rhs_row - bo] = 9 * nsep;
+      }
     }
+    border_blocks_ = segmented_ ? fr_[0].nblk - fr_[0].ncols : (9 * nsep + 1 + 127) / 128;
     FrontHost& r = fr_[2];
-    r.nblk = r.ncols = border_blocks_; r.cams = nsep; r.dim = (size_t)border_blocks_ * 128; r.rhs_row = 9 * nsep;  // dense
+    r.nblk = r.ncols = (9 * nsep + 1 + 127) / 128; r.cams = nsep; r.dim = (size_t)r.nblk * 128; r.rhs_row = 9 * nsep;
+    r.last = root_last_;  // (one separator: dense)
   }
   {
     size_t s_off = 0, linv_off = 0, y_off = 0;
@@ -817,17 +980,19 @@ int BalSolver::setup() {
     std::vector<int> col0(F.nblk, 0);
     // the widest group of either way to factor (with / without the resident chain, which a timing mode switches off)
     const bool chain_here = chain_ok() && f != 1;
-    const int widen = F.last.empty() ? 1 : std::max(group_, cholesky_plan_max_group(cholesky_plan(F.nblk, group_, F.last.data(), chain_here, F.ncols)));
+    const int widen = F.last.empty() ? 1 : std::max(group_, cholesky_plan_max_group(cholesky_plan(F.nblk, group_, F.last.data(), chain_here, F.ncols, F.tail_rows)));
     if (!F.last.empty()) {
       int c = 0;
-      for (int i = 0; i + 1 < F.nblk; ++i) {
+      for (int i = 0; i + F.tail_rows < F.nblk; ++i) {  // (the tail rows: from column 0)
         while (c < i && F.last[c] < i) ++c;
         col0[i] = std::max(0, c - (widen - 1));
       }
     }
     SK_HIP_TRY(b_zero_col0_f_[f].upload(col0, s));
   }
-  if (dissected_) {
+  for (int f = 0; f < 2; ++f) if (!border_row_h[f].empty()) SK_HIP_TRY(b_border_row_[f].upload(border_row_h[f], s));
+  if (segmented_) { SK_HIP_TRY(b_leaf_map_.upload(leaf_map_h, s)); SK_HIP_TRY(b_leaf_gmap_.upload(leaf_gmap_h, s)); }
+  if (dissected_ && !segmented_) {
     const int nsep = C_ - cam_b_;
     std::vector<int> mapB((size_t)border_blocks_ * 128, -1);
     for (int k = 0; k < nsep; ++k) for (int c = 0; c < 9; ++c) mapB[9 * k + c] = 9 * (nsep - 1 - k) + c;  // camera order reversed, coordinates in order
@@ -851,11 +1016,17 @@ int BalSolver::setup() {
   d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.Fcam = b_Fcam_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.rt = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
   for (int f = 0; f < 3; ++f) {
     d_.front[f].S = fr_[f].nblk > 0 ? b_S_.p + fr_[f].s_off : nullptr; d_.front[f].ld = (int)fr_[f].dim; d_.front[f].interior = fr_[f].ncols * 128;
+    d_.front[f].rhs_row = fr_[f].rhs_row; d_.front[f].border_row = f < 2 ? b_border_row_[f].p : nullptr;
     d_.y_front[f] = b_yf_.p + fr_[f].y_off;
   }
-  d_.cam_a = cam_a_; d_.cam_b = cam_b_; d_.rhs_off = fr_[2].rhs_row;
+  d_.seg_lo = segmented_ ? my_lo_ : 0; d_.cam_a = segmented_ ? my_hi_ : cam_a_; d_.cam_b = cam_b_;
   d_.S = d_.front[2].S; d_.ld = d_.front[2].ld; d_.rhs_row = fr_[2].rhs_row;
-  if (dissected_) {
+  if (segmented_) {
+    const FrontHost& F = fr_[0];
+    leaf_.S = d_.front[0].S; leaf_.ld = (long)F.dim; leaf_.nblk = F.nblk; leaf_.ncols = F.ncols; leaf_.last = F.env();
+    leaf_.Linv = b_Linv_.p + F.linv_off; leaf_.rhs_row = F.rhs_row; leaf_.tail_rows = F.tail_rows; leaf_.spike = role_ > 0 && role_ + 1 < segments_;
+  }
+  if (dissected_ && !segmented_) {
     auto view = [&](int f) {
       FrontView v;
       v.S = d_.front[f].S; v.ld = (long)fr_[f].dim; v.nblk = fr_[f].nblk; v.ncols = fr_[f].ncols; v.last = fr_[f].env();
@@ -863,7 +1034,6 @@ int BalSolver::setup() {
       return v;
     };
     ds_.A = view(0); ds_.B = view(1); ds_.R = view(2); ds_.border_blocks = border_blocks_; ds_.mapB = b_mapB_.p;
-    if (segmented_) { if (role_ == 0) ds_.B = FrontView(); else ds_.A = FrontView(); }
   }
   d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = b_fail_.p;
   d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0];
@@ -970,7 +1140,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   launch_bal_pt_reduce(d_, s);
   if (opt_.allreduce) {  // camera columns are summed over all ranks' observations
     double* buf = b_small_.p;
-    if (segmented_ && opt_.rank >= 2) {  // a replica: its sums are rank (r mod 2)'s over again
+    if (replica_) {  // its sums are rank (r mod segments_)'s over again
       SK_HIP_TRY(hipMemsetAsync(buf, 0, 2 * nc * sizeof(double), s));
     } else {
       SK_HIP_TRY(hipMemcpyAsync(buf, d_.colsq_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -992,9 +1162,9 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   // cameras: every rank holds all of them — but in a segmented world only its own segment's (and the separator's) are
   // current, and the separator's |x|^2 must be counted once: the head's rank takes it
   int c_lo = 0, c_n = (int)nc;
-  if (segmented_) { c_lo = role_ == 0 ? 0 : 9 * cam_a_; c_n = role_ == 0 ? 9 * cam_a_ : 9 * (cam_b_ - cam_a_); }
+  if (segmented_) { c_lo = 9 * my_lo_; c_n = 9 * (my_hi_ - my_lo_); }
   int gc = launch_grad_max_xnorm(d_.gs_c + c_lo, d_.scale_c + c_lo, d_.xc + c_lo, c_n, b_partial_.p, partial_stride_, s);
-  if (segmented_ && role_ == 0) {  // + the separator (slots behind the head's)
+  if (segmented_ && role_ == 0) {  // + the separators (slots behind the segment's)
     const int lo2 = 9 * cam_b_, n2 = (int)nc - lo2;
     gc += launch_grad_max_xnorm(d_.gs_c + lo2, d_.scale_c + lo2, d_.xc + lo2, n2, b_partial_.p + gc, partial_stride_, s);
   }
@@ -1092,21 +1262,29 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   double* yf[3] = {b_yf_.p + fr_[0].y_off, b_yf_.p + fr_[1].y_off, b_yf_.p + fr_[2].y_off};
   double* wf[3] = {b_wf_.p + fr_[0].y_off, b_wf_.p + fr_[1].y_off, b_wf_.p + fr_[2].y_off};
   if (segmented_) {
-    // this rank's segment: factor its interior, leave its Schur complement on the separator; sum the root fronts over the
-    // ranks (the separator's own blocks come from whichever rank owns the point, the Schur complements from both segments);
-    // then every rank factors the same root and solves its own interior
-    const FrontView& L = role_ == 0 ? ds_.A : ds_.B;
-    cholesky_factor(L.S, L.ld, L.nblk * 128, L.Linv, b_info_.p, group_, s, ctx, &kt_, L.last, chain_ok(), L.ncols);
-    cholesky_border_add(ds_.R.S, ds_.R.ld, L.S, L.ld, L.ncols, border_blocks_, role_ == 0 ? nullptr : ds_.mapB, s);
-    if (opt_.rank >= 2) SK_HIP_TRY(hipMemsetAsync(b_pack_.p, 0, packed_elems_ * sizeof(double), s));  // a replica adds nothing
-    else launch_tri_pack(ds_.R.S, (int)ds_.R.ld, b_pack_.p, border_blocks_, b_pack_col0_.p, b_pack_off_.p, true, s);
+    // this rank's segment: factor its interior, leave its Schur complement on the separators next to it; sum the root
+    // fronts over the ranks (the separators' own blocks come from whichever rank owns the point, the Schur complements
+    // from the segments on either side); then every rank factors the same root and solves its own interior
+    const FrontView& L = leaf_;
+    const FrontHost& R = fr_[2];
+    double* Rs = d_.front[2].S;
+    double* RLinv = b_Linv_.p + R.linv_off;
+    if (L.ncols > 0) {
+      cholesky_factor(L.S, L.ld, L.nblk * 128, L.Linv, b_info_.p, group_, s, ctx, &kt_, L.last, chain_ok(), L.ncols, L.tail_rows);
+      cholesky_border_add(Rs, (long)R.dim, L.S, L.ld, L.ncols, L.nblk - L.ncols, b_leaf_map_.p, s);
+    }
+    if (replica_) SK_HIP_TRY(hipMemsetAsync(b_pack_.p, 0, packed_elems_ * sizeof(double), s));  // a replica adds nothing
+    else launch_tri_pack(Rs, (int)R.dim, b_pack_.p, R.nblk, b_pack_col0_.p, b_pack_off_.p, true, s);
     int rc = allreduce(b_pack_.p, packed_elems_);
     if (rc) return rc;
-    launch_tri_pack(ds_.R.S, (int)ds_.R.ld, b_pack_.p, border_blocks_, b_pack_col0_.p, b_pack_off_.p, false, s);
+    launch_tri_pack(Rs, (int)R.dim, b_pack_.p, R.nblk, b_pack_col0_.p, b_pack_off_.p, false, s);
     finish_root();
-    cholesky_factor(ds_.R.S, ds_.R.ld, ds_.R.nblk * 128, ds_.R.Linv, b_info_.p, group_, s, ctx, &kt_, ds_.R.last, chain_ok());
-    DissectedSystem mine = ds_;
-    cholesky_dissected_backsolve(mine, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, nullptr, &kt_);
+    cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, b_info_.p, group_, s, ctx, &kt_, R.env(), chain_ok());
+    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env());
+    if (L.ncols > 0) {
+      cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
+      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike);
+    }
   } else if (dissected_) {
     cholesky_dissected_factor(ds_, b_info_.p, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
     cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_);
@@ -1122,8 +1300,8 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     // whose cameras' steps this rank accounts for in |step|^2: all, or (segmented) its segment's, + the separator's on the head's rank
     int lo = 0, hi = (int)nc, lo2 = 0, hi2 = 0;
     if (segmented_) {
-      if (role_ == 0) { lo = 0; hi = 9 * cam_a_; lo2 = 9 * cam_b_; hi2 = (int)nc; }
-      else { lo = 9 * cam_a_; hi = 9 * cam_b_; }
+      lo = 9 * my_lo_; hi = 9 * my_hi_;
+      if (role_ == 0) { lo2 = 9 * cam_b_; hi2 = (int)nc; }
     }
     launch_bal_cam_step(d_, b_scal_.p + 8, lo, hi, lo2, hi2, s);
   }
@@ -1226,8 +1404,8 @@ int BalSolver::write_back() {
     // a rank's cameras of the OTHER segment were never updated: every camera from the rank that owns it (the separator's
     // from rank 0; replicas add zeros), summed into a zero-filled table
     std::vector<double> cams(nc, 0.0);
-    if (opt_.rank < 2) {
-      const size_t lo = role_ == 0 ? 0 : 9 * (size_t)cam_a_, hi = role_ == 0 ? 9 * (size_t)cam_a_ : 9 * (size_t)cam_b_;
+    if (!replica_) {
+      const size_t lo = 9 * (size_t)my_lo_, hi = 9 * (size_t)my_hi_;
       std::memcpy(&cams[lo], &x[lo], (hi - lo) * sizeof(double));
       if (role_ == 0) std::memcpy(&cams[9 * (size_t)cam_b_], &x[9 * (size_t)cam_b_], (nc - 9 * (size_t)cam_b_) * sizeof(double));
     }
@@ -1245,7 +1423,7 @@ int BalSolver::write_back() {
   }
   // every rank returns ALL points: zero-filled table, own slice filled, sum-reduced
   std::vector<double> all(3 * (size_t)P_total_, 0.0);
-  if (!(segmented_ && opt_.rank >= 2))  // (a replica adds zeros)
+  if (!replica_)  // (a replica adds zeros)
     for (int q = 0; q < P_; ++q) std::memcpy(&all[3 * (size_t)local_pt_[q]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
   DevBuf<double> tmp;
   SK_HIP_TRY(tmp.upload(all, stream_));

@@ -957,7 +957,7 @@ int sk_cholesky_solve_segments(int n, const double* A, const double* b, double* 
     DevBuf<int> dg;
     SK_HIP_TRY(dg.upload(gmap, s));
     cholesky_gather_map(dyR.p, dg.p, lf->yb.p, m, s);
-    cholesky_backsolve_front(lf->F.p, (long)lf->dim, L.nblk, L.ncols, L.rhs_row, lf->Linv.p, lf->yb.p, lf->w.p, lf->y.p, s, lf->last.data(), L.tail_rows);
+    cholesky_backsolve_front(lf->F.p, (long)lf->dim, L.nblk, L.ncols, L.rhs_row, lf->Linv.p, lf->yb.p, lf->w.p, lf->y.p, s, lf->last.data(), L.spike);
     SK_HIP_TRY(hipStreamSynchronize(s));
   }
   SK_HIP_TRY(hipStreamSynchronize(s));

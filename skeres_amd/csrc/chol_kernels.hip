@@ -1950,10 +1950,9 @@ void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f
 // Interior part of L^T y = z for a leaf front whose border unknowns are known.  yb: border unknowns (border_blocks * 128
 // values, zero where the border has padding or its right-hand-side row).  w: scratch (ncols * 128); y: interior solution.
 void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, int tail_rows) {
+                              hipStream_t s, const int* last, bool spike) {
   const int ni = ncols * 128, m = (nblk - ncols) * 128;
   if (ncols <= 0) return;
-  if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
   hipLaunchKernelGGL(copy_row_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, ni, ni);
   // block rows' first non-zero block columns (the border rows: from the first interior column that reaches the border)
   std::vector<int> first(nblk, 0);
@@ -1963,8 +1962,9 @@ void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int
       while (c0 < kb && last[c0] < kb) ++c0;
       first[kb] = c0;
     }
-  // (border rows of the tail reach every interior column: a spike; first[] of the last block row is 0 anyway)
-  const int bcol0 = tail_rows > 1 ? 0 : std::min(first[ncols < nblk - 1 ? ncols : nblk - 1], ncols) * 128;
+  // (spike: border rows that couple with the FIRST interior columns — the left separator of a segment between two — and so
+  // reach every column; otherwise the border starts where the first interior column reaches it)
+  const int bcol0 = spike ? 0 : std::min(first[ncols < nblk - 1 ? ncols : nblk - 1], ncols) * 128;
   if (ni > bcol0)
     hipLaunchKernelGGL(bs_border_kernel, dim3((ni - bcol0 + 63) / 64), dim3(1024), 0, s, S + (long)ncols * 128 * ld, ld, m, yb, w, bcol0, ni);
   for (int kb = ncols - 1; kb >= 0; --kb) {

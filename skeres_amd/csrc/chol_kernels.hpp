@@ -196,6 +196,7 @@ struct FrontView {
   double* Linv = nullptr;             // ncols inverted diagonal blocks
   int rhs_row = 0;                    // row that carries the right-hand side
   int tail_rows = 1;                  // block rows at the end that are active in every column (cholesky_plan)
+  bool spike = false;                 // the border has rows that couple with the first interior columns (SegmentLayout)
 };
 struct DissectedSystem {
   FrontView A, B, R;                  // head, tail (B.ncols == 0: none), root
@@ -214,7 +215,7 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
 // map: root index of each border index (nullptr: identity; < 0: skip)
 void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s);
 void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, int tail_rows = 1);
+                              hipStream_t s, const int* last, bool spike = false);
 void cholesky_gather_map(const double* src, const int* map, double* dst, int m, hipStream_t s);
 // --- multi-way dissection: R segments of a block-banded system with R - 1 separators between them ---
 // Leaf front of one segment, in scalar rows.  The interior is followed by a border:
@@ -229,6 +230,7 @@ struct SegmentLayout {
   int rhs_row = 0;                    // absolute row of the right-hand side in the front
   int right_off = -1, left_off = -1;  // first border row (relative to the border) of the right / left separator; -1: none
   bool reversed = false;
+  bool spike = false;                 // a segment between two separators: the left one's rows reach every interior column
 };
 inline SegmentLayout segment_layout(int interior_n, int left_n, int right_n) {
   SegmentLayout L;
@@ -243,7 +245,7 @@ inline SegmentLayout segment_layout(int interior_n, int left_n, int right_n) {
     L.rhs_row = L.ncols * 128 + left_n;
   } else {
     const int rb = (right_n + 127) / 128;
-    L.right_off = 0; L.left_off = rb * 128;
+    L.right_off = 0; L.left_off = rb * 128; L.spike = true;
     L.tail_rows = (left_n + 1 + 127) / 128;
     L.nblk = L.ncols + rb + L.tail_rows;
     L.rhs_row = L.ncols * 128 + L.left_off + left_n;

@@ -1,5 +1,5 @@
-"""Worker of test_sharded_solve_world_of_two_on_one_gpu: the multi-GPU decomposition with a REAL exchange
-between two ranks.  Both ranks use GPU 0 (the test box has one GPU), so RCCL cannot carry the traffic
+"""Worker of tests/test_gpu_parity.py::test_*_on_one_gpu_with_a_real_exchange: the multi-GPU decompositions with a REAL
+exchange between the ranks of a world of 2 to 5.  All ranks use GPU 0 (the test box has one GPU), so RCCL cannot carry the traffic
 (it refuses two ranks on one device); the all-reduce hook stages through the host and sums with gloo.
 Everything else — point partition, sharded evaluation and Schur assembly, the three exchanges per
 iteration, the replicated factorisation, the gather of the point blocks — is the production path."""
@@ -62,9 +62,14 @@ def main():
     while not solver.step():
         pass
     solver.finish(summary)
+    segments = int(solver.stat("segments"))
     if mode == "segmented":
-        # the camera sequence is cut: rank 0's device eliminates the head, rank 1's the tail; what travels is the separator's system
+        # the camera sequence is cut: rank r's device eliminates segment r (the last one back to front); what travels is the
+        # separators' system.  argv[3]: how many segments the sequence must have been cut into (ranks beyond: replicas)
         assert used == "segmented" and solver.stat("dissected") == 1
+        if len(sys.argv) > 3:
+            assert segments == int(sys.argv[3]), (segments, sys.argv[3])
+        assert 2 <= segments <= world
         if shape[0] >= 200:
             assert solver.stat("allreduce_bytes") < 0.6 * solver.stat("allreduce_bytes_full_triangle")
     elif mode != "auto":
@@ -72,10 +77,11 @@ def main():
     else:  # a 2600-observation problem: the host-staged all-reduce costs far more than sharding saves
         assert used == "replicated" and t_allreduce > t_saved > 0.0, (used, t_allreduce, t_saved)
     if used == "replicated":
-        assert hook.calls == (3 if mode == "auto" else 0) + (1 if mode == "auto" else 0), hook.calls  # only the probe of AUTO
+        # one exchange at set-up (do all ranks have the look-ahead queues? they must factor by one plan), then only the probe of AUTO
+        assert hook.calls == 1 + ((3 + 1) if mode == "auto" else 0), hook.calls
     a = [it["cost"] for it in summary.iterations()]
     b = [it["cost"] for it in s_plain.iterations()]
-    assert abs(len(a) - len(b)) <= 1, (len(a), len(b))
+    assert abs(len(a) - len(b)) <= 1, (len(a), len(b), a[:8], b[:8])
     for k in range(min(5, len(a), len(b))):
         assert abs(a[k] - b[k]) <= 1e-10 * b[k], (k, a[k], b[k])  # summation order differs: tolerance, not bits
     assert abs(summary.finalCost() - s_plain.finalCost()) <= 1e-9 * s_plain.finalCost()
@@ -89,7 +95,7 @@ def main():
     assert np.abs(x - x_plain).max() <= 1e-6 * max(1.0, np.abs(x_plain).max())
     dist.barrier()
     if rank == 0:
-        print("DIST_GPU2_OK world=%d mode=%s calls=%d iterations=%d" % (world, mode, hook.calls, summary.numIterations()))
+        print("DIST_GPU2_OK world=%d mode=%s segments=%d calls=%d iterations=%d" % (world, mode, segments, hook.calls, summary.numIterations()))
     dist.destroy_process_group()
 
 

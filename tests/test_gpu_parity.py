@@ -250,6 +250,25 @@ def test_multiway_dissected_factorisation_vs_numpy(shape, starts, automatic):
         sk.api.cholesky_solve_segments(A, b, bad, group=2)
 
 
+def test_multiway_dissection_with_separators_narrower_than_a_block():
+    """... and with a scalar band of 40: separators of 40 rows, so that a segment between two separators has its left
+    separator and the right-hand side in ONE border block (one tail row) — the spike must still reach every column in
+    the back-substitution."""
+    n, w = 128 * 30 - 17, 40
+    rng = np.random.default_rng(40)
+    A = np.zeros((n, n))
+    for d in range(1, w + 1):
+        A[np.arange(d, n), np.arange(0, n - d)] = rng.normal(0, 1.0, n - d)
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(axis=1) + np.abs(A).sum(axis=0) + 1.0 + rng.uniform(0, 1, n)
+    b = rng.normal(size=n)
+    xnp = np.linalg.solve(A + np.tril(A, -1).T, b)
+    for starts in ((700, 1500, 2600), (400, 900, 1400, 1900, 2400, 2900, 3400), (1900,)):
+        cuts = [(a, a + w) for a in starts]
+        for automatic in (True, False):
+            x = sk.api.cholesky_solve_segments(A, b, cuts, group=0 if automatic else 2, automatic_plan=automatic)
+            assert np.linalg.norm(x - xnp) <= 1e-11 * np.linalg.norm(xnp), (starts, automatic, np.linalg.norm(x - xnp) / np.linalg.norm(xnp))
+
+
 def test_cholesky_mfma_layout_asymmetric():
     # A = L0 L0^T with an asymmetric integer-valued L0: a swapped row/col map in the
     # MFMA C/D layout cannot reproduce L0.
@@ -950,22 +969,24 @@ def test_distributed_hook_path_world_of_one_matches_plain_solve():
     assert "DIST_GPU_OK" in out.stdout
 
 
-@pytest.mark.parametrize("world,mode", [(2, "sharded"), (3, "sharded"), (2, "replicated"), (2, "auto")])
-def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode, shape=None):
-    """tests/dist_gpu_worker2.py: `world` ranks share GPU 0 and exchange through gloo (host-staged hook)."""
+@pytest.mark.parametrize("world,mode", [(2, "sharded"), (3, "sharded"), (4, "sharded"), (2, "replicated"), (2, "auto")])
+def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode, shape=None, segments=None):
+    """tests/dist_gpu_worker2.py: `world` ranks share GPU 0 and exchange through gloo (host-staged hook).  (Worlds of at
+    most four here: the GPU box allows six processes on its card — this one, the launcher and four ranks; worlds of five and six
+    are run outside pytest by tools/rehearse_worlds.sh, their logs under profiles/.)"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29900 + world + (os.getpid() % 60)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker2.py"), mode] + ([shape] if shape else [])
+           "--master-port", str(port), os.path.join(root, "tests", "dist_gpu_worker2.py"), mode] + ([shape] if shape else []) + ([str(segments)] if segments else [])
     out = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "DIST_GPU2_OK world=%d" % world in out.stdout
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_solve_sends_only_the_envelope(world):
     """The same with a camera sequence long enough for a banded reduced system (400 cameras, 29 block columns): the
     all-reduce carries the blocks inside the envelope only, and the sharded solve follows the
@@ -973,13 +994,17 @@ def test_sharded_solve_sends_only_the_envelope(world):
     test_sharded_solve_on_one_gpu_with_a_real_exchange(world, "sharded", "400,12000,60000,3")
 
 
-@pytest.mark.parametrize("world,shape", [(2, "60,2500,12000,13"), (2, "400,12000,60000,3"), (3, "400,12000,60000,3")])
-def test_segmented_solve_on_one_gpu_with_a_real_exchange(world, shape):
-    """SK_DISTRIBUTION_SEGMENTED: the camera sequence dissected over the ranks — rank 0 eliminates the
-    head and its points, rank 1 the tail (rank 2, in the world of three, replicates rank 0 and adds zeros) — the separator's
-    system all-reduced, factored by everyone.  Same trajectory as the single-GPU solve (1e-10), every rank ends with all
-    parameters, bit for bit the same."""
-    test_sharded_solve_on_one_gpu_with_a_real_exchange(world, "segmented", shape)
+@pytest.mark.parametrize("world,shape,segments", [(2, "60,2500,12000,13", 2), (2, "400,12000,60000,3", 2), (3, "400,12000,60000,3", None),
+                                                  (3, "400,12000,27000,3", 3), (4, "400,12000,27000,3", 4),
+                                                  (4, "400,12000,60000,3", None), (4, "900,30000,70000,8", None)])
+def test_segmented_solve_on_one_gpu_with_a_real_exchange(world, shape, segments):
+    """SK_DISTRIBUTION_SEGMENTED: the camera sequence cut into as many segments as the world has ranks
+    (fewer when the sequence has no room for that many separators: the ranks beyond replicate and add zeros) — rank r
+    eliminates segment r and its points, the last one back to front, the ones between two separators with the left
+    separator's rows as a spike — the separators' block-tridiagonal system all-reduced and factored by everyone.  Same
+    trajectory as the single-GPU solve (1e-10), every rank ends with all parameters, bit for bit the same.  The 27 000- and
+    70 000-observation shapes have short tracks (separators of a few dozen cameras): a segment per rank."""
+    test_sharded_solve_on_one_gpu_with_a_real_exchange(world, "segmented", shape, segments)
 
 
 # ---------------------------------------------------------------------------
@@ -1015,7 +1040,7 @@ def test_dense_rows_vs_oracle(m, n):
     np.testing.assert_allclose(x_gpu, x_star, atol=5e-3)  # recovers the planted parameters
 
 
-@pytest.mark.parametrize("world,shape", [(2, "3000,200"), (3, "5000,300")])
+@pytest.mark.parametrize("world,shape", [(2, "3000,200"), (3, "5000,300"), (4, "5000,300")])
 def test_dense_rows_sharded_over_ranks(world, shape):
     """tests/dist_dense_rows_worker.py: the rows of the dense problem sharded over `world` ranks (SURVEY.md section 8e:
     "C5: shard rows of J"), J^T J all-reduced, Cholesky replicated — the single-GPU trajectory to 1e-10."""
