@@ -13,9 +13,12 @@ region of a real solve; how many of them were successful steps (an unsuccessful 
 reported in config.
 
 Multi-GPU (total work fixed => "strong"; the solver chooses, config.parallelism says what it chose): SEGMENTED — the
-camera sequence is dissected, rank 0's device eliminates the head and its points, rank 1's the tail, the separator's
-system is all-reduced (a few MB) and factored by every rank; or SHARDED — points sharded, the reduced system (its blocks
-inside the envelope) all-reduced, Cholesky replicated; or REPLICATED when neither pays.
+camera sequence is cut into as many segments as pay (at most one per rank), rank r's device eliminates segment r and its
+points, the separators' block-tridiagonal system is all-reduced (a few MB) and factored by every rank; or SHARDED — points
+sharded, the reduced system (its blocks inside the envelope) all-reduced, Cholesky replicated; or REPLICATED when neither
+pays.  The same line carries the other configurations of BASELINE.json: one GPU — `c2` (BAL-49), `c4` (Venice-1778), `c5`
+(dense rows); several ranks — `venice` and `c5` (rows sharded), each with the distribution used, the bytes all-reduced per
+iteration and the milliseconds that takes; and on one GPU `predicted_multi_gpu`, the chain model's figures for 2, 4, 8.
 
 Rank 0 prints ONE JSON line.
 """
@@ -52,7 +55,8 @@ def available_cpus():
                     n = min(n, max(1, q // period))
         except (OSError, ValueError, IndexError):
             pass
-    return max(1, min(n, int(os.environ.get("SKERES_CPU_THREADS", "16"))))
+    cap = os.environ.get("SKERES_CPU_THREADS")  # optional cap; by default every CPU of the process's share is used
+    return max(1, min(n, int(cap))) if cap else max(1, n)
 
 
 def build_problem(sk, prob):
@@ -113,7 +117,90 @@ def cpu_baseline(prob, iters, envelope=True, full_iters=1):
     return out
 
 
-def c5_record(sk, m=1000000, n=10000, iters=2, seed=5):
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E, ~8 TB/s
+
+
+def phase_rooflines(phases_ms, n_obs, envelope_bytes):
+    """HBM rooflines of the phases around the factorisation: SURVEY.md section 8(d)'s ALGORITHMIC bytes per observation
+    (A: 328 B — 120 read, 208 written; B: 208 B read + the blocks of the reduced system written once, here the blocks inside
+    the envelope; D: 136 B — back-substitution and cost-only evaluation) over the measured phase time."""
+    def rec(nbytes, ms, what):
+        gbs = nbytes / (ms * 1e-3) * 1e-9 if ms and ms > 0 else None
+        return {"bound": "hbm", "bytes": nbytes, "ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS if gbs else None, "what": what}
+    return {"A_jacobian_eval": rec(328.0 * n_obs, phases_ms.get("jacobian_eval"), "328 B/observation (per accepted step)"),
+            "B_schur_assemble": rec(208.0 * n_obs + envelope_bytes, phases_ms.get("schur_assemble"), "208 B/observation read + the reduced system's blocks inside the envelope written once"),
+            "D_backsub_cost": rec(136.0 * n_obs, (phases_ms.get("back_substitute") or 0.0) + (phases_ms.get("cost_eval") or 0.0), "136 B/observation")}
+
+
+PHASE_NAMES = ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"]
+
+
+def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, world, dist_mod=None, torch=None):
+    """One more bundle-adjustment workload of BASELINE.json in the same run (configs[1] BAL-49, configs[3] Venice-1778): `steps`
+    LM iterations of the same solve as the headline, timed the same way (barrier + synchronise on both sides, max over
+    ranks); with several ranks, the distribution the solver chose, what travels per iteration and how long it takes."""
+    prob = bal.generate_named(name, seed=seed, perturb=PERTURB)
+    problem, params, loss = build_problem(sk, prob)
+    o = sk.Solver.Options()
+    o.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    o.setMaxNumIterations(warmup + steps + 1000)
+    o.setFunctionTolerance(0.0)
+    o.setGradientTolerance(0.0)
+    o.setParameterTolerance(0.0)
+    o.setDevice(local_rank)
+    o.setStream(stream.cuda_stream)
+    hook = None
+    if world > 1:
+        from skeres_amd import dist as sk_dist
+        hook = sk_dist.attach(o, problem, rank, world)
+    solver = sk.StepSolver(o, problem)
+    mode = solver.distribution()[0] if world > 1 else "single"
+    stats = {k: solver.stat(k) for k in ("envelope_fill", "allreduce_bytes", "segments", "cholesky_flops_plan")}
+    for _ in range(warmup):
+        solver.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(steps):
+        done += 1
+        if solver.step():  # (terminated: e.g. the trust region collapsed on a converged small problem)
+            break
+    steps = done
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        elapsed = float(t.item())
+    summ = sk.Solver.Summary()
+    solver.finish(summ)
+    its = summ.iterations()
+    phases = {k: 1e3 * summ.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(PHASE_NAMES)}
+    chol_s = phases["cholesky"] * 1e-3
+    rec = {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d), DENSE_SCHUR" % (name, prob.num_cameras, prob.num_points, prob.num_observations, seed),
+           "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "iterations_per_second": steps / elapsed,
+           "phases_ms_per_step": phases, "envelope_fill": stats["envelope_fill"],
+           "roofline_cholesky_phase": {"bound": "mfma", "flops": stats["cholesky_flops_plan"], "achieved": stats["cholesky_flops_plan"] / chol_s * 1e-12 if chol_s > 0 else None,
+                                       "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": stats["cholesky_flops_plan"] / chol_s * 1e-12 / FP64_MFMA_PEAK_TFLOPS if chol_s > 0 else None},
+           "costs": [its[0]["cost"], its[-1]["cost"]]}
+    if world > 1:
+        rec["distribution"] = {"mode": mode, "segments": int(stats["segments"]), "allreduce_bytes_per_iteration": stats["allreduce_bytes"],
+                               "allreduce_ms_per_step": phases["allreduce"]}
+    else:
+        rec["roofline_phases_hbm"] = phase_rooflines(phases, prob.num_observations, stats["allreduce_bytes"])
+    del solver
+    return rec
+
+
+def c5_record(sk, m=1000000, n=10000, iters=2, seed=5, rank=0, world=1, stream=None, torch=None, dist_mod=None):
     """BASELINE.json config 5 (dense rows: m residuals x n parameters, DENSE_NORMAL_CHOLESKY) in the same run: the J^T J
     formation (syrk_gram_f64_kernel, fp64 MFMA) timed by HIP events around its launches, priced with the ALGORITHMIC
     flop count m n (n + 1) of SURVEY.md section 8(d) (not the padded tiles the launch computes)."""
@@ -130,24 +217,47 @@ def c5_record(sk, m=1000000, n=10000, iters=2, seed=5):
     o.setFunctionTolerance(0.0)
     o.setGradientTolerance(0.0)
     o.setParameterTolerance(0.0)
+    hook = None
+    if world > 1:  # the rows are sharded over the ranks, J^T J all-reduced, the Cholesky replicated
+        from skeres_amd import dist as sk_dist
+        o.setStream(stream.cuda_stream)
+        hook = sk_dist.TorchAllReduce()
+        o.setDistributed(rank, world, hook)
     s = sk.StepSolver(o, problem)
     s.setKernelTiming(1)
+    if world > 1:
+        torch.cuda.synchronize()
+        dist_mod.barrier()
     t0 = time.perf_counter()
     for _ in range(iters):
         s.step()
+    if world > 1:
+        torch.cuda.synchronize()
+        dist_mod.barrier()
     dt = (time.perf_counter() - t0) / iters
     sec, launches = s.kernelSeconds("syrk_gram")
-    flops_alg = s.stat("jtj_flops_algorithmic")
+    flops_alg = float(m) * float(n) * (float(n) + 1.0)  # the whole problem's, all ranks together
     flops_tiles = s.syrkFlopsPerSolve()
+    allreduce_bytes = s.stat("allreduce_bytes") if world > 1 else 0.0
     summ = sk.Solver.Summary()
     s.finish(summ)
+    if world > 1:  # the slowest rank's J^T J time and iteration time
+        t = torch.tensor([sec, dt], dtype=torch.float64, device="cuda")
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        sec, dt = float(t[0].item()), float(t[1].item())
     rate = flops_alg * launches / sec * 1e-12 if sec > 0 else None
-    return {"workload": "synthetic dense NLLS, %d residuals x %d parameters, DENSE_NORMAL_CHOLESKY (BASELINE.json configs[4])" % (m, n),
-            "iterations_per_second": 1.0 / dt, "seconds_per_iteration": dt,
-            "jtj": {"bound": "mfma", "kernel": "sk::syrk_gram_f64_kernel", "achieved": rate, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": rate / FP64_MFMA_PEAK_TFLOPS if rate else None, "flops_per_launch": flops_alg,
-                    "flops_per_launch_padded_tiles": flops_tiles, "launches": launches, "avg_launch_ms": 1e3 * sec / max(1, launches)},
-            "costs": [it["cost"] for it in summ.iterations()]}
+    rec = {"workload": "synthetic dense NLLS, %d residuals x %d parameters, DENSE_NORMAL_CHOLESKY (BASELINE.json configs[4])" % (m, n),
+           "n_gpus": world, "iterations_per_second": 1.0 / dt, "seconds_per_iteration": dt,
+           "jtj": {"bound": "mfma", "kernel": "sk::syrk_gram_f64_kernel", "achieved": rate, "peak": FP64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                   "frac": rate / (FP64_MFMA_PEAK_TFLOPS * world) if rate else None, "flops_per_launch": flops_alg / world,
+                   "flops_per_launch_padded_tiles": flops_tiles, "launches": launches, "avg_launch_ms": 1e3 * sec / max(1, launches),
+                   "note": "aggregate over the ranks: the whole problem's m n (n + 1) flops over the slowest rank's launch time; peak = %d x %.1f" % (world, FP64_MFMA_PEAK_TFLOPS)},
+           "costs": [it["cost"] for it in summ.iterations()]}
+    if world > 1:
+        n_it = max(1, len(summ.iterations()) - 1)
+        rec["distribution"] = {"mode": "rows sharded x%d, lower block triangle of J^T J all-reduced, Cholesky replicated" % world,
+                               "allreduce_bytes_per_iteration": allreduce_bytes, "allreduce_ms_per_step": 1e3 * summ.phaseSeconds(5) / n_it}
+    return rec
 
 
 def main():
@@ -238,7 +348,14 @@ def main():
     syrk_s, syrk_n = solver.kernelSeconds("gemm_syrk")
     syrk_flops = solver.syrkFlopsPerSolve()
     syrk_c_bytes = solver.syrkCBytesPerSolve()
-    plan = {k: solver.stat(k) for k in ("envelope_fill", "camera_order", "cholesky_flops_full", "cholesky_flops_plan", "cholesky_columns_resident")}
+    plan = {k: solver.stat(k) for k in ("envelope_fill", "camera_order", "cholesky_flops_full", "cholesky_flops_plan", "cholesky_columns_resident", "segments",
+                                        "allreduce_bytes")}
+    model_us = {}
+    for k in range(1, 9):
+        try:
+            model_us[k] = solver.stat("model_us_segments_%d" % k)
+        except sk.SkeresError:
+            model_us[k] = 0.0
     summary = sk.Solver.Summary()
     solver.finish(summary)
     # Untimed side measurement: the same kernel with the look-ahead off, i.e. alone on the chip.  In the
@@ -250,7 +367,7 @@ def main():
     if world == 1 and not args.no_lookahead and not args.no_alone:
         del solver
 
-        def side_run(lookahead, envelope):
+        def side_run(lookahead, envelope, nsteps=3):
             prob2 = bal.generate_named(args.workload, seed=SEED, perturb=PERTURB, long_range_fraction=args.long_range)
             problem2, params2, loss2 = build_problem(sk, prob2)
             options.setCholeskyTuning(args.group, lookahead)
@@ -260,12 +377,12 @@ def main():
             solver2.setKernelTiming(2)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(nsteps):
                 solver2.step()
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / 3
+            dt = (time.perf_counter() - t1) / nsteps
             s2, n2 = solver2.kernelSeconds("gemm_syrk")
-            rate = (solver2.syrkFlopsPerSolve() * 3) / s2 * 1e-12 if s2 > 0 else None
+            rate = (solver2.syrkFlopsPerSolve() * nsteps) / s2 * 1e-12 if s2 > 0 else None
             flops2 = solver2.syrkFlopsPerSolve()
             summ2 = sk.Solver.Summary()
             solver2.finish(summ2)
@@ -275,11 +392,30 @@ def main():
         alone, _, _, _ = side_run(False, not args.full_factorisation)
         # ... and the factorisation of EVERY block (no envelope): the same arithmetic (other SYRK grouping), more work in
         if not args.full_factorisation:
-            _, full_dt, full_flops, full_chol_s = side_run(True, False)
+            _, full_dt, full_flops, full_chol_s = side_run(True, False, args.steps)  # over as many steps as the headline
             full_ms = 1e3 * full_dt
     its = summary.iterations()
     timed = its[1 + args.warmup: 1 + args.warmup + args.steps]
     n_success = int(sum(it["step_is_successful"] for it in timed))
+    # ---- the other configurations of BASELINE.json in the same run (every rank takes part; rank 0 reports) ----
+    extra = {}
+    if not args.no_alone and args.workload == "ladybug-1723-156502":
+        try:
+            del solver
+        except NameError:
+            pass
+        dist_mod = dist if world > 1 else None
+        if world == 1:
+            extra["c2"] = bal_record(sk, bal, "problem-49-7776", 49, 20, 2, local_rank, stream, rank, world, dist_mod, torch)
+        try:
+            extra["c4" if world == 1 else "venice"] = bal_record(sk, bal, "venice-1778-993923", 1778, 10, 2, local_rank, stream, rank, world, dist_mod, torch)
+        except sk.SkeresError as e:
+            extra["c4" if world == 1 else "venice"] = {"error": str(e)}
+        if not args.no_c5:
+            try:
+                extra["c5"] = c5_record(sk, rank=rank, world=world, stream=stream, torch=torch, dist_mod=dist_mod)
+            except sk.SkeresError as e:  # e.g. not enough free HBM for the 80 GB Jacobian on a shared device
+                extra["c5"] = {"error": str(e)}
 
     if rank == 0:
         achieved = (syrk_flops * args.steps) / syrk_s * 1e-12 if syrk_s > 0 else 0.0
@@ -301,9 +437,9 @@ def main():
                 "cholesky_block_columns_resident": int(plan["cholesky_columns_resident"]),
                 "long_range_fraction": args.long_range,
                 "successful_steps_in_timed_region": n_success, "parallelism": ("one GPU" if world == 1 else
-                                "camera sequence dissected over the ranks (SK_DISTRIBUTION_SEGMENTED): the head and its points on rank 0's device, the tail "
-                                "on rank 1's, ranks beyond the second replicate rank r mod 2; per iteration the separator's system is all-reduced "
-                                "(%.1f MB) and factored by every rank" % allreduce_mb if dist_mode == "segmented" else
+                                "camera sequence cut into %d segments over the %d ranks (SK_DISTRIBUTION_SEGMENTED): rank r's device eliminates segment r "
+                                "and its points (ranks beyond the segments replicate and add zeros); per iteration the separators' block-tridiagonal "
+                                "system is all-reduced (%.1f MB) and factored by every rank" % (int(plan["segments"]), world, allreduce_mb) if dist_mode == "segmented" else
                                 "points sharded x%d, reduced system all-reduced (%.0f MB: the blocks inside the envelope), Cholesky replicated" % (world, allreduce_mb) if dist_mode == "sharded" else
                                 "replicated x%d: the solver measured %.1f ms for the all-reduce of the reduced system against %.1f ms of "
                                 "per-iteration work sharding would remove, and did not shard" % (world, 1e3 * t_allreduce, 1e3 * t_saved)),
@@ -326,9 +462,29 @@ def main():
                                  "panel chain (masked off 16-32 CUs) and most launches are a few dozen tile rows (a sparse envelope); "
                                  "*_alone: same kernel, look-ahead off, 3 untimed steps; "
                                  "flops_per_solve counts the blocks inside the envelope only"},
-            "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(
-                ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"])},
+            "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(PHASE_NAMES)},
         }
+        line["roofline_phases_hbm"] = phase_rooflines(line["phases_ms_per_step"], prob.num_observations if world == 1 else prob.num_observations / world,
+                                                      plan["allreduce_bytes"] if world == 1 else 0.0)
+        if world > 1:
+            line["distribution"] = {"mode": dist_mode, "segments": int(plan["segments"]), "allreduce_bytes_per_iteration": plan["allreduce_bytes"],
+                                    "allreduce_ms_per_step": line["phases_ms_per_step"]["allreduce"]}
+        # What the chain model (microseconds per block column — 42 under a resident chain, 70 launch by
+        # launch, the trailing update at 32 TFLOP/s where that is longer) predicts for this problem cut into 2, 4 and 8
+        # segments, calibrated on this run: model(N) / model(1) x the measured Cholesky phase + the measured phases that
+        # shard with the points / N.  UNMEASURED on more than one device until a SCALE run exists; printed so that one can be
+        # read against it.
+        if world == 1 and model_us.get(1, 0.0) > 0.0:
+            ph = line["phases_ms_per_step"]
+            shard = ph["jacobian_eval"] + ph["schur_assemble"] + ph["back_substitute"] + ph["cost_eval"]
+            pred = {}
+            for n_dev in (2, 4, 8):
+                feas = [model_us[k] for k in range(2, n_dev + 1) if model_us.get(k, 0.0) > 0.0]
+                best = min(feas + [model_us[1]])
+                pred[str(n_dev)] = {"ms_per_step": ph["cholesky"] * best / model_us[1] + shard / n_dev, "segments": (
+                    [k for k in range(2, n_dev + 1) if model_us.get(k, 0.0) == best] or [1])[0]}
+            line["predicted_multi_gpu"] = {"model_us_per_segments": {str(k): v for k, v in model_us.items() if v > 0.0}, "per_n_gpus": pred,
+                                           "note": "chain model, calibrated on this run's Cholesky phase; no scaling curve has been measured on hardware"}
         # The whole Cholesky phase (factorisation + triangular solves, every kernel of it) against the MFMA peak.  The
         # timed region factors the blocks inside the envelope (cholesky_flops_plan); the structure-independent figure
         # is the FULL factorisation — SURVEY.md section 8(d)'s n^3 / 3 over the measured Cholesky phase of the side run
@@ -352,11 +508,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, envelope=not args.full_factorisation, full_iters=args.cpu_full_iters)
         elif world == 1:
             line["cpu_baseline"] = None
-        if world == 1 and not args.no_c5 and not args.no_alone:
-            try:
-                line["c5"] = c5_record(sk)
-            except sk.SkeresError as e:  # e.g. not enough free HBM for the 80 GB Jacobian on a shared device
-                line["c5"] = {"error": str(e)}
+        line.update(extra)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -416,6 +416,16 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
     for (int c = 0; c < nblk; ++c) { fwd_sum[c + 1] = fwd_sum[c] + fwd[c]; bwd_sum[c + 1] = bwd_sum[c] + bwd[c]; }
     out.model_us[1] = out.t_plain;
     auto sep_blocks = [&](int a) { return (9 * (reach[a - 1] + 1 - a) + 1 + 127) / 128; };
+    // room[k]: the last camera at which a segment may START so that k more cuts (each a candidate below, each followed by a
+    // segment of at least 14 cameras) still fit behind it
+    std::vector<int> room(9, -1);
+    room[0] = C - 15;
+    for (int k = 1; k <= 8; ++k)
+      for (int a = 14; a + 14 < C; a += 7) {
+        const int b = reach[a - 1] + 1;
+        if (b >= C - 14) break;
+        if (sep_blocks(a) <= 24 && b <= room[k - 1]) room[k] = std::max(room[k], a - 14);
+      }
     // can the sequence be cut into Rn segments none of whose chains is longer than T?  Greedy: every segment as long as T allows.
     auto plan_for = [&](int Rn, double T, std::vector<int>* as) {
       int pos = 0;
@@ -424,7 +434,8 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
         int best_a = -1;
         for (int a = ((pos + 14 + 6) / 7) * 7; a + 14 < C; a += 7) {
           const int b = reach[a - 1] + 1;
-          if (b >= C - 14 - 42 * (Rn - 2 - sgm)) break;  // (room for the cuts still to come: a generous T must not spend the whole sequence on this segment)
+          if (b >= C - 14) break;
+          if (b > room[Rn - 2 - sgm]) continue;  // (room for the cuts still to come: a generous T must not spend the whole sequence on this segment)
           if (fwd_sum[(9 * a + 127) / 128] - fwd_sum[(9 * pos) / 128] > T) break;
           if (sep_blocks(a) <= 24) best_a = a;
         }
@@ -719,7 +730,10 @@ int BalSolver::setup() {
         } else ds.a = 0;
       }
       dissect_t_plain_ = ds.t_plain; dissect_t_model_ = ds.t_dissected;
-      model_us_[1] = ds.t_plain; model_us_[2] = ds.t_dissected;
+      {  // what the chain model predicts for 2 .. 8 devices (sk_solver_stat "model_us_segments_<n>": bench.py prints it beside what it measures)
+        const Segments sg = choose_segments(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, 8, false);
+        for (int k = 0; k < 9; ++k) model_us_[k] = sg.model_us[k];
+      }
       if (ds.a > 0 && ds.b < C_) { cut_a.push_back(ds.a); cut_b.push_back(ds.b); }
     }
     if (multi && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && cut_a.empty()) {
