@@ -1294,7 +1294,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     launch_tri_pack(Rs, (int)R.dim, b_pack_.p, R.nblk, b_pack_col0_.p, b_pack_off_.p, false, s);
     finish_root();
     cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, b_info_.p, group_, s, ctx, &kt_, R.env(), chain_ok());
-    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env());
+    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), b_info_.p);
     if (L.ncols > 0) {
       cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
       cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike);
@@ -1305,7 +1305,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   } else {
     const FrontHost& R = fr_[2];
     cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, b_info_.p, group_, s, ctx, &kt_, R.env(), chain_ok());
-    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env());
+    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), b_info_.p);
   }
   launch_bal_gather_y(d_, s);
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));

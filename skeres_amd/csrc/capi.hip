@@ -746,7 +746,7 @@ int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, dou
   SK_HIP_TRY(hipDeviceSynchronize());  // uploads above ran on the null stream
   const bool chain = automatic_plan != 0 && la && ctx.server != nullptr;  // (the plan; resident or not is the device's state)
   cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr, last, chain);
-  cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dw.p, dy.p, s, nullptr, last);
+  cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dw.p, dy.p, s, nullptr, last, dinfo.p);
   SK_HIP_TRY(hipStreamSynchronize(s));
   SK_HIP_TRY(hipStreamDestroy(s));
   s = nullptr;
@@ -945,7 +945,7 @@ int sk_cholesky_solve_segments(int n, const double* A, const double* b, double* 
   DevBuf<double> dLinvR, dwR, dyR;
   SK_HIP_TRY(dLinvR.alloc(dR * 128)); SK_HIP_TRY(dLinvR.zero(s)); SK_HIP_TRY(dwR.alloc(dR)); SK_HIP_TRY(dyR.alloc(dR));
   cholesky_factor(dFR.p, (long)dR, (int)dR, dLinvR.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr, lastR.empty() ? nullptr : lastR.data(), chain);
-  cholesky_backsolve(dFR.p, (long)dR, nroot, (int)dR, nroot, dLinvR.p, dwR.p, dyR.p, s, nullptr, lastR.empty() ? nullptr : lastR.data());
+  cholesky_backsolve(dFR.p, (long)dR, nroot, (int)dR, nroot, dLinvR.p, dwR.p, dyR.p, s, nullptr, lastR.empty() ? nullptr : lastR.data(), dinfo.p);
   std::vector<double> y(dR);
   for (auto& lf : leaves) {
     const SegmentLayout& L = lf->L;

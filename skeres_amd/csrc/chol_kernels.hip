@@ -1069,6 +1069,103 @@ __global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same backward substitution as ONE resident launch (round 3).  The 122 dependent launches of bs_step_kernel cost
+// 5.7 us each on Ladybug-1723 — dispatch, a memory round trip for w, one for the block row — 0.65 ms of an 8.9 ms
+// iteration for 0.3 ms of memory traffic.  Here block column kb has an OWNER workgroup (blockIdx nblk - 1 - kb: the
+// last block column, which starts the chain, is dispatched first, and no workgroup waits for one dispatched after it,
+// so the grid drains however few of its workgroups are resident at once).  The owner keeps w_kb in LDS and Linv_kb in
+// registers, applies the block rows kb' > kb of its envelope in descending order as their y_kb' appear —
+//   w_kb -= L[kb'][kb]^T y_kb'      (the 128 x 128 block prefetched into registers while it waits)
+// — then forms y_kb = Linv_kb^T w_kb and publishes it.  There is no flag: y itself is the signal.  The y buffer is
+// filled with a pattern no arithmetic produces (all ones) before the launch, a producer writes its 128 values through
+// to memory, consumers poll the values they need with device-scope loads: ONE memory round trip per hop of the chain.
+// The sums are grouped exactly as in bs_step_kernel (16 groups of 8 rows per update, 8 groups of 16 rows per y): the
+// solution is the same, bit for bit (tests/test_gpu_parity.py::test_resident_backsolve_is_bitwise_the_launch_by_launch_one).
+// A poll gives up after kChainTimeoutTicks: info = 2 (the caller factors and solves again, launch by launch).
+// ---------------------------------------------------------------------------
+struct BsTop { unsigned short top[1024]; };  // per block column: the last block row of its contiguous run (<= nblk - 1)
+constexpr unsigned long long kBsSentinel = ~0ull;
+__global__ __launch_bounds__(256, 1) void bs_resident_kernel(const double* __restrict__ Linv, const double* __restrict__ S, long ld, const double* __restrict__ rhs,
+                                                              int n, double* y, int nblk, BsTop env, int* info) {
+  __shared__ double ysh[128], wsh[128], part[16][128];
+  __shared__ int abort_s;
+  const int kb = nblk - 1 - (int)blockIdx.x;
+  const int t = threadIdx.x, c = t & 127, half = t >> 7;
+  if (t == 0) abort_s = 0;
+  if (t < 128) { const int j = kb * 128 + t; wsh[t] = j < n ? rhs[j] : 0.0; }
+  double li[64], lr[64];
+  {
+    const double* p = Linv + (long)kb * 128 * 128 + (long)(half * 64) * 128 + c;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) li[i] = p[(long)i * 128];
+  }
+  const int top = min((int)env.top[kb], nblk - 1);
+  int cur = (kb < nblk - 1 && top < nblk - 1) ? nblk - 1 : top;  // block rows to apply: nblk - 1 (always active), then top .. kb + 1
+  const double* Lcol = S + (long)(half * 64) * ld + (long)kb * 128 + c;
+  if (cur > kb) {
+    const double* p = Lcol + (long)cur * 128 * ld;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) lr[i] = p[(long)i * ld];
+  }
+  __syncthreads();
+  while (cur > kb) {
+    if (t < 128) {
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(y + (long)cur * 128 + t);
+      unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v == kBsSentinel) {
+        const long long t0 = wall_clock64();
+        do {
+          __builtin_amdgcn_s_sleep(1);
+          v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v == kBsSentinel && wall_clock64() - t0 > kChainTimeoutTicks) { abort_s = 1; v = 0ull; }
+        } while (v == kBsSentinel);
+      }
+      ysh[t] = __longlong_as_double((long long)v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sacc += lr[g * 8 + i] * ysh[half * 64 + g * 8 + i];
+      part[half * 8 + g][c] = sacc;
+    }
+    const int nxt = (cur == nblk - 1 && top < nblk - 1) ? top : cur - 1;
+    if (nxt > kb) {  // the next block: its loads are in flight across the barrier and the next poll
+      const double* p = Lcol + (long)nxt * 128 * ld;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) lr[i] = p[(long)i * ld];
+    }
+    __syncthreads();
+    if (t < 128) {
+      double u = 0.0;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) u += part[g][t];
+      wsh[t] -= u;
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc += li[g * 16 + i] * wsh[half * 64 + g * 16 + i];
+    part[half * 4 + g][c] = sacc;
+  }
+  __syncthreads();
+  if (t < 128) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sacc += part[q][t];
+    unsigned long long bits = (unsigned long long)__double_as_longlong(sacc);
+    if (bits == kBsSentinel) bits ^= 1ull;  // (a NaN out of a failed factorisation must not look like "not there yet")
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(y + (long)kb * 128 + t), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (t == 0 && abort_s && info) info_raise(info, 2);
+}
+
 __global__ void copy_row_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int npad) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < npad) dst[j] = j < n ? src[j] : 0.0;
@@ -1090,6 +1187,7 @@ static int g_chain_server = 1;  // developer knob SK_CHOL_CHAIN_SERVER=0: the la
 static int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see cholesky_plan (developer knobs SK_CHAIN_MAX_TRAILING, SK_CHAIN_PREFIX_GROUP)
 static int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK (developer knob SK_THIN_SYRK)
 static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
+static std::atomic<int> g_bs_resident{1};  // developer knob SK_BS_RESIDENT=0: the back-substitution as one launch per block step (bs_step_kernel)
 // Unsupported test hooks, read once in cholesky_init (cholesky_factor runs on two threads when a tail front has its own):
 // SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds, once per process, what that column's launch waits for (the wait
 // times out; tests/chain_abort_worker.py); SK_CHAIN_NO_SERVER_JOIN=1 leaves the server's stream unjoined (a probe).
@@ -1101,6 +1199,7 @@ hipError_t cholesky_init() {
     if (const char* e = getenv("SK_CHAIN_NO_SERVER_JOIN")) g_no_server_join.store(atoi(e));
   });
   if (const char* e = getenv("SK_TAIL_TILES")) g_tail_tiles = atoi(e);  // developer knobs
+  if (const char* e = getenv("SK_BS_RESIDENT")) g_bs_resident.store(atoi(e));
   if (const char* e = getenv("SK_TAIL_GROUP")) g_tail_group = atoi(e);
   if (const char* e = getenv("SK_THIN_GRID")) g_thin_grid = atoi(e);
   if (const char* e = getenv("SK_THIN_SYRK")) g_thin_syrk_tiles = atoi(e);
@@ -1594,6 +1693,7 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
 // device factors launch by launch from here on, and the caller factors the same matrix again that way (BalSolver::try_step).
 // Returns true when the caller should do that.
 bool cholesky_note_info(CholeskyContext* ctx, int info) {
+  if (info == 2) g_bs_resident.store(0);  // (whichever resident kernel it was: the back-substitution is launch by launch from here on, too)
   if (info != 2 || !ctx || !ctx->dq) return false;
   std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());
   if (ctx->dq->chain_server) {
@@ -1859,8 +1959,17 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
 // y (npad) <- solution of L^T y = z, with z^T = row rhs_row of L (first n entries).  w: scratch (npad).
 // With an envelope, block row kb of L is zero left of the first block column c with last[c] >= kb.
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt, const int* last) {
+                        hipStream_t s, KernelTimer* kt, const int* last, int* info) {
   const int nblk = npad / 128;
+  if (info && g_bs_resident && nblk <= 1024) {
+    BsTop env;
+    for (int c = 0; c < nblk; ++c) env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1);
+    if (kt) kt->begin("backsolve", s);
+    (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(256), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info);
+    if (kt) kt->end("backsolve", s);
+    return;
+  }
   hipLaunchKernelGGL(copy_row_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, n, npad);
   if (kt) kt->begin("backsolve", s);
   int c0 = 0;

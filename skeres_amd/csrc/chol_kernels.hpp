@@ -186,8 +186,9 @@ struct CholeskyPlan {
 };
 CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols = -1, int tail_rows = 1);
 int cholesky_plan_max_group(const CholeskyPlan& plan);
+// info != nullptr: one resident launch (bs_resident_kernel; a time-out of its polls raises *info to 2); nullptr: one launch per block step
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt, const int* last = nullptr);
+                        hipStream_t s, KernelTimer* kt, const int* last = nullptr, int* info = nullptr);
 // --- dissected factorisation (chol_kernels.hip, "Two-way dissection") ---
 struct FrontView {
   double* S = nullptr; long ld = 0;   // row-major, lower triangle

@@ -799,6 +799,26 @@ def test_resident_chain_timeout_is_reported_and_refactored():
         assert abs(a - b) <= 1e-9 * max(abs(b), 1e-300)
 
 
+def test_resident_backsolve_is_bitwise_the_launch_by_launch_one(tmp_path):
+    """the back-substitution of the reduced system as ONE resident launch (bs_resident_kernel: an owner
+    workgroup per block column, the solution vector itself as the hand-over signal) instead of one launch per block step —
+    the same sums in the same order: every solution of tests/backsolve_worker.py (a banded and a dense system, three LM
+    iterations of a 400-camera problem) bit for bit."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "backsolve_worker.py")
+    res = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / ("bs%s.npz" % mode))
+        out = subprocess.run([sys.executable, worker, path], env=dict(os.environ, SK_BS_RESIDENT=mode), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        res[mode] = np.load(path)
+    for k in ("banded", "dense", "bal_x", "bal_costs"):
+        assert np.array_equal(res["1"][k], res["0"][k]), k
+    assert len(res["1"]["bal_costs"]) == 4 and res["1"]["bal_costs"][-1] < res["1"]["bal_costs"][0]
+
+
 def test_two_solvers_share_the_queues_of_their_device():
     """the factorisation's queues belong to the DEVICE (csrc/device_table.hpp), not to the process or
     the solver.  Two solvers created with setDevice(0), alive at the same time and stepped alternately, give the
