@@ -357,6 +357,22 @@ int sk_options_set_cholesky_dissection(sk_options* o, int mode);
 typedef int (*sk_allreduce_fn)(void* user, double* device_buffer, size_t count, void* hip_stream);
 int sk_options_set_distributed(sk_options* o, int rank, int world, sk_allreduce_fn allreduce,
                                void* user);
+/* A ready-made `allreduce` over RCCL for callers that have no collective of their own (C, C++, the JVM: INTEGRATION.md
+ * section 3) — the native counterpart of skeres_amd/dist.py's torch.distributed hook.  librccl.so is opened at run time
+ * (dlopen): the library loads without it, and these calls then fail with SK_ERR_COMM / NULL + sk_last_error.
+ *   rank 0:      sk_rccl_unique_id(id)  — 128 bytes (ncclUniqueId), passed to the other ranks by the caller's own means;
+ *   every rank:  h = sk_allreduce_rccl_init(rank, world, id)  — ncclCommInitRank on the CURRENT HIP device — or
+ *                h = sk_allreduce_rccl_create(comm) around an ncclComm_t the caller already has (not destroyed by _free);
+ *                sk_options_set_distributed(o, rank, world, sk_allreduce_rccl_fn(), h);
+ *   afterwards:  sk_allreduce_rccl_free(h).
+ * The hook is an in-place ncclAllReduce(ncclDouble, ncclSum) on the stream the solver hands it. */
+typedef struct sk_rccl sk_rccl;
+int sk_rccl_unique_id(void* id128);
+sk_rccl* sk_allreduce_rccl_init(int rank, int world, const void* id128);
+sk_rccl* sk_allreduce_rccl_create(void* nccl_comm);
+void sk_allreduce_rccl_free(sk_rccl* h);
+long sk_allreduce_rccl_calls(const sk_rccl* h);
+sk_allreduce_fn sk_allreduce_rccl_fn(void);
 /* SEGMENTED: the camera sequence is dissected (sk_options_set_cholesky_dissection): rank 0's device eliminates the head and
  * its points, rank 1's the tail (further ranks replicate rank r mod 2 and add zeros to the sums); what is all-reduced per
  * iteration is the separator's system with both Schur complements — a few MB instead of the reduced system — and the two

@@ -139,6 +139,12 @@ _SIGS = {
     "sk_solver_stat": (C.c_int, [C.c_void_p, C.c_char_p, _dp]),
     "sk_last_status": (C.c_int, []),
     "sk_cholesky_solve_dissected": (C.c_int, [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sk_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "sk_allreduce_rccl_init": (C.c_void_p, [C.c_int, C.c_int, C.c_void_p]),
+    "sk_allreduce_rccl_create": (C.c_void_p, [C.c_void_p]),
+    "sk_allreduce_rccl_free": (None, [C.c_void_p]),
+    "sk_allreduce_rccl_calls": (C.c_long, [C.c_void_p]),
+    "sk_allreduce_rccl_fn": (C.c_void_p, []),
     "sk_cholesky_solve_segments": (C.c_int, [C.c_int, _dp, _dp, _dp, C.c_int, _ip, C.c_int, C.c_int]),
     "sk_cholesky_solve_ex": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, C.c_int]),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
@@ -1110,6 +1116,12 @@ class Solver:
             self._keep.append(cb)
             _check(lib().sk_options_set_distributed(self._h, int(rank), int(world), cb, None))
 
+        def setDistributedRccl(self, rank, world, rccl):
+            """The library's own RCCL hook (sk_allreduce_rccl_fn) instead of a Python callback: `rccl` is an RcclAllReduce."""
+            fn = C.cast(lib().sk_allreduce_rccl_fn(), ALLREDUCE_FN)
+            self._keep.append(rccl)
+            _check(lib().sk_options_set_distributed(self._h, int(rank), int(world), fn, rccl._h))
+
         def setCholeskyEnvelope(self, on):
             """DENSE_SCHUR: factor only the blocks inside the reduced system's block envelope (default on; bit-identical)."""
             _check(lib().sk_options_set_cholesky_envelope(self._h, int(bool(on))))
@@ -1244,6 +1256,39 @@ def cholesky_solve_dissected(A, b, head, tail_begin, group=0, automatic_plan=Fal
     _check(lib().sk_cholesky_solve_dissected(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp), int(head), int(tail_begin),
                                              int(group), int(bool(automatic_plan))))
     return x
+
+
+class RcclAllReduce:
+    """Native RCCL all-reduce for the multi-GPU path (sk_allreduce_rccl_*): no torch involved.  Rank 0 makes the 128-byte
+    id (RcclAllReduce.unique_id()) and hands it to the others; every rank then constructs RcclAllReduce(rank, world, id) on
+    its own device."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().sk_rccl_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, rank, world, unique_id):
+        self._id = C.create_string_buffer(bytes(unique_id), 128)
+        self._h = lib().sk_allreduce_rccl_init(int(rank), int(world), self._id)
+        if not self._h:
+            raise SkeresError("status 6: %s" % lib().sk_last_error().decode())
+
+    @property
+    def calls(self):
+        return int(lib().sk_allreduce_rccl_calls(self._h))
+
+    def close(self):
+        if self._h:
+            lib().sk_allreduce_rccl_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def cholesky_solve_segments(A, b, cuts, group=0, automatic_plan=False):

@@ -989,6 +989,18 @@ def test_distributed_hook_path_world_of_one_matches_plain_solve():
     assert "DIST_GPU_OK" in out.stdout
 
 
+def test_native_rccl_hook_world_of_one_matches_plain_solve():
+    """sk_allreduce_rccl_* — the library's own RCCL all-reduce (librccl opened at run time), for callers
+    without torch.  tests/dist_rccl_worker.py: a communicator of one rank, the whole hook path, bit-identical to the plain solve."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_rccl_worker.py")], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "DIST_RCCL_OK" in out.stdout
+
+
 @pytest.mark.parametrize("world,mode", [(2, "sharded"), (3, "sharded"), (4, "sharded"), (2, "replicated"), (2, "auto")])
 def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode, shape=None, segments=None):
     """tests/dist_gpu_worker2.py: `world` ranks share GPU 0 and exchange through gloo (host-staged hook).  (Worlds of at
