@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--no-lookahead", action="store_true", help="(tuning) single-stream Cholesky")
     ap.add_argument("--no-alone", action="store_true", help="skip the untimed side measurements (profiling runs)")
     ap.add_argument("--full-factorisation", action="store_true", help="factor every 128-block of the reduced system (no block envelope)")
+    ap.add_argument("--dissection", default="auto", choices=["auto", "on", "off"], help="(tuning) two-way dissection of the camera sequence on ONE device")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -311,6 +312,7 @@ def main():
     options.setDevice(local_rank)
     options.setCholeskyTuning(args.group, not args.no_lookahead)
     options.setCholeskyEnvelope(not args.full_factorisation)
+    options.setCholeskyDissection(args.dissection)
     # a stream of our own, not torch's default (null) stream: the null stream synchronises implicitly with every
     # blocking stream, which would serialise the factorisation's CU-masked SYRK stream against it
     stream = torch.cuda.Stream(device=local_rank)

@@ -110,14 +110,14 @@ class BalSolver : public SolverBase {
   // over the fronts of the reduced system (one when it is not dissected); the tail front is factored launch by launch
   double syrk_flops_per_solve() const override {
     double f = 0.0;
-    for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && k != 1, nullptr, fr_[k].ncols, fr_[k].tail_rows);
+    for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && (k != 1 || tail_chain()), nullptr, fr_[k].ncols, fr_[k].tail_rows);
     return f;
   }
   double syrk_c_bytes_per_solve() const override {
     double tiles = 0.0;
     for (int k = 0; k < 3; ++k) {
       double t = 0.0;
-      if (fr_[k].nblk > 0) (void)cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && k != 1, &t, fr_[k].ncols, fr_[k].tail_rows);
+      if (fr_[k].nblk > 0) (void)cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && (k != 1 || tail_chain()), &t, fr_[k].ncols, fr_[k].tail_rows);
       tiles += t;
     }
     return tiles * 2.0 * 128.0 * 128.0 * sizeof(double);
@@ -158,7 +158,7 @@ class BalSolver : public SolverBase {
       int r = 0;
       for (int k = 0; k < 3; ++k) {
         if (fr_[k].nblk == 0) continue;
-        const CholeskyPlan plan = cholesky_plan(fr_[k].nblk, group_, fr_[k].env(), chain_live() && k != 1, fr_[k].ncols, fr_[k].tail_rows);
+        const CholeskyPlan plan = cholesky_plan(fr_[k].nblk, group_, fr_[k].env(), chain_live() && (k != 1 || tail_chain()), fr_[k].ncols, fr_[k].tail_rows);
         for (char c : plan.resident) r += c ? 1 : 0;
       }
       *value = r;
@@ -182,6 +182,7 @@ class BalSolver : public SolverBase {
   // by launch — SK_CHOL_CHAIN_SERVER=0, a time-out — is cholesky_factor's business: chain_live())
   bool chain_ok() const { return opt_.cholesky_group == 0 && opt_.lookahead && chol_ctx_.server != nullptr; }
   bool chain_live() const { return chain_ok() && cholesky_chain_enabled(&chol_ctx_); }
+  bool tail_chain() const { return chol_ctx_b_.server != nullptr; }  // one device, dissected: the tail front has a resident chain of its own
   int distribution(double* allreduce_s, double* saved_s) const override {
     if (allreduce_s) *allreduce_s = est_allreduce_s_;
     if (saved_s) *saved_s = est_saved_s_;
@@ -993,7 +994,7 @@ int BalSolver::setup() {
     if (F.nblk == 0) continue;
     std::vector<int> col0(F.nblk, 0);
     // the widest group of either way to factor (with / without the resident chain, which a timing mode switches off)
-    const bool chain_here = chain_ok() && f != 1;
+    const bool chain_here = chain_ok() && (f != 1 || tail_chain());
     const int widen = F.last.empty() ? 1 : std::max(group_, cholesky_plan_max_group(cholesky_plan(F.nblk, group_, F.last.data(), chain_here, F.ncols, F.tail_rows)));
     if (!F.last.empty()) {
       int c = 0;

@@ -1399,7 +1399,15 @@ hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
   DeviceQueues* q = primary.dq;
   std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());  // (the device's entry may gain streams below)
   dq = q; device = primary.device;
+  // A resident potrf server of its own (round 3): one of the candidates the primary context does not use, on the same
+  // CU mask (CU 0 of every XCD: eight CUs, a server each).  SK_DISSECT_TAIL_CHAIN=0: none — the tail launch by launch.
   server = nullptr;
+  {
+    static const int tail_chain = getenv("SK_DISSECT_TAIL_CHAIN") ? atoi(getenv("SK_DISSECT_TAIL_CHAIN")) : 1;
+    if (tail_chain && primary.server)
+      for (int k = kServerCand - 1; k >= 0 && !server; --k) if (q->server_candidates[k] && q->server_candidates[k] != primary.server) server = q->server_candidates[k];
+  }
+  prepared = true;  // (the queues are chosen here, from what the device's trial left over: cholesky_prepare must not adopt the primary's)
   reserved_cus = q->reserved_cus; early_tiles = q->early_tiles;
   const char* mode = getenv("SK_DISSECT_B_STREAMS");  // developer knob: "plain" = ordinary streams instead of the left-over CU-masked candidates
   if (mode && !strcmp(mode, "plain")) {
@@ -1426,7 +1434,7 @@ hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
     if (bb >= 0) { bulk = q->bulk_candidates[bb]; bulk_early = q->bulk_early_candidates[bb]; }
     if (getenv("SK_DEBUG_QUEUES")) std::fprintf(stderr, "[skeres_amd] secondary context: panel candidate %d (primary %d), bulk candidate %d (primary %d)\n", bp, kp, bb, kb);
   }
-  if (!panel || !bulk) { panel = bulk = bulk_early = nullptr; return hipErrorNotSupported; }  // (no CU-masked candidates on this device)
+  if (!panel || !bulk) { panel = bulk = bulk_early = nullptr; server = nullptr; return hipErrorNotSupported; }  // (no CU-masked candidates on this device)
   if (const char* e = getenv("SK_DISSECT_B_SINGLE")) if (atoi(e)) bulk = bulk_early = panel;  // developer knob: the whole tail on ONE in-order queue
   if (!q->fork) {
     if (hipStreamCreateWithFlags(&q->fork, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); panel = bulk = bulk_early = nullptr; return hipErrorOutOfMemory; }
@@ -2114,7 +2122,8 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
   bool tail_async = false;
   auto tail = [&]() {
     if (d.B.ncols <= 0) return;
-    if (!side) { cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, false, d.B.ncols); return; }
+    // (one after the other on the primary context: launch by launch, as the fronts' plans assume when there is no second server)
+    if (!side) { cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, allow_chain && ctxB && ctxB->server, d.B.ncols); return; }
     fork_join_events(ctxB);
     static const int no_fork = getenv("SK_DISSECT_NO_FORK") ? atoi(getenv("SK_DISSECT_NO_FORK")) : 0;  // developer knob: the tail's panel queue stands in for its caller's stream
     hipStream_t sB = no_fork ? ctxB->panel : ctxB->fork;
@@ -2122,9 +2131,10 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
     (void)hipStreamWaitEvent(sB, ctxB->fork_ev, 0);
     // the tail's launches (and the event that says they are all enqueued behind `fork`) from ctxB's own thread: the
     // head's are enqueued by this one meanwhile
-    auto job = [&d, info, group, ctxB, ktB, sB] {
+    const bool chainB = allow_chain && ctxB->server != nullptr;  // the tail under a resident chain of its own
+    auto job = [&d, info, group, ctxB, ktB, sB, chainB] {
       const auto h0 = std::chrono::steady_clock::now();
-      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, sB, ctxB, ktB, d.B.last, false, d.B.ncols);
+      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, sB, ctxB, ktB, d.B.last, chainB, d.B.ncols);
       (void)hipEventRecord(ctxB->join_ev, sB);
       if (timing) std::fprintf(stderr, "[skeres_amd]   host: tail enqueued in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count());
     };
