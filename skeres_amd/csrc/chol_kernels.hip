@@ -59,7 +59,8 @@ constexpr int gemm_lds_doubles(int kBKT, int kTM, int kTN) { return 2 * (kTM + k
 template <int kMode, int kShape, int kBKT, int kPF, int kTM, int kTN>
 __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ldc, const double* A, long lda, const double* B, long ldb, int K,
                                                  int tiles_m, int skip, int main_t = 0x7fffffff, int jump_t = 0, int main_n = 0x7fffffff,
-                                                 int jump_n = 0, int block_id = -1, int* first_column_done = nullptr) {
+                                                 int jump_n = 0, int block_id = -1, int* first_column_done = nullptr, int count_cols = 1,
+                                                 int* diag_done = nullptr) {
   constexpr int mode = kMode;
   constexpr int kLdT = kBKT + 2;            // LDS row stride in doubles
   constexpr int kChA = kTM * kBKT / 512;    // 16-byte chunks per thread and stage, A operand
@@ -69,7 +70,8 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ld
   static_assert(kChA >= 1 && kChB >= 1, "tile too small for 256 staging threads");
   constexpr int kShBuf = (kTM + kTN) * kLdT;  // shp: 2 * kShBuf doubles of LDS (gemm_lds_doubles), 16-byte aligned
   int ti, tj;
-  bool first_column = false;  // kShape 2: a tile of the first block column of the enumeration (see the epilogue)
+  bool first_column = false;  // kShape 2: a tile of the first block column(s) of the enumeration (see the epilogue)
+  bool diag_tile = false;     // ... of the first DIAGONAL block: what the resident potrf server waits for after a paired SYRK
   if (kShape == 1) {
     const int b = blockIdx.x + skip;  // lower-triangular enumeration
     int r = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
@@ -93,7 +95,8 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ld
     while ((r + 1) * (r + 2) / 2 <= k) ++r;
     while (r * (r + 1) / 2 > k) --r;
     tj = T - 1 - r;
-    first_column = tj == 0;
+    first_column = tj < count_cols;
+    diag_tile = tj == 0 && (k - r * (r + 1) / 2) == T - 1;
     ti = (T - 1 - (k - r * (r + 1) / 2)) * kSub + w % kSub;
     if (ti >= main_t) ti += jump_t;
     if (tj >= main_n) tj += jump_n;
@@ -207,7 +210,10 @@ __device__ __forceinline__ void gemm_nt_f64_body(double* shp, double* C, long ld
           __hip_atomic_store(&Cg[(long)(crow + mt * 16 + 4 * i) * ldc + ccol + nt * 16], sgn * acc[mt][nt][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(first_column_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(first_column_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (diag_done && diag_tile) __hip_atomic_fetch_add(diag_done, 16 / (128 / kTM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // 16 when the block's tiles are in
+    }
     return;
   }
 #pragma unroll
@@ -232,9 +238,9 @@ __global__ __launch_bounds__(256, 2) void syrk_trailing_f64_kernel(double* C, lo
 // 30-50 us however few tiles there are (load 128 KB of C, eight K-steps, store 128 KB); 32-row tiles are four
 // times as many workgroups, each a quarter as long, and the whole launch fits in two rounds.
 __global__ __launch_bounds__(256, 2) void syrk_trailing_thin_f64_kernel(double* C, long ldc, const double* A, long lda, int K, int tiles_m, int main_t,
-                                                                        int jump_t, int main_n, int jump_n, int* first_column_done) {
+                                                                        int jump_t, int main_n, int jump_n, int* first_column_done, int count_cols, int* diag_done) {
   SK_GEMM_LDS(16, 32, 128)
-  gemm_nt_f64_body<0, 2, 16, 2, 32, 128>(sh, C, ldc, A, lda, A, lda, K, tiles_m, 0, main_t, jump_t, main_n, jump_n, -1, first_column_done);
+  gemm_nt_f64_body<0, 2, 16, 2, 32, 128>(sh, C, ldc, A, lda, A, lda, K, tiles_m, 0, main_t, jump_t, main_n, jump_n, -1, first_column_done, count_cols, diag_done);
 }
 // Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
 // transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
@@ -934,7 +940,7 @@ __device__ __forceinline__ long crit_tile_off(long ldc, int i) {
 // Xs: 128 x 128 scratch.  X(j+1,j) cannot be formed in place tile by tile (every column tile reads whole rows of
 // S(j+1,j)): the tiles go to Xs, which next(j) reads, and into S(j+1,j) once all 16 are known to have loaded theirs.
 __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld, int j, const double* Linv_j, int tiles_m, int main_t, int jump_t,
-                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info) {
+                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info, int do_next, int wait_first) {
   __shared__ __attribute__((aligned(16))) double sh[2 * 32 * kCritLd];
   static_assert(2 * 32 * kCritLd >= gemm_lds_doubles(16, 32, 128), "LDS of the thin tiles");
   __shared__ int ok_s;
@@ -952,7 +958,12 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
   // A wait that gave up (its own time-out, or the abort flag another wait raised): this column was NOT computed.  The
   // host must hear of it from whichever kernel noticed — the server may have nothing left to wait for (the last
   // column of a resident run hands back to launch-by-launch kernels, which would factor stale data): *info = 2.
-  if (threadIdx.x == 0) ok_s = chain_wait(sync + kSyncPotrfDone, j + 1, sync + kSyncAbort) ? 1 : 0;
+  // wait_first: block column j received its last update from the K = 256 SYRK of the resident pair before it (not from the
+  // column launch before this one, which stream order would cover): the server went ahead on the diagonal block alone, the
+  // TRSM needs every row — the SYRK's first block columns, counted by its workgroups
+  if (threadIdx.x == 0)
+    ok_s = (chain_wait(sync + kSyncPotrfDone, j + 1, sync + kSyncAbort) &&
+            (!wait_first || (chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort) && chain_wait(sync + kSyncSyrkColumn, column_need, sync + kSyncAbort)))) ? 1 : 0;
   __syncthreads();
   if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
   SK_CHAIN_ACQUIRE_ALL
@@ -972,9 +983,12 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
     __syncthreads();
   }
   if (stamp) SK_CHAIN_STAMP(j, 4)
+  // do_next == 0: the SECOND column of a resident pair — its panel is applied by the pair's K = 256 SYRK, which also
+  // hands block column j + 1 to the server; only the 16 tiles of block row j + 1 have something left to do (X into place)
+  if (!do_next && !crit) return;
   if (threadIdx.x == 0)
-    ok_s = (chain_wait(x_ready, ncrit, sync + kSyncAbort) && chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort) &&
-            chain_wait(sync + kSyncSyrkColumn, column_need, sync + kSyncAbort)) ? 1 : 0;
+    ok_s = (chain_wait(x_ready, ncrit, sync + kSyncAbort) && (!do_next || (chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort) &&
+            chain_wait(sync + kSyncSyrkColumn, column_need, sync + kSyncAbort)))) ? 1 : 0;
   __syncthreads();
   if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
   SK_CHAIN_ACQUIRE_ALL
@@ -983,6 +997,7 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
   if (crit) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) A21[(long)(ri * 32) * ld + q * 32 + crit_tile_off(ld, i)] = xacc[i];  // every tile has read S(j+1,j) by now
+    if (!do_next) return;
     if (q <= ri) {  // the server reads the lower 32-blocks only
       double* Ct = A21 + 128 + (long)(ri * 32) * ld + q * 32;
       d4 acc;
@@ -1185,6 +1200,13 @@ static int g_ext_events = 1;  // events on the producing kernel's own dispatch (
 static unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;  // developer knob SK_LA_SYSTEM_FENCE=1: default fences
 static int g_chain_server = 1;  // developer knob SK_CHOL_CHAIN_SERVER=0: the launch-per-step panel chain even where the resident one applies (initial value of every device's DeviceQueues::chain_server)
 static int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see cholesky_plan (developer knobs SK_CHAIN_MAX_TRAILING, SK_CHAIN_PREFIX_GROUP)
+// Most trailing tile rows of a resident PAIR of block columns (cholesky_plan; developer knob SK_CHAIN_PAIR_MAX_TRAILING).  0 = no
+// pairs, the DEFAULT: measured on Ladybug-1723 with 56 (block columns 8-44 as 18 pairs + 1: every column under the server) the
+// factorisation takes 7.14 ms against 7.13 with those columns launch by launch, and the bench line 8.86 ms against 8.65 —
+// that region is bound by the in-situ rate of its K = 256 SYRKs either way (34 TFLOP/s in the 32-row tiling the pairs need for
+// their first-column signal, 38 in the 128-row tiling the launch-by-launch plan uses above 48 tile rows), not by its panel
+// chain (profiles/r03_pair_chain_timeline.txt).  Kept behind the knob, covered by tests/pair_plan_worker.py.
+static int g_pair_max_trailing = 0;
 static int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK (developer knob SK_THIN_SYRK)
 static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
 static std::atomic<int> g_bs_resident{1};  // developer knob SK_BS_RESIDENT=0: the back-substitution as one launch per block step (bs_step_kernel)
@@ -1209,6 +1231,7 @@ hipError_t cholesky_init() {
   if (const char* e = getenv("SK_CHOL_CHAIN_SERVER")) g_chain_server = atoi(e);
   if (const char* e = getenv("SK_CHAIN_MAX_TRAILING")) g_chain_max_trailing = atoi(e);
   if (const char* e = getenv("SK_CHAIN_PREFIX_GROUP")) g_chain_prefix_group = atoi(e);
+  if (const char* e = getenv("SK_CHAIN_PAIR_MAX_TRAILING")) g_pair_max_trailing = atoi(e);
   hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_server_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_potrf_lds);
   if (rc != hipSuccess) return rc;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1500,6 +1523,7 @@ static void plan_close_partial(CholeskyPlan* plan, int nblk, int ncols) {
 CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols, int tail_rows) {
   CholeskyPlan plan;
   plan.resident.assign(nblk, 0);
+  plan.paired.assign(nblk, 0);
   if (group < 1) group = 1;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
   if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
@@ -1531,6 +1555,26 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int
     if (e - j < kMinChainRun) for (int i = j; i < e; ++i) plan.resident[i] = 0;
     j = e;
   }
+  // Resident PAIRS (round 3): the block columns between two resident runs whose trailing update is too long for a K = 128
+  // SYRK per column (it would be bound by the traffic of its C tiles) but short enough for the 32-row tiling
+  // (g_pair_max_trailing) are taken two at a time UNDER THE SERVER as well: the first column's launch applies its panel to the
+  // second column only, the second column's launch is a TRSM, and ONE K = 256 SYRK applies both panels to everything from the
+  // next pair on — its first diagonal block, written through and counted by its own workgroups, is what the server waits
+  // for.  The serial chain of a pair is then two resident column cycles plus the first block column of that SYRK instead of
+  // eight launches with their dispatch and completion latencies; the SYRKs follow each other on the bulk stream as before.
+  if (g_pair_max_trailing > 0) {
+    bool any_resident = false;
+    for (int j = 0; j < jend; ++j) any_resident = any_resident || plan.resident[j];
+    auto pairable = [&](int c) { return !plan.resident[c] && count(c + 2, last_main(c)) <= g_pair_max_trailing && count(c + 2, last_main(c)) >= 1 && 4 * count(c + 1, last_main(c)) <= g_thin_grid; };
+    for (int j = 0; any_resident && j < jend;) {
+      if (!pairable(j)) { ++j; continue; }
+      int e = j;
+      while (e < jend && pairable(e)) ++e;
+      for (int c = j; c + 1 < e; c += 2) { plan.paired[c] = 1; plan.paired[c + 1] = 2; }
+      for (int c = j; c < e; ++c) plan.resident[c] = 1;  // (an odd column left over at the end of the run: resident on its own, one K = 128 SYRK)
+      j = e;
+    }
+  }
   if (!partial) plan.resident[nblk - 1] = plan.resident[nblk - 2];  // the server factors the last diagonal block too when it has the column before it
   bool any = false;
   for (int j = 0; j < nblk; ++j) any = any || plan.resident[j];
@@ -1538,6 +1582,7 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int
   const int pg = group == 1 ? g_chain_prefix_group : group;
   for (int k = 0; k < ncols;) {
     plan.bounds.push_back(k);
+    if (plan.paired[k] == 1) { k += 2; continue; }
     if (plan.resident[k]) { ++k; continue; }
     int stop = k;
     while (stop < ncols && !plan.resident[stop]) ++stop;
@@ -1853,6 +1898,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }
   if (!is_resident(0) && ncols > 0) panel(gb[0], gb[1]);
   hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
+  hipEvent_t syrk_any = nullptr, syrk_done2 = nullptr;  // the completion of the last SYRK launched (whenever it carries an event), and of the one before it
   int seq = 0;                     // SYRK completions announced to the chain so far (chain_marker_kernel)
   int col_seq = 0;                 // ... and first-column workgroups of SYRKs that announce themselves (syrk_trailing_thin_f64_kernel)
   for (int g = 0; g + 1 < ngroups; ++g) {
@@ -1867,7 +1913,11 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     // group's width there: block column k1 + 1 never received this panel's update — a wrong factor that the
     // full-size property tests could not see; tests/test_gpu_parity.py::test_default_plan_matches_explicit_grouping_at_full_size
     // and test_factorisation_plans_vs_numpy now do.)
-    const int na = resident ? 1 : gb[g + 2] - k1;
+    // a resident PAIR (cholesky_plan): one K = 256 SYRK applies both panels to everything from k1 on — there is no next(g);
+    // launch by launch (no resident chain on this device) the same launches, the next panel behind the whole SYRK
+    const bool pair = plan.paired[k0] == 1 && k1 - k0 == 2;
+    const bool after_pair = k0 > 0 && plan.paired[k0 - 1] == 2 && is_resident(k0 - 1);  // block column k0 was last updated by a resident pair's SYRK
+    const int na = pair ? 0 : (resident ? 1 : gb[g + 2] - k1);
     const int Lg = last_main(k1 - 1);  // rows below Lg (other than nblk-1) are zero in every column of this group
     const Rows rn = rows_from(k1, Lg);       // rows that next(g) updates
     const Rows rs = rows_from(k1 + na, Lg);  // rows (and columns) that syrk(g) updates
@@ -1877,13 +1927,30 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     if (la) sb = Tb >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
     if (sb != sb_prev && syrk_done) (void)hipStreamWaitEvent(sb, syrk_done, 0);  // syrk(g) after syrk(g-1) across the two bulk streams
     sb_prev = sb;
-    if (resident) {
+    if (resident && pair) {
+      // first column: TRSM + its panel applied to the second column (the server waits for S(k0+1,k0+1)); second column: TRSM.
+      // The first column's workgroups wait (resident, 66 KB of LDS each, a few hundred of them) for the first block columns of
+      // the SYRK before this pair, which starts when the SYRK before THAT has finished: launched any earlier they would sit on
+      // the CUs for the whole length of that SYRK and take its occupancy.  So the launch follows the completion of the SYRK
+      // two back (an event that rode on its dispatch).
+      if (syrk_done2) (void)hipStreamWaitEvent(sp, syrk_done2, 0);
+      hipEvent_t col_done = ctx->event(ev++);
+      for (int c = 0; c < 2; ++c) {
+        const Rows rc = rows_from(k0 + c + 1, last_main(k0 + c));
+        const int T = rc.main + rc.extra;
+        const int ncrit = (rc.main > 0 || rc.jump == 0) ? 16 : 0;
+        hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, c == 1 ? col_done : (hipEvent_t) nullptr, 0, S, ld,
+                              k0 + c, (const double*)(Linv + (long)(k0 + c) * 128 * 128), 4 * T, 4 * rc.main, 4 * rc.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, info,
+                              c == 0 ? 1 : 0, c == 0 && after_pair ? 1 : 0);
+      }
+      (void)hipStreamWaitEvent(sb, col_done, 0);
+    } else if (resident) {
       const int T = rn.main + rn.extra;  // rows of X(.,k0) == rows that next(g) updates (K = 128, na == 1)
       // block row k0+1 is active as the start of the main run, or as the last block row itself
       const int ncrit = (rn.main > 0 || rn.jump == 0) ? 16 : 0;
       hipEvent_t col_done = Tb > 0 ? ctx->event(ev++) : nullptr;
       hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, col_done, 0, S, ld, k0,
-                            (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, info);
+                            (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, info, 1, after_pair ? 1 : 0);
       if (col_done) (void)hipStreamWaitEvent(sb, col_done, 0);
     } else {
       // panel(g) is final: syrk(g) may start (after syrk(g-1))
@@ -1899,16 +1966,18 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       double* Cb = S + (long)(k1 + na) * 128 * ld + (long)(k1 + na) * 128;
       const double* Pb = S + (long)(k1 + na) * 128 * ld + (long)k0 * 128;
       // the launch-by-launch next(g+1) waits for this SYRK as an event; so does a SYRK that follows on the other bulk stream
-      bool record = la && !next_resident;
+      bool record = la && (!next_resident || (pair && !resident));  // (a pair launch by launch: the next panel waits for the whole SYRK)
       if (la && !record && g + 3 < (int)gb.size()) {
-        const Rows rs1 = rows_from(gb[g + 3], last_main(gb[g + 2] - 1));
+        // (where the NEXT group's SYRK starts: behind its next(g + 1) — one block column after a resident column, none after a pair)
+        const int k2 = gb[g + 2], na1 = (plan.paired[k1] == 1 && k2 - k1 == 2) ? 0 : (is_resident(k1) ? 1 : gb[g + 3] - k2);
+        const Rows rs1 = rows_from(k2 + na1, last_main(k2 - 1));
         record = (rs1.main + rs1.extra >= ctx->early_tiles) != (sb == ctx->bulk_early);
       }
       // ... an event that rides on the SYRK's own dispatch (as do the two of the kernel timer): a separate record is a
       // packet of its own behind the SYRK, in front of the next one
       hipEvent_t t_start = nullptr, t_stop = nullptr;
       if (kt) kt->pair("gemm_syrk", &t_start, &t_stop);
-      hipEvent_t stop_ev = t_stop ? t_stop : (record ? ctx->event(ev++) : nullptr);
+      hipEvent_t stop_ev = t_stop ? t_stop : ((record || (la && chain)) ? ctx->event(ev++) : nullptr);  // (under the chain every SYRK: a pair's column launch is gated on one, below)
       // What the next column launch waits for when it is resident: the FIRST block column of this SYRK, counted by its
       // own workgroups as they finish (the 32-row tiling: 4 Tb of them, enumerated first) — or, with the 128-row tiling,
       // the whole SYRK, announced by a marker kernel behind it.
@@ -1916,19 +1985,29 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       // waits for, once per process — the wait times out, and the factorisation must be reported as lost: info = 2)
       bool withheld = false;
       if (next_resident && !ctx->dq->tuning) { int want = k1; withheld = want >= 0 && g_test_withhold.compare_exchange_strong(want, -1); }
-      const bool thin = Tb <= g_thin_syrk_tiles, by_column = next_resident && thin && g_early_column;
+      const bool pair_chain = pair && resident;  // (always the 32-row tiling: its first block columns count themselves)
+      const bool thin = Tb <= g_thin_syrk_tiles || pair_chain, by_column = next_resident && thin && (g_early_column || pair_chain);
+      // after a resident pair the next column launch updates the SECOND block column this SYRK touches (its own next(j) applies
+      // panel j to block column j + 1): both are counted; and the first diagonal block is what the server waits for
+      const int count_cols = pair_chain ? 2 : 1;
       if (thin)
         hipExtLaunchKernelGGL(syrk_trailing_thin_f64_kernel, dim3(2 * Tb * (Tb + 1)), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 4 * Tb, 4 * rs.main,
-                              4 * rs.jump, rs.main, rs.jump, by_column && !withheld ? sync + kSyncSyrkColumn : (int*)nullptr);
+                              4 * rs.jump, rs.main, rs.jump, by_column && !withheld ? sync + kSyncSyrkColumn : (int*)nullptr, count_cols,
+                              pair_chain && next_resident && !withheld ? sync + kSyncHeader + k1 : (int*)nullptr);
       else
         hipExtLaunchKernelGGL(syrk_trailing_f64_kernel, dim3(Tb * (Tb + 1) / 2), dim3(256), 0, sb, t_start, stop_ev, 0, Cb, ld, Pb, ld, K, 0, rs.main, rs.jump);
       if (by_column) {
-        col_seq += 4 * Tb;
+        col_seq += 4 * Tb + (count_cols > 1 && Tb > 1 ? 4 * (Tb - 1) : 0);
       } else if (next_resident) {
         ++seq;
         if (!withheld) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, seq);
       }
       if (record) syrk_done = stop_ev;
+      syrk_done2 = syrk_any;
+      syrk_any = stop_ev;
+    } else {
+      syrk_done2 = syrk_any;
+      syrk_any = nullptr;
     }
     if (next_resident) {
       // hand-over: block column k1 has its last launch-by-launch update; the server takes it from here (a column launch
@@ -1939,7 +2018,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       // group take this panel's update from syrk(g), on the bulk stream)
       const int k2 = gb[g + 2];
       if (k1 < ncols) {
-        if (resident && k2 - k1 > 1 && la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
+        if ((pair || (resident && k2 - k1 > 1)) && la && syrk_done) (void)hipStreamWaitEvent(sp, syrk_done, 0);
         panel(k1, k2);
       }
     }
@@ -2220,7 +2299,8 @@ double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, dou
   double f = 0.0, tiles = 0.0;
   for (size_t g = 0; g + 2 < gb.size(); ++g) {
     if (gb[g] >= ncols) break;
-    const int k0 = gb[g], k1 = gb[g + 1], na = plan.resident[k0] ? 1 : gb[g + 2] - k1;  // as cholesky_factor splits next(g) / syrk(g)
+    const int k0 = gb[g], k1 = gb[g + 1];
+    const int na = (plan.paired[k0] == 1 && k1 - k0 == 2) ? 0 : (plan.resident[k0] ? 1 : gb[g + 2] - k1);  // as cholesky_factor splits next(g) / syrk(g)
     const int Lg = last ? (last[k1 - 1] < nblk - 1 ? last[k1 - 1] : nblk - 1) : nblk - 1;
     const int first_row = k1 + na;
     const int main_rows = Lg >= first_row ? Lg - first_row + 1 : 0;

@@ -183,6 +183,7 @@ void cholesky_disable_chain(CholeskyContext* ctx);
 struct CholeskyPlan {
   std::vector<int> bounds;  // group start columns + nblk
   std::vector<char> resident;  // per block column: under the resident panel chain
+  std::vector<char> paired;    // ... as the first (1) / second (2) column of a resident pair (one K = 256 SYRK for both); else 0
 };
 CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols = -1, int tail_rows = 1);
 int cholesky_plan_max_group(const CholeskyPlan& plan);

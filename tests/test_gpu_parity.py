@@ -819,6 +819,19 @@ def test_resident_backsolve_is_bitwise_the_launch_by_launch_one(tmp_path):
     assert len(res["1"]["bal_costs"]) == 4 and res["1"]["bal_costs"][-1] < res["1"]["bal_costs"][0]
 
 
+def test_resident_pairs_plan_vs_numpy_and_oracle():
+    """The plan with resident PAIRS of block columns (one K = 256 SYRK per pair under the potrf server; built in round 3,
+    measured not to pay and off by default: SK_CHAIN_PAIR_MAX_TRAILING) stays correct: tests/pair_plan_worker.py with the
+    knob on — numpy's factor at 1e-11 on four envelope shapes, the oracle's trajectory on a 400-camera problem."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pair_plan_worker.py")
+    out = subprocess.run([sys.executable, worker], env=dict(os.environ, SK_CHAIN_PAIR_MAX_TRAILING="56"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "PAIR_PLAN_OK" in out.stdout
+
+
 def test_two_solvers_share_the_queues_of_their_device():
     """the factorisation's queues belong to the DEVICE (csrc/device_table.hpp), not to the process or
     the solver.  Two solvers created with setDevice(0), alive at the same time and stepped alternately, give the
