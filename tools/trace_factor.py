@@ -13,7 +13,7 @@ for r in rows:
 rows.sort(key=lambda r: r['s'])
 pi = [i for i, r in enumerate(rows) if r['n'] == 'bal_pair_kernel'][-1]
 it = rows[pi:]
-end = [i for i, r in enumerate(it) if r['n'] == 'copy_row_kernel'][0]
+end = [i for i, r in enumerate(it) if r['n'] in ('copy_row_kernel', 'bs_resident_kernel')][0]  # (the back-substitution: what follows the factorisation)
 names = ('potrf128_kernel', 'trsm_gemm_f64_kernel', 'trsm_gemm_thin_f64_kernel', 'gemm_update_f64_kernel', 'gemm_update_thin_f64_kernel',
          'gemm_diag_f64_kernel', 'syrk_trailing_f64_kernel', 'syrk_trailing_thin_f64_kernel', 'potrf_server_kernel', 'chain_column_kernel',
          'chain_marker_kernel', 'crit_server_kernel')
