@@ -136,11 +136,11 @@ def phase_rooflines(phases_ms, n_obs, envelope_bytes):
 PHASE_NAMES = ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"]
 
 
-def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, world, dist_mod=None, torch=None):
+def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, world, dist_mod=None, torch=None, long_range_fraction=0.0):
     """One more bundle-adjustment workload of BASELINE.json in the same run (configs[1] BAL-49, configs[3] Venice-1778): `steps`
     LM iterations of the same solve as the headline, timed the same way (barrier + synchronise on both sides, max over
     ranks); with several ranks, the distribution the solver chose, what travels per iteration and how long it takes."""
-    prob = bal.generate_named(name, seed=seed, perturb=PERTURB)
+    prob = bal.generate_named(name, seed=seed, perturb=PERTURB, long_range_fraction=long_range_fraction)
     problem, params, loss = build_problem(sk, prob)
     o = sk.Solver.Options()
     o.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
@@ -184,7 +184,8 @@ def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, wor
     its = summ.iterations()
     phases = {k: 1e3 * summ.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(PHASE_NAMES)}
     chol_s = phases["cholesky"] * 1e-3
-    rec = {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d), DENSE_SCHUR" % (name, prob.num_cameras, prob.num_points, prob.num_observations, seed),
+    rec = {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d%s), DENSE_SCHUR" % (
+               name, prob.num_cameras, prob.num_points, prob.num_observations, seed, ", long_range_fraction %g" % long_range_fraction if long_range_fraction else ""),
            "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "iterations_per_second": steps / elapsed,
            "phases_ms_per_step": phases, "envelope_fill": stats["envelope_fill"],
            "roofline_cholesky_phase": {"bound": "mfma", "flops": stats["cholesky_flops_plan"], "achieved": stats["cholesky_flops_plan"] / chol_s * 1e-12 if chol_s > 0 else None,
@@ -413,6 +414,14 @@ def main():
             extra["c4" if world == 1 else "venice"] = bal_record(sk, bal, "venice-1778-993923", 1778, 10, 2, local_rank, stream, rank, world, dist_mod, torch)
         except sk.SkeresError as e:
             extra["c4" if world == 1 else "venice"] = {"error": str(e)}
+        if world == 1:
+            # what the headline rests on: the same problem with 0.5 % of the tracks seen from two distant windows (loop closures:
+            # the envelope of the reduced system fills up and the block-envelope factorisation has no zeros left to skip)
+            try:
+                extra["loop_closures"] = bal_record(sk, bal, "ladybug-1723-156502", SEED, 6, 2, local_rank, stream, rank, world, dist_mod, torch,
+                                                    long_range_fraction=0.005)
+            except sk.SkeresError as e:
+                extra["loop_closures"] = {"error": str(e)}
         if not args.no_c5:
             try:
                 extra["c5"] = c5_record(sk, rank=rank, world=world, stream=stream, torch=torch, dist_mod=dist_mod)

@@ -281,7 +281,8 @@ int sk_problem_add_residual_blocks(sk_problem* p, int functor_id, int n, const d
 int sk_problem_add_residual_blocks_tape(sk_problem* p, const sk_cost_function* cost, int n, const double* captured,
                                         const sk_loss_function* loss, double* const* parameter_blocks);
 /* Bulk add of `num_rows` residual blocks of a dense-row functor (SK_FUNCTOR_SYNTH_TANH_ROW) that all
- * depend on the single parameter block x[0..n).  consts is num_rows x 3 row-major. */
+ * depend on the single parameter block x[0..n).  consts is num_rows x 3 row-major.  `loss` (NULL == trivial) applies to
+ * every row of the call; the dense-rows solver takes ONE loss for all rows of a problem (SK_ERR_UNSUPPORTED otherwise). */
 int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const double* consts,
                               const sk_loss_function* loss, double* x, int n);
 /* ceres::Problem::AddParameterBlock(values, size[, local_parameterization]), SetParameterization,

@@ -164,7 +164,11 @@ static bool evaluate_dense(const Problem& P, const double* x, bool want_jac, Den
       const int blk = P.pidx[P.pidx_off[b]], off = P.block_off[blk], nb = P.block_size[blk];
       if (!synth_tanh_row_evaluate(P.consts + P.const_off[b], x + off, nb, &out->r[P.res_off[b]],
                                    want_jac ? &out->J[(size_t)P.res_off[b] * n + off] : nullptr)) { ok = false; break; }
-      csum += out->r[P.res_off[b]] * out->r[P.res_off[b]];
+      {  // the block's loss and corrector, as for every other residual block below (the Jacobian row is corrected in place)
+        int Nb[1] = {nb};
+        double* jrow[1] = {want_jac ? &out->J[(size_t)P.res_off[b] * n + off] : nullptr};
+        csum += oracle::loss_correct(P.loss_nodes, P.block_loss.empty() ? -1 : P.block_loss[b], 1, &out->r[P.res_off[b]], 1, Nb, want_jac ? jrow : nullptr);
+      }
       continue;
     }
     FunctorInfo fi; functor_info(P.functor[b], &fi);

@@ -489,7 +489,6 @@ int sk_problem_add_residual_blocks_tape(sk_problem* p, const sk_cost_function* c
 }
 int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const double* consts, const sk_loss_function* loss, double* x, int n) {
   SK_GUARD_BEGIN
-  if (loss && !loss->l.nodes.empty()) { set_error("dense rows take the trivial loss only"); return SK_ERR_UNSUPPORTED; }
   if (!p || num_rows < 0 || !consts || !x || n <= 0) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
   if (functor_id != SK_FUNCTOR_SYNTH_TANH_ROW) { set_error("functor %d is not a dense-row functor", functor_id); return SK_ERR_INVALID_ARGUMENT; }
   Problem& P = p->p;
@@ -497,7 +496,7 @@ int sk_problem_add_dense_rows(sk_problem* p, int functor_id, int num_rows, const
   if (id < 0) return SK_ERR_INVALID_ARGUMENT;
   const size_t base = P.rb_functor.size();
   P.rb_functor.resize(base + num_rows, functor_id); P.rb_num_residuals.resize(base + num_rows, 1); P.rb_cost.resize(base + num_rows, nullptr);
-  P.rb_loss.resize(base + num_rows, -1);
+  P.rb_loss.resize(base + num_rows, P.intern_loss(loss ? &loss->l : nullptr));  // (one loss for the rows of a call; the solver takes one for all rows)
   P.rb_const_off.reserve(base + num_rows); P.rb_pidx.reserve(P.rb_pidx.size() + num_rows); P.rb_pidx_off.reserve(P.rb_pidx_off.size() + num_rows);
   for (int i = 0; i < num_rows; ++i) {
     P.rb_const_off.push_back(P.consts.size() + 3 * (size_t)i);
@@ -705,7 +704,7 @@ int sk_synth_dense_targets(double seed, int m, int n, const double* x_star, doub
   DevBuf<double> dc, dx, dr;
   hipStream_t s = nullptr;
   SK_HIP_TRY(dc.upload(consts, s)); SK_HIP_TRY(dx.upload(xs, s)); SK_HIP_TRY(dr.alloc(m));
-  DenseRowsArgs a; a.m = m; a.n = n; a.m_pad = m; a.consts = dc.p; a.inv_sqrt_n = 1.0 / std::sqrt((double)n);
+  DenseRowsArgs a{}; a.loss_root = -1; a.m = m; a.n = n; a.m_pad = m; a.consts = dc.p; a.inv_sqrt_n = 1.0 / std::sqrt((double)n);
   launch_rows_residual(a, dx.p, dr.p, nullptr, false, s);
   SK_HIP_TRY(hipMemcpy(y_out, dr.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
   return SK_OK;

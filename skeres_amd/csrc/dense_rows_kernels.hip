@@ -7,6 +7,7 @@
 // tanh propagates (tanh u, (1 - tanh^2 u) a)  — the spire / Ceres Jet rule for tanh.
 #include <hip/hip_runtime.h>
 #include "dense_rows_kernels.hpp"
+#include "loss.hpp"
 #include "synth.hpp"
 
 namespace sk {
@@ -31,8 +32,20 @@ __global__ __launch_bounds__(256) void rows_residual_kernel(DenseRowsArgs a, con
   }
   if (!live) return;
   const double t = tanh(u * a.inv_sqrt_n);
-  r[i] = t - a.consts[3 * (size_t)i + 2];
-  if (want_sd) sd[i] = (1.0 - t * t) * a.inv_sqrt_n;
+  double res = t - a.consts[3 * (size_t)i + 2], d = (1.0 - t * t) * a.inv_sqrt_n;
+  if (a.loss_root >= 0) {
+    const double sq = res * res;
+    double rho[3];
+    loss_evaluate(a.loss_nodes, a.loss_root, sq, rho);
+    a.cterm[i] = rho[0];
+    if (want_sd) {  // (the candidate evaluation needs the cost term only)
+      const LossCorrector c(sq, rho);
+      d *= c.sqrt_rho1 * (1.0 - c.alpha_sq_norm * sq);
+      res *= c.residual_scaling;
+    }
+  }
+  r[i] = res;
+  if (want_sd) sd[i] = d;
 }
 
 // Jt[j][i] = sd_i * unit(i, j) * scale_j  — one workgroup = 256 residuals x 16 parameters
@@ -94,11 +107,11 @@ __global__ __launch_bounds__(256) void rows_model_kernel(const double* __restric
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
-// partial[b] = sum r_i^2 over the workgroup
-__global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restrict__ r, int m, double* __restrict__ partial) {
+// partial[b] = sum r_i^2 over the workgroup (cterm != nullptr: sum of the rows' cost terms rho(r_i^2) instead)
+__global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restrict__ r, const double* __restrict__ cterm, int m, double* __restrict__ partial) {
   __shared__ double sh[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  sh[threadIdx.x] = i < m ? r[i] * r[i] : 0.0;
+  sh[threadIdx.x] = i < m ? (cterm ? cterm[i] : r[i] * r[i]) : 0.0;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
@@ -126,9 +139,9 @@ int launch_rows_model(const double* Jt, const double* r, const double* step, int
   hipLaunchKernelGGL(rows_model_kernel, dim3(g), dim3(256), 0, s, Jt, r, step, m, n, m_pad, partial);
   return g;
 }
-int launch_rows_sumsq(const double* r, int m, double* partial, hipStream_t s) {
+int launch_rows_sumsq(const double* r, const double* cterm, int m, double* partial, hipStream_t s) {
   const int g = (m + 255) / 256;
-  hipLaunchKernelGGL(rows_sumsq_kernel, dim3(g), dim3(256), 0, s, r, m, partial);
+  hipLaunchKernelGGL(rows_sumsq_kernel, dim3(g), dim3(256), 0, s, r, cterm, m, partial);
   return g;
 }
 void launch_rows_set_rhs(double* H, long ld, int rhs_row, const double* gs, int n, hipStream_t s) {

@@ -60,6 +60,8 @@ class DenseRowsSolver : public SolverBase {
   DevBuf<double> b_consts_, b_xa_, b_xb_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_, b_w_, b_r_, b_rc_, b_sd_, b_Jt_, b_H_, b_Linv_,
       b_partial_, b_small_, b_scal_;
   DevBuf<int> b_info_;
+  DevBuf<LossNode> b_loss_nodes_;
+  DevBuf<double> b_cterm_;
   CholeskyContext chol_ctx_;
   double* x_ = nullptr; double* x_new_ = nullptr;
   double* h_scal_ = nullptr;
@@ -117,6 +119,14 @@ int DenseRowsSolver::setup() {
   SK_HIP_TRY(cholesky_init());
   if (opt_.lookahead && chol_ctx_.init() != hipSuccess) { (void)hipGetLastError(); opt_.lookahead = false; }
   a_.m = m_; a_.n = n_; a_.m_pad = m_pad_; a_.consts = b_consts_.p; a_.inv_sqrt_n = 1.0 / std::sqrt((double)n_);
+  // one robust loss for every row (ceres.i:159-184; the residual kernel applies loss and corrector per row)
+  a_.loss_nodes = nullptr; a_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0]; a_.cterm = nullptr;
+  for (size_t b = 1; b < p.rb_loss.size(); ++b)
+    if (p.rb_loss[b] != p.rb_loss[0]) { set_error("dense rows take one loss function for all rows"); return SK_ERR_UNSUPPORTED; }
+  if (a_.loss_root >= 0) {
+    SK_HIP_TRY(b_loss_nodes_.upload(p.loss_nodes, s)); SK_HIP_TRY(b_cterm_.alloc(m_));
+    a_.loss_nodes = b_loss_nodes_.p; a_.cterm = b_cterm_.p;
+  }
   SK_HIP_TRY(hipStreamSynchronize(s));
   return SK_OK;
 }
@@ -140,7 +150,7 @@ int DenseRowsSolver::evaluate_with_jacobian(bool first) {
     launch_rows_scale(b_Jt_.p, b_scale_.p, m_, n_, m_pad_, s);
     launch_apply_scale_to_reductions(b_colsq_.p, b_gs_.p, b_scale_.p, n_, s);
   }
-  const int g = launch_rows_sumsq(b_r_.p, m_, b_partial_.p, s);
+  const int g = launch_rows_sumsq(b_r_.p, a_.cterm, m_, b_partial_.p, s);
   launch_final_reduce(b_partial_.p, g, g, 1, 0, b_scal_.p, s);
   if (opt_.allreduce) { int rc = allreduce(b_scal_.p, 1); if (rc) return rc; }  // sum r^2 over the ranks' rows
   const int gg = launch_grad_max_xnorm(b_gs_.p, b_scale_.p, x_, n_, b_small_.p, 256, s);
@@ -180,7 +190,7 @@ int DenseRowsSolver::try_step(double radius, bool* valid, double* mcc, double* n
   launch_final_reduce(b_partial_.p, gm, gm, 1, 0, b_scal_.p + 1, s);
   SK_HIP_TRY(hipEventRecord(ev_[kEvBacksub], s));
   launch_rows_residual(a_, x_new_, b_rc_.p, b_sd_.p, false, s);
-  const int g = launch_rows_sumsq(b_rc_.p, m_, b_partial_.p, s);
+  const int g = launch_rows_sumsq(b_rc_.p, a_.cterm, m_, b_partial_.p, s);
   launch_final_reduce(b_partial_.p, g, g, 1, 0, b_scal_.p + 2, s);
   if (opt_.allreduce) { int rc = allreduce(b_scal_.p + 1, 2); if (rc) return rc; }  // model term and candidate sum r^2 over the ranks' rows
   SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));

@@ -140,15 +140,16 @@ def test_predefined_loss_functions_construction_and_validation():
         deep = L.composedLoss(deep, L.trivialLoss())
     with pytest.raises(sk.SkeresError, match="nested deeper"):
         L.composedLoss(deep, None)
-    # a problem accepts any of them per residual block; dense rows take the trivial loss only
+    # a problem accepts any of them per residual block; dense rows take ONE for all their rows (refused at solve time otherwise)
     m, c = sk.DoubleArray(1), sk.DoubleArray(1)
     problem = sk.Problem()
     for l in losses:
         problem.addResidualBlock(sk.ExponentialResidual(1.0, 2.0).toAutoDiffCostFunction(), l, m, c)
     assert problem.numResidualBlocks() == len(losses)
     x = sk.DoubleArray(8)
-    with pytest.raises(sk.SkeresError):
-        sk.Problem().addDenseRows(10, np.zeros((4, 3)), L.huberLoss(1.0), x, 8)
+    rows = sk.Problem()
+    rows.addDenseRows(10, np.zeros((4, 3)), L.huberLoss(1.0), x, 8)
+    assert rows.numResidualBlocks() == 4
     if sk.device_count() == 0:
         with pytest.raises(sk.SkeresError, match="no HIP device"):
             L.huberLoss(1.0).evaluate([1.0])
