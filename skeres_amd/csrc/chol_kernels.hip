@@ -1288,6 +1288,12 @@ struct DeviceQueues {
   std::atomic<int> chain_server{1};   // 0: block columns are factored launch by launch on this device (knob, or a time-out happened)
   hipStream_t fork = nullptr;  // stands in for the caller's stream in a secondary context (CholeskyContext::init_secondary)
   hipStream_t plain[2] = {nullptr, nullptr};
+  // The panel / bulk / server streams are the DEVICE's: two solvers on one device, driven from two threads, enqueue onto the
+  // same streams.  Interleaved, their cross-stream event waits can close a cycle (A's wait on the panel stream in front of
+  // B's panel kernel, B's wait on the bulk stream in front of A's SYRK: each waits for the other's queue to move).  A
+  // factorisation's launches are therefore enqueued as ONE unit per stream set: [0] the primary set, [1] the secondary one
+  // (the tail front of a dissected system, enqueued by its own thread NEXT TO the head's on purpose).
+  std::mutex enqueue_mutex[2];
 };
 static PerDeviceTable<DeviceQueues> g_device_queues;
 
@@ -1678,7 +1684,8 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
         // waits for a column launch that cannot start, gives up (kChainTimeoutTicks) and sets info.  Then every
         // block column is factored launch by launch for the rest of the process — the same plan, the same launches.
         int h = 0;
-        (void)hipMemcpy(&h, info, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpyAsync(&h, info, sizeof(int), hipMemcpyDeviceToHost, s);  // (not the null stream: it would wait for other solvers' resident servers)
+        (void)hipStreamSynchronize(s);
         if (h != 0) { serialised = true; break; }
       }
     }
@@ -1747,6 +1754,15 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
 // Returns true when the caller should do that.
 bool cholesky_note_info(CholeskyContext* ctx, int info) {
   if (info == 2) g_bs_resident.store(0);  // (whichever resident kernel it was: the back-substitution is launch by launch from here on, too)
+  if (info == 2 && ctx && ctx->sync && getenv("SK_DEBUG_CHAIN_ABORT")) {  // developer knob: where the chain stood when a wait gave up
+    std::vector<int> h((size_t)kSyncHeader + 2 * ctx->sync_blk);
+    (void)hipMemcpy(h.data(), ctx->sync, h.size() * sizeof(int), hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "[skeres_amd] chain abort: potrf_done %d abort %d syrk_seq %d syrk_column %d | diag_ready:", h[kSyncPotrfDone], h[kSyncAbort], h[kSyncSyrkSeq], h[kSyncSyrkColumn]);
+    for (int j = 0; j < 40 && j < ctx->sync_blk; ++j) std::fprintf(stderr, " %d", h[kSyncHeader + j]);
+    std::fprintf(stderr, " | x_ready:");
+    for (int j = 0; j < 40 && j < ctx->sync_blk; ++j) std::fprintf(stderr, " %d", h[kSyncHeader + ctx->sync_blk + j]);
+    std::fprintf(stderr, "\n");
+  }
   if (info != 2 || !ctx || !ctx->dq) return false;
   std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());
   if (ctx->dq->chain_server) {
@@ -1790,6 +1806,19 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   // one the trial picks): every look-ahead factorisation asks for the trial, which runs once per device.
   if (ctx && ctx->dq && !ctx->prepared && !(ctx->dq->tuning && ctx->in_trial)) cholesky_prepare(ctx, s);
   const bool la = ctx != nullptr && ctx->panel != nullptr && ctx->bulk != nullptr;
+  std::unique_lock<std::mutex> enqueue_lock;
+  const auto t_wait0 = std::chrono::steady_clock::now();
+  if (la && ctx->dq) enqueue_lock = std::unique_lock<std::mutex>(ctx->dq->enqueue_mutex[ctx->fork ? 1 : 0]);
+  struct EnqueueClock {  // developer knob SK_DEBUG_CHAIN_ABORT: a factorisation whose launches took the host unusually long to enqueue
+    std::chrono::steady_clock::time_point t0, t1 = std::chrono::steady_clock::now();
+    ~EnqueueClock() {
+      static const bool on = getenv("SK_DEBUG_CHAIN_ABORT") != nullptr;
+      const double held = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+      const double waited = std::chrono::duration<double, std::milli>(t1 - t0).count();
+      if (on && (held > 50.0 || waited > 500.0)) std::fprintf(stderr, "[skeres_amd] cholesky_factor: waited %.1f ms for the device's enqueue lock, enqueued for %.1f ms\n", waited, held);
+    }
+  } enqueue_clock;
+  enqueue_clock.t0 = t_wait0;
   hipStream_t sp = la ? ctx->panel : s;
   hipStream_t sb = la ? ctx->bulk : s;  // of the current group (chosen below)
   hipStream_t sb_prev = sb;

@@ -186,7 +186,10 @@ int DenseSolver::host_callbacks(const double* x_dev, bool jac) {
         for (int r = 0; r < nres; ++r) {
           rowbuf.resize(nq);
           for (int j = 0; j < nq; ++j) rowbuf[j] = jbuf[q][(size_t)r * nq + j] * scale[off + j];
-          SK_HIP_TRY(hipMemcpy(Jrows + (size_t)(res_off_h_[b] + r) * ng_ + off, rowbuf.data(), nq * sizeof(double), hipMemcpyHostToDevice));
+          // (on the solver's stream, never the null stream: a null-stream copy would wait for every blocking stream of the device —
+          // among them another solver's resident potrf server — and hold back whatever is enqueued behind it)
+          SK_HIP_TRY(hipMemcpyAsync(Jrows + (size_t)(res_off_h_[b] + r) * ng_ + off, rowbuf.data(), nq * sizeof(double), hipMemcpyHostToDevice, stream_));
+          SK_HIP_TRY(hipStreamSynchronize(stream_));  // (rowbuf is reused)
         }
       }
     }
