@@ -477,6 +477,14 @@ int sk_solver_stat(const sk_solver* s, const char* name, double* value);
  * not bundle-adjustment shaped. */
 int sk_problem_point_partition(const sk_problem* p, int world, int* cuts, int* num_cameras,
                                int* num_points, int* point_of_block);
+/* The plan of the SEGMENTED distribution for this problem, from host data alone (no device needed; what every rank derives
+ * for itself at set-up): the camera sequence cut into *num_segments segments (at most max_segments; 1 = not cut) with a
+ * separator between neighbours.  camera_part_of_block[b] (may be NULL): the segment of residual block b's camera, or -k for a
+ * camera of separator k (1 <= k < segments); point_owner_of_block[b] (may be NULL): the rank that owns block b's point.
+ * forced != 0: as SK_DISTRIBUTION_SEGMENTED cuts (as many segments as the sequence allows); 0: as AUTO (the chain model's
+ * choice).  No point is seen from two segments; a point's blocks all have one owner. */
+int sk_problem_segment_plan(const sk_problem* p, int max_segments, int forced, int* num_segments, int* camera_part_of_block,
+                            int* point_owner_of_block);
 
 /* ---- inputs of BASELINE.json config 5 (utility) ----------------------------------
  * y_out[i] = tanh(a_i . x_star) for the generated rows a_i of SK_FUNCTOR_SYNTH_TANH_ROW

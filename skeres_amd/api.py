@@ -153,6 +153,7 @@ _SIGS = {
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
     "sk_synth_dense_targets": (C.c_int, [C.c_double, C.c_int, C.c_int, _dp, _dp]),
     "sk_problem_point_partition": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip]),
+    "sk_problem_segment_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _ip]),
 }
 
 
@@ -1039,6 +1040,15 @@ class Problem:
         if rc == 1:
             raise ValueError(lib().sk_last_error().decode())
         _check(rc)
+
+    def segmentPlan(self, max_segments, forced=True):
+        """(number of segments, camera part of every residual block — its segment, or -k for separator k —, owner rank of every
+        block's point): the segmented distribution's plan (sk_problem_segment_plan; host logic, no device needed)."""
+        nb = self.numResidualBlocks()
+        n = C.c_int(0)
+        part, owner = np.zeros(nb, dtype=np.int32), np.zeros(nb, dtype=np.int32)
+        _check(lib().sk_problem_segment_plan(self._h, int(max_segments), int(bool(forced)), C.byref(n), part.ctypes.data_as(_ip), owner.ctypes.data_as(_ip)))
+        return n.value, part, owner
 
     def pointPartition(self, world):
         """(cuts[world+1], num_cameras, num_points, point_of_block[num residual blocks]):

@@ -534,6 +534,35 @@ static std::vector<int> rcm_order(const std::vector<int>& ocam, const std::vecto
   return new_id;
 }
 
+// The candidate orders of the cameras inside the reduced system and the one with the fewest trailing-update flops (ties keep
+// the earlier candidate).  with_memory_order: host addresses are this process's own — with separately allocated camera
+// blocks the order could differ from rank to rank, and the ranks must build the same reduced system: one process only (the
+// slot then repeats candidate 0, which keeps the numbering of sk_solver_stat("camera_order")).
+static std::vector<std::vector<int>> camera_order_candidates(const Problem& p, const std::vector<int>& cam_block, const std::vector<int>& ocam,
+                                                             const std::vector<int>& opt, int C, int P, bool with_memory_order) {
+  std::vector<std::vector<int>> cand;
+  { std::vector<int> id(C); std::iota(id.begin(), id.end(), 0); cand.push_back(id); }  // first appearance
+  if (with_memory_order) {
+    std::vector<int> by_addr(C); std::iota(by_addr.begin(), by_addr.end(), 0);
+    std::sort(by_addr.begin(), by_addr.end(), [&](int a, int b) { return p.block_ptr[cam_block[a]] < p.block_ptr[cam_block[b]]; });
+    std::vector<int> id(C); for (int k = 0; k < C; ++k) id[by_addr[k]] = k; cand.push_back(id);
+  } else {
+    cand.push_back(cand[0]);
+  }
+  cand.push_back(rcm_order(ocam, opt, C, P));
+  return cand;
+}
+static void choose_camera_order(const std::vector<std::vector<int>>& cand, const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int npad,
+                                int* best_k, std::vector<int>* best_env, double* best_flops) {
+  double best = -1.0;
+  for (size_t k = 0; k < cand.size(); ++k) {
+    std::vector<int> env = envelope_of_order(ocam, opt, cand[k], C, P, npad / 128);
+    const double f = cholesky_syrk_flops(npad, 1, env.data());
+    if (best < 0.0 || f < best * (1.0 - 1e-9)) { best = f; *best_k = (int)k; best_env->swap(env); }
+  }
+  *best_flops = best;
+}
+
 // Sharding the points pays when the per-iteration work it removes from a rank (evaluation, Schur
 // assembly, back-substitution: linear in observations and pair entries) exceeds the all-reduce of the
 // reduced system it adds.  The all-reduce is MEASURED here (second and third call of the hook on the real
@@ -620,24 +649,11 @@ int BalSolver::setup() {
   // settings differ in nothing but the blocks they skip and give bit-identical results. ----
   {
     const int nblk = npad_ / 128;
-    std::vector<std::vector<int>> cand;
-    { std::vector<int> id(C_); std::iota(id.begin(), id.end(), 0); cand.push_back(id); }  // first appearance
-    // (memory order: host addresses are this process's own — with separately allocated camera blocks the order could
-    // differ from rank to rank, and the ranks must build the same reduced system: one process only)
-    if (!opt_.allreduce) {
-      std::vector<int> by_addr(C_); std::iota(by_addr.begin(), by_addr.end(), 0);
-      std::sort(by_addr.begin(), by_addr.end(), [&](int a, int b) { return p.block_ptr[cam_block_[a]] < p.block_ptr[cam_block_[b]]; });
-      std::vector<int> id(C_); for (int k = 0; k < C_; ++k) id[by_addr[k]] = k; cand.push_back(id);
-    } else {
-      cand.push_back(cand[0]);  // keeps the candidate numbering of sk_solver_stat("camera_order")
-    }
-    cand.push_back(rcm_order(ocam, opt, C_, P_total_));
-    double best = -1.0; int best_k = 0; std::vector<int> best_env;
-    for (size_t k = 0; k < cand.size(); ++k) {
-      std::vector<int> env = envelope_of_order(ocam, opt, cand[k], C_, P_total_, nblk);
-      const double f = cholesky_syrk_flops(npad_, 1, env.data());
-      if (best < 0.0 || f < best * (1.0 - 1e-9)) { best = f; best_k = (int)k; best_env.swap(env); }
-    }
+    std::vector<int> best_env;
+    double best = 0.0;
+    int best_k = 0;
+    std::vector<std::vector<int>> cand = camera_order_candidates(p, cam_block_, ocam, opt, C_, P_total_, opt_.allreduce == nullptr);
+    choose_camera_order(cand, ocam, opt, C_, P_total_, npad_, &best_k, &best_env, &best);
     const std::vector<int>& id = cand[best_k];
     camera_order_ = best_k;
     {  // what every rank must agree on: the order and the envelope (checked below, once the exchange buffers exist)
@@ -1451,6 +1467,44 @@ int BalSolver::write_back() {
 }
 
 }  // namespace
+
+// The segmented distribution's plan as the solver derives it (BalSolver::setup), from host data alone: for every residual
+// block the segment its camera belongs to (0 .. segments - 1; -k for a camera of separator k, 1 <= k < segments) and the rank
+// that owns its point.  Returns the number of segments (1: the sequence was not cut).  Rank-invariant by construction: the
+// same code every rank runs.
+int bal_segment_plan(const Problem& p, int max_segments, bool forced, std::vector<int>* block_camera_part, std::vector<int>* block_point_owner) {
+  std::vector<int> cam_block, pt_block, ocam, opt;
+  bal_index_problem(p, &cam_block, &pt_block, &ocam, &opt);
+  const int C = (int)cam_block.size(), P = (int)pt_block.size();
+  const int npad = ((9 * C + 1 + 127) / 128) * 128, nblk = npad / 128;
+  std::vector<int> env;
+  double flops = 0.0;
+  int best_k = 0;
+  const std::vector<std::vector<int>> cand = camera_order_candidates(p, cam_block, ocam, opt, C, P, false);
+  choose_camera_order(cand, ocam, opt, C, P, npad, &best_k, &env, &flops);
+  for (int& c : ocam) c = cand[best_k][c];
+  std::vector<int> first_col;
+  (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C); std::iota(e.begin(), e.end(), 0); return e; }(), C, P, nblk, &first_col);
+  const Segments sg = choose_segments(ocam, opt, C, P, nblk, env, first_col, max_segments, forced);
+  const int R = (int)sg.a.size() + 1;
+  std::vector<int> part(C, 0);  // per camera of the banded numbering
+  for (int c = 0; c < C; ++c) {
+    int seg = 0;
+    for (int k = 0; k < R - 1; ++k) {
+      if (c >= sg.a[k] && c < sg.b[k]) { seg = -(k + 1); break; }
+      if (c >= sg.b[k]) seg = k + 1;
+    }
+    part[c] = seg;
+  }
+  std::vector<int> seg_of_pt(P, -1);
+  for (size_t b = 0; b < ocam.size(); ++b) if (part[ocam[b]] >= 0) seg_of_pt[opt[b]] = part[ocam[b]];
+  block_camera_part->resize(ocam.size()); block_point_owner->resize(ocam.size());
+  for (size_t b = 0; b < ocam.size(); ++b) {
+    (*block_camera_part)[b] = part[ocam[b]];
+    (*block_point_owner)[b] = seg_of_pt[opt[b]] >= 0 ? seg_of_pt[opt[b]] : opt[b] % R;
+  }
+  return R;
+}
 
 std::unique_ptr<SolverBase> make_bal_solver(const Options& o, Problem* p) { return std::unique_ptr<SolverBase>(new BalSolver(o, p)); }
 

@@ -694,6 +694,21 @@ int sk_problem_point_partition(const sk_problem* p, int world, int* cuts, int* n
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }
 
+int sk_problem_segment_plan(const sk_problem* p, int max_segments, int forced, int* num_segments, int* camera_part_of_block, int* point_owner_of_block) {
+  SK_GUARD_BEGIN
+  if (!p || max_segments < 1 || !num_segments) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  std::string why;
+  if (!problem_is_bal_shaped(p->p, &why)) { set_error("%s", why.c_str()); return SK_ERR_UNSUPPORTED; }
+  std::vector<int> part, owner;
+  *num_segments = bal_segment_plan(p->p, max_segments, forced != 0, &part, &owner);
+  for (size_t b = 0; b < part.size(); ++b) {
+    if (camera_part_of_block) camera_part_of_block[b] = part[b];
+    if (point_owner_of_block) point_owner_of_block[b] = owner[b];
+  }
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
 int sk_synth_dense_targets(double seed, int m, int n, const double* x_star, double* y_out) {
   SK_GUARD_BEGIN
   if (m <= 0 || n <= 0 || !x_star || !y_out) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }

@@ -74,6 +74,7 @@ bool problem_is_bal_shaped(const Problem& p, std::string* why_not);
 void bal_index_problem(const Problem& p, std::vector<int>* cam_block, std::vector<int>* pt_block, std::vector<int>* ocam,
                        std::vector<int>* opt);
 void bal_partition_points(const std::vector<int>& opt, int num_points, int world, std::vector<int>* cut);
+int bal_segment_plan(const Problem& p, int max_segments, bool forced, std::vector<int>* block_camera_part, std::vector<int>* block_point_owner);
 // Generic dense Jacobian path: DENSE_QR / DENSE_NORMAL_CHOLESKY.
 std::unique_ptr<SolverBase> make_dense_solver(const Options& o, Problem* p);
 // Tall dense rows over one parameter block (transposed Jacobian + long-K MFMA SYRK): DENSE_NORMAL_CHOLESKY.
