@@ -44,6 +44,14 @@ __device__ __forceinline__ double* bal_rhs(const BalDev& d, int i) {
   return f.S + (size_t)f.rhs_row * f.ld + bal_pos(d, i, pi);
 }
 
+// rho(s) of observation o's loss: the one loss of the problem, or (mixed losses: BalDev::loss_of_obs) the observation's own —
+// a trivial one among robust ones is rho(s) = s, whose corrector is the identity.
+__device__ __forceinline__ void bal_loss_eval(const BalDev& d, size_t o, double s, double rho[3]) {
+  const int root = d.loss_of_obs ? d.loss_of_obs[o] : d.loss_root;
+  if (root < 0) { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; return; }
+  loss_evaluate(d.loss_nodes, root, s, rho);
+}
+
 // Block-level sum of up to 4 values; result valid in thread 0.
 // The per-point kernels give a point kPointLanes adjacent lanes, which take its observations in turn and are summed
 // in a fixed tree: with a lane per point, the points seen by a hundred cameras set the length of the whole launch
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void bal_eval_jac_kernel(BalDev d) {
     if (kLoss) {
       const double sq = r0 * r0 + r1 * r1;
       double rho[3];
-      loss_evaluate(d.loss_nodes, d.loss_root, sq, rho);
+      bal_loss_eval(d, o, sq, rho);
       const LossCorrector lc(sq, rho);
       acc[0] += rho[0];
 #pragma unroll
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void bal_eval_cost_kernel(BalDev d) {
     SnavelyReprojectionError::apply<double>(c, params, out);
     if (kLoss) {
       double rho[3];
-      loss_evaluate(d.loss_nodes, d.loss_root, out[0] * out[0] + out[1] * out[1], rho);
+      bal_loss_eval(d, o, out[0] * out[0] + out[1] * out[1], rho);
       acc[0] += rho[0];
     } else {
       acc[0] += out[0] * out[0] + out[1] * out[1];
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void bal_eval_jac_tape_kernel(BalDev d, Tap
         if (kLoss) {
           const double sq = r0 * r0 + r1 * r1;
           double rho[3];
-          loss_evaluate(d.loss_nodes, d.loss_root, sq, rho);
+          bal_loss_eval(d, o, sq, rho);
           const LossCorrector lc(sq, rho);
           acc[0] += rho[0];
           sqrt_rho1 = lc.sqrt_rho1; alpha_sq_norm = lc.alpha_sq_norm;
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void bal_eval_cost_tape_kernel(BalDev d, Ta
     tape_run<double>(t, c, param, 0, regs, out);
     if (kLoss) {
       double rho[3];
-      loss_evaluate(d.loss_nodes, d.loss_root, out[0] * out[0] + out[1] * out[1], rho);
+      bal_loss_eval(d, o, out[0] * out[0] + out[1] * out[1], rho);
       acc[0] += rho[0];
     } else {
       acc[0] += out[0] * out[0] + out[1] * out[1];
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void bal_host_jac_kernel(BalDev d, int part
     if (kLoss) {
       const double sq = r0 * r0 + r1 * r1;
       double rho[3];
-      loss_evaluate(d.loss_nodes, d.loss_root, sq, rho);
+      bal_loss_eval(d, o, sq, rho);
       const LossCorrector lc(sq, rho);
       acc[0] += rho[0];
 #pragma unroll
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void bal_host_cost_kernel(BalDev d, int par
     const double n0 = d.host_rows[(size_t)h * kHostRow], n1 = d.host_rows[(size_t)h * kHostRow + 1];  // residuals at the candidate point
     if (kLoss) {
       double rho[3];
-      loss_evaluate(d.loss_nodes, d.loss_root, n0 * n0 + n1 * n1, rho);
+      bal_loss_eval(d, o, n0 * n0 + n1 * n1, rho);
       acc[0] += rho[0];
     } else {
       acc[0] += n0 * n0 + n1 * n1;

@@ -64,8 +64,10 @@ struct BalDev {
   // reductions
   double* partial;  int partial_stride;
   int* fail_flag;
-  // robust loss shared by every residual block (loss.hpp); loss_root < 0 = trivial
-  const LossNode* loss_nodes;  int loss_root;
+  // robust loss (loss.hpp): loss_root < 0 = every residual block has the trivial loss; otherwise the root of the one loss all
+  // blocks share, or — loss_of_obs != nullptr: the blocks have different losses (CORE/Problem.scala:20 takes one per block) —
+  // any valid root (it only selects the kernels with a loss) and per observation its own root, -1 = trivial
+  const LossNode* loss_nodes;  int loss_root;  const int* loss_of_obs;
   // residual blocks whose cost function is the caller's host code (the reference's director path, ceres.i:48:
   // sk_cost_function_new_callback with 2 residuals over a 9- and a 3-block): evaluated on the host, their rows uploaded
   const unsigned char* is_host;  // [N] 1 = host-evaluated observation; nullptr when there is none

@@ -43,8 +43,6 @@ bool problem_is_bal_shaped(const Problem& p, std::string* why) {
     *why = "the recorded functor needs more registers (or captures more doubles) than the device interpreter holds: not supported";
     return false;
   }
-  for (size_t b = 1; b < nb && b < p.rb_loss.size(); ++b)
-    if (p.rb_loss[b] != p.rb_loss[0]) { *why = "DENSE_SCHUR takes one loss function for all residual blocks"; return false; }
   std::vector<char> role(p.block_size.size(), 0);
   for (size_t b = 0; b < nb; ++b) {
     const int c = p.rb_pidx[p.rb_pidx_off[b]], q = p.rb_pidx[p.rb_pidx_off[b] + 1];
@@ -223,6 +221,7 @@ class BalSolver : public SolverBase {
   std::vector<int> local_pt_;                 // global point id of local point
   BalDev d_{};
   DevBuf<LossNode> b_loss_nodes_;
+  DevBuf<int> b_loss_of_obs_;
   DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_obs_slot_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_, b_fail_, b_info_;
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_Fcam_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
@@ -1067,7 +1066,20 @@ int BalSolver::setup() {
     ds_.A = view(0); ds_.B = view(1); ds_.R = view(2); ds_.border_blocks = border_blocks_; ds_.mapB = b_mapB_.p;
   }
   d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = b_fail_.p;
-  d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0];
+  d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0]; d_.loss_of_obs = nullptr;
+  {
+    // one loss for every residual block (the usual case: SimpleBundleAdjuster shares one trivialLoss, EX/SimpleBundleAdjuster.scala:135),
+    // or a loss per block: then every observation carries its own root
+    bool mixed = false;
+    int any_root = -1;
+    for (size_t b = 0; b < p.rb_loss.size(); ++b) { mixed = mixed || p.rb_loss[b] != p.rb_loss[0]; any_root = std::max(any_root, p.rb_loss[b]); }
+    if (mixed) {
+      std::vector<int> roots(N_);
+      for (int o = 0; o < N_; ++o) roots[o] = p.rb_loss[order[o]];
+      SK_HIP_TRY(b_loss_of_obs_.upload(roots, s));
+      d_.loss_of_obs = b_loss_of_obs_.p; d_.loss_root = any_root;
+    }
+  }
   if (d_.loss_root >= 0) { SK_HIP_TRY(b_loss_nodes_.upload(p.loss_nodes, s)); d_.loss_nodes = b_loss_nodes_.p; }
   d_.is_host = nullptr; d_.num_host = (int)host_obs_.size(); d_.host_obs = nullptr; d_.host_rows = nullptr;
   if (!host_obs_.empty()) {
