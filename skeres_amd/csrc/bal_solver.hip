@@ -394,8 +394,9 @@ static std::vector<int> front_envelope(const std::vector<int>& ocam, const std::
 // predicted critical path.  forced: cut wherever separators exist (tests, small problems), as evenly as the sequence allows.
 struct Segments { std::vector<int> a, b; double t_plain = 0.0, t_model = 0.0; double model_us[9] = {0}; };
 static Segments choose_segments(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
-                                const std::vector<int>& first_col, int max_segments, bool forced) {
+                                const std::vector<int>& first_col, int max_segments, bool forced, int world = 0) {
   Segments out;
+  if (world <= 0) world = max_segments;
   max_segments = std::min(max_segments, 8);
   if (max_segments < 2 || C < 6) return out;
   std::vector<int> cmin(P, C), cmax(P, -1), reach(C);
@@ -458,9 +459,22 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
         const int E = sep_blocks(as[k]), Enext = k + 1 < as.size() ? sep_blocks(as[k + 1]) : 0;
         for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i + Enext, true);
       }
-      const double t = hi + root + 220.0;  // + fork, join, border add, the all-reduce of the root
+      // + the all-reduce of the root over the world's ranks: its lower triangle inside the block-tridiagonal envelope, a ring over
+      // one xGMI link per direction (153 GB/s: 2 (W - 1) / W x the bytes) — 39 MB and 0.4 ms for ONE 24-block separator, which is
+      // what keeps a second wide separator from paying on the Ladybug-shaped problem
+      double blocks = 0.0;
+      for (size_t k = 0; k < as.size(); ++k) {
+        const double E = sep_blocks(as[k]), Eprev = k > 0 ? sep_blocks(as[k - 1]) : 0.0;
+        blocks += 0.5 * E * (E + 1.0) + E * Eprev;
+      }
+      const int W = std::max(2, world);
+      const double allreduce_us = 50.0 + 2.0 * (W - 1.0) / W * blocks * 128.0 * 128.0 * 8.0 / 153e3;
+      const double t = hi + root + 170.0 + allreduce_us;  // + fork, join, border add
       out.model_us[Rn] = t;
-      if (forced ? true : t < best) { best = t; best_as = as; }  // (forced: a segment per rank, as far as the sequence can be cut)
+      if (getenv("SK_DEBUG_SEGMENTS")) std::fprintf(stderr, "[skeres_amd] %d segments: longest chain %.0f us, root %.0f us, all-reduce %.0f us (%.0f blocks) -> %.0f us (undissected %.0f)\n", Rn, hi, root, allreduce_us, blocks, t, out.t_plain);
+      // (forced: a segment per rank, as far as the sequence can be cut; otherwise a further segment has to beat the plan so far by
+      // 5 %: the model is no better than that, and every separator is more to all-reduce and to factor on every rank)
+      if (forced ? true : t < best * (Rn > 2 ? 0.95 : 1.0)) { best = t; best_as = as; }
     }
     out.t_model = best;
     if (!best_as.empty() && (forced || best <= 0.9 * out.t_plain)) {
@@ -651,16 +665,31 @@ int BalSolver::setup() {
     std::vector<int> best_env;
     double best = 0.0;
     int best_k = 0;
-    std::vector<std::vector<int>> cand = camera_order_candidates(p, cam_block_, ocam, opt, C_, P_total_, opt_.allreduce == nullptr);
-    choose_camera_order(cand, ocam, opt, C_, P_total_, npad_, &best_k, &best_env, &best);
-    const std::vector<int>& id = cand[best_k];
-    camera_order_ = best_k;
-    {  // what every rank must agree on: the order and the envelope (checked below, once the exchange buffers exist)
+    // The memory order of the camera blocks (the BAL file's numbering under the reference's layout) is usually the best
+    // candidate by far — and host addresses are a process's own: with separately allocated camera blocks it could differ from
+    // rank to rank, and the ranks must build the SAME reduced system.  Round 3: the ranks try it and compare (a hash of the
+    // order and the envelope: one tiny exchange); only if they disagree do they all fall back to the rank-invariant candidates.
+    // (Until then a world of ranks never used it: on the Ladybug-shaped problem the chain model of the best remaining order,
+    // reverse Cuthill-McKee, is 12.1 ms against 9.1 — every multi-rank run would have factored a third more slowly.)
+    std::vector<std::vector<int>> cand;
+    auto pick = [&](bool with_memory_order) {
+      cand = camera_order_candidates(p, cam_block_, ocam, opt, C_, P_total_, with_memory_order);
+      best_env.clear();
+      choose_camera_order(cand, ocam, opt, C_, P_total_, npad_, &best_k, &best_env, &best);
       unsigned long long h = 1469598103934665603ull;
-      for (int v : id) { h ^= (unsigned)v; h *= 1099511628211ull; }
+      for (int v : cand[best_k]) { h ^= (unsigned)v; h *= 1099511628211ull; }
       for (int v : best_env) { h ^= (unsigned)v; h *= 1099511628211ull; }
       order_hash_ = (double)(h >> 12);  // 52 bits: exact in a double
+    };
+    pick(true);
+    if (opt_.allreduce && opt_.world > 1) {
+      double v[2] = {order_hash_, -order_hash_};
+      int rc = gather_rank_scalars_signed(v, 2);
+      if (rc) return rc;
+      if (v[0] != order_hash_ || v[1] != -order_hash_) pick(false);  // (every rank sees the disagreement: max and min differ)
     }
+    const std::vector<int>& id = cand[best_k];
+    camera_order_ = best_k;
     std::vector<int> cb(C_);
     for (int c = 0; c < C_; ++c) cb[id[c]] = cam_block_[c];
     cam_block_.swap(cb);
@@ -712,7 +741,7 @@ int BalSolver::setup() {
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
       int max_seg = opt_.world;
       if (const char* e = getenv("SK_SEGMENTS")) max_seg = std::max(2, std::min(max_seg, atoi(e)));  // developer knob: at most that many segments
-      const Segments sg = choose_segments(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, max_seg, opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED);
+      const Segments sg = choose_segments(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, max_seg, opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED, opt_.world);
       cut_a = sg.a; cut_b = sg.b;
       dissect_t_plain_ = sg.t_plain; dissect_t_model_ = sg.t_model;
       for (int k = 0; k < 9; ++k) model_us_[k] = sg.model_us[k];
@@ -1492,7 +1521,7 @@ int bal_segment_plan(const Problem& p, int max_segments, bool forced, std::vecto
   std::vector<int> env;
   double flops = 0.0;
   int best_k = 0;
-  const std::vector<std::vector<int>> cand = camera_order_candidates(p, cam_block, ocam, opt, C, P, false);
+  const std::vector<std::vector<int>> cand = camera_order_candidates(p, cam_block, ocam, opt, C, P, true);  // (as the ranks do when their address orders agree)
   choose_camera_order(cand, ocam, opt, C, P, npad, &best_k, &env, &flops);
   for (int& c : ocam) c = cand[best_k][c];
   std::vector<int> first_col;

@@ -77,8 +77,9 @@ def main():
     else:  # a 2600-observation problem: the host-staged all-reduce costs far more than sharding saves
         assert used == "replicated" and t_allreduce > t_saved > 0.0, (used, t_allreduce, t_saved)
     if used == "replicated":
-        # one exchange at set-up (do all ranks have the look-ahead queues? they must factor by one plan), then only the probe of AUTO
-        assert hook.calls == 1 + ((3 + 1) if mode == "auto" else 0), hook.calls
+        # two exchanges at set-up (do all ranks have the look-ahead queues? they must factor by one plan; did all ranks pick the same
+        # camera order with the memory-order candidate in play?), then only the probe of AUTO
+        assert hook.calls == 2 + ((3 + 1) if mode == "auto" else 0), hook.calls
     a = [it["cost"] for it in summary.iterations()]
     b = [it["cost"] for it in s_plain.iterations()]
     assert abs(len(a) - len(b)) <= 1, (len(a), len(b), a[:8], b[:8])

@@ -4,7 +4,7 @@ copies the rank's buffer to the host, meets the other ranks at a barrier, sums t
 same sum: the ranks stay bitwise equal) and copies the sum back.  The solvers factor CONCURRENTLY on the device's shared
 look-ahead streams (enqueued as one unit per factorisation: chol_kernels.hip, DeviceQueues::enqueue_mutex).
 
-  python tests/threads_world_worker.py <world> <mode: segmented | sharded | rows> <shape> [segments]
+  python tests/threads_world_worker.py <world> <mode: segmented | sharded | rows> <shape> [segments | 0] [scrambled]
 
 Used by tests/test_gpu_parity.py::test_world_of_eight_ranks_as_threads_*."""
 import ctypes
@@ -95,8 +95,22 @@ def main():
     prob = bal.generate(shape[0], shape[1], shape[2], seed=shape[3])
     x_plain, s_plain = solve_bal_gpu(prob)
 
+    scrambled = len(sys.argv) > 5 and sys.argv[5] == "scrambled"
+
     def body(rank, hook):
-        problem, params, loss = bal_problem_to_sk(prob)
+        if scrambled and rank == 1:
+            # this rank keeps its cameras in REVERSE order in memory: its memory-order candidate for the camera sequence differs from
+            # the other ranks', the ranks notice (a hash of order and envelope) and all fall back to the rank-invariant candidates
+            C = prob.num_cameras
+            x0 = prob.parameters.copy()
+            x0[:9 * C] = prob.parameters[:9 * C].reshape(C, 9)[::-1].ravel()
+            params = sk.RichDoubleArray.fromArray(x0)
+            problem = sk.Problem()
+            loss = sk.PredefinedLossFunctions.trivialLoss()
+            offs = np.stack([9 * (C - 1 - prob.camera_index.astype(np.int64)), 9 * C + 3 * prob.point_index.astype(np.int64)], axis=1)
+            problem.addResidualBlocks(sk.SnavelyReprojectionError.FUNCTOR_ID, prob.observations, loss, params, offs)
+        else:
+            problem, params, loss = bal_problem_to_sk(prob)
         options = sk.Solver.Options()
         options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
         options.setDistributed(rank, world, hook)
@@ -108,12 +122,16 @@ def main():
             pass
         summary = sk.Solver.Summary()
         solver.finish(summary)
-        return params.toArray(prob.num_parameters), summary, used, segments
+        x = params.toArray(prob.num_parameters)
+        if scrambled and rank == 1:
+            C = prob.num_cameras
+            x[:9 * C] = x[:9 * C].reshape(C, 9)[::-1].ravel()
+        return x, summary, used, segments
     results, tw = run_ranks(world, body)
     b = [it["cost"] for it in s_plain.iterations()]
     for x, summary, used, segments in results:
         assert used == mode, (used, mode)
-        if mode == "segmented" and len(sys.argv) > 4:
+        if mode == "segmented" and len(sys.argv) > 4 and int(sys.argv[4]) > 0:
             assert segments == int(sys.argv[4]), (segments, sys.argv[4])
         a = [it["cost"] for it in summary.iterations()]
         assert abs(len(a) - len(b)) <= 1, (len(a), len(b), a[:6], b[:6])
