@@ -480,18 +480,20 @@ def main():
                                     "allreduce_ms_per_step": line["phases_ms_per_step"]["allreduce"]}
         # What the chain model (microseconds per block column — 42 under a resident chain, 70 launch by
         # launch, the trailing update at 32 TFLOP/s where that is longer) predicts for this problem cut into 2, 4 and 8
-        # segments, calibrated on this run: model(N) / model(1) x the measured Cholesky phase + the measured phases that
-        # shard with the points / N.  UNMEASURED on more than one device until a SCALE run exists; printed so that one can be
+        # segments, calibrated on this run: model(k) / model(1) x the measured Cholesky phase + the measured phases that
+        # shard with the points / k (k segments).  UNMEASURED on more than one device until a SCALE run exists; printed so that one can be
         # read against it.
         if world == 1 and model_us.get(1, 0.0) > 0.0:
             ph = line["phases_ms_per_step"]
             shard = ph["jacobian_eval"] + ph["schur_assemble"] + ph["back_substitute"] + ph["cost_eval"]
             pred = {}
             for n_dev in (2, 4, 8):
-                feas = [model_us[k] for k in range(2, n_dev + 1) if model_us.get(k, 0.0) > 0.0]
-                best = min(feas + [model_us[1]])
-                pred[str(n_dev)] = {"ms_per_step": ph["cholesky"] * best / model_us[1] + shard / n_dev, "segments": (
-                    [k for k in range(2, n_dev + 1) if model_us.get(k, 0.0) == best] or [1])[0]}
+                # the plan a world of n_dev ranks takes by itself (sk_problem_segment_plan, not forced: the rule of a real run — a
+                # third or later segment has to beat the plan so far by 5 % in the model)
+                k = int(problem.segmentPlan(n_dev, forced=False)[0])
+                k = k if model_us.get(k, 0.0) > 0.0 else 1
+                # (ranks beyond the segments are replicas of one: the point work shards by segment, not by rank)
+                pred[str(n_dev)] = {"ms_per_step": ph["cholesky"] * model_us[k] / model_us[1] + shard / k, "segments": k}
             line["predicted_multi_gpu"] = {"model_us_per_segments": {str(k): v for k, v in model_us.items() if v > 0.0}, "per_n_gpus": pred,
                                            "note": "chain model, calibrated on this run's Cholesky phase; no scaling curve has been measured on hardware"}
         # The whole Cholesky phase (factorisation + triangular solves, every kernel of it) against the MFMA peak.  The
