@@ -712,10 +712,20 @@ __device__ __forceinline__ void pair_accumulate(const BalDev& d, int e_begin, in
   }
 }
 
+// Workgroup w of a launch goes to XCD w mod 8, each with an L2 of its own.  The segment lists are in camera order — the
+// segments of one row camera follow each other and gather that camera's records over and over — so the launch is cut into
+// runs of `group` consecutive logical blocks per XCD: what a row's segments re-read is then in ONE L2 instead of being
+// fetched into all eight.  (grid: a multiple of 8 * group; logical blocks beyond the work return.)
+__device__ __forceinline__ int xcd_grouped_block(int w, int group) {
+  if (group <= 0) return w;
+  const int x = w & 7, q = w >> 3;
+  return ((q / group) * 8 + x) * group + q % group;
+}
+
 // Short segments: seven per wave, nine lanes each, entries in list order.
-__global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d) {
+__global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d, int xcd_group) {
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int wave = (xcd_grouped_block((int)blockIdx.x, xcd_group) * kBlock + threadIdx.x) >> 6;
   __shared__ __attribute__((aligned(16))) double share[kBlock / 64][7][kPairSlot];
   const int sub = lane / 9, c = lane - 9 * sub;
   const int slot = wave * 7 + sub;
@@ -736,11 +746,11 @@ __global__ __launch_bounds__(kBlock) void bal_pair_kernel(BalDev d) {
 // one wave per segment.  The seven nine-lane groups take every seventh entry; their partial blocks are summed
 // in group order through LDS, so the result does not depend on timing (but the summation order differs from
 // the short-segment kernel's list order: which kernel a segment goes to is fixed at set-up).
-__global__ __launch_bounds__(kBlock) void bal_pair_long_kernel(BalDev d) {
+__global__ __launch_bounds__(kBlock) void bal_pair_long_kernel(BalDev d, int xcd_group) {
   __shared__ double red[kBlock / 64][7][81];
   __shared__ __attribute__((aligned(16))) double share[kBlock / 64][7][kPairSlot];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int slot = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int slot = (xcd_grouped_block((int)blockIdx.x, xcd_group) * kBlock + threadIdx.x) >> 6;
   if (slot >= d.num_long_segments) return;  // wave-uniform
   const int seg = d.long_segments[slot];
   const int sub = lane / 9, c = lane - 9 * sub;
@@ -986,11 +996,16 @@ void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLa
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_pair(const BalDev& d, hipStream_t s) {
+  // runs of eight logical blocks per XCD (developer knobs; 0: plain order.  Measured, Schur-assembly phase per iteration, plain -> 8:
+  // Ladybug-1723 0.520 -> 0.499 ms, Venice-1778 3.02 -> 2.79 ms; 32 is worse on Ladybug — profiles/r03_pair_xcd_sweep.txt)
+  static const int group_long = getenv("SK_PAIR_XCD_GROUP_LONG") ? atoi(getenv("SK_PAIR_XCD_GROUP_LONG")) : 8;
+  static const int group_short = getenv("SK_PAIR_XCD_GROUP") ? atoi(getenv("SK_PAIR_XCD_GROUP")) : 8;
+  auto grid = [](int blocks, int group) { return group > 0 ? (blocks + 8 * group - 1) / (8 * group) * (8 * group) : blocks; };
   if (d.num_long_segments > 0)  // first: the long ones take longest
-    hipLaunchKernelGGL(bal_pair_long_kernel, dim3((d.num_long_segments * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
+    hipLaunchKernelGGL(bal_pair_long_kernel, dim3(grid((d.num_long_segments * 64 + kBlock - 1) / kBlock, group_long)), dim3(kBlock), 0, s, d, group_long);
   if (d.num_short_segments > 0) {
     const int waves = (d.num_short_segments + 6) / 7;
-    hipLaunchKernelGGL(bal_pair_kernel, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
+    hipLaunchKernelGGL(bal_pair_kernel, dim3(grid((waves * 64 + kBlock - 1) / kBlock, group_short)), dim3(kBlock), 0, s, d, group_short);
   }
 }
 void launch_finish_normal_matrix(double* S, int ld, int n, int npad, int rhs_row, const double* D, hipStream_t s) { hipLaunchKernelGGL(finish_normal_matrix_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, n, npad, rhs_row, D); }

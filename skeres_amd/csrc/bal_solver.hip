@@ -222,7 +222,8 @@ class BalSolver : public SolverBase {
   BalDev d_{};
   DevBuf<LossNode> b_loss_nodes_;
   DevBuf<int> b_loss_of_obs_;
-  DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_obs_slot_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_, b_fail_, b_info_;
+  DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_obs_slot_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_;
+  int *fail_p_ = nullptr, *info_p_ = nullptr;  // device flags: slots 14 and 15 of b_scal_ (one reset, one copy back with the scalars)
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_Fcam_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
@@ -285,8 +286,16 @@ class BalSolver : public SolverBase {
   CholeskyContext chol_ctx_;
   double* h_scal_ = nullptr;  // pinned
   int partial_stride_ = 0;
+  // The envelope of S has to be zero again before the next assembly (the factor overwrote it): zeroed on a stream of its own
+  // when the step's results are in — enqueued THEN, by the host, never behind a device-side wait of milliseconds (a queue that
+  // waits costs the queues that run) — next to the Jacobian evaluation of the next iteration.
+  hipStream_t zero_stream_ = nullptr;
+  hipEvent_t ev_zero_ = nullptr;
+  bool zero_pending_ = false;
  public:
   ~BalSolver() override {
+    if (zero_stream_) { (void)hipStreamSynchronize(zero_stream_); (void)hipStreamDestroy(zero_stream_); }
+    if (ev_zero_) (void)hipEventDestroy(ev_zero_);
     for (hipGraphExec_t g : {g_step_[0], g_step_[1], g_eval_[0], g_eval_[1]}) if (g) (void)hipGraphExecDestroy(g);
     if (h_scal_) (void)hipHostFree(h_scal_);
   }
@@ -1060,8 +1069,8 @@ int BalSolver::setup() {
   }
   partial_stride_ = std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_)), 256) + bal_partial_blocks((int)host_obs_.size());
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
-  SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
-  SK_HIP_TRY(b_fail_.alloc(1)); SK_HIP_TRY(b_fail_.zero(s)); SK_HIP_TRY(b_info_.alloc(1)); SK_HIP_TRY(b_info_.zero(s));
+  SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_scal_.zero(s)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
+  fail_p_ = reinterpret_cast<int*>(b_scal_.p + 14); info_p_ = reinterpret_cast<int*>(b_scal_.p + 15);
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
@@ -1094,7 +1103,7 @@ int BalSolver::setup() {
     };
     ds_.A = view(0); ds_.B = view(1); ds_.R = view(2); ds_.border_blocks = border_blocks_; ds_.mapB = b_mapB_.p;
   }
-  d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = b_fail_.p;
+  d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = fail_p_;
   d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0]; d_.loss_of_obs = nullptr;
   {
     // one loss for every residual block (the usual case: SimpleBundleAdjuster shares one trivialLoss, EX/SimpleBundleAdjuster.scala:135),
@@ -1121,6 +1130,10 @@ int BalSolver::setup() {
     host_x_.resize(nx); host_rows_h_.resize(host_obs_.size() * (size_t)kHostRow);
   }
   graph_mode_ = graph_mode_ && host_obs_.empty() && !dissected_ && !tape_mode_;
+  if (!graph_mode_ && !getenv("SK_NO_ZERO_OVERLAP")) {  // (developer knob: the envelope zeroed in line, on the solver's stream)
+    SK_HIP_TRY(hipStreamCreateWithFlags(&zero_stream_, hipStreamNonBlocking));
+    SK_HIP_TRY(hipEventCreateWithFlags(&ev_zero_, hipEventDisableTiming));
+  }
   SK_HIP_TRY(hipStreamSynchronize(s));
   if (opt_.allreduce) {
     // every rank derived the camera order and the envelope for itself (from rank-invariant data): they must be the same
@@ -1299,12 +1312,16 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     launch_lm_diagonal(b_colsq_.p, b_D_.p, (int)(nc + np), opt_.min_lm_diagonal, opt_.max_lm_diagonal, radius, s);
   }
   // ---- B. Schur complement assembly ----
-  kt_.begin("memset_S", s);
-  for (int f = 0; f < 3; ++f)  // only what the factorisations can read
-    if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, b_zero_col0_f_[f].p, fr_[f].nblk, s);
-  kt_.end("memset_S", s);
-  SK_HIP_TRY(hipMemsetAsync(b_fail_.p, 0, sizeof(int), s));
-  SK_HIP_TRY(hipMemsetAsync(b_info_.p, 0, sizeof(int), s));
+  if (zero_pending_) {
+    SK_HIP_TRY(hipStreamWaitEvent(s, ev_zero_, 0));  // zeroed since the last step's results came in
+    zero_pending_ = false;
+  } else {
+    kt_.begin("memset_S", s);
+    for (int f = 0; f < 3; ++f)  // only what the factorisations can read
+      if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, b_zero_col0_f_[f].p, fr_[f].nblk, s);
+    kt_.end("memset_S", s);
+  }
+  SK_HIP_TRY(hipMemsetAsync(b_scal_.p + 14, 0, 2 * sizeof(double), s));  // the failure flag and the factorisation's info
   launch_bal_point_block(d_, s);
   launch_bal_obs_precompute(d_, s);
   kt_.begin("bal_cam_diag", s); launch_bal_cam_diag(d_, s); kt_.end("bal_cam_diag", s);
@@ -1342,7 +1359,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     double* Rs = d_.front[2].S;
     double* RLinv = b_Linv_.p + R.linv_off;
     if (L.ncols > 0) {
-      cholesky_factor(L.S, L.ld, L.nblk * 128, L.Linv, b_info_.p, group_, s, ctx, &kt_, L.last, chain_ok(), L.ncols, L.tail_rows);
+      cholesky_factor(L.S, L.ld, L.nblk * 128, L.Linv, info_p_, group_, s, ctx, &kt_, L.last, chain_ok(), L.ncols, L.tail_rows);
       cholesky_border_add(Rs, (long)R.dim, L.S, L.ld, L.ncols, L.nblk - L.ncols, b_leaf_map_.p, s);
     }
     if (replica_) SK_HIP_TRY(hipMemsetAsync(b_pack_.p, 0, packed_elems_ * sizeof(double), s));  // a replica adds nothing
@@ -1351,19 +1368,19 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     if (rc) return rc;
     launch_tri_pack(Rs, (int)R.dim, b_pack_.p, R.nblk, b_pack_col0_.p, b_pack_off_.p, false, s);
     finish_root();
-    cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, b_info_.p, group_, s, ctx, &kt_, R.env(), chain_ok());
-    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), b_info_.p);
+    cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok());
+    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), info_p_);
     if (L.ncols > 0) {
       cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
       cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike);
     }
   } else if (dissected_) {
-    cholesky_dissected_factor(ds_, b_info_.p, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
+    cholesky_dissected_factor(ds_, info_p_, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
     cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_);
   } else {
     const FrontHost& R = fr_[2];
-    cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, b_info_.p, group_, s, ctx, &kt_, R.env(), chain_ok());
-    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), b_info_.p);
+    cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok());
+    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), info_p_);
   }
   launch_bal_gather_y(d_, s);
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
@@ -1391,9 +1408,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   }
   launch_final_reduce(b_partial_.p, partial_stride_, nb_cost, 2, 0, b_scal_.p, s);
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
-  SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 10 * sizeof(double), hipMemcpyDeviceToHost, s));
-  SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 16, b_fail_.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 17, b_info_.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 16 * sizeof(double), hipMemcpyDeviceToHost, s));  // scalars 0-9, the two flags in 14 and 15
   }
   if (graph) {
     if (!replay) { capture.release(); int rc = finish_capture(s, &g_step_[parity_]); if (rc) return rc; if (!graph_mode_) return try_step_once(radius, valid, mcc, new_cost, step_norm, chain_lost); }
@@ -1401,6 +1416,12 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
   }
   SK_HIP_TRY(hipStreamSynchronize(s));
+  if (!graph && zero_stream_) {  // (everything that reads S is done: see zero_stream_)
+    for (int f = 0; f < 3; ++f)
+      if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, b_zero_col0_f_[f].p, fr_[f].nblk, zero_stream_);
+    SK_HIP_TRY(hipEventRecord(ev_zero_, zero_stream_));
+    zero_pending_ = true;
+  }
   float ms = 0.f;
   if (graph) {  // one replayed graph: no events inside it — the whole linear solve + candidate evaluation is reported as "factor"
     if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvCost]) == hipSuccess) phase_[2] += 1e-3 * ms;
@@ -1411,7 +1432,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     if (hipEventElapsedTime(&ms, ev_[kEvBacksub], ev_[kEvCost]) == hipSuccess) phase_[4] += 1e-3 * ms;
   }
   int fail = 0, info = 0;
-  std::memcpy(&fail, h_scal_ + 16, sizeof(int)); std::memcpy(&info, h_scal_ + 17, sizeof(int));
+  std::memcpy(&fail, h_scal_ + 14, sizeof(int)); std::memcpy(&info, h_scal_ + 15, sizeof(int));
   if (cholesky_note_info(&chol_ctx_, info) && !opt_.allreduce) { *chain_lost = true; return SK_OK; }  // factor again, launch by launch
   // sum r_new^2, model term, |delta_p|^2 (segmented: + this rank's cameras' |delta_c|^2, which no other rank has), failure
   double loc[4] = {h_scal_[0], h_scal_[1], h_scal_[9] + (segmented_ ? h_scal_[8] : 0.0), (double)(fail | info)};
