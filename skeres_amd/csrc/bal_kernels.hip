@@ -9,9 +9,9 @@
 //   observations are stored POINT-MAJOR (all observations of a local point are
 //   contiguous, ascending camera) — obs index `o` below is that order.
 //   r   [2][N]   residuals                      F  [18][N]  d r / d camera  (row-major 2x9 per obs)
-//   E   [6][N]   d r / d point (2x3)            What [N][28] F^T (E M^T)    (9x3 per obs, one 216-byte run: the
-//                                                            Schur kernels gather whole observations)
-//   rt  [2][N]   r - E T^-1 g
+//   E   [6][N]   d r / d point (2x3)            What [N][32] F^T (E M^T) (9x3) + rt = r - E T^-1 g (2): one 256-byte record per
+//                                                            observation, CAMERA-major (bal_kernels.hpp: kWs)
+//   u   [3][N]   E^T F y_c (back-substitution)
 // Jacobi column scaling is folded into F / E as they are written.
 #include <hip/hip_runtime.h>
 #include "functors.hpp"
@@ -576,17 +576,17 @@ __global__ __launch_bounds__(kBlock) void bal_point_block_kernel(BalDev d) {
   if (!(l00 > 0.0) || !(l11 > 0.0) || !(l22 > 0.0)) *d.fail_flag = 1;  // not positive definite
 }
 
-// Per observation: Ehat = E M^T (2x3), What = F^T Ehat (9x3), rt = r - E q.
-// What is an array of records ([N][kWs], what the pair kernels gather): a lane storing its own record writes 27 doubles
-// 224 bytes apart from its neighbour's — 64 cache lines per store instruction.  The wave's 64 records are contiguous,
-// so they go through LDS and out as 28 fully coalesced stores (184 -> about 65 us on the Ladybug-shaped problem).
+// Per observation: Ehat = E M^T (2x3), What = F^T Ehat (9x3), rt = r - E q: the observation's 256-byte record, written at
+// its slot of the CAMERA-major order (obs_slot).  A lane storing its own record would write 29 doubles 256 bytes apart from
+// every other lane's — 64 cache lines per store instruction; the wave's 64 records go through LDS and out sixteen lanes to
+// a record, 16 bytes each: four whole records per store instruction.
 __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
-  constexpr int kLs = kWs + 1;  // odd record stride in LDS: lane l's k-th value in bank pair (29 l + k) mod 32, conflict-free
-  __shared__ double stage[kBlock / 64][64 * kLs];
+  constexpr int kLs = kWs + 2;  // record stride in LDS (even: 16-byte reads)
+  __shared__ __attribute__((aligned(16))) double stage[kBlock / 64][64 * kLs];
   const size_t N = d.N, P = d.P;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* mine = &stage[wave][0];
-  // whole waves walk the observations: a wave's 64 records are consecutive (the last wave may be partly out of range)
+  // whole waves walk the observations (the last wave may be partly out of range)
   for (long base = (long)(blockIdx.x * kBlock + wave * 64); base < (long)d.N; base += (long)gridDim.x * kBlock) {
     const long o = base + lane;
     if (o < (long)d.N) {
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
         eh[r][0] = e0 * m00;
         eh[r][1] = e0 * m10 + e1 * m11;
         eh[r][2] = e0 * m20 + e1 * m21 + e2 * m22;
-        d.rt[r * N + o] = d.r[r * N + o] - (e0 * q0 + e1 * q1 + e2 * q2);
+        mine[lane * kLs + 27 + r] = d.r[r * N + o] - (e0 * q0 + e1 * q1 + e2 * q2);
       }
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
@@ -608,17 +608,18 @@ __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) mine[lane * kLs + 3 * c + a] = f0 * eh[0][a] + f1 * eh[1][a];
       }
-      mine[lane * kLs + 27] = 0.0;  // (the record's padding)
+      mine[lane * kLs + 29] = 0.0; mine[lane * kLs + 30] = 0.0; mine[lane * kLs + 31] = 0.0;  // (the record's padding)
     }
     __builtin_amdgcn_wave_barrier();  // LDS writes of a wave are in order with its reads; keep the compiler from mixing them
-    const long count = ((long)d.N - base < 64 ? (long)d.N - base : 64) * kWs;
-    double* out = d.What + (size_t)base * kWs;
-    int rec = lane / kWs, idx = lane % kWs;  // element k = lane + 64 i of the wave's 64 x kWs doubles: record k / kWs, entry k % kWs
+    const int nrec = (int)(((long)d.N - base) < 64 ? ((long)d.N - base) : 64);
+    const int sub = lane >> 4, chunk = lane & 15;
 #pragma unroll 4
-    for (int k = lane; k < 64 * kWs; k += 64) {
-      if (k < count) out[k] = mine[rec * kLs + idx];
-      rec += 64 / kWs; idx += 64 % kWs;
-      if (idx >= kWs) { idx -= kWs; ++rec; }
+    for (int it = 0; it < 16; ++it) {
+      const int rec = 4 * it + sub;
+      if (rec < nrec) {
+        const double2 v = *reinterpret_cast<const double2*>(&mine[rec * kLs + 2 * chunk]);
+        *reinterpret_cast<double2*>(d.What + (size_t)d.obs_slot[base + rec] * kWs + 2 * chunk) = v;
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -638,8 +639,7 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
 #pragma unroll
   for (int k = 0; k < 9; ++k) rh[k] = 0.0;
   for (int e = d.cam_start[i] + lane; e < d.cam_start[i + 1]; e += 64) {
-    const int o = d.cam_obs[e];
-    double f0[9], f1[9], w[27];
+    double f0[9], f1[9], w[28];
     {
       const double2* rec = reinterpret_cast<const double2*>(d.Fcam + (size_t)e * kFcam);  // camera-major: streamed
 #pragma unroll
@@ -649,9 +649,10 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
         if (2 * k + 1 < 9) f0[2 * k + 1] = t.y; else f1[2 * k + 1 - 9] = t.y;
       }
     }
+    const double2* wrec = reinterpret_cast<const double2*>(d.What + (size_t)e * kWs);  // camera-major: streamed
 #pragma unroll
-    for (int k = 0; k < 27; ++k) w[k] = d.What[(size_t)o * kWs + k];
-    const double r0 = d.rt[o], r1 = d.rt[N + o];
+    for (int k = 0; k < 14; ++k) { const double2 t = wrec[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
+    const double r0 = w[27], r1 = wrec[14].x;
     int k = 0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
@@ -696,9 +697,9 @@ __device__ __forceinline__ void pair_accumulate(const BalDev& d, int e_begin, in
   for (int e = e_begin; e < e_end; e += stride) {
     slot[3 * c] = v0; slot[3 * c + 1] = v1; slot[3 * c + 2] = v2;
     __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave execute in order: no wait, only no reordering by the compiler)
-    double w[kWs];
+    double w[kWu];
 #pragma unroll
-    for (int k = 0; k < kWs / 2; ++k) { const double2 t = reinterpret_cast<const double2*>(slot)[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
+    for (int k = 0; k < kWu / 2; ++k) { const double2 t = reinterpret_cast<const double2*>(slot)[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
     __builtin_amdgcn_wave_barrier();
     const double* wrn = d.What + (size_t)ob1 * kWs + 3 * c;
     const double* wcn = d.What + (size_t)oa1 * kWs + 3 * c;
@@ -815,9 +816,8 @@ __global__ void bal_gather_y_kernel(BalDev d) {
 //   step = -y ; x_new = x + step * scale
 // partial[0] += |delta|^2 (points),  one thread per point.
 // ---------------------------------------------------------------------------
-// Per observation u_o = E_o^T (F_o y_c[cam o]) into the first three slots of the observation's What record (free by
-// now: What is only read during the Schur assembly).  Keeps the per-point pass
-// light, so a 400-observation track does not stall its wave.
+// Per observation u_o = E_o^T (F_o y_c[cam o]), three point-major planes.  Keeps the per-point pass light, so a
+// 400-observation track does not stall its wave.
 __global__ __launch_bounds__(kBlock) void bal_obs_backsub_kernel(BalDev d) {
   const size_t N = d.N;
   for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
@@ -825,9 +825,9 @@ __global__ __launch_bounds__(kBlock) void bal_obs_backsub_kernel(BalDev d) {
     double f0 = 0.0, f1 = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) { f0 += d.F[c * N + o] * yc[c]; f1 += d.F[(9 + c) * N + o] * yc[c]; }
-    d.What[(size_t)o * kWs] = d.E[o] * f0 + d.E[3 * N + o] * f1;
-    d.What[(size_t)o * kWs + 1] = d.E[N + o] * f0 + d.E[4 * N + o] * f1;
-    d.What[(size_t)o * kWs + 2] = d.E[2 * N + o] * f0 + d.E[5 * N + o] * f1;
+    d.u[o] = d.E[o] * f0 + d.E[3 * N + o] * f1;
+    d.u[N + o] = d.E[N + o] * f0 + d.E[4 * N + o] * f1;
+    d.u[2 * N + o] = d.E[2 * N + o] * f0 + d.E[5 * N + o] * f1;
   }
 }
 
@@ -838,9 +838,9 @@ __global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
   double w0 = 0.0, w1 = 0.0, w2 = 0.0;
   if (p < d.P) {
     for (int o = d.pt_start[p] + sub; o < d.pt_start[p + 1]; o += kPointLanes) {
-      w0 += d.What[(size_t)o * kWs];
-      w1 += d.What[(size_t)o * kWs + 1];
-      w2 += d.What[(size_t)o * kWs + 2];
+      w0 += d.u[o];
+      w1 += d.u[(size_t)d.N + o];
+      w2 += d.u[2 * (size_t)d.N + o];
     }
   }
   w0 = point_lanes_sum(w0); w1 = point_lanes_sum(w1); w2 = point_lanes_sum(w2);

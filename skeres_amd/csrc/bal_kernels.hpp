@@ -9,7 +9,12 @@
 namespace sk {
 
 constexpr int kLongSegment = 32;  // entries from which a camera pair gets a wave of its own (bal_pair_long_kernel)
-constexpr int kWs = 28;  // doubles per observation record of What (27 used; 224 bytes keeps records 32-byte aligned)
+// doubles per observation record of What: 27 of F^T (E M^T), then rt (2), then padding — 256 bytes, two whole 128-byte lines, so
+// that a gathered record costs exactly its own bytes (at 224 bytes a record straddled 2.75 lines on average).  Records are in
+// CAMERA-major order (record e belongs to observation cam_obs[e]): the diagonal-block kernel streams them, and a pair
+// segment's two gathers each walk one camera's records in ascending order.
+constexpr int kWs = 32;
+constexpr int kWu = 28;  // ... of which the pair kernels read the first 28 (27 used)
 struct BalDev {
   int C, P, N;            // cameras (all, replicated), LOCAL points, LOCAL observations
   // structure (built once on the host, point-major observation order)
@@ -39,7 +44,7 @@ struct BalDev {
   double* step_c;  double* step_p;    // step in scaled space
   double* y_c;                        // reduced-system solution
   // per-observation planes
-  double* r;  double* F;  double* E;  double* What;  double* rt;
+  double* r;  double* F;  double* E;  double* What;  double* u;  // u [3][N]: E^T F y_c per observation (back-substitution)
   // CAMERA-major copy of what the per-camera kernels read of an observation: record e (the e-th entry of the camera CSR,
   // i.e. observation cam_obs[e]) holds F row 0 (9), F row 1 (9), r (2).  The planes above are point-major — lane o streams —
   // and a wave that walks a camera's observations through them fetches 20 scattered 64-byte sectors per observation for

@@ -944,7 +944,14 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_cam_.upload(cam, s)); SK_HIP_TRY(b_pt_.upload(pt, s)); SK_HIP_TRY(b_obs_.upload(obs, s));
   if (tape) { tape_mode_ = true; SK_HIP_TRY(tape_dev_.upload(*tape, s)); }
   SK_HIP_TRY(b_pt_start_.upload(pt_start, s)); SK_HIP_TRY(b_cam_start_.upload(cam_start, s)); SK_HIP_TRY(b_cam_obs_.upload(cam_obs, s));
-  { std::vector<int> slot(N_); for (int e = 0; e < N_; ++e) slot[cam_obs[e]] = e; SK_HIP_TRY(b_obs_slot_.upload(slot, s)); }
+  {
+    std::vector<int> slot(N_);
+    for (int e = 0; e < N_; ++e) slot[cam_obs[e]] = e;
+    SK_HIP_TRY(b_obs_slot_.upload(slot, s));
+    // the pair lists address the What records, which are in camera-major order (bal_kernels.hpp: kWs)
+    for (int& v : pair_row) v = slot[v];
+    for (int& v : pair_col) v = slot[v];
+  }
   SK_HIP_TRY(b_seg_start_.upload(seg_start, s)); SK_HIP_TRY(b_seg_row_.upload(seg_row, s)); SK_HIP_TRY(b_seg_col_.upload(seg_col, s));
   SK_HIP_TRY(b_pair_row_.upload(pair_row, s)); SK_HIP_TRY(b_pair_col_.upload(pair_col, s));
   std::vector<int> short_segs, long_segs;
@@ -981,7 +988,7 @@ int BalSolver::setup() {
   }
   SK_HIP_TRY(b_y_.alloc(npad_ + 128));
   SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_Fcam_.alloc(kFcam * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
-  SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(2 * (size_t)N_));
+  SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(3 * (size_t)N_));
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
   // ---- the fronts of the reduced camera system ----
   std::vector<int> border_row_h[2], leaf_map_h, leaf_gmap_h;
@@ -1081,7 +1088,7 @@ int BalSolver::setup() {
   d_.xc = b_xc_.p; d_.xp = b_xc_.p + nc; d_.xc_new = b_xc_new_.p; d_.xp_new = b_xc_new_.p + nc;
   d_.scale_c = b_scale_.p; d_.scale_p = b_scale_.p + nc; d_.colsq_c = b_colsq_.p; d_.colsq_p = b_colsq_.p + nc;
   d_.gs_c = b_gs_.p; d_.gs_p = b_gs_.p + nc; d_.D_c = b_D_.p; d_.D_p = b_D_.p + nc; d_.step_c = b_step_.p; d_.step_p = b_step_.p + nc;
-  d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.Fcam = b_Fcam_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.rt = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
+  d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.Fcam = b_Fcam_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.u = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
   for (int f = 0; f < 3; ++f) {
     d_.front[f].S = fr_[f].nblk > 0 ? b_S_.p + fr_[f].s_off : nullptr; d_.front[f].ld = (int)fr_[f].dim; d_.front[f].interior = fr_[f].ncols * 128;
     d_.front[f].rhs_row = fr_[f].rhs_row; d_.front[f].border_row = f < 2 ? b_border_row_[f].p : nullptr;
