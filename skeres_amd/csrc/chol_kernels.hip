@@ -1099,6 +1099,8 @@ __global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict_
 // solution is the same, bit for bit (tests/test_gpu_parity.py::test_resident_backsolve_is_bitwise_the_launch_by_launch_one).
 // A poll gives up after kChainTimeoutTicks: info = 2 (the caller factors and solves again, launch by launch).
 // ---------------------------------------------------------------------------
+__device__ long long g_bs_stamps[1024][4];  // developer timeline SK_BS_STAMPS=<file>: per block column, wall clock when its owner started waiting for
+__device__ int g_bs_stamps_on;              // the block row next to the diagonal, when that y had arrived, and when its own y was stored
 struct BsTop { unsigned short top[1024]; };  // per block column: the last block row of its contiguous run (<= nblk - 1)
 constexpr unsigned long long kBsSentinel = ~0ull;
 __global__ __launch_bounds__(256, 1) void bs_resident_kernel(const double* __restrict__ Linv, const double* __restrict__ S, long ld, const double* __restrict__ rhs,
@@ -1125,6 +1127,7 @@ __global__ __launch_bounds__(256, 1) void bs_resident_kernel(const double* __res
   }
   __syncthreads();
   while (cur > kb) {
+    if (g_bs_stamps_on && t == 0 && cur == kb + 1) g_bs_stamps[kb][0] = wall_clock64();
     if (t < 128) {
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(y + (long)cur * 128 + t);
       unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1139,6 +1142,7 @@ __global__ __launch_bounds__(256, 1) void bs_resident_kernel(const double* __res
       ysh[t] = __longlong_as_double((long long)v);
     }
     __syncthreads();
+    if (g_bs_stamps_on && t == 0 && cur == kb + 1) g_bs_stamps[kb][1] = wall_clock64();
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       double sacc = 0.0;
@@ -1177,6 +1181,7 @@ __global__ __launch_bounds__(256, 1) void bs_resident_kernel(const double* __res
     unsigned long long bits = (unsigned long long)__double_as_longlong(sacc);
     if (bits == kBsSentinel) bits ^= 1ull;  // (a NaN out of a failed factorisation must not look like "not there yet")
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(y + (long)kb * 128 + t), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g_bs_stamps_on && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_bs_stamps[kb][2] = wall_clock64(); }
   }
   if (t == 0 && abort_s && info) info_raise(info, 2);
 }
@@ -2082,8 +2087,19 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
     for (int c = 0; c < nblk; ++c) env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1);
     if (kt) kt->begin("backsolve", s);
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);
+    static const char* bs_stamps = getenv("SK_BS_STAMPS");
+    if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
     hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(256), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info);
     if (kt) kt->end("backsolve", s);
+    if (bs_stamps) {
+      (void)hipStreamSynchronize(s);
+      std::vector<long long> st((size_t)1024 * 4);
+      (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_bs_stamps), st.size() * sizeof(long long));
+      if (FILE* f = fopen(bs_stamps, "w")) {
+        for (int kb = nblk - 1; kb >= 0; --kb) fprintf(f, "%d %lld %lld %lld\n", kb, st[(size_t)kb * 4], st[(size_t)kb * 4 + 1], st[(size_t)kb * 4 + 2]);
+        fclose(f);
+      }
+    }
     return;
   }
   hipLaunchKernelGGL(copy_row_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, n, npad);
