@@ -819,6 +819,24 @@ def test_resident_backsolve_is_bitwise_the_launch_by_launch_one(tmp_path):
     assert len(res["1"]["bal_costs"]) == 4 and res["1"]["bal_costs"][-1] < res["1"]["bal_costs"][0]
 
 
+def test_schedule_of_the_schur_assembly_does_not_change_a_bit(tmp_path):
+    """Round 3 moved work of the Schur assembly around without touching its arithmetic: the envelope of S is zeroed on a
+    stream of its own next to the next Jacobian evaluation, and the pair kernels' logical blocks run in groups of eight per
+    XCD.  With both switched off (developer knobs) the 400-camera trajectory of tests/backsolve_worker.py is the same, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "backsolve_worker.py")
+    res = {}
+    for mode, env in (("new", {}), ("plain", {"SK_NO_ZERO_OVERLAP": "1", "SK_PAIR_XCD_GROUP": "0", "SK_PAIR_XCD_GROUP_LONG": "0"})):
+        path = str(tmp_path / ("sched_%s.npz" % mode))
+        out = subprocess.run([sys.executable, worker, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        res[mode] = np.load(path)
+    for k in ("bal_x", "bal_costs"):
+        assert np.array_equal(res["new"][k], res["plain"][k]), k
+
+
 def test_resident_pairs_plan_vs_numpy_and_oracle():
     """The plan with resident PAIRS of block columns (one K = 256 SYRK per pair under the potrf server; built in round 3,
     measured not to pay and off by default: SK_CHAIN_PAIR_MAX_TRAILING) stays correct: tests/pair_plan_worker.py with the
