@@ -1103,27 +1103,30 @@ __device__ long long g_bs_stamps[1024][4];  // developer timeline SK_BS_STAMPS=<
 __device__ int g_bs_stamps_on;              // the block row next to the diagonal, when that y had arrived, and when its own y was stored
 struct BsTop { unsigned short top[1024]; };  // per block column: the last block row of its contiguous run (<= nblk - 1)
 constexpr unsigned long long kBsSentinel = ~0ull;
-__global__ __launch_bounds__(256, 1) void bs_resident_kernel(const double* __restrict__ Linv, const double* __restrict__ S, long ld, const double* __restrict__ rhs,
-                                                              int n, double* y, int nblk, BsTop env, int* info) {
+__global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __restrict__ Linv, const double* __restrict__ S, long ld, const double* __restrict__ rhs,
+                                                               int n, double* y, int nblk, BsTop env, int* info) {
+  // 1024 threads: column c of the block and one of eight groups of sixteen rows each — sixteen products per thread and matrix
+  // on the chain's critical path where 256 threads had sixty-four (0.41 -> 0.39 ms on Ladybug-1723: the hop is mostly hand-over and barriers); the partial sums are formed over the
+  // same rows and added in the same order as before (and as in bs_step_kernel)
   __shared__ double ysh[128], wsh[128], part[16][128];
   __shared__ int abort_s;
   const int kb = nblk - 1 - (int)blockIdx.x;
-  const int t = threadIdx.x, c = t & 127, half = t >> 7;
+  const int t = threadIdx.x, c = t & 127, rg = t >> 7;
   if (t == 0) abort_s = 0;
   if (t < 128) { const int j = kb * 128 + t; wsh[t] = j < n ? rhs[j] : 0.0; }
-  double li[64], lr[64];
+  double li[16], lr[16];
   {
-    const double* p = Linv + (long)kb * 128 * 128 + (long)(half * 64) * 128 + c;
+    const double* p = Linv + (long)kb * 128 * 128 + (long)(rg * 16) * 128 + c;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) li[i] = p[(long)i * 128];
+    for (int i = 0; i < 16; ++i) li[i] = p[(long)i * 128];
   }
   const int top = min((int)env.top[kb], nblk - 1);
   int cur = (kb < nblk - 1 && top < nblk - 1) ? nblk - 1 : top;  // block rows to apply: nblk - 1 (always active), then top .. kb + 1
-  const double* Lcol = S + (long)(half * 64) * ld + (long)kb * 128 + c;
+  const double* Lcol = S + (long)(rg * 16) * ld + (long)kb * 128 + c;
   if (cur > kb) {
     const double* p = Lcol + (long)cur * 128 * ld;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) lr[i] = p[(long)i * ld];
+    for (int i = 0; i < 16; ++i) lr[i] = p[(long)i * ld];
   }
   __syncthreads();
   while (cur > kb) {
@@ -1132,6 +1135,8 @@ __global__ __launch_bounds__(256, 1) void bs_resident_kernel(const double* __res
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(y + (long)cur * 128 + t);
       unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (v == kBsSentinel) {
+        // (four polls in flight instead of one at a time: measured, no difference — a hop waits for one coherent read, 1.9 us
+        // from the producer's completed store to the consumer's barrier, not for the poll that happens to see it)
         const long long t0 = wall_clock64();
         do {
           __builtin_amdgcn_s_sleep(1);
@@ -1144,17 +1149,17 @@ __global__ __launch_bounds__(256, 1) void bs_resident_kernel(const double* __res
     __syncthreads();
     if (g_bs_stamps_on && t == 0 && cur == kb + 1) g_bs_stamps[kb][1] = wall_clock64();
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < 2; ++g) {  // groups of eight rows: 2 rg and 2 rg + 1
       double sacc = 0.0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sacc += lr[g * 8 + i] * ysh[half * 64 + g * 8 + i];
-      part[half * 8 + g][c] = sacc;
+      for (int i = 0; i < 8; ++i) sacc += lr[g * 8 + i] * ysh[rg * 16 + g * 8 + i];
+      part[rg * 2 + g][c] = sacc;
     }
     const int nxt = (cur == nblk - 1 && top < nblk - 1) ? top : cur - 1;
     if (nxt > kb) {  // the next block: its loads are in flight across the barrier and the next poll
       const double* p = Lcol + (long)nxt * 128 * ld;
 #pragma unroll
-      for (int i = 0; i < 64; ++i) lr[i] = p[(long)i * ld];
+      for (int i = 0; i < 16; ++i) lr[i] = p[(long)i * ld];
     }
     __syncthreads();
     if (t < 128) {
@@ -1166,12 +1171,11 @@ __global__ __launch_bounds__(256, 1) void bs_resident_kernel(const double* __res
     cur = nxt;
   }
   __syncthreads();
+  {
+    double sacc = 0.0;  // the group of sixteen rows rg
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    double sacc = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sacc += li[g * 16 + i] * wsh[half * 64 + g * 16 + i];
-    part[half * 4 + g][c] = sacc;
+    for (int i = 0; i < 16; ++i) sacc += li[i] * wsh[rg * 16 + i];
+    part[rg][c] = sacc;
   }
   __syncthreads();
   if (t < 128) {
@@ -2089,7 +2093,7 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);
     static const char* bs_stamps = getenv("SK_BS_STAMPS");
     if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
-    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(256), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info);
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info);
     if (kt) kt->end("backsolve", s);
     if (bs_stamps) {
       (void)hipStreamSynchronize(s);
