@@ -117,6 +117,8 @@ public final class SkeresNative {
   public static native double skSummaryInitialCost(long s);
   public static native double skSummaryFinalCost(long s);
   public static native int skSummaryNumIterations(long s);
+  public static native int skSummaryLinearSolverTypeUsed(long s);
+  public static native int skSummaryLinearSolverTypeGiven(long s);
   public static native int skSummaryNumSuccessfulSteps(long s);
   public static native int skSummaryNumUnsuccessfulSteps(long s);
   public static native int skSummaryTerminationType(long s);

@@ -319,6 +319,8 @@ SK_JNI(jint, skSummaryNumIterations)(JNIEnv* env, jclass c, jlong s) { (void)env
 SK_JNI(jint, skSummaryNumSuccessfulSteps)(JNIEnv* env, jclass c, jlong s) { (void)env; (void)c; return sk_summary_num_successful_steps(PTR(sk_summary, s)); }
 SK_JNI(jint, skSummaryNumUnsuccessfulSteps)(JNIEnv* env, jclass c, jlong s) { (void)env; (void)c; return sk_summary_num_unsuccessful_steps(PTR(sk_summary, s)); }
 SK_JNI(jint, skSummaryTerminationType)(JNIEnv* env, jclass c, jlong s) { (void)env; (void)c; return sk_summary_termination_type(PTR(sk_summary, s)); }
+SK_JNI(jint, skSummaryLinearSolverTypeUsed)(JNIEnv* env, jclass c, jlong s) { (void)env; (void)c; return sk_summary_linear_solver_type_used(PTR(sk_summary, s)); }
+SK_JNI(jint, skSummaryLinearSolverTypeGiven)(JNIEnv* env, jclass c, jlong s) { (void)env; (void)c; return sk_summary_linear_solver_type_given(PTR(sk_summary, s)); }
 SK_JNI(jstring, skSummaryMessage)(JNIEnv* env, jclass c, jlong s) { (void)c; return (*env)->NewStringUTF(env, sk_summary_message(PTR(sk_summary, s))); }
 SK_JNI(jstring, skSummaryBriefReport)(JNIEnv* env, jclass c, jlong s) { (void)c; return (*env)->NewStringUTF(env, sk_summary_brief_report(PTR(sk_summary, s))); }
 SK_JNI(jstring, skSummaryFullReport)(JNIEnv* env, jclass c, jlong s) { (void)c; return (*env)->NewStringUTF(env, sk_summary_full_report(PTR(sk_summary, s))); }

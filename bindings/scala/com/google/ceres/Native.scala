@@ -144,6 +144,9 @@ object Solver {
     def numSuccessfulSteps: Int = SkeresNative.skSummaryNumSuccessfulSteps(handle)
     def numUnsuccessfulSteps: Int = SkeresNative.skSummaryNumUnsuccessfulSteps(handle)
     def terminationType: TerminationType.Value = TerminationType(SkeresNative.skSummaryTerminationType(handle))
+    // (they differ when DENSE_SCHUR met a problem without the 2 / (9, 3) block structure: its alternate, DENSE_QR, was used — as Ceres does)
+    def linearSolverTypeUsed: LinearSolverType.Value = LinearSolverType(SkeresNative.skSummaryLinearSolverTypeUsed(handle))
+    def linearSolverTypeGiven: LinearSolverType.Value = LinearSolverType(SkeresNative.skSummaryLinearSolverTypeGiven(handle))
     def message: String = SkeresNative.skSummaryMessage(handle)
     def briefReport(): String = SkeresNative.skSummaryBriefReport(handle)
     def fullReport(): String = SkeresNative.skSummaryFullReport(handle)

@@ -413,6 +413,11 @@ double sk_summary_iteration_field(const sk_summary* s, int iteration, int field)
  * solver's stream). phase: 0 jacobian_eval, 1 schur_assemble (or J^T J),
  * 2 cholesky (or QR), 3 back_substitute, 4 cost_eval, 5 allreduce, 6 total */
 double sk_summary_phase_seconds(const sk_summary* s, int phase);
+/* Summary.linear_solver_type_used / _given (ceres::Solver::Summary; SWIG exposes both through /root/reference ceres.i:186-210).
+   They differ when DENSE_SCHUR was asked for on a problem without the 2-residual / 9- and 3-parameter block structure: the
+   alternate, DENSE_QR, is used, as Ceres does for a Schur-type solver with nothing to eliminate. */
+int sk_summary_linear_solver_type_used(const sk_summary* s);
+int sk_summary_linear_solver_type_given(const sk_summary* s);
 
 /* ---- solve ----------------------------------------------------------------- */
 /* ceres.solve(options, problem, summary) — EX/SimpleBundleAdjuster.scala:152,

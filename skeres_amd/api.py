@@ -126,6 +126,8 @@ _SIGS = {
     "sk_summary_num_logged_iterations": (C.c_int, [C.c_void_p]),
     "sk_summary_iteration_field": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
     "sk_summary_phase_seconds": (C.c_double, [C.c_void_p, C.c_int]),
+    "sk_summary_linear_solver_type_used": (C.c_int, [C.c_void_p]),
+    "sk_summary_linear_solver_type_given": (C.c_int, [C.c_void_p]),
     "sk_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sk_solver_create": (C.c_void_p, [C.c_void_p, C.c_void_p]),
     "sk_solver_free": (None, [C.c_void_p]),
@@ -1167,6 +1169,8 @@ class Solver:
         def briefReport(self): return lib().sk_summary_brief_report(self._h).decode()
         def fullReport(self): return lib().sk_summary_full_report(self._h).decode()
         def phaseSeconds(self, k): return lib().sk_summary_phase_seconds(self._h, k)
+        def linearSolverTypeUsed(self): return lib().sk_summary_linear_solver_type_used(self._h)
+        def linearSolverTypeGiven(self): return lib().sk_summary_linear_solver_type_given(self._h)
 
         def iterations(self):
             names = ["cost", "cost_change", "gradient_max_norm", "step_norm", "relative_decrease",

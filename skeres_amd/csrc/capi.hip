@@ -592,6 +592,8 @@ double sk_summary_iteration_field(const sk_summary* s, int it, int field) {
   }
   return NAN;
 }
+int sk_summary_linear_solver_type_used(const sk_summary* s) { return s->s.linear_solver_type; }
+int sk_summary_linear_solver_type_given(const sk_summary* s) { return s->s.linear_solver_type_given >= 0 ? s->s.linear_solver_type_given : s->s.linear_solver_type; }
 double sk_summary_phase_seconds(const sk_summary* s, int phase) { return (phase >= 0 && phase < 7) ? s->s.phase_seconds[phase] : NAN; }
 
 // ---- solve ------------------------------------------------------------------------------
@@ -603,8 +605,18 @@ static std::unique_ptr<SolverBase> make_solver(const Options& o, Problem* p, int
   }
   if (o.linear_solver_type == SK_DENSE_SCHUR) {
     std::string why;
-    if (!problem_is_bal_shaped(*p, &why)) { set_error("%s", why.c_str()); *rc = SK_ERR_UNSUPPORTED; return nullptr; }
-    return make_bal_solver(o, p);
+    if (problem_is_bal_shaped(*p, &why)) return make_bal_solver(o, p);
+    // Not the (2; 9, 3) structure the Schur path eliminates.  Ceres, given a Schur-type solver and nothing to eliminate, falls
+    // back to its alternate — DENSE_QR for DENSE_SCHUR (trust_region_preprocessor: the LM step is the same whatever solves the
+    // linear system) — and reports "Given / Used".  So does this library for residual-block problems (the dense path takes every
+    // shape, parameterization and loss; it refuses only what does not fit in device memory); dense rows and local
+    // parameterizations on them stay refused, with the reason.
+    if (problem_is_dense_rows(*p)) { set_error("%s", why.c_str()); *rc = SK_ERR_UNSUPPORTED; return nullptr; }
+    for (int f : p->rb_functor) if (f == SK_FUNCTOR_SYNTH_TANH_ROW) { set_error("%s", why.c_str()); *rc = SK_ERR_UNSUPPORTED; return nullptr; }
+    Options alt = o;
+    alt.linear_solver_type_given = SK_DENSE_SCHUR;
+    alt.linear_solver_type = SK_DENSE_QR;
+    return make_dense_solver(alt, p);
   }
   if (problem_is_dense_rows(*p)) {
     if (o.linear_solver_type != SK_DENSE_NORMAL_CHOLESKY) { set_error("dense-row problems are implemented for DENSE_NORMAL_CHOLESKY only (not supported: %s)", linear_solver_name(o.linear_solver_type)); *rc = SK_ERR_UNSUPPORTED; return nullptr; }

@@ -134,6 +134,7 @@ struct Problem {  // CeresProblem; parameter blocks identified by pointer value
 
 struct Options {  // Solver.Options; Ceres 1.x defaults
   int linear_solver_type = SK_DENSE_QR;  // ceres default is SPARSE_NORMAL_CHOLESKY when built with a sparse backend, else DENSE_QR
+  int linear_solver_type_given = -1;     // set when the solver in use is an alternate for the one asked for (capi.hip: make_solver)
   int minimizer_type = SK_TRUST_REGION;
   int max_num_iterations = 50;
   bool progress_to_stdout = false;
@@ -179,6 +180,7 @@ struct Summary {
   int num_parameter_blocks = 0, num_parameters = 0, num_residual_blocks = 0;
   long num_residuals = 0;
   int linear_solver_type = 0;
+  int linear_solver_type_given = -1;  // what Solver.Options asked for when the solver used is its alternate (Ceres: "Given / Used")
   int num_e_blocks = 0, num_f_blocks = 0;
   int world = 1;
   std::string device_name;

@@ -216,6 +216,7 @@ int SolverBase::finish(Summary* s) {
   sum_.device_name = device_name_;
   sum_.world = opt_.world;
   sum_.linear_solver_type = opt_.linear_solver_type;
+  sum_.linear_solver_type_given = opt_.linear_solver_type_given;
   describe(&sum_);
   sum_.build_reports();
   *s = sum_;
@@ -237,6 +238,12 @@ void Summary::build_reports() {
            num_parameter_blocks, num_parameters, num_residual_blocks, num_residuals, linear_solver_name(linear_solver_type),
            device_name.c_str(), world);
   f += b;
+  if (linear_solver_type_given >= 0 && linear_solver_type_given != linear_solver_type) {
+    // (Ceres reports "Given / Used"; its alternate for a Schur-type solver with nothing to eliminate is DENSE_QR too)
+    snprintf(b, sizeof(b), "Linear solver given    %22s   (no 2-residual / 9- and 3-parameter block structure to eliminate: its alternate is used)\n",
+             linear_solver_name(linear_solver_type_given));
+    f += b;
+  }
   if (linear_solver_type == SK_DENSE_SCHUR) {
     snprintf(b, sizeof(b), "Schur structure                        2,3,9\nE blocks (eliminated)       % 12d\nF blocks                    % 12d\n", num_e_blocks, num_f_blocks);
     f += b;

@@ -819,6 +819,38 @@ def test_resident_backsolve_is_bitwise_the_launch_by_launch_one(tmp_path):
     assert len(res["1"]["bal_costs"]) == 4 and res["1"]["bal_costs"][-1] < res["1"]["bal_costs"][0]
 
 
+def test_dense_schur_without_the_camera_point_structure_uses_its_alternate():
+    """Ceres, given a Schur-type linear solver and nothing to eliminate, uses its alternate (DENSE_QR for DENSE_SCHUR) and reports
+    both in the summary ("Given / Used"): the LM step does not depend on how the linear system is solved.  Same here: the
+    reference's curve-fitting example (EX/CurveFitting.scala: 1 residual over two 1-parameter blocks) under DENSE_SCHUR is the
+    DENSE_QR solve, bit for bit, and says so."""
+    from helpers import curve_fitting_data
+    data = curve_fitting_data()
+
+    def run(kind):
+        m, c = sk.DoubleArray(1), sk.DoubleArray(1)
+        m.set(0, 0.0)
+        c.set(0, 0.0)
+        loss = sk.PredefinedLossFunctions.trivialLoss()
+        problem = sk.Problem()
+        for x, y in data:
+            problem.addResidualBlock(sk.ExponentialResidual(x, y).toAutoDiffCostFunction(), loss, m, c)
+        o = sk.Solver.Options()
+        o.setMaxNumIterations(25)
+        o.setLinearSolverType(kind)
+        s = sk.Solver.Summary()
+        sk.ceres.solve(o, problem, s)
+        return m.get(0), c.get(0), s
+
+    m1, c1, s1 = run(sk.LinearSolverType.DENSE_SCHUR)
+    m2, c2, s2 = run(sk.LinearSolverType.DENSE_QR)
+    assert (m1, c1) == (m2, c2) and s1.finalCost() == s2.finalCost() and s1.numIterations() == s2.numIterations()
+    assert s1.linearSolverTypeGiven() == int(sk.LinearSolverType.DENSE_SCHUR) and s1.linearSolverTypeUsed() == int(sk.LinearSolverType.DENSE_QR)
+    assert s2.linearSolverTypeGiven() == s2.linearSolverTypeUsed() == int(sk.LinearSolverType.DENSE_QR)
+    assert "DENSE_QR" in s1.fullReport() and "Linear solver given" in s1.fullReport() and "Linear solver given" not in s2.fullReport()
+    np.testing.assert_allclose([m1, c1], [0.2915, 0.1314], atol=2e-3)  # m ~ 0.3, c ~ 0.1 (CurveFitting.scala:11-19)
+
+
 def test_schedule_of_the_schur_assembly_does_not_change_a_bit(tmp_path):
     """Round 3 moved work of the Schur assembly around without touching its arithmetic: the envelope of S is zeroed on a
     stream of its own next to the next Jacobian evaluation, and the pair kernels' logical blocks run in groups of eight per
