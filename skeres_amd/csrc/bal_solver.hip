@@ -43,6 +43,16 @@ bool problem_is_bal_shaped(const Problem& p, std::string* why) {
     *why = "the recorded functor needs more registers (or captures more doubles) than the device interpreter holds: not supported";
     return false;
   }
+  // the Schur path carries identity and subset parameterizations and constant blocks; a quaternion or homogeneous-vector block
+  // (a 4-block cannot be a camera or a point here anyway) sends the problem to the alternate solver like any other shape
+  for (size_t b = 0; b < p.block_param.size(); ++b)
+    if (p.block_param[b] >= 0) {
+      const int t = p.params[p.block_param[b]].type;
+      if (t != kParamIdentity && t != kParamSubset) {
+        *why = "DENSE_SCHUR takes identity and subset parameterizations and constant parameter blocks (quaternion / homogeneous-vector blocks are implemented for DENSE_QR / DENSE_NORMAL_CHOLESKY; not supported here)";
+        return false;
+      }
+    }
   std::vector<char> role(p.block_size.size(), 0);
   for (size_t b = 0; b < nb; ++b) {
     const int c = p.rb_pidx[p.rb_pidx_off[b]], q = p.rb_pidx[p.rb_pidx_off[b] + 1];

@@ -1644,14 +1644,23 @@ def test_parameterization_with_host_callback_and_unsupported_solvers():
     np.testing.assert_allclose(got, q0 / np.linalg.norm(q0), atol=1e-4)  # the closest unit quaternion to q0 (default tolerances)
     assert abs(np.linalg.norm(got) - 1.0) < 1e-13
     # DENSE_SCHUR takes constant blocks and identity / subset parameterizations (test_dense_schur_with_constant_and_subset_blocks);
-    # a homogeneous-vector point block is refused, not solved another way
+    # with a homogeneous-vector point block the Schur path does not apply and — since the end of round 3, as Ceres does for a
+    # Schur-type solver it cannot use — the alternate solver (DENSE_QR) takes the problem: the same solve, reported as such
     prob = bal.generate(4, 20, 60, seed=2)
-    problem, params, loss = bal_problem_to_sk(prob)
-    options = sk.Solver.Options()
-    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
-    problem.setParameterization(params.slice(9 * 4), sk.PredefinedLocalParameterizations.homogeneousVector(3))  # the first point block
-    with pytest.raises(sk.SkeresError, match="status 4"):
-        sk.ceres.solve(options, problem, sk.Solver.Summary())
+    got = {}
+    for kind in (sk.LinearSolverType.DENSE_SCHUR, sk.LinearSolverType.DENSE_QR):
+        problem, params, loss = bal_problem_to_sk(prob)
+        options = sk.Solver.Options()
+        options.setLinearSolverType(kind)
+        options.setMaxNumIterations(8)
+        problem.setParameterization(params.slice(9 * 4), sk.PredefinedLocalParameterizations.homogeneousVector(3))  # the first point block
+        summary = sk.Solver.Summary()
+        sk.ceres.solve(options, problem, summary)
+        got[int(kind)] = (params.toArray(prob.num_parameters), summary)
+    xs, ss = got[int(sk.LinearSolverType.DENSE_SCHUR)]
+    xq, sq = got[int(sk.LinearSolverType.DENSE_QR)]
+    assert np.array_equal(xs, xq) and ss.finalCost() == sq.finalCost() and ss.finalCost() < ss.initialCost()
+    assert ss.linearSolverTypeGiven() == int(sk.LinearSolverType.DENSE_SCHUR) and ss.linearSolverTypeUsed() == int(sk.LinearSolverType.DENSE_QR)
 
 
 def _host_snavely_functor():
