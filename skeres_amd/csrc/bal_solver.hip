@@ -1389,11 +1389,11 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), info_p_);
     if (L.ncols > 0) {
       cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
-      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike);
+      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, info_p_);
     }
   } else if (dissected_) {
     cholesky_dissected_factor(ds_, info_p_, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
-    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_);
+    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, info_p_);
   } else {
     const FrontHost& R = fr_[2];
     cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok());

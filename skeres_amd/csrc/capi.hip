@@ -865,7 +865,7 @@ int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double*
   cholesky_dissected_factor(d, dinfo.p, group, s, la ? &ctx : nullptr, side ? &ctxB : nullptr, nullptr, nullptr, chain);
   double *wA = dw.p, *wB = dw.p + dA, *wR = dw.p + dA + dB, *ybB = dw.p + dA + dB + dR;
   double *yA = dy.p, *yB = dy.p + dA, *yR = dy.p + dA + dB;
-  cholesky_dissected_backsolve(d, msep, wR, yR, wA, yA, wB, yB, ybB, s, side ? &ctxB : nullptr, nullptr);
+  cholesky_dissected_backsolve(d, msep, wR, yR, wA, yA, wB, yB, ybB, s, side ? &ctxB : nullptr, nullptr, dinfo.p);
   SK_HIP_TRY(hipStreamSynchronize(s));
   SK_HIP_TRY(hipStreamDestroy(s));
   int info = 0;
@@ -983,7 +983,7 @@ int sk_cholesky_solve_segments(int n, const double* A, const double* b, double* 
     DevBuf<int> dg;
     SK_HIP_TRY(dg.upload(gmap, s));
     cholesky_gather_map(dyR.p, dg.p, lf->yb.p, m, s);
-    cholesky_backsolve_front(lf->F.p, (long)lf->dim, L.nblk, L.ncols, L.rhs_row, lf->Linv.p, lf->yb.p, lf->w.p, lf->y.p, s, lf->last.data(), L.spike);
+    cholesky_backsolve_front(lf->F.p, (long)lf->dim, L.nblk, L.ncols, L.rhs_row, lf->Linv.p, lf->yb.p, lf->w.p, lf->y.p, s, lf->last.data(), L.spike, L.tail_rows, dinfo.p);
     SK_HIP_TRY(hipStreamSynchronize(s));
   }
   SK_HIP_TRY(hipStreamSynchronize(s));

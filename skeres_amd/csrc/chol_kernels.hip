@@ -1104,13 +1104,18 @@ __device__ int g_bs_stamps_on;              // the block row next to the diagona
 struct BsTop { unsigned short top[1024]; };  // per block column: the last block row of its contiguous run (<= nblk - 1)
 constexpr unsigned long long kBsSentinel = ~0ull;
 __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __restrict__ Linv, const double* __restrict__ S, long ld, const double* __restrict__ rhs,
-                                                               int n, double* y, int nblk, BsTop env, int* info) {
+                                                               int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb,
+                                                               int tail0) {
+  // nown < nblk: the interior of a LEAF FRONT (cholesky_backsolve_front): block columns [0, nown) have owners, the unknowns of
+  // the block rows below them — the front's border — are known (yb, in the border's order: the separators' solution); the block
+  // rows from tail0 on are active in every column (the right-hand-side row; a spike: SegmentLayout), the others up to the
+  // column's envelope.  nown == nblk, tail0 == nblk - 1: a whole system.
   // 1024 threads: column c of the block and one of eight groups of sixteen rows each — sixteen products per thread and matrix
   // on the chain's critical path where 256 threads had sixty-four (0.41 -> 0.39 ms on Ladybug-1723: the hop is mostly hand-over and barriers); the partial sums are formed over the
   // same rows and added in the same order as before (and as in bs_step_kernel)
   __shared__ double ysh[128], wsh[128], part[16][128];
   __shared__ int abort_s;
-  const int kb = nblk - 1 - (int)blockIdx.x;
+  const int kb = nown - 1 - (int)blockIdx.x;
   const int t = threadIdx.x, c = t & 127, rg = t >> 7;
   if (t == 0) abort_s = 0;
   if (t < 128) { const int j = kb * 128 + t; wsh[t] = j < n ? rhs[j] : 0.0; }
@@ -1121,7 +1126,8 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
     for (int i = 0; i < 16; ++i) li[i] = p[(long)i * 128];
   }
   const int top = min((int)env.top[kb], nblk - 1);
-  int cur = (kb < nblk - 1 && top < nblk - 1) ? nblk - 1 : top;  // block rows to apply: nblk - 1 (always active), then top .. kb + 1
+  const int tlo = max(tail0, top + 1);                             // the always-active rows that the envelope's run does not reach: [tlo, nblk)
+  int cur = (kb < nblk - 1 && tlo <= nblk - 1) ? nblk - 1 : top;  // block rows to apply: nblk - 1 .. tlo, then top .. kb + 1
   const double* Lcol = S + (long)(rg * 16) * ld + (long)kb * 128 + c;
   if (cur > kb) {
     const double* p = Lcol + (long)cur * 128 * ld;
@@ -1131,7 +1137,9 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
   __syncthreads();
   while (cur > kb) {
     if (g_bs_stamps_on && t == 0 && cur == kb + 1) g_bs_stamps[kb][0] = wall_clock64();
-    if (t < 128) {
+    if (t < 128 && cur >= nown) {
+      ysh[t] = yb[(long)(cur - nown) * 128 + t];  // a border row: known
+    } else if (t < 128) {
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(y + (long)cur * 128 + t);
       unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (v == kBsSentinel) {
@@ -1155,7 +1163,7 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
       for (int i = 0; i < 8; ++i) sacc += lr[g * 8 + i] * ysh[rg * 16 + g * 8 + i];
       part[rg * 2 + g][c] = sacc;
     }
-    const int nxt = (cur == nblk - 1 && top < nblk - 1) ? top : cur - 1;
+    const int nxt = (cur > top && cur - 1 < tlo) ? top : cur - 1;  // from the always-active rows down into the envelope's run
     if (nxt > kb) {  // the next block: its loads are in flight across the barrier and the next poll
       const double* p = Lcol + (long)nxt * 128 * ld;
 #pragma unroll
@@ -2093,7 +2101,7 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);
     static const char* bs_stamps = getenv("SK_BS_STAMPS");
     if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
-    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info);
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info, nblk, (const double*)nullptr, nblk - 1);
     if (kt) kt->end("backsolve", s);
     if (bs_stamps) {
       (void)hipStreamSynchronize(s);
@@ -2195,9 +2203,20 @@ void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f
 // Interior part of L^T y = z for a leaf front whose border unknowns are known.  yb: border unknowns (border_blocks * 128
 // values, zero where the border has padding or its right-hand-side row).  w: scratch (ncols * 128); y: interior solution.
 void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike) {
+                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info) {
   const int ni = ncols * 128, m = (nblk - ncols) * 128;
   if (ncols <= 0) return;
+  if (info && g_bs_resident && nblk <= 1024) {
+    // one resident launch (bs_resident_kernel): an owner per interior block column, the border's unknowns read from yb.  Not the
+    // same grouping of the border's terms as bs_border_kernel below (block row by block row there, sixteen interleaved row
+    // groups here): equal to rounding, not to the bit — a front's interior solution belongs to one rank.
+    if (tail_rows < 1 || tail_rows > nblk - ncols) tail_rows = 1;
+    BsTop env;
+    for (int c = 0; c < nblk && c < 1024; ++c) env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1);
+    (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)ni, s);
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, ni, y, nblk, env, info, ncols, yb, nblk - tail_rows);
+    return;
+  }
   hipLaunchKernelGGL(copy_row_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, ni, ni);
   // block rows' first non-zero block columns (the border rows: from the first interior column that reaches the border)
   std::vector<int> first(nblk, 0);
@@ -2295,8 +2314,8 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
 }
 
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,
-                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt) {
-  cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last);
+                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info) {
+  cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last, info);
   if (kt) kt->begin("backsolve", s);
   const int m = d.border_blocks * 128;
   const bool side = d.B.ncols > 0 && d.A.ncols > 0 && ctxB && ctxB->fork;
@@ -2309,10 +2328,10 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
       sB = ctxB->fork;
     }
     cholesky_gather_map(yR, d.mapB, ybB, m, sB);
-    cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, ybB, wB, yB, sB, d.B.last);
+    cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, ybB, wB, yB, sB, d.B.last, false, 1, info);
   }
   // (yR is zero in the root's padding rows and in its right-hand-side row: it serves as A's border unknowns as it stands)
-  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last);
+  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info);
   if (side) {
     (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);

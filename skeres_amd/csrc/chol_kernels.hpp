@@ -212,12 +212,13 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
 // Solve: root, then the two interiors side by side.  yR / yA / yB: solutions in each front's own order; w*: scratch of the
 // fronts' sizes; ybB: scratch of border size.  The right-hand sides are the fronts' rhs rows after the factorisation.
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,
-                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt);
+                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info = nullptr);
 // root += border x border block of a leaf front (front: ncols interior block columns, then border_blocks block rows);
 // map: root index of each border index (nullptr: identity; < 0: skip)
 void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s);
+// info != nullptr: one resident launch (the kernel of cholesky_backsolve; tail_rows as in cholesky_factor); nullptr: one launch per block step
 void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike = false);
+                              hipStream_t s, const int* last, bool spike = false, int tail_rows = 1, int* info = nullptr);
 void cholesky_gather_map(const double* src, const int* map, double* dst, int m, hipStream_t s);
 // --- multi-way dissection: R segments of a block-banded system with R - 1 separators between them ---
 // Leaf front of one segment, in scalar rows.  The interior is followed by a border:
