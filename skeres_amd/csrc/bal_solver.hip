@@ -348,8 +348,11 @@ static double column_cost_us(int h, bool resident_capable) {
 }
 // tail_resident: the tail has a device of its own (segmented world) and runs under a resident panel chain like the head;
 // on one device it is factored launch by launch next to the head's chain.
+// lockstep: the schedule of ONE device since the end of round 3 — the tail's block columns ride in the launches of the head's
+// trailing run of chain-bound columns (CholeskyPartner), so a paired step costs the dearer of its two columns and the head's
+// block columns before that run are not shortened at all.
 static Dissection choose_dissection(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
-                                    const std::vector<int>& first_col, bool tail_resident) {
+                                    const std::vector<int>& first_col, bool tail_resident, bool lockstep = false) {
   Dissection d;
   if (C < 64 || nblk < 24) return d;
   // reach[c]: the last camera that shares a point with any camera <= c (cameras in the chosen order)
@@ -360,10 +363,12 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
   for (int c = 1; c < C; ++c) reach[c] = std::max(reach[c], reach[c - 1]);
   // per block column: height forward (rows below, as the envelope has it) and backward (rows above: the tail's view)
   std::vector<double> fwd(nblk), bwd(nblk), fwd_sum(nblk + 1, 0.0), bwd_sum(nblk + 1, 0.0);
+  std::vector<int> height(nblk);
   std::vector<int> fc(first_col);
   for (int i = nblk - 2; i >= 0; --i) fc[i] = std::min(fc[i], fc[i + 1] < i + 1 ? fc[i + 1] : i);  // (monotone, as the backward envelope is)
   for (int c = 0; c < nblk; ++c) {
     const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0);
+    height[c] = hf;
     fwd[c] = column_cost_us(hf, true);
     bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1, tail_resident);
     d.t_plain += fwd[c];
@@ -377,11 +382,23 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
     if (E > 24) continue;  // a separator that wide is no separator: its dense system is factored after both chains, alone
     double root = 0.0;
     for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i, true);
-    const double t = std::max(fwd_sum[ca], bwd_sum[nblk] - bwd_sum[cb]) + root + 120.0;  // + fork, join, border add
+    double t = std::max(fwd_sum[ca], bwd_sum[nblk] - bwd_sum[cb]) + root + 120.0;  // + fork, join, border add
+    if (lockstep) {
+      int sa = ca;  // the head's trailing run of chain-bound columns: [sa, ca)
+      while (sa > 0 && height[sa - 1] <= 24) --sa;
+      const int na = ca - sa, nb = nblk - cb;
+      t = fwd_sum[sa] + root + 250.0;  // + border add, a second resident server's set-up, two more back-substitution launches
+      for (int k = 0; k < std::max(na, nb); ++k) {
+        const double fa = k < na ? fwd[sa + k] : 0.0, fb = k < nb ? bwd[nblk - 1 - k] : 0.0;
+        t += std::max(fa, fb);
+      }
+    }
     if (t < best) { best = t; d.a = a; d.b = b; }
   }
   d.t_dissected = best;
-  if (best > 0.9 * d.t_plain) { d.a = d.b = 0; }
+  // (the lock-step schedule adds no queues and no second chain's interference: it is taken for half the predicted gain the
+  // side-by-side one needed — measured on Ladybug-1723: predicted 9.8 %, 2.3 % of the iteration in the bench line)
+  if (best > (lockstep ? 0.95 : 0.9) * d.t_plain) { d.a = d.b = 0; }
   return d;
 }
 
@@ -768,11 +785,14 @@ int BalSolver::setup() {
       Dissection ds;
       std::vector<int> first_col;
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
-      ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, false);
+      // one device: the lock-step schedule and its own cut (developer knob SK_DISSECT_AUTO_SINGLE=0: AUTO leaves a single device undissected, as until the end of round 3)
+      static const int auto_single = getenv("SK_DISSECT_AUTO_SINGLE") ? atoi(getenv("SK_DISSECT_AUTO_SINGLE")) : 1;
+      const bool lockstep_cut = !multi && auto_single && opt_.dissection == SK_DISSECTION_AUTO;
+      ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, lockstep_cut, lockstep_cut);
       // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
       // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon there.
-      if (opt_.dissection == SK_DISSECTION_AUTO && !getenv("SK_DISSECT_AT")) { ds.a = ds.b = 0; }
+      if (opt_.dissection == SK_DISSECTION_AUTO && !getenv("SK_DISSECT_AT") && !lockstep_cut) { ds.a = ds.b = 0; }
       if (opt_.dissection == SK_DISSECTION_ON && ds.a == 0 && C_ >= 6) {
         // forced (tests, small problems): cut at the middle camera wherever that leaves a tail
         std::vector<int> cmin(P_total_, C_), cmax(P_total_, -1);

@@ -242,6 +242,15 @@ __global__ __launch_bounds__(256, 2) void syrk_trailing_thin_f64_kernel(double* 
   SK_GEMM_LDS(16, 32, 128)
   gemm_nt_f64_body<0, 2, 16, 2, 32, 128>(sh, C, ldc, A, lda, A, lda, K, tiles_m, 0, main_t, jump_t, main_n, jump_n, -1, first_column_done, count_cols, diag_done);
 }
+// ... and of two fronts in one launch (blockIdx.y picks the front)
+struct ThinSyrkArgs { double* C; long ldc; const double* A; long lda; int K, tiles_m, main_t, jump_t, main_n, jump_n; int* first_column_done; int grid; };
+struct ThinSyrkPair { ThinSyrkArgs f[2]; };
+__global__ __launch_bounds__(256, 2) void syrk_trailing_thin_pair_f64_kernel(ThinSyrkPair pair) {
+  const ThinSyrkArgs& p = pair.f[blockIdx.y];
+  if ((int)blockIdx.x >= p.grid) return;
+  SK_GEMM_LDS(16, 32, 128)
+  gemm_nt_f64_body<0, 2, 16, 2, 32, 128>(sh, p.C, p.ldc, p.A, p.lda, p.A, p.lda, p.K, p.tiles_m, 0, p.main_t, p.jump_t, p.main_n, p.jump_n, -1, p.first_column_done, 1, nullptr);
+}
 // Gram matrix H = A A^T (lower-triangular tiles): J^T J of the dense path with the Jacobian stored
 // transposed (A = J^T, K = number of residuals) — BASELINE.json config 5.
 // The K range is split over blockIdx.y (chunk c covers columns [c*K, (c+1)*K) of A and writes slab c of C):
@@ -874,8 +883,7 @@ __device__ __forceinline__ void chain_publish_through(int* p, int add) {
 
 struct ChainRanges { int n; int begin[8], end[8]; };  // the resident runs of block columns, [begin, end)
 
-__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __forceinline__ void potrf_server_body(double* lds, double* S, long ld, const ChainRanges& ranges, double* Linv, int* info, int* sync, int maxblk) {
   __shared__ int ok_s;
   int done = 0;  // value of the potrf counter
   for (int r = 0; r < ranges.n; ++r)
@@ -895,6 +903,19 @@ __global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld
       done = j + 1;
       SK_CHAIN_STAMP(j, 1)
     }
+}
+__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  potrf_server_body(lds, S, ld, ranges, Linv, info, sync, maxblk);
+}
+// Two fronts eliminated in ONE sequence of launches (cholesky_factor with a partner front): a
+// server workgroup each, on a CU 0 each.
+struct ServerArgs { double* S; long ld; ChainRanges ranges; double* Linv; int* sync; int maxblk; };
+struct ServerPair { ServerArgs f[2]; };
+__global__ __launch_bounds__(256, 1) void potrf_server_pair_kernel(ServerPair pair, int* info) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const ServerArgs& p = pair.f[blockIdx.x];  // (indexed in the kernel-argument segment: scalar loads)
+  potrf_server_body(lds, p.S, p.ld, p.ranges, p.Linv, info, p.sync, p.maxblk);
 }
 
 // One 32 x 32 tile with K = 128 in a single memory round trip: C = A B^T (kMode 1) or C -= A B^T (kMode 0), A and B
@@ -939,8 +960,8 @@ __device__ __forceinline__ long crit_tile_off(long ldc, int i) {
 // of the other active rows (thin tile 4 + (blockIdx.x - ncrit)).  ncrit == 0: block row j+1 is outside the envelope.
 // Xs: 128 x 128 scratch.  X(j+1,j) cannot be formed in place tile by tile (every column tile reads whole rows of
 // S(j+1,j)): the tiles go to Xs, which next(j) reads, and into S(j+1,j) once all 16 are known to have loaded theirs.
-__global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld, int j, const double* Linv_j, int tiles_m, int main_t, int jump_t,
-                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info, int do_next, int wait_first) {
+__device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int j, const double* Linv_j, int tiles_m, int main_t, int jump_t,
+                                                  int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info, int do_next, int wait_first) {
   __shared__ __attribute__((aligned(16))) double sh[2 * 32 * kCritLd];
   static_assert(2 * 32 * kCritLd >= gemm_lds_doubles(16, 32, 128), "LDS of the thin tiles");
   __shared__ int ok_s;
@@ -948,7 +969,6 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
   double* A21 = S + (long)(j + 1) * 128 * ld + (long)j * 128;
   int* x_ready = sync + kSyncHeader + maxblk + j;
   int* diag_ready = sync + kSyncHeader + j + 1;
-  const int b = blockIdx.x;
   const bool crit = b < ncrit;
   const int ri = b >> 2, q = b & 3;        // critical tile: rows ri * 32, columns q * 32 of the block
   const int thin_id = 4 + (b - ncrit);     // other workgroups (ncrit == 16), or every workgroup from 0 (ncrit == 0)
@@ -1016,6 +1036,18 @@ __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld
     if (ncrit == 0 && b == 0) chain_publish(diag_ready, 16);
   }
   if (stamp) SK_CHAIN_STAMP(j, 6)
+}
+__global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld, int j, const double* Linv_j, int tiles_m, int main_t, int jump_t,
+                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info, int do_next, int wait_first) {
+  chain_column_body((int)blockIdx.x, S, ld, j, Linv_j, tiles_m, main_t, jump_t, ncrit, Xs, sync, maxblk, syrk_need, column_need, info, do_next, wait_first);
+}
+// ... the column launches of two fronts as one launch: blockIdx.y picks the front (grid.x: the larger of the two grids)
+struct ColumnArgs { double* S; long ld; int j; const double* Linv_j; int tiles_m, main_t, jump_t, ncrit; double* Xs; int* sync; int maxblk, syrk_need, column_need, grid; };
+struct ColumnPair { ColumnArgs f[2]; };
+__global__ __launch_bounds__(256, 2) void chain_column_pair_kernel(ColumnPair pair, int* info) {
+  const ColumnArgs& p = pair.f[blockIdx.y];
+  if ((int)blockIdx.x >= p.grid) return;
+  chain_column_body((int)blockIdx.x, p.S, p.ld, p.j, p.Linv_j, p.tiles_m, p.main_t, p.jump_t, p.ncrit, p.Xs, p.sync, p.maxblk, p.syrk_need, p.column_need, info, 1, 0);
 }
 
 // after a SYRK on its stream: the SYRK's completion (and its end-of-kernel write-back) as a counter the chain can poll
@@ -1250,6 +1282,8 @@ hipError_t cholesky_init() {
   if (const char* e = getenv("SK_CHAIN_PREFIX_GROUP")) g_chain_prefix_group = atoi(e);
   if (const char* e = getenv("SK_CHAIN_PAIR_MAX_TRAILING")) g_pair_max_trailing = atoi(e);
   hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_server_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_potrf_lds);
+  if (rc != hipSuccess) return rc;
+  rc = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_server_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_potrf_lds);
   if (rc != hipSuccess) return rc;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(potrf128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -1813,7 +1847,7 @@ void cholesky_prepare(CholeskyContext* ctx, hipStream_t s) {
 }
 
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt, const int* last, bool allow_chain, int ncols, int tail_rows) {
+                     KernelTimer* kt, const int* last, bool allow_chain, int ncols, int tail_rows, const CholeskyPartner* partner) {
   const int nblk = npad / 128;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
   if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
@@ -1931,14 +1965,77 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   const int maxblk = chain ? ctx->sync_blk : 0;
   const char* stamps_file = chain ? getenv("SK_CHAIN_STAMPS") : nullptr;
   hipStream_t srv = nullptr;
+  struct PartnerState {
+    bool on = false; CholeskyPlan plan; int nblk = 0, ncols = 0, tail0 = 0, start_at = 0, maxblk = 0; const int* last = nullptr;
+    double* S = nullptr; long ld = 0; double* Linv = nullptr; int* sync = nullptr; double* xs = nullptr;
+    int next = 0, seq = 0, col_seq = 0;
+  } pb;
+  // the partner's block column kB: its column launch and its thin SYRK (Tb == 0: none), as the resident branch below forms them
+  struct PartnerStep { ColumnArgs col; ThinSyrkArgs syrk; int Tb; bool next_resident, by_column; };
+  auto partner_step = [&](int kB) {
+    PartnerStep st;
+    auto lm = [&](int c) { return pb.last ? (pb.last[c] < pb.nblk - 1 ? pb.last[c] : pb.nblk - 1) : pb.nblk - 1; };
+    auto rf = [&](int first_row, int last_row) {
+      Rows r;
+      r.main = last_row >= first_row ? last_row - first_row + 1 : 0;
+      const int t0 = std::max(pb.tail0, first_row + r.main);
+      r.extra = std::max(0, pb.nblk - t0);
+      r.jump = r.extra ? t0 - (first_row + r.main) : 0;
+      return r;
+    };
+    const int k1 = kB + 1, Lg = lm(kB);
+    const Rows rn = rf(k1, Lg), rs = rf(k1 + 1, Lg);
+    const int T = rn.main + rn.extra, ncrit = (rn.main > 0 || rn.jump == 0) ? 16 : 0;
+    st.Tb = rs.main + rs.extra;
+    st.next_resident = k1 < pb.ncols;
+    st.by_column = st.next_resident && g_early_column;
+    st.col = ColumnArgs{pb.S, pb.ld, kB, pb.Linv + (long)kB * 128 * 128, 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, pb.xs, pb.sync, pb.maxblk, pb.seq, pb.col_seq,
+                        ncrit ? 16 + 4 * T - 4 : 4 * T};
+    st.syrk = ThinSyrkArgs{pb.S + (long)(k1 + 1) * 128 * pb.ld + (long)(k1 + 1) * 128, pb.ld, pb.S + (long)(k1 + 1) * 128 * pb.ld + (long)kB * 128, pb.ld, 128, 4 * st.Tb,
+                           4 * rs.main, 4 * rs.jump, rs.main, rs.jump, st.by_column ? pb.sync + kSyncSyrkColumn : (int*)nullptr, st.Tb > 0 ? 2 * st.Tb * (st.Tb + 1) : 0};
+    return st;
+  };
+  // ... and what its SYRK leaves for its next column launch to wait for (after the launch that carried it)
+  auto partner_advance = [&](const PartnerStep& st, hipStream_t bulk_stream) {
+    if (st.Tb > 0) {
+      if (st.by_column) pb.col_seq += 4 * st.Tb;
+      else if (st.next_resident) { ++pb.seq; hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, bulk_stream, pb.sync + kSyncSyrkSeq, pb.seq); }
+    }
+    ++pb.next;
+  };
   if (chain) {
     const int stamps_on = stamps_file ? 1 : 0;
     static int stamps_state = 0;
     if (stamps_on != stamps_state) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamps_on), &stamps_on, sizeof(int)); stamps_state = stamps_on; }
     srv = ctx->server;
     (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * maxblk), s);
+    // ---- the partner front (see CholeskyPartner): taken along if every one of its block columns is a resident single column,
+    // from the first of this front's trailing run of resident single columns on
+    if (partner && partner->ncols > 0 && partner->ctx && !(kt && kt->times_all())) {
+      pb.plan = cholesky_plan(partner->nblk, group, partner->last, true, partner->ncols, partner->tail_rows);
+      bool all = (int)pb.plan.resident.size() >= partner->ncols;
+      for (int j = 0; all && j < partner->ncols; ++j) all = pb.plan.resident[j] && !pb.plan.paired[j];
+      int start = ncols;
+      while (start > 0 && plan.resident[start - 1] && !plan.paired[start - 1]) --start;
+      int* sb_sync = all && start < ncols ? partner->ctx->sync_for(partner->nblk) : nullptr;
+      if (sb_sync && partner->ctx->xs) {
+        pb.on = true; pb.start_at = start; pb.sync = sb_sync; pb.maxblk = partner->ctx->sync_blk; pb.xs = partner->ctx->xs;
+        pb.nblk = partner->nblk; pb.ncols = partner->ncols; pb.tail0 = partner->nblk - std::max(1, std::min(partner->tail_rows, partner->nblk - partner->ncols));
+        pb.last = partner->last; pb.S = partner->S; pb.ld = partner->ld; pb.Linv = partner->Linv;
+        (void)hipMemsetAsync(pb.sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * pb.maxblk), s);
+        partner->taken = true;
+      }
+    }
     order(s, srv);
-    hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk);
+    if (pb.on) {
+      ServerPair sp2;
+      sp2.f[0] = ServerArgs{S, ld, ranges, Linv, sync, maxblk};
+      ChainRanges rb; rb.n = 1; rb.begin[0] = 0; rb.end[0] = pb.ncols;
+      sp2.f[1] = ServerArgs{pb.S, pb.ld, rb, pb.Linv, pb.sync, pb.maxblk};
+      hipLaunchKernelGGL(potrf_server_pair_kernel, dim3(2), dim3(256), potrf128_lds_bytes(), srv, sp2, info);
+    } else {
+      hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk);
+    }
   }
   order(s, sp);
   if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }
@@ -1951,6 +2048,8 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     const int k0 = gb[g], k1 = gb[g + 1];
     if (k0 >= ncols) break;  // (a partial factorisation: the border's pseudo-groups)
     const int K = (k1 - k0) * 128;
+    bool with_partner = false;  // this group's column launch and SYRK carry a block column of the partner front
+    PartnerStep pst{};
     const bool resident = is_resident(k0);        // potrf(k0) by the server; TRSM and next(g) by one column launch
     const bool next_resident = is_resident(k1);   // ... and the same for the next group
     // tile columns that next(g) updates: those of the next group — but a resident column's launch applies its panel to
@@ -1994,9 +2093,18 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       const int T = rn.main + rn.extra;  // rows of X(.,k0) == rows that next(g) updates (K = 128, na == 1)
       // block row k0+1 is active as the start of the main run, or as the last block row itself
       const int ncrit = (rn.main > 0 || rn.jump == 0) ? 16 : 0;
-      hipEvent_t col_done = Tb > 0 ? ctx->event(ev++) : nullptr;
-      hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, col_done, 0, S, ld, k0,
-                            (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, info, 1, after_pair ? 1 : 0);
+      with_partner = pb.on && k0 >= pb.start_at && pb.next < pb.ncols && !after_pair && Tb <= g_thin_syrk_tiles;
+      if (with_partner) pst = partner_step(pb.next);
+      hipEvent_t col_done = (Tb > 0 || (with_partner && pst.Tb > 0)) ? ctx->event(ev++) : nullptr;
+      if (with_partner) {
+        ColumnPair cp;
+        cp.f[0] = ColumnArgs{S, ld, k0, Linv + (long)k0 * 128 * 128, 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, ncrit ? 16 + 4 * T - 4 : 4 * T};
+        cp.f[1] = pst.col;
+        hipExtLaunchKernelGGL(chain_column_pair_kernel, dim3(std::max(cp.f[0].grid, cp.f[1].grid), 2), dim3(256), 0, sp, nullptr, col_done, 0, cp, info);
+      } else {
+        hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, col_done, 0, S, ld, k0,
+                              (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, info, 1, after_pair ? 1 : 0);
+      }
       if (col_done) (void)hipStreamWaitEvent(sb, col_done, 0);
     } else {
       // panel(g) is final: syrk(g) may start (after syrk(g-1))
@@ -2008,7 +2116,27 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     }
     // syrk(g): everything right of them, lower triangle over the active rows
     syrk_done = nullptr;
-    if (Tb > 0) {
+    if (with_partner) {
+      // both fronts' thin SYRKs as one launch; each front's first block column counts into its own counter
+      const bool by_col = next_resident && g_early_column;
+      ThinSyrkPair tp;
+      tp.f[0] = ThinSyrkArgs{S + (long)(k1 + 1) * 128 * ld + (long)(k1 + 1) * 128, ld, S + (long)(k1 + 1) * 128 * ld + (long)k0 * 128, ld, 128, 4 * Tb, 4 * rs.main, 4 * rs.jump,
+                             rs.main, rs.jump, by_col ? sync + kSyncSyrkColumn : (int*)nullptr, Tb > 0 ? 2 * Tb * (Tb + 1) : 0};
+      tp.f[1] = pst.syrk;
+      const int gx = std::max(tp.f[0].grid, tp.f[1].grid);
+      hipEvent_t t_start = nullptr, t_stop = nullptr;
+      if (kt && gx > 0) kt->pair("gemm_syrk", &t_start, &t_stop);  // (the SYRK timer of the bench line covers both fronts' tiles: so does its flop count)
+      hipEvent_t stop_ev = t_stop ? t_stop : ctx->event(ev++);
+      if (gx > 0) hipExtLaunchKernelGGL(syrk_trailing_thin_pair_f64_kernel, dim3(gx, 2), dim3(256), 0, sb, t_start, stop_ev, 0, tp);
+      if (Tb > 0) {
+        if (by_col) col_seq += 4 * Tb;
+        else if (next_resident) { ++seq; hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, seq); }
+      }
+      partner_advance(pst, sb);
+      if (gx > 0 && !next_resident) syrk_done = stop_ev;  // (the launch-by-launch panel that follows waits for it)
+      syrk_done2 = syrk_any;
+      syrk_any = gx > 0 ? stop_ev : nullptr;
+    } else if (Tb > 0) {
       double* Cb = S + (long)(k1 + na) * 128 * ld + (long)(k1 + na) * 128;
       const double* Pb = S + (long)(k1 + na) * 128 * ld + (long)k0 * 128;
       // the launch-by-launch next(g+1) waits for this SYRK as an event; so does a SYRK that follows on the other bulk stream
@@ -2068,6 +2196,23 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
         panel(k1, k2);
       }
     }
+  }
+  // the partner's block columns that found no column of this front to ride with: launches of their own, on the same streams
+  while (pb.on && pb.next < pb.ncols) {
+    const PartnerStep st = partner_step(pb.next);
+    hipEvent_t col_done = st.Tb > 0 ? ctx->event(ev++) : nullptr;
+    ColumnPair cp;
+    cp.f[0] = st.col; cp.f[1] = st.col; cp.f[1].grid = 0;
+    hipExtLaunchKernelGGL(chain_column_pair_kernel, dim3(st.col.grid, 1), dim3(256), 0, sp, nullptr, col_done, 0, cp, info);
+    if (st.Tb > 0) {
+      (void)hipStreamWaitEvent(ctx->bulk, col_done, 0);
+      ThinSyrkPair tp;
+      tp.f[0] = st.syrk; tp.f[1] = st.syrk; tp.f[1].grid = 0;
+      hipEvent_t t_start = nullptr, t_stop = nullptr;
+      if (kt) kt->pair("gemm_syrk", &t_start, &t_stop);
+      hipExtLaunchKernelGGL(syrk_trailing_thin_pair_f64_kernel, dim3(st.syrk.grid, 1), dim3(256), 0, ctx->bulk, t_start, t_stop, 0, tp);
+    }
+    partner_advance(st, ctx->bulk);
   }
   order(sp, s);
   if (la) { order(ctx->bulk, s); order(ctx->bulk_early, s); }
@@ -2266,6 +2411,22 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
   static const int head_first = getenv("SK_DISSECT_HEAD_FIRST") ? atoi(getenv("SK_DISSECT_HEAD_FIRST")) : 0;
   const bool side = d.B.ncols > 0 && ctxB && ctxB->fork && !serial;
   static const int threaded = getenv("SK_DISSECT_THREAD") ? atoi(getenv("SK_DISSECT_THREAD")) : 1;
+  // The tail front rides in the launches of the head's chain-bound block columns (CholeskyPartner) instead of having queues of
+  // its own (developer knob SK_DISSECT_LOCKSTEP=0: the side-by-side form of rounds 2 and 3, slower on every cut measured)
+  static const int lockstep = getenv("SK_DISSECT_LOCKSTEP") ? atoi(getenv("SK_DISSECT_LOCKSTEP")) : 1;
+  if (lockstep && d.A.ncols > 0 && d.B.ncols > 0 && ctxA && ctxB && allow_chain) {
+    CholeskyPartner pt{d.B.S, d.B.ld, d.B.nblk, d.B.ncols, 1, d.B.last, d.B.Linv, ctxB};
+    cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols, 1, &pt);
+    if (!pt.taken)  // (not every block column of the tail is a resident single column: factored afterwards, on the primary context)
+      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, allow_chain, d.B.ncols);
+    if (timing) { (void)hipEventRecord(tev[1], s); (void)hipEventRecord(tev[2], s); }
+    cholesky_border_add(d.R.S, d.R.ld, d.A.S, d.A.ld, d.A.ncols, d.border_blocks, nullptr, s);
+    cholesky_border_add(d.R.S, d.R.ld, d.B.S, d.B.ld, d.B.ncols, d.border_blocks, d.mapB, s);
+    if (timing) (void)hipEventRecord(tev[3], s);
+    cholesky_factor(d.R.S, d.R.ld, d.R.nblk * 128, d.R.Linv, info, group, s, ctxA, kt, d.R.last, allow_chain);
+    if (timing) (void)hipEventRecord(tev[4], s);
+    return;
+  }
   bool tail_async = false;
   auto tail = [&]() {
     if (d.B.ncols <= 0) return;

@@ -174,8 +174,16 @@ size_t potrf128_lds_bytes();
 // Linv: (npad/128) blocks of 128x128, zero-initialised once by the caller.
 // ctx == nullptr: everything on `s`; otherwise the panel chain overlaps the trailing SYRK.
 // allow_chain: the grouping is the library's to choose (cholesky_plan): resident panel chain for the chain-bound columns.
+// partner: a SECOND leaf front whose block columns — all under the resident chain — ride in the launches of the first one's
+// chain-bound columns (one server workgroup each, the column launches and thin SYRKs of both fronts as ONE launch each, blockIdx.y
+// picking the front: DESIGN.md section 8, item 0).  ctx lends its counters and scratch only.  taken: whether it was factored.
+struct CholeskyPartner {
+  double* S; long ld; int nblk, ncols, tail_rows; const int* last; double* Linv; CholeskyContext* ctx;
+  mutable bool taken = false;
+};
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt, const int* last = nullptr, bool allow_chain = false, int ncols = -1, int tail_rows = 1);
+                     KernelTimer* kt, const int* last = nullptr, bool allow_chain = false, int ncols = -1, int tail_rows = 1,
+                     const CholeskyPartner* partner = nullptr);
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
 bool cholesky_note_info(CholeskyContext* ctx, int info);
 bool cholesky_chain_enabled(const CholeskyContext* ctx);

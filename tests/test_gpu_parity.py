@@ -644,13 +644,15 @@ def test_default_plan_matches_explicit_grouping_at_full_size():
     updates are grouped (different rounding), not in the algorithm: 1e-10."""
     prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1))
 
-    def run(group):
+    def run(group, dissection=None):
         problem, params, loss = bal_problem_to_sk(prob)
         options = sk.Solver.Options()
         options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
         options.setMaxNumIterations(2)
         if group:
             options.setCholeskyTuning(group, True)
+        if dissection:
+            options.setCholeskyDissection(dissection)
         solver = sk.StepSolver(options, problem)
         resident = solver.stat("cholesky_columns_resident"), solver.stat("dissected")
         while not solver.step():
@@ -658,16 +660,23 @@ def test_default_plan_matches_explicit_grouping_at_full_size():
         summary = sk.Solver.Summary()
         solver.finish(summary)
         return params.toArray(prob.num_parameters), summary, resident
-    x_auto, s_auto, (resident, dissected) = run(0)
+    x_auto, s_auto, (resident, dissected) = run(0, "off")
     x_g, s_g, (resident_g, dissected_g) = run(2)
     # the automatic plan really ran the resident chain; the explicit one did not
     assert resident >= 60 and dissected == 0 and resident_g == 0 and dissected_g == 0
-    a, b = s_auto.iterations(), s_g.iterations()
-    assert len(a) == len(b) == 3
-    for u, v in zip(a, b):
-        # (the gradient at the new point amplifies the rounding difference of the step: 1e-10 observed)
-        for k, tol in (("cost", 1e-10), ("step_norm", 1e-9), ("relative_decrease", 1e-9), ("trust_region_radius", 1e-9), ("gradient_max_norm", 1e-8)):
-            assert abs(u[k] - v[k]) <= tol * max(abs(v[k]), 1e-300), (k, u[k], v[k])
+    # ... and what a single device does by default since the end of round 3: the camera sequence dissected, the tail front riding
+    # in the launches of the head's chain-bound block columns (CholeskyPartner) — another elimination order, the same system
+    x_d, s_d, (resident_d, dissected_d) = run(0)
+    assert dissected_d == 1
+    b = s_g.iterations()
+    for s_other in (s_auto, s_d):
+        a = s_other.iterations()
+        assert len(a) == len(b) == 3
+        for u, v in zip(a, b):
+            # (the gradient at the new point amplifies the rounding difference of the step: 1e-10 observed)
+            for k, tol in (("cost", 1e-10), ("step_norm", 1e-9), ("relative_decrease", 1e-9), ("trust_region_radius", 1e-9), ("gradient_max_norm", 1e-8)):
+                assert abs(u[k] - v[k]) <= tol * max(abs(v[k]), 1e-300), (k, u[k], v[k])
+    assert np.abs(x_d - x_g).max() <= 1e-9 * max(1.0, np.abs(x_g).max())
     assert np.linalg.norm(x_auto - x_g) <= 1e-10 * np.linalg.norm(x_g - prob.parameters)
     # ... and the explicit grouping is what the oracle-compared small problems run too: same check at a size the oracle solves
     small = bal.generate(150, 3000, 14000, seed=5)
