@@ -787,7 +787,9 @@ int BalSolver::setup() {
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
       // one device: the lock-step schedule and its own cut (developer knob SK_DISSECT_AUTO_SINGLE=0: AUTO leaves a single device undissected, as until the end of round 3)
       static const int auto_single = getenv("SK_DISSECT_AUTO_SINGLE") ? atoi(getenv("SK_DISSECT_AUTO_SINGLE")) : 1;
-      const bool lockstep_cut = !multi && auto_single && opt_.dissection == SK_DISSECTION_AUTO;
+      // (only under the resident chain: the partner front rides in ITS launches — with SK_CHOL_CHAIN_SERVER=0, or on a device that
+      // lost its chain, a single device stays undissected)
+      const bool lockstep_cut = !multi && auto_single && opt_.dissection == SK_DISSECTION_AUTO && cholesky_chain_enabled(&chol_ctx_);
       ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, lockstep_cut, lockstep_cut);
       // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under

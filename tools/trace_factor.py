@@ -16,7 +16,7 @@ it = rows[pi:]
 end = [i for i, r in enumerate(it) if r['n'] in ('copy_row_kernel', 'bs_resident_kernel')][0]  # (the back-substitution: what follows the factorisation)
 names = ('potrf128_kernel', 'trsm_gemm_f64_kernel', 'trsm_gemm_thin_f64_kernel', 'gemm_update_f64_kernel', 'gemm_update_thin_f64_kernel',
          'gemm_diag_f64_kernel', 'syrk_trailing_f64_kernel', 'syrk_trailing_thin_f64_kernel', 'potrf_server_kernel', 'chain_column_kernel',
-         'chain_marker_kernel', 'crit_server_kernel')
+         'chain_marker_kernel', 'crit_server_kernel', 'chain_column_pair_kernel', 'syrk_trailing_thin_pair_f64_kernel', 'potrf_server_pair_kernel')
 ch = [r for r in it[1:end] if r['n'] in names]
 t0 = ch[0]['s']; t1 = max(r['e'] for r in ch)
 print("factor wall %.2f ms, kernels %d" % ((t1 - t0) / 1e6, len(ch)))

@@ -11,7 +11,8 @@ for r in rows:
     r['n'] = r['Kernel_Name'].split('(')[0].replace('sk::', '').replace('void ', '')
 rows.sort(key=lambda r: r['s'])
 skip = ('potrf128_kernel', 'trsm_gemm_f64_kernel', 'trsm_gemm_thin_f64_kernel', 'gemm_update_f64_kernel', 'gemm_update_thin_f64_kernel', 'gemm_diag_f64_kernel',
-        'syrk_trailing_f64_kernel', 'syrk_trailing_thin_f64_kernel', 'potrf_server_kernel', 'chain_column_kernel', 'chain_marker_kernel')
+        'syrk_trailing_f64_kernel', 'syrk_trailing_thin_f64_kernel', 'potrf_server_kernel', 'chain_column_kernel', 'chain_marker_kernel',
+        'chain_column_pair_kernel', 'syrk_trailing_thin_pair_f64_kernel', 'potrf_server_pair_kernel', 'border_add_kernel')
 bs = [i for i, r in enumerate(rows) if r['n'] == 'bs_resident_kernel']
 a, b = bs[-3], bs[-2]  # from one back-substitution to the next: D, A, B (and the factorisation, skipped)
 prev_end = rows[a]['s']
