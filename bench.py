@@ -487,14 +487,21 @@ def main():
             ph = line["phases_ms_per_step"]
             shard = ph["jacobian_eval"] + ph["schur_assemble"] + ph["back_substitute"] + ph["cost_eval"]
             pred = {}
+            # (what the model says of THIS run's factorisation: the lock-step dissection of one device where that was taken)
+            model_one = model_us[1]
+            try:
+                if solver.stat("dissected") == 1.0 and solver.stat("dissection_model_us") > 0.0:
+                    model_one = solver.stat("dissection_model_us")
+            except Exception:
+                pass
             for n_dev in (2, 4, 8):
                 # the plan a world of n_dev ranks takes by itself (sk_problem_segment_plan, not forced: the rule of a real run — a
                 # third or later segment has to beat the plan so far by 5 % in the model)
                 k = int(problem.segmentPlan(n_dev, forced=False)[0])
                 k = k if model_us.get(k, 0.0) > 0.0 else 1
                 # (ranks beyond the segments are replicas of one: the point work shards by segment, not by rank)
-                pred[str(n_dev)] = {"ms_per_step": ph["cholesky"] * model_us[k] / model_us[1] + shard / k, "segments": k}
-            line["predicted_multi_gpu"] = {"model_us_per_segments": {str(k): v for k, v in model_us.items() if v > 0.0}, "per_n_gpus": pred,
+                pred[str(n_dev)] = {"ms_per_step": ph["cholesky"] * model_us[k] / model_one + shard / k, "segments": k}
+            line["predicted_multi_gpu"] = {"model_us_per_segments": {str(k): v for k, v in model_us.items() if v > 0.0}, "model_us_this_run": model_one, "per_n_gpus": pred,
                                            "note": "chain model, calibrated on this run's Cholesky phase; no scaling curve has been measured on hardware"}
         # The whole Cholesky phase (factorisation + triangular solves, every kernel of it) against the MFMA peak.  The
         # timed region factors the blocks inside the envelope (cholesky_flops_plan); the structure-independent figure
