@@ -384,14 +384,15 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
     for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i, true);
     double t = std::max(fwd_sum[ca], bwd_sum[nblk] - bwd_sum[cb]) + root + 120.0;  // + fork, join, border add
     if (lockstep) {
-      int sa = ca;  // the head's trailing run of chain-bound columns: [sa, ca)
-      while (sa > 0 && height[sa - 1] <= 24) --sa;
-      const int na = ca - sa, nb = nblk - cb;
-      t = fwd_sum[sa] + root + 250.0;  // + border add, a second resident server's set-up, two more back-substitution launches
-      for (int k = 0; k < std::max(na, nb); ++k) {
-        const double fa = k < na ? fwd[sa + k] : 0.0, fb = k < nb ? bwd[nblk - 1 - k] : 0.0;
-        t += std::max(fa, fb);
+      // the head's chain-bound columns (its first few, and its trailing run) each carry one of the tail's; the others cost what they cost
+      const int nb = nblk - cb;
+      int k = 0;
+      t = root + 250.0;  // + border add, a second resident server's set-up, two more back-substitution launches
+      for (int c = 0; c < ca; ++c) {
+        if (height[c] <= 24 && k < nb) { t += std::max(fwd[c], bwd[nblk - 1 - k]); ++k; }
+        else t += fwd[c];
       }
+      for (; k < nb; ++k) t += bwd[nblk - 1 - k];
     }
     if (t < best) { best = t; d.a = a; d.b = b; }
   }

@@ -2010,13 +2010,15 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     srv = ctx->server;
     (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * maxblk), s);
     // ---- the partner front (see CholeskyPartner): taken along if every one of its block columns is a resident single column,
-    // from the first of this front's trailing run of resident single columns on
+    // in the launches of this front's resident single columns
     if (partner && partner->ncols > 0 && partner->ctx && !(kt && kt->times_all())) {
       pb.plan = cholesky_plan(partner->nblk, group, partner->last, true, partner->ncols, partner->tail_rows);
       bool all = (int)pb.plan.resident.size() >= partner->ncols;
       for (int j = 0; all && j < partner->ncols; ++j) all = pb.plan.resident[j] && !pb.plan.paired[j];
-      int start = ncols;
-      while (start > 0 && plan.resident[start - 1] && !plan.paired[start - 1]) --start;
+      // (from the first resident single column of this front on — its first few block columns are chain-bound too, before the
+      // wide ones: the partner's chain pauses while those are factored launch by launch, and goes on in the trailing run)
+      int start = 0;
+      while (start < ncols && !(plan.resident[start] && !plan.paired[start])) ++start;
       int* sb_sync = all && start < ncols ? partner->ctx->sync_for(partner->nblk) : nullptr;
       if (sb_sync && partner->ctx->xs) {
         pb.on = true; pb.start_at = start; pb.sync = sb_sync; pb.maxblk = partner->ctx->sync_blk; pb.xs = partner->ctx->xs;
