@@ -1009,6 +1009,28 @@ void launch_bal_pair(const BalDev& d, hipStream_t s) {
   }
 }
 void launch_finish_normal_matrix(double* S, int ld, int n, int npad, int rhs_row, const double* D, hipStream_t s) { hipLaunchKernelGGL(finish_normal_matrix_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S, ld, n, npad, rhs_row, D); }
+// bal_finish_S for every front + up to four set_diagonal ranges, in one launch (a single device: six launches of ~6 us each
+// in front of the factorisation when the system is dissected, four when it is not)
+__global__ void bal_finish_all_kernel(BalDev d, BalFinishRanges r, int jmax) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= jmax) return;
+  if (j < 9 * d.C) {
+    const int i = j / 9, c = j - 9 * i, part = bal_part(d, i);
+    if (d.front[part].S) {
+      int ld;
+      double* blk = bal_block(d, i, i, &ld);
+      blk[(size_t)c * ld + c] += d.D_c[j] * d.D_c[j];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (r.S[k] && j >= r.from[k] && j < r.to[k]) r.S[k][(size_t)j * r.ld[k] + j] = r.value[k];
+}
+void launch_bal_finish_all(const BalDev& d, const BalFinishRanges& r, hipStream_t s) {
+  int jmax = 9 * d.C;
+  for (int k = 0; k < 4; ++k) if (r.S[k] && r.to[k] > jmax) jmax = r.to[k];
+  hipLaunchKernelGGL(bal_finish_all_kernel, dim3((jmax + 255) / 256), dim3(256), 0, s, d, r, jmax);
+}
 void launch_bal_finish_S(const BalDev& d, int parts, hipStream_t s) { hipLaunchKernelGGL(bal_finish_S_kernel, dim3((9 * d.C + 255) / 256), dim3(256), 0, s, d, parts); }
 void launch_set_diagonal(double* S, int ld, int from, int to, double value, hipStream_t s) {
   if (to > from) hipLaunchKernelGGL(set_diagonal_kernel, dim3((to - from + 255) / 256), dim3(256), 0, s, S, ld, from, to, value);

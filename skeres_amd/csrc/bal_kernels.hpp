@@ -118,6 +118,8 @@ void launch_bal_cam_diag(const BalDev& d, hipStream_t s);
 void launch_bal_pair(const BalDev& d, hipStream_t s);
 void launch_finish_normal_matrix(double* S, int ld, int n, int npad, int rhs_row, const double* D, hipStream_t s);
 void launch_bal_finish_S(const BalDev& d, int parts, hipStream_t s);  // D_c^2 onto the diagonal entries of the cameras of `parts` (bit mask)
+struct BalFinishRanges { double* S[4] = {nullptr, nullptr, nullptr, nullptr}; int ld[4] = {0, 0, 0, 0}, from[4] = {0, 0, 0, 0}, to[4] = {0, 0, 0, 0}; double value[4] = {0, 0, 0, 0}; };
+void launch_bal_finish_all(const BalDev& d, const BalFinishRanges& r, hipStream_t s);  // ... of every camera, + S[k][j][j] = value[k] for from[k] <= j < to[k]
 void launch_set_diagonal(double* S, int ld, int from, int to, double value, hipStream_t s);  // S[j][j] = value, from <= j < to
 void launch_bal_gather_y(const BalDev& d, hipStream_t s);  // y_c[9 i + k] from the fronts' solutions
 int launch_bal_point_backsub(const BalDev& d, hipStream_t s);

@@ -1381,10 +1381,21 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row, fr_[2].rhs_row + 1, 1e300, s);
     launch_set_diagonal(d_.front[2].S, (int)fr_[2].dim, fr_[2].rhs_row + 1, (int)fr_[2].dim, 1.0, s);
   };
-  launch_bal_finish_S(d_, 3, s);
-  for (int f = 0; f < 2; ++f)
-    if (fr_[f].nblk > 0) launch_set_diagonal(d_.front[f].S, (int)fr_[f].dim, 9 * fr_[f].cams, fr_[f].ncols * 128, 1.0, s);
-  if (!segmented_) finish_root();  // (segmented: after the ranks' root fronts have been summed — D^2 and the diagonals are added once)
+  if (!segmented_) {
+    // one launch: D^2 of every camera, the identities on the leaf fronts' padding, the root's two diagonal ranges
+    BalFinishRanges r;
+    int k = 0;
+    for (int f = 0; f < 2; ++f)
+      if (fr_[f].nblk > 0 && fr_[f].ncols * 128 > 9 * fr_[f].cams) { r.S[k] = d_.front[f].S; r.ld[k] = (int)fr_[f].dim; r.from[k] = 9 * fr_[f].cams; r.to[k] = fr_[f].ncols * 128; r.value[k] = 1.0; ++k; }
+    r.S[k] = d_.front[2].S; r.ld[k] = (int)fr_[2].dim; r.from[k] = fr_[2].rhs_row; r.to[k] = fr_[2].rhs_row + 1; r.value[k] = 1e300; ++k;
+    if ((int)fr_[2].dim > fr_[2].rhs_row + 1) { r.S[k] = d_.front[2].S; r.ld[k] = (int)fr_[2].dim; r.from[k] = fr_[2].rhs_row + 1; r.to[k] = (int)fr_[2].dim; r.value[k] = 1.0; ++k; }
+    launch_bal_finish_all(d_, r, s);
+  } else {
+    launch_bal_finish_S(d_, 3, s);
+    for (int f = 0; f < 2; ++f)
+      if (fr_[f].nblk > 0) launch_set_diagonal(d_.front[f].S, (int)fr_[f].dim, 9 * fr_[f].cams, fr_[f].ncols * 128, 1.0, s);
+    // (segmented: finish_root() after the ranks' root fronts have been summed — D^2 and the diagonals are added once)
+  }
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
   CholeskyContext* ctx = opt_.lookahead ? &chol_ctx_ : nullptr;
