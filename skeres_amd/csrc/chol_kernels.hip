@@ -1965,6 +1965,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   const int maxblk = chain ? ctx->sync_blk : 0;
   const char* stamps_file = chain ? getenv("SK_CHAIN_STAMPS") : nullptr;
   hipStream_t srv = nullptr;
+  hipEvent_t start_ev = nullptr;
   struct PartnerState {
     bool on = false; CholeskyPlan plan; int nblk = 0, ncols = 0, tail0 = 0, start_at = 0, maxblk = 0; const int* last = nullptr;
     double* S = nullptr; long ld = 0; double* Linv = nullptr; int* sync = nullptr; double* xs = nullptr;
@@ -2028,7 +2029,11 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
         partner->taken = true;
       }
     }
-    order(s, srv);
+    // ONE event on the caller's stream for all four queues (the server's here, the others below): each record is a packet of
+    // its own in that queue, in front of everything that follows
+    start_ev = ctx->event(ev++);
+    (void)hipEventRecord(start_ev, s);
+    (void)hipStreamWaitEvent(srv, start_ev, 0);
     if (pb.on) {
       ServerPair sp2;
       sp2.f[0] = ServerArgs{S, ld, ranges, Linv, sync, maxblk};
@@ -2039,8 +2044,10 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk);
     }
   }
-  order(s, sp);
-  if (la) { order(s, ctx->bulk); order(s, ctx->bulk_early); }
+  if (la) {
+    if (!start_ev) { start_ev = ctx->event(ev++); (void)hipEventRecord(start_ev, s); }
+    for (hipStream_t q : {sp, ctx->bulk, ctx->bulk_early}) if (q != s) (void)hipStreamWaitEvent(q, start_ev, 0);
+  }
   if (!is_resident(0) && ncols > 0) panel(gb[0], gb[1]);
   hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
   hipEvent_t syrk_any = nullptr, syrk_done2 = nullptr;  // the completion of the last SYRK launched (whenever it carries an event), and of the one before it
