@@ -359,6 +359,13 @@ def main():
             model_us[k] = solver.stat("model_us_segments_%d" % k)
         except sk.SkeresError:
             model_us[k] = 0.0
+    # (what the model says of THIS run's factorisation: the lock-step dissection of one device where that was taken)
+    model_one = model_us.get(1, 0.0)
+    try:
+        if solver.stat("dissected") == 1.0 and solver.stat("dissection_model_us") > 0.0:
+            model_one = solver.stat("dissection_model_us")
+    except sk.SkeresError:
+        pass
     summary = sk.Solver.Summary()
     solver.finish(summary)
     # Untimed side measurement: the same kernel with the look-ahead off, i.e. alone on the chip.  In the
@@ -487,13 +494,6 @@ def main():
             ph = line["phases_ms_per_step"]
             shard = ph["jacobian_eval"] + ph["schur_assemble"] + ph["back_substitute"] + ph["cost_eval"]
             pred = {}
-            # (what the model says of THIS run's factorisation: the lock-step dissection of one device where that was taken)
-            model_one = model_us[1]
-            try:
-                if solver.stat("dissected") == 1.0 and solver.stat("dissection_model_us") > 0.0:
-                    model_one = solver.stat("dissection_model_us")
-            except Exception:
-                pass
             for n_dev in (2, 4, 8):
                 # the plan a world of n_dev ranks takes by itself (sk_problem_segment_plan, not forced: the rule of a real run — a
                 # third or later segment has to beat the plan so far by 5 % in the model)
