@@ -302,8 +302,10 @@ class BalSolver : public SolverBase {
   hipStream_t zero_stream_ = nullptr;
   hipEvent_t ev_zero_ = nullptr;
   bool zero_pending_ = false;
+  bool pair_claimed_ = false;  // cholesky_claim_pair_servers: this solver may run a partner front's server beside its own
  public:
   ~BalSolver() override {
+    if (pair_claimed_) cholesky_release_pair_servers(&chol_ctx_);
     if (zero_stream_) { (void)hipStreamSynchronize(zero_stream_); (void)hipStreamDestroy(zero_stream_); }
     if (ev_zero_) (void)hipEventDestroy(ev_zero_);
     for (hipGraphExec_t g : {g_step_[0], g_step_[1], g_eval_[0], g_eval_[1]}) if (g) (void)hipGraphExecDestroy(g);
@@ -792,6 +794,10 @@ int BalSolver::setup() {
       // lost its chain, a single device stays undissected)
       const bool lockstep_cut = !multi && auto_single && opt_.dissection == SK_DISSECTION_AUTO && cholesky_chain_enabled(&chol_ctx_);
       ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, lockstep_cut, lockstep_cut);
+      if (lockstep_cut && ds.a > 0) {  // (two resident servers per factorisation: the fifth such solver alive on a device stays undissected)
+        if (!pair_claimed_) pair_claimed_ = cholesky_claim_pair_servers(&chol_ctx_);
+        if (!pair_claimed_) ds.a = ds.b = 0;
+      }
       // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
       // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon there.

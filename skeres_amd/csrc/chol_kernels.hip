@@ -1337,6 +1337,10 @@ struct DeviceQueues {
   int queue_choice = -1;  // -1: not measured yet; else (bulk * kPanelCand + panel) * kServerCand + server
   std::atomic<bool> tuning{false};  // the queue trial of this device is running (under the table's operation mutex)
   std::atomic<int> chain_server{1};   // 0: block columns are factored launch by launch on this device (knob, or a time-out happened)
+  // Solvers on this device that run TWO resident servers per factorisation (a partner front: CholeskyPartner).  There are eight
+  // CU 0s; a pair launch whose first server has one and whose second waits for one holds it while it waits, so more than four
+  // such solvers factoring at once could wait for each other until the chain's time-out: at most four claim the right.
+  std::atomic<int> pair_users{0};
   hipStream_t fork = nullptr;  // stands in for the caller's stream in a secondary context (CholeskyContext::init_secondary)
   hipStream_t plain[2] = {nullptr, nullptr};
   // The panel / bulk / server streams are the DEVICE's: two solvers on one device, driven from two threads, enqueue onto the
@@ -1831,6 +1835,13 @@ void cholesky_disable_chain(CholeskyContext* ctx) {
   ctx->dq->chain_server = 0;
 }
 bool cholesky_chain_enabled(const CholeskyContext* ctx) { return ctx && ctx->dq && ctx->server && ctx->dq->chain_server; }
+bool cholesky_claim_pair_servers(CholeskyContext* ctx) {
+  if (!ctx || !ctx->dq) return false;
+  if (ctx->dq->pair_users.fetch_add(1) < 4) return true;
+  ctx->dq->pair_users.fetch_sub(1);
+  return false;
+}
+void cholesky_release_pair_servers(CholeskyContext* ctx) { if (ctx && ctx->dq) ctx->dq->pair_users.fetch_sub(1); }
 
 // Before the first factorisation with allow_chain on stream s (cholesky_factor does it otherwise): choose the queues.
 // One trial per device, one at a time (two solvers on two threads would otherwise measure each other).

@@ -187,6 +187,9 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
 bool cholesky_note_info(CholeskyContext* ctx, int info);
 bool cholesky_chain_enabled(const CholeskyContext* ctx);
+// the right to run two resident servers per factorisation on this device (a partner front): at most four solvers hold it
+bool cholesky_claim_pair_servers(CholeskyContext* ctx);
+void cholesky_release_pair_servers(CholeskyContext* ctx);
 void cholesky_disable_chain(CholeskyContext* ctx);
 struct CholeskyPlan {
   std::vector<int> bounds;  // group start columns + nblk

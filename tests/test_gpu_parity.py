@@ -860,6 +860,33 @@ def test_dense_schur_without_the_camera_point_structure_uses_its_alternate():
     np.testing.assert_allclose([m1, c1], [0.2915, 0.1314], atol=2e-3)  # m ~ 0.3, c ~ 0.1 (CurveFitting.scala:11-19)
 
 
+def test_at_most_four_solvers_of_a_device_run_two_resident_servers():
+    """A single device dissects the camera sequence and runs the two fronts in one sequence of launches — with TWO resident potrf
+    servers, on two of the eight CU 0s.  More than four such solvers factoring at once could hold one CU 0 each while waiting for
+    a second: the fifth solver alive on a device stays undissected (and gets the right when one of the four goes away)."""
+    prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1))
+    live = []
+    for _ in range(5):
+        problem, params, loss = bal_problem_to_sk(prob)
+        options = sk.Solver.Options()
+        options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+        live.append((sk.StepSolver(options, problem), problem, params))
+    assert [int(s.stat("dissected")) for s, _, _ in live] == [1, 1, 1, 1, 0]
+    for k in (0, 4):  # a dissected one and the undissected one: the same first steps
+        for _ in range(2):
+            live[k][0].step()
+    sa, sb = sk.Solver.Summary(), sk.Solver.Summary()
+    live[0][0].finish(sa); live[4][0].finish(sb)
+    for u, v in zip(sa.iterations(), sb.iterations()):
+        assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
+    del live[0]
+    problem, params, loss = bal_problem_to_sk(prob)
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    again = sk.StepSolver(options, problem)
+    assert int(again.stat("dissected")) == 1
+
+
 def test_schedule_of_the_schur_assembly_does_not_change_a_bit(tmp_path):
     """Round 3 moved work of the Schur assembly around without touching its arithmetic: the envelope of S is zeroed on a
     stream of its own next to the next Jacobian evaluation, and the pair kernels' logical blocks run in groups of eight per
