@@ -466,8 +466,9 @@ def main():
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic() if (args.workload == "ladybug-1723-156502" and args.group <= 0 and not args.full_factorisation) else None,
                          "traffic_note": "bytes/launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled, gfx950; "
-                                         "includes Infinity-Cache hits; SK_CHOL_CHAIN_SERVER=0: the same launches with no resident kernel, "
-                                         "which counter collection would serialise); algorithmic C-tile bytes/launch (each 128x128 tile of "
+                                         "includes Infinity-Cache hits; SK_CHOL_CHAIN_SERVER=0: the same SYRK kernels launch by launch on the UNDISSECTED system — "
+                                         "counter collection serialises kernels, a resident one would wait for ever, and without the resident chain "
+                                         "a single device does not dissect); algorithmic C-tile bytes/launch (each 128x128 tile of "
                                          "the trailing matrix read and written once per launch; K = 256 per launch where the SYRK is the "
                                          "long pole, 128 under the resident panel chain) = %.3e" % (
                                              syrk_c_bytes / max(1, syrk_n // max(1, args.steps))),
