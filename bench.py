@@ -136,11 +136,25 @@ def phase_rooflines(phases_ms, n_obs, envelope_bytes):
 PHASE_NAMES = ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"]
 
 
-def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, world, dist_mod=None, torch=None, long_range_fraction=0.0):
+REVISITS = [(200, 900, 40, 150), (450, 1300, 40, 150), (700, 1600, 40, 150)]  # three places seen twice, 40 cameras and 150 tracks each
+
+
+def all_ranks_ok(ok, world, dist_mod, torch, what):
+    """Failure is collective: every rank learns whether every rank got this far, so that all of them skip a record together
+    instead of one of them leaving the others inside a collective."""
+    if world > 1:
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda")
+        dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MIN)
+        if float(t.item()) < 1.0 and ok:
+            raise RuntimeError("another rank failed at: %s" % what)
+
+
+def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, world, dist_mod=None, torch=None, long_range_fraction=0.0,
+               revisits=(), border=None):
     """One more bundle-adjustment workload of BASELINE.json in the same run (configs[1] BAL-49, configs[3] Venice-1778): `steps`
     LM iterations of the same solve as the headline, timed the same way (barrier + synchronise on both sides, max over
     ranks); with several ranks, the distribution the solver chose, what travels per iteration and how long it takes."""
-    prob = bal.generate_named(name, seed=seed, perturb=PERTURB, long_range_fraction=long_range_fraction)
+    prob = bal.generate_named(name, seed=seed, perturb=PERTURB, long_range_fraction=long_range_fraction, revisits=revisits)
     problem, params, loss = build_problem(sk, prob)
     o = sk.Solver.Options()
     o.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
@@ -150,13 +164,23 @@ def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, wor
     o.setParameterTolerance(0.0)
     o.setDevice(local_rank)
     o.setStream(stream.cuda_stream)
+    if border is not None:
+        o.setCholeskyBorder(border)
     hook = None
-    if world > 1:
-        from skeres_amd import dist as sk_dist
-        hook = sk_dist.attach(o, problem, rank, world)
-    solver = sk.StepSolver(o, problem)
+    solver, err = None, None
+    try:
+        if world > 1:
+            from skeres_amd import dist as sk_dist
+            hook = sk_dist.attach(o, problem, rank, world)
+        solver = sk.StepSolver(o, problem)
+    except Exception as e:  # noqa: BLE001
+        err = e
+    all_ranks_ok(err is None, world, dist_mod, torch, "set-up of %s" % name)
+    if err is not None:
+        raise err
     mode = solver.distribution()[0] if world > 1 else "single"
-    stats = {k: solver.stat(k) for k in ("envelope_fill", "allreduce_bytes", "segments", "cholesky_flops_plan")}
+    stats = {k: solver.stat(k) for k in ("envelope_fill", "allreduce_bytes", "segments", "cholesky_flops_plan", "border_cameras", "border_model_us",
+                                         "border_model_us_plain", "cholesky_columns_resident", "dissected")}
     for _ in range(warmup):
         solver.step()
     torch.cuda.synchronize()
@@ -184,14 +208,19 @@ def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, wor
     its = summ.iterations()
     phases = {k: 1e3 * summ.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(PHASE_NAMES)}
     chol_s = phases["cholesky"] * 1e-3
-    rec = {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d%s), DENSE_SCHUR" % (
-               name, prob.num_cameras, prob.num_points, prob.num_observations, seed, ", long_range_fraction %g" % long_range_fraction if long_range_fraction else ""),
+    rec = {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d%s%s), DENSE_SCHUR" % (
+               name, prob.num_cameras, prob.num_points, prob.num_observations, seed, ", long_range_fraction %g" % long_range_fraction if long_range_fraction else "",
+               ", revisits (first camera a, first camera b, cameras, tracks) %s" % (list(revisits),) if revisits else ""),
            "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "iterations_per_second": steps / elapsed,
            "phases_ms_per_step": phases, "envelope_fill": stats["envelope_fill"],
            "roofline_cholesky_phase": {"bound": "mfma", "flops": stats["cholesky_flops_plan"], "achieved": stats["cholesky_flops_plan"] / chol_s * 1e-12 if chol_s > 0 else None,
                                        "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": stats["cholesky_flops_plan"] / chol_s * 1e-12 / FP64_MFMA_PEAK_TFLOPS if chol_s > 0 else None},
            "costs": [its[0]["cost"], its[-1]["cost"]]}
+    if revisits or long_range_fraction:
+        rec["border"] = {"mode": border or "auto", "cameras": int(stats["border_cameras"]), "chain_model_us": stats["border_model_us"],
+                         "chain_model_us_plain_order": stats["border_model_us_plain"], "block_columns_resident": int(stats["cholesky_columns_resident"]),
+                         "dissected": int(stats["dissected"])}
     if world > 1:
         rec["distribution"] = {"mode": mode, "segments": int(stats["segments"]), "allreduce_bytes_per_iteration": stats["allreduce_bytes"],
                                "allreduce_ms_per_step": phases["allreduce"]}
@@ -224,7 +253,14 @@ def c5_record(sk, m=1000000, n=10000, iters=2, seed=5, rank=0, world=1, stream=N
         o.setStream(stream.cuda_stream)
         hook = sk_dist.TorchAllReduce()
         o.setDistributed(rank, world, hook)
-    s = sk.StepSolver(o, problem)
+    s, err = None, None
+    try:
+        s = sk.StepSolver(o, problem)
+    except Exception as e:  # noqa: BLE001 (e.g. not enough free HBM for this rank's rows of the Jacobian on a shared device)
+        err = e
+    all_ranks_ok(err is None, world, dist_mod, torch, "set-up of the dense-rows problem")
+    if err is not None:
+        raise err
     s.setKernelTiming(1)
     if world > 1:
         torch.cuda.synchronize()
@@ -290,13 +326,31 @@ def main():
     backend = os.environ.get("SK_BENCH_DIST_BACKEND", "nccl")
     if "SK_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["SK_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+    def fail(stage, e):
+        """One JSON line the driver can parse instead of a traceback, and a non-zero exit code (a plain exit: never a re-exec)."""
+        if rank == 0:
+            print(json.dumps({"metric": "LM iterations/sec", "value": None, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "error": "%s: %s: %s" % (stage, type(e).__name__, e)}), flush=True)
+        sys.stderr.write("[bench] rank %d failed at %s: %r\n" % (rank, stage, e))
+        sys.stderr.flush()
+        os._exit(3)
+
+    try:
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            # the first collective is where a communicator really comes up (RCCL connects lazily): do it here, where a failure is reported as one
+            probe = torch.ones(1, dtype=torch.float64, device="cuda")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("the first all-reduce over %d ranks returned %r" % (world, probe.item()))
+    except Exception as e:  # noqa: BLE001
+        fail("process group (%s, %d ranks)" % (backend, world), e)
 
     import skeres_amd as sk
     from skeres_amd import bal
@@ -324,7 +378,10 @@ def main():
         from skeres_amd import dist as sk_dist
         hook = sk_dist.attach(options, problem, rank, world)  # reduce buffer + all-reduce hook over torch.distributed (RCCL)
 
-    solver = sk.StepSolver(options, problem)  # uploads the shard, builds the pair lists, runs iteration 0
+    try:
+        solver = sk.StepSolver(options, problem)  # uploads the shard, builds the pair lists, runs iteration 0 (several ranks: the first calls of the all-reduce hook)
+    except Exception as e:  # noqa: BLE001
+        fail("solver set-up", e)
     dist_mode, t_allreduce, t_saved = solver.distribution() if world > 1 else ("single", 0.0, 0.0)
     allreduce_mb = solver.stat("allreduce_bytes") / 1e6 if world > 1 else 0.0
     for _ in range(args.warmup):
@@ -407,32 +464,7 @@ def main():
     its = summary.iterations()
     timed = its[1 + args.warmup: 1 + args.warmup + args.steps]
     n_success = int(sum(it["step_is_successful"] for it in timed))
-    # ---- the other configurations of BASELINE.json in the same run (every rank takes part; rank 0 reports).  None of them may
-    # cost the headline its line: whatever goes wrong in one is recorded in its place. ----
-    extra = {}
-    if not args.no_alone and args.workload == "ladybug-1723-156502":
-        try:
-            del solver
-        except NameError:
-            pass
-        dist_mod = dist if world > 1 else None
-
-        def record(key, fn):
-            try:
-                extra[key] = fn()
-            except Exception as e:  # noqa: BLE001 (e.g. not enough free HBM for the 80 GB Jacobian on a shared device)
-                extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if world == 1:
-            record("c2", lambda: bal_record(sk, bal, "problem-49-7776", 49, 20, 2, local_rank, stream, rank, world, dist_mod, torch))
-        record("c4" if world == 1 else "venice",
-               lambda: bal_record(sk, bal, "venice-1778-993923", 1778, 10, 2, local_rank, stream, rank, world, dist_mod, torch))
-        if world == 1:
-            # what the headline rests on: the same problem with 0.5 % of the tracks seen from two distant windows (loop closures:
-            # the envelope of the reduced system fills up and the block-envelope factorisation has no zeros left to skip)
-            record("loop_closures", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 6, 2, local_rank, stream, rank, world, dist_mod, torch,
-                                                       long_range_fraction=0.005))
-        if not args.no_c5:
-            record("c5", lambda: c5_record(sk, rank=rank, world=world, stream=stream, torch=torch, dist_mod=dist_mod))
+    line = None
     if rank == 0:
         achieved = (syrk_flops * args.steps) / syrk_s * 1e-12 if syrk_s > 0 else 0.0
         line = {
@@ -527,8 +559,63 @@ def main():
             line["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, envelope=not args.full_factorisation, full_iters=args.cpu_full_iters)
         elif world == 1:
             line["cpu_baseline"] = None
-        line.update(extra)
-        print(json.dumps(line), flush=True)
+    # The headline is complete here.  The other configurations below run on every rank and use collectives: should one of them
+    # hang (a rank that died inside a collective), every rank's watchdog ends the run after SK_BENCH_EXTRAS_TIMEOUT seconds and
+    # rank 0 prints the headline as it stands — an extra configuration may not cost the headline its line.
+    import threading
+    printed = threading.Lock()
+
+    def emit(extra_records):
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            line.update(extra_records)
+            print(json.dumps(line), flush=True)
+
+    def watchdog():
+        emit({"extras_error": "the extra configurations did not finish within %s s; the headline above them is complete" % timeout_s})
+        os._exit(0)
+    timeout_s = float(os.environ.get("SK_BENCH_EXTRAS_TIMEOUT", "900"))
+    timer = None
+    if world > 1:
+        timer = threading.Timer(timeout_s, watchdog)
+        timer.daemon = True
+        timer.start()
+    # ---- the other configurations of BASELINE.json in the same run (every rank takes part; rank 0 reports).  None of them may
+    # cost the headline its line: whatever goes wrong in one is recorded in its place. ----
+    extra = {}
+    if not args.no_alone and args.workload == "ladybug-1723-156502":
+        try:
+            del solver
+        except NameError:
+            pass
+        dist_mod = dist if world > 1 else None
+
+        def record(key, fn):
+            try:
+                extra[key] = fn()
+            except Exception as e:  # noqa: BLE001 (e.g. not enough free HBM for the 80 GB Jacobian on a shared device)
+                extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1:
+            record("c2", lambda: bal_record(sk, bal, "problem-49-7776", 49, 20, 2, local_rank, stream, rank, world, dist_mod, torch))
+        record("c4" if world == 1 else "venice",
+               lambda: bal_record(sk, bal, "venice-1778-993923", 1778, 10, 2, local_rank, stream, rank, world, dist_mod, torch))
+        if world == 1:
+            # what the headline rests on: the same problem with 0.5 % of the tracks seen from two distant windows (loop closures:
+            # the envelope of the reduced system fills up and the block-envelope factorisation has no zeros left to skip)
+            record("loop_closures", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 6, 2, local_rank, stream, rank, world, dist_mod, torch,
+                                                       long_range_fraction=0.005))
+            # ... and with LOCALISED loop closures — three places seen twice, as a real sequence revisits streets: the revisiting
+            # cameras are ordered into a trailing border of the reduced system (sk_options_set_cholesky_border, AUTO: the chain
+            # model's choice), and beside it the same problem in the band's own order (border off)
+            record("revisits", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 10, 2, local_rank, stream, rank, world, dist_mod, torch, revisits=REVISITS))
+            record("revisits_plain_order", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 6, 2, local_rank, stream, rank, world, dist_mod, torch,
+                                                              revisits=REVISITS, border="off"))
+        if not args.no_c5:
+            record("c5", lambda: c5_record(sk, rank=rank, world=world, stream=stream, torch=torch, dist_mod=dist_mod))
+    if timer:
+        timer.cancel()
+    emit(extra)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -105,6 +105,7 @@ public final class SkeresNative {
   public static native int skOptionsSetDevice(long o, int v);
   public static native int skOptionsSetCholeskyEnvelope(long o, int v);
   public static native int skOptionsSetCholeskyDissection(long o, int v);
+  public static native int skOptionsSetCholeskyBorder(long o, int v);
   public static native int skOptionsSetDistributionMode(long o, int v);
   public static native int skOptionsSetCholeskyTuning(long o, int group, int lookahead);
   public static native byte[] skRcclUniqueId();

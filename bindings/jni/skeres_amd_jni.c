@@ -288,6 +288,7 @@ SK_OPT_INT(skOptionsSetMaxNumConsecutiveInvalidSteps, sk_options_set_max_num_con
 SK_OPT_INT(skOptionsSetDevice, sk_options_set_device)
 SK_OPT_INT(skOptionsSetCholeskyEnvelope, sk_options_set_cholesky_envelope)
 SK_OPT_INT(skOptionsSetCholeskyDissection, sk_options_set_cholesky_dissection)
+SK_OPT_INT(skOptionsSetCholeskyBorder, sk_options_set_cholesky_border)
 SK_OPT_INT(skOptionsSetDistributionMode, sk_options_set_distribution_mode)
 SK_JNI(jint, skOptionsSetCholeskyTuning)(JNIEnv* env, jclass c, jlong o, jint group, jint lookahead) { (void)c; return check(env, sk_options_set_cholesky_tuning(PTR(sk_options, o), group, lookahead)); }
 /* multi-GPU from the JVM: the library's own RCCL hook (no collective to write on the JVM side) */

@@ -350,6 +350,17 @@ int sk_options_set_cholesky_envelope(sk_options* o, int on);
  * prediction is reported by sk_solver_stat. */
 enum { SK_DISSECTION_AUTO = 0, SK_DISSECTION_ON = 1, SK_DISSECTION_OFF = 2 };
 int sk_options_set_cholesky_dissection(sk_options* o, int mode);
+/* DENSE_SCHUR: loop closures.  A camera sequence that revisits a place couples two distant windows of the band, and in
+ * the band's own order every block column between the two windows joins the envelope.  The solver may instead number
+ * the revisiting cameras BEHIND the band, as a border whose block rows are active from the first block column that
+ * reaches them (and whose own block columns are factored last): the band keeps its width.  The result of the solve
+ * does not depend on the order of the cameras inside the reduced system (Ceres' DENSE_SCHUR,
+ * examples/.../SimpleBundleAdjuster.scala:147-152, orders it itself); another elimination order agrees to rounding,
+ * not bit for bit.  AUTO (default): when the model of the factorisation's serial chain predicts a gain of 10 %;
+ * ON: whenever the camera lists of the points show visits (jumps in the camera sequence) — tests, small problems;
+ * OFF: never.  sk_solver_stat: "border_cameras", "border_gap", "border_model_us", "border_model_us_plain". */
+enum { SK_BORDER_AUTO = 0, SK_BORDER_ON = 1, SK_BORDER_OFF = 2 };
+int sk_options_set_cholesky_border(sk_options* o, int mode);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,
  * one per GPU.  Points (e-blocks) are partitioned over ranks; the
  * normal-equation terms are summed with `allreduce` once per linear solve.
@@ -490,6 +501,14 @@ int sk_problem_point_partition(const sk_problem* p, int world, int* cuts, int* n
  * choice).  No point is seen from two segments; a point's blocks all have one owner. */
 int sk_problem_segment_plan(const sk_problem* p, int max_segments, int forced, int* num_segments, int* camera_part_of_block,
                             int* point_owner_of_block);
+/* The order of the cameras inside the reduced system, and the border of loop-closure cameras (sk_options_set_cholesky_border),
+ * as one process derives them at set-up — from host data alone, no device needed.  *num_border_cameras: cameras ordered into
+ * the trailing border (0: none); camera_position_of_block[b] (may be NULL): position of residual block b's camera in the
+ * reduced system (border cameras: the last *num_border_cameras positions); gap: the jump in a point's camera list that
+ * separated visits; model_us / model_us_plain: the chain model's microseconds per factorisation with the order chosen /
+ * with the best unbordered order; envelope_fill: 128-blocks inside the envelope over the lower block triangle. */
+int sk_problem_border_plan(const sk_problem* p, int mode, int* num_border_cameras, int* camera_position_of_block, int* gap,
+                           double* model_us, double* model_us_plain, double* envelope_fill);
 
 /* ---- inputs of BASELINE.json config 5 (utility) ----------------------------------
  * y_out[i] = tanh(a_i . x_star) for the generated rows a_i of SK_FUNCTOR_SYNTH_TANH_ROW
@@ -513,6 +532,12 @@ int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double
  * explicit `group`, launch by launch.  Known-answer tests of the plans sk_solve runs at full size. */
 int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, double* L, int group, const int* last,
                          int automatic_plan);
+/* ... and with a BORDER (sk_options_set_cholesky_border): rows from border_begin_row on are the border — they may couple
+ * with any column before them — and the rows before it a block-banded matrix.  The bordered block envelope is derived
+ * from A's own non-zero 128-blocks: per block column the run of the band, and the border's block rows from the first
+ * block column that reaches them (a border row, once reached, stays active, and so does every border row behind it). */
+int sk_cholesky_solve_bordered(int n, const double* A, const double* b, double* x, double* L, int group,
+                               int border_begin_row, int automatic_plan);
 
 /* The same system solved by two-way dissection (what DENSE_SCHUR does with the reduced camera system of a camera
  * sequence when that pays — DESIGN.md section 4): rows [0, head) are eliminated front to back, rows [tail_begin, n) back

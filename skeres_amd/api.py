@@ -149,9 +149,12 @@ _SIGS = {
     "sk_allreduce_rccl_fn": (C.c_void_p, []),
     "sk_cholesky_solve_segments": (C.c_int, [C.c_int, _dp, _dp, _dp, C.c_int, _ip, C.c_int, C.c_int]),
     "sk_cholesky_solve_ex": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, _ip, C.c_int]),
+    "sk_problem_border_plan": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), _ip, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sk_cholesky_solve_bordered": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int]),
     "sk_options_set_distribution_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_dissection": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_cholesky_border": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
     "sk_synth_dense_targets": (C.c_int, [C.c_double, C.c_int, C.c_int, _dp, _dp]),
     "sk_problem_point_partition": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip]),
@@ -1052,6 +1055,19 @@ class Problem:
         _check(lib().sk_problem_segment_plan(self._h, int(max_segments), int(bool(forced)), C.byref(n), part.ctypes.data_as(_ip), owner.ctypes.data_as(_ip)))
         return n.value, part, owner
 
+    def borderPlan(self, mode="auto"):
+        """The camera order of the reduced system and the border of loop-closure cameras as set-up derives them
+        (sk_problem_border_plan; host logic, no device needed): a dict with border_cameras, position (of every residual
+        block's camera inside the reduced system), gap, model_us, model_us_plain, envelope_fill."""
+        mode = {"auto": 0, "on": 1, "off": 2}.get(mode, mode)
+        nb = self.numResidualBlocks()
+        n, gap = C.c_int(0), C.c_int(0)
+        pos = np.zeros(nb, dtype=np.int32)
+        us, us_plain, fill = C.c_double(0), C.c_double(0), C.c_double(0)
+        _check(lib().sk_problem_border_plan(self._h, int(mode), C.byref(n), pos.ctypes.data_as(_ip), C.byref(gap), C.byref(us), C.byref(us_plain), C.byref(fill)))
+        return {"border_cameras": n.value, "position": pos, "gap": gap.value, "model_us": us.value, "model_us_plain": us_plain.value,
+                "envelope_fill": fill.value}
+
     def pointPartition(self, world):
         """(cuts[world+1], num_cameras, num_points, point_of_block[num residual blocks]):
         how sk_solve shards this problem over `world` ranks (host logic only)."""
@@ -1142,6 +1158,11 @@ class Solver:
             """DENSE_SCHUR: two-way dissection of the camera sequence: "auto" (default) / "on" / "off" (or 0 / 1 / 2)."""
             mode = {"auto": 0, "on": 1, "off": 2}.get(mode, mode)
             _check(lib().sk_options_set_cholesky_dissection(self._h, int(mode)))
+
+        def setCholeskyBorder(self, mode):
+            """DENSE_SCHUR: loop-closure cameras ordered into a trailing border: "auto" (default) / "on" / "off" (or 0 / 1 / 2)."""
+            mode = {"auto": 0, "on": 1, "off": 2}.get(mode, mode)
+            _check(lib().sk_options_set_cholesky_border(self._h, int(mode)))
 
         def setDistributionMode(self, mode):
             """0 auto (default), 1 sharded, 2 replicated: what a world > 1 does (include/skeres_amd.h)."""
@@ -1257,6 +1278,19 @@ def cholesky_solve(A, b, want_L=False, group=0, last=None, automatic_plan=False)
         lp = last.ctypes.data_as(_ip)
     _check(lib().sk_cholesky_solve_ex(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp),
                                       L.ctypes.data_as(_dp) if want_L else _dp(), int(group), lp, int(bool(automatic_plan))))
+    return (x, L) if want_L else x
+
+
+def cholesky_solve_bordered(A, b, border_begin, want_L=False, group=0, automatic_plan=False):
+    """Dense SPD solve on the GPU with a bordered block envelope (sk_cholesky_solve_bordered): rows from `border_begin` on are
+    the border (they may couple with any column), the rows before it a block-banded matrix; the envelope is A's own."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    n = A.shape[0]
+    x = np.empty(n)
+    L = np.empty((n, n)) if want_L else None
+    _check(lib().sk_cholesky_solve_bordered(n, A.ctypes.data_as(_dp), b.ctypes.data_as(_dp), x.ctypes.data_as(_dp),
+                                            L.ctypes.data_as(_dp) if want_L else _dp(), int(group), int(border_begin), int(bool(automatic_plan))))
     return (x, L) if want_L else x
 
 

@@ -88,7 +88,7 @@ def snavely_project(cameras, points):
 
 
 def generate(num_cameras, num_points, num_observations, seed=1723, sigma_px=0.5,
-             perturb=(1e-2, 1e-1, 1e-1), long_range_fraction=0.0):
+             perturb=(1e-2, 1e-1, 1e-1), long_range_fraction=0.0, revisits=()):
     """Seeded synthetic BAL problem with exactly the requested shape.
 
     Cameras sit on a noisy trajectory along +x looking down -z at a slab of
@@ -104,6 +104,13 @@ def generate(num_cameras, num_points, num_observations, seed=1723, sigma_px=0.5,
     far-apart groups of cameras, which is what widens the envelope of the reduced camera system; the sensitivity of
     the factorisation to it is reported in profiles/ (tools/envelope_sensitivity.py).  0 leaves the problem exactly
     as it was (the extra draws come from a generator of their own).
+
+    ``revisits`` (LOCALISED loop closures): ``[(first_a, first_b, width, tracks), ...]`` — the trajectory comes back, with
+    the ``width`` cameras from ``first_b`` on, to the place the ``width`` cameras from ``first_a`` on have seen: ``tracks``
+    of the short tracks that lie inside window a keep the first half of their cameras there and have the second half
+    moved to the same offsets inside window b (a street driven twice; real sequences revisit a few places, they do not
+    scatter tracks over the whole trajectory as ``long_range_fraction`` does).  Shapes (C, P, N and every track length)
+    stay exactly what they were.
     """
     C, P, N = int(num_cameras), int(num_points), int(num_observations)
     if N < 2 * P:
@@ -185,6 +192,22 @@ def generate(num_cameras, num_points, num_observations, seed=1723, sigma_px=0.5,
             t = int(u[p] * (len_l + len_r))
             base2 = t if t < len_l else hi + 1 + (t - len_l)
             cam_idx[h:b] = base2 + off
+    for ri, (first_a, first_b, width, tracks) in enumerate(revisits):
+        first_a, first_b, width, tracks = int(first_a), int(first_b), int(width), int(tracks)
+        if not (0 <= first_a and first_a + width <= C and 0 <= first_b and first_b + width <= C and width >= 2):
+            raise ValueError("revisit %d: windows must lie inside the trajectory" % ri)
+        if abs(first_a - first_b) < width:
+            raise ValueError("revisit %d: the two windows overlap" % ri)
+        rng_rv = np.random.default_rng([seed, 0x7e15, ri])
+        lo = cam_idx[pt_start[:-1]]
+        hi = cam_idx[pt_start[1:] - 1]
+        inside = np.flatnonzero((lo >= first_a) & (hi < first_a + width) & (k >= 2))
+        if inside.size < tracks:
+            raise ValueError("revisit %d: only %d tracks lie inside window a" % (ri, inside.size))
+        for p in np.sort(rng_rv.choice(inside, size=tracks, replace=False)):
+            a, b = int(pt_start[p]), int(pt_start[p + 1])
+            h = a + (b - a + 1) // 2                 # second half: observations [h, b)
+            cam_idx[h:b] = cam_idx[h:b] - first_a + first_b
     pt_idx = np.repeat(np.arange(P, dtype=np.int64), k)
 
     # points near the centroid of their cameras' x positions

@@ -118,14 +118,14 @@ class BalSolver : public SolverBase {
   // over the fronts of the reduced system (one when it is not dissected); the tail front is factored launch by launch
   double syrk_flops_per_solve() const override {
     double f = 0.0;
-    for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && (k != 1 || tail_chain()), nullptr, fr_[k].ncols, fr_[k].tail_rows);
+    for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && (k != 1 || tail_chain()), nullptr, fr_[k].ncols, fr_[k].tail_rows, fr_[k].tl());
     return f;
   }
   double syrk_c_bytes_per_solve() const override {
     double tiles = 0.0;
     for (int k = 0; k < 3; ++k) {
       double t = 0.0;
-      if (fr_[k].nblk > 0) (void)cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && (k != 1 || tail_chain()), &t, fr_[k].ncols, fr_[k].tail_rows);
+      if (fr_[k].nblk > 0) (void)cholesky_syrk_flops((int)fr_[k].dim, group_, fr_[k].env(), chain_ok() && (k != 1 || tail_chain()), &t, fr_[k].ncols, fr_[k].tail_rows, fr_[k].tl());
       tiles += t;
     }
     return tiles * 2.0 * 128.0 * 128.0 * sizeof(double);
@@ -148,7 +148,8 @@ class BalSolver : public SolverBase {
         const int* env = F.env();
         for (int c = 0; c < F.ncols; ++c) {
           const int lm = env ? std::min(env[c], F.nblk - 1) : F.nblk - 1;
-          in += (lm - c + 1) + std::max(0, F.nblk - std::max(F.nblk - F.tail_rows, lm + 1));  // the run from the diagonal block down, and the tail rows (right-hand side)
+          const int t0 = F.tl() ? F.tl()[c] : F.nblk - F.tail_rows;
+          in += (lm - c + 1) + std::max(0, F.nblk - std::max(t0, lm + 1));  // the run from the diagonal block down, and the tail rows (right-hand side; a border)
         }
       }
       *value = in / (0.5 * nblk * (nblk + 1.0));
@@ -158,7 +159,7 @@ class BalSolver : public SolverBase {
     if (name == "cholesky_flops_full") { const double n = 9.0 * C_; *value = n * n * n / 3.0; return true; }
     if (name == "cholesky_flops_plan") {
       double f = 0.0;
-      for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_plan_flops(fr_[k].nblk, fr_[k].env(), fr_[k].ncols, fr_[k].tail_rows);
+      for (int k = 0; k < 3; ++k) if (fr_[k].nblk > 0) f += cholesky_plan_flops(fr_[k].nblk, fr_[k].env(), fr_[k].ncols, fr_[k].tail_rows, fr_[k].tl());
       *value = f;
       return true;
     }
@@ -166,7 +167,7 @@ class BalSolver : public SolverBase {
       int r = 0;
       for (int k = 0; k < 3; ++k) {
         if (fr_[k].nblk == 0) continue;
-        const CholeskyPlan plan = cholesky_plan(fr_[k].nblk, group_, fr_[k].env(), chain_live() && (k != 1 || tail_chain()), fr_[k].ncols, fr_[k].tail_rows);
+        const CholeskyPlan plan = cholesky_plan(fr_[k].nblk, group_, fr_[k].env(), chain_live() && (k != 1 || tail_chain()), fr_[k].ncols, fr_[k].tail_rows, fr_[k].tl());
         for (char c : plan.resident) r += c ? 1 : 0;
       }
       *value = r;
@@ -175,6 +176,10 @@ class BalSolver : public SolverBase {
     if (name == "allreduce_bytes") { *value = (double)packed_elems_ * sizeof(double); return true; }
     if (name == "allreduce_bytes_full_triangle") { *value = (double)tri_packed_elems(nblk) * sizeof(double); return true; }
     if (name == "dissected") { *value = dissected_ ? 1.0 : 0.0; return true; }
+    if (name == "border_cameras") { *value = border_cams_; return true; }
+    if (name == "border_gap") { *value = border_gap_; return true; }
+    if (name == "border_model_us") { *value = border_model_us_; return true; }
+    if (name == "border_model_us_plain") { *value = border_plain_us_; return true; }
     if (name == "segments") { *value = segmented_ ? segments_ : (dissected_ ? 2 : 1); return true; }
     if (name == "segment_cameras") { *value = segmented_ ? my_hi_ - my_lo_ : C_; return true; }
     if (name.rfind("model_us_segments_", 0) == 0) { const int k = atoi(name.c_str() + 18); if (k < 1 || k > 8) return false; *value = model_us_[k]; return true; }
@@ -237,6 +242,9 @@ class BalSolver : public SolverBase {
   DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
       b_r_, b_F_, b_Fcam_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
+  std::vector<int> env_tail_;  // ... and its tail profile when loop-closure cameras are ordered into a trailing border (choose_border); empty = none
+  int border_cams_ = 0, border_gap_ = 0;          // cameras in that border; the jump in a point's camera list that made a visit
+  double border_model_us_ = 0.0, border_plain_us_ = 0.0;
   // The reduced camera system as fronts (BalDev::front): 0 head, 1 tail, 2 root.  Not dissected: only the root, which is
   // then the whole system.  Each front is a dense dim x dim matrix inside b_S_.
   struct FrontHost {
@@ -245,7 +253,9 @@ class BalSolver : public SolverBase {
     int rhs_row = 0;
     int tail_rows = 1;                   // block rows at the end that every column reaches (cholesky_plan): > 1 for a segment between two separators
     std::vector<int> last;               // block envelope (empty: dense)
+    std::vector<int> tail;               // tail profile of a bordered envelope (cholesky_factor; empty: the uniform tail_rows)
     const int* env() const { return last.empty() ? nullptr : last.data(); }
+    const int* tl() const { return tail.empty() ? nullptr : tail.data(); }
   };
   FrontHost fr_[3];
   bool dissected_ = false;
@@ -615,6 +625,148 @@ static void choose_camera_order(const std::vector<std::vector<int>>& cand, const
   *best_flops = best;
 }
 
+// ---- loop closures: the cameras that revisit a place, ordered into a trailing BORDER (round 4) ------------------------------
+// A camera sequence that comes back to a street it has seen couples two distant windows of the band: in the band's own
+// order every block column between the two windows is dragged into the envelope (a handful of such tracks fill it: 0.37 ->
+// 0.99 of the blocks on the Ladybug-shaped problem).  Numbered BEHIND the band instead, the revisiting cameras are border
+// rows — "rows active in every column from the column that first reaches them", the tail profile of cholesky_factor — the
+// band keeps its width, and the border's own few block columns are factored last.  Which cameras: in a point's ascending
+// camera list a jump of more than `gap` cameras separates visits; the cameras of the later visits (or, the other variant,
+// of all visits but the last) go to the border.  Which gap and variant, and whether at all: the chain model of
+// choose_dissection (microseconds per block column), over a few gaps; the border is taken when it predicts 10 % less than
+// the band's own envelope.  A result of the solve does not depend on the order (EX/SimpleBundleAdjuster.scala:147-152: DENSE_SCHUR
+// of Ceres orders its reduced system itself); tests hold the bordered order against the plain one and the oracle.
+struct BorderChoice {
+  std::vector<int> new_id;        // banded numbering -> final numbering (band cameras in order, then the border)
+  std::vector<int> last, tail;    // bordered envelope (cholesky_envelope_bordered)
+  int border_cams = 0, gap = 0, variant = 0;
+  double model_us = 0.0, plain_us = 0.0;
+};
+static double envelope_model_us(int nblk, const std::vector<int>& last, const int* tail) {
+  double t = 0.0;
+  for (int c = 0; c < nblk; ++c) {
+    const int lm = std::min(last[c], nblk - 1);
+    const int main_rows = lm > c ? lm - c : 0;
+    const int t0 = tail ? tail[c] : nblk - 1;
+    const int h = main_rows + std::max(0, nblk - std::max(t0, c + 1 + main_rows));
+    t += column_cost_us(h, true);
+  }
+  return t;
+}
+// ocam: cameras in the banded numbering.  mode: SK_BORDER_AUTO (the model decides) / SK_BORDER_ON (the best candidate whatever the model says).
+static bool choose_border(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& plain_last, int mode,
+                          BorderChoice* out) {
+  out->plain_us = envelope_model_us(nblk, plain_last, nullptr);
+  if (C < 8) return false;
+  // cameras of every point, ascending
+  std::vector<int> pstart(P + 1, 0), pcam(ocam.size());
+  for (int q : opt) pstart[q + 1]++;
+  for (int q = 0; q < P; ++q) pstart[q + 1] += pstart[q];
+  { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (size_t b = 0; b < ocam.size(); ++b) pcam[fill[opt[b]]++] = ocam[b]; }
+  int max_jump = 0;
+  for (int q = 0; q < P; ++q) {
+    std::sort(pcam.begin() + pstart[q], pcam.begin() + pstart[q + 1]);
+    for (int k = pstart[q] + 1; k < pstart[q + 1]; ++k) max_jump = std::max(max_jump, pcam[k] - pcam[k - 1]);
+  }
+  bool found = false;
+  double best = mode == SK_BORDER_ON ? std::numeric_limits<double>::max() : 0.9 * out->plain_us;
+  std::vector<char> prev_mark;
+  for (int gap = 4; gap < C && gap < max_jump; gap *= 2) {
+    for (int variant = 0; variant < 2; ++variant) {
+      std::vector<char> mark(C, 0);
+      int nb = 0;
+      for (int q = 0; q < P; ++q) {
+        const int a = pstart[q], e = pstart[q + 1];
+        if (variant == 0) {  // everything behind the first jump
+          int k = a + 1;
+          while (k < e && pcam[k] - pcam[k - 1] <= gap) ++k;
+          for (; k < e; ++k) if (!mark[pcam[k]]) { mark[pcam[k]] = 1; ++nb; }
+        } else {             // everything before the last jump
+          int k = e - 1;
+          while (k > a && pcam[k] - pcam[k - 1] <= gap) --k;
+          for (int i = a; i < k; ++i) if (!mark[pcam[i]]) { mark[pcam[i]] = 1; ++nb; }
+        }
+      }
+      if (nb == 0 || nb > C / 4 || C - nb < 4) continue;   // (a border that wide is no border: its dense system would be the factorisation)
+      if (mark == prev_mark) continue;
+      prev_mark = mark;
+      // first band camera each border camera couples with (through any of its points): the border is ordered so that the
+      // cameras reached first come LAST — a column's tail rows are a suffix of the matrix
+      std::vector<int> band_id(C, -1);
+      int Cb = 0;
+      for (int c = 0; c < C; ++c) if (!mark[c]) band_id[c] = Cb++;
+      std::vector<int> first_band(C, C);
+      for (int q = 0; q < P; ++q) {
+        int mn = C;
+        for (int k = pstart[q]; k < pstart[q + 1]; ++k) if (!mark[pcam[k]]) { mn = band_id[pcam[k]]; break; }
+        for (int k = pstart[q]; k < pstart[q + 1]; ++k) if (mark[pcam[k]]) first_band[pcam[k]] = std::min(first_band[pcam[k]], mn);
+      }
+      std::vector<int> border;
+      for (int c = 0; c < C; ++c) if (mark[c]) border.push_back(c);
+      std::stable_sort(border.begin(), border.end(), [&](int x, int y) { return first_band[x] > first_band[y]; });
+      BorderChoice cand;
+      cand.new_id = band_id;
+      for (size_t k = 0; k < border.size(); ++k) cand.new_id[border[k]] = Cb + (int)k;
+      std::vector<int> first_col;
+      (void)envelope_of_order(ocam, opt, cand.new_id, C, P, nblk, &first_col);
+      cholesky_envelope_bordered(first_col, (9 * Cb) / 128, &cand.last, &cand.tail);
+      cand.model_us = envelope_model_us(nblk, cand.last, cand.tail.data());
+      cand.border_cams = nb; cand.gap = gap; cand.variant = variant; cand.plain_us = out->plain_us;
+      if (cand.model_us < best) { best = cand.model_us; *out = cand; found = true; }
+    }
+  }
+  return found;
+}
+
+// The order of the cameras inside the reduced system as setup() takes it: the candidate with the fewest trailing-update flops,
+// or a bordered variant of one of the candidates when the chain model prefers it.  From host data alone.
+struct CameraOrderPlan {
+  std::vector<int> id;           // first-appearance numbering -> final numbering
+  std::vector<int> last, tail;   // the envelope of the reduced system in that numbering (tail: empty unless bordered)
+  int candidate = 0;             // 0 first appearance, 1 memory order, 2 RCM
+  bool bordered = false;
+  BorderChoice border;
+  double flops = 0.0;            // trailing-update flops of the envelope
+};
+static CameraOrderPlan plan_camera_order(const Problem& p, const std::vector<int>& cam_block, const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P,
+                                         int npad, bool with_memory_order, bool border_ok, int border_mode) {
+  CameraOrderPlan out;
+  const int nblk = npad / 128;
+  const std::vector<std::vector<int>> cand = camera_order_candidates(p, cam_block, ocam, opt, C, P, with_memory_order);
+  std::vector<int> best_env;
+  int best_k = 0;
+  double best = 0.0;
+  choose_camera_order(cand, ocam, opt, C, P, npad, &best_k, &best_env, &best);
+  if (border_ok) {
+    // every candidate order may hide a band behind a few revisits: the border is tried on each, the chain model compares
+    double best_us = 0.0;
+    for (size_t k = 0; k < cand.size(); ++k) {
+      if (k == 1 && !with_memory_order) continue;  // (the slot repeats candidate 0)
+      std::vector<int> oc(ocam.size());
+      for (size_t b = 0; b < ocam.size(); ++b) oc[b] = cand[k][ocam[b]];
+      const std::vector<int> plain = (int)k == best_k ? best_env : envelope_of_order(ocam, opt, cand[k], C, P, nblk);
+      BorderChoice bc;
+      if (!choose_border(oc, opt, C, P, nblk, plain, border_mode, &bc)) continue;
+      if (!out.bordered || bc.model_us < best_us) {
+        best_us = bc.model_us; out.bordered = true; out.candidate = (int)k;
+        out.border = bc;
+        for (int c = 0; c < C; ++c) out.border.new_id[c] = bc.new_id[cand[k][c]];  // first-appearance numbering -> final numbering
+      }
+    }
+    // (against the envelope of the order that would be used otherwise)
+    const double plain_us = envelope_model_us(nblk, best_env, nullptr);
+    if (out.bordered && border_mode != SK_BORDER_ON && out.border.model_us >= 0.9 * plain_us) out.bordered = false;
+  }
+  out.border.plain_us = envelope_model_us(nblk, best_env, nullptr);
+  if (out.bordered) {
+    out.id = out.border.new_id; out.last = out.border.last; out.tail = out.border.tail;
+    out.flops = cholesky_syrk_flops(npad, 1, out.last.data(), false, nullptr, -1, 1, out.tail.data());
+  } else {
+    out.id = cand[best_k]; out.last = best_env; out.candidate = best_k; out.flops = best;
+  }
+  return out;
+}
+
 // Sharding the points pays when the per-iteration work it removes from a rank (evaluation, Schur
 // assembly, back-substitution: linear in observations and pair entries) exceeds the all-reduce of the
 // reduced system it adds.  The all-reduce is MEASURED here (second and third call of the hook on the real
@@ -703,21 +855,23 @@ int BalSolver::setup() {
     const int nblk = npad_ / 128;
     std::vector<int> best_env;
     double best = 0.0;
-    int best_k = 0;
     // The memory order of the camera blocks (the BAL file's numbering under the reference's layout) is usually the best
     // candidate by far — and host addresses are a process's own: with separately allocated camera blocks it could differ from
     // rank to rank, and the ranks must build the SAME reduced system.  Round 3: the ranks try it and compare (a hash of the
     // order and the envelope: one tiny exchange); only if they disagree do they all fall back to the rank-invariant candidates.
     // (Until then a world of ranks never used it: on the Ladybug-shaped problem the chain model of the best remaining order,
     // reverse Cuthill-McKee, is 12.1 ms against 9.1 — every multi-rank run would have factored a third more slowly.)
-    std::vector<std::vector<int>> cand;
+    // (the border of loop-closure cameras: not with an explicit dissection or segmentation — the fronts of those have borders of
+    // their own kind — and only inside the envelope machinery)
+    const bool border_ok = opt_.envelope && opt_.border != SK_BORDER_OFF && opt_.dissection != SK_DISSECTION_ON && !getenv("SK_DISSECT_AT") &&
+                           !(opt_.allreduce && opt_.world > 1 && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED);
+    CameraOrderPlan plan;
     auto pick = [&](bool with_memory_order) {
-      cand = camera_order_candidates(p, cam_block_, ocam, opt, C_, P_total_, with_memory_order);
-      best_env.clear();
-      choose_camera_order(cand, ocam, opt, C_, P_total_, npad_, &best_k, &best_env, &best);
+      plan = plan_camera_order(p, cam_block_, ocam, opt, C_, P_total_, npad_, with_memory_order, border_ok, opt_.border);
       unsigned long long h = 1469598103934665603ull;
-      for (int v : cand[best_k]) { h ^= (unsigned)v; h *= 1099511628211ull; }
-      for (int v : best_env) { h ^= (unsigned)v; h *= 1099511628211ull; }
+      for (int v : plan.id) { h ^= (unsigned)v; h *= 1099511628211ull; }
+      for (int v : plan.last) { h ^= (unsigned)v; h *= 1099511628211ull; }
+      for (int v : plan.tail) { h ^= (unsigned)v; h *= 1099511628211ull; }
       order_hash_ = (double)(h >> 12);  // 52 bits: exact in a double
     };
     pick(true);
@@ -727,13 +881,20 @@ int BalSolver::setup() {
       if (rc) return rc;
       if (v[0] != order_hash_ || v[1] != -order_hash_) pick(false);  // (every rank sees the disagreement: max and min differ)
     }
-    const std::vector<int>& id = cand[best_k];
-    camera_order_ = best_k;
+    const std::vector<int>& id = plan.id;
+    camera_order_ = plan.candidate;
+    best_env = plan.last; best = plan.flops;
     std::vector<int> cb(C_);
     for (int c = 0; c < C_; ++c) cb[id[c]] = cam_block_[c];
     cam_block_.swap(cb);
     for (int& c : ocam) c = id[c];
     const double full = cholesky_syrk_flops(npad_, 1, nullptr);
+    border_plain_us_ = plan.border.plain_us;
+    if (plan.bordered) {
+      env_tail_ = plan.tail;
+      border_cams_ = plan.border.border_cams; border_gap_ = plan.border.gap;
+      border_model_us_ = plan.border.model_us;
+    }
     group_ = opt_.group_or(opt_.envelope && best < 0.5 * full ? 1 : 3);
     env_for_model = best_env;
     if (opt_.envelope) env_last_.swap(best_env);
@@ -741,7 +902,10 @@ int BalSolver::setup() {
       long h = 0;
       for (int c = 0; c < nblk; ++c) h += env_last_[c] - c;
       std::fprintf(stderr, "[skeres_amd] camera order %d (0 first appearance, 1 memory, 2 RCM); envelope: %d block columns, mean height %.1f; "
-                   "trailing-update flops %.3e (full %.3e)\n", best_k, nblk, (double)h / nblk, best, full);
+                   "trailing-update flops %.3e (full %.3e)\n", camera_order_, nblk, (double)h / nblk, best, full);
+      if (border_cams_ > 0)
+        std::fprintf(stderr, "[skeres_amd] loop closures: %d cameras in a trailing border (visits split at jumps of more than %d cameras): chain model %.0f us against %.0f\n",
+                     border_cams_, border_gap_, border_model_us_, border_plain_us_);
     }
   }
   // ---- multi-GPU: shard the points, or replicate? ----
@@ -752,10 +916,7 @@ int BalSolver::setup() {
     const int nblk = npad_ / 128;
     std::vector<int> pack_col0(nblk, 0);
     std::vector<long long> pack_off(nblk + 1, 0);
-    if (!env_last_.empty()) {
-      int c = 0;
-      for (int i = 0; i + 1 < nblk; ++i) { while (c < i && env_last_[c] < i) ++c; pack_col0[i] = c; }
-    }
+    if (!env_last_.empty()) pack_col0 = cholesky_row_first_cols(nblk, env_last_.data(), env_tail_.empty() ? nullptr : env_tail_.data());
     for (int kb = 0; kb < nblk; ++kb) pack_off[kb + 1] = pack_off[kb] + (long long)128 * 128 * (kb + 1 - pack_col0[kb]);
     packed_elems_ = (size_t)pack_off[nblk];
     pack_col0_h_ = pack_col0; pack_off_h_ = pack_off;
@@ -765,7 +926,7 @@ int BalSolver::setup() {
     // ---- dissect?  One process: only when forced (measured not to pay on one chip).  Several ranks: the SEGMENTED
     // distribution — every rank's device eliminates one segment of the camera sequence — when the model of the chains
     // predicts a gain (or when asked for). ----
-    const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0;
+    const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0 && env_tail_.empty();  // (a bordered envelope is not dissected)
     const bool multi = opt_.allreduce != nullptr && opt_.world >= 2;
     bool may_dissect = plan_ok && (multi ? (opt_.distribution_mode == SK_DISTRIBUTION_AUTO || opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED)
                                          : (!opt_.allreduce && chol_ctx_b_.init_secondary(chol_ctx_) == hipSuccess));
@@ -1033,7 +1194,7 @@ int BalSolver::setup() {
   std::vector<int> border_row_h[2], leaf_map_h, leaf_gmap_h;
   if (!dissected_) {
     FrontHost& r = fr_[2];
-    r.nblk = r.ncols = npad_ / 128; r.cams = C_; r.dim = (size_t)npad_; r.rhs_row = rhs_row_; r.last = env_last_;
+    r.nblk = r.ncols = npad_ / 128; r.cams = C_; r.dim = (size_t)npad_; r.rhs_row = rhs_row_; r.last = env_last_; r.tail = env_tail_;
     border_blocks_ = 0;
   } else {
     const int nsep = C_ - cam_b_;
@@ -1094,13 +1255,10 @@ int BalSolver::setup() {
     std::vector<int> col0(F.nblk, 0);
     // the widest group of either way to factor (with / without the resident chain, which a timing mode switches off)
     const bool chain_here = chain_ok() && (f != 1 || tail_chain());
-    const int widen = F.last.empty() ? 1 : std::max(group_, cholesky_plan_max_group(cholesky_plan(F.nblk, group_, F.last.data(), chain_here, F.ncols, F.tail_rows)));
+    const int widen = F.last.empty() ? 1 : std::max(group_, cholesky_plan_max_group(cholesky_plan(F.nblk, group_, F.last.data(), chain_here, F.ncols, F.tail_rows, F.tl())));
     if (!F.last.empty()) {
-      int c = 0;
-      for (int i = 0; i + F.tail_rows < F.nblk; ++i) {  // (the tail rows: from column 0)
-        while (c < i && F.last[c] < i) ++c;
-        col0[i] = std::max(0, c - (widen - 1));
-      }
+      const std::vector<int> first = cholesky_row_first_cols(F.nblk, F.last.data(), F.tl(), F.tail_rows);  // (the tail rows: from column 0, or as the profile has them)
+      for (int i = 0; i < F.nblk; ++i) col0[i] = std::max(0, first[i] - (widen - 1));
     }
     SK_HIP_TRY(b_zero_col0_f_[f].upload(col0, s));
   }
@@ -1436,8 +1594,8 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, info_p_);
   } else {
     const FrontHost& R = fr_[2];
-    cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok());
-    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), info_p_);
+    cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok(), -1, 1, nullptr, R.tl());
+    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), info_p_, R.tl());
   }
   launch_bal_gather_y(d_, s);
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
@@ -1623,6 +1781,30 @@ int bal_segment_plan(const Problem& p, int max_segments, bool forced, std::vecto
     (*block_point_owner)[b] = seg_of_pt[opt[b]] >= 0 ? seg_of_pt[opt[b]] : opt[b] % R;
   }
   return R;
+}
+
+// The camera order and the border of loop-closure cameras as BalSolver::setup derives them (one process), from host data alone.
+// final_index_of_block[b]: the position of residual block b's camera inside the reduced system; returns the number of border cameras.
+int bal_border_plan(const Problem& p, int mode, std::vector<int>* final_index_of_block, int* gap, double* model_us, double* plain_us, double* fill) {
+  std::vector<int> cam_block, pt_block, ocam, opt;
+  bal_index_problem(p, &cam_block, &pt_block, &ocam, &opt);
+  const int C = (int)cam_block.size(), P = (int)pt_block.size();
+  const int npad = ((9 * C + 1 + 127) / 128) * 128, nblk = npad / 128;
+  const CameraOrderPlan plan = plan_camera_order(p, cam_block, ocam, opt, C, P, npad, true, mode != SK_BORDER_OFF, mode);
+  final_index_of_block->resize(ocam.size());
+  for (size_t b = 0; b < ocam.size(); ++b) (*final_index_of_block)[b] = plan.id[ocam[b]];
+  if (gap) *gap = plan.bordered ? plan.border.gap : 0;
+  if (model_us) *model_us = plan.bordered ? plan.border.model_us : plan.border.plain_us;
+  if (plain_us) *plain_us = plan.border.plain_us;
+  if (fill) {
+    double in = 0.0;
+    for (int c = 0; c < nblk; ++c) {
+      const int lm = std::min(plan.last[c], nblk - 1), t0 = plan.tail.empty() ? nblk - 1 : plan.tail[c];
+      in += (lm - c + 1) + std::max(0, nblk - std::max(t0, lm + 1));
+    }
+    *fill = in / (0.5 * nblk * (nblk + 1.0));
+  }
+  return plan.bordered ? plan.border.border_cams : 0;
 }
 
 std::unique_ptr<SolverBase> make_bal_solver(const Options& o, Problem* p) { return std::unique_ptr<SolverBase>(new BalSolver(o, p)); }

@@ -559,6 +559,10 @@ int sk_options_set_distribution_mode(sk_options* o, int mode) {
   if (mode != SK_DISTRIBUTION_AUTO && mode != SK_DISTRIBUTION_SHARDED && mode != SK_DISTRIBUTION_REPLICATED && mode != SK_DISTRIBUTION_SEGMENTED) { set_error("invalid distribution mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
   o->o.distribution_mode = mode; return SK_OK;
 }
+int sk_options_set_cholesky_border(sk_options* o, int mode) {
+  if (mode != SK_BORDER_AUTO && mode != SK_BORDER_ON && mode != SK_BORDER_OFF) { set_error("invalid border mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
+  o->o.border = mode; return SK_OK;
+}
 int sk_options_set_reduce_buffer(sk_options* o, void* ptr, size_t bytes) { o->o.reduce_buffer = ptr; o->o.reduce_buffer_bytes = bytes; return SK_OK; }
 size_t sk_reduce_buffer_bytes(const sk_options* o, const sk_problem* p) {
   (void)o;
@@ -721,6 +725,20 @@ int sk_problem_segment_plan(const sk_problem* p, int max_segments, int forced, i
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }
 
+int sk_problem_border_plan(const sk_problem* p, int mode, int* num_border_cameras, int* camera_position_of_block, int* gap, double* model_us, double* model_us_plain,
+                           double* envelope_fill) {
+  SK_GUARD_BEGIN
+  if (!p || !num_border_cameras) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (mode != SK_BORDER_AUTO && mode != SK_BORDER_ON && mode != SK_BORDER_OFF) { set_error("invalid border mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
+  std::string why;
+  if (!problem_is_bal_shaped(p->p, &why)) { set_error("%s", why.c_str()); return SK_ERR_UNSUPPORTED; }
+  std::vector<int> pos;
+  *num_border_cameras = bal_border_plan(p->p, mode, &pos, gap, model_us, model_us_plain, envelope_fill);
+  if (camera_position_of_block) for (size_t b = 0; b < pos.size(); ++b) camera_position_of_block[b] = pos[b];
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
 int sk_synth_dense_targets(double seed, int m, int n, const double* x_star, double* y_out) {
   SK_GUARD_BEGIN
   if (m <= 0 || n <= 0 || !x_star || !y_out) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
@@ -742,7 +760,17 @@ int sk_cholesky_solve(int n, const double* A, const double* b, double* x, double
   return sk_cholesky_solve_ex(n, A, b, x, L, group, nullptr, 0);
 }
 
+static int cholesky_solve_impl(int n, const double* A, const double* b, double* x, double* L, int group, const int* last, int automatic_plan, int border_begin_row);
 int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, double* L, int group, const int* last, int automatic_plan) {
+  return cholesky_solve_impl(n, A, b, x, L, group, last, automatic_plan, -1);
+}
+int sk_cholesky_solve_bordered(int n, const double* A, const double* b, double* x, double* L, int group, int border_begin_row, int automatic_plan) {
+  if (border_begin_row < 0 || border_begin_row > n) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  return cholesky_solve_impl(n, A, b, x, L, group, nullptr, automatic_plan, border_begin_row);
+}
+static std::vector<int> host_block_first_cols(const std::vector<double>& M, size_t ld, int nblk);
+// border_begin_row >= 0: the bordered envelope of the matrix itself (cholesky_envelope_bordered), rows from there on being the border
+static int cholesky_solve_impl(int n, const double* A, const double* b, double* x, double* L, int group, const int* last, int automatic_plan, int border_begin_row) {
   SK_GUARD_BEGIN
   if (n <= 0 || !A || !b || !x) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
   if (sk_device_count() <= 0) { set_error("no HIP device available: libskeres_amd has no CPU fallback"); return SK_ERR_NO_DEVICE; }
@@ -759,6 +787,12 @@ int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, dou
   std::memcpy(&S[(size_t)rhs_row * npad], b, (size_t)n * sizeof(double));
   S[(size_t)rhs_row * npad + rhs_row] = 1e300;
   for (int j = n + 1; j < npad; ++j) S[(size_t)j * npad + j] = 1.0;
+  std::vector<int> b_last, b_tail;
+  const int* tail = nullptr;
+  if (border_begin_row >= 0) {
+    cholesky_envelope_bordered(host_block_first_cols(S, (size_t)npad, nblk), border_begin_row / 128, &b_last, &b_tail);
+    last = b_last.data(); tail = b_tail.data();
+  }
   DevBuf<double> dS, dLinv, dy; DevBuf<int> dinfo;
   hipStream_t s = nullptr;
   SK_HIP_TRY(dS.upload(S, s)); SK_HIP_TRY(dLinv.alloc((size_t)npad * 128)); SK_HIP_TRY(dLinv.zero(s));
@@ -771,8 +805,8 @@ int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, dou
   SK_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   SK_HIP_TRY(hipDeviceSynchronize());  // uploads above ran on the null stream
   const bool chain = automatic_plan != 0 && la && ctx.server != nullptr;  // (the plan; resident or not is the device's state)
-  cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr, last, chain);
-  cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dw.p, dy.p, s, nullptr, last, dinfo.p);
+  cholesky_factor(dS.p, npad, npad, dLinv.p, dinfo.p, group, s, la ? &ctx : nullptr, nullptr, last, chain, -1, 1, nullptr, tail);
+  cholesky_backsolve(dS.p, npad, n, npad, rhs_row, dLinv.p, dw.p, dy.p, s, nullptr, last, dinfo.p, tail);
   SK_HIP_TRY(hipStreamSynchronize(s));
   SK_HIP_TRY(hipStreamDestroy(s));
   s = nullptr;
@@ -793,7 +827,7 @@ int sk_cholesky_solve_ex(int n, const double* A, const double* b, double* x, dou
 }
 
 // Block envelope of a front held on the host (lower triangle, row-major, ld): first non-zero block column per block row.
-static std::vector<int> host_block_envelope(const std::vector<double>& M, size_t ld, int nblk, int tail_rows = 1) {
+static std::vector<int> host_block_first_cols(const std::vector<double>& M, size_t ld, int nblk) {
   std::vector<int> first_col(nblk);
   for (int i = 0; i < nblk; ++i) {
     first_col[i] = i;
@@ -806,7 +840,10 @@ static std::vector<int> host_block_envelope(const std::vector<double>& M, size_t
       if (nz) first_col[i] = j;
     }
   }
-  return cholesky_envelope_last(first_col, tail_rows);
+  return first_col;
+}
+static std::vector<int> host_block_envelope(const std::vector<double>& M, size_t ld, int nblk, int tail_rows = 1) {
+  return cholesky_envelope_last(host_block_first_cols(M, ld, nblk), tail_rows);
 }
 
 int sk_cholesky_solve_dissected(int n, const double* A, const double* b, double* x, int head, int tail_begin, int group, int automatic_plan) {

@@ -1133,15 +1133,15 @@ __global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict_
 // ---------------------------------------------------------------------------
 __device__ long long g_bs_stamps[1024][4];  // developer timeline SK_BS_STAMPS=<file>: per block column, wall clock when its owner started waiting for
 __device__ int g_bs_stamps_on;              // the block row next to the diagonal, when that y had arrived, and when its own y was stored
-struct BsTop { unsigned short top[1024]; };  // per block column: the last block row of its contiguous run (<= nblk - 1)
+constexpr int kBsMaxBlocks = 960;  // (two tables of that many entries + the other arguments: inside the 4 KB kernel-argument segment)
+struct BsTop { unsigned short top[kBsMaxBlocks]; unsigned short tail[kBsMaxBlocks]; };  // per block column: the last block row of its contiguous run (<= nblk - 1), and the first of its tail rows
 constexpr unsigned long long kBsSentinel = ~0ull;
 __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __restrict__ Linv, const double* __restrict__ S, long ld, const double* __restrict__ rhs,
-                                                               int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb,
-                                                               int tail0) {
+                                                               int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb) {
   // nown < nblk: the interior of a LEAF FRONT (cholesky_backsolve_front): block columns [0, nown) have owners, the unknowns of
   // the block rows below them — the front's border — are known (yb, in the border's order: the separators' solution); the block
-  // rows from tail0 on are active in every column (the right-hand-side row; a spike: SegmentLayout), the others up to the
-  // column's envelope.  nown == nblk, tail0 == nblk - 1: a whole system.
+  // rows from env.tail[kb] on are active in block column kb whatever its run (the right-hand-side row; a spike: SegmentLayout; the
+  // border of a bordered envelope, from the column that first reaches it), the others up to the column's envelope.  nown == nblk: a whole system.
   // 1024 threads: column c of the block and one of eight groups of sixteen rows each — sixteen products per thread and matrix
   // on the chain's critical path where 256 threads had sixty-four (0.41 -> 0.39 ms on Ladybug-1723: the hop is mostly hand-over and barriers); the partial sums are formed over the
   // same rows and added in the same order as before (and as in bs_step_kernel)
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
     for (int i = 0; i < 16; ++i) li[i] = p[(long)i * 128];
   }
   const int top = min((int)env.top[kb], nblk - 1);
-  const int tlo = max(tail0, top + 1);                             // the always-active rows that the envelope's run does not reach: [tlo, nblk)
+  const int tlo = max((int)env.tail[kb], top + 1);                 // the tail rows that the envelope's run does not reach: [tlo, nblk)
   int cur = (kb < nblk - 1 && tlo <= nblk - 1) ? nblk - 1 : top;  // block rows to apply: nblk - 1 .. tlo, then top .. kb + 1
   const double* Lcol = S + (long)(rg * 16) * ld + (long)kb * 128 + c;
   if (cur > kb) {
@@ -1581,14 +1581,15 @@ static void plan_close_partial(CholeskyPlan* plan, int nblk, int ncols) {
 // tail_rows: how many block rows at the end of the matrix are active in EVERY block column (1: the block row that carries
 // the right-hand side; more for a leaf front whose border has rows that the first columns of the interior couple with —
 // the "spike" of a segment between two separators); only a partial factorisation has more than one.
-CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols, int tail_rows) {
+CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols, int tail_rows, const int* tail) {
   CholeskyPlan plan;
   plan.resident.assign(nblk, 0);
   plan.paired.assign(nblk, 0);
   if (group < 1) group = 1;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
   if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
-  const int tail0 = nblk - tail_rows;  // first block row of the tail
+  const int tail_uniform = nblk - tail_rows;  // first block row of the tail
+  auto tail0_of = [&](int c) { return tail ? tail[c < nblk ? c : nblk - 1] : tail_uniform; };  // ... as block column c sees it (a profile: cholesky_factor)
   const bool partial = ncols < nblk;
   if (!chain || nblk < 3) {
     plan.bounds = cholesky_group_bounds(nblk, group);
@@ -1602,13 +1603,14 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int
     return plan;
   }
   auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
-  auto count = [&](int first_row, int last_row) {  // active block rows from first_row: the run up to last_row, and the tail rows
+  auto count = [&](int first_row, int col) {  // active block rows of block column col from first_row: its run, and the tail rows
+    const int last_row = last_main(col);
     const int main_rows = last_row >= first_row ? last_row - first_row + 1 : 0;
-    return main_rows + std::max(0, nblk - std::max(tail0, first_row + main_rows));
+    return main_rows + std::max(0, nblk - std::max(tail0_of(col), first_row + main_rows));
   };
   const int jend = partial ? ncols : nblk - 1;  // block columns that have a column launch of their own
   for (int j = 0; j < jend; ++j)
-    plan.resident[j] = count(j + 2, last_main(j)) <= g_chain_max_trailing && 4 * count(j + 1, last_main(j)) <= g_thin_grid;
+    plan.resident[j] = count(j + 2, j) <= g_chain_max_trailing && 4 * count(j + 1, j) <= g_thin_grid;
   for (int j = 0; j < jend;) {  // drop the short runs: a hand-over costs more than a few columns gain
     if (!plan.resident[j]) { ++j; continue; }
     int e = j;
@@ -1626,7 +1628,7 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int
   if (g_pair_max_trailing > 0) {
     bool any_resident = false;
     for (int j = 0; j < jend; ++j) any_resident = any_resident || plan.resident[j];
-    auto pairable = [&](int c) { return !plan.resident[c] && count(c + 2, last_main(c)) <= g_pair_max_trailing && count(c + 2, last_main(c)) >= 1 && 4 * count(c + 1, last_main(c)) <= g_thin_grid; };
+    auto pairable = [&](int c) { return !plan.resident[c] && count(c + 2, c) <= g_pair_max_trailing && count(c + 2, c) >= 1 && 4 * count(c + 1, c) <= g_thin_grid; };
     for (int j = 0; any_resident && j < jend;) {
       if (!pairable(j)) { ++j; continue; }
       int e = j;
@@ -1639,7 +1641,7 @@ CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int
   if (!partial) plan.resident[nblk - 1] = plan.resident[nblk - 2];  // the server factors the last diagonal block too when it has the column before it
   bool any = false;
   for (int j = 0; j < nblk; ++j) any = any || plan.resident[j];
-  if (!any) return cholesky_plan(nblk, group, last, false, ncols, tail_rows);
+  if (!any) return cholesky_plan(nblk, group, last, false, ncols, tail_rows, tail);
   const int pg = group == 1 ? g_chain_prefix_group : group;
   for (int k = 0; k < ncols;) {
     plan.bounds.push_back(k);
@@ -1858,11 +1860,13 @@ void cholesky_prepare(CholeskyContext* ctx, hipStream_t s) {
 }
 
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
-                     KernelTimer* kt, const int* last, bool allow_chain, int ncols, int tail_rows, const CholeskyPartner* partner) {
+                     KernelTimer* kt, const int* last, bool allow_chain, int ncols, int tail_rows, const CholeskyPartner* partner, const int* tail) {
   const int nblk = npad / 128;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
   if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
-  const int tail0 = nblk - tail_rows;
+  const int tail_uniform = nblk - tail_rows;
+  // first block row of the tail as block column c sees it (a profile: the border of a bordered envelope; else uniform)
+  auto tail0_of = [&](int c) { return tail ? tail[c < nblk ? c : nblk - 1] : tail_uniform; };
   // Which hardware queues the panel and bulk streams sit on decides how well their kernels overlap — with or without the
   // resident chain (Venice-1778 in explicit groups of two: 30.6 ms per iteration on the first combination, 19.1 on the
   // one the trial picks): every look-ahead factorisation asks for the trial, which runs once per device.
@@ -1894,10 +1898,13 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   // last active main row of block column c, and whether block row nblk-1 comes on top of the run that ends there
   auto last_main = [&](int c) { return last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1; };
   struct Rows { int main, extra, jump; };  // `main` consecutive block rows from `first_row`, then `extra` rows of the tail (what is left of it), `jump` blocks further
-  auto rows_from = [&](int first_row, int last_row) {
+  // the active block rows of block column `col` from first_row on (a group's update takes those of the group's LAST column:
+  // envelope and tail profile both widen from column to column, and what the earlier columns lack of them is exact zeros)
+  auto rows_from = [&](int first_row, int col) {
     Rows r;
+    const int last_row = last_main(col);
     r.main = last_row >= first_row ? last_row - first_row + 1 : 0;
-    const int t0 = std::max(tail0, first_row + r.main);
+    const int t0 = std::max(tail0_of(col), first_row + r.main);
     r.extra = std::max(0, nblk - t0);
     r.jump = r.extra ? t0 - (first_row + r.main) : 0;
     return r;
@@ -1929,7 +1936,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     panel_done = nullptr;
     for (int kb = k0; kb < k1; ++kb) {
       double* Akk = S + (long)kb * 128 * ld + (long)kb * 128;
-      const Rows below = rows_from(kb + 1, last_main(kb));
+      const Rows below = rows_from(kb + 1, kb);
       const double* P = S + (long)kb * 128 * ld + (long)k0 * 128;
       const int K = (kb - k0) * 128;
       if (kb > k0) update_diag(sp, "gemm_diag_update", Akk, P, K);  // lazy left-looking update from columns [k0, kb): diagonal tile ...
@@ -1955,7 +1962,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     }
   };
   // the block columns under the resident panel chain (cholesky_plan)
-  const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr, ncols, tail_rows);
+  const CholeskyPlan plan = cholesky_plan(nblk, group, last, la && allow_chain && ctx->server != nullptr, ncols, tail_rows, tail);
   const std::vector<int>& gb = plan.bounds;
   const int ngroups = (int)gb.size() - 1;
   ChainRanges ranges;
@@ -2083,9 +2090,9 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     const bool pair = plan.paired[k0] == 1 && k1 - k0 == 2;
     const bool after_pair = k0 > 0 && plan.paired[k0 - 1] == 2 && is_resident(k0 - 1);  // block column k0 was last updated by a resident pair's SYRK
     const int na = pair ? 0 : (resident ? 1 : gb[g + 2] - k1);
-    const int Lg = last_main(k1 - 1);  // rows below Lg (other than nblk-1) are zero in every column of this group
-    const Rows rn = rows_from(k1, Lg);       // rows that next(g) updates
-    const Rows rs = rows_from(k1 + na, Lg);  // rows (and columns) that syrk(g) updates
+    // (rows below the run of the group's last column, other than its tail rows, are zero in every column of this group)
+    const Rows rn = rows_from(k1, k1 - 1);       // rows that next(g) updates
+    const Rows rs = rows_from(k1 + na, k1 - 1);  // rows (and columns) that syrk(g) updates
     double* A22 = S + (long)k1 * 128 * ld + (long)k1 * 128;
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
     const int Tb = rs.main + rs.extra;
@@ -2101,7 +2108,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       if (syrk_done2) (void)hipStreamWaitEvent(sp, syrk_done2, 0);
       hipEvent_t col_done = ctx->event(ev++);
       for (int c = 0; c < 2; ++c) {
-        const Rows rc = rows_from(k0 + c + 1, last_main(k0 + c));
+        const Rows rc = rows_from(k0 + c + 1, k0 + c);
         const int T = rc.main + rc.extra;
         const int ncrit = (rc.main > 0 || rc.jump == 0) ? 16 : 0;
         hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, c == 1 ? col_done : (hipEvent_t) nullptr, 0, S, ld,
@@ -2164,7 +2171,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       if (la && !record && g + 3 < (int)gb.size()) {
         // (where the NEXT group's SYRK starts: behind its next(g + 1) — one block column after a resident column, none after a pair)
         const int k2 = gb[g + 2], na1 = (plan.paired[k1] == 1 && k2 - k1 == 2) ? 0 : (is_resident(k1) ? 1 : gb[g + 3] - k2);
-        const Rows rs1 = rows_from(k2 + na1, last_main(k2 - 1));
+        const Rows rs1 = rows_from(k2 + na1, k2 - 1);
         record = (rs1.main + rs1.extra >= ctx->early_tiles) != (sb == ctx->bulk_early);
       }
       // ... an event that rides on the SYRK's own dispatch (as do the two of the kernel timer): a separate record is a
@@ -2246,7 +2253,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
         if (!plan.resident[j]) continue;
         fprintf(f, "%d ", j);
         for (int i = 0; i < 7; ++i) fprintf(f, "%lld ", st[(size_t)j * 8 + i]);
-        const Rows rs = rows_from(j + 2, last_main(j));
+        const Rows rs = rows_from(j + 2, j);
         fprintf(f, "%d\n", rs.main + rs.extra);
       }
       fclose(f);
@@ -2257,16 +2264,19 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
 // y (npad) <- solution of L^T y = z, with z^T = row rhs_row of L (first n entries).  w: scratch (npad).
 // With an envelope, block row kb of L is zero left of the first block column c with last[c] >= kb.
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt, const int* last, int* info) {
+                        hipStream_t s, KernelTimer* kt, const int* last, int* info, const int* tail) {
   const int nblk = npad / 128;
-  if (info && g_bs_resident && nblk <= 1024) {
+  if (info && g_bs_resident && nblk <= kBsMaxBlocks) {
     BsTop env;
-    for (int c = 0; c < nblk; ++c) env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1);
+    for (int c = 0; c < nblk; ++c) {
+      env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1);
+      env.tail[c] = (unsigned short)(tail ? std::min(std::max(tail[c], 0), nblk - 1) : nblk - 1);
+    }
     if (kt) kt->begin("backsolve", s);
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);
     static const char* bs_stamps = getenv("SK_BS_STAMPS");
     if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
-    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info, nblk, (const double*)nullptr, nblk - 1);
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info, nblk, (const double*)nullptr);
     if (kt) kt->end("backsolve", s);
     if (bs_stamps) {
       (void)hipStreamSynchronize(s);
@@ -2281,13 +2291,7 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
   }
   hipLaunchKernelGGL(copy_row_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, n, npad);
   if (kt) kt->begin("backsolve", s);
-  int c0 = 0;
-  std::vector<int> first(nblk, 0);
-  if (last)
-    for (int kb = 0; kb < nblk - 1; ++kb) {  // last is non-decreasing: one sweep
-      while (c0 < kb && last[c0] < kb) ++c0;
-      first[kb] = c0;
-    }
+  const std::vector<int> first = cholesky_row_first_cols(nblk, last, tail);
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int ncols = kb * 128, col0 = first[kb] * 128;
     const int grid = ncols > col0 ? (ncols - col0 + 63) / 64 : 1;
@@ -2371,15 +2375,15 @@ void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int
                               hipStream_t s, const int* last, bool spike, int tail_rows, int* info) {
   const int ni = ncols * 128, m = (nblk - ncols) * 128;
   if (ncols <= 0) return;
-  if (info && g_bs_resident && nblk <= 1024) {
+  if (info && g_bs_resident && nblk <= kBsMaxBlocks) {
     // one resident launch (bs_resident_kernel): an owner per interior block column, the border's unknowns read from yb.  Not the
     // same grouping of the border's terms as bs_border_kernel below (block row by block row there, sixteen interleaved row
     // groups here): equal to rounding, not to the bit — a front's interior solution belongs to one rank.
     if (tail_rows < 1 || tail_rows > nblk - ncols) tail_rows = 1;
     BsTop env;
-    for (int c = 0; c < nblk && c < 1024; ++c) env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1);
+    for (int c = 0; c < nblk; ++c) { env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1); env.tail[c] = (unsigned short)(nblk - tail_rows); }
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)ni, s);
-    hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, ni, y, nblk, env, info, ncols, yb, nblk - tail_rows);
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, ni, y, nblk, env, info, ncols, yb);
     return;
   }
   hipLaunchKernelGGL(copy_row_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, ni, ni);
@@ -2538,12 +2542,11 @@ void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, in
 
 // Algorithmic flops of the dominant kernel's launches (part (b) of each trailing SYRK:
 // lower-triangular 128x128 tiles incl. the diagonal tiles, 2*128*128*K each).
-double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, double* c_tiles, int ncols, int tail_rows) {
+double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, double* c_tiles, int ncols, int tail_rows, const int* tail) {
   const int nblk = npad / 128;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
   if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
-  const int tail0 = nblk - tail_rows;
-  const CholeskyPlan plan = cholesky_plan(nblk, group, last, chain, ncols, tail_rows);
+  const CholeskyPlan plan = cholesky_plan(nblk, group, last, chain, ncols, tail_rows, tail);
   const std::vector<int>& gb = plan.bounds;
   double f = 0.0, tiles = 0.0;
   for (size_t g = 0; g + 2 < gb.size(); ++g) {
@@ -2553,6 +2556,7 @@ double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, dou
     const int Lg = last ? (last[k1 - 1] < nblk - 1 ? last[k1 - 1] : nblk - 1) : nblk - 1;
     const int first_row = k1 + na;
     const int main_rows = Lg >= first_row ? Lg - first_row + 1 : 0;
+    const int tail0 = tail ? tail[k1 - 1] : nblk - tail_rows;  // (of the group's last column, as cholesky_factor takes them)
     const int Tb = main_rows + std::max(0, nblk - std::max(tail0, first_row + main_rows));
     f += 0.5 * Tb * (Tb + 1.0) * 2.0 * 128.0 * 128.0 * (double)((k1 - k0) * 128);
     tiles += 0.5 * Tb * (Tb + 1.0);
@@ -2564,12 +2568,12 @@ double cholesky_syrk_flops(int npad, int group, const int* last, bool chain, dou
 // Algorithmic flops of factoring the blocks inside the envelope (last == nullptr: every block): per block column with
 // h active block rows below it, 128^3 (1/3 + h + h^2) — diagonal factorisation, triangular solve of h blocks, symmetric
 // update of h (h + 1) / 2 blocks with its diagonal blocks counted once.  Sums to n^3 / 3 for a full matrix.
-double cholesky_plan_flops(int nblk, const int* last, int ncols, int tail_rows) {
+double cholesky_plan_flops(int nblk, const int* last, int ncols, int tail_rows, const int* tail) {
   double f = 0.0;
   if (ncols < 0 || ncols > nblk) ncols = nblk;
   if (tail_rows < 1 || ncols > nblk - tail_rows) tail_rows = 1;
-  const int tail0 = nblk - tail_rows;
   for (int c = 0; c < ncols; ++c) {
+    const int tail0 = tail ? tail[c] : nblk - tail_rows;
     const int lm = last ? (last[c] < nblk - 1 ? last[c] : nblk - 1) : nblk - 1;
     const int main_rows = lm >= c + 1 ? lm - c : 0;
     const double h = main_rows + std::max(0, nblk - std::max(tail0, c + 1 + main_rows));
@@ -2602,6 +2606,51 @@ std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col, int t
   for (int c = 1; c < nblk; ++c) if (last[c] < last[c - 1]) last[c] = last[c - 1];
   if (nblk >= 2 && last[nblk - 2] > nblk - 2) last[nblk - 2] = nblk - 2;
   return last;
+}
+
+
+void cholesky_envelope_bordered(const std::vector<int>& first_col, int border_begin, std::vector<int>* last_out, std::vector<int>* tail_out) {
+  const int nblk = (int)first_col.size();
+  const int bb = std::max(0, std::min(border_begin, nblk - 1));
+  std::vector<int>& last = *last_out;
+  std::vector<int>& tail = *tail_out;
+  last.assign(nblk, 0); tail.assign(nblk, nblk - 1);
+  // the band: rows before the border
+  for (int c = 0; c < nblk; ++c) last[c] = c < bb ? c : nblk - 1;
+  for (int i = 0; i < bb; ++i) { const int c = first_col[i] < i ? first_col[i] : i; if (c >= 0 && last[c] < i) last[c] = i; }
+  for (int c = 1; c < bb; ++c) if (last[c] < last[c - 1]) last[c] = last[c - 1];
+  // the border: row i is active from reach[i] on — its own first column, or that of any border row before it (a column's tail rows
+  // are the LAST rows of the matrix: once row i is in, so is everything behind it); the right-hand-side row from column 0
+  std::vector<int> reach(nblk, 0);
+  int r = nblk;
+  for (int i = bb; i < nblk - 1; ++i) { r = std::min(r, std::max(0, std::min(first_col[i], i))); reach[i] = r; }
+  reach[nblk - 1] = 0;
+  for (int c = 0; c < nblk; ++c) {  // first active border row of column c: reach is non-increasing in i, so the rows active in column c are a suffix
+    int t = nblk - 1;
+    while (t - 1 >= bb && reach[t - 1] <= c) --t;
+    tail[c] = t;
+  }
+}
+
+std::vector<int> cholesky_row_first_cols(int nblk, const int* last, const int* tail, int tail_rows) {
+  std::vector<int> first(nblk, 0);
+  if (!last) return first;
+  int c0 = 0;
+  for (int kb = 0; kb < nblk; ++kb) {  // last is non-decreasing: one sweep
+    while (c0 < kb && last[c0] < kb) ++c0;
+    first[kb] = c0;
+  }
+  if (tail) {
+    for (int kb = 0; kb < nblk; ++kb) {  // ... or earlier, as a tail row (tail is non-increasing)
+      int c = 0;
+      while (c < first[kb] && tail[c] > kb) ++c;
+      first[kb] = c;
+    }
+  } else {
+    if (tail_rows < 1) tail_rows = 1;
+    for (int kb = std::max(0, nblk - tail_rows); kb < nblk; ++kb) first[kb] = 0;
+  }
+  return first;
 }
 
 }  // namespace sk

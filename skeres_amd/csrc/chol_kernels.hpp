@@ -181,9 +181,14 @@ struct CholeskyPartner {
   double* S; long ld; int nblk, ncols, tail_rows; const int* last; double* Linv; CholeskyContext* ctx;
   mutable bool taken = false;
 };
+// tail (optional, nblk entries; round 4): a PROFILE of the trailing block rows instead of the uniform `tail_rows` — block rows
+// [tail[c], nblk) are active in block column c on top of its contiguous run (non-increasing in c, tail[c] <= nblk - 1: the
+// right-hand-side row is active everywhere).  With it a FULL factorisation may have a border as well: the trailing block
+// columns are then the border's own (dense among themselves, last[c] == nblk - 1 there) — the cameras of loop closures, ordered
+// behind the band of the camera sequence ("Bordered envelope").
 void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int group, hipStream_t s, CholeskyContext* ctx,
                      KernelTimer* kt, const int* last = nullptr, bool allow_chain = false, int ncols = -1, int tail_rows = 1,
-                     const CholeskyPartner* partner = nullptr);
+                     const CholeskyPartner* partner = nullptr, const int* tail = nullptr);
 void cholesky_prepare(CholeskyContext* ctx, hipStream_t s);
 bool cholesky_note_info(CholeskyContext* ctx, int info);
 bool cholesky_chain_enabled(const CholeskyContext* ctx);
@@ -196,11 +201,11 @@ struct CholeskyPlan {
   std::vector<char> resident;  // per block column: under the resident panel chain
   std::vector<char> paired;    // ... as the first (1) / second (2) column of a resident pair (one K = 256 SYRK for both); else 0
 };
-CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols = -1, int tail_rows = 1);
+CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols = -1, int tail_rows = 1, const int* tail = nullptr);
 int cholesky_plan_max_group(const CholeskyPlan& plan);
 // info != nullptr: one resident launch (bs_resident_kernel; a time-out of its polls raises *info to 2); nullptr: one launch per block step
 void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt, const int* last = nullptr, int* info = nullptr);
+                        hipStream_t s, KernelTimer* kt, const int* last = nullptr, int* info = nullptr, const int* tail = nullptr);
 // --- dissected factorisation (chol_kernels.hip, "Two-way dissection") ---
 struct FrontView {
   double* S = nullptr; long ld = 0;   // row-major, lower triangle
@@ -271,9 +276,17 @@ inline SegmentLayout segment_layout(int interior_n, int left_n, int right_n) {
 // separator in the root and, last, their total.  Empty result: dense (one separator).
 std::vector<int> root_envelope(const std::vector<int>& sep_off);
 
-double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false, double* c_tiles = nullptr, int ncols = -1, int tail_rows = 1);
-double cholesky_plan_flops(int nblk, const int* last, int ncols = -1, int tail_rows = 1);
+double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false, double* c_tiles = nullptr, int ncols = -1, int tail_rows = 1,
+                           const int* tail = nullptr);
+double cholesky_plan_flops(int nblk, const int* last, int ncols = -1, int tail_rows = 1, const int* tail = nullptr);
 std::vector<int> cholesky_envelope_last(const std::vector<int>& first_col, int tail_rows = 1);
+// Bordered envelope of a whole system: block rows [border_begin, nblk) are the border (the last one carries the right-hand side).
+// From the block rows' first non-zero block columns: last[c] over the rows before the border (nblk - 1 for the border's own
+// columns), and the profile tail[c] = first border row active in column c — a border row, once reached, stays active, and so
+// does every border row behind it (the caller orders the border so that the rows reached first come last).
+void cholesky_envelope_bordered(const std::vector<int>& first_col, int border_begin, std::vector<int>* last, std::vector<int>* tail);
+// first block column in which block row i is active, for every i (from the envelope: the run `last`, the tail profile or uniform tail)
+std::vector<int> cholesky_row_first_cols(int nblk, const int* last, const int* tail, int tail_rows = 1);
 std::vector<int> cholesky_group_bounds(int nblk, int group);
 void launch_syrk_gram(double* H, long ldh, const double* A, long lda, int Kc, int nslabs, double* slabs, int tiles, hipStream_t s,
                       KernelTimer* kt);

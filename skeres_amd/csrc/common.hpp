@@ -160,6 +160,7 @@ struct Options {  // Solver.Options; Ceres 1.x defaults
   bool lookahead = true;   // potrf128 on a second stream, off the critical path
   int dissection = SK_DISSECTION_AUTO;  // DENSE_SCHUR: eliminate the head and the tail of a camera sequence side by side (sk_options_set_cholesky_dissection)
   bool envelope = true;    // DENSE_SCHUR: skip the blocks of the reduced system outside its block envelope (bit-identical result)
+  int border = SK_BORDER_AUTO;  // DENSE_SCHUR: order the cameras of loop closures into a trailing border of the reduced system (sk_options_set_cholesky_border)
 };
 
 struct IterationLog {

@@ -250,6 +250,67 @@ def test_multiway_dissected_factorisation_vs_numpy(shape, starts, automatic):
         sk.api.cholesky_solve_segments(A, b, bad, group=2)
 
 
+def _bordered_spd(heights, border_rows, reach_blocks, seed, off_grid=70):
+    """A block-banded SPD matrix (heights: active block rows below the diagonal per block column) followed by a border:
+    border row group g (border_rows[g] scalar rows) couples with a few columns of block reach_blocks[g] of the band and
+    with its own neighbourhood at the end of the band; the border is dense among itself."""
+    nblk_band = len(heights) + 1
+    first_col = np.arange(nblk_band)
+    for c, h in enumerate(heights):
+        for r in range(c, min(nblk_band - 1, c + h + 1)):
+            first_col[r] = min(first_col[r], c)
+    last = _envelope_last(first_col)
+    nb = 128 * nblk_band - off_grid
+    band = _banded_spd(nb, last, seed=seed)
+    m = int(sum(border_rows))
+    n = nb + m
+    rng = np.random.default_rng(seed + 1000)
+    A = np.zeros((n, n))
+    A[:nb, :nb] = band
+    row = nb
+    for rows, blk in zip(border_rows, reach_blocks):
+        c0 = min(nb - 40, 128 * blk + 11)
+        A[row:row + rows, c0:c0 + 37] = rng.normal(0, 1.0, (rows, 37))       # the place revisited
+        A[row:row + rows, nb - 90:nb - 60] = rng.normal(0, 1.0, (rows, 30))  # ... and something late in the band
+        row += rows
+    A[nb:, nb:] = np.tril(rng.normal(0, 1.0, (m, m)))
+    A = np.tril(A)
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(axis=1) + np.abs(A).sum(axis=0) + 1.0 + rng.uniform(0, 1, n)
+    return A, nb
+
+
+@pytest.mark.parametrize("shape,border_rows,reach_blocks", [
+    ("band", (360,), (12,)),                       # one revisit, border of 2.8 blocks
+    ("band", (200, 300, 250), (30, 18, 5)),        # three revisits, the rows reached first LAST (as the solver orders them)
+    ("band", (250, 300, 200), (5, 18, 30)),        # ... and in the other order: every border row active from the first reach on
+    ("band", (40,), (20,)),                        # a border narrower than a block: it shares the block row of the right-hand side
+    ("resident-then-wide-then-resident", (300, 260), (40, 3)),
+    ("two-wide-parts", (128, 128, 128), (50, 25, 0)),
+    ("odd-resident-run", (500,), (0,)),            # reached by the very first block column: a uniform tail
+])
+def test_bordered_factorisation_vs_numpy(shape, border_rows, reach_blocks):
+    """The bordered block envelope (sk_cholesky_solve_bordered; round 4): a block-banded matrix followed by a border whose
+    block rows are active from the first block column that reaches them — the reduced camera system with the cameras of
+    loop closures ordered behind the band — factored by the plans sk_solve uses (explicit groups, automatic plan with the
+    resident chain) against numpy's factor and solution.  Borders off the block grid, narrower than a block, reached in
+    either order, and envelopes that take every regime of the plan."""
+    A, nb = _bordered_spd(_PLAN_SHAPES[shape], border_rows, reach_blocks, seed=len(shape) + len(border_rows))
+    n = A.shape[0]
+    b = np.random.default_rng(11).normal(size=n)
+    Af = A + np.tril(A, -1).T
+    Lnp = np.linalg.cholesky(Af)
+    xnp = np.linalg.solve(Af, b)
+    scale = np.abs(Lnp).max()
+    for kw in ({"group": 2, "automatic_plan": False}, {"group": 1, "automatic_plan": False}, {"group": 3, "automatic_plan": False},
+               {"group": 0, "automatic_plan": True}):
+        x, L = sk.api.cholesky_solve_bordered(A, b, nb, want_L=True, **kw)
+        assert np.abs(L - Lnp).max() <= 1e-11 * scale, (shape, kw, np.abs(L - Lnp).max())
+        assert np.linalg.norm(x - xnp) <= 1e-11 * np.linalg.norm(xnp), (shape, kw)
+    # the same matrix with everything declared border (border_begin 0): the dense factorisation
+    x = sk.api.cholesky_solve_bordered(A, b, 0, group=2)
+    assert np.linalg.norm(x - xnp) <= 1e-11 * np.linalg.norm(xnp)
+
+
 def test_multiway_dissection_with_separators_narrower_than_a_block():
     """... and with a scalar band of 40: separators of 40 rows, so that a segment between two separators has its left
     separator and the right-hand side in ONE border block (one tail row) — the spike must still reach every column in
@@ -731,6 +792,83 @@ def test_dissected_dense_schur_vs_oracle(C, P, N, seed, extra):
         x_off, s_off = solve_bal_gpu(prob, setCholeskyDissection="off")
         for u, v in zip(summary.iterations()[:5], s_off.iterations()[:5]):
             assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
+
+
+@pytest.mark.parametrize("C,P,N,seed,revisits", [(600, 6000, 26000, 9, [(60, 350, 12, 40), (200, 520, 12, 40)]),
+                                                 (800, 8000, 34000, 9, [(100, 450, 16, 40), (300, 700, 16, 40), (30, 600, 10, 25)])])
+def test_bordered_dense_schur_vs_oracle(C, P, N, seed, revisits):
+    """Loop closures (bal.generate(revisits=...): a few places seen twice) with the revisiting cameras ordered into a trailing
+    border of the reduced system (sk_options_set_cholesky_border), forced on at sizes the oracle solves: the oracle's plain
+    Schur path gives the same trajectory (1e-10), and so does the device with the border off — the result of
+    EX/SimpleBundleAdjuster.scala:147-152 does not depend on the order of the cameras inside the reduced system."""
+    prob = bal.generate(C, P, N, seed=seed, revisits=revisits)
+    problem, params, loss = bal_problem_to_sk(prob)
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    options.setCholeskyBorder("on")
+    solver = sk.StepSolver(options, problem)
+    nb = solver.stat("border_cameras")
+    assert 1 <= nb <= sum(w for _, _, w, _ in revisits) and solver.stat("dissected") == 0
+    fill_on = solver.stat("envelope_fill")
+    while not solver.step():
+        pass
+    summary = sk.Solver.Summary()
+    solver.finish(summary)
+    x_gpu = params.toArray(prob.num_parameters)
+    x_cpu, so = oracle.solve_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=4))
+    _check_against_oracle(prob, summary, x_gpu, so, x_cpu)
+    problem2, params2, loss2 = bal_problem_to_sk(prob)
+    options.setCholeskyBorder("off")
+    solver2 = sk.StepSolver(options, problem2)
+    assert solver2.stat("border_cameras") == 0 and solver2.stat("envelope_fill") > fill_on  # the revisits widen the plain envelope
+    while not solver2.step():
+        pass
+    s_off = sk.Solver.Summary()
+    solver2.finish(s_off)
+    for u, v in zip(summary.iterations()[:5], s_off.iterations()[:5]):
+        assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
+    # ... and with an explicit SYRK depth, launch by launch (no resident chain)
+    x_g, s_g = solve_bal_gpu(prob, setCholeskyBorder="on", setCholeskyTuning=2)
+    for u, v in zip(s_g.iterations()[:5], s_off.iterations()[:5]):
+        assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
+
+
+def test_border_at_full_size_matches_the_plain_order_and_the_oracle():
+    """Ladybug-1723 at full size with three places revisited (40 cameras each, 150 tracks each): AUTO takes the border (the
+    chain model prefers it), the envelope stays near the band's, and two LM iterations agree with the plain order of the
+    device (border off: the revisits fill the envelope between the windows) and with the oracle at 1e-10."""
+    prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1),
+                              revisits=[(200, 900, 40, 150), (450, 1300, 40, 150), (700, 1600, 40, 150)])
+
+    def run(border):
+        problem, params, loss = bal_problem_to_sk(prob)
+        options = sk.Solver.Options()
+        options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+        options.setMaxNumIterations(2)
+        options.setCholeskyBorder(border)
+        solver = sk.StepSolver(options, problem)
+        stats = {k: solver.stat(k) for k in ("border_cameras", "envelope_fill", "cholesky_columns_resident", "dissected")}
+        while not solver.step():
+            pass
+        summary = sk.Solver.Summary()
+        solver.finish(summary)
+        return params.toArray(prob.num_parameters), summary, stats
+    x_b, s_b, st_b = run("auto")
+    x_p, s_p, st_p = run("off")
+    assert 100 <= st_b["border_cameras"] <= 124 and st_b["dissected"] == 0 and st_p["border_cameras"] == 0
+    assert st_b["envelope_fill"] < 0.45 and st_p["envelope_fill"] > 0.55
+    assert st_b["cholesky_columns_resident"] >= 60
+    for u, v in zip(s_b.iterations(), s_p.iterations()):
+        for k, tol in (("cost", 1e-10), ("step_norm", 1e-9), ("relative_decrease", 1e-9), ("trust_region_radius", 1e-9)):
+            assert abs(u[k] - v[k]) <= tol * max(abs(v[k]), 1e-300), (k, u[k], v[k])
+    assert np.linalg.norm(x_b - x_p) <= 1e-10 * np.linalg.norm(x_p - prob.parameters)
+    x_cpu, so = oracle.solve_bal(prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=_oracle_threads(), max_num_iterations=2, cholesky_envelope=1))
+    for k in range(3):
+        c = so.iterations[k]
+        assert abs(s_b.iterations()[k]["cost"] - c.cost) <= 1e-10 * c.cost
+    assert np.linalg.norm(x_b - x_cpu) <= 1e-8 * np.linalg.norm(x_cpu - prob.parameters)
 
 
 def test_dissection_at_full_size_matches_the_undissected_solve():
