@@ -1160,6 +1160,18 @@ int BalSolver::setup() {
   // points.  (Round 1 sorted the long list by length, longest first, against a long tail: 2.14 ms on Venice-1778 where
   // camera order takes 1.65.  Sorting the short list by length, so that the seven lane groups of a wave finish together,
   // changes nothing in time and fetches 588 MB instead of 345 on Ladybug-1723.)
+  {
+    // EXPERIMENT (round 4): the lists in Z-order of (row camera, column camera) instead of row-major — a run of consecutive
+    // segments then stays inside a small square of camera pairs, whose rows' AND columns' records fit an XCD's L2
+    static const int z_order = getenv("SK_PAIR_Z_ORDER") ? atoi(getenv("SK_PAIR_Z_ORDER")) : 0;
+    if (z_order) {
+      auto spread = [](unsigned v) { unsigned long long x = v; x = (x | (x << 16)) & 0x0000ffff0000ffffull; x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+                                     x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full; x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull; return x; };
+      auto key = [&](int g) { return (spread((unsigned)seg_row[g] / z_order) << 1) | spread((unsigned)seg_col[g] / z_order); };
+      auto zsort = [&](std::vector<int>& v) { std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return key(a) < key(b); }); };
+      zsort(short_segs); zsort(long_segs);
+    }
+  }
   SK_HIP_TRY(b_short_segs_.upload(short_segs, s)); SK_HIP_TRY(b_long_segs_.upload(long_segs, s));
   d_.num_short_segments = (int)short_segs.size(); d_.num_long_segments = (int)long_segs.size();
   const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_, nx = nc + np;
