@@ -131,9 +131,17 @@ static int jvm_evaluate(void* user, double const* const* parameters, double* res
     if ((*g_vm)->AttachCurrentThread(g_vm, (void**)&env, NULL) != JNI_OK) return 0;
     attached = 1;
   }
-  const jboolean ok = (*env)->CallBooleanMethod(env, d->self, d->evaluate, HANDLE(parameters), HANDLE(residuals), HANDLE(jacobians));
-  int result = ok == JNI_TRUE;
-  if ((*env)->ExceptionCheck(env)) result = 0;  /* evaluate threw: the block cannot be evaluated; the exception surfaces when sk_solve returns */
+  /* an earlier evaluate() of this solve threw: the solver may still ask for other blocks (or retry the step) before it gives
+   * up, and calling into the JVM with an exception pending is undefined behaviour (an abort under -Xcheck:jni).  Every
+   * further evaluation fails without an up-call; the exception surfaces, untouched, when sk_solve returns (skSolve).
+   * (On a thread this function had to attach, DetachCurrentThread would drop a pending exception: such a thread has no Java
+   * frame to throw into — the failure is then reported by the solve's status alone.) */
+  int result = 0;
+  if (!(*env)->ExceptionCheck(env)) {
+    const jboolean ok = (*env)->CallBooleanMethod(env, d->self, d->evaluate, HANDLE(parameters), HANDLE(residuals), HANDLE(jacobians));
+    result = ok == JNI_TRUE;
+    if ((*env)->ExceptionCheck(env)) result = 0;  /* evaluate threw: the block cannot be evaluated */
+  }
   if (attached) (*g_vm)->DetachCurrentThread(g_vm);
   return result;
 }

@@ -32,6 +32,8 @@ object DoubleMatrix {
 /** std::vector<double*> (ceres.i:82) */
 class StdVectorDoublePointer {
   val handle: Long = SkeresNative.skPtrvecNew()
+  /** std::vector<double*>(n): n null pointers (CORE/RichDoubleMatrix.scala:74) */
+  def this(n: Int) = { this(); var i = 0; while (i < n) { SkeresNative.skPtrvecAdd(handle, 0L); i += 1 } }
   def add(p: DoublePointer): Unit = SkeresNative.skPtrvecAdd(handle, p.address)
   def set(i: Int, p: DoublePointer): Unit = SkeresNative.skPtrvecSet(handle, i, p.address)
   def get(i: Int): DoublePointer = new DoublePointer(SkeresNative.skPtrvecGet(handle, i))
@@ -41,9 +43,51 @@ class StdVectorDoublePointer {
   override def finalize(): Unit = SkeresNative.skPtrvecFree(handle)
 }
 
+/** std::vector<int> (ceres.i:79): what CostFunction's block sizes are to the JVM — `size` is a long and elements are read with
+  * `get`, as SWIG's proxy has them (CORE/CostFunctionToFunctor.scala:24-25, CORE/SizedCostFunction.scala:13). */
+class StdVectorInt {
+  private val values = scala.collection.mutable.ArrayBuffer.empty[Int]
+  def add(x: Int): Unit = values += x
+  def get(i: Int): Int = values(i)
+  def set(i: Int, x: Int): Unit = values(i) = x
+  def size: Long = values.length.toLong
+  def isEmpty: Boolean = values.isEmpty
+  def clear(): Unit = values.clear()
+  def toArray: Array[Int] = values.toArray
+}
+
 object Ownership extends Enumeration { val DO_NOT_TAKE_OWNERSHIP, TAKE_OWNERSHIP = Value }
 object LinearSolverType extends Enumeration { val DENSE_NORMAL_CHOLESKY = Value(0); val DENSE_QR = Value(1); val DENSE_SCHUR = Value(3) }
 object MinimizerType extends Enumeration { val LINE_SEARCH = Value(0); val TRUST_REGION = Value(1) }
+/** ceres::NumericDiffMethodType (ceres/types.h through ceres.i:137).  A class with members, as SWIG's Java enums are: the reference
+  * uses the name as a TYPE (CORE/NumericDiffCostFunction.scala:69, CORE/CostFunctor.scala:62) and imports its members
+  * (`import NumericDiffMethodType._`, CORE/NumericDiffCostFunction.scala:80). */
+sealed abstract class NumericDiffMethodType(val swigValue: Int)
+object NumericDiffMethodType {
+  case object CENTRAL extends NumericDiffMethodType(0)
+  case object FORWARD extends NumericDiffMethodType(1)
+  case object RIDDERS extends NumericDiffMethodType(2)
+}
+/** ceres::NumericDiffOptions (ceres/numeric_diff_options.h through ceres.i:39,143) with the defaults of Ceres 1.x; plain JVM state —
+  * numerically differentiated functors are evaluated on the JVM (CORE/NumericDiffCostFunction.scala:75-162) and reach the solver
+  * through the director path. */
+class NumericDiffOptions {
+  private var relativeStepSize = 1e-6
+  private var riddersRelativeInitialStepSize = 1e-2
+  private var maxNumRiddersExtrapolations = 10
+  private var riddersEpsilon = 1e-12
+  private var riddersStepShrinkFactor = 2.0
+  def getRelativeStepSize: Double = relativeStepSize
+  def setRelativeStepSize(v: Double): Unit = relativeStepSize = v
+  def getRiddersRelativeInitialStepSize: Double = riddersRelativeInitialStepSize
+  def setRiddersRelativeInitialStepSize(v: Double): Unit = riddersRelativeInitialStepSize = v
+  def getMaxNumRiddersExtrapolations: Int = maxNumRiddersExtrapolations
+  def setMaxNumRiddersExtrapolations(v: Int): Unit = maxNumRiddersExtrapolations = v
+  def getRiddersEpsilon: Double = riddersEpsilon
+  def setRiddersEpsilon(v: Double): Unit = riddersEpsilon = v
+  def getRiddersStepShrinkFactor: Double = riddersStepShrinkFactor
+  def setRiddersStepShrinkFactor(v: Double): Unit = riddersStepShrinkFactor = v
+}
 object TerminationType extends Enumeration { val CONVERGENCE = Value(0); val NO_CONVERGENCE = Value(1); val FAILURE = Value(2) }
 
 /** ceres::LossFunction as an opaque handle; the JVM proxy owns it (`%newobject`, ceres.i:160-167). */
@@ -73,11 +117,11 @@ object PredefinedLocalParameterizations {
   * code (SizedCostFunction.nativeHandle): a device functor id, a recorded body, or the director trampoline. */
 abstract class CostFunction {
   protected var numResidualsValue = 0
-  protected val blockSizes = scala.collection.mutable.ArrayBuffer.empty[Int]
+  protected val blockSizes = new StdVectorInt
   def setNumResiduals(n: Int): Unit = numResidualsValue = n
-  def numResiduals: Int = numResidualsValue
-  def mutableParameterBlockSizes: scala.collection.mutable.Buffer[Int] = blockSizes
-  def parameterBlockSizes: Seq[Int] = blockSizes
+  def numResiduals(): Int = numResidualsValue
+  def mutableParameterBlockSizes(): StdVectorInt = blockSizes
+  def parameterBlockSizes(): StdVectorInt = blockSizes
   /** CostFunction::Evaluate: `jacobians` may be null, and so may any of its rows. */
   def evaluate(parameters: DoublePointerPointer, residuals: DoublePointer, jacobians: DoublePointerPointer): Boolean
   /** what the native director calls (jvm_evaluate in skeres_amd_jni.c) */

@@ -1,5 +1,6 @@
 package org.somelightprojections.skeres
 
+import com.google.ceres.{NumericDiffMethodType, NumericDiffOptions}
 import scala.reflect.ClassTag
 import scala.{specialized => sp}
 import spire.algebra._
@@ -33,5 +34,10 @@ abstract class AutoDiffCostFunctor(kNumResiduals: Int, N: Int*) extends CostFunc
 
 /** Unchanged in shape (CORE/CostFunctor.scala:57-71): numerically differentiated functors are evaluated on the JVM. */
 abstract class NumericDiffCostFunctor(kNumResiduals: Int, N: Int*) extends CostFunctor(kNumResiduals, N: _*) {
+  /** A numerically differentiated cost function computed through this functor (CORE/CostFunctor.scala:61-64): the reference's own
+    * NumericDiffCostFunction.scala, unchanged — it extends SizedCostFunction and so reaches the solver through the director path. */
+  def toNumericDiffCostFunction(method: NumericDiffMethodType, options: Option[NumericDiffOptions] = None) =
+    NumericDiffCostFunction(method, options.getOrElse(new NumericDiffOptions), this)
+
   def apply(x: Array[Double]*): Array[Double]
 }

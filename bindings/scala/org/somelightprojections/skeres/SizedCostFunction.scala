@@ -10,7 +10,7 @@ abstract class SizedCostFunction(val kNumResiduals: Int, val N: Int*) extends Co
   require(N.indices.tail.forall(i => N(i) == 0 || N(i - 1) > 0),
     "Zero block cannot precede a non-zero block. Block sizes are (ignore trailing 0's): " + N.mkString(", "))
   setNumResiduals(kNumResiduals)
-  N.foreach(mutableParameterBlockSizes += _)
+  N.foreach(mutableParameterBlockSizes.add)
 
   private var director = 0L
   /** how this cost function reaches native code; AutoDiffCostFunction overrides it for device and recorded bodies */

@@ -44,6 +44,12 @@ __device__ __forceinline__ double* bal_rhs(const BalDev& d, int i) {
   return f.S + (size_t)f.rhs_row * f.ld + bal_pos(d, i, pi);
 }
 
+// LM diagonal of a coordinate from its squared column norm (BalDev::lm_*): the same operations, in the same order, as lm_diagonal_kernel
+__device__ __forceinline__ double bal_lm_diag(const BalDev& d, double colsq) {
+  const double radius = d.lm_radius_dev ? d.lm_radius_dev[0] : d.lm_radius;
+  return sqrt(fmin(fmax(colsq, d.lm_lo), d.lm_hi) / radius);
+}
+
 // rho(s) of observation o's loss: the one loss of the problem, or (mixed losses: BalDev::loss_of_obs) the observation's own —
 // a trivial one among robust ones is rho(s) = s, whose corrector is the identity.
 __device__ __forceinline__ void bal_loss_eval(const BalDev& d, size_t o, double s, double rho[3]) {
@@ -90,53 +96,97 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* out_partial, i
 // ---------------------------------------------------------------------------
 // kLoss: robust loss (loss.hpp) — the block's residuals and both Jacobian blocks are corrected before they
 // are stored, the cost term is rho(|r|^2).  A separate instantiation: the trivial-loss kernel stays as it was.
-template <bool kLoss>
+// Round 4, kRecords: the camera-major records of (F, r) — what bal_cam_records_kernel wrote in a launch of its own, re-reading
+// the planes — are staged in LDS as the columns come and written by the wave, 3.2 records per store instruction, next to the
+// planes.  (Also tried: forward mode in 12 / W passes of Jet<W>, W = 6 or 4, as the tape interpreter does — a Jet component
+// depends on the real parts and on that component of the operands only, so the passes give the same Jacobian — to fit more
+// than two waves per SIMD: the compiler keeps the body at 250 VGPRs whatever W, and capped at 128 it spills 400-800 bytes
+// per lane.  The loop over passes is kept in this form, with W = 12: one pass.)
+template <bool kLoss, bool kRecords>
 __global__ __launch_bounds__(kBlock) void bal_eval_jac_kernel(BalDev d) {
+  constexpr int W = 12;
+  __shared__ __attribute__((aligned(16))) double stage[kRecords ? kBlock / 64 : 1][kRecords ? 64 * kFcam : 2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double* st = stage[kRecords ? wv : 0];
   double acc[1] = {0.0};
-  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
-    if (d.is_host && d.is_host[o]) continue;  // the caller's host code evaluates this one (bal_host_jac_kernel)
-    const int ci = d.cam[o], pi = d.pt[o];
-    typedef Jet<12> J;
-    J cam[9], X[3], out[2];
+  // whole waves walk the observations (the records are written by the wave; the last wave may be partly out of range)
+  for (long o0 = ((long)blockIdx.x * (kBlock / 64) + wv) * 64; o0 < (long)d.N; o0 += (long)gridDim.x * kBlock) {
+    const long o = o0 + lane;
+    const bool live = o < (long)d.N && !(d.is_host && d.is_host[o]);  // (a host-evaluated observation: bal_host_jac_kernel)
+    const int my_slot = (kRecords && o < (long)d.N) ? d.obs_slot[o] : 0;  // where this observation's record goes (in flight during the arithmetic)
+    if (live) {
+      const int ci = d.cam[o], pi = d.pt[o];
+      typedef Jet<W> J;
+      double xcam[9], xpt[3];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) cam[k] = J(d.xc[9 * (size_t)ci + k], k);
+      for (int k = 0; k < 9; ++k) xcam[k] = d.xc[9 * (size_t)ci + k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) X[k] = J(d.xp[3 * (size_t)pi + k], 9 + k);
-    const J* params[2] = {cam, X};
-    const double c[2] = {d.obs[o], d.obs[(size_t)d.N + o]};
-    SnavelyReprojectionError::apply<J>(c, params, out);
-    const double r0 = out[0].a, r1 = out[1].a;
-    if (kLoss) {
-      const double sq = r0 * r0 + r1 * r1;
-      double rho[3];
-      bal_loss_eval(d, o, sq, rho);
-      const LossCorrector lc(sq, rho);
-      acc[0] += rho[0];
+      for (int k = 0; k < 3; ++k) xpt[k] = d.xp[3 * (size_t)pi + k];
+      const double c[2] = {d.obs[o], d.obs[(size_t)d.N + o]};
+      double r0 = 0.0, r1 = 0.0, sqrt_rho1 = 1.0, alpha_sq_norm = 0.0;
+#pragma unroll 1
+      for (int first = 0; first < 12; first += W) {
+        J cam[9], X[3], out[2];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        const double j0 = out[0].v[k], j1 = out[1].v[k];
-        const double rtj = lc.alpha_sq_norm * (r0 * j0 + r1 * j1);
-        out[0].v[k] = lc.sqrt_rho1 * (j0 - r0 * rtj);
-        out[1].v[k] = lc.sqrt_rho1 * (j1 - r1 * rtj);
+        for (int k = 0; k < 9; ++k) cam[k] = J(xcam[k], k - first);  // (a seed outside this pass's slots: a constant)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X[k] = J(xpt[k], 9 + k - first);
+        const J* params[2] = {cam, X};
+        SnavelyReprojectionError::apply<J>(c, params, out);
+        if (first == 0) {
+          r0 = out[0].a; r1 = out[1].a;
+          double s0 = r0, s1 = r1;
+          if (kLoss) {
+            const double sq = r0 * r0 + r1 * r1;
+            double rho[3];
+            bal_loss_eval(d, o, sq, rho);
+            const LossCorrector lc(sq, rho);
+            acc[0] += rho[0];
+            sqrt_rho1 = lc.sqrt_rho1; alpha_sq_norm = lc.alpha_sq_norm;
+            s0 = r0 * lc.residual_scaling; s1 = r1 * lc.residual_scaling;
+          } else {
+            acc[0] += r0 * r0 + r1 * r1;
+          }
+          d.r[o] = s0;
+          d.r[(size_t)d.N + o] = s1;
+          if (kRecords) { st[lane * kFcam + 18] = s0; st[lane * kFcam + 19] = s1; }
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const int k = first + w;
+          double j0 = out[0].v[w], j1 = out[1].v[w];
+          if (kLoss) {
+            const double rtj = alpha_sq_norm * (r0 * j0 + r1 * j1);
+            const double a0 = sqrt_rho1 * (j0 - r0 * rtj), a1 = sqrt_rho1 * (j1 - r1 * rtj);
+            j0 = a0; j1 = a1;
+          }
+          if (k < 9) {
+            const double s = d.scale_c[9 * (size_t)ci + k];
+            const double f0 = j0 * s, f1 = j1 * s;
+            d.F[(size_t)k * d.N + o] = f0;
+            d.F[(size_t)(9 + k) * d.N + o] = f1;
+            if (kRecords) { st[lane * kFcam + k] = f0; st[lane * kFcam + 9 + k] = f1; }
+          } else {
+            const double s = d.scale_p[3 * (size_t)pi + (k - 9)];
+            d.E[(size_t)(k - 9) * d.N + o] = j0 * s;
+            d.E[(size_t)(3 + k - 9) * d.N + o] = j1 * s;
+          }
+        }
       }
-      d.r[o] = r0 * lc.residual_scaling;
-      d.r[(size_t)d.N + o] = r1 * lc.residual_scaling;
-    } else {
-      d.r[o] = r0;
-      d.r[(size_t)d.N + o] = r1;
-      acc[0] += r0 * r0 + r1 * r1;
     }
+    if (kRecords) {
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
+      __builtin_amdgcn_wave_barrier();
+      const int nrec = (int)(((long)d.N - o0) < 64 ? ((long)d.N - o0) : 64);
+      // ten lanes to a record, 16 bytes each: 6.4 records per store instruction, the slots passed from lane to lane
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const double s = d.scale_c[9 * (size_t)ci + k];
-      d.F[(size_t)k * d.N + o] = out[0].v[k] * s;
-      d.F[(size_t)(9 + k) * d.N + o] = out[1].v[k] * s;
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double s = d.scale_p[3 * (size_t)pi + k];
-      d.E[(size_t)k * d.N + o] = out[0].v[9 + k] * s;
-      d.E[(size_t)(3 + k) * d.N + o] = out[1].v[9 + k] * s;
+      for (int i = 0; i < kFcam / 2; ++i) {
+        const int e2 = i * 64 + lane, rr = e2 / (kFcam / 2), f2 = e2 - rr * (kFcam / 2);
+        const int slot = __shfl(my_slot, rr, 64);
+        if (rr < nrec) reinterpret_cast<double2*>(d.Fcam + (size_t)slot * kFcam)[f2] = reinterpret_cast<const double2*>(st)[e2];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   block_sum<1>(acc, d.partial, d.partial_stride);
@@ -166,13 +216,9 @@ __global__ __launch_bounds__(kBlock) void bal_eval_cost_kernel(BalDev d) {
     } else {
       acc[0] += out[0] * out[0] + out[1] * out[1];
     }
-    double m0 = 0.0, m1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const double s = d.step_c[9 * (size_t)ci + k];
-      m0 += d.F[(size_t)k * d.N + o] * s;
-      m1 += d.F[(size_t)(9 + k) * d.N + o] * s;
-    }
+    // F s_c = -(F y_c): the back-substitution formed F y_c per observation (bal_obs_backsub_kernel: d.u planes 3 and 4), in the
+    // order the sum over the camera's nine coordinates was formed here until round 4 — the same bits, 128 bytes less to read
+    double m0 = -d.u[3 * (size_t)d.N + o], m1 = -d.u[4 * (size_t)d.N + o];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const double s = d.step_p[3 * (size_t)pi + k];
@@ -264,13 +310,9 @@ __global__ __launch_bounds__(kBlock) void bal_eval_cost_tape_kernel(BalDev d, Ta
     } else {
       acc[0] += out[0] * out[0] + out[1] * out[1];
     }
-    double m0 = 0.0, m1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const double s = d.step_c[9 * (size_t)ci + k];
-      m0 += d.F[(size_t)k * d.N + o] * s;
-      m1 += d.F[(size_t)(9 + k) * d.N + o] * s;
-    }
+    // F s_c = -(F y_c): the back-substitution formed F y_c per observation (bal_obs_backsub_kernel: d.u planes 3 and 4), in the
+    // order the sum over the camera's nine coordinates was formed here until round 4 — the same bits, 128 bytes less to read
+    double m0 = -d.u[3 * (size_t)d.N + o], m1 = -d.u[4 * (size_t)d.N + o];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const double s = d.step_p[3 * (size_t)pi + k];
@@ -348,13 +390,9 @@ __global__ __launch_bounds__(kBlock) void bal_host_cost_kernel(BalDev d, int par
     } else {
       acc[0] += n0 * n0 + n1 * n1;
     }
-    double m0 = 0.0, m1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const double s = d.step_c[9 * (size_t)ci + k];
-      m0 += d.F[(size_t)k * d.N + o] * s;
-      m1 += d.F[(size_t)(9 + k) * d.N + o] * s;
-    }
+    // F s_c = -(F y_c): the back-substitution formed F y_c per observation (bal_obs_backsub_kernel: d.u planes 3 and 4), in the
+    // order the sum over the camera's nine coordinates was formed here until round 4 — the same bits, 128 bytes less to read
+    double m0 = -d.u[3 * (size_t)d.N + o], m1 = -d.u[4 * (size_t)d.N + o];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const double s = d.step_p[3 * (size_t)pi + k];
@@ -489,11 +527,6 @@ __global__ void lm_diagonal_kernel(const double* colsq, double* D, int n, double
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) D[j] = sqrt(fmin(fmax(colsq[j], lo), hi) / radius);
 }
-// the same with the radius in device memory: the launch is then identical from one iteration to the next (hipGraph replay)
-__global__ void lm_diagonal_dev_kernel(const double* colsq, double* D, int n, double lo, double hi, const double* radius) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) D[j] = sqrt(fmin(fmax(colsq[j], lo), hi) / radius[0]);
-}
 // partial[0] = max |gs_j / scale_j| , partial[1] = sum x_j^2 over this block
 __global__ __launch_bounds__(kBlock) void grad_max_xnorm_kernel(const double* gs, const double* scale, const double* x,
                                                                 int n, double* partial, int stride) {
@@ -552,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void bal_point_block_kernel(BalDev d) {
   t00 = point_lanes_sum(t00); t10 = point_lanes_sum(t10); t11 = point_lanes_sum(t11);
   t20 = point_lanes_sum(t20); t21 = point_lanes_sum(t21); t22 = point_lanes_sum(t22);
   if (sub != 0) return;
-  const double d0 = d.D_p[3 * (size_t)p], d1 = d.D_p[3 * (size_t)p + 1], d2 = d.D_p[3 * (size_t)p + 2];
+  const double d0 = bal_lm_diag(d, d.colsq_p[3 * (size_t)p]), d1 = bal_lm_diag(d, d.colsq_p[3 * (size_t)p + 1]), d2 = bal_lm_diag(d, d.colsq_p[3 * (size_t)p + 2]);
   t00 += d0 * d0; t11 += d1 * d1; t22 += d2 * d2;
   // Cholesky T = L L^T
   const double l00 = sqrt(t00);
@@ -589,6 +622,7 @@ __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
   // whole waves walk the observations (the last wave may be partly out of range)
   for (long base = (long)(blockIdx.x * kBlock + wave * 64); base < (long)d.N; base += (long)gridDim.x * kBlock) {
     const long o = base + lane;
+    const int my_slot = o < (long)d.N ? d.obs_slot[o] : 0;
     if (o < (long)d.N) {
       const int p = d.pt[o];
       const double m00 = d.M[p], m10 = d.M[P + p], m11 = d.M[2 * P + p], m20 = d.M[3 * P + p], m21 = d.M[4 * P + p], m22 = d.M[5 * P + p];
@@ -616,9 +650,10 @@ __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
       const int rec = 4 * it + sub;
+      const int slot = __shfl(my_slot, rec, 64);
       if (rec < nrec) {
         const double2 v = *reinterpret_cast<const double2*>(&mine[rec * kLs + 2 * chunk]);
-        *reinterpret_cast<double2*>(d.What + (size_t)d.obs_slot[base + rec] * kWs + 2 * chunk) = v;
+        *reinterpret_cast<double2*>(d.What + (size_t)slot * kWs + 2 * chunk) = v;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -797,17 +832,12 @@ __global__ void bal_finish_S_kernel(BalDev d, int parts) {
   if (!((parts >> part) & 1) || !d.front[part].S) return;
   int ld;
   double* blk = bal_block(d, i, i, &ld);
-  blk[(size_t)c * ld + c] += d.D_c[j] * d.D_c[j];
+  const double D = bal_lm_diag(d, d.colsq_c[j]);
+  blk[(size_t)c * ld + c] += D * D;
 }
 __global__ void set_diagonal_kernel(double* S, int ld, int from, int to, double value) {
   const int j = from + blockIdx.x * blockDim.x + threadIdx.x;
   if (j < to) S[(size_t)j * ld + j] = value;
-}
-__global__ void bal_gather_y_kernel(BalDev d) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= 9 * d.C) return;
-  const int i = j / 9, c = j - 9 * i, part = bal_part(d, i);
-  d.y_c[j] = d.front[part].S ? d.y_front[part][bal_pos(d, i, part) + c] : 0.0;  // (another rank's segment: no step here)
 }
 
 // ---------------------------------------------------------------------------
@@ -828,6 +858,8 @@ __global__ __launch_bounds__(kBlock) void bal_obs_backsub_kernel(BalDev d) {
     d.u[o] = d.E[o] * f0 + d.E[3 * N + o] * f1;
     d.u[N + o] = d.E[N + o] * f0 + d.E[4 * N + o] * f1;
     d.u[2 * N + o] = d.E[2 * N + o] * f0 + d.E[5 * N + o] * f1;
+    d.u[3 * N + o] = f0;  // F y_c itself: the candidate evaluation's model residual starts from it (bal_eval_cost_kernel)
+    d.u[4 * N + o] = f1;
   }
 }
 
@@ -862,30 +894,53 @@ __global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
       acc[0] += df * df;
     }
   }
-  block_sum<1>(acc, d.partial, d.partial_stride);
+  block_sum<1>(acc, d.partial + d.partial_stride, d.partial_stride);  // (row 1: row 0 holds the cameras' partial sums, bal_cam_step_kernel)
 }
 
 // cameras: step_c = -y_c ; xc_new = xc + step_c * scale_c ; out[0] = |delta_c|^2
 // (norm_lo, norm_hi: the coordinates whose step this rank accounts for — all of them, or in a segmented world its own
 // segment's, the separator's being counted by the head's rank alone)
-__global__ __launch_bounds__(1024) void bal_cam_step_kernel(BalDev d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2) {
-  double acc = 0.0;
+// Round 4: one thread per coordinate over many workgroups (one workgroup walked the 9 C values in sixteen dependent rounds:
+// 17 us), reading the reduced system's solution straight from the fronts (what bal_gather_y_kernel did in a launch of its
+// own) and leaving y_c for the back-substitution; the workgroups' partial sums go to row 0 of `partial`, summed in a fixed
+// order by the final reduction that follows the points' (launch_bal_point_backsub).
+__global__ __launch_bounds__(kBlock) void bal_cam_step_kernel(BalDev d, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2) {
+  double acc[1] = {0.0};
   const int n = 9 * d.C;
-  // one workgroup (the sum's order is fixed), sixteen waves: 9 C values are a few loads per lane
-  for (int j = threadIdx.x; j < n; j += 1024) {
-    const double st = -d.y_c[j];
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j < n) {
+    const int i = j / 9, c = j - 9 * i, part = bal_part(d, i);
+    const double y = d.front[part].S ? d.y_front[part][bal_pos(d, i, part) + c] : 0.0;  // (another rank's segment: no step here)
+    d.y_c[j] = y;
+    const double st = -y;
     d.step_c[j] = st;
     const double xo = d.xc[j];
     const double xn = xo + st * d.scale_c[j];
     d.xc_new[j] = xn;
     const double df = xo - xn;
-    if ((j >= norm_lo && j < norm_hi) || (j >= norm_lo2 && j < norm_hi2)) acc += df * df;
+    if ((j >= norm_lo && j < norm_hi) || (j >= norm_lo2 && j < norm_hi2)) acc[0] += df * df;
   }
-  __shared__ double sh[16];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  block_sum<1>(acc, d.partial, d.partial_stride);
+}
+// Up to four reductions of different lengths in one launch: workgroup k reduces partial[row[k] * stride .. + count[k]) — a sum or a
+// maximum, in a fixed order — into *out[k].
+__global__ __launch_bounds__(1024) void final_reduce_rows_kernel(const double* partial, int stride, ReduceRows rows) {
+  __shared__ double sh[1024];
+  const int k = blockIdx.x, count = rows.count[k];
+  const bool is_max = rows.is_max[k] != 0;
+  const double* src = partial + (size_t)rows.row[k] * stride;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < count; i += 1024) a = is_max ? fmax(a, src[i]) : a + src[i];  // (Venice-1778: 31 000 partial sums of the points)
+  sh[threadIdx.x] = a;
   __syncthreads();
-  if (threadIdx.x == 0) { double s = 0.0; for (int i = 0; i < 16; ++i) s += sh[i]; out[0] = s; }
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] = is_max ? fmax(sh[threadIdx.x], sh[threadIdx.x + w]) : sh[threadIdx.x] + sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *rows.out[k] = sh[0];
+}
+void launch_final_reduce_rows(const double* partial, int stride, const ReduceRows& rows, hipStream_t s) {
+  if (rows.n > 0) hipLaunchKernelGGL(final_reduce_rows_kernel, dim3(rows.n), dim3(1024), 0, s, partial, stride, rows);
 }
 
 // Lower block triangle of S <-> packed buffer (see bal_kernels.hpp), 16 bytes per lane.
@@ -934,9 +989,12 @@ void launch_tri_pack(double* S, int ld, double* packed, int nblk, const int* col
   if (nblk > 0) hipLaunchKernelGGL(tri_pack_kernel, dim3(64, nblk), dim3(256), 0, s, S, ld, packed, col0, off, to_packed ? 1 : 0);
 }
 
-void launch_bal_eval_jac(const BalDev& d, hipStream_t s) {
-  if (d.loss_root >= 0) hipLaunchKernelGGL(bal_eval_jac_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
-  else hipLaunchKernelGGL(bal_eval_jac_kernel<false>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
+// records: also write the camera-major records of (F, r) (no host-evaluated observations, whose rows arrive after this launch)
+void launch_bal_eval_jac(const BalDev& d, bool records, hipStream_t s) {
+  const dim3 g(grid_for((d.N + 63) / 64 * 64)), b(kBlock);
+#define SK_EVAL_JAC(LOSS) { if (records) hipLaunchKernelGGL((bal_eval_jac_kernel<LOSS, true>), g, b, 0, s, d); else hipLaunchKernelGGL((bal_eval_jac_kernel<LOSS, false>), g, b, 0, s, d); }
+  if (d.loss_root >= 0) SK_EVAL_JAC(true) else SK_EVAL_JAC(false)
+#undef SK_EVAL_JAC
 }
 void launch_bal_eval_cost(const BalDev& d, hipStream_t s) {
   if (d.loss_root >= 0) hipLaunchKernelGGL(bal_eval_cost_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
@@ -985,7 +1043,6 @@ void launch_bal_pt_reduce(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaun
 void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(jacobi_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, scale, n); }
 void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(apply_scale_to_reductions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, gs, scale, n); }
 void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(lm_diagonal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, D, n, lo, hi, radius); }
-void launch_lm_diagonal_dev(const double* colsq, double* D, int n, double lo, double hi, const double* radius, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(lm_diagonal_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, D, n, lo, hi, radius); }
 int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x, int n, double* partial, int stride, hipStream_t s) {
   const int g = grid_for(n, 256);
   hipLaunchKernelGGL(grad_max_xnorm_kernel, dim3(g), dim3(kBlock), 0, s, gs, scale, x, n, partial, stride);
@@ -1019,7 +1076,8 @@ __global__ void bal_finish_all_kernel(BalDev d, BalFinishRanges r, int jmax) {
     if (d.front[part].S) {
       int ld;
       double* blk = bal_block(d, i, i, &ld);
-      blk[(size_t)c * ld + c] += d.D_c[j] * d.D_c[j];
+      const double D = bal_lm_diag(d, d.colsq_c[j]);
+      blk[(size_t)c * ld + c] += D * D;
     }
   }
 #pragma unroll
@@ -1035,15 +1093,18 @@ void launch_bal_finish_S(const BalDev& d, int parts, hipStream_t s) { hipLaunchK
 void launch_set_diagonal(double* S, int ld, int from, int to, double value, hipStream_t s) {
   if (to > from) hipLaunchKernelGGL(set_diagonal_kernel, dim3((to - from + 255) / 256), dim3(256), 0, s, S, ld, from, to, value);
 }
-void launch_bal_gather_y(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_gather_y_kernel, dim3((9 * d.C + 255) / 256), dim3(256), 0, s, d); }
-int launch_bal_point_backsub(const BalDev& d, hipStream_t s) {
-  const int g = bal_point_blocks(d.P);
+// Phase D up to the candidate point: the cameras' step from the fronts' solutions (out[0] = |delta_c|^2 of the coordinates in the two
+// ranges), the points' back-substitution (out[1] = |delta_p|^2) — three launches and one final reduction
+void launch_bal_backsub(const BalDev& d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2, hipStream_t s) {
+  const int gc = (9 * d.C + kBlock - 1) / kBlock, gp = bal_point_blocks(d.P);
+  hipLaunchKernelGGL(bal_cam_step_kernel, dim3(gc), dim3(kBlock), 0, s, d, norm_lo, norm_hi, norm_lo2, norm_hi2);
   hipLaunchKernelGGL(bal_obs_backsub_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
-  hipLaunchKernelGGL(bal_point_backsub_kernel, dim3(g), dim3(kBlock), 0, s, d);
-  return g;
-}
-void launch_bal_cam_step(const BalDev& d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2, hipStream_t s) {
-  hipLaunchKernelGGL(bal_cam_step_kernel, dim3(1), dim3(1024), 0, s, d, out, norm_lo, norm_hi, norm_lo2, norm_hi2);
+  hipLaunchKernelGGL(bal_point_backsub_kernel, dim3(gp), dim3(kBlock), 0, s, d);
+  ReduceRows rows;
+  rows.n = 2;
+  rows.row[0] = 0; rows.count[0] = gc; rows.out[0] = out;
+  rows.row[1] = 1; rows.count[1] = d.P > 0 ? gp : 0; rows.out[1] = out + 1;
+  launch_final_reduce_rows(d.partial, d.partial_stride, rows, s);
 }
 
 }  // namespace sk

@@ -40,11 +40,14 @@ struct BalDev {
   double* scale_c;  double* scale_p;  // Jacobi scaling
   double* colsq_c;  double* colsq_p;  // squared column norms of the scaled Jacobian
   double* gs_c;  double* gs_p;        // scaled gradient J_s^T r
-  double* D_c;  double* D_p;          // LM diagonal
+  // LM diagonal D_j = sqrt(clamp(colsq_j, lm_lo, lm_hi) / radius) (LevenbergMarquardtStrategy), formed where it is used — the points'
+  // Schur blocks, the cameras' diagonal entries — since round 4 (a launch of its own over every coordinate until then).  The radius is
+  // lm_radius, or *lm_radius_dev when that is set (hipGraph replay: the launch must not change from one iteration to the next)
+  double lm_lo, lm_hi, lm_radius;  const double* lm_radius_dev;
   double* step_c;  double* step_p;    // step in scaled space
   double* y_c;                        // reduced-system solution
   // per-observation planes
-  double* r;  double* F;  double* E;  double* What;  double* u;  // u [3][N]: E^T F y_c per observation (back-substitution)
+  double* r;  double* F;  double* E;  double* What;  double* u;  // u [5][N]: E^T F y_c per observation (back-substitution), then F y_c itself (2)
   // CAMERA-major copy of what the per-camera kernels read of an observation: record e (the e-th entry of the camera CSR,
   // i.e. observation cam_obs[e]) holds F row 0 (9), F row 1 (9), r (2).  The planes above are point-major — lane o streams —
   // and a wave that walks a camera's observations through them fetches 20 scattered 64-byte sectors per observation for
@@ -91,7 +94,7 @@ void launch_zero_envelope(double* S, int ld, const int* col0, int nblk, hipStrea
 size_t tri_packed_elems(int nblk);
 // col0[kb]: first block column of block row kb that travels; off[kb]: where the row starts in the packed buffer (elements)
 void launch_tri_pack(double* S, int ld, double* packed, int nblk, const int* col0, const long long* off, bool to_packed, hipStream_t s);
-void launch_bal_eval_jac(const BalDev& d, hipStream_t s);
+void launch_bal_eval_jac(const BalDev& d, bool records, hipStream_t s);  // records: + the camera-major records of (F, r) (launch_bal_cam_records)
 void launch_bal_eval_cost(const BalDev& d, hipStream_t s);
 // the same two for a recorded functor (tape.hpp); bal_tape_width == 0: its register file does not fit the LDS
 int bal_tape_width(const Tape& t);
@@ -109,9 +112,10 @@ void launch_bal_pt_reduce(const BalDev& d, hipStream_t s);
 void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s);
 void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* scale, int n, hipStream_t s);
 void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s);
-void launch_lm_diagonal_dev(const double* colsq, double* D, int n, double lo, double hi, const double* radius, hipStream_t s);
 int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x, int n, double* partial, int stride, hipStream_t s);
 void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s);
+struct ReduceRows { int n = 0; int row[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0}, is_max[4] = {0, 0, 0, 0}; double* out[4] = {nullptr, nullptr, nullptr, nullptr}; };
+void launch_final_reduce_rows(const double* partial, int stride, const ReduceRows& rows, hipStream_t s);  // up to four reductions of different lengths, one launch
 void launch_bal_point_block(const BalDev& d, hipStream_t s);
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s);
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s);
@@ -121,8 +125,8 @@ void launch_bal_finish_S(const BalDev& d, int parts, hipStream_t s);  // D_c^2 o
 struct BalFinishRanges { double* S[4] = {nullptr, nullptr, nullptr, nullptr}; int ld[4] = {0, 0, 0, 0}, from[4] = {0, 0, 0, 0}, to[4] = {0, 0, 0, 0}; double value[4] = {0, 0, 0, 0}; };
 void launch_bal_finish_all(const BalDev& d, const BalFinishRanges& r, hipStream_t s);  // ... of every camera, + S[k][j][j] = value[k] for from[k] <= j < to[k]
 void launch_set_diagonal(double* S, int ld, int from, int to, double value, hipStream_t s);  // S[j][j] = value, from <= j < to
-void launch_bal_gather_y(const BalDev& d, hipStream_t s);  // y_c[9 i + k] from the fronts' solutions
-int launch_bal_point_backsub(const BalDev& d, hipStream_t s);
-void launch_bal_cam_step(const BalDev& d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2, hipStream_t s);
+// y_c from the fronts' solutions, the cameras' step (out[0] = |delta_c|^2 over [norm_lo, norm_hi) and [norm_lo2, norm_hi2)), the points'
+// back-substitution and step (out[1] = |delta_p|^2)
+void launch_bal_backsub(const BalDev& d, double* out, int norm_lo, int norm_hi, int norm_lo2, int norm_hi2, hipStream_t s);
 
 }  // namespace sk

@@ -239,7 +239,7 @@ class BalSolver : public SolverBase {
   DevBuf<int> b_loss_of_obs_;
   DevBuf<int> b_cam_, b_pt_, b_pt_start_, b_cam_start_, b_cam_obs_, b_obs_slot_, b_seg_start_, b_seg_row_, b_seg_col_, b_pair_row_, b_pair_col_, b_short_segs_, b_long_segs_;
   int *fail_p_ = nullptr, *info_p_ = nullptr;  // device flags: slots 14 and 15 of b_scal_ (one reset, one copy back with the scalars)
-  DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_D_, b_step_, b_y_,
+  DevBuf<double> b_obs_, b_xc_, b_xp_, b_xc_new_, b_xp_new_, b_scale_, b_colsq_, b_gs_, b_step_, b_y_,
       b_r_, b_F_, b_Fcam_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
   std::vector<int> env_tail_;  // ... and its tail profile when loop-closure cameras are ordered into a trailing border (choose_border); empty = none
@@ -312,6 +312,7 @@ class BalSolver : public SolverBase {
   hipStream_t zero_stream_ = nullptr;
   hipEvent_t ev_zero_ = nullptr;
   bool zero_pending_ = false;
+  bool zero_deferred_ = false;  // the step's results are in, the zeroing is not enqueued yet: behind the Jacobian evaluation's first launch (round 4)
   bool pair_claimed_ = false;  // cholesky_claim_pair_servers: this solver may run a partner front's server beside its own
  public:
   ~BalSolver() override {
@@ -1160,18 +1161,9 @@ int BalSolver::setup() {
   // points.  (Round 1 sorted the long list by length, longest first, against a long tail: 2.14 ms on Venice-1778 where
   // camera order takes 1.65.  Sorting the short list by length, so that the seven lane groups of a wave finish together,
   // changes nothing in time and fetches 588 MB instead of 345 on Ladybug-1723.)
-  {
-    // EXPERIMENT (round 4): the lists in Z-order of (row camera, column camera) instead of row-major — a run of consecutive
-    // segments then stays inside a small square of camera pairs, whose rows' AND columns' records fit an XCD's L2
-    static const int z_order = getenv("SK_PAIR_Z_ORDER") ? atoi(getenv("SK_PAIR_Z_ORDER")) : 0;
-    if (z_order) {
-      auto spread = [](unsigned v) { unsigned long long x = v; x = (x | (x << 16)) & 0x0000ffff0000ffffull; x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
-                                     x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full; x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull; return x; };
-      auto key = [&](int g) { return (spread((unsigned)seg_row[g] / z_order) << 1) | spread((unsigned)seg_col[g] / z_order); };
-      auto zsort = [&](std::vector<int>& v) { std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return key(a) < key(b); }); };
-      zsort(short_segs); zsort(long_segs);
-    }
-  }
+  // (Round 4 tried the lists in Z-order of (row camera, column camera) — runs of consecutive segments inside small squares of
+  // camera pairs, so that the rows' AND the columns' records stay in an XCD's L2: no gain, Schur assembly 0.41 -> 0.42-0.44 ms on
+  // Ladybug-1723, 2.46 -> 2.40-2.54 on Venice-1778 for cells of 1, 4 and 16 cameras: the gathers are not bound by L2 misses.)
   SK_HIP_TRY(b_short_segs_.upload(short_segs, s)); SK_HIP_TRY(b_long_segs_.upload(long_segs, s));
   d_.num_short_segments = (int)short_segs.size(); d_.num_long_segments = (int)long_segs.size();
   const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_, nx = nc + np;
@@ -1180,7 +1172,7 @@ int BalSolver::setup() {
   for (int q = 0; q < P_; ++q) std::memcpy(&x[nc + 3 * (size_t)q], p.block_ptr[pt_block_[local_pt_[q]]], 3 * sizeof(double));
   // x vectors are stored [cameras | points] so whole-vector kernels run once
   SK_HIP_TRY(b_xc_.upload(x, s)); SK_HIP_TRY(b_xc_new_.alloc(nx));
-  SK_HIP_TRY(b_scale_.alloc(nx)); SK_HIP_TRY(b_colsq_.alloc(nx)); SK_HIP_TRY(b_gs_.alloc(nx)); SK_HIP_TRY(b_D_.alloc(nx)); SK_HIP_TRY(b_step_.alloc(nx));
+  SK_HIP_TRY(b_scale_.alloc(nx)); SK_HIP_TRY(b_colsq_.alloc(nx)); SK_HIP_TRY(b_gs_.alloc(nx)); SK_HIP_TRY(b_step_.alloc(nx));
   {
     // scale starts as the mask of free coordinates: 1, or 0 for a coordinate that is held constant — a constant parameter
     // block (Problem::SetParameterBlockConstant) or the constant coordinates of a SubsetParameterization (ceres.i:186-210);
@@ -1200,7 +1192,7 @@ int BalSolver::setup() {
   }
   SK_HIP_TRY(b_y_.alloc(npad_ + 128));
   SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_Fcam_.alloc(kFcam * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
-  SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(3 * (size_t)N_));
+  SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(5 * (size_t)N_));
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
   // ---- the fronts of the reduced camera system ----
   std::vector<int> border_row_h[2], leaf_map_h, leaf_gmap_h;
@@ -1283,7 +1275,7 @@ int BalSolver::setup() {
     mapB[9 * nsep] = 9 * nsep;  // right-hand-side row
     SK_HIP_TRY(b_mapB_.upload(mapB, s));
   }
-  partial_stride_ = std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_)), 256) + bal_partial_blocks((int)host_obs_.size());
+  partial_stride_ = std::max(std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_)), (9 * C_ + 255) / 256), 256) + bal_partial_blocks((int)host_obs_.size());
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
   SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_scal_.zero(s)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
   fail_p_ = reinterpret_cast<int*>(b_scal_.p + 14); info_p_ = reinterpret_cast<int*>(b_scal_.p + 15);
@@ -1296,7 +1288,7 @@ int BalSolver::setup() {
   d_.pair_row_obs = b_pair_row_.p; d_.pair_col_obs = b_pair_col_.p;
   d_.xc = b_xc_.p; d_.xp = b_xc_.p + nc; d_.xc_new = b_xc_new_.p; d_.xp_new = b_xc_new_.p + nc;
   d_.scale_c = b_scale_.p; d_.scale_p = b_scale_.p + nc; d_.colsq_c = b_colsq_.p; d_.colsq_p = b_colsq_.p + nc;
-  d_.gs_c = b_gs_.p; d_.gs_p = b_gs_.p + nc; d_.D_c = b_D_.p; d_.D_p = b_D_.p + nc; d_.step_c = b_step_.p; d_.step_p = b_step_.p + nc;
+  d_.gs_c = b_gs_.p; d_.gs_p = b_gs_.p + nc; d_.step_c = b_step_.p; d_.step_p = b_step_.p + nc;
   d_.y_c = b_y_.p; d_.r = b_r_.p; d_.F = b_F_.p; d_.Fcam = b_Fcam_.p; d_.E = b_E_.p; d_.What = b_W_.p; d_.u = b_rt_.p; d_.M = b_M_.p; d_.q = b_q_.p;
   for (int f = 0; f < 3; ++f) {
     d_.front[f].S = fr_[f].nblk > 0 ? b_S_.p + fr_[f].s_off : nullptr; d_.front[f].ld = (int)fr_[f].dim; d_.front[f].interior = fr_[f].ncols * 128;
@@ -1426,8 +1418,18 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   CaptureGuard capture(s, graph && !replay, &graph_mode_);  // an early return below must not leave the stream capturing
   if (!replay) {
   kt_.begin("bal_eval_jac", s);
-  if (tape_mode_) launch_bal_eval_jac_tape(d_, tape_dev_, s); else launch_bal_eval_jac(d_, s);
+  // (the camera-major records of (F, r) come out of the evaluation kernel itself, unless rows of host-evaluated observations are
+  // still to arrive or the functor is a recorded one: then bal_cam_records_kernel transposes the planes as until round 3)
+  const bool fused_records = !tape_mode_ && d_.num_host == 0;
+  if (tape_mode_) launch_bal_eval_jac_tape(d_, tape_dev_, s); else launch_bal_eval_jac(d_, fused_records, s);
   kt_.end("bal_eval_jac", s);
+  if (zero_deferred_ && zero_stream_ && !graph) {  // the envelope of the reduced system zeroed next to this evaluation (try_step_once)
+    for (int f = 0; f < 3; ++f)
+      if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, b_zero_col0_f_[f].p, fr_[f].nblk, zero_stream_);
+    SK_HIP_TRY(hipEventRecord(ev_zero_, zero_stream_));
+    zero_pending_ = true;
+    zero_deferred_ = false;
+  }
   int nb = bal_partial_blocks(N_);
   if (d_.num_host > 0) {
     bool failed = false;
@@ -1436,7 +1438,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
     if (failed) return SK_ERR_EVALUATION_FAILED;
     nb += launch_bal_host_jac(d_, nb, s);
   }
-  kt_.begin("bal_cam_records", s); launch_bal_cam_records(d_, s); kt_.end("bal_cam_records", s);
+  if (!fused_records) { kt_.begin("bal_cam_records", s); launch_bal_cam_records(d_, s); kt_.end("bal_cam_records", s); }
   kt_.begin("bal_cam_reduce", s); launch_bal_cam_reduce(d_, s); kt_.end("bal_cam_reduce", s);
   launch_bal_pt_reduce(d_, s);
   if (opt_.allreduce) {  // camera columns are summed over all ranks' observations
@@ -1459,6 +1461,18 @@ int BalSolver::evaluate_with_jacobian(bool first) {
     launch_apply_scale_to_reductions(b_colsq_.p, b_gs_.p, b_scale_.p, (int)(nc + np), s);
   }
   // scalars: sum r^2 (slot 4) ; gradient max-norm and |x|^2 (cameras once, points local)
+  if (!opt_.allreduce) {
+    // one process: cameras and points as ONE vector ([cameras | points] in every buffer), and the three reductions — sum r^2,
+    // max |g|, |x|^2 — in one launch (round 4: five launches of ~6 us each became two)
+    const int g = launch_grad_max_xnorm(b_gs_.p, b_scale_.p, d_.xc, (int)(nc + np), b_partial_.p + (size_t)partial_stride_, partial_stride_, s);
+    // (slots 2 and 3, the points' share in a world of ranks, stay zero: it is inside the cameras' slots here)
+    ReduceRows rows;
+    rows.n = 3;
+    rows.row[0] = 0; rows.count[0] = nb; rows.out[0] = b_scal_.p + 4;
+    rows.row[1] = 1; rows.count[1] = g; rows.is_max[1] = 1; rows.out[1] = b_scal_.p;
+    rows.row[2] = 2; rows.count[2] = g; rows.out[2] = b_scal_.p + 1;
+    launch_final_reduce_rows(b_partial_.p, partial_stride_, rows, s);
+  } else {
   launch_final_reduce(b_partial_.p, partial_stride_, nb, 1, 0, b_scal_.p + 4, s);
   // cameras: every rank holds all of them — but in a segmented world only its own segment's (and the separator's) are
   // current, and the separator's |x|^2 must be counted once: the head's rank takes it
@@ -1472,6 +1486,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   launch_final_reduce(b_partial_.p, partial_stride_, gc, 2, 1, b_scal_.p, s);
   const int gp = launch_grad_max_xnorm(d_.gs_p, d_.scale_p, d_.xp, (int)np, b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, s);
   launch_final_reduce(b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, np ? gp : 0, 2, 1, b_scal_.p + 2, s);
+  }
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   if (graph) {
@@ -1521,13 +1536,15 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   }
   CaptureGuard capture(s, graph && !replay, &graph_mode_);
   if (!replay) {
+  // the LM diagonal is formed where it is used (bal_lm_diag): the radius travels in the kernel arguments, or — a replayed graph —
+  // through device memory
+  d_.lm_lo = opt_.min_lm_diagonal; d_.lm_hi = opt_.max_lm_diagonal; d_.lm_radius = radius; d_.lm_radius_dev = nullptr;
   if (graph) {
     SK_HIP_TRY(hipMemcpyAsync(b_scal_.p + 12, h_scal_ + 32, sizeof(double), hipMemcpyHostToDevice, s));
-    launch_lm_diagonal_dev(b_colsq_.p, b_D_.p, (int)(nc + np), opt_.min_lm_diagonal, opt_.max_lm_diagonal, b_scal_.p + 12, s);
-  } else {
-    launch_lm_diagonal(b_colsq_.p, b_D_.p, (int)(nc + np), opt_.min_lm_diagonal, opt_.max_lm_diagonal, radius, s);
+    d_.lm_radius_dev = b_scal_.p + 12;
   }
   // ---- B. Schur complement assembly ----
+  zero_deferred_ = false;
   if (zero_pending_) {
     SK_HIP_TRY(hipStreamWaitEvent(s, ev_zero_, 0));  // zeroed since the last step's results came in
     zero_pending_ = false;
@@ -1609,7 +1626,6 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok(), -1, 1, nullptr, R.tl());
     cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), info_p_, R.tl());
   }
-  launch_bal_gather_y(d_, s);
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----
   {
@@ -1619,10 +1635,8 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
       lo = 9 * my_lo_; hi = 9 * my_hi_;
       if (role_ == 0) { lo2 = 9 * cam_b_; hi2 = (int)nc; }
     }
-    launch_bal_cam_step(d_, b_scal_.p + 8, lo, hi, lo2, hi2, s);
+    launch_bal_backsub(d_, b_scal_.p + 8, lo, hi, lo2, hi2, s);  // (|delta_c|^2 to slot 8, |delta_p|^2 to slot 9)
   }
-  const int gb = launch_bal_point_backsub(d_, s);
-  launch_final_reduce(b_partial_.p, partial_stride_, P_ > 0 ? gb : 0, 1, 0, b_scal_.p + 9, s);
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvBacksub], s));
   kt_.begin("bal_eval_cost", s);
   if (tape_mode_) launch_bal_eval_cost_tape(d_, tape_dev_, s); else launch_bal_eval_cost(d_, s);
@@ -1643,12 +1657,10 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
   }
   SK_HIP_TRY(hipStreamSynchronize(s));
-  if (!graph && zero_stream_) {  // (everything that reads S is done: see zero_stream_)
-    for (int f = 0; f < 3; ++f)
-      if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, b_zero_col0_f_[f].p, fr_[f].nblk, zero_stream_);
-    SK_HIP_TRY(hipEventRecord(ev_zero_, zero_stream_));
-    zero_pending_ = true;
-  }
+  // (everything that reads S is done: see zero_stream_.  The launches themselves wait until the Jacobian evaluation of an accepted
+  // step has its first kernel enqueued — the host's three launches and the event cost the evaluation 30 us of its start otherwise;
+  // after a rejected step the next assembly zeroes in line)
+  zero_deferred_ = !graph && zero_stream_ != nullptr;
   float ms = 0.f;
   if (graph) {  // one replayed graph: no events inside it — the whole linear solve + candidate evaluation is reported as "factor"
     if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvCost]) == hipSuccess) phase_[2] += 1e-3 * ms;

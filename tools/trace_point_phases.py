@@ -13,8 +13,10 @@ rows.sort(key=lambda r: r['s'])
 skip = ('potrf128_kernel', 'trsm_gemm_f64_kernel', 'trsm_gemm_thin_f64_kernel', 'gemm_update_f64_kernel', 'gemm_update_thin_f64_kernel', 'gemm_diag_f64_kernel',
         'syrk_trailing_f64_kernel', 'syrk_trailing_thin_f64_kernel', 'potrf_server_kernel', 'chain_column_kernel', 'chain_marker_kernel',
         'chain_column_pair_kernel', 'syrk_trailing_thin_pair_f64_kernel', 'potrf_server_pair_kernel', 'border_add_kernel')
-bs = [i for i, r in enumerate(rows) if r['n'] == 'bs_resident_kernel']
-a, b = bs[-3], bs[-2]  # from one back-substitution to the next: D, A, B (and the factorisation, skipped)
+skip = skip + ('bs_resident_kernel', 'tri_pack_kernel')
+marks = [i for i, r in enumerate(rows) if r['n'] == 'bal_cam_step_kernel']  # one per LM iteration: the start of phase D
+which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
+a, b = marks[which], marks[which + 1]  # from one camera step to the next: D, A, B (and the factorisation, skipped)
 prev_end = rows[a]['s']
 t0 = rows[a]['s']
 for r in rows[a:b + 1]:
