@@ -70,17 +70,23 @@ def build_problem(sk, prob):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/*pmc_traffic.json, made by tools/pmc_summary.py from two separate rocprofv3 --pmc
-    runs of this script).  PMC counters cannot be read from inside the timed run: null when absent."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc_traffic.json, made by
+    tools/pmc_summary.py from two separate rocprofv3 --pmc runs of this script with --no-resident-kernels), LIKE FOR LIKE: the
+    counter bytes per SYRK launch of the plan those passes ran, beside the algorithmic C-tile bytes per launch of THAT plan
+    (from the passes' own bench line).  PMC counters cannot be read from inside the timed run: None when absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
         return None
     try:
-        kernels = json.load(open(files[-1]))["kernels"]
-        k = kernels.get("syrk_trailing (both tilings)") or kernels["sk::syrk_trailing_f64_kernel"]
-        return k["hbm_bytes_per_launch_corrected"]
+        d = json.load(open(files[-1]))
+        lfl = d.get("syrk_like_for_like")
+        if lfl:
+            return {"bytes_per_launch": lfl["counter_bytes_per_launch"], "algorithmic_bytes_per_launch": lfl["algorithmic_c_tile_bytes_per_launch"],
+                    "ratio": lfl["ratio"], "plan": lfl.get("plan"), "launches_per_iteration": lfl.get("launches_per_iteration"),
+                    "per_iteration": d.get("hbm_bytes_per_iteration"), "algorithmic_per_iteration": d.get("algorithmic_bytes_per_iteration"),
+                    "file": os.path.basename(files[-1])}
+        return None  # (a summary of an earlier round: its per-launch figure belongs to another plan than the one it was printed beside)
     except (KeyError, ValueError, OSError):
         return None
 
@@ -311,6 +317,7 @@ def main():
     ap.add_argument("--no-lookahead", action="store_true", help="(tuning) single-stream Cholesky")
     ap.add_argument("--no-alone", action="store_true", help="skip the untimed side measurements (profiling runs)")
     ap.add_argument("--full-factorisation", action="store_true", help="factor every 128-block of the reduced system (no block envelope)")
+    ap.add_argument("--no-resident-kernels", action="store_true", help="sk_options_set_resident_kernels(o, 0): the same plans launch by launch (counter-collection passes)")
     ap.add_argument("--dissection", default="auto", choices=["auto", "on", "off"], help="(tuning) two-way dissection of the camera sequence on ONE device")
     args = ap.parse_args()
 
@@ -368,6 +375,8 @@ def main():
     options.setCholeskyTuning(args.group, not args.no_lookahead)
     options.setCholeskyEnvelope(not args.full_factorisation)
     options.setCholeskyDissection(args.dissection)
+    if args.no_resident_kernels:
+        options.setResidentKernels(False)
     # a stream of our own, not torch's default (null) stream: the null stream synchronises implicitly with every
     # blocking stream, which would serialise the factorisation's CU-masked SYRK stream against it
     stream = torch.cuda.Stream(device=local_rank)
@@ -409,7 +418,7 @@ def main():
     syrk_flops = solver.syrkFlopsPerSolve()
     syrk_c_bytes = solver.syrkCBytesPerSolve()
     plan = {k: solver.stat(k) for k in ("envelope_fill", "camera_order", "cholesky_flops_full", "cholesky_flops_plan", "cholesky_columns_resident", "segments",
-                                        "allreduce_bytes")}
+                                        "allreduce_bytes", "dissected")}
     model_us = {}
     for k in range(1, 9):
         try:
@@ -465,6 +474,7 @@ def main():
     timed = its[1 + args.warmup: 1 + args.warmup + args.steps]
     n_success = int(sum(it["step_is_successful"] for it in timed))
     line = None
+    traffic = pmc_traffic() if (args.workload == "ladybug-1723-156502" and args.group <= 0 and not args.full_factorisation) else None
     if rank == 0:
         achieved = (syrk_flops * args.steps) / syrk_s * 1e-12 if syrk_s > 0 else 0.0
         line = {
@@ -473,7 +483,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d), DENSE_SCHUR" % (
                 args.workload, prob.num_cameras, prob.num_points, prob.num_observations, SEED),
-                "linear_solver": "DENSE_SCHUR", "reduced_system_n": 9 * prob.num_cameras,
+                "linear_solver": "DENSE_SCHUR", "reduced_system_n": 9 * prob.num_cameras, "observations": prob.num_observations,
+                "envelope_bytes": plan["allreduce_bytes"],  # the lower-triangular 128-blocks inside the envelope, in bytes (what the Schur assembly writes once)
                 "cholesky": ("full: every 128-block of the reduced system" if args.full_factorisation else
                              "block envelope: cameras ordered for a banded reduced system, the structurally zero 128-blocks outside the envelope "
                              "skipped — the same arithmetic as the full factorisation (bit-identical at equal SYRK depth: "
@@ -496,14 +507,16 @@ def main():
                                                      "body in 128x128 and 32x128 tiles, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic() if (args.workload == "ladybug-1723-156502" and args.group <= 0 and not args.full_factorisation) else None,
-                         "traffic_note": "bytes/launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled, gfx950; "
-                                         "includes Infinity-Cache hits; SK_CHOL_CHAIN_SERVER=0: the same SYRK kernels launch by launch on the UNDISSECTED system — "
-                                         "counter collection serialises kernels, a resident one would wait for ever, and without the resident chain "
-                                         "a single device does not dissect); algorithmic C-tile bytes/launch (each 128x128 tile of "
-                                         "the trailing matrix read and written once per launch; K = 256 per launch where the SYRK is the "
-                                         "long pole, 128 under the resident panel chain) = %.3e" % (
-                                             syrk_c_bytes / max(1, syrk_n // max(1, args.steps))),
+                         "plan": ("%s, %s" % ("camera sequence dissected (head + tail in one sequence of launches, root)" if plan["dissected"] else "undissected",
+                                              "no resident kernels (launch by launch)" if args.no_resident_kernels else "resident panel chain")),
+                         "launches_per_iteration": syrk_n // max(1, args.steps),
+                         # each 128x128 tile of the trailing matrix read and written once per launch (K = 256 per launch where the SYRK is the long pole, 128 under the chain)
+                         "algorithmic_c_tile_bytes_per_launch": syrk_c_bytes / max(1, syrk_n // max(1, args.steps)),
+                         # HBM bytes by the counters: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH doubled, gfx950; Infinity-Cache hits
+                         # included), run with --no-resident-kernels on the UNDISSECTED plan (counter collection serialises kernels) — and compared with the
+                         # algorithmic bytes of THAT plan: traffic.ratio is like for like; the timed region above runs another plan
+                         "traffic": (traffic or {}).get("bytes_per_launch"),
+                         "traffic_like_for_like": traffic,
                          "launches": syrk_n, "avg_launch_ms": 1e3 * syrk_s / max(1, syrk_n),
                          "flops_per_solve": syrk_flops,
                          "achieved_alone": alone, "frac_alone": (alone / FP64_MFMA_PEAK_TFLOPS) if alone else None,

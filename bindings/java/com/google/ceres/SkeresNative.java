@@ -106,6 +106,9 @@ public final class SkeresNative {
   public static native int skOptionsSetCholeskyEnvelope(long o, int v);
   public static native int skOptionsSetCholeskyDissection(long o, int v);
   public static native int skOptionsSetCholeskyBorder(long o, int v);
+  public static native int skOptionsSetResidentKernels(long o, int v);
+  public static native int skOptionsSetGraphReplay(long o, int v);
+  public static native int skOptionsSetMaxSegments(long o, int v);
   public static native int skOptionsSetDistributionMode(long o, int v);
   public static native int skOptionsSetCholeskyTuning(long o, int group, int lookahead);
   public static native byte[] skRcclUniqueId();

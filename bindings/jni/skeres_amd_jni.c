@@ -43,8 +43,12 @@ static jint check(JNIEnv* env, int status) {
   if (status != SK_OK) throw_status(env, status);
   return (jint)status;
 }
+/* A factory that returns NULL: an argument was wrong (an unknown functor id, an index out of range, a nesting too deep) —
+ * IllegalArgumentException with sk_last_error().  (Round 4, found by executing this file against the mock JNIEnv of
+ * tests/jni_stub: it used to consult sk_last_status(), which belongs to sk_solver_create alone, and so threw whatever an
+ * EARLIER failure of the process had left there.) */
 static jlong check_handle(JNIEnv* env, const void* p) {
-  if (!p) throw_status(env, sk_last_status() ? sk_last_status() : SK_ERR_INVALID_ARGUMENT);
+  if (!p) throw_status(env, SK_ERR_INVALID_ARGUMENT);
   return HANDLE(p);
 }
 
@@ -297,6 +301,9 @@ SK_OPT_INT(skOptionsSetDevice, sk_options_set_device)
 SK_OPT_INT(skOptionsSetCholeskyEnvelope, sk_options_set_cholesky_envelope)
 SK_OPT_INT(skOptionsSetCholeskyDissection, sk_options_set_cholesky_dissection)
 SK_OPT_INT(skOptionsSetCholeskyBorder, sk_options_set_cholesky_border)
+SK_OPT_INT(skOptionsSetResidentKernels, sk_options_set_resident_kernels)
+SK_OPT_INT(skOptionsSetGraphReplay, sk_options_set_graph_replay)
+SK_OPT_INT(skOptionsSetMaxSegments, sk_options_set_max_segments)
 SK_OPT_INT(skOptionsSetDistributionMode, sk_options_set_distribution_mode)
 SK_JNI(jint, skOptionsSetCholeskyTuning)(JNIEnv* env, jclass c, jlong o, jint group, jint lookahead) { (void)c; return check(env, sk_options_set_cholesky_tuning(PTR(sk_options, o), group, lookahead)); }
 /* multi-GPU from the JVM: the library's own RCCL hook (no collective to write on the JVM side) */

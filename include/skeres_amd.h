@@ -359,6 +359,20 @@ int sk_options_set_cholesky_dissection(sk_options* o, int mode);
  * not bit for bit.  AUTO (default): when the model of the factorisation's serial chain predicts a gain of 10 %;
  * ON: whenever the camera lists of the points show visits (jumps in the camera sequence) — tests, small problems;
  * OFF: never.  sk_solver_stat: "border_cameras", "border_gap", "border_model_us", "border_model_us_plain". */
+/* Resident kernels.  By default the factorisation of the reduced system runs its chain-bound block columns under a RESIDENT
+ * panel chain (one workgroup that factors the diagonal blocks as their updates land, column launches enqueued ahead of time
+ * that wait for it) and the back-substitution is one resident launch — kernels that wait for other kernels of the same
+ * process.  on == 0: this solver uses none — the same factorisation plan and the same arithmetic, one launch per step —
+ * for processes in which kernels are serialised (hardware-counter collection under rocprofv3 --pmc) or in which the caller
+ * does not want kernels that spin.  (A wait that gives up after its 1 s time-out has the same effect for the device from
+ * then on, and says so on stderr.) */
+int sk_options_set_resident_kernels(sk_options* o, int on);
+/* Launch-bound problems (a reduced system of at most eight 128-blocks: BAL problem-49) replay their iteration as a hipGraph;
+ * on == 0: every launch is enqueued directly. */
+int sk_options_set_graph_replay(sk_options* o, int on);
+/* Several ranks, SK_DISTRIBUTION_SEGMENTED / AUTO: cut the camera sequence into at most n segments (0, the default: at
+ * most one per rank; n >= 2 otherwise). */
+int sk_options_set_max_segments(sk_options* o, int n);
 enum { SK_BORDER_AUTO = 0, SK_BORDER_ON = 1, SK_BORDER_OFF = 2 };
 int sk_options_set_cholesky_border(sk_options* o, int mode);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,

@@ -155,6 +155,9 @@ _SIGS = {
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_dissection": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_border": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_resident_kernels": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_graph_replay": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_max_segments": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_cholesky_solve": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
     "sk_synth_dense_targets": (C.c_int, [C.c_double, C.c_int, C.c_int, _dp, _dp]),
     "sk_problem_point_partition": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _ip]),
@@ -168,9 +171,12 @@ def exported_symbols():
 
 
 def lib():
-    """Load libskeres_amd.so (raises loudly when it has not been built)."""
+    """Load libskeres_amd.so (raises loudly when it has not been built).  SKERES_AMD_LIBRARY=<path> loads another build of it
+    instead — the fault-injection build of the tests (libskeres_amd_testing.so, `make -C skeres_amd/csrc testing`)."""
     global _lib
     if _lib is None:
+        global _LIB_PATH
+        _LIB_PATH = os.environ.get("SKERES_AMD_LIBRARY", _LIB_PATH)
         if not os.path.exists(_LIB_PATH):
             raise SkeresError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(make -C skeres_amd/csrc). There is no CPU fallback." % _LIB_PATH)
@@ -1158,6 +1164,18 @@ class Solver:
             """DENSE_SCHUR: two-way dissection of the camera sequence: "auto" (default) / "on" / "off" (or 0 / 1 / 2)."""
             mode = {"auto": 0, "on": 1, "off": 2}.get(mode, mode)
             _check(lib().sk_options_set_cholesky_dissection(self._h, int(mode)))
+
+        def setResidentKernels(self, on):
+            """0: no kernel of this solver waits for another (the same plans, launch by launch): counter-collection runs."""
+            _check(lib().sk_options_set_resident_kernels(self._h, int(bool(on))))
+
+        def setGraphReplay(self, on):
+            """0: launch-bound problems enqueue every launch instead of replaying their iteration as a hipGraph."""
+            _check(lib().sk_options_set_graph_replay(self._h, int(bool(on))))
+
+        def setMaxSegments(self, n):
+            """Several ranks: cut the camera sequence into at most n segments (0: one per rank)."""
+            _check(lib().sk_options_set_max_segments(self._h, int(n)))
 
         def setCholeskyBorder(self, mode):
             """DENSE_SCHUR: loop-closure cameras ordered into a trailing border: "auto" (default) / "on" / "off" (or 0 / 1 / 2)."""

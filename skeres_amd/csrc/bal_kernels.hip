@@ -96,101 +96,64 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* out_partial, i
 // ---------------------------------------------------------------------------
 // kLoss: robust loss (loss.hpp) — the block's residuals and both Jacobian blocks are corrected before they
 // are stored, the cost term is rho(|r|^2).  A separate instantiation: the trivial-loss kernel stays as it was.
-// Round 4, kRecords: the camera-major records of (F, r) — what bal_cam_records_kernel wrote in a launch of its own, re-reading
-// the planes — are staged in LDS as the columns come and written by the wave, 3.2 records per store instruction, next to the
-// planes.  (Also tried: forward mode in 12 / W passes of Jet<W>, W = 6 or 4, as the tape interpreter does — a Jet component
-// depends on the real parts and on that component of the operands only, so the passes give the same Jacobian — to fit more
-// than two waves per SIMD: the compiler keeps the body at 250 VGPRs whatever W, and capped at 128 it spills 400-800 bytes
-// per lane.  The loop over passes is kept in this form, with W = 12: one pass.)
-template <bool kLoss, bool kRecords>
+template <bool kLoss>
 __global__ __launch_bounds__(kBlock) void bal_eval_jac_kernel(BalDev d) {
-  constexpr int W = 12;
-  __shared__ __attribute__((aligned(16))) double stage[kRecords ? kBlock / 64 : 1][kRecords ? 64 * kFcam : 2];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double* st = stage[kRecords ? wv : 0];
   double acc[1] = {0.0};
-  // whole waves walk the observations (the records are written by the wave; the last wave may be partly out of range)
-  for (long o0 = ((long)blockIdx.x * (kBlock / 64) + wv) * 64; o0 < (long)d.N; o0 += (long)gridDim.x * kBlock) {
-    const long o = o0 + lane;
-    const bool live = o < (long)d.N && !(d.is_host && d.is_host[o]);  // (a host-evaluated observation: bal_host_jac_kernel)
-    const int my_slot = (kRecords && o < (long)d.N) ? d.obs_slot[o] : 0;  // where this observation's record goes (in flight during the arithmetic)
-    if (live) {
-      const int ci = d.cam[o], pi = d.pt[o];
-      typedef Jet<W> J;
-      double xcam[9], xpt[3];
+  for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
+    if (d.is_host && d.is_host[o]) continue;  // the caller's host code evaluates this one (bal_host_jac_kernel)
+    const int ci = d.cam[o], pi = d.pt[o];
+    typedef Jet<12> J;
+    J cam[9], X[3], out[2];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) xcam[k] = d.xc[9 * (size_t)ci + k];
+    for (int k = 0; k < 9; ++k) cam[k] = J(d.xc[9 * (size_t)ci + k], k);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) xpt[k] = d.xp[3 * (size_t)pi + k];
-      const double c[2] = {d.obs[o], d.obs[(size_t)d.N + o]};
-      double r0 = 0.0, r1 = 0.0, sqrt_rho1 = 1.0, alpha_sq_norm = 0.0;
-#pragma unroll 1
-      for (int first = 0; first < 12; first += W) {
-        J cam[9], X[3], out[2];
+    for (int k = 0; k < 3; ++k) X[k] = J(d.xp[3 * (size_t)pi + k], 9 + k);
+    const J* params[2] = {cam, X};
+    const double c[2] = {d.obs[o], d.obs[(size_t)d.N + o]};
+    SnavelyReprojectionError::apply<J>(c, params, out);
+    const double r0 = out[0].a, r1 = out[1].a;
+    if (kLoss) {
+      const double sq = r0 * r0 + r1 * r1;
+      double rho[3];
+      bal_loss_eval(d, o, sq, rho);
+      const LossCorrector lc(sq, rho);
+      acc[0] += rho[0];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) cam[k] = J(xcam[k], k - first);  // (a seed outside this pass's slots: a constant)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) X[k] = J(xpt[k], 9 + k - first);
-        const J* params[2] = {cam, X};
-        SnavelyReprojectionError::apply<J>(c, params, out);
-        if (first == 0) {
-          r0 = out[0].a; r1 = out[1].a;
-          double s0 = r0, s1 = r1;
-          if (kLoss) {
-            const double sq = r0 * r0 + r1 * r1;
-            double rho[3];
-            bal_loss_eval(d, o, sq, rho);
-            const LossCorrector lc(sq, rho);
-            acc[0] += rho[0];
-            sqrt_rho1 = lc.sqrt_rho1; alpha_sq_norm = lc.alpha_sq_norm;
-            s0 = r0 * lc.residual_scaling; s1 = r1 * lc.residual_scaling;
-          } else {
-            acc[0] += r0 * r0 + r1 * r1;
-          }
-          d.r[o] = s0;
-          d.r[(size_t)d.N + o] = s1;
-          if (kRecords) { st[lane * kFcam + 18] = s0; st[lane * kFcam + 19] = s1; }
-        }
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-          const int k = first + w;
-          double j0 = out[0].v[w], j1 = out[1].v[w];
-          if (kLoss) {
-            const double rtj = alpha_sq_norm * (r0 * j0 + r1 * j1);
-            const double a0 = sqrt_rho1 * (j0 - r0 * rtj), a1 = sqrt_rho1 * (j1 - r1 * rtj);
-            j0 = a0; j1 = a1;
-          }
-          if (k < 9) {
-            const double s = d.scale_c[9 * (size_t)ci + k];
-            const double f0 = j0 * s, f1 = j1 * s;
-            d.F[(size_t)k * d.N + o] = f0;
-            d.F[(size_t)(9 + k) * d.N + o] = f1;
-            if (kRecords) { st[lane * kFcam + k] = f0; st[lane * kFcam + 9 + k] = f1; }
-          } else {
-            const double s = d.scale_p[3 * (size_t)pi + (k - 9)];
-            d.E[(size_t)(k - 9) * d.N + o] = j0 * s;
-            d.E[(size_t)(3 + k - 9) * d.N + o] = j1 * s;
-          }
-        }
+      for (int k = 0; k < 12; ++k) {
+        const double j0 = out[0].v[k], j1 = out[1].v[k];
+        const double rtj = lc.alpha_sq_norm * (r0 * j0 + r1 * j1);
+        out[0].v[k] = lc.sqrt_rho1 * (j0 - r0 * rtj);
+        out[1].v[k] = lc.sqrt_rho1 * (j1 - r1 * rtj);
       }
+      d.r[o] = r0 * lc.residual_scaling;
+      d.r[(size_t)d.N + o] = r1 * lc.residual_scaling;
+    } else {
+      d.r[o] = r0;
+      d.r[(size_t)d.N + o] = r1;
+      acc[0] += r0 * r0 + r1 * r1;
     }
-    if (kRecords) {
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
-      __builtin_amdgcn_wave_barrier();
-      const int nrec = (int)(((long)d.N - o0) < 64 ? ((long)d.N - o0) : 64);
-      // ten lanes to a record, 16 bytes each: 6.4 records per store instruction, the slots passed from lane to lane
 #pragma unroll
-      for (int i = 0; i < kFcam / 2; ++i) {
-        const int e2 = i * 64 + lane, rr = e2 / (kFcam / 2), f2 = e2 - rr * (kFcam / 2);
-        const int slot = __shfl(my_slot, rr, 64);
-        if (rr < nrec) reinterpret_cast<double2*>(d.Fcam + (size_t)slot * kFcam)[f2] = reinterpret_cast<const double2*>(st)[e2];
-      }
-      __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < 9; ++k) {
+      const double s = d.scale_c[9 * (size_t)ci + k];
+      d.F[(size_t)k * d.N + o] = out[0].v[k] * s;
+      d.F[(size_t)(9 + k) * d.N + o] = out[1].v[k] * s;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double s = d.scale_p[3 * (size_t)pi + k];
+      d.E[(size_t)k * d.N + o] = out[0].v[9 + k] * s;
+      d.E[(size_t)(3 + k) * d.N + o] = out[1].v[9 + k] * s;
     }
   }
   block_sum<1>(acc, d.partial, d.partial_stride);
 }
+// (Round 4 tried two things on this kernel, neither kept.  (i) The camera-major records of (F, r) written here, staged in LDS and
+// stored by the wave, instead of by bal_cam_records_kernel in a launch of its own: 148-165 us against 99 + 50 — the kernel runs two
+// waves per SIMD on its 172 registers, and the staging and the store loop are serial work on each of them, where the separate
+// transposition has the whole chip's occupancy.  (ii) Forward mode in 12 / W passes of Jet<W>, W = 6 or 4, as the tape
+// interpreter does — a Jet component depends on the real parts and on that component of the operands only, so the passes give the
+// same Jacobian — to fit more than two waves per SIMD: the compiler keeps the body at 250 VGPRs whatever W, and capped at 128
+// it spills 400-800 bytes per lane.)
 
 // Candidate cost at (xc_new, xp_new) with T = double (cost-only branch,
 // AutodiffCostFunction.scala:80-93) fused with the model residual J*step that
@@ -432,12 +395,13 @@ __global__ __launch_bounds__(kBlock) void bal_scale_jac_kernel(BalDev d) {
 // F, r planes (point-major) -> camera-major records.  A wave takes 64 consecutive observations: coalesced plane reads,
 // the 64 records staged in LDS, then written 3.2 records per store instruction (each record's 160 bytes contiguous).
 __global__ __launch_bounds__(kBlock) void bal_cam_records_kernel(BalDev d) {
-  __shared__ double stage[kBlock / 64][64 * kFcam];
+  __shared__ __attribute__((aligned(16))) double stage[kBlock / 64][64 * kFcam];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double* st = stage[w];
   const size_t N = d.N;
   for (long o0 = ((long)blockIdx.x * (kBlock / 64) + w) * 64; o0 < d.N; o0 += (long)gridDim.x * kBlock) {
     const long o = o0 + lane;
+    const int my_slot = o < d.N ? d.obs_slot[o] : 0;
     if (o < d.N) {
 #pragma unroll
       for (int k = 0; k < 18; ++k) st[lane * kFcam + k] = d.F[(size_t)k * N + o];
@@ -448,10 +412,12 @@ __global__ __launch_bounds__(kBlock) void bal_cam_records_kernel(BalDev d) {
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     const int nrec = (int)((d.N - o0) < 64 ? (d.N - o0) : 64);
-#pragma unroll 4
-    for (int i = 0; i < kFcam; ++i) {
-      const int e = i * 64 + lane, rr = e / kFcam, f = e - rr * kFcam;
-      if (rr < nrec) d.Fcam[(size_t)d.obs_slot[o0 + rr] * kFcam + f] = st[e];
+    // ten lanes to a record, 16 bytes each: 6.4 records per store instruction, the slots passed from lane to lane
+#pragma unroll
+    for (int i = 0; i < kFcam / 2; ++i) {
+      const int e2 = i * 64 + lane, rr = e2 / (kFcam / 2), f2 = e2 - rr * (kFcam / 2);
+      const int slot = __shfl(my_slot, rr, 64);
+      if (rr < nrec) reinterpret_cast<double2*>(d.Fcam + (size_t)slot * kFcam)[f2] = reinterpret_cast<const double2*>(st)[e2];
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -989,12 +955,9 @@ void launch_tri_pack(double* S, int ld, double* packed, int nblk, const int* col
   if (nblk > 0) hipLaunchKernelGGL(tri_pack_kernel, dim3(64, nblk), dim3(256), 0, s, S, ld, packed, col0, off, to_packed ? 1 : 0);
 }
 
-// records: also write the camera-major records of (F, r) (no host-evaluated observations, whose rows arrive after this launch)
-void launch_bal_eval_jac(const BalDev& d, bool records, hipStream_t s) {
-  const dim3 g(grid_for((d.N + 63) / 64 * 64)), b(kBlock);
-#define SK_EVAL_JAC(LOSS) { if (records) hipLaunchKernelGGL((bal_eval_jac_kernel<LOSS, true>), g, b, 0, s, d); else hipLaunchKernelGGL((bal_eval_jac_kernel<LOSS, false>), g, b, 0, s, d); }
-  if (d.loss_root >= 0) SK_EVAL_JAC(true) else SK_EVAL_JAC(false)
-#undef SK_EVAL_JAC
+void launch_bal_eval_jac(const BalDev& d, hipStream_t s) {
+  if (d.loss_root >= 0) hipLaunchKernelGGL(bal_eval_jac_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
+  else hipLaunchKernelGGL(bal_eval_jac_kernel<false>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
 }
 void launch_bal_eval_cost(const BalDev& d, hipStream_t s) {
   if (d.loss_root >= 0) hipLaunchKernelGGL(bal_eval_cost_kernel<true>, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
@@ -1053,10 +1016,9 @@ void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLa
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_pair(const BalDev& d, hipStream_t s) {
-  // runs of eight logical blocks per XCD (developer knobs; 0: plain order.  Measured, Schur-assembly phase per iteration, plain -> 8:
+  // runs of eight logical blocks per XCD (developer variable SK_SCHEDULE_PLAIN=1: plain order.  Measured, Schur-assembly phase per iteration, plain -> 8:
   // Ladybug-1723 0.520 -> 0.499 ms, Venice-1778 3.02 -> 2.79 ms; 32 is worse on Ladybug — profiles/r03_pair_xcd_sweep.txt)
-  static const int group_long = getenv("SK_PAIR_XCD_GROUP_LONG") ? atoi(getenv("SK_PAIR_XCD_GROUP_LONG")) : 8;
-  static const int group_short = getenv("SK_PAIR_XCD_GROUP") ? atoi(getenv("SK_PAIR_XCD_GROUP")) : 8;
+  const int group_long = dev_knobs().schedule_plain ? 0 : 8, group_short = group_long;
   auto grid = [](int blocks, int group) { return group > 0 ? (blocks + 8 * group - 1) / (8 * group) * (8 * group) : blocks; };
   if (d.num_long_segments > 0)  // first: the long ones take longest
     hipLaunchKernelGGL(bal_pair_long_kernel, dim3(grid((d.num_long_segments * 64 + kBlock - 1) / kBlock, group_long)), dim3(kBlock), 0, s, d, group_long);

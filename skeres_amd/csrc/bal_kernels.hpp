@@ -94,7 +94,7 @@ void launch_zero_envelope(double* S, int ld, const int* col0, int nblk, hipStrea
 size_t tri_packed_elems(int nblk);
 // col0[kb]: first block column of block row kb that travels; off[kb]: where the row starts in the packed buffer (elements)
 void launch_tri_pack(double* S, int ld, double* packed, int nblk, const int* col0, const long long* off, bool to_packed, hipStream_t s);
-void launch_bal_eval_jac(const BalDev& d, bool records, hipStream_t s);  // records: + the camera-major records of (F, r) (launch_bal_cam_records)
+void launch_bal_eval_jac(const BalDev& d, hipStream_t s);
 void launch_bal_eval_cost(const BalDev& d, hipStream_t s);
 // the same two for a recorded functor (tape.hpp); bal_tape_width == 0: its register file does not fit the LDS
 int bal_tape_width(const Tape& t);

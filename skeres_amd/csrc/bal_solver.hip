@@ -521,7 +521,7 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
       const double allreduce_us = 50.0 + 2.0 * (W - 1.0) / W * blocks * 128.0 * 128.0 * 8.0 / 153e3;
       const double t = hi + root + 170.0 + allreduce_us;  // + fork, join, border add
       out.model_us[Rn] = t;
-      if (getenv("SK_DEBUG_SEGMENTS")) std::fprintf(stderr, "[skeres_amd] %d segments: longest chain %.0f us, root %.0f us, all-reduce %.0f us (%.0f blocks) -> %.0f us (undissected %.0f)\n", Rn, hi, root, allreduce_us, blocks, t, out.t_plain);
+      if (dev_knobs().debug_segments) std::fprintf(stderr, "[skeres_amd] %d segments: longest chain %.0f us, root %.0f us, all-reduce %.0f us (%.0f blocks) -> %.0f us (undissected %.0f)\n", Rn, hi, root, allreduce_us, blocks, t, out.t_plain);
       // (forced: a segment per rank, as far as the sequence can be cut; otherwise a further segment has to beat the plan so far by
       // 5 %: the model is no better than that, and every separator is more to all-reduce and to factor on every rank)
       if (forced ? true : t < best * (Rn > 2 ? 0.95 : 1.0)) { best = t; best_as = as; }
@@ -829,12 +829,12 @@ int BalSolver::setup() {
   {
     // Launch-bound problems replay their iteration as a hipGraph on ONE stream (below): decided before the look-ahead
     // context exists, so that a reduced system of a few blocks pays neither the queue trial nor its 134 MB of scratch.
-    const char* e = getenv("SK_BAL_GRAPH");  // developer knob: 0 = never replay graphs
     bool host_or_tape = false;
     for (size_t b = 0; b < p.rb_functor.size() && !host_or_tape; ++b) host_or_tape = p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK || p.tape_of_block(b) != nullptr;
-    graph_mode_ = npad_ / 128 <= 8 && !opt_.allreduce && !host_or_tape && opt_.dissection != SK_DISSECTION_ON && !getenv("SK_DISSECT_AT") && !(e && !atoi(e));
+    graph_mode_ = npad_ / 128 <= 8 && !opt_.allreduce && !host_or_tape && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 && opt_.graph_replay;
     if (graph_mode_) opt_.lookahead = false;  // one stream: the whole iteration is one in-order launch sequence
   }
+  chol_ctx_.resident = chol_ctx_b_.resident = opt_.resident_kernels;
   if (opt_.lookahead && chol_ctx_.init() != hipSuccess) {  // CU-masked streams unavailable: plain in-order factorisation
     (void)hipGetLastError();
     opt_.lookahead = false;
@@ -864,7 +864,7 @@ int BalSolver::setup() {
     // reverse Cuthill-McKee, is 12.1 ms against 9.1 — every multi-rank run would have factored a third more slowly.)
     // (the border of loop-closure cameras: not with an explicit dissection or segmentation — the fronts of those have borders of
     // their own kind — and only inside the envelope machinery)
-    const bool border_ok = opt_.envelope && opt_.border != SK_BORDER_OFF && opt_.dissection != SK_DISSECTION_ON && !getenv("SK_DISSECT_AT") &&
+    const bool border_ok = opt_.envelope && opt_.border != SK_BORDER_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 &&
                            !(opt_.allreduce && opt_.world > 1 && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED);
     CameraOrderPlan plan;
     auto pick = [&](bool with_memory_order) {
@@ -899,7 +899,7 @@ int BalSolver::setup() {
     group_ = opt_.group_or(opt_.envelope && best < 0.5 * full ? 1 : 3);
     env_for_model = best_env;
     if (opt_.envelope) env_last_.swap(best_env);
-    if (getenv("SK_DEBUG_ENVELOPE") && opt_.envelope) {
+    if (dev_knobs().debug_envelope && opt_.envelope) {
       long h = 0;
       for (int c = 0; c < nblk; ++c) h += env_last_[c] - c;
       std::fprintf(stderr, "[skeres_amd] camera order %d (0 first appearance, 1 memory, 2 RCM); envelope: %d block columns, mean height %.1f; "
@@ -941,7 +941,7 @@ int BalSolver::setup() {
       std::vector<int> first_col;
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
       int max_seg = opt_.world;
-      if (const char* e = getenv("SK_SEGMENTS")) max_seg = std::max(2, std::min(max_seg, atoi(e)));  // developer knob: at most that many segments
+      if (opt_.max_segments >= 2) max_seg = std::min(max_seg, opt_.max_segments);  // (sk_options_set_max_segments)
       const Segments sg = choose_segments(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, max_seg, opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED, opt_.world);
       cut_a = sg.a; cut_b = sg.b;
       dissect_t_plain_ = sg.t_plain; dissect_t_model_ = sg.t_model;
@@ -950,11 +950,10 @@ int BalSolver::setup() {
       Dissection ds;
       std::vector<int> first_col;
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
-      // one device: the lock-step schedule and its own cut (developer knob SK_DISSECT_AUTO_SINGLE=0: AUTO leaves a single device undissected, as until the end of round 3)
-      static const int auto_single = getenv("SK_DISSECT_AUTO_SINGLE") ? atoi(getenv("SK_DISSECT_AUTO_SINGLE")) : 1;
+      // one device: the lock-step schedule and its own cut
       // (only under the resident chain: the partner front rides in ITS launches — with SK_CHOL_CHAIN_SERVER=0, or on a device that
       // lost its chain, a single device stays undissected)
-      const bool lockstep_cut = !multi && auto_single && opt_.dissection == SK_DISSECTION_AUTO && cholesky_chain_enabled(&chol_ctx_);
+      const bool lockstep_cut = !multi && opt_.dissection == SK_DISSECTION_AUTO && opt_.resident_kernels && cholesky_chain_enabled(&chol_ctx_);
       ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, lockstep_cut, lockstep_cut);
       if (lockstep_cut && ds.a > 0) {  // (two resident servers per factorisation: the fifth such solver alive on a device stays undissected)
         if (!pair_claimed_) pair_claimed_ = cholesky_claim_pair_servers(&chol_ctx_);
@@ -963,7 +962,7 @@ int BalSolver::setup() {
       // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
       // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon there.
-      if (opt_.dissection == SK_DISSECTION_AUTO && !getenv("SK_DISSECT_AT") && !lockstep_cut) { ds.a = ds.b = 0; }
+      if (opt_.dissection == SK_DISSECTION_AUTO && dev_knobs().dissect_at < 0 && !lockstep_cut) { ds.a = ds.b = 0; }
       if (opt_.dissection == SK_DISSECTION_ON && ds.a == 0 && C_ >= 6) {
         // forced (tests, small problems): cut at the middle camera wherever that leaves a tail
         std::vector<int> cmin(P_total_, C_), cmax(P_total_, -1);
@@ -974,8 +973,8 @@ int BalSolver::setup() {
           if (b < C_) { ds.a = a; ds.b = b; }
         }
       }
-      if (const char* e = getenv("SK_DISSECT_AT")) {  // developer knob: head size in cameras (0: no dissection)
-        ds.a = atoi(e); ds.b = 0;
+      if (dev_knobs().dissect_at >= 0) {  // developer variable SK_DISSECT_AT: head size in cameras (0: no dissection)
+        ds.a = dev_knobs().dissect_at; ds.b = 0;
         if (ds.a > 0 && ds.a < C_) {
           ds.b = ds.a;
           std::vector<int> cmin(P_total_, C_);
@@ -1338,7 +1337,7 @@ int BalSolver::setup() {
     host_x_.resize(nx); host_rows_h_.resize(host_obs_.size() * (size_t)kHostRow);
   }
   graph_mode_ = graph_mode_ && host_obs_.empty() && !dissected_ && !tape_mode_;
-  if (!graph_mode_ && !getenv("SK_NO_ZERO_OVERLAP")) {  // (developer knob: the envelope zeroed in line, on the solver's stream)
+  if (!graph_mode_ && !dev_knobs().schedule_plain) {  // (developer variable SK_SCHEDULE_PLAIN: the envelope zeroed in line, on the solver's stream)
     SK_HIP_TRY(hipStreamCreateWithFlags(&zero_stream_, hipStreamNonBlocking));
     SK_HIP_TRY(hipEventCreateWithFlags(&ev_zero_, hipEventDisableTiming));
   }
@@ -1418,10 +1417,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   CaptureGuard capture(s, graph && !replay, &graph_mode_);  // an early return below must not leave the stream capturing
   if (!replay) {
   kt_.begin("bal_eval_jac", s);
-  // (the camera-major records of (F, r) come out of the evaluation kernel itself, unless rows of host-evaluated observations are
-  // still to arrive or the functor is a recorded one: then bal_cam_records_kernel transposes the planes as until round 3)
-  const bool fused_records = !tape_mode_ && d_.num_host == 0;
-  if (tape_mode_) launch_bal_eval_jac_tape(d_, tape_dev_, s); else launch_bal_eval_jac(d_, fused_records, s);
+  if (tape_mode_) launch_bal_eval_jac_tape(d_, tape_dev_, s); else launch_bal_eval_jac(d_, s);
   kt_.end("bal_eval_jac", s);
   if (zero_deferred_ && zero_stream_ && !graph) {  // the envelope of the reduced system zeroed next to this evaluation (try_step_once)
     for (int f = 0; f < 3; ++f)
@@ -1438,7 +1434,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
     if (failed) return SK_ERR_EVALUATION_FAILED;
     nb += launch_bal_host_jac(d_, nb, s);
   }
-  if (!fused_records) { kt_.begin("bal_cam_records", s); launch_bal_cam_records(d_, s); kt_.end("bal_cam_records", s); }
+  kt_.begin("bal_cam_records", s); launch_bal_cam_records(d_, s); kt_.end("bal_cam_records", s);
   kt_.begin("bal_cam_reduce", s); launch_bal_cam_reduce(d_, s); kt_.end("bal_cam_reduce", s);
   launch_bal_pt_reduce(d_, s);
   if (opt_.allreduce) {  // camera columns are summed over all ranks' observations
@@ -1592,6 +1588,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
   CholeskyContext* ctx = opt_.lookahead ? &chol_ctx_ : nullptr;
+  int* bs_info = opt_.resident_kernels ? info_p_ : nullptr;  // (nullptr: the back-substitutions one launch per block step — nothing resident, nothing that waits)
   double* yf[3] = {b_yf_.p + fr_[0].y_off, b_yf_.p + fr_[1].y_off, b_yf_.p + fr_[2].y_off};
   double* wf[3] = {b_wf_.p + fr_[0].y_off, b_wf_.p + fr_[1].y_off, b_wf_.p + fr_[2].y_off};
   if (segmented_) {
@@ -1613,18 +1610,18 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     launch_tri_pack(Rs, (int)R.dim, b_pack_.p, R.nblk, b_pack_col0_.p, b_pack_off_.p, false, s);
     finish_root();
     cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok());
-    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), info_p_);
+    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info);
     if (L.ncols > 0) {
       cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
-      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, info_p_);
+      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info);
     }
   } else if (dissected_) {
     cholesky_dissected_factor(ds_, info_p_, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
-    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, info_p_);
+    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, bs_info);
   } else {
     const FrontHost& R = fr_[2];
     cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok(), -1, 1, nullptr, R.tl());
-    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), info_p_, R.tl());
+    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl());
   }
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----

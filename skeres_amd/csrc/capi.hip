@@ -51,6 +51,33 @@ int Problem::intern_loss(const LossFunction* l) {
 
 namespace sk { int rotation_apply(int op, int row_major, int jet_dim, const double* in, int n, double* out); }
 
+namespace sk {
+const DevKnobs& dev_knobs() {
+  static const DevKnobs knobs = [] {
+    DevKnobs k;
+    auto num = [](const char* name, int def) { const char* e = getenv(name); return e ? atoi(e) : def; };
+    k.chain_server = num("SK_CHOL_CHAIN_SERVER", 1);
+    k.bs_resident = num("SK_BS_RESIDENT", 1);
+    k.chain_stamps = getenv("SK_CHAIN_STAMPS");
+    k.bs_stamps = getenv("SK_BS_STAMPS");
+    if (const char* e = getenv("SK_DEBUG")) {
+      const std::string topics = std::string(",") + e + ",";
+      k.debug_queues = topics.find(",queues,") != std::string::npos;
+      k.debug_envelope = topics.find(",envelope,") != std::string::npos;
+      k.debug_segments = topics.find(",segments,") != std::string::npos;
+      k.debug_chain_abort = topics.find(",chain_abort,") != std::string::npos;
+    }
+    k.queue_shift = num("SK_QUEUE_SHIFT", 0);
+    k.chain_queues = num("SK_CHAIN_QUEUES", -1);
+    k.pair_max_trailing = num("SK_CHAIN_PAIR_MAX_TRAILING", 0);
+    k.dissect_at = num("SK_DISSECT_AT", -1);
+    k.schedule_plain = num("SK_SCHEDULE_PLAIN", 0);
+    return k;
+  }();
+  return knobs;
+}
+}  // namespace sk
+
 extern "C" {
 
 const char* sk_version(void) { return "skeres_amd 0.1 (gfx950)"; }
@@ -558,6 +585,12 @@ int sk_options_set_cholesky_dissection(sk_options* o, int mode) {
 int sk_options_set_distribution_mode(sk_options* o, int mode) {
   if (mode != SK_DISTRIBUTION_AUTO && mode != SK_DISTRIBUTION_SHARDED && mode != SK_DISTRIBUTION_REPLICATED && mode != SK_DISTRIBUTION_SEGMENTED) { set_error("invalid distribution mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
   o->o.distribution_mode = mode; return SK_OK;
+}
+int sk_options_set_resident_kernels(sk_options* o, int on) { o->o.resident_kernels = on != 0; return SK_OK; }
+int sk_options_set_graph_replay(sk_options* o, int on) { o->o.graph_replay = on != 0; return SK_OK; }
+int sk_options_set_max_segments(sk_options* o, int n) {
+  if (n < 0 || n == 1) { set_error("max_segments must be 0 (one per rank) or at least 2"); return SK_ERR_INVALID_ARGUMENT; }
+  o->o.max_segments = n; return SK_OK;
 }
 int sk_options_set_cholesky_border(sk_options* o, int mode) {
   if (mode != SK_BORDER_AUTO && mode != SK_BORDER_ON && mode != SK_BORDER_OFF) { set_error("invalid border mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }

@@ -1243,12 +1243,13 @@ static const size_t g_potrf_lds = (size_t)(18 * kBlk + 192 + 4) * sizeof(double)
 size_t potrf128_lds_bytes() { return g_potrf_lds; }
 
 static std::vector<hipStream_t> g_orphan_streams;  // streams of a device whose queue set could not be completed: kept, never destroyed
-static int g_early_column = 1;  // developer knob SK_CHAIN_EARLY_COLUMN=0: a resident column launch waits for the whole SYRK before it (marker kernel)
-static int g_thin_grid = 512;  // panel launches of at most this many 32-row workgroups use the 32 x 128 kernels (developer knob SK_THIN_GRID)
-static int g_ext_events = 1;  // events on the producing kernel's own dispatch (developer knob SK_LA_EXT_EVENTS=0: separate records)
-static unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;  // developer knob SK_LA_SYSTEM_FENCE=1: default fences
-static int g_chain_server = 1;  // developer knob SK_CHOL_CHAIN_SERVER=0: the launch-per-step panel chain even where the resident one applies (initial value of every device's DeviceQueues::chain_server)
-static int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see cholesky_plan (developer knobs SK_CHAIN_MAX_TRAILING, SK_CHAIN_PREFIX_GROUP)
+// Settled values of the tuning sweeps of rounds 1-3 (they were environment variables until round 4):
+constexpr int g_early_column = 1;  // a resident column launch waits for the FIRST block column of the SYRK before it, not for a marker kernel behind all of it
+constexpr int g_thin_grid = 512;   // panel launches of at most this many 32-row workgroups use the 32 x 128 kernels
+constexpr int g_ext_events = 1;    // events ride on the producing kernel's own dispatch (hipExtLaunchKernelGGL) instead of separate records
+constexpr unsigned g_event_flags = hipEventDisableTiming | hipEventDisableSystemFence;
+static int g_chain_server = 1;  // developer variable SK_CHOL_CHAIN_SERVER=0 (dev_knobs): the launch-per-step panel chain even where the resident one applies (initial value of every device's DeviceQueues::chain_server)
+constexpr int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see cholesky_plan (profiles/r03_prefix_group_sweep.txt)
 // Most trailing tile rows of a resident PAIR of block columns (cholesky_plan; developer knob SK_CHAIN_PAIR_MAX_TRAILING).  0 = no
 // pairs, the DEFAULT: measured on Ladybug-1723 with 56 (block columns 8-44 as 18 pairs + 1: every column under the server) the
 // factorisation takes 7.14 ms against 7.13 with those columns launch by launch, and the bench line 8.86 ms against 8.65 —
@@ -1256,31 +1257,26 @@ static int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see cholesky
 // their first-column signal, 38 in the 128-row tiling the launch-by-launch plan uses above 48 tile rows), not by its panel
 // chain (profiles/r03_pair_chain_timeline.txt).  Kept behind the knob, covered by tests/pair_plan_worker.py.
 static int g_pair_max_trailing = 0;
-static int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK (developer knob SK_THIN_SYRK)
-static int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
+constexpr int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK
+constexpr int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
 static std::atomic<int> g_bs_resident{1};  // developer knob SK_BS_RESIDENT=0: the back-substitution as one launch per block step (bs_step_kernel)
-// Unsupported test hooks, read once in cholesky_init (cholesky_factor runs on two threads when a tail front has its own):
-// SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds, once per process, what that column's launch waits for (the wait
-// times out; tests/chain_abort_worker.py); SK_CHAIN_NO_SERVER_JOIN=1 leaves the server's stream unjoined (a probe).
-static std::atomic<int> g_test_withhold{-1}, g_no_server_join{0};
+// Fault injection, compiled in only with -DSK_TESTING (libskeres_amd_testing.so, `make testing`; never in the product library):
+// SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds, once per process, what that column's launch waits for — the wait
+// times out (tests/chain_abort_worker.py).
+#ifdef SK_TESTING
+static std::atomic<int> g_test_withhold{-1};
+#endif
 hipError_t cholesky_init() {
-  static std::once_flag hooks;
-  std::call_once(hooks, [] {
+  static std::once_flag once;
+  std::call_once(once, [] {
+#ifdef SK_TESTING
     if (const char* e = getenv("SK_CHAIN_TEST_WITHHOLD_MARKER")) g_test_withhold.store(atoi(e));
-    if (const char* e = getenv("SK_CHAIN_NO_SERVER_JOIN")) g_no_server_join.store(atoi(e));
+#endif
+    const DevKnobs& k = dev_knobs();
+    g_bs_resident.store(k.bs_resident);
+    g_chain_server = k.chain_server;
+    g_pair_max_trailing = k.pair_max_trailing;
   });
-  if (const char* e = getenv("SK_TAIL_TILES")) g_tail_tiles = atoi(e);  // developer knobs
-  if (const char* e = getenv("SK_BS_RESIDENT")) g_bs_resident.store(atoi(e));
-  if (const char* e = getenv("SK_TAIL_GROUP")) g_tail_group = atoi(e);
-  if (const char* e = getenv("SK_THIN_GRID")) g_thin_grid = atoi(e);
-  if (const char* e = getenv("SK_THIN_SYRK")) g_thin_syrk_tiles = atoi(e);
-  if (const char* e = getenv("SK_CHAIN_EARLY_COLUMN")) g_early_column = atoi(e);
-  if (const char* e = getenv("SK_LA_SYSTEM_FENCE")) { if (atoi(e)) g_event_flags = hipEventDisableTiming; }
-  if (const char* e = getenv("SK_LA_EXT_EVENTS")) g_ext_events = atoi(e);
-  if (const char* e = getenv("SK_CHOL_CHAIN_SERVER")) g_chain_server = atoi(e);
-  if (const char* e = getenv("SK_CHAIN_MAX_TRAILING")) g_chain_max_trailing = atoi(e);
-  if (const char* e = getenv("SK_CHAIN_PREFIX_GROUP")) g_chain_prefix_group = atoi(e);
-  if (const char* e = getenv("SK_CHAIN_PAIR_MAX_TRAILING")) g_pair_max_trailing = atoi(e);
   hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_server_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_potrf_lds);
   if (rc != hipSuccess) return rc;
   rc = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_server_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_potrf_lds);
@@ -1373,13 +1369,11 @@ static DeviceQueues* create_device_queues(int dev) {
   int ncu = 0, reserved = 0, reserved_early = 0;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   // CUs per XCD kept free of the SYRK; developer knobs (0 = no mask)
-  int per_xcd = 4, per_xcd_early = 2, early_tiles = 72;
-  if (const char* e = getenv("SK_LA_RESERVED_PER_XCD")) per_xcd = atoi(e);
-  if (const char* e = getenv("SK_LA_RESERVED_EARLY")) per_xcd_early = atoi(e);
-  if (const char* e = getenv("SK_LA_EARLY_TILES")) early_tiles = atoi(e);
-  if (const char* e = getenv("SK_QUEUE_SHIFT")) {  // developer knob: extra queues first, as another library in the process would create them
+  // (settled by the sweeps of rounds 1 and 2: profiles/r02_cu_reservation_sweep.txt, tools/sweep_early_tiles.sh)
+  const int per_xcd = 4, per_xcd_early = 2, early_tiles = 72;
+  if (dev_knobs().queue_shift > 0) {  // developer variable SK_QUEUE_SHIFT: extra queues first, as another library in the process would create them
     std::vector<uint32_t> all((size_t)(ncu + 31) / 32, 0xffffffffu);
-    for (int k = 0; k < atoi(e); ++k) {
+    for (int k = 0; k < dev_knobs().queue_shift; ++k) {
       hipStream_t d = nullptr;
       if (hipExtStreamCreateWithCUMask(&d, (uint32_t)all.size(), all.data()) != hipSuccess) (void)hipGetLastError();
       else q->all_streams.push_back(d);
@@ -1427,7 +1421,7 @@ static DeviceQueues* create_device_queues(int dev) {
     p = q->panel_candidates[0];
     sv = p ? q->server_candidates[0] : nullptr;
     if (!ok) q->queue_choice = 0;  // no choice to make
-    if (const char* e = getenv("SK_CHAIN_QUEUES")) q->queue_choice = atoi(e) % (kBulkCand * kPanelCand * kServerCand);
+    if (dev_knobs().chain_queues >= 0) q->queue_choice = dev_knobs().chain_queues % (kBulkCand * kPanelCand * kServerCand);
     if (ok && q->queue_choice >= 0) {
       b = q->bulk_candidates[q->queue_choice / (kPanelCand * kServerCand)];
       be = q->bulk_early_candidates[q->queue_choice / (kPanelCand * kServerCand)];
@@ -1484,27 +1478,16 @@ hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
   std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());  // (the device's entry may gain streams below)
   dq = q; device = primary.device;
   // A resident potrf server of its own (round 3): one of the candidates the primary context does not use, on the same
-  // CU mask (CU 0 of every XCD: eight CUs, a server each).  SK_DISSECT_TAIL_CHAIN=0: none — the tail launch by launch.
+  // CU mask (CU 0 of every XCD: eight CUs, a server each).
   server = nullptr;
-  {
-    static const int tail_chain = getenv("SK_DISSECT_TAIL_CHAIN") ? atoi(getenv("SK_DISSECT_TAIL_CHAIN")) : 1;
-    if (tail_chain && primary.server)
-      for (int k = kServerCand - 1; k >= 0 && !server; --k) if (q->server_candidates[k] && q->server_candidates[k] != primary.server) server = q->server_candidates[k];
-  }
+  if (primary.server)
+    for (int k = kServerCand - 1; k >= 0 && !server; --k) if (q->server_candidates[k] && q->server_candidates[k] != primary.server) server = q->server_candidates[k];
   prepared = true;  // (the queues are chosen here, from what the device's trial left over: cholesky_prepare must not adopt the primary's)
   reserved_cus = q->reserved_cus; early_tiles = q->early_tiles;
-  const char* mode = getenv("SK_DISSECT_B_STREAMS");  // developer knob: "plain" = ordinary streams instead of the left-over CU-masked candidates
-  if (mode && !strcmp(mode, "plain")) {
-    for (int k = 0; k < 2; ++k)
-      if (!q->plain[k]) {
-        if (hipStreamCreateWithFlags(&q->plain[k], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
-        q->all_streams.push_back(q->plain[k]);
-      }
-    panel = q->plain[0]; bulk = bulk_early = q->plain[1];
-  } else {
+  {
     // The queues the primary context does not use — of the same creation parity as the ones it does: which queues suffer
     // from a resident kernel on the server's queue goes by that parity (tune_chain_queues), and the primary's were
-    // measured to be on the good side.  (Developer knobs SK_DISSECT_B_PANEL / SK_DISSECT_B_BULK: candidate indices.)
+    // measured to be on the good side.
     int kp = -1, kb = -1;
     for (int k = 0; k < kPanelCand; ++k) if (q->panel_candidates[k] == primary.panel) kp = k;
     for (int k = 0; k < kBulkCand; ++k) if (q->bulk_candidates[k] == primary.bulk) kb = k;
@@ -1512,14 +1495,11 @@ hipError_t CholeskyContext::init_secondary(const CholeskyContext& primary) {
     for (int k = 0; k < kPanelCand; ++k) if (k != kp && q->panel_candidates[k] && (kp < 0 || (k - kp) % 2 == 0)) { bp = k; break; }
     if (bp < 0) for (int k = 0; k < kPanelCand; ++k) if (k != kp && q->panel_candidates[k]) { bp = k; break; }
     for (int k = 0; k < kBulkCand; ++k) if (k != kb && q->bulk_candidates[k]) { bb = k; break; }
-    if (const char* e = getenv("SK_DISSECT_B_PANEL")) bp = atoi(e) % kPanelCand;
-    if (const char* e = getenv("SK_DISSECT_B_BULK")) bb = atoi(e) % kBulkCand;
     if (bp >= 0) panel = q->panel_candidates[bp];
     if (bb >= 0) { bulk = q->bulk_candidates[bb]; bulk_early = q->bulk_early_candidates[bb]; }
-    if (getenv("SK_DEBUG_QUEUES")) std::fprintf(stderr, "[skeres_amd] secondary context: panel candidate %d (primary %d), bulk candidate %d (primary %d)\n", bp, kp, bb, kb);
+    if (dev_knobs().debug_queues) std::fprintf(stderr, "[skeres_amd] secondary context: panel candidate %d (primary %d), bulk candidate %d (primary %d)\n", bp, kp, bb, kb);
   }
   if (!panel || !bulk) { panel = bulk = bulk_early = nullptr; server = nullptr; return hipErrorNotSupported; }  // (no CU-masked candidates on this device)
-  if (const char* e = getenv("SK_DISSECT_B_SINGLE")) if (atoi(e)) bulk = bulk_early = panel;  // developer knob: the whole tail on ONE in-order queue
   if (!q->fork) {
     if (hipStreamCreateWithFlags(&q->fork, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); panel = bulk = bulk_early = nullptr; return hipErrorOutOfMemory; }
     q->all_streams.push_back(q->fork);
@@ -1789,7 +1769,7 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
     best2 = std::min(best2, ms2[c]);
   }
   for (int c = ncomb - 1; c >= 0; --c) if (ms2[c] <= 1.04 * best2) q.queue_choice = c;  // the first of those within noise of the best: the same choice run after run
-  if (getenv("SK_DEBUG_QUEUES")) {
+  if (dev_knobs().debug_queues) {
     std::fprintf(stderr, "[skeres_amd] synthetic factorisations (ms: banded under the resident chain / dense on the early-group queue) per (bulk, panel, server) queue candidates:");
     for (int c = 0; c < ncomb; ++c) {
       std::fprintf(stderr, "%s%.2f", c % kServerCand == 0 ? "  " : " ", ms[c]);
@@ -1811,7 +1791,7 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
 // Returns true when the caller should do that.
 bool cholesky_note_info(CholeskyContext* ctx, int info) {
   if (info == 2) g_bs_resident.store(0);  // (whichever resident kernel it was: the back-substitution is launch by launch from here on, too)
-  if (info == 2 && ctx && ctx->sync && getenv("SK_DEBUG_CHAIN_ABORT")) {  // developer knob: where the chain stood when a wait gave up
+  if (info == 2 && ctx && ctx->sync && dev_knobs().debug_chain_abort) {  // developer knob: where the chain stood when a wait gave up
     std::vector<int> h((size_t)kSyncHeader + 2 * ctx->sync_blk);
     (void)hipMemcpy(h.data(), ctx->sync, h.size() * sizeof(int), hipMemcpyDeviceToHost);
     std::fprintf(stderr, "[skeres_amd] chain abort: potrf_done %d abort %d syrk_seq %d syrk_column %d | diag_ready:", h[kSyncPotrfDone], h[kSyncAbort], h[kSyncSyrkSeq], h[kSyncSyrkColumn]);
@@ -1836,7 +1816,7 @@ void cholesky_disable_chain(CholeskyContext* ctx) {
   std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());
   ctx->dq->chain_server = 0;
 }
-bool cholesky_chain_enabled(const CholeskyContext* ctx) { return ctx && ctx->dq && ctx->server && ctx->dq->chain_server; }
+bool cholesky_chain_enabled(const CholeskyContext* ctx) { return ctx && ctx->dq && ctx->server && ctx->resident && ctx->dq->chain_server; }
 bool cholesky_claim_pair_servers(CholeskyContext* ctx) {
   if (!ctx || !ctx->dq) return false;
   if (ctx->dq->pair_users.fetch_add(1) < 4) return true;
@@ -1878,7 +1858,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   struct EnqueueClock {  // developer knob SK_DEBUG_CHAIN_ABORT: a factorisation whose launches took the host unusually long to enqueue
     std::chrono::steady_clock::time_point t0, t1 = std::chrono::steady_clock::now();
     ~EnqueueClock() {
-      static const bool on = getenv("SK_DEBUG_CHAIN_ABORT") != nullptr;
+      const bool on = dev_knobs().debug_chain_abort;
       const double held = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
       const double waited = std::chrono::duration<double, std::milli>(t1 - t0).count();
       if (on && (held > 50.0 || waited > 500.0)) std::fprintf(stderr, "[skeres_amd] cholesky_factor: waited %.1f ms for the device's enqueue lock, enqueued for %.1f ms\n", waited, held);
@@ -1976,12 +1956,12 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     }
   // the same groups launch by launch: while every chain kernel is being timed, and with SK_CHOL_CHAIN_SERVER=0 (PMC
   // passes serialise the kernels of a process: a resident kernel that waits for another one would time out)
-  bool chain = ranges.n > 0 && ctx->dq && ctx->dq->chain_server && !(kt && kt->times_all());
+  bool chain = ranges.n > 0 && ctx->dq && ctx->dq->chain_server && ctx->resident && !(kt && kt->times_all());
   int* sync = chain ? ctx->sync_for(nblk) : nullptr;
   if (!sync) chain = false;  // (the same groups, launch by launch)
   auto is_resident = [&](int k) { return chain && k < nblk && plan.resident[k]; };
   const int maxblk = chain ? ctx->sync_blk : 0;
-  const char* stamps_file = chain ? getenv("SK_CHAIN_STAMPS") : nullptr;
+  const char* stamps_file = chain ? dev_knobs().chain_stamps : nullptr;
   hipStream_t srv = nullptr;
   hipEvent_t start_ev = nullptr;
   struct PartnerState {
@@ -2185,7 +2165,9 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       // (fault injection for tests: SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds what that column's launch
       // waits for, once per process — the wait times out, and the factorisation must be reported as lost: info = 2)
       bool withheld = false;
+#ifdef SK_TESTING
       if (next_resident && !ctx->dq->tuning) { int want = k1; withheld = want >= 0 && g_test_withhold.compare_exchange_strong(want, -1); }
+#endif
       const bool pair_chain = pair && resident;  // (always the 32-row tiling: its first block columns count themselves)
       const bool thin = Tb <= g_thin_syrk_tiles || pair_chain, by_column = next_resident && thin && (g_early_column || pair_chain);
       // after a resident pair the next column launch updates the SECOND block column this SYRK touches (its own next(j) applies
@@ -2243,7 +2225,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   }
   order(sp, s);
   if (la) { order(ctx->bulk, s); order(ctx->bulk_early, s); }
-  if (chain && !g_no_server_join.load(std::memory_order_relaxed)) order(srv, s);
+  if (chain) order(srv, s);
   if (stamps_file) {
     (void)hipStreamSynchronize(s);
     std::vector<long long> st((size_t)1024 * 8);
@@ -2274,7 +2256,7 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
     }
     if (kt) kt->begin("backsolve", s);
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);
-    static const char* bs_stamps = getenv("SK_BS_STAMPS");
+    const char* bs_stamps = dev_knobs().bs_stamps;
     if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
     hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info, nblk, (const double*)nullptr);
     if (kt) kt->end("backsolve", s);
@@ -2414,88 +2396,47 @@ static void fork_join_events(CholeskyContext* c) {
 
 void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, hipStream_t s, CholeskyContext* ctxA, CholeskyContext* ctxB,
                                KernelTimer* kt, KernelTimer* ktB, bool allow_chain) {
-  // developer knob SK_DISSECT_TIMING=1: HIP events on the caller's stream around the parts (printed by the NEXT call, when
-  // they have completed): with SK_DISSECT_SERIAL=1 the tail, the head and the root one after the other
-  static const int timing = getenv("SK_DISSECT_TIMING") ? atoi(getenv("SK_DISSECT_TIMING")) : 0;
-  static hipEvent_t tev[5] = {};
-  static int tcalls = 0;
-  if (timing) {
-    if (!tev[0]) for (auto& e : tev) (void)hipEventCreate(&e);
-    else if (tcalls < 40) {
-      (void)hipEventSynchronize(tev[4]);
-      float a = 0, b = 0, c = 0, dd = 0;
-      (void)hipEventElapsedTime(&a, tev[0], tev[1]); (void)hipEventElapsedTime(&b, tev[1], tev[2]);
-      (void)hipEventElapsedTime(&c, tev[2], tev[3]); (void)hipEventElapsedTime(&dd, tev[3], tev[4]);
-      std::fprintf(stderr, "[skeres_amd] dissected factorisation: first part %.2f ms, second part (+ join) %.2f ms, border add %.2f ms, root %.2f ms\n", a, b, c, dd);
-    }
-    ++tcalls;
-    (void)hipEventRecord(tev[0], s);
-  }
-  static const int serial = getenv("SK_DISSECT_SERIAL") ? atoi(getenv("SK_DISSECT_SERIAL")) : 0;       // developer knobs
-  static const int head_first = getenv("SK_DISSECT_HEAD_FIRST") ? atoi(getenv("SK_DISSECT_HEAD_FIRST")) : 0;
-  const bool side = d.B.ncols > 0 && ctxB && ctxB->fork && !serial;
-  static const int threaded = getenv("SK_DISSECT_THREAD") ? atoi(getenv("SK_DISSECT_THREAD")) : 1;
-  // The tail front rides in the launches of the head's chain-bound block columns (CholeskyPartner) instead of having queues of
-  // its own (developer knob SK_DISSECT_LOCKSTEP=0: the side-by-side form of rounds 2 and 3, slower on every cut measured)
-  static const int lockstep = getenv("SK_DISSECT_LOCKSTEP") ? atoi(getenv("SK_DISSECT_LOCKSTEP")) : 1;
-  if (lockstep && d.A.ncols > 0 && d.B.ncols > 0 && ctxA && ctxB && allow_chain) {
+  // Under the resident chain the tail front rides in the launches of the head's chain-bound block columns (CholeskyPartner) instead
+  // of having queues of its own: the only form that pays on one device (the side-by-side form below
+  // was slower on every cut measured — profiles/r02_dissection_*.txt, r03_dissection_probe.txt, r03_lockstep_cut_sweep.txt)
+  if (d.A.ncols > 0 && d.B.ncols > 0 && ctxA && ctxB && allow_chain) {
     CholeskyPartner pt{d.B.S, d.B.ld, d.B.nblk, d.B.ncols, 1, d.B.last, d.B.Linv, ctxB};
     cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols, 1, &pt);
     if (!pt.taken)  // (not every block column of the tail is a resident single column: factored afterwards, on the primary context)
       cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, allow_chain, d.B.ncols);
-    if (timing) { (void)hipEventRecord(tev[1], s); (void)hipEventRecord(tev[2], s); }
     cholesky_border_add(d.R.S, d.R.ld, d.A.S, d.A.ld, d.A.ncols, d.border_blocks, nullptr, s);
     cholesky_border_add(d.R.S, d.R.ld, d.B.S, d.B.ld, d.B.ncols, d.border_blocks, d.mapB, s);
-    if (timing) (void)hipEventRecord(tev[3], s);
     cholesky_factor(d.R.S, d.R.ld, d.R.nblk * 128, d.R.Linv, info, group, s, ctxA, kt, d.R.last, allow_chain);
-    if (timing) (void)hipEventRecord(tev[4], s);
     return;
   }
-  bool tail_async = false;
-  auto tail = [&]() {
-    if (d.B.ncols <= 0) return;
-    // (one after the other on the primary context: launch by launch, as the fronts' plans assume when there is no second server)
-    if (!side) { cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, allow_chain && ctxB && ctxB->server, d.B.ncols); return; }
+  // Without the resident chain (a device without CU-masked streams, a forced dissection with an explicit grouping): the tail
+  // side by side with the head on a second set of queues, its launches enqueued by a thread of its own — or, without such
+  // queues, one front after the other.
+  const bool side = d.B.ncols > 0 && ctxB && ctxB->fork;
+  if (d.B.ncols > 0 && !side) {
+    cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, allow_chain && ctxB && ctxB->server, d.B.ncols);
+  } else if (side) {
     fork_join_events(ctxB);
-    static const int no_fork = getenv("SK_DISSECT_NO_FORK") ? atoi(getenv("SK_DISSECT_NO_FORK")) : 0;  // developer knob: the tail's panel queue stands in for its caller's stream
-    hipStream_t sB = no_fork ? ctxB->panel : ctxB->fork;
+    hipStream_t sB = ctxB->fork;
     (void)hipEventRecord(ctxB->fork_ev, s);
     (void)hipStreamWaitEvent(sB, ctxB->fork_ev, 0);
-    // the tail's launches (and the event that says they are all enqueued behind `fork`) from ctxB's own thread: the
-    // head's are enqueued by this one meanwhile
+    // the tail's launches (and the event that says they are all enqueued behind `fork`) from ctxB's own thread: the head's are
+    // enqueued by this one meanwhile
     const bool chainB = allow_chain && ctxB->server != nullptr;  // the tail under a resident chain of its own
-    auto job = [&d, info, group, ctxB, ktB, sB, chainB] {
-      const auto h0 = std::chrono::steady_clock::now();
+    if (!ctxB->runner) ctxB->runner.reset(new AsyncRunner(ctxB->device));
+    ctxB->runner->run([&d, info, group, ctxB, ktB, sB, chainB] {
       cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, sB, ctxB, ktB, d.B.last, chainB, d.B.ncols);
       (void)hipEventRecord(ctxB->join_ev, sB);
-      if (timing) std::fprintf(stderr, "[skeres_amd]   host: tail enqueued in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count());
-    };
-    if (threaded) {
-      if (!ctxB->runner) ctxB->runner.reset(new AsyncRunner(ctxB->device));
-      ctxB->runner->run(job);
-      tail_async = true;
-    } else {
-      job();
-    }
-  };
-  // the tail first: its launches are enqueued (and start) while the host is still enqueueing the head's
-  if (!head_first) tail();
-  if (timing && !head_first) (void)hipEventRecord(tev[1], s);
-  const auto hA = std::chrono::steady_clock::now();
+    });
+  }
   if (d.A.ncols > 0) cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols);
-  if (timing) std::fprintf(stderr, "[skeres_amd]   host: head enqueued in %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hA).count());
-  if (timing && head_first) (void)hipEventRecord(tev[1], s);
-  if (head_first) tail();
   if (side) {
-    if (tail_async) ctxB->runner->wait();  // (the join event has been recorded)
+    ctxB->runner->wait();  // (the join event has been recorded)
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);
   }
-  if (timing) (void)hipEventRecord(tev[2], s);
   if (d.A.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.A.S, d.A.ld, d.A.ncols, d.border_blocks, nullptr, s);
   if (d.B.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.B.S, d.B.ld, d.B.ncols, d.border_blocks, d.mapB, s);
-  if (timing) (void)hipEventRecord(tev[3], s);
   cholesky_factor(d.R.S, d.R.ld, d.R.nblk * 128, d.R.Linv, info, group, s, ctxA, kt, d.R.last, allow_chain);
-  if (timing) (void)hipEventRecord(tev[4], s);
 }
 
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,

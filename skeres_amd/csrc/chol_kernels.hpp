@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include "dev_knobs.hpp"
+
 namespace sk {
 
 // HIP-event timing of named kernel launches on the stream they run on.
@@ -143,6 +145,7 @@ struct CholeskyContext {
   DeviceQueues* dq = nullptr;        // the device's queue set this context uses (init(): the device current at that time)
   bool prepared = false;             // the device's queue choice has been made and adopted (cholesky_prepare)
   bool in_trial = false;             // this context is the one running its device's queue trial
+  bool resident = true;              // false: this context's factorisations never use the resident panel chain (sk_options_set_resident_kernels): the same plan, launch by launch
   int device = -1;
   void use(DeviceQueues* q);
   hipStream_t panel = nullptr;

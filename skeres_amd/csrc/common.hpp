@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/skeres_amd.h"
+#include "dev_knobs.hpp"
 #include "functors.hpp"
 #include "loss.hpp"
 #include "parameterization.hpp"
@@ -160,6 +161,9 @@ struct Options {  // Solver.Options; Ceres 1.x defaults
   bool lookahead = true;   // potrf128 on a second stream, off the critical path
   int dissection = SK_DISSECTION_AUTO;  // DENSE_SCHUR: eliminate the head and the tail of a camera sequence side by side (sk_options_set_cholesky_dissection)
   bool envelope = true;    // DENSE_SCHUR: skip the blocks of the reduced system outside its block envelope (bit-identical result)
+  bool resident_kernels = true;  // sk_options_set_resident_kernels: 0 = no kernel of this solver waits for another one (same plans, launch by launch)
+  bool graph_replay = true;      // sk_options_set_graph_replay: launch-bound problems replay their iteration as a hipGraph
+  int max_segments = 0;          // sk_options_set_max_segments: SEGMENTED / AUTO cut the camera sequence into at most this many segments (0: one per rank)
   int border = SK_BORDER_AUTO;  // DENSE_SCHUR: order the cameras of loop closures into a trailing border of the reduced system (sk_options_set_cholesky_border)
 };
 

@@ -95,8 +95,7 @@ hipError_t TapeDevBuffers::upload(const Tape& t, hipStream_t s) {
 // workgroup per CU, 1.28 ms; W = 2, two, 1.08 ms; W = 1, three, 1.92 ms), else the widest that fits at all;
 // 0 = not even one slot fits (too many registers)
 int tape_pick_width(const Tape& t, int threads) {
-  static const int cap = getenv("SK_TAPE_WIDTH") ? atoi(getenv("SK_TAPE_WIDTH")) : 3;  // developer knob
-  const int top = cap < 1 ? 1 : (cap > 3 ? 3 : cap);
+  const int top = 3;
   for (int W = top; W >= 1; --W) if (tape_lds_bytes(t, W, threads) <= kTapeLdsBudget / 2) return W;
   for (int W = top; W >= 1; --W) if (tape_lds_bytes(t, W, threads) <= kTapeLdsBudget) return W;
   return 0;

@@ -748,6 +748,36 @@ def test_default_plan_matches_explicit_grouping_at_full_size():
         assert np.linalg.norm(x_gpu - x_cpu) <= 1e-9 * np.linalg.norm(x_cpu - small.parameters)
 
 
+def test_without_resident_kernels_the_same_plan_runs_launch_by_launch():
+    """sk_options_set_resident_kernels(o, 0): no resident panel chain and no resident back-substitution for THIS solver (what a
+    counter-collection run needs, through the API instead of the process's environment) — the same factorisation plan, the
+    trajectory of the default to rounding; a second solver of the process keeps its resident kernels."""
+    prob = bal.generate(400, 30000, 140000, seed=77)
+
+    def run(resident):
+        problem, params, loss = bal_problem_to_sk(prob)
+        options = sk.Solver.Options()
+        options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+        options.setMaxNumIterations(4)
+        options.setResidentKernels(resident)
+        solver = sk.StepSolver(options, problem)
+        stats = (solver.stat("cholesky_columns_resident"), solver.stat("dissected"), solver.stat("cholesky_flops_plan"))
+        while not solver.step():
+            pass
+        summary = sk.Solver.Summary()
+        solver.finish(summary)
+        return summary, stats
+    s_on, (res_on, dis_on, flops_on) = run(True)
+    s_off, (res_off, dis_off, flops_off) = run(False)
+    s_on2, (res_on2, _, _) = run(True)
+    assert res_on >= 10 and res_off == 0 and res_on2 == res_on and dis_off == 0
+    assert flops_off == flops_on or dis_on == 1  # (the same plan unless the default dissected the sequence)
+    for u, v in zip(s_off.iterations(), s_on.iterations()):
+        for k, tol in (("cost", 1e-10), ("step_norm", 1e-9)):
+            assert abs(u[k] - v[k]) <= tol * max(abs(v[k]), 1e-300), (k, u[k], v[k])
+    assert [it["cost"] for it in s_on2.iterations()] == [it["cost"] for it in s_on.iterations()]
+
+
 @pytest.mark.parametrize("C,P,N,seed,extra", [(60, 2500, 12000, 13, None), (150, 3000, 14000, 5, None), (400, 30000, 140000, 77, None),
                                               (150, 3000, 14000, 6, "loss+masks")])
 def test_dissected_dense_schur_vs_oracle(C, P, N, seed, extra):
@@ -805,6 +835,7 @@ def test_bordered_dense_schur_vs_oracle(C, P, N, seed, revisits):
     problem, params, loss = bal_problem_to_sk(prob)
     options = sk.Solver.Options()
     options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    options.setMaxNumIterations(6)  # (the oracle factors a 7200 x 7200 reduced system per iteration)
     options.setCholeskyBorder("on")
     solver = sk.StepSolver(options, problem)
     nb = solver.stat("border_cameras")
@@ -816,7 +847,7 @@ def test_bordered_dense_schur_vs_oracle(C, P, N, seed, revisits):
     solver.finish(summary)
     x_gpu = params.toArray(prob.num_parameters)
     x_cpu, so = oracle.solve_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
-                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=4))
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=_oracle_threads(), max_num_iterations=6, cholesky_envelope=1))
     _check_against_oracle(prob, summary, x_gpu, so, x_cpu)
     problem2, params2, loss2 = bal_problem_to_sk(prob)
     options.setCholeskyBorder("off")
@@ -829,7 +860,7 @@ def test_bordered_dense_schur_vs_oracle(C, P, N, seed, revisits):
     for u, v in zip(summary.iterations()[:5], s_off.iterations()[:5]):
         assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
     # ... and with an explicit SYRK depth, launch by launch (no resident chain)
-    x_g, s_g = solve_bal_gpu(prob, setCholeskyBorder="on", setCholeskyTuning=2)
+    x_g, s_g = solve_bal_gpu(prob, setCholeskyBorder="on", setCholeskyTuning=2, setMaxNumIterations=6)
     for u, v in zip(s_g.iterations()[:5], s_off.iterations()[:5]):
         assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
 
@@ -933,8 +964,12 @@ def test_resident_chain_timeout_is_reported_and_refactored():
         out = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stdout + out.stderr
         return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
-    clean, err_clean = run({})
-    hit, err_hit = run({"SK_CHAIN_TEST_WITHHOLD_MARKER": "7"})
+    # the fault-injection hook exists only in the testing build of the library (-DSK_TESTING: `make -C skeres_amd/csrc testing`,
+    # built by __graft_entry__.build()); the product library has no such variable
+    testing = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "skeres_amd", "libskeres_amd_testing.so")
+    assert os.path.exists(testing), "build the testing library: python -c 'import __graft_entry__ as g; g.build()'"
+    clean, err_clean = run({"SK_CHAIN_TEST_WITHHOLD_MARKER": "7"})  # (the product library: the variable is not even read)
+    hit, err_hit = run({"SK_CHAIN_TEST_WITHHOLD_MARKER": "7", "SKERES_AMD_LIBRARY": testing})
     assert "timed out" not in err_clean and clean["resident_after"] == clean["resident_before"] >= 60
     assert "the resident panel chain timed out" in err_hit          # loud
     assert hit["resident_before"] >= 60 and hit["resident_after"] == 0   # launch by launch from then on
@@ -1028,13 +1063,13 @@ def test_at_most_four_solvers_of_a_device_run_two_resident_servers():
 def test_schedule_of_the_schur_assembly_does_not_change_a_bit(tmp_path):
     """Round 3 moved work of the Schur assembly around without touching its arithmetic: the envelope of S is zeroed on a
     stream of its own next to the next Jacobian evaluation, and the pair kernels' logical blocks run in groups of eight per
-    XCD.  With both switched off (developer knobs) the 400-camera trajectory of tests/backsolve_worker.py is the same, bit for bit."""
+    XCD.  With both switched off (developer variable SK_SCHEDULE_PLAIN=1) the 400-camera trajectory of tests/backsolve_worker.py is the same, bit for bit."""
     import os
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "backsolve_worker.py")
     res = {}
-    for mode, env in (("new", {}), ("plain", {"SK_NO_ZERO_OVERLAP": "1", "SK_PAIR_XCD_GROUP": "0", "SK_PAIR_XCD_GROUP_LONG": "0"})):
+    for mode, env in (("new", {}), ("plain", {"SK_SCHEDULE_PLAIN": "1"})):
         path = str(tmp_path / ("sched_%s.npz" % mode))
         out = subprocess.run([sys.executable, worker, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
