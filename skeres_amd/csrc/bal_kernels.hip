@@ -209,10 +209,13 @@ __global__ __launch_bounds__(kBlock) void bal_eval_jac_tape_kernel(BalDev d, Tap
     const int ci = d.cam[o], pi = d.pt[o];
     double c[kTapeMaxObs];
     for (int k = 0; k < num_obs; ++k) c[k] = d.obs[(size_t)k * d.N + o];
-    auto param = [&](int k) { return k < 9 ? d.xc[9 * (size_t)ci + k] : d.xp[3 * (size_t)pi + (k - 9)]; };
+    // (the functor's own block sizes — at most (2; 9, 3): flattened parameter k is camera coordinate k, or point coordinate k - cam_size)
+    const int cs = d.cam_size, dim = d.cam_size + d.pt_size;
+    auto param = [&](int k) { return k < cs ? d.xc[9 * (size_t)ci + k] : d.xp[3 * (size_t)pi + (k - cs)]; };
     double r0 = 0.0, r1 = 0.0, sqrt_rho1 = 1.0, alpha_sq_norm = 0.0;
-    for (int first = 0; first < 12; first += W) {
+    for (int first = 0; first < dim; first += W) {
       J out[2];
+      out[1] = J(0.0);  // (a functor with one residual: the second row stays zero)
       tape_run<J>(t, c, param, first, regs, out);
       if (first == 0) {
         r0 = out[0].a; r1 = out[1].a;
@@ -234,20 +237,21 @@ __global__ __launch_bounds__(kBlock) void bal_eval_jac_tape_kernel(BalDev d, Tap
 #pragma unroll
       for (int w = 0; w < W; ++w) {
         const int k = first + w;
+        if (k >= dim) continue;  // (the last pass of a shape whose dimension W does not divide)
         double j0 = out[0].v[w], j1 = out[1].v[w];
         if (kLoss) {
           const double rtj = alpha_sq_norm * (r0 * j0 + r1 * j1);
           const double a0 = sqrt_rho1 * (j0 - r0 * rtj), a1 = sqrt_rho1 * (j1 - r1 * rtj);
           j0 = a0; j1 = a1;
         }
-        if (k < 9) {
+        if (k < cs) {
           const double s = d.scale_c[9 * (size_t)ci + k];
           d.F[(size_t)k * d.N + o] = j0 * s;
           d.F[(size_t)(9 + k) * d.N + o] = j1 * s;
         } else {
-          const double s = d.scale_p[3 * (size_t)pi + (k - 9)];
-          d.E[(size_t)(k - 9) * d.N + o] = j0 * s;
-          d.E[(size_t)(3 + k - 9) * d.N + o] = j1 * s;
+          const double s = d.scale_p[3 * (size_t)pi + (k - cs)];
+          d.E[(size_t)(k - cs) * d.N + o] = j0 * s;
+          d.E[(size_t)(3 + k - cs) * d.N + o] = j1 * s;
         }
       }
     }
@@ -264,7 +268,9 @@ __global__ __launch_bounds__(kBlock) void bal_eval_cost_tape_kernel(BalDev d, Ta
     const int ci = d.cam[o], pi = d.pt[o];
     double c[kTapeMaxObs], out[2];
     for (int k = 0; k < num_obs; ++k) c[k] = d.obs[(size_t)k * d.N + o];
-    auto param = [&](int k) { return k < 9 ? d.xc_new[9 * (size_t)ci + k] : d.xp_new[3 * (size_t)pi + (k - 9)]; };
+    const int cs = d.cam_size;
+    auto param = [&](int k) { return k < cs ? d.xc_new[9 * (size_t)ci + k] : d.xp_new[3 * (size_t)pi + (k - cs)]; };
+    out[1] = 0.0;
     tape_run<double>(t, c, param, 0, regs, out);
     if (kLoss) {
       double rho[3];

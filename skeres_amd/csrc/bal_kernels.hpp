@@ -17,6 +17,7 @@ constexpr int kWs = 32;
 constexpr int kWu = 28;  // ... of which the pair kernels read the first 28 (27 used)
 struct BalDev {
   int C, P, N;            // cameras (all, replicated), LOCAL points, LOCAL observations
+  int res_size, cam_size, pt_size;  // the problem's own block shape (r; c, q) <= (2; 9, 3) (bal_solver.hip: bal_block_shape); smaller shapes are padded
   // structure (built once on the host, point-major observation order)
   const int* cam;         // [N] camera of observation o
   const int* pt;          // [N] local point of observation o

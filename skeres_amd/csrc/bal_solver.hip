@@ -15,22 +15,40 @@
 
 namespace sk {
 
+// The block structure DENSE_SCHUR eliminates: every residual block has r residuals over TWO parameter blocks, a "camera" of c
+// coordinates (the f-block that stays in the reduced system) and a "point" of q coordinates (the e-block that is eliminated),
+// the same (r; c, q) for every block, with r <= 2, c <= 9, q <= 3.  The kernels are written for the reference's bundle
+// adjuster, (2; 9, 3) (EX/SimpleBundleAdjuster.scala:79-119); a smaller shape — a pinhole camera of six coordinates, a planar
+// point — runs in the same kernels PADDED: the missing coordinates are inert unknowns (Jacobi scale 0, as a coordinate held
+// constant by a SubsetParameterization: a zero Jacobian column, min_lm_diagonal / radius on the diagonal, step exactly 0), a
+// missing residual row is zero.  The LM trajectory is that of the unpadded problem; the reduced system is 9 C wide instead of c C.
+bool bal_block_shape(const Problem& p, int* r, int* c, int* q) {
+  if (p.rb_functor.empty()) return false;
+  const size_t b0 = 0;
+  if (p.rb_pidx_off[b0 + 1] - p.rb_pidx_off[b0] != 2) return false;
+  *r = p.rb_num_residuals[b0];
+  *c = p.block_size[p.rb_pidx[p.rb_pidx_off[b0]]];
+  *q = p.block_size[p.rb_pidx[p.rb_pidx_off[b0] + 1]];
+  return true;
+}
 bool problem_is_bal_shaped(const Problem& p, std::string* why) {
   const size_t nb = p.rb_functor.size();
   if (nb == 0) { *why = "problem has no residual blocks"; return false; }
-  // the registered device functor of that shape, or ANY cost function of that shape through the director path
+  int R = 0, Cs = 0, Qs = 0;
+  const char* shape_msg = "DENSE_SCHUR is implemented for residual blocks with at most 2 residuals over a camera block of at most 9 and a point block of at most 3 "
+                          "parameters, the same sizes for every block (SnavelyReprojectionError on the device, a recorded functor, or any host-callback cost "
+                          "function of such a shape); not supported: another shape";
+  if (!bal_block_shape(p, &R, &Cs, &Qs) || R < 1 || R > 2 || Cs < 1 || Cs > 9 || Qs < 1 || Qs > 3) { *why = shape_msg; return false; }
+  // the registered device functor (2; 9, 3), a recorded functor, or ANY cost function of the shape through the director path
   // (sk_cost_function_new_callback: the caller's Evaluate, run on the host — CORE/CostFunctor.scala:40-51, ceres.i:48)
   for (size_t b = 0; b < nb; ++b) {
+    if (p.rb_pidx_off[b + 1] - p.rb_pidx_off[b] != 2 || p.rb_num_residuals[b] != R || p.block_size[p.rb_pidx[p.rb_pidx_off[b]]] != Cs ||
+        p.block_size[p.rb_pidx[p.rb_pidx_off[b] + 1]] != Qs) { *why = shape_msg; return false; }
     const CostFunction* cf = b < p.rb_cost.size() ? p.rb_cost[b] : nullptr;
-    const bool host_ok = p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK && cf && cf->callback && cf->num_residuals == 2 && cf->block_sizes.size() == 2 &&
-                         cf->block_sizes[0] == 9 && cf->block_sizes[1] == 3;
-    const Tape* tp = p.tape_of_block(b);
-    const bool tape_ok = tp && tp->num_residuals == 2 && tp->block_sizes.size() == 2 && tp->block_sizes[0] == 9 && tp->block_sizes[1] == 3;
-    if (p.rb_functor[b] != SK_FUNCTOR_SNAVELY_REPROJECTION && !host_ok && !tape_ok) {
-      *why = "DENSE_SCHUR is implemented for residual blocks with 2 residuals over a 9- and a 3-parameter block (SnavelyReprojectionError on the "
-             "device, a recorded functor of that shape, or any host-callback cost function of that shape); not supported: another shape";
-      return false;
-    }
+    const bool host_ok = p.rb_functor[b] == SK_FUNCTOR_HOST_CALLBACK && cf && cf->callback;
+    const bool tape_ok = p.tape_of_block(b) != nullptr;
+    const bool snavely_ok = p.rb_functor[b] == SK_FUNCTOR_SNAVELY_REPROJECTION && R == 2 && Cs == 9 && Qs == 3;
+    if (!snavely_ok && !host_ok && !tape_ok) { *why = shape_msg; return false; }
   }
   // one device functor per problem: the evaluation kernels are launched over all device-evaluated observations at once
   int device_functor = -1;
@@ -231,6 +249,7 @@ class BalSolver : public SolverBase {
   int gather_rank_scalars_signed(double* vals, int K);
 
   int C_ = 0, P_total_ = 0, P_ = 0, N_ = 0;   // cameras, all points, local points, local observations
+  int res_size_ = 2, cam_size_ = 9, pt_size_ = 3;  // the problem's own (r; c, q) (bal_block_shape): padded to (2; 9, 3) inside
   int n_ = 0, npad_ = 0, rhs_row_ = 0;
   std::vector<int> cam_block_, pt_block_;     // parameter block id of camera i / global point p
   std::vector<int> local_pt_;                 // global point id of local point
@@ -821,6 +840,7 @@ int BalSolver::setup() {
       }
     }
   const int Nall = (int)p.rb_functor.size();
+  (void)bal_block_shape(p, &res_size_, &cam_size_, &pt_size_);
   std::vector<int> ocam, opt;
   bal_index_problem(p, &cam_block_, &pt_block_, &ocam, &opt);
   C_ = (int)cam_block_.size(); P_total_ = (int)pt_block_.size();
@@ -1166,9 +1186,9 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_short_segs_.upload(short_segs, s)); SK_HIP_TRY(b_long_segs_.upload(long_segs, s));
   d_.num_short_segments = (int)short_segs.size(); d_.num_long_segments = (int)long_segs.size();
   const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_, nx = nc + np;
-  std::vector<double> x(nx);
-  for (int i = 0; i < C_; ++i) std::memcpy(&x[9 * (size_t)i], p.block_ptr[cam_block_[i]], 9 * sizeof(double));
-  for (int q = 0; q < P_; ++q) std::memcpy(&x[nc + 3 * (size_t)q], p.block_ptr[pt_block_[local_pt_[q]]], 3 * sizeof(double));
+  std::vector<double> x(nx, 0.0);  // (the padding coordinates of a smaller shape: zeros, and inert — see free_mask below)
+  for (int i = 0; i < C_; ++i) std::memcpy(&x[9 * (size_t)i], p.block_ptr[cam_block_[i]], cam_size_ * sizeof(double));
+  for (int q = 0; q < P_; ++q) std::memcpy(&x[nc + 3 * (size_t)q], p.block_ptr[pt_block_[local_pt_[q]]], pt_size_ * sizeof(double));
   // x vectors are stored [cameras | points] so whole-vector kernels run once
   SK_HIP_TRY(b_xc_.upload(x, s)); SK_HIP_TRY(b_xc_new_.alloc(nx));
   SK_HIP_TRY(b_scale_.alloc(nx)); SK_HIP_TRY(b_colsq_.alloc(nx)); SK_HIP_TRY(b_gs_.alloc(nx)); SK_HIP_TRY(b_step_.alloc(nx));
@@ -1177,21 +1197,25 @@ int BalSolver::setup() {
     // block (Problem::SetParameterBlockConstant) or the constant coordinates of a SubsetParameterization (ceres.i:186-210);
     // an IdentityParameterization changes nothing.  See jacobi_scale_kernel.
     std::vector<double> free_mask(nx, 1.0);
-    auto mask_block = [&](int block, size_t off, int size) {
+    auto mask_block = [&](int block, size_t off, int size, int padded) {
+      for (int k = size; k < padded; ++k) free_mask[off + k] = 0.0;  // padding of a shape smaller than (2; 9, 3): inert coordinates
       if ((size_t)block < p.block_constant.size() && p.block_constant[block]) { for (int k = 0; k < size; ++k) free_mask[off + k] = 0.0; return; }
       const int pi = (size_t)block < p.block_param.size() ? p.block_param[block] : -1;
       if (pi < 0) return;
       const LocalParameterization& lp = p.params[pi];
       if (lp.type == kParamSubset) for (int k = 0; k < size; ++k) if ((lp.constant_mask >> k) & 1u) free_mask[off + k] = 0.0;
     };
-    for (int i = 0; i < C_; ++i) mask_block(cam_block_[i], 9 * (size_t)i, 9);
-    for (int q = 0; q < P_; ++q) mask_block(pt_block_[local_pt_[q]], nc + 3 * (size_t)q, 3);
+    for (int i = 0; i < C_; ++i) mask_block(cam_block_[i], 9 * (size_t)i, cam_size_, 9);
+    for (int q = 0; q < P_; ++q) mask_block(pt_block_[local_pt_[q]], nc + 3 * (size_t)q, pt_size_, 3);
     SK_HIP_TRY(hipMemcpyAsync(b_scale_.p, free_mask.data(), nx * sizeof(double), hipMemcpyHostToDevice, s));
     SK_HIP_TRY(hipStreamSynchronize(s));
   }
   SK_HIP_TRY(b_y_.alloc(npad_ + 128));
   SK_HIP_TRY(b_r_.alloc(2 * (size_t)N_)); SK_HIP_TRY(b_F_.alloc(18 * (size_t)N_)); SK_HIP_TRY(b_Fcam_.alloc(kFcam * (size_t)N_)); SK_HIP_TRY(b_E_.alloc(6 * (size_t)N_));
   SK_HIP_TRY(b_W_.alloc(kWs * (size_t)N_)); SK_HIP_TRY(b_rt_.alloc(5 * (size_t)N_));
+  if (res_size_ < 2 || cam_size_ < 9 || pt_size_ < 3) {  // the planes of the padding coordinates / the missing residual row are never written: zero, once
+    SK_HIP_TRY(b_r_.zero(s)); SK_HIP_TRY(b_F_.zero(s)); SK_HIP_TRY(b_E_.zero(s));
+  }
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
   // ---- the fronts of the reduced camera system ----
   std::vector<int> border_row_h[2], leaf_map_h, leaf_gmap_h;
@@ -1281,6 +1305,7 @@ int BalSolver::setup() {
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
+  d_.res_size = res_size_; d_.cam_size = cam_size_; d_.pt_size = pt_size_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p; d_.obs_slot = b_obs_slot_.p;
   d_.num_segments = (int)seg_row.size(); d_.seg_start = b_seg_start_.p; d_.seg_row = b_seg_row_.p; d_.seg_col = b_seg_col_.p;
   d_.short_segments = b_short_segs_.p; d_.long_segments = b_long_segs_.p;
@@ -1716,8 +1741,23 @@ int BalSolver::host_callbacks(const double* x_dev, bool jac, bool* failed) {
     const double* params[2] = {&host_x_[9 * (size_t)h_cam_[o]], &host_x_[nc + 3 * (size_t)h_pt_[o]]};
     double* row = &host_rows_h_[h * (size_t)kHostRow];
     for (int k = 0; k < kHostRow; ++k) row[k] = 0.0;
-    double* jptr[2] = {row + 2, row + 20};
-    if (!cf->callback(cf->user, params, row, jac ? jptr : nullptr)) { *failed = true; return SK_OK; }
+    if (res_size_ == 2 && cam_size_ == 9 && pt_size_ == 3) {
+      double* jptr[2] = {row + 2, row + 20};
+      if (!cf->callback(cf->user, params, row, jac ? jptr : nullptr)) { *failed = true; return SK_OK; }
+    } else {
+      // a smaller shape: the caller's Evaluate writes r residuals and row-major r x c / r x q blocks (CORE/AutodiffCostFunction.scala:115-130);
+      // they go into the (2; 9, 3) row the kernels read, the rest of it zero
+      double res[2] = {0.0, 0.0}, jc[2 * 9], jq[2 * 3];
+      double* jptr[2] = {jc, jq};
+      if (!cf->callback(cf->user, params, res, jac ? jptr : nullptr)) { *failed = true; return SK_OK; }
+      for (int r = 0; r < res_size_; ++r) {
+        row[r] = res[r];
+        if (jac) {
+          for (int k = 0; k < cam_size_; ++k) row[2 + 9 * r + k] = jc[r * cam_size_ + k];
+          for (int k = 0; k < pt_size_; ++k) row[20 + 3 * r + k] = jq[r * pt_size_ + k];
+        }
+      }
+    }
   }
   SK_HIP_TRY(hipMemcpyAsync(b_host_rows_.p, host_rows_h_.data(), host_rows_h_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
   SK_HIP_TRY(hipStreamSynchronize(stream_));  // (host_rows_h_ is pageable and reused by the next evaluation)
@@ -1745,9 +1785,9 @@ int BalSolver::write_back() {
     SK_HIP_TRY(hipMemcpyAsync(x.data(), tmpc.p, nc * sizeof(double), hipMemcpyDeviceToHost, stream_));
     SK_HIP_TRY(hipStreamSynchronize(stream_));
   }
-  for (int i = 0; i < C_; ++i) std::memcpy(problem_->block_ptr[cam_block_[i]], &x[9 * (size_t)i], 9 * sizeof(double));
+  for (int i = 0; i < C_; ++i) std::memcpy(problem_->block_ptr[cam_block_[i]], &x[9 * (size_t)i], cam_size_ * sizeof(double));
   if (!opt_.allreduce) {
-    for (int q = 0; q < P_; ++q) std::memcpy(problem_->block_ptr[pt_block_[local_pt_[q]]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
+    for (int q = 0; q < P_; ++q) std::memcpy(problem_->block_ptr[pt_block_[local_pt_[q]]], &x[nc + 3 * (size_t)q], pt_size_ * sizeof(double));
     return SK_OK;
   }
   // every rank returns ALL points: zero-filled table, own slice filled, sum-reduced
@@ -1760,7 +1800,7 @@ int BalSolver::write_back() {
   if (rc) return rc;
   SK_HIP_TRY(hipMemcpyAsync(all.data(), tmp.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
   SK_HIP_TRY(hipStreamSynchronize(stream_));
-  for (int q = 0; q < P_total_; ++q) std::memcpy(problem_->block_ptr[pt_block_[q]], &all[3 * (size_t)q], 3 * sizeof(double));
+  for (int q = 0; q < P_total_; ++q) std::memcpy(problem_->block_ptr[pt_block_[q]], &all[3 * (size_t)q], pt_size_ * sizeof(double));
   return SK_OK;
 }
 

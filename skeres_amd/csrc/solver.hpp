@@ -75,6 +75,7 @@ void bal_index_problem(const Problem& p, std::vector<int>* cam_block, std::vecto
                        std::vector<int>* opt);
 void bal_partition_points(const std::vector<int>& opt, int num_points, int world, std::vector<int>* cut);
 int bal_segment_plan(const Problem& p, int max_segments, bool forced, std::vector<int>* block_camera_part, std::vector<int>* block_point_owner);
+bool bal_block_shape(const Problem& p, int* r, int* c, int* q);
 int bal_border_plan(const Problem& p, int mode, std::vector<int>* final_index_of_block, int* gap, double* model_us, double* plain_us, double* fill);
 // Generic dense Jacobian path: DENSE_QR / DENSE_NORMAL_CHOLESKY.
 std::unique_ptr<SolverBase> make_dense_solver(const Options& o, Problem* p);

@@ -5,6 +5,8 @@ handed to the device as recordings (``skeres_amd.TracedCostFunctor``): none of t
                                      (CORE/Rotation.scala:449-522, whose `if` on theta^2 becomes a ``where``)
     TracedExponentialResidual        EX/CurveFitting.scala:92-98
     TracedPowell                     EX/Powell.scala:14-53, the four residuals as one functor over four 1-blocks
+    TracedPinholeReprojectionError   the bundle adjuster's functor with the camera's intrinsics CAPTURED instead of optimised: a
+                                     (2; 6, 3) block shape — DENSE_SCHUR on a shape other than the reference's (2; 9, 3)
 """
 import numpy as np
 
@@ -61,3 +63,22 @@ class TracedPowell(TracedCostFunctor):
     def apply(self, x1, x2, x3, x4):
         a, b, c, d = x1[0], x2[0], x3[0], x4[0]
         return [a + 10.0 * b, float(np.sqrt(5.0)) * (c - d), (b - 2.0 * c) * (b - 2.0 * c), float(np.sqrt(10.0)) * (a - d) * (a - d)]
+
+
+class TracedPinholeReprojectionError(TracedCostFunctor):
+    """EX/SimpleBundleAdjuster.scala:79-119 over a camera of SIX parameters (angle-axis, translation); focal length and the two
+    distortion coefficients are captured doubles of the closure, like the observation.  The same residual as
+    SnavelyReprojectionError on a camera whose intrinsics are held constant."""
+
+    def __init__(self, observedX, observedY, focal, k1, k2, residuals=2):
+        super().__init__(residuals, 6, 3, captured=(observedX, observedY, focal, k1, k2))
+
+    def apply(self, camera, point):
+        ox, oy, focal, k1, k2 = self.captured_values()
+        p = angle_axis_rotate_point(camera[0:3], point)
+        p = [p[0] + camera[3], p[1] + camera[4], p[2] + camera[5]]
+        xp, yp = (-p[0]) / p[2], (-p[1]) / p[2]
+        r2 = xp * xp + yp * yp
+        distortion = 1.0 + r2 * (k1 + k2 * r2)
+        fd = focal * distortion
+        return [fd * xp - ox, fd * yp - oy][: self.kNumResiduals]

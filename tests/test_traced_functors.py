@@ -11,7 +11,8 @@ import pytest
 
 import skeres_amd as sk
 from skeres_amd import bal, tape as T
-from skeres_amd.examples.traced_functors import TracedExponentialResidual, TracedPowell, TracedSnavelyReprojectionError
+from skeres_amd.examples.traced_functors import (TracedExponentialResidual, TracedPinholeReprojectionError, TracedPowell,
+                                                  TracedSnavelyReprojectionError)
 from skeres_amd.rotation import Jet
 
 
@@ -315,6 +316,82 @@ def test_recorded_snavely_under_dense_schur_follows_the_device_functor_and_the_o
     for k in range(min(5, len(a), so.num_logged)):
         assert abs(a[k]["cost"] - so.iterations[k].cost) <= 1e-10 * so.iterations[k].cost
     np.testing.assert_allclose(params.toArray(prob.num_parameters), x_dev, atol=1e-7)
+
+
+def _pinhole_problem(prob, residuals=2, host_every=0):
+    """The bundle-adjustment problem `prob` over SIX-parameter cameras: (problem, params, keep-alive list).  The cameras' intrinsics
+    become captured doubles of the functor; host_every > 0: every host_every-th block through the director path instead of the
+    recording (the caller's Evaluate over Jets on the host, with the (r; 6, 3) sizes)."""
+    C, P = prob.num_cameras, prob.num_points
+    cams = prob.cameras()
+    x6 = np.concatenate([cams[:, :6].ravel(), prob.points().ravel()])
+    params = sk.RichDoubleArray.fromArray(x6)
+    problem = sk.Problem()
+    loss = sk.PredefinedLossFunctions.trivialLoss()
+    captured = np.concatenate([prob.observations, cams[prob.camera_index, 6:9]], axis=1)
+    offs = np.stack([6 * prob.camera_index.astype(np.int64), 6 * C + 3 * prob.point_index.astype(np.int64)], axis=1)
+    recorded = TracedPinholeReprojectionError(0.0, 0.0, 1.0, 0.0, 0.0, residuals=residuals)
+    keep = [recorded]
+    if host_every <= 0:
+        problem.addResidualBlocksTraced(recorded, captured, loss, params, offs)
+    else:
+        for i in range(prob.num_observations):
+            f = recorded.withCaptured(*captured[i])
+            cf = f.toHostAutoDiffCostFunction() if i % host_every == 0 else f.toAutoDiffCostFunction()
+            keep.append(cf)
+            problem.addResidualBlock(cf, loss, params.slice(int(offs[i, 0])), params.slice(int(offs[i, 1])))
+    return problem, params, keep
+
+
+@gpu
+@pytest.mark.parametrize("host_every", [0, 4])
+def test_dense_schur_on_a_smaller_block_shape_vs_oracle(host_every):
+    """DENSE_SCHUR on a block shape other than the reference's (2; 9, 3) — round 4: until then such a problem went to the DENSE_QR
+    alternate.  A pinhole camera of six parameters (intrinsics captured by the closure) and 3-D points, (2; 6, 3), as a recorded
+    functor (and, host_every = 4, with every fourth block through the director path): the kernels run it padded to (2; 9, 3)
+    with three inert coordinates per camera.  The oracle's Schur path solves the SAME problem as SnavelyReprojectionError with
+    the cameras' intrinsics held constant (cam_mask): per-iteration cost at 1e-10, the parameters it moved."""
+    import oracle
+    C, P, N = 16, 200, 900
+    prob = bal.generate(C, P, N, seed=23)
+    problem, params, keep = _pinhole_problem(prob, host_every=host_every)
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    summary = sk.Solver.Summary()
+    sk.ceres.solve(options, problem, summary)
+    assert summary.linearSolverTypeUsed() == sk.LinearSolverType.DENSE_SCHUR  # (not the alternate)
+    cam_mask = np.full(C, 0b111000000, dtype=np.int32)
+    x_cpu, so = oracle.solve_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR), cam_mask=cam_mask, pt_mask=np.zeros(P, dtype=np.int32))
+    a = summary.iterations()
+    assert abs(len(a) - so.num_logged) <= 1
+    for k in range(min(5, len(a), so.num_logged)):
+        assert abs(a[k]["cost"] - so.iterations[k].cost) <= 1e-10 * so.iterations[k].cost, (k, a[k]["cost"], so.iterations[k].cost)
+    assert abs(summary.finalCost() - so.final_cost) <= 1e-9 * so.final_cost
+    x6 = params.toArray(6 * C + 3 * P)
+    ref = np.concatenate([x_cpu[:9 * C].reshape(C, 9)[:, :6].ravel(), x_cpu[9 * C:]])
+    assert np.linalg.norm(x6 - ref) <= 1e-7 * np.linalg.norm(ref)
+
+
+@gpu
+def test_dense_schur_with_one_residual_per_block_follows_the_dense_path():
+    """... and (1; 6, 3): one residual per block (the x coordinate of the reprojection only), the second row of every block zero
+    inside the kernels.  No oracle solves that shape through its Schur path; the device's own DENSE_QR on the same problem gives
+    the same LM trajectory (the step does not depend on how the linear system is solved)."""
+    prob = bal.generate(8, 120, 700, seed=5)
+    costs = {}
+    for kind in ("DENSE_SCHUR", "DENSE_QR"):
+        problem, params, keep = _pinhole_problem(prob, residuals=1)
+        options = sk.Solver.Options()
+        options.setLinearSolverType(getattr(sk.LinearSolverType, kind))
+        options.setMaxNumIterations(8)
+        summary = sk.Solver.Summary()
+        sk.ceres.solve(options, problem, summary)
+        assert summary.linearSolverTypeUsed() == getattr(sk.LinearSolverType, kind)
+        costs[kind] = [it["cost"] for it in summary.iterations()]
+    assert len(costs["DENSE_SCHUR"]) == len(costs["DENSE_QR"]) >= 4
+    for u, v in zip(costs["DENSE_SCHUR"], costs["DENSE_QR"]):
+        assert abs(u - v) <= 1e-8 * v, (costs["DENSE_SCHUR"], costs["DENSE_QR"])
 
 
 @gpu

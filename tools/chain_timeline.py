@@ -16,7 +16,12 @@ from skeres_amd import bal  # noqa: E402
 def main():
     path = os.path.join(tempfile.gettempdir(), "sk_chain_stamps.txt")
     os.environ["SK_CHAIN_STAMPS"] = path
-    prob = bal.generate_named(sys.argv[1] if len(sys.argv) > 1 else "ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1))
+    which = sys.argv[1] if len(sys.argv) > 1 else "ladybug-1723-156502"
+    if which.startswith("band:"):  # a synthetic camera band of another size: band:C,P,N,seed
+        C_, P_, N_, seed_ = (int(v) for v in which[5:].split(","))
+        prob = bal.generate(C_, P_, N_, seed=seed_)
+    else:
+        prob = bal.generate_named(which, seed=1723, perturb=(1e-2, 1e-1, 1e-1))
     params = sk.RichDoubleArray.fromArray(prob.parameters)
     problem = sk.Problem()
     offs = np.stack([9 * prob.camera_index.astype(np.int64), 9 * prob.num_cameras + 3 * prob.point_index.astype(np.int64)], axis=1)
@@ -27,6 +32,7 @@ def main():
     o.setFunctionTolerance(0.0)
     o.setGradientTolerance(0.0)
     o.setParameterTolerance(0.0)
+    o.setCholeskyDissection(sys.argv[2] if len(sys.argv) > 2 else "off")  # (the stamps are per block column of ONE front)
     s = sk.StepSolver(o, problem)
     for _ in range(4):
         s.step()
