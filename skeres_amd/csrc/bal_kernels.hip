@@ -96,8 +96,10 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* out_partial, i
 // ---------------------------------------------------------------------------
 // kLoss: robust loss (loss.hpp) — the block's residuals and both Jacobian blocks are corrected before they
 // are stored, the cost term is rho(|r|^2).  A separate instantiation: the trivial-loss kernel stays as it was.
+// (launch bounds: three waves per SIMD.  Left to itself the kernel takes 170 VGPRs — two waves; asked for three it fits 168 without a
+// byte of scratch, and the kernel is bound by how many waves are in flight, not by its arithmetic — round 4)
 template <bool kLoss>
-__global__ __launch_bounds__(kBlock) void bal_eval_jac_kernel(BalDev d) {
+__global__ __launch_bounds__(kBlock, kLoss ? 2 : 3) void bal_eval_jac_kernel(BalDev d) {
   double acc[1] = {0.0};
   for (int o = blockIdx.x * kBlock + threadIdx.x; o < d.N; o += gridDim.x * kBlock) {
     if (d.is_host && d.is_host[o]) continue;  // the caller's host code evaluates this one (bal_host_jac_kernel)
@@ -429,8 +431,10 @@ __global__ __launch_bounds__(kBlock) void bal_cam_records_kernel(BalDev d) {
   }
 }
 
-__global__ __launch_bounds__(kBlock) void bal_cam_reduce_kernel(BalDev d) {
-  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+// Round 4: the cameras' and the points' column reductions are ONE launch — workgroups [0, cam_blocks) take the cameras, the rest the
+// points (bal_reduce_kernel below): the two do not depend on each other, and side by side they take as long as the longer one.
+__device__ __forceinline__ void bal_cam_reduce_body(const BalDev& d, int block) {
+  const int wave = (block * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= d.C) return;
   double sq[9], g[9];
 #pragma unroll
@@ -457,8 +461,8 @@ __global__ __launch_bounds__(kBlock) void bal_cam_reduce_kernel(BalDev d) {
   }
 }
 
-__global__ __launch_bounds__(kBlock) void bal_pt_reduce_kernel(BalDev d) {
-  const int gid = blockIdx.x * kBlock + threadIdx.x, sub = gid % kPointLanes;
+__device__ __forceinline__ void bal_pt_reduce_body(const BalDev& d, int block) {
+  const int gid = block * kBlock + threadIdx.x, sub = gid % kPointLanes;
   const int p = gid / kPointLanes;
   if (p >= d.P) return;  // (whole lane groups: kBlock is a multiple of kPointLanes)
   double sq[3] = {0, 0, 0}, g[3] = {0, 0, 0};
@@ -477,6 +481,11 @@ __global__ __launch_bounds__(kBlock) void bal_pt_reduce_kernel(BalDev d) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { d.colsq_p[3 * (size_t)p + k] = sq[k]; d.gs_p[3 * (size_t)p + k] = g[k]; }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void bal_reduce_kernel(BalDev d, int cam_blocks) {
+  if ((int)blockIdx.x < cam_blocks) bal_cam_reduce_body(d, (int)blockIdx.x);
+  else bal_pt_reduce_body(d, (int)blockIdx.x - cam_blocks);
 }
 
 // Generic small vector kernels -------------------------------------------------
@@ -585,9 +594,11 @@ __global__ __launch_bounds__(kBlock) void bal_point_block_kernel(BalDev d) {
 // its slot of the CAMERA-major order (obs_slot).  A lane storing its own record would write 29 doubles 256 bytes apart from
 // every other lane's — 64 cache lines per store instruction; the wave's 64 records go through LDS and out sixteen lanes to
 // a record, 16 bytes each: four whole records per store instruction.
-__global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
+__global__ __launch_bounds__(kBlock, 4) void bal_obs_precompute_kernel(BalDev d) {
+  // Round 4: the records of HALF a wave are staged at a time (the values wait in registers): 8.7 KB of LDS per wave instead of
+  // 17.4, four workgroups per CU instead of two — the kernel streams, and what bounds it is the loads in flight.
   constexpr int kLs = kWs + 2;  // record stride in LDS (even: 16-byte reads)
-  __shared__ __attribute__((aligned(16))) double stage[kBlock / 64][64 * kLs];
+  __shared__ __attribute__((aligned(16))) double stage[kBlock / 64][32 * kLs];
   const size_t N = d.N, P = d.P;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* mine = &stage[wave][0];
@@ -595,6 +606,7 @@ __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
   for (long base = (long)(blockIdx.x * kBlock + wave * 64); base < (long)d.N; base += (long)gridDim.x * kBlock) {
     const long o = base + lane;
     const int my_slot = o < (long)d.N ? d.obs_slot[o] : 0;
+    double w[27], rt[2];
     if (o < (long)d.N) {
       const int p = d.pt[o];
       const double m00 = d.M[p], m10 = d.M[P + p], m11 = d.M[2 * P + p], m20 = d.M[3 * P + p], m21 = d.M[4 * P + p], m22 = d.M[5 * P + p];
@@ -606,29 +618,38 @@ __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
         eh[r][0] = e0 * m00;
         eh[r][1] = e0 * m10 + e1 * m11;
         eh[r][2] = e0 * m20 + e1 * m21 + e2 * m22;
-        mine[lane * kLs + 27 + r] = d.r[r * N + o] - (e0 * q0 + e1 * q1 + e2 * q2);
+        rt[r] = d.r[r * N + o] - (e0 * q0 + e1 * q1 + e2 * q2);
       }
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
         const double f0 = d.F[c * N + o], f1 = d.F[(9 + c) * N + o];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) mine[lane * kLs + 3 * c + a] = f0 * eh[0][a] + f1 * eh[1][a];
+        for (int a = 0; a < 3; ++a) w[3 * c + a] = f0 * eh[0][a] + f1 * eh[1][a];
       }
-      mine[lane * kLs + 29] = 0.0; mine[lane * kLs + 30] = 0.0; mine[lane * kLs + 31] = 0.0;  // (the record's padding)
     }
-    __builtin_amdgcn_wave_barrier();  // LDS writes of a wave are in order with its reads; keep the compiler from mixing them
     const int nrec = (int)(((long)d.N - base) < 64 ? ((long)d.N - base) : 64);
     const int sub = lane >> 4, chunk = lane & 15;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int rec = 4 * it + sub;
-      const int slot = __shfl(my_slot, rec, 64);
-      if (rec < nrec) {
-        const double2 v = *reinterpret_cast<const double2*>(&mine[rec * kLs + 2 * chunk]);
-        *reinterpret_cast<double2*>(d.What + (size_t)slot * kWs + 2 * chunk) = v;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((lane >> 5) == half && o < (long)d.N) {
+        double* rec = mine + (lane & 31) * kLs;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) rec[k] = w[k];
+        rec[27] = rt[0]; rec[28] = rt[1];
+        rec[29] = 0.0; rec[30] = 0.0; rec[31] = 0.0;  // (the record's padding)
       }
+      __builtin_amdgcn_wave_barrier();  // LDS writes of a wave are in order with its reads; keep the compiler from mixing them
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int rl = 4 * it + sub, rec = 32 * half + rl;  // sixteen lanes to a record, 16 bytes each: four whole records per store instruction
+        const int slot = __shfl(my_slot, rec, 64);
+        if (rec < nrec) {
+          const double2 v = *reinterpret_cast<const double2*>(&mine[rl * kLs + 2 * chunk]);
+          *reinterpret_cast<double2*>(d.What + (size_t)slot * kWs + 2 * chunk) = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -636,16 +657,18 @@ __global__ __launch_bounds__(kBlock) void bal_obs_precompute_kernel(BalDev d) {
 //   S_ii = sum_o (F^T F - What What^T)      (D_c^2 is added after the all-reduce)
 //   rhs_i = sum_o F^T rt
 // rhs goes to row `rhs_row` of S (the augmented row the factorisation carries).
+// Round 4: a WORKGROUP per camera (four waves, each a quarter of the camera's observations in turns of 64, summed in wave order
+// through LDS) instead of a wave: the cameras that the long tracks see have thousands of observations — 47 turns of one wave
+// where the average camera has 6 — and the launch lasted as long as the longest of them.
 __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
-  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (i >= d.C) return;
-  const size_t N = d.N;
+  __shared__ double part[kBlock / 64][54];
+  const int i = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double acc[45], rh[9];
 #pragma unroll
   for (int k = 0; k < 45; ++k) acc[k] = 0.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) rh[k] = 0.0;
-  for (int e = d.cam_start[i] + lane; e < d.cam_start[i + 1]; e += 64) {
+  for (int e = d.cam_start[i] + wv * 64 + lane; e < d.cam_start[i + 1]; e += kBlock) {
     double f0[9], f1[9], w[28];
     {
       const double2* rec = reinterpret_cast<const double2*>(d.Fcam + (size_t)e * kFcam);  // camera-major: streamed
@@ -670,18 +693,22 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < 45; ++k) acc[k] = wave_sum(acc[k]);
+  for (int k = 0; k < 45; ++k) { const double v = wave_sum(acc[k]); if (lane == 0) part[wv][k] = v; }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) rh[k] = wave_sum(rh[k]);
-  if (lane == 0 && d.front[bal_part(d, i)].S) {  // (a rank of a segmented world holds one leaf front and the root)
-    int k = 0, ld;
-    double* blk = bal_block(d, i, i, &ld);
-    double* rhs = bal_rhs(d, i);
+  for (int k = 0; k < 9; ++k) { const double v = wave_sum(rh[k]); if (lane == 0) part[wv][45 + k] = v; }
+  __syncthreads();
+  if (threadIdx.x < 54 && d.front[bal_part(d, i)].S) {  // (a rank of a segmented world holds one leaf front and the root)
+    const int k = threadIdx.x;
+    double v = part[0][k];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      rhs[c] = rh[c];
-#pragma unroll
-      for (int e2 = 0; e2 <= c; ++e2, ++k) blk[(size_t)c * ld + e2] = acc[k];
+    for (int w2 = 1; w2 < kBlock / 64; ++w2) v += part[w2][k];
+    if (k >= 45) {
+      bal_rhs(d, i)[k - 45] = v;
+    } else {
+      int ld, c = 0;
+      while ((c + 1) * (c + 2) / 2 <= k) ++c;  // entry k of the lower triangle: row c, column k - c (c + 1) / 2
+      double* blk = bal_block(d, i, i, &ld);
+      blk[(size_t)c * ld + (k - c * (c + 1) / 2)] = v;
     }
   }
 }
@@ -1005,10 +1032,13 @@ int launch_bal_host_cost(const BalDev& d, int partial_off, hipStream_t s) {
 }
 void launch_bal_scale_jac(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_scale_jac_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_records(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_records_kernel, dim3(grid_for((d.N + 63) / 64 * 64)), dim3(kBlock), 0, s, d); }
-void launch_bal_cam_reduce(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_reduce_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+// the cameras' and the points' column norms and gradient entries (colsq, gs), one launch
+void launch_bal_reduce(const BalDev& d, hipStream_t s) {
+  const int cam_blocks = (d.C * 64 + kBlock - 1) / kBlock, pt_blocks = d.P > 0 ? (int)(((long)d.P * kPointLanes + kBlock - 1) / kBlock) : 0;
+  hipLaunchKernelGGL(bal_reduce_kernel, dim3(cam_blocks + pt_blocks), dim3(kBlock), 0, s, d, cam_blocks);
+}
 static int point_grid(int P) { return (int)(((long)P * kPointLanes + kBlock - 1) / kBlock); }
 int bal_point_blocks(int P) { return P > 0 ? point_grid(P) : 1; }
-void launch_bal_pt_reduce(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_pt_reduce_kernel, dim3(point_grid(d.P)), dim3(kBlock), 0, s, d); }
 void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(jacobi_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, scale, n); }
 void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* scale, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(apply_scale_to_reductions_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, gs, scale, n); }
 void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(lm_diagonal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, colsq, D, n, lo, hi, radius); }
@@ -1020,7 +1050,7 @@ int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x
 void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s) { hipLaunchKernelGGL(final_reduce_kernel, dim3(K), dim3(kBlock), 0, s, partial, stride, count, K, maxmask, out); }
 void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_point_block_kernel, dim3(point_grid(d.P)), dim3(kBlock), 0, s, d); }
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
-void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3(d.C), dim3(kBlock), 0, s, d); }
 void launch_bal_pair(const BalDev& d, hipStream_t s) {
   // runs of eight logical blocks per XCD (developer variable SK_SCHEDULE_PLAIN=1: plain order.  Measured, Schur-assembly phase per iteration, plain -> 8:
   // Ladybug-1723 0.520 -> 0.499 ms, Venice-1778 3.02 -> 2.79 ms; 32 is worse on Ladybug — profiles/r03_pair_xcd_sweep.txt)

@@ -108,8 +108,7 @@ int launch_bal_host_jac(const BalDev& d, int partial_off, hipStream_t s);
 int launch_bal_host_cost(const BalDev& d, int partial_off, hipStream_t s);
 void launch_bal_scale_jac(const BalDev& d, hipStream_t s);
 void launch_bal_cam_records(const BalDev& d, hipStream_t s);  // F, r planes -> camera-major records (Fcam)
-void launch_bal_cam_reduce(const BalDev& d, hipStream_t s);
-void launch_bal_pt_reduce(const BalDev& d, hipStream_t s);
+void launch_bal_reduce(const BalDev& d, hipStream_t s);  // colsq and gs of cameras (from the camera-major records) and points, one launch
 void launch_jacobi_scale(const double* colsq, double* scale, int n, hipStream_t s);
 void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* scale, int n, hipStream_t s);
 void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s);

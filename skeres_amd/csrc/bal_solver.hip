@@ -372,9 +372,11 @@ static std::vector<int> envelope_of_order(const std::vector<int>& ocam, const st
 // column costs the larger of its panel chain and its trailing update.
 struct Dissection { int a = 0, b = 0; double t_plain = 0.0, t_dissected = 0.0; };
 static double column_cost_us(int h, bool resident_capable) {
-  // trailing update: 14 TFLOP/s where it is a few dozen thin tiles, 32 TFLOP/s (+ 20 us between launches) where it is wide
+  // trailing update: 14 TFLOP/s where it is a few dozen thin tiles, 38 TFLOP/s (+ 14 us between launches) where it is wide
   const double flops = 128.0 * 128.0 * 128.0 * ((double)h * h + h);
-  const double update_us = h > 24 ? flops / 32e6 + 20.0 : flops / 14e6;
+  // (round 4, recalibrated on the bench line's chain_model records — the wide launches ran at 38-44 TFLOP/s in situ where 32 + 20 us
+  // was assumed: measured / model was 0.69-0.75 on the wide envelopes of the loop-closure problems, 0.87-0.9 on the banded ones)
+  const double update_us = h > 24 ? flops / 38e6 + 14.0 : flops / 14e6;
   const double chain_us = (resident_capable && h <= 24) ? 42.0 : 70.0;  // resident panel chain / four launches per column
   return std::max(update_us, chain_us);
 }
@@ -1460,8 +1462,7 @@ int BalSolver::evaluate_with_jacobian(bool first) {
     nb += launch_bal_host_jac(d_, nb, s);
   }
   kt_.begin("bal_cam_records", s); launch_bal_cam_records(d_, s); kt_.end("bal_cam_records", s);
-  kt_.begin("bal_cam_reduce", s); launch_bal_cam_reduce(d_, s); kt_.end("bal_cam_reduce", s);
-  launch_bal_pt_reduce(d_, s);
+  kt_.begin("bal_reduce", s); launch_bal_reduce(d_, s); kt_.end("bal_reduce", s);
   if (opt_.allreduce) {  // camera columns are summed over all ranks' observations
     double* buf = b_small_.p;
     if (replica_) {  // its sums are rank (r mod segments_)'s over again

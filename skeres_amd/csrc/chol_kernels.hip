@@ -1833,7 +1833,9 @@ void cholesky_prepare(CholeskyContext* ctx, hipStream_t s) {
   // it and skewing what it measures; the trial's own factorisations never get here: cholesky_factor checks `tuning`)
   std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());
   DeviceQueues& q = *ctx->dq;
-  if (!q.chain_server) return;
+  // (a context that may not run resident kernels — sk_options_set_resident_kernels(o, 0) — does not run the trial either: its
+  // first stage IS a resident chain; such a solver takes the device's choice if another solver has made one, else combination 0)
+  if (!q.chain_server || !ctx->resident) { if (q.queue_choice >= 0) { ctx->use(&q); ctx->prepared = true; } return; }
   if (q.queue_choice < 0) tune_chain_queues(ctx, s);
   ctx->use(&q);  // (every context of the device: the choice is the device's)
   ctx->prepared = q.queue_choice >= 0;  // the choice is final: later factorisations of this context take no lock
