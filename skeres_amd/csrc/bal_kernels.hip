@@ -657,18 +657,18 @@ __global__ __launch_bounds__(kBlock, 4) void bal_obs_precompute_kernel(BalDev d)
 //   S_ii = sum_o (F^T F - What What^T)      (D_c^2 is added after the all-reduce)
 //   rhs_i = sum_o F^T rt
 // rhs goes to row `rhs_row` of S (the augmented row the factorisation carries).
-// Round 4: a WORKGROUP per camera (four waves, each a quarter of the camera's observations in turns of 64, summed in wave order
-// through LDS) instead of a wave: the cameras that the long tracks see have thousands of observations — 47 turns of one wave
-// where the average camera has 6 — and the launch lasted as long as the longest of them.
+// (Round 4 tried a WORKGROUP per camera — four waves, a quarter of the camera's observations each, summed in wave order through
+// LDS — against the cameras with thousands of observations that set the length of the launch: 91-96 us against 66-68; the 54
+// wave-level sums at the end of every wave cost more than the long cameras' turns.)
 __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
-  __shared__ double part[kBlock / 64][54];
-  const int i = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (i >= d.C) return;
   double acc[45], rh[9];
 #pragma unroll
   for (int k = 0; k < 45; ++k) acc[k] = 0.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) rh[k] = 0.0;
-  for (int e = d.cam_start[i] + wv * 64 + lane; e < d.cam_start[i + 1]; e += kBlock) {
+  for (int e = d.cam_start[i] + lane; e < d.cam_start[i + 1]; e += 64) {
     double f0[9], f1[9], w[28];
     {
       const double2* rec = reinterpret_cast<const double2*>(d.Fcam + (size_t)e * kFcam);  // camera-major: streamed
@@ -693,22 +693,18 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < 45; ++k) { const double v = wave_sum(acc[k]); if (lane == 0) part[wv][k] = v; }
+  for (int k = 0; k < 45; ++k) acc[k] = wave_sum(acc[k]);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { const double v = wave_sum(rh[k]); if (lane == 0) part[wv][45 + k] = v; }
-  __syncthreads();
-  if (threadIdx.x < 54 && d.front[bal_part(d, i)].S) {  // (a rank of a segmented world holds one leaf front and the root)
-    const int k = threadIdx.x;
-    double v = part[0][k];
+  for (int k = 0; k < 9; ++k) rh[k] = wave_sum(rh[k]);
+  if (lane == 0 && d.front[bal_part(d, i)].S) {  // (a rank of a segmented world holds one leaf front and the root)
+    int k = 0, ld;
+    double* blk = bal_block(d, i, i, &ld);
+    double* rhs = bal_rhs(d, i);
 #pragma unroll
-    for (int w2 = 1; w2 < kBlock / 64; ++w2) v += part[w2][k];
-    if (k >= 45) {
-      bal_rhs(d, i)[k - 45] = v;
-    } else {
-      int ld, c = 0;
-      while ((c + 1) * (c + 2) / 2 <= k) ++c;  // entry k of the lower triangle: row c, column k - c (c + 1) / 2
-      double* blk = bal_block(d, i, i, &ld);
-      blk[(size_t)c * ld + (k - c * (c + 1) / 2)] = v;
+    for (int c = 0; c < 9; ++c) {
+      rhs[c] = rh[c];
+#pragma unroll
+      for (int e2 = 0; e2 <= c; ++e2, ++k) blk[(size_t)c * ld + e2] = acc[k];
     }
   }
 }
@@ -1050,7 +1046,7 @@ int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x
 void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s) { hipLaunchKernelGGL(final_reduce_kernel, dim3(K), dim3(kBlock), 0, s, partial, stride, count, K, maxmask, out); }
 void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_point_block_kernel, dim3(point_grid(d.P)), dim3(kBlock), 0, s, d); }
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
-void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3(d.C), dim3(kBlock), 0, s, d); }
+void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_pair(const BalDev& d, hipStream_t s) {
   // runs of eight logical blocks per XCD (developer variable SK_SCHEDULE_PLAIN=1: plain order.  Measured, Schur-assembly phase per iteration, plain -> 8:
   // Ladybug-1723 0.520 -> 0.499 ms, Venice-1778 3.02 -> 2.79 ms; 32 is worse on Ladybug — profiles/r03_pair_xcd_sweep.txt)

@@ -325,19 +325,20 @@ class BalSolver : public SolverBase {
   CholeskyContext chol_ctx_;
   double* h_scal_ = nullptr;  // pinned
   int partial_stride_ = 0;
-  // The envelope of S has to be zero again before the next assembly (the factor overwrote it): zeroed on a stream of its own
-  // when the step's results are in — enqueued THEN, by the host, never behind a device-side wait of milliseconds (a queue that
-  // waits costs the queues that run) — next to the Jacobian evaluation of the next iteration.
-  hipStream_t zero_stream_ = nullptr;
-  hipEvent_t ev_zero_ = nullptr;
-  bool zero_pending_ = false;
-  bool zero_deferred_ = false;  // the step's results are in, the zeroing is not enqueued yet: behind the Jacobian evaluation's first launch (round 4)
+  // The envelope of S has to be zero again before the next assembly (the factor overwrote it).  Round 4: the back-substitution
+  // does it — every block of L below the diagonal is read exactly once there, by the owner workgroup of its column, which
+  // writes zeros back (cholesky_backsolve(..., zero_after)); what it does not visit, the diagonal 128-blocks and a leaf front's
+  // border x border square, is a small pass at the start of the next assembly (b_zero_min_f_: 16-40 MB instead of the envelope's
+  // 378 MB on Ladybug-1723).  Rounds 2-3 zeroed the whole envelope on a stream of its own next to the Jacobian evaluation, which
+  // that slowed to a third (bal_eval_jac 40 us alone, 116 us beside the zeroing: profiles/r04_point_phases_*).  The full pass
+  // remains for a solver without resident kernels, after a factorisation that failed or timed out, and under SK_SCHEDULE_PLAIN.
+  bool zero_by_backsolve_ = false;
+  bool need_full_zero_ = false;  // the last back-substitution did not (or not surely) zero what it read
+  DevBuf<int> b_zero_min_f_[3];
   bool pair_claimed_ = false;  // cholesky_claim_pair_servers: this solver may run a partner front's server beside its own
  public:
   ~BalSolver() override {
     if (pair_claimed_) cholesky_release_pair_servers(&chol_ctx_);
-    if (zero_stream_) { (void)hipStreamSynchronize(zero_stream_); (void)hipStreamDestroy(zero_stream_); }
-    if (ev_zero_) (void)hipEventDestroy(ev_zero_);
     for (hipGraphExec_t g : {g_step_[0], g_step_[1], g_eval_[0], g_eval_[1]}) if (g) (void)hipGraphExecDestroy(g);
     if (h_scal_) (void)hipHostFree(h_scal_);
   }
@@ -1290,6 +1291,11 @@ int BalSolver::setup() {
       for (int i = 0; i < F.nblk; ++i) col0[i] = std::max(0, first[i] - (widen - 1));
     }
     SK_HIP_TRY(b_zero_col0_f_[f].upload(col0, s));
+    // ... and what the back-substitution leaves to zero: the diagonal block of every factored block column, and from the first border
+    // column on in the border's block rows (the Schur complement a leaf front accumulates there)
+    std::vector<int> col_min(F.nblk);
+    for (int i = 0; i < F.nblk; ++i) col_min[i] = i < F.ncols ? i : F.ncols;
+    SK_HIP_TRY(b_zero_min_f_[f].upload(col_min, s));
   }
   for (int f = 0; f < 2; ++f) if (!border_row_h[f].empty()) SK_HIP_TRY(b_border_row_[f].upload(border_row_h[f], s));
   if (segmented_) { SK_HIP_TRY(b_leaf_map_.upload(leaf_map_h, s)); SK_HIP_TRY(b_leaf_gmap_.upload(leaf_gmap_h, s)); }
@@ -1364,10 +1370,8 @@ int BalSolver::setup() {
     host_x_.resize(nx); host_rows_h_.resize(host_obs_.size() * (size_t)kHostRow);
   }
   graph_mode_ = graph_mode_ && host_obs_.empty() && !dissected_ && !tape_mode_;
-  if (!graph_mode_ && !dev_knobs().schedule_plain) {  // (developer variable SK_SCHEDULE_PLAIN: the envelope zeroed in line, on the solver's stream)
-    SK_HIP_TRY(hipStreamCreateWithFlags(&zero_stream_, hipStreamNonBlocking));
-    SK_HIP_TRY(hipEventCreateWithFlags(&ev_zero_, hipEventDisableTiming));
-  }
+  zero_by_backsolve_ = !graph_mode_ && !dev_knobs().schedule_plain && opt_.resident_kernels;
+  for (int f = 0; f < 3; ++f) if (fr_[f].nblk > 0 && !cholesky_backsolve_resident(fr_[f].nblk)) zero_by_backsolve_ = false;
   SK_HIP_TRY(hipStreamSynchronize(s));
   if (opt_.allreduce) {
     // every rank derived the camera order and the envelope for itself (from rank-invariant data): they must be the same
@@ -1446,13 +1450,6 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   kt_.begin("bal_eval_jac", s);
   if (tape_mode_) launch_bal_eval_jac_tape(d_, tape_dev_, s); else launch_bal_eval_jac(d_, s);
   kt_.end("bal_eval_jac", s);
-  if (zero_deferred_ && zero_stream_ && !graph) {  // the envelope of the reduced system zeroed next to this evaluation (try_step_once)
-    for (int f = 0; f < 3; ++f)
-      if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, b_zero_col0_f_[f].p, fr_[f].nblk, zero_stream_);
-    SK_HIP_TRY(hipEventRecord(ev_zero_, zero_stream_));
-    zero_pending_ = true;
-    zero_deferred_ = false;
-  }
   int nb = bal_partial_blocks(N_);
   if (d_.num_host > 0) {
     bool failed = false;
@@ -1566,16 +1563,13 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     d_.lm_radius_dev = b_scal_.p + 12;
   }
   // ---- B. Schur complement assembly ----
-  zero_deferred_ = false;
-  if (zero_pending_) {
-    SK_HIP_TRY(hipStreamWaitEvent(s, ev_zero_, 0));  // zeroed since the last step's results came in
-    zero_pending_ = false;
-  } else {
-    kt_.begin("memset_S", s);
-    for (int f = 0; f < 3; ++f)  // only what the factorisations can read
-      if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, b_zero_col0_f_[f].p, fr_[f].nblk, s);
-    kt_.end("memset_S", s);
-  }
+  // (this step's back-substitution zeroes what it reads when it is the resident launch: decided here, once, for the whole step)
+  const bool zero_after = zero_by_backsolve_ && cholesky_backsolve_resident(npad_ / 128);
+  kt_.begin("memset_S", s);
+  for (int f = 0; f < 3; ++f)
+    if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, (zero_by_backsolve_ && !need_full_zero_) ? b_zero_min_f_[f].p : b_zero_col0_f_[f].p, fr_[f].nblk, s);
+  kt_.end("memset_S", s);
+  need_full_zero_ = !zero_after;
   SK_HIP_TRY(hipMemsetAsync(b_scal_.p + 14, 0, 2 * sizeof(double), s));  // the failure flag and the factorisation's info
   launch_bal_point_block(d_, s);
   launch_bal_obs_precompute(d_, s);
@@ -1636,18 +1630,18 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     launch_tri_pack(Rs, (int)R.dim, b_pack_.p, R.nblk, b_pack_col0_.p, b_pack_off_.p, false, s);
     finish_root();
     cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok());
-    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info);
+    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info, nullptr, zero_after);
     if (L.ncols > 0) {
       cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
-      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info);
+      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info, zero_after);
     }
   } else if (dissected_) {
     cholesky_dissected_factor(ds_, info_p_, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
-    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, bs_info);
+    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, bs_info, zero_after);
   } else {
     const FrontHost& R = fr_[2];
     cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok(), -1, 1, nullptr, R.tl());
-    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl());
+    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl(), zero_after);
   }
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----
@@ -1680,10 +1674,6 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
   }
   SK_HIP_TRY(hipStreamSynchronize(s));
-  // (everything that reads S is done: see zero_stream_.  The launches themselves wait until the Jacobian evaluation of an accepted
-  // step has its first kernel enqueued — the host's three launches and the event cost the evaluation 30 us of its start otherwise;
-  // after a rejected step the next assembly zeroes in line)
-  zero_deferred_ = !graph && zero_stream_ != nullptr;
   float ms = 0.f;
   if (graph) {  // one replayed graph: no events inside it — the whole linear solve + candidate evaluation is reported as "factor"
     if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvCost]) == hipSuccess) phase_[2] += 1e-3 * ms;
@@ -1695,7 +1685,17 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   }
   int fail = 0, info = 0;
   std::memcpy(&fail, h_scal_ + 14, sizeof(int)); std::memcpy(&info, h_scal_ + 15, sizeof(int));
-  if (cholesky_note_info(&chol_ctx_, info) && !opt_.allreduce) { *chain_lost = true; return SK_OK; }  // factor again, launch by launch
+  if (info != 0) need_full_zero_ = true;  // (a pivot that was not positive, a wait that gave up: whatever the back-substitution did, start from a clean envelope)
+  if (cholesky_note_info(opt_.lookahead ? &chol_ctx_ : nullptr, info) && !opt_.allreduce) {  // factor again, launch by launch
+    if (graph_mode_) {
+      // a replayed graph would launch the resident kernel that has just timed out again and again (the choice is made at capture): the
+      // iteration is enqueued launch by launch from here on
+      for (hipGraphExec_t* g : {&g_step_[0], &g_step_[1], &g_eval_[0], &g_eval_[1]}) if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+      graph_mode_ = false;
+    }
+    *chain_lost = true;
+    return SK_OK;
+  }
   // sum r_new^2, model term, |delta_p|^2 (segmented: + this rank's cameras' |delta_c|^2, which no other rank has), failure
   double loc[4] = {h_scal_[0], h_scal_[1], h_scal_[9] + (segmented_ ? h_scal_[8] : 0.0), (double)(fail | info)};
   const int ops4[4] = {0, 0, 0, 1};

@@ -1136,8 +1136,8 @@ __device__ int g_bs_stamps_on;              // the block row next to the diagona
 constexpr int kBsMaxBlocks = 960;  // (two tables of that many entries + the other arguments: inside the 4 KB kernel-argument segment)
 struct BsTop { unsigned short top[kBsMaxBlocks]; unsigned short tail[kBsMaxBlocks]; };  // per block column: the last block row of its contiguous run (<= nblk - 1), and the first of its tail rows
 constexpr unsigned long long kBsSentinel = ~0ull;
-__global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __restrict__ Linv, const double* __restrict__ S, long ld, const double* __restrict__ rhs,
-                                                               int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb) {
+__global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __restrict__ Linv, double* S, long ld, const double* rhs,
+                                                               int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb, int zero_after /* number of janitor workgroups */) {
   // nown < nblk: the interior of a LEAF FRONT (cholesky_backsolve_front): block columns [0, nown) have owners, the unknowns of
   // the block rows below them — the front's border — are known (yb, in the border's order: the separators' solution); the block
   // rows from env.tail[kb] on are active in block column kb whatever its run (the right-hand-side row; a spike: SegmentLayout; the
@@ -1145,6 +1145,44 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
   // 1024 threads: column c of the block and one of eight groups of sixteen rows each — sixteen products per thread and matrix
   // on the chain's critical path where 256 threads had sixty-four (0.41 -> 0.39 ms on Ladybug-1723: the hop is mostly hand-over and barriers); the partial sums are formed over the
   // same rows and added in the same order as before (and as in bs_step_kernel)
+  // janitors > 0 (round 4): the launch has `janitors` more workgroups behind the owners.  Every block of L below the diagonal is read
+  // here exactly once, by the owner of its column; when y_kb is out, the owner is done with column kb, and janitor kb mod
+  // janitors writes ZEROS over that column's blocks: the assembly of the next linear system needs the envelope zero again, and
+  // a separate pass over it (378 MB on Ladybug-1723) either sits on the critical path or — on a stream of its own next to the
+  // Jacobian evaluation, as in rounds 2-3 — slows that evaluation to a third.  (The OWNERS storing the zeros behind their loads
+  // was tried first: +0.25 ms of Cholesky phase — a workgroup's store path is one CU's, and an owner that has to write back every
+  // block it reads no longer keeps up with the chain's 3.3 us per hop.)  The launch has idle CUs to spare (an owner per block
+  // column on 256 CUs); a janitor waits for an owner, which was dispatched before it.  What the owners do not visit — the diagonal
+  // blocks, a leaf front's border x border square — stays with zero_envelope_kernel (BalSolver: b_zero_min_f_).
+  if ((int)blockIdx.x >= nown) {
+    const int jn = (int)blockIdx.x - nown, t = threadIdx.x, c = t & 127, rg = t >> 7;
+    __shared__ int ok_s;
+    for (int kb = nown - 1 - jn; kb >= 0; kb -= zero_after) {
+      if (t == 0) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(y + (long)kb * 128);
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kBsSentinel) {
+          __builtin_amdgcn_s_sleep(8);
+          if (wall_clock64() - t0 > kChainTimeoutTicks) { ok = 0; break; }  // (the owners report the time-out; the host then zeroes everything)
+        }
+        ok_s = ok;
+      }
+      __syncthreads();
+      if (!ok_s) return;
+      const int top = min((int)env.top[kb], nblk - 1);
+      const int tlo = max((int)env.tail[kb], top + 1);
+      double* col = S + (long)(rg * 16) * ld + (long)kb * 128 + c;
+      for (int cur = kb + 1; cur < nblk; ++cur) {
+        if (cur > top && cur < tlo) { cur = tlo - 1; continue; }
+        double* pz = col + (long)cur * 128 * ld;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pz[(long)i * ld] = 0.0;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   __shared__ double ysh[128], wsh[128], part[16][128];
   __shared__ int abort_s;
   const int kb = nown - 1 - (int)blockIdx.x;
@@ -1201,6 +1239,7 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
 #pragma unroll
       for (int i = 0; i < 16; ++i) lr[i] = p[(long)i * ld];
     }
+
     __syncthreads();
     if (t < 128) {
       double u = 0.0;
@@ -1800,7 +1839,13 @@ bool cholesky_note_info(CholeskyContext* ctx, int info) {
     for (int j = 0; j < 40 && j < ctx->sync_blk; ++j) std::fprintf(stderr, " %d", h[kSyncHeader + ctx->sync_blk + j]);
     std::fprintf(stderr, "\n");
   }
-  if (info != 2 || !ctx || !ctx->dq) return false;
+  if (info != 2) return false;
+  // (no look-ahead queues — a solver with the look-ahead off, or one that replays its iteration as a graph: the wait that gave up
+  // was the resident back-substitution's.  It is switched off above; the same system is to be solved again — ADVICE r03)
+  if (!ctx || !ctx->dq) {
+    std::fprintf(stderr, "[skeres_amd] the resident back-substitution timed out: one launch per block step from now on\n");
+    return true;
+  }
   std::lock_guard<std::mutex> lock(g_device_queues.operation_mutex());
   if (ctx->dq->chain_server) {
     ctx->dq->chain_server = 0;
@@ -2102,7 +2147,9 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       const int T = rn.main + rn.extra;  // rows of X(.,k0) == rows that next(g) updates (K = 128, na == 1)
       // block row k0+1 is active as the start of the main run, or as the last block row itself
       const int ncrit = (rn.main > 0 || rn.jump == 0) ? 16 : 0;
-      with_partner = pb.on && k0 >= pb.start_at && pb.next < pb.ncols && !after_pair && Tb <= g_thin_syrk_tiles;
+      // (a partner rides only with SYRKs in the thin tiling, which all go to ctx->bulk: early_tiles > g_thin_syrk_tiles, or consecutive
+      // SYRKs of a front could land on two streams with only their first block column awaited — ADVICE r03)
+      with_partner = pb.on && k0 >= pb.start_at && pb.next < pb.ncols && !after_pair && Tb <= g_thin_syrk_tiles && ctx->early_tiles > g_thin_syrk_tiles;
       if (with_partner) pst = partner_step(pb.next);
       hipEvent_t col_done = (Tb > 0 || (with_partner && pst.Tb > 0)) ? ctx->event(ev++) : nullptr;
       if (with_partner) {
@@ -2247,8 +2294,12 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
 
 // y (npad) <- solution of L^T y = z, with z^T = row rhs_row of L (first n entries).  w: scratch (npad).
 // With an envelope, block row kb of L is zero left of the first block column c with last[c] >= kb.
-void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt, const int* last, int* info, const int* tail) {
+bool cholesky_backsolve_resident(int nblk) { return g_bs_resident.load() != 0 && nblk <= kBsMaxBlocks; }
+// janitor workgroups of a resident back-substitution with `owners` owner workgroups (bs_resident_kernel): as many as there are owners, up
+// to 96 — with the owners they stay inside the chip's 256 CUs (a workgroup of 1024 threads at 256 VGPRs fills one)
+static int bs_janitors(int owners) { return std::max(1, std::min(owners, 96)); }
+void cholesky_backsolve(double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
+                        hipStream_t s, KernelTimer* kt, const int* last, int* info, const int* tail, bool zero_after) {
   const int nblk = npad / 128;
   if (info && g_bs_resident && nblk <= kBsMaxBlocks) {
     BsTop env;
@@ -2260,7 +2311,9 @@ void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, 
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);
     const char* bs_stamps = dev_knobs().bs_stamps;
     if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
-    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, n, y, nblk, env, info, nblk, (const double*)nullptr);
+    const int janitors = zero_after ? bs_janitors(nblk) : 0;
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), n, y, nblk, env, info, nblk, (const double*)nullptr,
+                       janitors);
     if (kt) kt->end("backsolve", s);
     if (bs_stamps) {
       (void)hipStreamSynchronize(s);
@@ -2355,8 +2408,8 @@ void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f
 
 // Interior part of L^T y = z for a leaf front whose border unknowns are known.  yb: border unknowns (border_blocks * 128
 // values, zero where the border has padding or its right-hand-side row).  w: scratch (ncols * 128); y: interior solution.
-void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info) {
+void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
+                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info, bool zero_after) {
   const int ni = ncols * 128, m = (nblk - ncols) * 128;
   if (ncols <= 0) return;
   if (info && g_bs_resident && nblk <= kBsMaxBlocks) {
@@ -2367,7 +2420,8 @@ void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int
     BsTop env;
     for (int c = 0; c < nblk; ++c) { env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1); env.tail[c] = (unsigned short)(nblk - tail_rows); }
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)ni, s);
-    hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols), dim3(1024), 0, s, Linv, S, ld, S + (long)rhs_row * ld, ni, y, nblk, env, info, ncols, yb);
+    const int janitors = zero_after ? bs_janitors(ncols) : 0;
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), ni, y, nblk, env, info, ncols, yb, janitors);
     return;
   }
   hipLaunchKernelGGL(copy_row_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, ni, ni);
@@ -2442,8 +2496,8 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
 }
 
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,
-                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info) {
-  cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last, info);
+                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info, bool zero_after) {
+  cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last, info, nullptr, zero_after);
   if (kt) kt->begin("backsolve", s);
   const int m = d.border_blocks * 128;
   const bool side = d.B.ncols > 0 && d.A.ncols > 0 && ctxB && ctxB->fork;
@@ -2456,10 +2510,10 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
       sB = ctxB->fork;
     }
     cholesky_gather_map(yR, d.mapB, ybB, m, sB);
-    cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, ybB, wB, yB, sB, d.B.last, false, 1, info);
+    cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, ybB, wB, yB, sB, d.B.last, false, 1, info, zero_after);
   }
   // (yR is zero in the root's padding rows and in its right-hand-side row: it serves as A's border unknowns as it stands)
-  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info);
+  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after);
   if (side) {
     (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);

@@ -207,8 +207,11 @@ struct CholeskyPlan {
 CholeskyPlan cholesky_plan(int nblk, int group, const int* last, bool chain, int ncols = -1, int tail_rows = 1, const int* tail = nullptr);
 int cholesky_plan_max_group(const CholeskyPlan& plan);
 // info != nullptr: one resident launch (bs_resident_kernel; a time-out of its polls raises *info to 2); nullptr: one launch per block step
-void cholesky_backsolve(const double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt, const int* last = nullptr, int* info = nullptr, const int* tail = nullptr);
+// zero_after (the resident launch only): every block below the diagonal that is read is overwritten with zeros once it is in
+// registers — the envelope is ready for the next assembly but for its diagonal blocks (BalSolver's reduced zero_envelope pass).
+void cholesky_backsolve(double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
+                        hipStream_t s, KernelTimer* kt, const int* last = nullptr, int* info = nullptr, const int* tail = nullptr, bool zero_after = false);
+bool cholesky_backsolve_resident(int nblk);  // would cholesky_backsolve(..., info != nullptr) of a system of nblk block rows be the resident launch?
 // --- dissected factorisation (chol_kernels.hip, "Two-way dissection") ---
 struct FrontView {
   double* S = nullptr; long ld = 0;   // row-major, lower triangle
@@ -231,13 +234,13 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
 // Solve: root, then the two interiors side by side.  yR / yA / yB: solutions in each front's own order; w*: scratch of the
 // fronts' sizes; ybB: scratch of border size.  The right-hand sides are the fronts' rhs rows after the factorisation.
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,
-                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info = nullptr);
+                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info = nullptr, bool zero_after = false);
 // root += border x border block of a leaf front (front: ncols interior block columns, then border_blocks block rows);
 // map: root index of each border index (nullptr: identity; < 0: skip)
 void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s);
 // info != nullptr: one resident launch (the kernel of cholesky_backsolve; tail_rows as in cholesky_factor); nullptr: one launch per block step
-void cholesky_backsolve_front(const double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike = false, int tail_rows = 1, int* info = nullptr);
+void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
+                              hipStream_t s, const int* last, bool spike = false, int tail_rows = 1, int* info = nullptr, bool zero_after = false);
 void cholesky_gather_map(const double* src, const int* map, double* dst, int m, hipStream_t s);
 // --- multi-way dissection: R segments of a block-banded system with R - 1 separators between them ---
 // Leaf front of one segment, in scalar rows.  The interior is followed by a border:

@@ -1273,6 +1273,13 @@ def test_native_rccl_hook_world_of_one_matches_plain_solve():
     assert "DIST_RCCL_OK" in out.stdout
 
 
+def test_sharded_solve_with_a_border_of_loop_closure_cameras():
+    """A world of two ranks, points sharded, on a problem with two places revisited and the border forced on: the ranks order the
+    same cameras behind the band, the all-reduce carries the blocks inside the BORDERED envelope, the trajectory is the
+    single-GPU one in the band's own order (1e-10)."""
+    test_sharded_solve_on_one_gpu_with_a_real_exchange(2, "sharded", shape="600,6000,26000,9,rev")
+
+
 @pytest.mark.parametrize("world,mode", [(2, "sharded"), (3, "sharded"), (4, "sharded"), (2, "replicated"), (2, "auto")])
 def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode, shape=None, segments=None):
     """tests/dist_gpu_worker2.py: `world` ranks share GPU 0 and exchange through gloo (host-staged hook).  (Worlds of at
