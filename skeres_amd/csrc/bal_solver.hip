@@ -1183,6 +1183,11 @@ int BalSolver::setup() {
   // points.  (Round 1 sorted the long list by length, longest first, against a long tail: 2.14 ms on Venice-1778 where
   // camera order takes 1.65.  Sorting the short list by length, so that the seven lane groups of a wave finish together,
   // changes nothing in time and fetches 588 MB instead of 345 on Ladybug-1723.)
+  // (Round 4 also tried sorting the short list by length inside windows of 224 consecutive segments — the 32 waves that run on
+  // one XCD together — so that the seven lane groups of a wave carry segments of like length: bal_pair 131 -> 178 us on
+  // Ladybug-1723, 250 -> 322 on Venice-1778.  A wave of seven LONG short segments gathers seven times the records at once;
+  // mixed lengths spread that load.  And bal_pair_long at six waves per SIMD (79 VGPRs, no scratch) instead of five: 83-88 ->
+  // 87 us, Venice 1088 -> 1130.  Neither kept.)
   // (Round 4 tried the lists in Z-order of (row camera, column camera) — runs of consecutive segments inside small squares of
   // camera pairs, so that the rows' AND the columns' records stay in an XCD's L2: no gain, Schur assembly 0.41 -> 0.42-0.44 ms on
   // Ladybug-1723, 2.46 -> 2.40-2.54 on Venice-1778 for cells of 1, 4 and 16 cameras: the gathers are not bound by L2 misses.)
