@@ -375,6 +375,20 @@ int sk_options_set_graph_replay(sk_options* o, int on);
 int sk_options_set_max_segments(sk_options* o, int n);
 enum { SK_BORDER_AUTO = 0, SK_BORDER_ON = 1, SK_BORDER_OFF = 2 };
 int sk_options_set_cholesky_border(sk_options* o, int mode);
+/* DENSE_SCHUR: RETAINED POINTS.  The Schur complement of a point seen by k cameras is a dense k x k square of camera blocks; a
+ * landmark that stays in view for hundreds of frames sets the height of the reduced system's block envelope over every block
+ * column it spans (the Ladybug-1723-shaped problem: 5 of 156 502 points account for 80 % of the factorisation's flops).  Such
+ * points are not eliminated: their three coordinates stay in the reduced system as three more rows behind the cameras — a
+ * border in the sense of sk_options_set_cholesky_border — and the Schur complement is formed from the other points alone.  The
+ * linear system, and therefore the LM step, is the same (Ceres' DENSE_SCHUR eliminates every point,
+ * examples/.../SimpleBundleAdjuster.scala:147-152; which unknowns are eliminated first changes rounding only).  AUTO (default):
+ * the widest tracks, as many as the model of the factorisation's serial chain says pay, when it predicts 10 % less than
+ * eliminating everything; ON: the best count whatever the model says (tests, small problems); OFF: every point is eliminated.
+ * max_points: at most this many — with ON: exactly this many, as far as there are tracks wider than a block — (a multiple of three is
+ * used; 0: the library's limit, 192).  Not with the SEGMENTED distribution
+ * of several ranks.  sk_solver_stat: "retained_points", "retained_model_us", "retained_model_us_without". */
+enum { SK_RETAINED_AUTO = 0, SK_RETAINED_ON = 1, SK_RETAINED_OFF = 2 };
+int sk_options_set_retained_points(sk_options* o, int mode, int max_points);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,
  * one per GPU.  Points (e-blocks) are partitioned over ranks; the
  * normal-equation terms are summed with `allreduce` once per linear solve.
@@ -523,6 +537,12 @@ int sk_problem_segment_plan(const sk_problem* p, int max_segments, int forced, i
  * with the best unbordered order; envelope_fill: 128-blocks inside the envelope over the lower block triangle. */
 int sk_problem_border_plan(const sk_problem* p, int mode, int* num_border_cameras, int* camera_position_of_block, int* gap,
                            double* model_us, double* model_us_plain, double* envelope_fill);
+/* The retained points (sk_options_set_retained_points) as one process chooses them at set-up — host data alone.  *num_retained:
+ * how many (0: none); retained_of_block[b] (may be NULL): 1 when residual block b's point is retained; model_us /
+ * model_us_without: the chain model's microseconds per factorisation with them / with every point eliminated (the loop-closure
+ * border of `border_mode` in both). */
+int sk_problem_retained_plan(const sk_problem* p, int mode, int max_points, int border_mode, int* num_retained, int* retained_of_block,
+                             double* model_us, double* model_us_without);
 
 /* ---- inputs of BASELINE.json config 5 (utility) ----------------------------------
  * y_out[i] = tanh(a_i . x_star) for the generated rows a_i of SK_FUNCTOR_SYNTH_TANH_ROW

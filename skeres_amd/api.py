@@ -155,6 +155,8 @@ _SIGS = {
     "sk_options_set_cholesky_envelope": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_dissection": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_cholesky_border": (C.c_int, [C.c_void_p, C.c_int]),
+    "sk_options_set_retained_points": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "sk_problem_retained_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sk_options_set_resident_kernels": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_graph_replay": (C.c_int, [C.c_void_p, C.c_int]),
     "sk_options_set_max_segments": (C.c_int, [C.c_void_p, C.c_int]),
@@ -1074,6 +1076,19 @@ class Problem:
         return {"border_cameras": n.value, "position": pos, "gap": gap.value, "model_us": us.value, "model_us_plain": us_plain.value,
                 "envelope_fill": fill.value}
 
+    def retainedPlan(self, mode="auto", max_points=0, border="auto"):
+        """The points DENSE_SCHUR keeps in the reduced system instead of eliminating them, as set-up chooses them
+        (sk_problem_retained_plan; host logic, no device needed): a dict with retained_points, retained_of_block (1 per residual
+        block whose point is retained), model_us, model_us_without."""
+        modes = {"auto": 0, "on": 1, "off": 2}
+        nb = self.numResidualBlocks()
+        n = C.c_int(0)
+        flag = np.zeros(nb, dtype=np.int32)
+        us, us_without = C.c_double(0), C.c_double(0)
+        _check(lib().sk_problem_retained_plan(self._h, int(modes.get(mode, mode)), int(max_points), int(modes.get(border, border)), C.byref(n),
+                                              flag.ctypes.data_as(_ip), C.byref(us), C.byref(us_without)))
+        return {"retained_points": n.value, "retained_of_block": flag, "model_us": us.value, "model_us_without": us_without.value}
+
     def pointPartition(self, world):
         """(cuts[world+1], num_cameras, num_points, point_of_block[num residual blocks]):
         how sk_solve shards this problem over `world` ranks (host logic only)."""
@@ -1181,6 +1196,12 @@ class Solver:
             """DENSE_SCHUR: loop-closure cameras ordered into a trailing border: "auto" (default) / "on" / "off" (or 0 / 1 / 2)."""
             mode = {"auto": 0, "on": 1, "off": 2}.get(mode, mode)
             _check(lib().sk_options_set_cholesky_border(self._h, int(mode)))
+
+        def setRetainedPoints(self, mode, max_points=0):
+            """DENSE_SCHUR: the points with the widest tracks stay in the reduced system instead of being eliminated:
+            "auto" (default) / "on" / "off" (or 0 / 1 / 2); at most max_points of them (0: the library's limit)."""
+            mode = {"auto": 0, "on": 1, "off": 2}.get(mode, mode)
+            _check(lib().sk_options_set_retained_points(self._h, int(mode), int(max_points)))
 
         def setDistributionMode(self, mode):
             """0 auto (default), 1 sharded, 2 replicated: what a world > 1 does (include/skeres_amd.h)."""

@@ -590,6 +590,57 @@ __global__ __launch_bounds__(kBlock) void bal_point_block_kernel(BalDev d) {
   if (!(l00 > 0.0) || !(l11 > 0.0) || !(l22 > 0.0)) *d.fail_flag = 1;  // not positive definite
 }
 
+// Retained points (BalDev::kept_pt): one wave per point.  Its rows of the reduced system —
+//   block (pseudo-camera, camera c of observation o) rows 3 t + a:  (E_o^T F_o)[a][.]      (9 x 3 per observation, transposed into place)
+//   diagonal block, rows / columns 3 t ..:                          T = sum E^T E + D_p^2  (lower triangle)
+//   right-hand side, entries 3 t ..:                                g_p
+// — and M = 0, q = 0, so that what bal_obs_precompute forms for its observations is What = 0, rt = r: nothing of the point enters the
+// Schur complement, and its cameras' own blocks and right-hand sides take F^T F and F^T r as they stand (bal_cam_diag_kernel).
+// Every block has one writer (a camera sees a point once: setup() refuses two residual blocks on one pair).
+__global__ __launch_bounds__(kBlock) void bal_kept_points_kernel(BalDev d) {
+  const int k = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (k >= d.num_kept) return;  // wave-uniform
+  const int p = d.kept_pt[k], ic = d.kept_cam[k] / 3, t3 = 3 * (d.kept_cam[k] % 3);
+  const size_t N = d.N, P = d.P;
+  double t00 = 0, t10 = 0, t11 = 0, t20 = 0, t21 = 0, t22 = 0;
+  for (int o = d.pt_start[p] + lane; o < d.pt_start[p + 1]; o += 64) {
+    double e[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) e[r][a] = d.E[(size_t)(3 * r + a) * N + o];
+    t00 += e[0][0] * e[0][0] + e[1][0] * e[1][0]; t10 += e[0][1] * e[0][0] + e[1][1] * e[1][0]; t11 += e[0][1] * e[0][1] + e[1][1] * e[1][1];
+    t20 += e[0][2] * e[0][0] + e[1][2] * e[1][0]; t21 += e[0][2] * e[0][1] + e[1][2] * e[1][1]; t22 += e[0][2] * e[0][2] + e[1][2] * e[1][2];
+    const int c = d.cam[o];
+    const bool below = ic > c;  // the pseudo-camera's rows are below camera c's (else: a border camera that is numbered behind it)
+    if (!d.front[bal_part(d, below ? c : ic)].S) continue;  // (another rank's front)
+    int ld;
+    double* blk = below ? bal_block(d, ic, c, &ld) : bal_block(d, c, ic, &ld);
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+      const double f0 = d.F[(size_t)b * N + o], f1 = d.F[(size_t)(9 + b) * N + o];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double v = e[0][a] * f0 + e[1][a] * f1;
+        if (below) blk[(size_t)(t3 + a) * ld + b] = v; else blk[(size_t)b * ld + t3 + a] = v;
+      }
+    }
+  }
+  t00 = wave_sum(t00); t10 = wave_sum(t10); t11 = wave_sum(t11); t20 = wave_sum(t20); t21 = wave_sum(t21); t22 = wave_sum(t22);
+  if (lane != 0) return;
+  d.M[p] = 0.0; d.M[P + p] = 0.0; d.M[2 * P + p] = 0.0; d.M[3 * P + p] = 0.0; d.M[4 * P + p] = 0.0; d.M[5 * P + p] = 0.0;
+  d.q[p] = 0.0; d.q[P + p] = 0.0; d.q[2 * P + p] = 0.0;
+  if (!d.front[bal_part(d, ic)].S) return;
+  const double d0 = bal_lm_diag(d, d.colsq_p[3 * (size_t)p]), d1 = bal_lm_diag(d, d.colsq_p[3 * (size_t)p + 1]), d2 = bal_lm_diag(d, d.colsq_p[3 * (size_t)p + 2]);
+  int ld;
+  double* blk = bal_block(d, ic, ic, &ld) + (size_t)t3 * ld + t3;
+  blk[0] = t00 + d0 * d0;
+  blk[ld] = t10; blk[ld + 1] = t11 + d1 * d1;
+  blk[2 * (size_t)ld] = t20; blk[2 * (size_t)ld + 1] = t21; blk[2 * (size_t)ld + 2] = t22 + d2 * d2;
+  double* rhs = bal_rhs(d, ic) + t3;
+  rhs[0] = d.gs_p[3 * (size_t)p]; rhs[1] = d.gs_p[3 * (size_t)p + 1]; rhs[2] = d.gs_p[3 * (size_t)p + 2];
+}
+
 // Per observation: Ehat = E M^T (2x3), What = F^T Ehat (9x3), rt = r - E q: the observation's 256-byte record, written at
 // its slot of the CAMERA-major order (obs_slot).  A lane storing its own record would write 29 doubles 256 bytes apart from
 // every other lane's — 64 cache lines per store instruction; the wave's 64 records go through LDS and out sixteen lanes to
@@ -663,6 +714,7 @@ __global__ __launch_bounds__(kBlock, 4) void bal_obs_precompute_kernel(BalDev d)
 __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
   const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (i >= d.C) return;
+  if (d.pseudo && d.pseudo[i]) return;  // (a pseudo-camera of retained points: its block and right-hand side are bal_kept_points_kernel's)
   double acc[45], rh[9];
 #pragma unroll
   for (int k = 0; k < 45; ++k) acc[k] = 0.0;
@@ -825,6 +877,7 @@ __global__ void bal_finish_S_kernel(BalDev d, int parts) {
   if (j >= 9 * d.C) return;
   const int i = j / 9, c = j - 9 * i, part = bal_part(d, i);
   if (!((parts >> part) & 1) || !d.front[part].S) return;
+  if (d.pseudo && d.pseudo[i]) return;  // (retained points carry their own D_p^2: bal_kept_points_kernel)
   int ld;
   double* blk = bal_block(d, i, i, &ld);
   const double D = bal_lm_diag(d, d.colsq_c[j]);
@@ -890,6 +943,26 @@ __global__ __launch_bounds__(kBlock) void bal_point_backsub_kernel(BalDev d) {
     }
   }
   block_sum<1>(acc, d.partial + d.partial_stride, d.partial_stride);  // (row 1: row 0 holds the cameras' partial sums, bal_cam_step_kernel)
+}
+
+// Retained points: their part of the reduced system's solution is their y_p (bal_point_backsub_kernel left them a zero step: M = 0).
+// One workgroup; its |delta_p|^2 goes to slot `slot` of the points' row of partial sums.
+__global__ __launch_bounds__(kBlock) void bal_kept_step_kernel(BalDev d, int slot) {
+  double acc[1] = {0.0};
+  for (int k = threadIdx.x; k < d.num_kept; k += kBlock) {
+    const int p = d.kept_pt[k], ic = d.kept_cam[k] / 3, t3 = 3 * (d.kept_cam[k] % 3);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double st = -d.y_c[9 * (size_t)ic + t3 + a];
+      d.step_p[3 * (size_t)p + a] = st;
+      const double xo = d.xp[3 * (size_t)p + a];
+      const double xn = xo + st * d.scale_p[3 * (size_t)p + a];
+      d.xp_new[3 * (size_t)p + a] = xn;
+      const double df = xo - xn;
+      acc[0] += df * df;
+    }
+  }
+  block_sum<1>(acc, d.partial + d.partial_stride + slot, d.partial_stride);
 }
 
 // cameras: step_c = -y_c ; xc_new = xc + step_c * scale_c ; out[0] = |delta_c|^2
@@ -1045,6 +1118,7 @@ int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x
 }
 void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s) { hipLaunchKernelGGL(final_reduce_kernel, dim3(K), dim3(kBlock), 0, s, partial, stride, count, K, maxmask, out); }
 void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_point_block_kernel, dim3(point_grid(d.P)), dim3(kBlock), 0, s, d); }
+void launch_bal_kept_points(const BalDev& d, hipStream_t s) { if (d.num_kept > 0) hipLaunchKernelGGL(bal_kept_points_kernel, dim3((d.num_kept * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_pair(const BalDev& d, hipStream_t s) {
@@ -1067,7 +1141,7 @@ __global__ void bal_finish_all_kernel(BalDev d, BalFinishRanges r, int jmax) {
   if (j >= jmax) return;
   if (j < 9 * d.C) {
     const int i = j / 9, c = j - 9 * i, part = bal_part(d, i);
-    if (d.front[part].S) {
+    if (d.front[part].S && !(d.pseudo && d.pseudo[i])) {
       int ld;
       double* blk = bal_block(d, i, i, &ld);
       const double D = bal_lm_diag(d, d.colsq_c[j]);
@@ -1094,10 +1168,11 @@ void launch_bal_backsub(const BalDev& d, double* out, int norm_lo, int norm_hi, 
   hipLaunchKernelGGL(bal_cam_step_kernel, dim3(gc), dim3(kBlock), 0, s, d, norm_lo, norm_hi, norm_lo2, norm_hi2);
   hipLaunchKernelGGL(bal_obs_backsub_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d);
   hipLaunchKernelGGL(bal_point_backsub_kernel, dim3(gp), dim3(kBlock), 0, s, d);
+  if (d.num_kept > 0) hipLaunchKernelGGL(bal_kept_step_kernel, dim3(1), dim3(kBlock), 0, s, d, gp);
   ReduceRows rows;
   rows.n = 2;
   rows.row[0] = 0; rows.count[0] = gc; rows.out[0] = out;
-  rows.row[1] = 1; rows.count[1] = d.P > 0 ? gp : 0; rows.out[1] = out + 1;
+  rows.row[1] = 1; rows.count[1] = d.P > 0 ? gp + (d.num_kept > 0 ? 1 : 0) : 0; rows.out[1] = out + 1;
   launch_final_reduce_rows(d.partial, d.partial_stride, rows, s);
 }
 

@@ -35,6 +35,12 @@ struct BalDev {
   const int* long_segments;   // [num_long_segments]
   const int* pair_row_obs;  // [num_pairs] observation of camera i
   const int* pair_col_obs;  // [num_pairs] observation of camera j
+  // Retained points (bal_solver.hip, choose_retained_points): local points that are NOT eliminated — their three coordinates are rows
+  // of the reduced system, three points to a PSEUDO-camera (a camera index of the layout with no observations and no parameters:
+  // pseudo[i] != 0).  kept_pt[k]: the local point; kept_cam[k] = 3 * pseudo-camera + slot.  num_kept == 0 / pseudo == nullptr: none.
+  int num_kept;
+  const int* kept_pt;  const int* kept_cam;
+  const unsigned char* pseudo;  // [C]
   // state
   double* xc;  double* xp;          // current parameters [9C], [3P]
   double* xc_new;  double* xp_new;  // candidate
@@ -117,6 +123,7 @@ void launch_final_reduce(const double* partial, int stride, int count, int K, in
 struct ReduceRows { int n = 0; int row[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0}, is_max[4] = {0, 0, 0, 0}; double* out[4] = {nullptr, nullptr, nullptr, nullptr}; };
 void launch_final_reduce_rows(const double* partial, int stride, const ReduceRows& rows, hipStream_t s);  // up to four reductions of different lengths, one launch
 void launch_bal_point_block(const BalDev& d, hipStream_t s);
+void launch_bal_kept_points(const BalDev& d, hipStream_t s);  // after bal_point_block: the retained points' rows of the reduced system; M = 0, q = 0 for them
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s);
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s);
 void launch_bal_pair(const BalDev& d, hipStream_t s);

@@ -194,6 +194,9 @@ class BalSolver : public SolverBase {
     if (name == "allreduce_bytes") { *value = (double)packed_elems_ * sizeof(double); return true; }
     if (name == "allreduce_bytes_full_triangle") { *value = (double)tri_packed_elems(nblk) * sizeof(double); return true; }
     if (name == "dissected") { *value = dissected_ ? 1.0 : 0.0; return true; }
+    if (name == "retained_points") { *value = (double)retained_pts_.size(); return true; }
+    if (name == "retained_model_us") { *value = retained_model_us_; return true; }
+    if (name == "retained_model_us_without") { *value = retained_without_us_; return true; }
     if (name == "border_cameras") { *value = border_cams_; return true; }
     if (name == "border_gap") { *value = border_gap_; return true; }
     if (name == "border_model_us") { *value = border_model_us_; return true; }
@@ -232,7 +235,7 @@ class BalSolver : public SolverBase {
     s->num_parameters = problem_->num_parameters();
     s->num_residual_blocks = (int)problem_->rb_functor.size();
     s->num_residuals = problem_->num_residuals;
-    s->num_e_blocks = P_total_; s->num_f_blocks = C_;
+    s->num_e_blocks = P_total_; s->num_f_blocks = C_ - pseudo_cams_;
   }
 
  private:
@@ -262,6 +265,16 @@ class BalSolver : public SolverBase {
       b_r_, b_F_, b_Fcam_, b_E_, b_W_, b_rt_, b_M_, b_q_, b_S_, b_Linv_, b_partial_, b_scal_, b_small_;
   std::vector<int> env_last_;  // block envelope of S (cholesky_factor); empty = dense
   std::vector<int> env_tail_;  // ... and its tail profile when loop-closure cameras are ordered into a trailing border (choose_border); empty = none
+  // Retained points (choose_retained_points): not eliminated, three to a pseudo-camera of the reduced system's layout.  C_ includes
+  // the pseudo-cameras (cam_block_[i] == -1; no observations, no parameters: inert coordinates); retained_cam_[k] / k % 3: the
+  // pseudo-camera (final numbering) and the slot in it of retained point k.
+  std::vector<int> retained_pts_, retained_cam_;
+  int pseudo_cams_ = 0;
+  double retained_model_us_ = 0.0, retained_without_us_ = 0.0;
+  std::vector<int> struct_ocam_, struct_opt_;   // the structure of the reduced system WITH pseudo-cameras (retained_graphs), final numbering; empty: ocam / opt as they are
+  int struct_P_ = 0;
+  DevBuf<int> b_kept_pt_, b_kept_cam_;
+  DevBuf<unsigned char> b_pseudo_;
   int border_cams_ = 0, border_gap_ = 0;          // cameras in that border; the jump in a point's camera list that made a visit
   double border_model_us_ = 0.0, border_plain_us_ = 0.0;
   // The reduced camera system as fronts (BalDev::front): 0 head, 1 tail, 2 root.  Not dissected: only the root, which is
@@ -676,29 +689,78 @@ static double envelope_model_us(int nblk, const std::vector<int>& last, const in
   }
   return t;
 }
-// ocam: cameras in the banded numbering.  mode: SK_BORDER_AUTO (the model decides) / SK_BORDER_ON (the best candidate whatever the model says).
-static bool choose_border(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& plain_last, int mode,
-                          BorderChoice* out) {
-  out->plain_us = envelope_model_us(nblk, plain_last, nullptr);
-  if (C < 8) return false;
+// A camera graph: per observation its camera and its point.  Two of them describe a problem with RETAINED points (below): `g`, the
+// observations of the points the Schur complement eliminates, over the C real cameras; `x`, the structure of the reduced system —
+// g's observations, and for every observation of a retained point a point of its own that couples the observation's camera with
+// the retained point's pseudo-camera (index >= g.C).  Without retained points x is g.
+struct CamGraph { const std::vector<int>* ocam; const std::vector<int>* opt; int C, P; };
+static void point_camera_lists(const CamGraph& g, std::vector<int>* pstart, std::vector<int>* pcam) {
+  pstart->assign(g.P + 1, 0); pcam->resize(g.ocam->size());
+  for (int q : *g.opt) (*pstart)[q + 1]++;
+  for (int q = 0; q < g.P; ++q) (*pstart)[q + 1] += (*pstart)[q];
+  { std::vector<int> fill(pstart->begin(), pstart->end() - 1); for (size_t b = 0; b < g.ocam->size(); ++b) (*pcam)[fill[(*g.opt)[b]]++] = (*g.ocam)[b]; }
+  for (int q = 0; q < g.P; ++q) std::sort(pcam->begin() + (*pstart)[q], pcam->begin() + (*pstart)[q + 1]);
+}
+// g, x: cameras in the banded numbering (pseudo-cameras behind the real ones).  mode: SK_BORDER_AUTO (the model decides) / SK_BORDER_ON
+// (the best candidate whatever the model says).  gaps_ok: loop-closure cameras may go to the border; pseudo-cameras always do, and with
+// them a border is always returned (plain_us is then the model of the border of pseudo-cameras alone).
+static bool choose_border(const CamGraph& g, const CamGraph& x, int nblk, const std::vector<int>& plain_last, int mode, bool gaps_ok, BorderChoice* out) {
+  const int C = g.C, Cx = x.C;
+  const bool forced = Cx > C;
+  out->plain_us = forced ? 0.0 : envelope_model_us(nblk, plain_last, nullptr);
+  if (!forced && (C < 8 || !gaps_ok)) return false;
   // cameras of every point, ascending
-  std::vector<int> pstart(P + 1, 0), pcam(ocam.size());
-  for (int q : opt) pstart[q + 1]++;
-  for (int q = 0; q < P; ++q) pstart[q + 1] += pstart[q];
-  { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (size_t b = 0; b < ocam.size(); ++b) pcam[fill[opt[b]]++] = ocam[b]; }
+  std::vector<int> pstart, pcam, xstart_s, xcam_s;
+  point_camera_lists(g, &pstart, &pcam);
+  if (forced) point_camera_lists(x, &xstart_s, &xcam_s);
+  const std::vector<int>& xstart = forced ? xstart_s : pstart;
+  const std::vector<int>& xcam = forced ? xcam_s : pcam;
   int max_jump = 0;
-  for (int q = 0; q < P; ++q) {
-    std::sort(pcam.begin() + pstart[q], pcam.begin() + pstart[q + 1]);
+  for (int q = 0; q < g.P; ++q)
     for (int k = pstart[q] + 1; k < pstart[q + 1]; ++k) max_jump = std::max(max_jump, pcam[k] - pcam[k - 1]);
-  }
   bool found = false;
   double best = mode == SK_BORDER_ON ? std::numeric_limits<double>::max() : 0.9 * out->plain_us;
+  // one candidate: the real cameras marked in `mark` (nb of them) and every pseudo-camera behind the band
+  auto candidate = [&](std::vector<char>& mark, int nb, int gap, int variant, BorderChoice* cand) {
+    mark.resize(Cx, 1);
+    // first band camera each border camera couples with (through any of its points): the border is ordered so that the
+    // cameras reached first come LAST — a column's tail rows are a suffix of the matrix
+    std::vector<int> band_id(Cx, -1);
+    int Cb = 0;
+    for (int c = 0; c < Cx; ++c) if (!mark[c]) band_id[c] = Cb++;
+    std::vector<int> first_band(Cx, Cx);
+    for (int q = 0; q < x.P; ++q) {
+      int mn = Cx;
+      for (int k = xstart[q]; k < xstart[q + 1]; ++k) if (!mark[xcam[k]]) { mn = band_id[xcam[k]]; break; }
+      for (int k = xstart[q]; k < xstart[q + 1]; ++k) if (mark[xcam[k]]) first_band[xcam[k]] = std::min(first_band[xcam[k]], mn);
+    }
+    std::vector<int> border;
+    for (int c = 0; c < Cx; ++c) if (mark[c]) border.push_back(c);
+    std::stable_sort(border.begin(), border.end(), [&](int a, int b) { return first_band[a] > first_band[b]; });
+    cand->new_id = band_id;
+    for (size_t k = 0; k < border.size(); ++k) cand->new_id[border[k]] = Cb + (int)k;
+    std::vector<int> first_col;
+    (void)envelope_of_order(*x.ocam, *x.opt, cand->new_id, Cx, x.P, nblk, &first_col);
+    cholesky_envelope_bordered(first_col, (9 * Cb) / 128, &cand->last, &cand->tail);
+    cand->model_us = envelope_model_us(nblk, cand->last, cand->tail.data());
+    cand->border_cams = nb; cand->gap = gap; cand->variant = variant;
+    mark.resize(C);
+  };
+  if (forced) {
+    std::vector<char> mark(C, 0);
+    BorderChoice cand;
+    candidate(mark, 0, 0, 0, &cand);
+    out->plain_us = cand.model_us;
+    cand.plain_us = cand.model_us;
+    *out = cand; found = true;
+    best = mode == SK_BORDER_ON ? cand.model_us : 0.9 * cand.model_us;  // (loop-closure cameras on top of the pseudo-cameras: when the model gains another 10 %)
+  }
   std::vector<char> prev_mark;
-  for (int gap = 4; gap < C && gap < max_jump; gap *= 2) {
+  for (int gap = 4; gaps_ok && C >= 8 && gap < C && gap < max_jump; gap *= 2) {
     for (int variant = 0; variant < 2; ++variant) {
       std::vector<char> mark(C, 0);
       int nb = 0;
-      for (int q = 0; q < P; ++q) {
+      for (int q = 0; q < g.P; ++q) {
         const int a = pstart[q], e = pstart[q + 1];
         if (variant == 0) {  // everything behind the first jump
           int k = a + 1;
@@ -713,28 +775,9 @@ static bool choose_border(const std::vector<int>& ocam, const std::vector<int>& 
       if (nb == 0 || nb > C / 4 || C - nb < 4) continue;   // (a border that wide is no border: its dense system would be the factorisation)
       if (mark == prev_mark) continue;
       prev_mark = mark;
-      // first band camera each border camera couples with (through any of its points): the border is ordered so that the
-      // cameras reached first come LAST — a column's tail rows are a suffix of the matrix
-      std::vector<int> band_id(C, -1);
-      int Cb = 0;
-      for (int c = 0; c < C; ++c) if (!mark[c]) band_id[c] = Cb++;
-      std::vector<int> first_band(C, C);
-      for (int q = 0; q < P; ++q) {
-        int mn = C;
-        for (int k = pstart[q]; k < pstart[q + 1]; ++k) if (!mark[pcam[k]]) { mn = band_id[pcam[k]]; break; }
-        for (int k = pstart[q]; k < pstart[q + 1]; ++k) if (mark[pcam[k]]) first_band[pcam[k]] = std::min(first_band[pcam[k]], mn);
-      }
-      std::vector<int> border;
-      for (int c = 0; c < C; ++c) if (mark[c]) border.push_back(c);
-      std::stable_sort(border.begin(), border.end(), [&](int x, int y) { return first_band[x] > first_band[y]; });
       BorderChoice cand;
-      cand.new_id = band_id;
-      for (size_t k = 0; k < border.size(); ++k) cand.new_id[border[k]] = Cb + (int)k;
-      std::vector<int> first_col;
-      (void)envelope_of_order(ocam, opt, cand.new_id, C, P, nblk, &first_col);
-      cholesky_envelope_bordered(first_col, (9 * Cb) / 128, &cand.last, &cand.tail);
-      cand.model_us = envelope_model_us(nblk, cand.last, cand.tail.data());
-      cand.border_cams = nb; cand.gap = gap; cand.variant = variant; cand.plain_us = out->plain_us;
+      candidate(mark, nb, gap, variant, &cand);
+      cand.plain_us = out->plain_us;
       if (cand.model_us < best) { best = cand.model_us; *out = cand; found = true; }
     }
   }
@@ -744,49 +787,157 @@ static bool choose_border(const std::vector<int>& ocam, const std::vector<int>& 
 // The order of the cameras inside the reduced system as setup() takes it: the candidate with the fewest trailing-update flops,
 // or a bordered variant of one of the candidates when the chain model prefers it.  From host data alone.
 struct CameraOrderPlan {
-  std::vector<int> id;           // first-appearance numbering -> final numbering
+  std::vector<int> id;           // first-appearance numbering -> final numbering (pseudo-cameras of retained points: indices >= the real cameras')
+  std::vector<int> plain_id;     // ... of the best candidate as it stands (real cameras only; what the retained points are chosen on)
   std::vector<int> last, tail;   // the envelope of the reduced system in that numbering (tail: empty unless bordered)
   int candidate = 0;             // 0 first appearance, 1 memory order, 2 RCM
   bool bordered = false;
   BorderChoice border;
   double flops = 0.0;            // trailing-update flops of the envelope
+  double model_us = 0.0;         // the chain model of the plan
 };
-static CameraOrderPlan plan_camera_order(const Problem& p, const std::vector<int>& cam_block, const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P,
+// g: the eliminated points' observations over the real cameras; x: the reduced system's structure (== g without retained points), whose
+// pseudo-cameras always go to the border.  npad: padded order of the reduced system (x.C cameras).
+static CameraOrderPlan plan_camera_order(const Problem& p, const std::vector<int>& cam_block, const CamGraph& g, const CamGraph& x,
                                          int npad, bool with_memory_order, bool border_ok, int border_mode) {
   CameraOrderPlan out;
-  const int nblk = npad / 128;
-  const std::vector<std::vector<int>> cand = camera_order_candidates(p, cam_block, ocam, opt, C, P, with_memory_order);
+  const int nblk = npad / 128, C = g.C, Cx = x.C;
+  const bool forced = Cx > C;
+  const std::vector<std::vector<int>> cand = camera_order_candidates(p, cam_block, *g.ocam, *g.opt, C, g.P, with_memory_order);
   std::vector<int> best_env;
   int best_k = 0;
   double best = 0.0;
-  choose_camera_order(cand, ocam, opt, C, P, npad, &best_k, &best_env, &best);
-  if (border_ok) {
+  if (!forced) choose_camera_order(cand, *g.ocam, *g.opt, C, g.P, npad, &best_k, &best_env, &best);
+  if (border_ok || forced) {
     // every candidate order may hide a band behind a few revisits: the border is tried on each, the chain model compares
     double best_us = 0.0;
     for (size_t k = 0; k < cand.size(); ++k) {
       if (k == 1 && !with_memory_order) continue;  // (the slot repeats candidate 0)
-      std::vector<int> oc(ocam.size());
-      for (size_t b = 0; b < ocam.size(); ++b) oc[b] = cand[k][ocam[b]];
-      const std::vector<int> plain = (int)k == best_k ? best_env : envelope_of_order(ocam, opt, cand[k], C, P, nblk);
+      std::vector<int> oc(g.ocam->size()), ocx;
+      for (size_t b = 0; b < oc.size(); ++b) oc[b] = cand[k][(*g.ocam)[b]];
+      if (forced) { ocx.resize(x.ocam->size()); for (size_t b = 0; b < ocx.size(); ++b) { const int c = (*x.ocam)[b]; ocx[b] = c < C ? cand[k][c] : c; } }
+      const CamGraph gk{&oc, g.opt, C, g.P}, xk{forced ? &ocx : &oc, x.opt, Cx, x.P};
+      std::vector<int> plain;
+      if (!forced) plain = (int)k == best_k ? best_env : envelope_of_order(*g.ocam, *g.opt, cand[k], C, g.P, nblk);
       BorderChoice bc;
-      if (!choose_border(oc, opt, C, P, nblk, plain, border_mode, &bc)) continue;
+      if (!choose_border(gk, xk, nblk, plain, border_mode, border_ok, &bc)) continue;
       if (!out.bordered || bc.model_us < best_us) {
         best_us = bc.model_us; out.bordered = true; out.candidate = (int)k;
         out.border = bc;
-        for (int c = 0; c < C; ++c) out.border.new_id[c] = bc.new_id[cand[k][c]];  // first-appearance numbering -> final numbering
+        for (int c = 0; c < Cx; ++c) out.border.new_id[c] = bc.new_id[c < C ? cand[k][c] : c];  // first-appearance numbering -> final numbering
       }
     }
     // (against the envelope of the order that would be used otherwise)
-    const double plain_us = envelope_model_us(nblk, best_env, nullptr);
-    if (out.bordered && border_mode != SK_BORDER_ON && out.border.model_us >= 0.9 * plain_us) out.bordered = false;
+    if (!forced) {
+      const double plain_us = envelope_model_us(nblk, best_env, nullptr);
+      if (out.bordered && border_mode != SK_BORDER_ON && out.border.model_us >= 0.9 * plain_us) out.bordered = false;
+    }
   }
-  out.border.plain_us = envelope_model_us(nblk, best_env, nullptr);
+  if (!forced) { out.border.plain_us = envelope_model_us(nblk, best_env, nullptr); out.plain_id = cand[best_k]; }
   if (out.bordered) {
     out.id = out.border.new_id; out.last = out.border.last; out.tail = out.border.tail;
     out.flops = cholesky_syrk_flops(npad, 1, out.last.data(), false, nullptr, -1, 1, out.tail.data());
+    out.model_us = out.border.model_us;
   } else {
     out.id = cand[best_k]; out.last = best_env; out.candidate = best_k; out.flops = best;
+    out.model_us = out.border.plain_us;
   }
+  return out;
+}
+
+// ---- retained points (round 4): the few points with the longest tracks stay IN the reduced system ---------------------------------
+// The Schur complement of a point seen by k cameras is a dense k x k square of camera blocks.  A landmark that stays in view for
+// hundreds of frames — five such points among the 156 502 of the Ladybug-shaped problem — sets the height of the block envelope for
+// every block column it spans (there: 25-55 block rows where the other points need 8-19; 166 of the 176 GFlop of the
+// factorisation).  Such a point is not eliminated: its three coordinates stay in the reduced system as three more rows, behind the
+// cameras — [S W; W^T T] (y_c; y_p) = (g_c; g_p) with S, g_c formed from the other points alone, W = F^T E (9 x 3 per observation),
+// T = sum E^T E + D_p^2 — which is a BORDER in the sense of the loop-closure cameras above: rows that are active from the first
+// camera that sees the point.  Three retained points share a pseudo-camera (nine rows), so that every layout of the reduced
+// system — the bordered envelope, the fronts of a dissection — takes them as they take cameras.  The step is the same linear
+// system's solution (EX/SimpleBundleAdjuster.scala:147-152: the result of DENSE_SCHUR does not depend on which unknowns were
+// eliminated first); tests hold it against the all-eliminated order and the oracle.
+// Which points: by the span of their cameras in the banded numbering, widest first, in steps of 3, 6, 12, ... as long as the chain
+// model of the bordered envelope improves; taken when it predicts 10 % less than the plan without them (SK_RETAINED_ON: the best
+// count whatever the model says).
+struct RetainedChoice {
+  std::vector<int> points;   // point ids, three to a pseudo-camera, pseudo-cameras in index order
+  double model_us = 0.0;
+};
+// the two graphs of a problem whose points `points` (slot s -> pseudo-camera C + s / 3) are retained
+struct RetainedGraphs {
+  std::vector<int> ocam_g, opt_g, ocam_x, opt_x;
+  int Cx = 0, Px = 0;
+  CamGraph g(int C, int P) const { return CamGraph{&ocam_g, &opt_g, C, P}; }
+  CamGraph x() const { return CamGraph{&ocam_x, &opt_x, Cx, Px}; }
+};
+static RetainedGraphs retained_graphs(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, const std::vector<int>& points) {
+  RetainedGraphs r;
+  std::vector<int> slot(P, -1);
+  for (size_t s = 0; s < points.size(); ++s) slot[points[s]] = (int)s;
+  r.Cx = C + ((int)points.size() + 2) / 3; r.Px = P;
+  for (size_t b = 0; b < ocam.size(); ++b) {
+    const int s = slot[opt[b]];
+    if (s < 0) { r.ocam_g.push_back(ocam[b]); r.opt_g.push_back(opt[b]); r.ocam_x.push_back(ocam[b]); r.opt_x.push_back(opt[b]); continue; }
+    r.ocam_x.push_back(ocam[b]); r.opt_x.push_back(r.Px);
+    r.ocam_x.push_back(C + s / 3); r.opt_x.push_back(r.Px);
+    ++r.Px;
+  }
+  return r;
+}
+// ocam: cameras in the banded numbering (the best candidate order, no border).  base_us: the model of the plan without retained points.
+static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int mode, int max_points, bool gaps_ok,
+                                             double base_us) {
+  RetainedChoice out;
+  if (mode == SK_RETAINED_OFF) return out;
+  if (mode == SK_RETAINED_AUTO && (C < 64 || (9 * C + 128) / 128 < 16)) return out;  // (a reduced system of a few blocks: nothing to gain)
+  std::vector<int> cmin(P, C), cmax(P, -1), cnt(P, 0);
+  for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); cnt[opt[b]]++; }
+  std::vector<int> wide;
+  for (int q = 0; q < P; ++q) if (cnt[q] >= 2 && 9 * (cmax[q] - cmin[q]) >= 128) wide.push_back(q);
+  std::sort(wide.begin(), wide.end(), [&](int a, int b) { const int sa = cmax[a] - cmin[a], sb = cmax[b] - cmin[b]; return sa != sb ? sa > sb : a < b; });
+  const bool exactly = mode == SK_RETAINED_ON && max_points > 0;  // (ON with a count: that many, as far as there are candidates)
+  if (max_points <= 0) max_points = 192;
+  max_points = std::min(max_points - max_points % 3, (int)wide.size() - (int)wide.size() % 3);
+  double best = mode == SK_RETAINED_ON ? std::numeric_limits<double>::max() : 0.9 * base_us;
+  int worse = 0;
+  for (int R = exactly ? std::max(3, max_points) : 3; R <= max_points && worse < 2; R = R < 6 ? 6 : 2 * R) {
+    std::vector<int> pts(wide.begin(), wide.begin() + R);
+    // pseudo-cameras in the order the border wants them: the points reached first come last
+    std::sort(pts.begin(), pts.end(), [&](int a, int b) { return cmin[a] != cmin[b] ? cmin[a] > cmin[b] : a < b; });
+    const RetainedGraphs rg = retained_graphs(ocam, opt, C, P, pts);
+    const int nblk = (9 * rg.Cx + 1 + 127) / 128;
+    BorderChoice bc;
+    if (!choose_border(rg.g(C, P), rg.x(), nblk, {}, SK_BORDER_AUTO, gaps_ok, &bc)) continue;
+    if (bc.model_us < best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; worse = 0; }
+    else ++worse;
+  }
+  return out;
+}
+
+// The layout of the reduced system as setup() takes it: the camera order (with its border of loop-closure cameras), and — when
+// retained_mode allows and the chain model agrees — the retained points with their pseudo-cameras.  From host data alone.
+struct ReducedSystemPlan {
+  CameraOrderPlan order;            // over the real cameras and the pseudo-cameras
+  std::vector<int> retained;        // the retained points (three to a pseudo-camera, in pseudo-camera order); empty: every point is eliminated
+  RetainedGraphs graphs;            // ... and the structure with them (first-appearance numbering)
+  double without_us = 0.0;          // the chain model of the plan with every point eliminated
+};
+static ReducedSystemPlan plan_reduced_system(const Problem& p, const std::vector<int>& cam_block, const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P,
+                                             bool with_memory_order, bool border_ok, int border_mode, int retained_mode, int retained_max) {
+  ReducedSystemPlan out;
+  const CamGraph g0{&ocam, &opt, C, P};
+  const int npad = ((9 * C + 1 + 127) / 128) * 128;
+  out.order = plan_camera_order(p, cam_block, g0, g0, npad, with_memory_order, border_ok, border_mode);
+  out.without_us = out.order.model_us;
+  if (retained_mode == SK_RETAINED_OFF) return out;
+  std::vector<int> oc(ocam.size());
+  for (size_t b = 0; b < ocam.size(); ++b) oc[b] = out.order.plain_id[ocam[b]];
+  const RetainedChoice rc = choose_retained_points(oc, opt, C, P, retained_mode, retained_max, border_ok, out.order.model_us);
+  if (rc.points.empty()) return out;
+  RetainedGraphs rg = retained_graphs(ocam, opt, C, P, rc.points);
+  const int npadx = ((9 * rg.Cx + 1 + 127) / 128) * 128;
+  CameraOrderPlan px = plan_camera_order(p, cam_block, rg.g(C, P), rg.x(), npadx, with_memory_order, border_ok, border_mode);
+  if (retained_mode == SK_RETAINED_ON || px.model_us < 0.9 * out.order.model_us) { out.order = std::move(px); out.retained = rc.points; out.graphs = std::move(rg); }
   return out;
 }
 
@@ -847,6 +998,7 @@ int BalSolver::setup() {
   std::vector<int> ocam, opt;
   bal_index_problem(p, &cam_block_, &pt_block_, &ocam, &opt);
   C_ = (int)cam_block_.size(); P_total_ = (int)pt_block_.size();
+  const int Creal = C_;  // (C_ grows by the pseudo-cameras of retained points, below)
   n_ = 9 * C_; rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
   SK_HIP_TRY(cholesky_init());
   {
@@ -887,12 +1039,21 @@ int BalSolver::setup() {
     // reverse Cuthill-McKee, is 12.1 ms against 9.1 — every multi-rank run would have factored a third more slowly.)
     // (the border of loop-closure cameras: not with an explicit dissection or segmentation — the fronts of those have borders of
     // their own kind — and only inside the envelope machinery)
+    RetainedGraphs rgraphs;
     const bool border_ok = opt_.envelope && opt_.border != SK_BORDER_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 &&
                            !(opt_.allreduce && opt_.world > 1 && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED);
+    // (retained points: not with an explicit dissection or segmentation either; a launch-bound problem under hipGraph replay has nothing to gain)
+    const bool retained_ok = opt_.retained != SK_RETAINED_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 && !graph_mode_ &&
+                             !(opt_.allreduce && opt_.world > 1 && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED);
     CameraOrderPlan plan;
     auto pick = [&](bool with_memory_order) {
-      plan = plan_camera_order(p, cam_block_, ocam, opt, C_, P_total_, npad_, with_memory_order, border_ok, opt_.border);
+      ReducedSystemPlan rp = plan_reduced_system(p, cam_block_, ocam, opt, Creal, P_total_, with_memory_order, border_ok, opt_.border,
+                                                 retained_ok ? opt_.retained : SK_RETAINED_OFF, opt_.retained_max);
+      plan = std::move(rp.order);
+      retained_pts_ = rp.retained; rgraphs = std::move(rp.graphs);
+      retained_without_us_ = rp.without_us; retained_model_us_ = retained_pts_.empty() ? 0.0 : plan.model_us;
       unsigned long long h = 1469598103934665603ull;
+      for (int v : retained_pts_) { h ^= (unsigned)v; h *= 1099511628211ull; }
       for (int v : plan.id) { h ^= (unsigned)v; h *= 1099511628211ull; }
       for (int v : plan.last) { h ^= (unsigned)v; h *= 1099511628211ull; }
       for (int v : plan.tail) { h ^= (unsigned)v; h *= 1099511628211ull; }
@@ -908,8 +1069,18 @@ int BalSolver::setup() {
     const std::vector<int>& id = plan.id;
     camera_order_ = plan.candidate;
     best_env = plan.last; best = plan.flops;
-    std::vector<int> cb(C_);
-    for (int c = 0; c < C_; ++c) cb[id[c]] = cam_block_[c];
+    if (!retained_pts_.empty()) {
+      // the reduced system has a pseudo-camera for every three retained points: C_ counts them from here on (cam_block_: -1)
+      pseudo_cams_ = rgraphs.Cx - Creal;
+      C_ = rgraphs.Cx;
+      n_ = 9 * C_; rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
+      struct_ocam_ = rgraphs.ocam_x; struct_opt_ = rgraphs.opt_x; struct_P_ = rgraphs.Px;
+      for (int& c : struct_ocam_) c = id[c];
+      retained_cam_.resize(retained_pts_.size());
+      for (size_t k = 0; k < retained_pts_.size(); ++k) retained_cam_[k] = id[Creal + (int)k / 3];
+    }
+    std::vector<int> cb(C_, -1);
+    for (int c = 0; c < Creal; ++c) cb[id[c]] = cam_block_[c];
     cam_block_.swap(cb);
     for (int& c : ocam) c = id[c];
     const double full = cholesky_syrk_flops(npad_, 1, nullptr);
@@ -922,6 +1093,7 @@ int BalSolver::setup() {
     group_ = opt_.group_or(opt_.envelope && best < 0.5 * full ? 1 : 3);
     env_for_model = best_env;
     if (opt_.envelope) env_last_.swap(best_env);
+    else env_tail_.clear();  // (retained points make a border with or without the envelope: without it every block is factored)
     if (dev_knobs().debug_envelope && opt_.envelope) {
       long h = 0;
       for (int c = 0; c < nblk; ++c) h += env_last_[c] - c;
@@ -1140,17 +1312,27 @@ int BalSolver::setup() {
   for (int o = 0; o < N_; ++o) cam_start[cam[o] + 1]++;
   for (int i = 0; i < C_; ++i) cam_start[i + 1] += cam_start[i];
   { std::vector<int> fill(cam_start.begin(), cam_start.end() - 1); for (int o = 0; o < N_; ++o) cam_obs[fill[cam[o]]++] = o; }
-  // pair lists: for every point, every (larger camera, smaller camera) pair of its observations
+  // retained points of this rank: local point, pseudo-camera, slot
+  std::vector<int> kept_of_local(P_, -1), kept_pt, kept_cam;
+  for (size_t k = 0; k < retained_pts_.size(); ++k) {
+    const int q = local_of[retained_pts_[k]];
+    if (q < 0) continue;
+    kept_of_local[q] = (int)k;
+    kept_pt.push_back(q); kept_cam.push_back(3 * retained_cam_[k] + (int)(k % 3));
+  }
+  // pair lists: for every point that is eliminated, every (larger camera, smaller camera) pair of its observations
   size_t npairs = 0;
-  for (int q = 0; q < P_; ++q) { const size_t k = pt_start[q + 1] - pt_start[q]; npairs += k * (k - 1) / 2; }
+  for (int q = 0; q < P_; ++q) { if (kept_of_local[q] >= 0) continue; const size_t k = pt_start[q + 1] - pt_start[q]; npairs += k * (k - 1) / 2; }
   if (npairs > 2000000000ull) { set_error("pair list too large"); return SK_ERR_UNSUPPORTED; }
   std::vector<int> pair_row(npairs), pair_col(npairs), seg_start, seg_row, seg_col;
   {
     const size_t CC = (size_t)C_ * C_;
     std::vector<unsigned> count(CC + 1, 0);  // key = row * C + col
-    for (int q = 0; q < P_; ++q)
+    for (int q = 0; q < P_; ++q) {
+      if (kept_of_local[q] >= 0) continue;
       for (int b = pt_start[q] + 1; b < pt_start[q + 1]; ++b)
         for (int a = pt_start[q]; a < b; ++a) count[(size_t)cam[b] * C_ + cam[a] + 1]++;
+    }
     seg_start.push_back(0);
     std::vector<unsigned> pos(CC, 0);
     unsigned run = 0;
@@ -1158,9 +1340,11 @@ int BalSolver::setup() {
       pos[key] = run;
       if (count[key + 1]) { seg_row.push_back((int)(key / C_)); seg_col.push_back((int)(key % C_)); run += count[key + 1]; seg_start.push_back((int)run); }
     }
-    for (int q = 0; q < P_; ++q)  // ascending point => entries of a segment are in ascending point order
+    for (int q = 0; q < P_; ++q) {  // ascending point => entries of a segment are in ascending point order
+      if (kept_of_local[q] >= 0) continue;
       for (int b = pt_start[q] + 1; b < pt_start[q + 1]; ++b)
         for (int a = pt_start[q]; a < b; ++a) { const unsigned e = pos[(size_t)cam[b] * C_ + cam[a]]++; pair_row[e] = b; pair_col[e] = a; }
+    }
   }
   // ---- device buffers ----
   hipStream_t s = stream_;
@@ -1195,7 +1379,7 @@ int BalSolver::setup() {
   d_.num_short_segments = (int)short_segs.size(); d_.num_long_segments = (int)long_segs.size();
   const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_, nx = nc + np;
   std::vector<double> x(nx, 0.0);  // (the padding coordinates of a smaller shape: zeros, and inert — see free_mask below)
-  for (int i = 0; i < C_; ++i) std::memcpy(&x[9 * (size_t)i], p.block_ptr[cam_block_[i]], cam_size_ * sizeof(double));
+  for (int i = 0; i < C_; ++i) if (cam_block_[i] >= 0) std::memcpy(&x[9 * (size_t)i], p.block_ptr[cam_block_[i]], cam_size_ * sizeof(double));  // (a pseudo-camera: zeros)
   for (int q = 0; q < P_; ++q) std::memcpy(&x[nc + 3 * (size_t)q], p.block_ptr[pt_block_[local_pt_[q]]], pt_size_ * sizeof(double));
   // x vectors are stored [cameras | points] so whole-vector kernels run once
   SK_HIP_TRY(b_xc_.upload(x, s)); SK_HIP_TRY(b_xc_new_.alloc(nx));
@@ -1213,7 +1397,10 @@ int BalSolver::setup() {
       const LocalParameterization& lp = p.params[pi];
       if (lp.type == kParamSubset) for (int k = 0; k < size; ++k) if ((lp.constant_mask >> k) & 1u) free_mask[off + k] = 0.0;
     };
-    for (int i = 0; i < C_; ++i) mask_block(cam_block_[i], 9 * (size_t)i, cam_size_, 9);
+    for (int i = 0; i < C_; ++i) {
+      if (cam_block_[i] >= 0) mask_block(cam_block_[i], 9 * (size_t)i, cam_size_, 9);
+      else for (int k = 0; k < 9; ++k) free_mask[9 * (size_t)i + k] = 0.0;  // a pseudo-camera's coordinates are nobody's parameters: inert
+    }
     for (int q = 0; q < P_; ++q) mask_block(pt_block_[local_pt_[q]], nc + 3 * (size_t)q, pt_size_, 3);
     SK_HIP_TRY(hipMemcpyAsync(b_scale_.p, free_mask.data(), nx * sizeof(double), hipMemcpyHostToDevice, s));
     SK_HIP_TRY(hipStreamSynchronize(s));
@@ -1225,6 +1412,12 @@ int BalSolver::setup() {
     SK_HIP_TRY(b_r_.zero(s)); SK_HIP_TRY(b_F_.zero(s)); SK_HIP_TRY(b_E_.zero(s));
   }
   SK_HIP_TRY(b_M_.alloc(6 * (size_t)P_)); SK_HIP_TRY(b_q_.alloc(3 * (size_t)P_));
+  if (pseudo_cams_ > 0) {
+    std::vector<unsigned char> pseudo(C_, 0);
+    for (int i = 0; i < C_; ++i) pseudo[i] = cam_block_[i] < 0 ? 1 : 0;
+    SK_HIP_TRY(b_pseudo_.upload(pseudo, s));
+    SK_HIP_TRY(b_kept_pt_.upload(kept_pt, s)); SK_HIP_TRY(b_kept_cam_.upload(kept_cam, s));
+  }
   // ---- the fronts of the reduced camera system ----
   std::vector<int> border_row_h[2], leaf_map_h, leaf_gmap_h;
   if (!dissected_) {
@@ -1311,13 +1504,14 @@ int BalSolver::setup() {
     mapB[9 * nsep] = 9 * nsep;  // right-hand-side row
     SK_HIP_TRY(b_mapB_.upload(mapB, s));
   }
-  partial_stride_ = std::max(std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_)), (9 * C_ + 255) / 256), 256) + bal_partial_blocks((int)host_obs_.size());
+  partial_stride_ = std::max(std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_) + 1), (9 * C_ + 255) / 256), 256) + bal_partial_blocks((int)host_obs_.size());  // (+ 1: the retained points' slot)
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
   SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_scal_.zero(s)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
   fail_p_ = reinterpret_cast<int*>(b_scal_.p + 14); info_p_ = reinterpret_cast<int*>(b_scal_.p + 15);
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
+  d_.pseudo = pseudo_cams_ > 0 ? b_pseudo_.p : nullptr; d_.num_kept = pseudo_cams_ > 0 ? (int)kept_pt.size() : 0; d_.kept_pt = b_kept_pt_.p; d_.kept_cam = b_kept_cam_.p;
   d_.res_size = res_size_; d_.cam_size = cam_size_; d_.pt_size = pt_size_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p; d_.obs_slot = b_obs_slot_.p;
   d_.num_segments = (int)seg_row.size(); d_.seg_start = b_seg_start_.p; d_.seg_row = b_seg_row_.p; d_.seg_col = b_seg_col_.p;
@@ -1577,6 +1771,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   need_full_zero_ = !zero_after;
   SK_HIP_TRY(hipMemsetAsync(b_scal_.p + 14, 0, 2 * sizeof(double), s));  // the failure flag and the factorisation's info
   launch_bal_point_block(d_, s);
+  launch_bal_kept_points(d_, s);  // (retained points: their rows of the reduced system; nothing of theirs enters the Schur complement)
   launch_bal_obs_precompute(d_, s);
   kt_.begin("bal_cam_diag", s); launch_bal_cam_diag(d_, s); kt_.end("bal_cam_diag", s);
   kt_.begin("bal_pair", s); launch_bal_pair(d_, s); kt_.end("bal_pair", s);
@@ -1791,7 +1986,7 @@ int BalSolver::write_back() {
     SK_HIP_TRY(hipMemcpyAsync(x.data(), tmpc.p, nc * sizeof(double), hipMemcpyDeviceToHost, stream_));
     SK_HIP_TRY(hipStreamSynchronize(stream_));
   }
-  for (int i = 0; i < C_; ++i) std::memcpy(problem_->block_ptr[cam_block_[i]], &x[9 * (size_t)i], cam_size_ * sizeof(double));
+  for (int i = 0; i < C_; ++i) if (cam_block_[i] >= 0) std::memcpy(problem_->block_ptr[cam_block_[i]], &x[9 * (size_t)i], cam_size_ * sizeof(double));
   if (!opt_.allreduce) {
     for (int q = 0; q < P_; ++q) std::memcpy(problem_->block_ptr[pt_block_[local_pt_[q]]], &x[nc + 3 * (size_t)q], pt_size_ * sizeof(double));
     return SK_OK;
@@ -1857,7 +2052,8 @@ int bal_border_plan(const Problem& p, int mode, std::vector<int>* final_index_of
   bal_index_problem(p, &cam_block, &pt_block, &ocam, &opt);
   const int C = (int)cam_block.size(), P = (int)pt_block.size();
   const int npad = ((9 * C + 1 + 127) / 128) * 128, nblk = npad / 128;
-  const CameraOrderPlan plan = plan_camera_order(p, cam_block, ocam, opt, C, P, npad, true, mode != SK_BORDER_OFF, mode);
+  const CamGraph g0{&ocam, &opt, C, P};
+  const CameraOrderPlan plan = plan_camera_order(p, cam_block, g0, g0, npad, true, mode != SK_BORDER_OFF, mode);
   final_index_of_block->resize(ocam.size());
   for (size_t b = 0; b < ocam.size(); ++b) (*final_index_of_block)[b] = plan.id[ocam[b]];
   if (gap) *gap = plan.bordered ? plan.border.gap : 0;
@@ -1872,6 +2068,20 @@ int bal_border_plan(const Problem& p, int mode, std::vector<int>* final_index_of
     *fill = in / (0.5 * nblk * (nblk + 1.0));
   }
   return plan.bordered ? plan.border.border_cams : 0;
+}
+
+int bal_retained_plan(const Problem& p, int mode, int max_points, int border_mode, std::vector<int>* retained_of_block, double* model_us, double* model_us_without) {
+  std::vector<int> cam_block, pt_block, ocam, opt;
+  bal_index_problem(p, &cam_block, &pt_block, &ocam, &opt);
+  const int C = (int)cam_block.size(), P = (int)pt_block.size();
+  const ReducedSystemPlan rp = plan_reduced_system(p, cam_block, ocam, opt, C, P, true, border_mode != SK_BORDER_OFF, border_mode, mode, max_points);
+  std::vector<char> kept(P, 0);
+  for (int q : rp.retained) kept[q] = 1;
+  retained_of_block->resize(ocam.size());
+  for (size_t b = 0; b < ocam.size(); ++b) (*retained_of_block)[b] = kept[opt[b]];
+  if (model_us) *model_us = rp.order.model_us;
+  if (model_us_without) *model_us_without = rp.without_us;
+  return (int)rp.retained.size();
 }
 
 std::unique_ptr<SolverBase> make_bal_solver(const Options& o, Problem* p) { return std::unique_ptr<SolverBase>(new BalSolver(o, p)); }

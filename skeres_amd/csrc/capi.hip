@@ -596,6 +596,11 @@ int sk_options_set_cholesky_border(sk_options* o, int mode) {
   if (mode != SK_BORDER_AUTO && mode != SK_BORDER_ON && mode != SK_BORDER_OFF) { set_error("invalid border mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
   o->o.border = mode; return SK_OK;
 }
+int sk_options_set_retained_points(sk_options* o, int mode, int max_points) {
+  if (mode != SK_RETAINED_AUTO && mode != SK_RETAINED_ON && mode != SK_RETAINED_OFF) { set_error("invalid retained-points mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
+  if (max_points < 0) { set_error("max_points must not be negative"); return SK_ERR_INVALID_ARGUMENT; }
+  o->o.retained = mode; o->o.retained_max = max_points; return SK_OK;
+}
 int sk_options_set_reduce_buffer(sk_options* o, void* ptr, size_t bytes) { o->o.reduce_buffer = ptr; o->o.reduce_buffer_bytes = bytes; return SK_OK; }
 size_t sk_reduce_buffer_bytes(const sk_options* o, const sk_problem* p) {
   (void)o;
@@ -768,6 +773,21 @@ int sk_problem_border_plan(const sk_problem* p, int mode, int* num_border_camera
   std::vector<int> pos;
   *num_border_cameras = bal_border_plan(p->p, mode, &pos, gap, model_us, model_us_plain, envelope_fill);
   if (camera_position_of_block) for (size_t b = 0; b < pos.size(); ++b) camera_position_of_block[b] = pos[b];
+  return SK_OK;
+  SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
+}
+
+int sk_problem_retained_plan(const sk_problem* p, int mode, int max_points, int border_mode, int* num_retained, int* retained_of_block, double* model_us,
+                             double* model_us_without) {
+  SK_GUARD_BEGIN
+  if (!p || !num_retained) { set_error("invalid argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (mode != SK_RETAINED_AUTO && mode != SK_RETAINED_ON && mode != SK_RETAINED_OFF) { set_error("invalid retained-points mode %d", mode); return SK_ERR_INVALID_ARGUMENT; }
+  if (border_mode != SK_BORDER_AUTO && border_mode != SK_BORDER_ON && border_mode != SK_BORDER_OFF) { set_error("invalid border mode %d", border_mode); return SK_ERR_INVALID_ARGUMENT; }
+  std::string why;
+  if (!problem_is_bal_shaped(p->p, &why)) { set_error("%s", why.c_str()); return SK_ERR_UNSUPPORTED; }
+  std::vector<int> flag;
+  *num_retained = bal_retained_plan(p->p, mode, max_points, border_mode, &flag, model_us, model_us_without);
+  if (retained_of_block) for (size_t b = 0; b < flag.size(); ++b) retained_of_block[b] = flag[b];
   return SK_OK;
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)
 }

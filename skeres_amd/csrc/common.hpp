@@ -165,6 +165,7 @@ struct Options {  // Solver.Options; Ceres 1.x defaults
   bool graph_replay = true;      // sk_options_set_graph_replay: launch-bound problems replay their iteration as a hipGraph
   int max_segments = 0;          // sk_options_set_max_segments: SEGMENTED / AUTO cut the camera sequence into at most this many segments (0: one per rank)
   int border = SK_BORDER_AUTO;  // DENSE_SCHUR: order the cameras of loop closures into a trailing border of the reduced system (sk_options_set_cholesky_border)
+  int retained = SK_RETAINED_AUTO, retained_max = 0;  // DENSE_SCHUR: the points with the widest tracks stay in the reduced system (sk_options_set_retained_points)
 };
 
 struct IterationLog {

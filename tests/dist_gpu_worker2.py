@@ -46,9 +46,10 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "auto"
     fields = sys.argv[2].split(",") if len(sys.argv) > 2 else ["16", "600", "2600", "11"]
     revisits = len(fields) > 4 and fields[4] == "rev"  # loop closures: the revisiting cameras go to a border of the reduced system (round 4)
+    kept = len(fields) > 4 and fields[4] == "kept"  # retained points: the widest tracks stay in the reduced system (round 4)
     shape = [int(v) for v in fields[:4]]
     prob = bal.generate(shape[0], shape[1], shape[2], seed=shape[3], revisits=[(60, 350, 12, 40), (200, 520, 12, 40)] if revisits else ())
-    x_plain, s_plain = solve_bal_gpu(prob, **({"setCholeskyBorder": "off"} if revisits else {}))
+    x_plain, s_plain = solve_bal_gpu(prob, **({"setCholeskyBorder": "off"} if revisits else ({"setRetainedPoints": "off"} if kept else {})))
     problem, params, loss = bal_problem_to_sk(prob)
     options = sk.Solver.Options()
     options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
@@ -57,6 +58,8 @@ def main():
     options.setDistributionMode({"auto": 0, "sharded": 1, "replicated": 2, "segmented": 3}[mode])
     if revisits:
         options.setCholeskyBorder("on")
+    if kept:
+        options.setRetainedPoints("on", 12)
     summary = sk.Solver.Summary()
     solver = sk.StepSolver(options, problem)
     used, t_allreduce, t_saved = solver.distribution()
@@ -65,6 +68,9 @@ def main():
         # profile), and the packed all-reduce follows the bordered envelope
         assert solver.stat("border_cameras") >= 1 and solver.stat("dissected") == 0
         assert solver.stat("allreduce_bytes") < solver.stat("allreduce_bytes_full_triangle")
+    if kept:
+        # every rank retains the same twelve points (the hash the ranks compare covers them); whichever rank owns one writes its rows
+        assert solver.stat("retained_points") == 12 and solver.stat("dissected") == 0
     if shape[0] >= 200 and mode == "sharded":
         # a camera sequence long enough for a band: only the blocks inside the envelope travel
         assert solver.stat("allreduce_bytes") < 0.9 * solver.stat("allreduce_bytes_full_triangle"), (solver.stat("allreduce_bytes"), solver.stat("allreduce_bytes_full_triangle"))

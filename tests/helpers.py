@@ -22,7 +22,7 @@ def solve_bal_gpu(prob, x0=None, loss=None, **opts):
     options = sk.Solver.Options()
     options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
     for k, v in opts.items():
-        getattr(options, k)(v)
+        getattr(options, k)(*v) if isinstance(v, tuple) else getattr(options, k)(v)
     summary = sk.Solver.Summary()
     sk.ceres.solve(options, problem, summary)
     return params.toArray(prob.num_parameters), summary

@@ -865,6 +865,110 @@ def test_bordered_dense_schur_vs_oracle(C, P, N, seed, revisits):
         assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
 
 
+@pytest.mark.parametrize("C,P,N,seed,max_points,extra", [(16, 600, 2600, 11, 3, None), (150, 3000, 14000, 5, 6, None), (150, 3000, 14000, 5, 12, "loss+constant"),
+                                                         (600, 6000, 26000, 9, 24, None)])
+def test_retained_points_dense_schur_vs_oracle(C, P, N, seed, max_points, extra):
+    """Retained points (sk_options_set_retained_points): the widest tracks are not eliminated — their coordinates stay in the reduced
+    system as border rows behind the cameras — forced on at sizes the oracle solves.  The oracle, which eliminates every point as
+    Ceres' DENSE_SCHUR does (EX/SimpleBundleAdjuster.scala:147-152), gives the same trajectory at 1e-10, and so does the device
+    with every point eliminated.  extra: a Huber loss, a constant camera, and ONE OF THE RETAINED POINTS held constant."""
+    prob = bal.generate(C, P, N, seed=seed)
+    loss_spec = ("huber", 1.5) if extra else None
+    problem, params, loss = bal_problem_to_sk(prob, loss=sk_loss(loss_spec) if extra else None)
+    plan = problem.retainedPlan("on", max_points)
+    assert plan["retained_points"] == max_points and 0 < plan["model_us"]
+    kept_points = np.unique(prob.point_index[plan["retained_of_block"] == 1])
+    assert len(kept_points) == max_points
+    # the widest tracks — in the order the cameras have inside the reduced system: every retained point's span is at least that of
+    # every point that is eliminated
+    pos = problem.borderPlan("off")["position"].astype(np.int64)
+    lo = np.full(P, C); hi = np.full(P, -1)
+    np.minimum.at(lo, prob.point_index, pos); np.maximum.at(hi, prob.point_index, pos)
+    span = hi - lo
+    rest = np.setdiff1d(np.arange(P), kept_points)
+    assert span[kept_points].min() >= span[rest].max()
+    cam_mask = pt_mask = None
+    if extra:
+        cam_mask = np.zeros(C, dtype=np.int32); pt_mask = np.zeros(P, dtype=np.int32)
+        cam_mask[3] = 0x1ff; pt_mask[kept_points[1]] = 7; pt_mask[rest[7]] = 7
+        problem.setParameterBlockConstant(params.slice(9 * 3))
+        problem.setParameterBlockConstant(params.slice(9 * C + 3 * int(kept_points[1])))
+        problem.setParameterBlockConstant(params.slice(9 * C + 3 * int(rest[7])))
+    iters = 6 if C >= 600 else 50
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    options.setMaxNumIterations(iters)
+    options.setGraphReplay(False)  # (a launch-bound problem under hipGraph replay retains nothing)
+    options.setRetainedPoints("on", max_points)
+    solver = sk.StepSolver(options, problem)
+    assert solver.stat("retained_points") == max_points and solver.stat("dissected") == 0
+    while not solver.step():
+        pass
+    summary = sk.Solver.Summary()
+    solver.finish(summary)
+    x_gpu = params.toArray(prob.num_parameters)
+    x_cpu, so = oracle.solve_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=_oracle_threads(), max_num_iterations=iters, cholesky_envelope=1),
+                                 loss=loss_spec, cam_mask=cam_mask, pt_mask=pt_mask)
+    _check_against_oracle(prob, summary, x_gpu, so, x_cpu)
+    assert summary.numIterations() >= 3
+    if extra:
+        x0 = prob.parameters
+        assert np.array_equal(x_gpu[27:36], x0[27:36])
+        for q in (int(kept_points[1]), int(rest[7])):
+            assert np.array_equal(x_gpu[9 * C + 3 * q:9 * C + 3 * q + 3], x0[9 * C + 3 * q:9 * C + 3 * q + 3])
+        return
+    # the device with every point eliminated, and with the retained points under an explicit SYRK depth (launch by launch) and without
+    # the block envelope (every block factored)
+    x_off, s_off = solve_bal_gpu(prob, setRetainedPoints="off", setMaxNumIterations=iters, setGraphReplay=False)
+    for opts in ({}, {"setCholeskyTuning": 2}, {"setCholeskyEnvelope": 0}):
+        x_k, s_k = (x_gpu, summary) if not opts else solve_bal_gpu(prob, setRetainedPoints=("on", max_points), setMaxNumIterations=iters, setGraphReplay=False, **opts)
+        for u, v in zip(s_k.iterations()[:5], s_off.iterations()[:5]):
+            assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"], opts
+        assert np.abs(x_k - x_off).max() <= 1e-6 * max(1.0, np.abs(x_off).max())
+
+
+def test_retained_points_at_full_size_match_the_all_eliminated_solve_and_the_oracle():
+    """Ladybug-1723 at full size: AUTO retains the twelve widest tracks (landmarks seen from up to 392 cameras), the block envelope
+    of the reduced system falls to a fifth of its flops, every block column is chain-bound — and three LM iterations agree at
+    1e-10 with the device's all-eliminated solve and with the oracle, which eliminates every point."""
+    prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1))
+
+    def run(mode):
+        problem, params, loss = bal_problem_to_sk(prob)
+        options = sk.Solver.Options()
+        options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+        options.setMaxNumIterations(3)
+        options.setRetainedPoints(mode)
+        solver = sk.StepSolver(options, problem)
+        stats = {k: solver.stat(k) for k in ("retained_points", "retained_model_us", "retained_model_us_without", "cholesky_flops_plan", "envelope_fill")}
+        while not solver.step():
+            pass
+        summary = sk.Solver.Summary()
+        solver.finish(summary)
+        return params.toArray(prob.num_parameters), summary, stats
+    x_r, s_r, st_r = run("auto")
+    x_e, s_e, st_e = run("off")
+    assert st_r["retained_points"] >= 3 and st_e["retained_points"] == 0
+    assert st_r["retained_model_us"] < 0.9 * st_r["retained_model_us_without"]
+    assert st_r["cholesky_flops_plan"] < 0.4 * st_e["cholesky_flops_plan"]
+    for u, v in zip(s_r.iterations(), s_e.iterations()):
+        assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
+        assert abs(u["step_norm"] - v["step_norm"]) <= 1e-8 * max(1.0, v["step_norm"])
+    assert np.abs(x_r - x_e).max() <= 1e-7 * max(1.0, np.abs(x_e).max())
+    C, P = prob.num_cameras, prob.num_points
+    _, so = oracle.solve_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                             oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=_oracle_threads(), max_num_iterations=3, cholesky_envelope=1))
+    for k, it in enumerate(s_r.iterations()[:so.num_logged]):
+        assert abs(it["cost"] - so.iterations[k].cost) <= 1e-10 * so.iterations[k].cost
+
+
+def test_sharded_solve_with_retained_points():
+    """Two ranks sharing the GPU, points sharded, twelve retained points: whichever rank owns a retained point writes its rows of the
+    reduced system, the all-reduce carries them with the envelope, every rank takes the same step."""
+    test_sharded_solve_on_one_gpu_with_a_real_exchange(2, "sharded", shape="600,6000,26000,9,kept")
+
+
 def test_border_at_full_size_matches_the_plain_order_and_the_oracle():
     """Ladybug-1723 at full size with three places revisited (40 cameras each, 150 tracks each): AUTO takes the border (the
     chain model prefers it), the envelope stays near the band's, and two LM iterations agree with the plain order of the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase milliseconds per LM iteration of a named BAL workload (developer tool).
-usage: phase_times.py [ladybug|venice|bal49] [steps] [key=value solver options: border=off dissection=off revisits=1]"""
+usage: phase_times.py [ladybug|venice|bal49] [steps] [key=value solver options: border=off dissection=off retained=off|on:12 revisits=1]"""
 import os
 import sys
 import time
@@ -39,6 +39,8 @@ def main():
         o.setCholeskyBorder(kw["border"])
     if "dissection" in kw:
         o.setCholeskyDissection(kw["dissection"])
+    if "retained" in kw:
+        o.setRetainedPoints(*(kw["retained"].split(":")[:1] + [int(v) for v in kw["retained"].split(":")[1:]]))
     solver = sk.StepSolver(o, problem)
     for _ in range(2):
         solver.step()
@@ -51,6 +53,9 @@ def main():
     its = summ.iterations()
     n = max(1, len(its) - 1)
     ph = {k: 1e3 * summ.phaseSeconds(i) / n for i, k in enumerate(PHASES)}
+    print("  retained points %d (model %.0f us, %.0f without), border cameras %d, dissected %d, envelope fill %.3f, resident columns %d" % (
+        solver.stat("retained_points"), solver.stat("retained_model_us"), solver.stat("retained_model_us_without"), solver.stat("border_cameras"),
+        solver.stat("dissected"), solver.stat("envelope_fill"), solver.stat("cholesky_columns_resident")))
     print("%s %s: %.3f ms/step | A %.3f  B %.3f  C %.3f  D %.3f + %.3f | final cost %.9e" % (
         which, " ".join(sys.argv[3:]), 1e3 * dt / steps, ph["jacobian_eval"], ph["schur_assemble"], ph["cholesky"], ph["back_substitute"], ph["cost_eval"], its[-1]["cost"]), flush=True)
 
