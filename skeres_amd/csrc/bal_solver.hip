@@ -173,6 +173,7 @@ class BalSolver : public SolverBase {
       *value = in / (0.5 * nblk * (nblk + 1.0));
       return true;
     }
+    if (name == "reduced_system_blocks") { *value = nblk; return true; }  // (block rows of the undissected reduced system: cameras, pseudo-cameras of retained points, the right-hand side)
     if (name == "camera_order") { *value = camera_order_; return true; }
     if (name == "cholesky_flops_full") { const double n = 9.0 * C_; *value = n * n * n / 3.0; return true; }
     if (name == "cholesky_flops_plan") {
@@ -399,8 +400,9 @@ static double column_cost_us(int h, bool resident_capable) {
 // lockstep: the schedule of ONE device since the end of round 3 — the tail's block columns ride in the launches of the head's
 // trailing run of chain-bound columns (CholeskyPartner), so a paired step costs the dearer of its two columns and the head's
 // block columns before that run are not shortened at all.
+// extra_sep: cameras that join the separator whatever the cut (the pseudo-cameras of retained points, which every camera may couple with)
 static Dissection choose_dissection(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
-                                    const std::vector<int>& first_col, bool tail_resident, bool lockstep = false) {
+                                    const std::vector<int>& first_col, bool tail_resident, bool lockstep = false, int extra_sep = 0) {
   Dissection d;
   if (C < 64 || nblk < 24) return d;
   // reach[c]: the last camera that shares a point with any camera <= c (cameras in the chosen order)
@@ -426,7 +428,7 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
   for (int a = 14; a + 14 < C; a += 7) {
     const int b = reach[a - 1] + 1;
     if (b >= C - 14) break;
-    const int ca = (9 * a + 127) / 128, cb = (9 * b) / 128, E = (9 * (b - a) + 1 + 127) / 128;
+    const int ca = (9 * a + 127) / 128, cb = (9 * b) / 128, E = (9 * (b - a + extra_sep) + 1 + 127) / 128;
     if (E > 24) continue;  // a separator that wide is no separator: its dense system is factored after both chains, alone
     double root = 0.0;
     for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i, true);
@@ -454,8 +456,10 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
 // Block envelope of one front: `pos[c]` is camera c's first row in the front (interior or border), -1 when the camera has
 // no rows in it; `interior[c]` whether its columns are eliminated in this front.  Only points that touch an interior
 // camera shape the envelope (the border x border block is the Schur complement's, covered by the last columns' reach).
+// tail_begin_row >= 0: the front's rows from there on (the rows of retained points, at the end of its border) are a border in the sense
+// of cholesky_envelope_bordered — active from the first column that reaches them, not part of a column's contiguous run: *tail_out.
 static std::vector<int> front_envelope(const std::vector<int>& ocam, const std::vector<int>& opt, const std::vector<int>& pos, const std::vector<char>& interior,
-                                       int P, int nblk, int tail_rows = 1) {
+                                       int P, int nblk, int tail_rows = 1, int tail_begin_row = -1, std::vector<int>* tail_out = nullptr) {
   const int kNone = 1 << 30;
   std::vector<int> minpos(P, kNone);
   for (size_t b = 0; b < ocam.size(); ++b) if (interior[ocam[b]]) minpos[opt[b]] = std::min(minpos[opt[b]], pos[ocam[b]]);
@@ -466,6 +470,11 @@ static std::vector<int> front_envelope(const std::vector<int>& ocam, const std::
     if (pos[c] < 0 || minpos[opt[b]] == kNone) continue;
     const int col = minpos[opt[b]] / 128;
     for (int row = pos[c] / 128; row <= (pos[c] + 8) / 128; ++row) first_col[row] = std::min(first_col[row], std::min(col, row));
+  }
+  if (tail_begin_row >= 0 && tail_out) {
+    std::vector<int> last;
+    cholesky_envelope_bordered(first_col, tail_begin_row / 128, &last, tail_out);
+    return last;
   }
   return cholesky_envelope_last(first_col, tail_rows);
 }
@@ -896,7 +905,7 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
   for (int q = 0; q < P; ++q) if (cnt[q] >= 2 && 9 * (cmax[q] - cmin[q]) >= 128) wide.push_back(q);
   std::sort(wide.begin(), wide.end(), [&](int a, int b) { const int sa = cmax[a] - cmin[a], sb = cmax[b] - cmin[b]; return sa != sb ? sa > sb : a < b; });
   const bool exactly = mode == SK_RETAINED_ON && max_points > 0;  // (ON with a count: that many, as far as there are candidates)
-  if (max_points <= 0) max_points = 192;
+  if (max_points <= 0) max_points = 768;
   max_points = std::min(max_points - max_points % 3, (int)wide.size() - (int)wide.size() % 3);
   double best = mode == SK_RETAINED_ON ? std::numeric_limits<double>::max() : 0.9 * base_us;
   int worse = 0;
@@ -1024,6 +1033,7 @@ int BalSolver::setup() {
     if (off[0] > 0.0) opt_.lookahead = false;
   }
   std::vector<int> env_for_model;  // the envelope of the chosen order (whether or not it is then used)
+  std::vector<int> band_ocam, band_opt;  // retained points: the eliminated points' observations over the real cameras, final numbering (the band a dissection cuts)
   // ---- camera order + block envelope of the reduced system (all ranks' observations: the all-reduced S has the union structure).
   // The order is chosen the same way whether or not the envelope is then used (opt_.envelope), so that the two
   // settings differ in nothing but the blocks they skip and give bit-identical results. ----
@@ -1076,6 +1086,8 @@ int BalSolver::setup() {
       n_ = 9 * C_; rhs_row_ = n_; npad_ = ((n_ + 1 + 127) / 128) * 128;
       struct_ocam_ = rgraphs.ocam_x; struct_opt_ = rgraphs.opt_x; struct_P_ = rgraphs.Px;
       for (int& c : struct_ocam_) c = id[c];
+      band_ocam = rgraphs.ocam_g; band_opt = rgraphs.opt_g;
+      for (int& c : band_ocam) c = id[c];
       retained_cam_.resize(retained_pts_.size());
       for (size_t k = 0; k < retained_pts_.size(); ++k) retained_cam_[k] = id[Creal + (int)k / 3];
     }
@@ -1122,9 +1134,13 @@ int BalSolver::setup() {
     // ---- dissect?  One process: only when forced (measured not to pay on one chip).  Several ranks: the SEGMENTED
     // distribution — every rank's device eliminates one segment of the camera sequence — when the model of the chains
     // predicts a gain (or when asked for). ----
-    const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0 && env_tail_.empty();  // (a bordered envelope is not dissected)
+    // (a border of loop-closure cameras is not dissected; a border of pseudo-cameras alone is: on one device they join the separator,
+    // which both fronts border on — the band of real cameras is what is cut)
+    const bool pseudo_border = pseudo_cams_ > 0 && border_cams_ == 0;
+    const int Cband = C_ - (pseudo_border ? pseudo_cams_ : 0);
+    const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0 && (env_tail_.empty() || pseudo_border);
     const bool multi = opt_.allreduce != nullptr && opt_.world >= 2;
-    bool may_dissect = plan_ok && (multi ? (opt_.distribution_mode == SK_DISTRIBUTION_AUTO || opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED)
+    bool may_dissect = plan_ok && (multi ? (pseudo_cams_ == 0 && (opt_.distribution_mode == SK_DISTRIBUTION_AUTO || opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED))
                                          : (!opt_.allreduce && chol_ctx_b_.init_secondary(chol_ctx_) == hipSuccess));
     if (!may_dissect) (void)hipGetLastError();
     if (!plan_ok && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED) {
@@ -1144,12 +1160,17 @@ int BalSolver::setup() {
     } else if (may_dissect) {
       Dissection ds;
       std::vector<int> first_col;
-      (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
+      // what is cut: the cameras' band — with retained points, the band of the real cameras under the points that are eliminated
+      const std::vector<int>& docam = pseudo_border ? band_ocam : ocam;
+      const std::vector<int>& dopt = pseudo_border ? band_opt : opt;
+      const int dnblk = pseudo_border ? (9 * Cband + 1 + 127) / 128 : nblk;
+      const std::vector<int> band_env = envelope_of_order(docam, dopt, [&] { std::vector<int> e(Cband); std::iota(e.begin(), e.end(), 0); return e; }(), Cband, P_total_, dnblk, &first_col);
+      const std::vector<int>& denv = pseudo_border ? band_env : env_for_model;
       // one device: the lock-step schedule and its own cut
       // (only under the resident chain: the partner front rides in ITS launches — with SK_CHOL_CHAIN_SERVER=0, or on a device that
       // lost its chain, a single device stays undissected)
       const bool lockstep_cut = !multi && opt_.dissection == SK_DISSECTION_AUTO && opt_.resident_kernels && cholesky_chain_enabled(&chol_ctx_);
-      ds = choose_dissection(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, lockstep_cut, lockstep_cut);
+      ds = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, lockstep_cut, lockstep_cut, C_ - Cband);
       if (lockstep_cut && ds.a > 0) {  // (two resident servers per factorisation: the fifth such solver alive on a device stays undissected)
         if (!pair_claimed_) pair_claimed_ = cholesky_claim_pair_servers(&chol_ctx_);
         if (!pair_claimed_) ds.a = ds.b = 0;
@@ -1180,10 +1201,10 @@ int BalSolver::setup() {
       }
       dissect_t_plain_ = ds.t_plain; dissect_t_model_ = ds.t_dissected;
       {  // what the chain model predicts for 2 .. 8 devices (sk_solver_stat "model_us_segments_<n>": bench.py prints it beside what it measures)
-        const Segments sg = choose_segments(ocam, opt, C_, P_total_, nblk, env_for_model, first_col, 8, false);
+        const Segments sg = choose_segments(docam, dopt, Cband, P_total_, dnblk, denv, first_col, 8, false);
         for (int k = 0; k < 9; ++k) model_us_[k] = sg.model_us[k];
       }
-      if (ds.a > 0 && ds.b < C_) { cut_a.push_back(ds.a); cut_b.push_back(ds.b); }
+      if (ds.a > 0 && ds.b < Cband) { cut_a.push_back(ds.a); cut_b.push_back(ds.b); }
     }
     if (multi && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && cut_a.empty()) {
       set_error("the segmented distribution needs a separator in the camera sequence (no point seen from both ends); not supported for this problem");
@@ -1197,22 +1218,26 @@ int BalSolver::setup() {
       const int R = (int)cut_a.size() + 1;
       seg_off_.assign(R + 1, 0);
       for (int sg = 0; sg < R; ++sg) {
-        const int lo = sg == 0 ? 0 : cut_b[sg - 1], hi = sg + 1 < R ? cut_a[sg] : C_;
+        const int lo = sg == 0 ? 0 : cut_b[sg - 1], hi = sg + 1 < R ? cut_a[sg] : Cband;
         seg_off_[sg + 1] = seg_off_[sg] + (hi - lo);
       }
       cam_b_ = seg_off_[R];
       std::vector<int> fin(C_);
       int sep_pos = cam_b_;
       for (int sg = 0; sg < R; ++sg) {
-        const int lo = sg == 0 ? 0 : cut_b[sg - 1], hi = sg + 1 < R ? cut_a[sg] : C_;
+        const int lo = sg == 0 ? 0 : cut_b[sg - 1], hi = sg + 1 < R ? cut_a[sg] : Cband;
         for (int c = lo; c < hi; ++c) fin[c] = sg + 1 < R ? seg_off_[sg] + (c - lo) : seg_off_[sg] + (hi - 1 - c);
         if (sg + 1 < R) { sep_first_.push_back(sep_pos); for (int c = cut_a[sg]; c < cut_b[sg]; ++c) fin[c] = sep_pos++; }
       }
+      for (int c = Cband; c < C_; ++c) fin[c] = sep_pos++;  // the pseudo-cameras of retained points: the end of the (one) separator
       sep_first_.push_back(C_);
       std::vector<int> cb2(C_);
       for (int c = 0; c < C_; ++c) cb2[fin[c]] = cam_block_[c];
       cam_block_.swap(cb2);
       for (int& c : ocam) c = fin[c];
+      for (int& c : struct_ocam_) c = fin[c];
+      for (int& c : retained_cam_) c = fin[c];
+      env_tail_.clear();  // (the fronts have envelopes of their own)
       cam_a_ = seg_off_[1];  // (one device: the head [0, cam_a_), the tail [cam_a_, cam_b_))
       segments_ = R;
     }
@@ -1443,8 +1468,15 @@ int BalSolver::setup() {
       for (int c = lo; c < hi; ++c) { pos[c] = 9 * (c - lo); interior[c] = 1; }
       const int bo = L.ncols * 128;
       for (int c = rl; c < rh; ++c) pos[c] = bo + lay.right_off + 9 * (c - rl);
-      for (int c = ll; c < lh; ++c) pos[c] = bo + lay.left_off + (lay.reversed ? 9 * (lh - 1 - c) : 9 * (c - ll));
-      L.last = front_envelope(ocam, opt, pos, interior, P_total_, L.nblk, L.tail_rows);
+      // (the pseudo-cameras of retained points — one device: the end of the one separator — stay at the END of a reversed border too:
+      // their rows are tail rows of the front's envelope, a suffix of the matrix)
+      const int lreal = lh - (segmented_ ? 0 : pseudo_cams_);
+      for (int c = ll; c < lh; ++c) pos[c] = bo + lay.left_off + (lay.reversed && c < lreal ? 9 * (lreal - 1 - c) : 9 * (c - ll));
+      if (struct_ocam_.empty()) {
+        L.last = front_envelope(ocam, opt, pos, interior, P_total_, L.nblk, L.tail_rows);
+      } else {
+        L.last = front_envelope(struct_ocam_, struct_opt_, pos, interior, struct_P_, L.nblk, L.tail_rows, pos[C_ - pseudo_cams_], &L.tail);
+      }
       border_row_h[f].assign(std::max(1, nsep), 0);
       for (int c = cam_b_; c < C_; ++c) border_row_h[f][c - cam_b_] = pos[c] >= 0 ? pos[c] : 0;  // (a separator that is not next to the segment: no block of it here)
       if (segmented_) {
@@ -1500,7 +1532,8 @@ int BalSolver::setup() {
   if (dissected_ && !segmented_) {
     const int nsep = C_ - cam_b_;
     std::vector<int> mapB((size_t)border_blocks_ * 128, -1);
-    for (int k = 0; k < nsep; ++k) for (int c = 0; c < 9; ++c) mapB[9 * k + c] = 9 * (nsep - 1 - k) + c;  // camera order reversed, coordinates in order
+    const int nreal = nsep - pseudo_cams_;
+    for (int k = 0; k < nsep; ++k) for (int c = 0; c < 9; ++c) mapB[9 * k + c] = k < nreal ? 9 * (nreal - 1 - k) + c : 9 * k + c;  // camera order reversed, coordinates in order (pseudo-cameras: in place)
     mapB[9 * nsep] = 9 * nsep;  // right-hand-side row
     SK_HIP_TRY(b_mapB_.upload(mapB, s));
   }
@@ -1537,7 +1570,7 @@ int BalSolver::setup() {
     auto view = [&](int f) {
       FrontView v;
       v.S = d_.front[f].S; v.ld = (long)fr_[f].dim; v.nblk = fr_[f].nblk; v.ncols = fr_[f].ncols; v.last = fr_[f].env();
-      v.Linv = b_Linv_.p + fr_[f].linv_off; v.rhs_row = fr_[f].rhs_row;
+      v.Linv = b_Linv_.p + fr_[f].linv_off; v.rhs_row = fr_[f].rhs_row; v.tail = fr_[f].tl();
       return v;
     };
     ds_.A = view(0); ds_.B = view(1); ds_.R = view(2); ds_.border_blocks = border_blocks_; ds_.mapB = b_mapB_.p;

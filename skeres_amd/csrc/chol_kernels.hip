@@ -2012,7 +2012,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   hipStream_t srv = nullptr;
   hipEvent_t start_ev = nullptr;
   struct PartnerState {
-    bool on = false; CholeskyPlan plan; int nblk = 0, ncols = 0, tail0 = 0, start_at = 0, maxblk = 0; const int* last = nullptr;
+    bool on = false; CholeskyPlan plan; int nblk = 0, ncols = 0, tail0 = 0, start_at = 0, maxblk = 0; const int* last = nullptr; const int* tail = nullptr;
     double* S = nullptr; long ld = 0; double* Linv = nullptr; int* sync = nullptr; double* xs = nullptr;
     int next = 0, seq = 0, col_seq = 0;
   } pb;
@@ -2021,10 +2021,10 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   auto partner_step = [&](int kB) {
     PartnerStep st;
     auto lm = [&](int c) { return pb.last ? (pb.last[c] < pb.nblk - 1 ? pb.last[c] : pb.nblk - 1) : pb.nblk - 1; };
-    auto rf = [&](int first_row, int last_row) {
+    auto rf = [&](int first_row, int last_row) {  // (of block column kB: its run and its tail rows)
       Rows r;
       r.main = last_row >= first_row ? last_row - first_row + 1 : 0;
-      const int t0 = std::max(pb.tail0, first_row + r.main);
+      const int t0 = std::max(pb.tail ? pb.tail[kB] : pb.tail0, first_row + r.main);
       r.extra = std::max(0, pb.nblk - t0);
       r.jump = r.extra ? t0 - (first_row + r.main) : 0;
       return r;
@@ -2058,7 +2058,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     // ---- the partner front (see CholeskyPartner): taken along if every one of its block columns is a resident single column,
     // in the launches of this front's resident single columns
     if (partner && partner->ncols > 0 && partner->ctx && !(kt && kt->times_all())) {
-      pb.plan = cholesky_plan(partner->nblk, group, partner->last, true, partner->ncols, partner->tail_rows);
+      pb.plan = cholesky_plan(partner->nblk, group, partner->last, true, partner->ncols, partner->tail_rows, partner->tail);
       bool all = (int)pb.plan.resident.size() >= partner->ncols;
       for (int j = 0; all && j < partner->ncols; ++j) all = pb.plan.resident[j] && !pb.plan.paired[j];
       // (from the first resident single column of this front on — its first few block columns are chain-bound too, before the
@@ -2069,7 +2069,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       if (sb_sync && partner->ctx->xs) {
         pb.on = true; pb.start_at = start; pb.sync = sb_sync; pb.maxblk = partner->ctx->sync_blk; pb.xs = partner->ctx->xs;
         pb.nblk = partner->nblk; pb.ncols = partner->ncols; pb.tail0 = partner->nblk - std::max(1, std::min(partner->tail_rows, partner->nblk - partner->ncols));
-        pb.last = partner->last; pb.S = partner->S; pb.ld = partner->ld; pb.Linv = partner->Linv;
+        pb.last = partner->last; pb.tail = partner->tail; pb.S = partner->S; pb.ld = partner->ld; pb.Linv = partner->Linv;
         (void)hipMemsetAsync(pb.sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * pb.maxblk), s);
         partner->taken = true;
       }
@@ -2175,9 +2175,13 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     if (with_partner) {
       // both fronts' thin SYRKs as one launch; each front's first block column counts into its own counter
       const bool by_col = next_resident && g_early_column;
+      bool withheld = false;  // (fault injection of the testing build, as in the unpaired branch below)
+#ifdef SK_TESTING
+      if (next_resident && Tb > 0 && !ctx->dq->tuning) { int want = k1; withheld = want >= 0 && g_test_withhold.compare_exchange_strong(want, -1); }
+#endif
       ThinSyrkPair tp;
       tp.f[0] = ThinSyrkArgs{S + (long)(k1 + 1) * 128 * ld + (long)(k1 + 1) * 128, ld, S + (long)(k1 + 1) * 128 * ld + (long)k0 * 128, ld, 128, 4 * Tb, 4 * rs.main, 4 * rs.jump,
-                             rs.main, rs.jump, by_col ? sync + kSyncSyrkColumn : (int*)nullptr, Tb > 0 ? 2 * Tb * (Tb + 1) : 0};
+                             rs.main, rs.jump, by_col && !withheld ? sync + kSyncSyrkColumn : (int*)nullptr, Tb > 0 ? 2 * Tb * (Tb + 1) : 0};
       tp.f[1] = pst.syrk;
       const int gx = std::max(tp.f[0].grid, tp.f[1].grid);
       hipEvent_t t_start = nullptr, t_stop = nullptr;
@@ -2186,7 +2190,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       if (gx > 0) hipExtLaunchKernelGGL(syrk_trailing_thin_pair_f64_kernel, dim3(gx, 2), dim3(256), 0, sb, t_start, stop_ev, 0, tp);
       if (Tb > 0) {
         if (by_col) col_seq += 4 * Tb;
-        else if (next_resident) { ++seq; hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, seq); }
+        else if (next_resident) { ++seq; if (!withheld) hipLaunchKernelGGL(chain_marker_kernel, dim3(1), dim3(1), 0, sb, sync + kSyncSyrkSeq, seq); }
       }
       partner_advance(pst, sb);
       if (gx > 0 && !next_resident) syrk_done = stop_ev;  // (the launch-by-launch panel that follows waits for it)
@@ -2409,7 +2413,7 @@ void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f
 // Interior part of L^T y = z for a leaf front whose border unknowns are known.  yb: border unknowns (border_blocks * 128
 // values, zero where the border has padding or its right-hand-side row).  w: scratch (ncols * 128); y: interior solution.
 void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info, bool zero_after) {
+                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info, bool zero_after, const int* tail) {
   const int ni = ncols * 128, m = (nblk - ncols) * 128;
   if (ncols <= 0) return;
   if (info && g_bs_resident && nblk <= kBsMaxBlocks) {
@@ -2418,7 +2422,10 @@ void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_r
     // groups here): equal to rounding, not to the bit — a front's interior solution belongs to one rank.
     if (tail_rows < 1 || tail_rows > nblk - ncols) tail_rows = 1;
     BsTop env;
-    for (int c = 0; c < nblk; ++c) { env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1); env.tail[c] = (unsigned short)(nblk - tail_rows); }
+    for (int c = 0; c < nblk; ++c) {
+      env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1);
+      env.tail[c] = (unsigned short)(tail ? std::min(std::max(tail[c], 0), nblk - 1) : nblk - tail_rows);
+    }
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)ni, s);
     const int janitors = zero_after ? bs_janitors(ncols) : 0;
     hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), ni, y, nblk, env, info, ncols, yb, janitors);
@@ -2434,8 +2441,11 @@ void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_r
       first[kb] = c0;
     }
   // (spike: border rows that couple with the FIRST interior columns — the left separator of a segment between two — and so
-  // reach every column; otherwise the border starts where the first interior column reaches it)
-  const int bcol0 = spike ? 0 : std::min(first[ncols < nblk - 1 ? ncols : nblk - 1], ncols) * 128;
+  // reach every column; otherwise the border starts where the first interior column reaches it.  A tail profile: its rows may share
+  // the LAST block row with the right-hand side, which every column has — from the first column on, then; what a column does not
+  // couple with is zeros)
+  const int bfirst = first[ncols < nblk - 1 ? ncols : nblk - 1];
+  const int bcol0 = (spike || tail) ? 0 : std::min(bfirst, ncols) * 128;
   if (ni > bcol0)
     hipLaunchKernelGGL(bs_border_kernel, dim3((ni - bcol0 + 63) / 64), dim3(1024), 0, s, S + (long)ncols * 128 * ld, ld, m, yb, w, bcol0, ni);
   for (int kb = ncols - 1; kb >= 0; --kb) {
@@ -2456,10 +2466,10 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
   // of having queues of its own: the only form that pays on one device (the side-by-side form below
   // was slower on every cut measured — profiles/r02_dissection_*.txt, r03_dissection_probe.txt, r03_lockstep_cut_sweep.txt)
   if (d.A.ncols > 0 && d.B.ncols > 0 && ctxA && ctxB && allow_chain) {
-    CholeskyPartner pt{d.B.S, d.B.ld, d.B.nblk, d.B.ncols, 1, d.B.last, d.B.Linv, ctxB};
-    cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols, 1, &pt);
+    CholeskyPartner pt{d.B.S, d.B.ld, d.B.nblk, d.B.ncols, 1, d.B.last, d.B.Linv, ctxB, d.B.tail};
+    cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols, 1, &pt, d.A.tail);
     if (!pt.taken)  // (not every block column of the tail is a resident single column: factored afterwards, on the primary context)
-      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, allow_chain, d.B.ncols);
+      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, allow_chain, d.B.ncols, 1, nullptr, d.B.tail);
     cholesky_border_add(d.R.S, d.R.ld, d.A.S, d.A.ld, d.A.ncols, d.border_blocks, nullptr, s);
     cholesky_border_add(d.R.S, d.R.ld, d.B.S, d.B.ld, d.B.ncols, d.border_blocks, d.mapB, s);
     cholesky_factor(d.R.S, d.R.ld, d.R.nblk * 128, d.R.Linv, info, group, s, ctxA, kt, d.R.last, allow_chain);
@@ -2470,7 +2480,7 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
   // queues, one front after the other.
   const bool side = d.B.ncols > 0 && ctxB && ctxB->fork;
   if (d.B.ncols > 0 && !side) {
-    cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, allow_chain && ctxB && ctxB->server, d.B.ncols);
+    cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, s, ctxA, kt, d.B.last, allow_chain && ctxB && ctxB->server, d.B.ncols, 1, nullptr, d.B.tail);
   } else if (side) {
     fork_join_events(ctxB);
     hipStream_t sB = ctxB->fork;
@@ -2481,11 +2491,11 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
     const bool chainB = allow_chain && ctxB->server != nullptr;  // the tail under a resident chain of its own
     if (!ctxB->runner) ctxB->runner.reset(new AsyncRunner(ctxB->device));
     ctxB->runner->run([&d, info, group, ctxB, ktB, sB, chainB] {
-      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, sB, ctxB, ktB, d.B.last, chainB, d.B.ncols);
+      cholesky_factor(d.B.S, d.B.ld, d.B.nblk * 128, d.B.Linv, info, group, sB, ctxB, ktB, d.B.last, chainB, d.B.ncols, 1, nullptr, d.B.tail);
       (void)hipEventRecord(ctxB->join_ev, sB);
     });
   }
-  if (d.A.ncols > 0) cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols);
+  if (d.A.ncols > 0) cholesky_factor(d.A.S, d.A.ld, d.A.nblk * 128, d.A.Linv, info, group, s, ctxA, kt, d.A.last, allow_chain, d.A.ncols, 1, nullptr, d.A.tail);
   if (side) {
     ctxB->runner->wait();  // (the join event has been recorded)
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);
@@ -2510,10 +2520,10 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
       sB = ctxB->fork;
     }
     cholesky_gather_map(yR, d.mapB, ybB, m, sB);
-    cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, ybB, wB, yB, sB, d.B.last, false, 1, info, zero_after);
+    cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, ybB, wB, yB, sB, d.B.last, false, 1, info, zero_after, d.B.tail);
   }
   // (yR is zero in the root's padding rows and in its right-hand-side row: it serves as A's border unknowns as it stands)
-  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after);
+  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after, d.A.tail);
   if (side) {
     (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);

@@ -182,6 +182,7 @@ size_t potrf128_lds_bytes();
 // picking the front: DESIGN.md section 8, item 0).  ctx lends its counters and scratch only.  taken: whether it was factored.
 struct CholeskyPartner {
   double* S; long ld; int nblk, ncols, tail_rows; const int* last; double* Linv; CholeskyContext* ctx;
+  const int* tail = nullptr;  // the partner's tail profile (as cholesky_factor's `tail`)
   mutable bool taken = false;
 };
 // tail (optional, nblk entries; round 4): a PROFILE of the trailing block rows instead of the uniform `tail_rows` — block rows
@@ -221,6 +222,8 @@ struct FrontView {
   int rhs_row = 0;                    // row that carries the right-hand side
   int tail_rows = 1;                  // block rows at the end that are active in every column (cholesky_plan)
   bool spike = false;                 // the border has rows that couple with the first interior columns (SegmentLayout)
+  const int* tail = nullptr;          // a PROFILE of trailing block rows instead of the uniform tail_rows (cholesky_factor): the leaf's border ends
+                                      // with the rows of retained points, which are active from the first camera that sees the point
 };
 struct DissectedSystem {
   FrontView A, B, R;                  // head, tail (B.ncols == 0: none), root
@@ -240,7 +243,7 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
 void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s);
 // info != nullptr: one resident launch (the kernel of cholesky_backsolve; tail_rows as in cholesky_factor); nullptr: one launch per block step
 void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike = false, int tail_rows = 1, int* info = nullptr, bool zero_after = false);
+                              hipStream_t s, const int* last, bool spike = false, int tail_rows = 1, int* info = nullptr, bool zero_after = false, const int* tail = nullptr);
 void cholesky_gather_map(const double* src, const int* map, double* dst, int m, hipStream_t s);
 // --- multi-way dissection: R segments of a block-banded system with R - 1 separators between them ---
 // Leaf front of one segment, in scalar rows.  The interior is followed by a border:

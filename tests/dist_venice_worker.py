@@ -40,7 +40,7 @@ def main():
             options.setDistributionMode({"auto": 0, "sharded": 1}[mode])
         solver = sk.StepSolver(options, problem)
         info = {"used": solver.distribution()[0] if distributed else "single", "allreduce_bytes": solver.stat("allreduce_bytes"),
-                "full_triangle": solver.stat("allreduce_bytes_full_triangle"), "fill": solver.stat("envelope_fill"), "problem": problem}
+                "full_triangle": solver.stat("allreduce_bytes_full_triangle"), "fill": solver.stat("envelope_fill"), "blocks": solver.stat("reduced_system_blocks"), "problem": problem}
         while not solver.step():
             pass
         summary = sk.Solver.Summary()
@@ -66,7 +66,8 @@ def main():
     imbalance = per_rank.max() / per_rank.mean()
     assert imbalance <= 1.05, (imbalance, per_rank)
     # what travels per iteration in sharded mode: the lower-triangular 128-blocks inside the envelope, nothing else
-    nblk = (9 * C + 1 + 127) // 128
+    nblk = int(info["blocks"])  # (the reduced system's block rows: the cameras' — and the retained points', three to a nine-row pseudo-camera)
+    assert nblk >= (9 * C + 1 + 127) // 128
     blocks = info["fill"] * 0.5 * nblk * (nblk + 1)
     if info["used"] == "sharded":
         assert abs(info["allreduce_bytes"] - blocks * 128 * 128 * 8) <= 1e-6 * info["allreduce_bytes"], (info["allreduce_bytes"], blocks)
