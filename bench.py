@@ -167,10 +167,13 @@ def chain_model_record(stat, cholesky_ms):
         except Exception:  # noqa: BLE001
             return 0.0
     which, model = "undissected", get("model_us_segments_1")
-    if get("border_cameras") > 0 and get("border_model_us") > 0:
+    kept = " with %d retained points" % int(get("retained_points")) if get("retained_points") > 0 else ""
+    if get("dissected") == 1.0 and get("dissection_model_us") > 0:
+        which, model = "lock-step dissection" + kept, get("dissection_model_us")
+    elif get("retained_points") > 0 and get("retained_model_us") > 0:
+        which, model = "bordered" + kept, get("retained_model_us")
+    elif get("border_cameras") > 0 and get("border_model_us") > 0:
         which, model = "bordered", get("border_model_us")
-    elif get("dissected") == 1.0 and get("dissection_model_us") > 0:
-        which, model = "lock-step dissection", get("dissection_model_us")
     if not model:
         return None
     return {"plan": which, "model_us": model, "measured_cholesky_phase_us": 1e3 * cholesky_ms,
@@ -178,7 +181,7 @@ def chain_model_record(stat, cholesky_ms):
 
 
 def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, world, dist_mod=None, torch=None, long_range_fraction=0.0,
-               revisits=(), border=None):
+               revisits=(), border=None, retained=None):
     """One more bundle-adjustment workload of BASELINE.json in the same run (configs[1] BAL-49, configs[3] Venice-1778): `steps`
     LM iterations of the same solve as the headline, timed the same way (barrier + synchronise on both sides, max over
     ranks); with several ranks, the distribution the solver chose, what travels per iteration and how long it takes."""
@@ -194,6 +197,8 @@ def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, wor
     o.setStream(stream.cuda_stream)
     if border is not None:
         o.setCholeskyBorder(border)
+    if retained is not None:
+        o.setRetainedPoints(retained)
     hook = None
     solver, err = None, None
     try:
@@ -208,7 +213,8 @@ def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, wor
         raise err
     mode = solver.distribution()[0] if world > 1 else "single"
     stats = {k: solver.stat(k) for k in ("envelope_fill", "allreduce_bytes", "segments", "cholesky_flops_plan", "border_cameras", "border_model_us",
-                                         "border_model_us_plain", "cholesky_columns_resident", "dissected", "model_us_segments_1", "dissection_model_us")}
+                                         "border_model_us_plain", "cholesky_columns_resident", "dissected", "model_us_segments_1", "dissection_model_us",
+                                         "retained_points", "retained_model_us", "retained_model_us_without")}
     for _ in range(warmup):
         solver.step()
     torch.cuda.synchronize()
@@ -249,6 +255,10 @@ def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, wor
         rec["border"] = {"mode": border or "auto", "cameras": int(stats["border_cameras"]), "chain_model_us": stats["border_model_us"],
                          "chain_model_us_plain_order": stats["border_model_us_plain"], "block_columns_resident": int(stats["cholesky_columns_resident"]),
                          "dissected": int(stats["dissected"])}
+    # retained points (sk_options_set_retained_points): the widest tracks stay in the reduced system instead of being eliminated
+    rec["retained_points"] = {"mode": retained or "auto", "points": int(stats["retained_points"]), "chain_model_us": stats["retained_model_us"],
+                              "chain_model_us_all_eliminated": stats["retained_model_us_without"], "dissected": int(stats["dissected"]),
+                              "block_columns_resident": int(stats["cholesky_columns_resident"])}
     if world == 1:
         rec["chain_model"] = chain_model_record(lambda k: stats.get(k, 0.0), phases["cholesky"])
     if world > 1:
@@ -457,7 +467,8 @@ def main():
     except sk.SkeresError:
         pass
     headline_stats = {}
-    for k in ("model_us_segments_1", "border_cameras", "border_model_us", "dissected", "dissection_model_us"):
+    for k in ("model_us_segments_1", "border_cameras", "border_model_us", "dissected", "dissection_model_us", "retained_points", "retained_model_us",
+              "retained_model_us_without", "dissection_head_cameras", "dissection_tail_cameras", "dissection_separator_cameras"):
         try:
             headline_stats[k] = solver.stat(k)
         except sk.SkeresError:
@@ -525,6 +536,13 @@ def main():
                 "camera_order": {0: "first appearance", 1: "memory order of the camera blocks", 2: "reverse Cuthill-McKee"}.get(int(plan["camera_order"])),
                 "cholesky_block_columns_resident": int(plan["cholesky_columns_resident"]),
                 "long_range_fraction": args.long_range,
+                # the points the Schur complement does NOT eliminate (sk_options_set_retained_points, AUTO): the widest tracks stay in the
+                # reduced system as border rows; "dissection": the lock-step two-way dissection of the camera band (head, tail, separator cameras)
+                "retained_points": {"points": int(headline_stats.get("retained_points", 0)), "chain_model_us": headline_stats.get("retained_model_us", 0.0),
+                                    "chain_model_us_all_eliminated": headline_stats.get("retained_model_us_without", 0.0)},
+                "dissection": {"dissected": int(headline_stats.get("dissected", 0)), "head_cameras": int(headline_stats.get("dissection_head_cameras", 0)),
+                               "tail_cameras": int(headline_stats.get("dissection_tail_cameras", 0)),
+                               "separator_cameras_and_pseudo_cameras": int(headline_stats.get("dissection_separator_cameras", 0))},
                 "successful_steps_in_timed_region": n_success, "parallelism": ("one GPU" if world == 1 else
                                 "camera sequence cut into %d segments over the %d ranks (SK_DISTRIBUTION_SEGMENTED): rank r's device eliminates segment r "
                                 "and its points (ranks beyond the segments replicate and add zeros); per iteration the separators' block-tridiagonal "
@@ -654,6 +672,8 @@ def main():
             # cameras are ordered into a trailing border of the reduced system (sk_options_set_cholesky_border, AUTO: the chain
             # model's choice), and beside it the same problem in the band's own order (border off)
             record("revisits", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 10, 2, local_rank, stream, rank, world, dist_mod, torch, revisits=REVISITS))
+            # ... and the headline's problem with EVERY point eliminated (sk_options_set_retained_points(o, OFF): the plan of rounds 1-3)
+            record("all_points_eliminated", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 10, 2, local_rank, stream, rank, world, dist_mod, torch, retained="off"))
             record("revisits_plain_order", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 6, 2, local_rank, stream, rank, world, dist_mod, torch,
                                                               revisits=REVISITS, border="off"))
         if not args.no_c5:

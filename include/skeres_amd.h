@@ -385,7 +385,7 @@ int sk_options_set_cholesky_border(sk_options* o, int mode);
  * the widest tracks, as many as the model of the factorisation's serial chain says pay, when it predicts 10 % less than
  * eliminating everything; ON: the best count whatever the model says (tests, small problems); OFF: every point is eliminated.
  * max_points: at most this many — with ON: exactly this many, as far as there are tracks wider than a block — (a multiple of three is
- * used; 0: the library's limit, 768).  Not with the SEGMENTED distribution
+ * used; 0: the library's limit, 1536).  Not with the SEGMENTED distribution
  * of several ranks.  sk_solver_stat: "retained_points", "retained_model_us", "retained_model_us_without". */
 enum { SK_RETAINED_AUTO = 0, SK_RETAINED_ON = 1, SK_RETAINED_OFF = 2 };
 int sk_options_set_retained_points(sk_options* o, int mode, int max_points);

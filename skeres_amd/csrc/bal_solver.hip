@@ -903,22 +903,31 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
   for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); cnt[opt[b]]++; }
   std::vector<int> wide;
   for (int q = 0; q < P; ++q) if (cnt[q] >= 2 && 9 * (cmax[q] - cmin[q]) >= 128) wide.push_back(q);
-  std::sort(wide.begin(), wide.end(), [&](int a, int b) { const int sa = cmax[a] - cmin[a], sb = cmax[b] - cmin[b]; return sa != sb ? sa > sb : a < b; });
   const bool exactly = mode == SK_RETAINED_ON && max_points > 0;  // (ON with a count: that many, as far as there are candidates)
-  if (max_points <= 0) max_points = 768;
+  if (max_points <= 0) max_points = 1536;
   max_points = std::min(max_points - max_points % 3, (int)wide.size() - (int)wide.size() % 3);
   double best = mode == SK_RETAINED_ON ? std::numeric_limits<double>::max() : 0.9 * base_us;
-  int worse = 0;
-  for (int R = exactly ? std::max(3, max_points) : 3; R <= max_points && worse < 2; R = R < 6 ? 6 : 2 * R) {
-    std::vector<int> pts(wide.begin(), wide.begin() + R);
-    // pseudo-cameras in the order the border wants them: the points reached first come last
-    std::sort(pts.begin(), pts.end(), [&](int a, int b) { return cmin[a] != cmin[b] ? cmin[a] > cmin[b] : a < b; });
-    const RetainedGraphs rg = retained_graphs(ocam, opt, C, P, pts);
-    const int nblk = (9 * rg.Cx + 1 + 127) / 128;
-    BorderChoice bc;
-    if (!choose_border(rg.g(C, P), rg.x(), nblk, {}, SK_BORDER_AUTO, gaps_ok, &bc)) continue;
-    if (bc.model_us < best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; worse = 0; }
-    else ++worse;
+  // Two orders of the candidates: by the span of their cameras (whatever widens the envelope: landmarks AND the tracks of loop
+  // closures, which a border of retained points can take as well as a border of cameras can), and by the number of their
+  // observations (the landmarks alone — the loop closures are then left to the border of cameras, when the problem has both)
+  for (int by_count = 0; by_count < (exactly ? 1 : 2); ++by_count) {
+    std::sort(wide.begin(), wide.end(), [&](int a, int b) {
+      const int sa = by_count ? cnt[a] : cmax[a] - cmin[a], sb = by_count ? cnt[b] : cmax[b] - cmin[b];
+      return sa != sb ? sa > sb : a < b;
+    });
+    double best_here = std::numeric_limits<double>::max();
+    for (int R = exactly ? std::max(3, max_points) : 3; R <= max_points; R = R < 6 ? 6 : 2 * R) {
+      std::vector<int> pts(wide.begin(), wide.begin() + R);
+      // pseudo-cameras in the order the border wants them: the points reached first come last
+      std::sort(pts.begin(), pts.end(), [&](int a, int b) { return cmin[a] != cmin[b] ? cmin[a] > cmin[b] : a < b; });
+      const RetainedGraphs rg = retained_graphs(ocam, opt, C, P, pts);
+      const int nblk = (9 * rg.Cx + 1 + 127) / 128;
+      BorderChoice bc;
+      if (!choose_border(rg.g(C, P), rg.x(), nblk, {}, SK_BORDER_AUTO, gaps_ok, &bc)) continue;
+      if (bc.model_us < best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; }
+      if (bc.model_us > 1.5 * best_here) break;  // (well past the best count of this order: more border rows only cost)
+      best_here = std::min(best_here, bc.model_us);
+    }
   }
   return out;
 }
