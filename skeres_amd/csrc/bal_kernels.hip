@@ -590,30 +590,28 @@ __global__ __launch_bounds__(kBlock) void bal_point_block_kernel(BalDev d) {
   if (!(l00 > 0.0) || !(l11 > 0.0) || !(l22 > 0.0)) *d.fail_flag = 1;  // not positive definite
 }
 
-// Retained points (BalDev::kept_pt): one wave per point.  Its rows of the reduced system —
+// Retained points (BalDev::kept_pt).  Their rows of the reduced system —
 //   block (pseudo-camera, camera c of observation o) rows 3 t + a:  (E_o^T F_o)[a][.]      (9 x 3 per observation, transposed into place)
 //   diagonal block, rows / columns 3 t ..:                          T = sum E^T E + D_p^2  (lower triangle)
 //   right-hand side, entries 3 t ..:                                g_p
-// — and M = 0, q = 0, so that what bal_obs_precompute forms for its observations is What = 0, rt = r: nothing of the point enters the
-// Schur complement, and its cameras' own blocks and right-hand sides take F^T F and F^T r as they stand (bal_cam_diag_kernel).
-// Every block has one writer (a camera sees a point once: setup() refuses two residual blocks on one pair).
-__global__ __launch_bounds__(kBlock) void bal_kept_points_kernel(BalDev d) {
-  const int k = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (k >= d.num_kept) return;  // wave-uniform
-  const int p = d.kept_pt[k], ic = d.kept_cam[k] / 3, t3 = 3 * (d.kept_cam[k] % 3);
+// — and M = 0, q = 0, so that what bal_obs_precompute forms for their observations is What = 0, rt = r: nothing of such a point enters
+// the Schur complement, and its cameras' own blocks and right-hand sides take F^T F and F^T r as they stand (bal_cam_diag_kernel).
+// One launch, two kinds of workgroup: the first `obs_blocks` take a lane per observation of a retained point (kept_obs: a landmark
+// seen from 392 cameras is seven waves' worth, not one wave's seven turns) and write the off-diagonal blocks; the others a wave per
+// point for T, g, M and q.  Every block has one writer (a camera sees a point once: setup() refuses two residual blocks on one pair).
+__global__ __launch_bounds__(kBlock) void bal_kept_points_kernel(BalDev d, int obs_blocks) {
   const size_t N = d.N, P = d.P;
-  double t00 = 0, t10 = 0, t11 = 0, t20 = 0, t21 = 0, t22 = 0;
-  for (int o = d.pt_start[p] + lane; o < d.pt_start[p + 1]; o += 64) {
-    double e[2][3];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int a = 0; a < 3; ++a) e[r][a] = d.E[(size_t)(3 * r + a) * N + o];
-    t00 += e[0][0] * e[0][0] + e[1][0] * e[1][0]; t10 += e[0][1] * e[0][0] + e[1][1] * e[1][0]; t11 += e[0][1] * e[0][1] + e[1][1] * e[1][1];
-    t20 += e[0][2] * e[0][0] + e[1][2] * e[1][0]; t21 += e[0][2] * e[0][1] + e[1][2] * e[1][1]; t22 += e[0][2] * e[0][2] + e[1][2] * e[1][2];
+  if ((int)blockIdx.x < obs_blocks) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= d.num_kept_obs) return;
+    const int o = d.kept_obs[e], k = d.kept_obs_slot[e];
+    const int ic = d.kept_cam[k] / 3, t3 = 3 * (d.kept_cam[k] % 3);
     const int c = d.cam[o];
     const bool below = ic > c;  // the pseudo-camera's rows are below camera c's (else: a border camera that is numbered behind it)
-    if (!d.front[bal_part(d, below ? c : ic)].S) continue;  // (another rank's front)
+    if (!d.front[bal_part(d, below ? c : ic)].S) return;  // (another rank's front)
+    double ea[3], eb[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ea[a] = d.E[(size_t)a * N + o]; eb[a] = d.E[(size_t)(3 + a) * N + o]; }
     int ld;
     double* blk = below ? bal_block(d, ic, c, &ld) : bal_block(d, c, ic, &ld);
 #pragma unroll
@@ -621,10 +619,21 @@ __global__ __launch_bounds__(kBlock) void bal_kept_points_kernel(BalDev d) {
       const double f0 = d.F[(size_t)b * N + o], f1 = d.F[(size_t)(9 + b) * N + o];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const double v = e[0][a] * f0 + e[1][a] * f1;
+        const double v = ea[a] * f0 + eb[a] * f1;
         if (below) blk[(size_t)(t3 + a) * ld + b] = v; else blk[(size_t)b * ld + t3 + a] = v;
       }
     }
+    return;
+  }
+  const int k = (((int)blockIdx.x - obs_blocks) * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (k >= d.num_kept) return;  // wave-uniform
+  const int p = d.kept_pt[k], ic = d.kept_cam[k] / 3, t3 = 3 * (d.kept_cam[k] % 3);
+  double t00 = 0, t10 = 0, t11 = 0, t20 = 0, t21 = 0, t22 = 0;
+  for (int o = d.pt_start[p] + lane; o < d.pt_start[p + 1]; o += 64) {
+    const double a0 = d.E[o], a1 = d.E[N + o], a2 = d.E[2 * N + o];
+    const double b0 = d.E[3 * N + o], b1 = d.E[4 * N + o], b2 = d.E[5 * N + o];
+    t00 += a0 * a0 + b0 * b0; t10 += a1 * a0 + b1 * b0; t11 += a1 * a1 + b1 * b1;
+    t20 += a2 * a0 + b2 * b0; t21 += a2 * a1 + b2 * b1; t22 += a2 * a2 + b2 * b2;
   }
   t00 = wave_sum(t00); t10 = wave_sum(t10); t11 = wave_sum(t11); t20 = wave_sum(t20); t21 = wave_sum(t21); t22 = wave_sum(t22);
   if (lane != 0) return;
@@ -1118,7 +1127,11 @@ int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x
 }
 void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s) { hipLaunchKernelGGL(final_reduce_kernel, dim3(K), dim3(kBlock), 0, s, partial, stride, count, K, maxmask, out); }
 void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_point_block_kernel, dim3(point_grid(d.P)), dim3(kBlock), 0, s, d); }
-void launch_bal_kept_points(const BalDev& d, hipStream_t s) { if (d.num_kept > 0) hipLaunchKernelGGL(bal_kept_points_kernel, dim3((d.num_kept * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+void launch_bal_kept_points(const BalDev& d, hipStream_t s) {
+  if (d.num_kept <= 0) return;
+  const int obs_blocks = (d.num_kept_obs + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(bal_kept_points_kernel, dim3(obs_blocks + (d.num_kept * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d, obs_blocks);
+}
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
 void launch_bal_pair(const BalDev& d, hipStream_t s) {

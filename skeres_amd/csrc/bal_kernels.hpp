@@ -40,6 +40,7 @@ struct BalDev {
   // pseudo[i] != 0).  kept_pt[k]: the local point; kept_cam[k] = 3 * pseudo-camera + slot.  num_kept == 0 / pseudo == nullptr: none.
   int num_kept;
   const int* kept_pt;  const int* kept_cam;
+  int num_kept_obs;  const int* kept_obs;  const int* kept_obs_slot;  // the retained points' observations, and which retained point (index into kept_pt) each belongs to
   const unsigned char* pseudo;  // [C]
   // state
   double* xc;  double* xp;          // current parameters [9C], [3P]

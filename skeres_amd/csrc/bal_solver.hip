@@ -274,7 +274,8 @@ class BalSolver : public SolverBase {
   double retained_model_us_ = 0.0, retained_without_us_ = 0.0;
   std::vector<int> struct_ocam_, struct_opt_;   // the structure of the reduced system WITH pseudo-cameras (retained_graphs), final numbering; empty: ocam / opt as they are
   int struct_P_ = 0;
-  DevBuf<int> b_kept_pt_, b_kept_cam_;
+  DevBuf<int> b_kept_pt_, b_kept_cam_, b_kept_obs_, b_kept_obs_slot_;
+  int num_kept_obs_ = 0;
   DevBuf<unsigned char> b_pseudo_;
   int border_cams_ = 0, border_gap_ = 0;          // cameras in that border; the jump in a point's camera list that made a visit
   double border_model_us_ = 0.0, border_plain_us_ = 0.0;
@@ -1451,6 +1452,11 @@ int BalSolver::setup() {
     for (int i = 0; i < C_; ++i) pseudo[i] = cam_block_[i] < 0 ? 1 : 0;
     SK_HIP_TRY(b_pseudo_.upload(pseudo, s));
     SK_HIP_TRY(b_kept_pt_.upload(kept_pt, s)); SK_HIP_TRY(b_kept_cam_.upload(kept_cam, s));
+    std::vector<int> kept_obs, kept_obs_slot;
+    for (size_t k = 0; k < kept_pt.size(); ++k)
+      for (int o = pt_start[kept_pt[k]]; o < pt_start[kept_pt[k] + 1]; ++o) { kept_obs.push_back(o); kept_obs_slot.push_back((int)k); }
+    SK_HIP_TRY(b_kept_obs_.upload(kept_obs, s)); SK_HIP_TRY(b_kept_obs_slot_.upload(kept_obs_slot, s));
+    num_kept_obs_ = (int)kept_obs.size();
   }
   // ---- the fronts of the reduced camera system ----
   std::vector<int> border_row_h[2], leaf_map_h, leaf_gmap_h;
@@ -1554,6 +1560,7 @@ int BalSolver::setup() {
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
   d_.pseudo = pseudo_cams_ > 0 ? b_pseudo_.p : nullptr; d_.num_kept = pseudo_cams_ > 0 ? (int)kept_pt.size() : 0; d_.kept_pt = b_kept_pt_.p; d_.kept_cam = b_kept_cam_.p;
+  d_.num_kept_obs = pseudo_cams_ > 0 ? num_kept_obs_ : 0; d_.kept_obs = b_kept_obs_.p; d_.kept_obs_slot = b_kept_obs_slot_.p;
   d_.res_size = res_size_; d_.cam_size = cam_size_; d_.pt_size = pt_size_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p; d_.obs_slot = b_obs_slot_.p;
   d_.num_segments = (int)seg_row.size(); d_.seg_start = b_seg_start_.p; d_.seg_row = b_seg_row_.p; d_.seg_col = b_seg_col_.p;

@@ -1137,7 +1137,8 @@ constexpr int kBsMaxBlocks = 960;  // (two tables of that many entries + the oth
 struct BsTop { unsigned short top[kBsMaxBlocks]; unsigned short tail[kBsMaxBlocks]; };  // per block column: the last block row of its contiguous run (<= nblk - 1), and the first of its tail rows
 constexpr unsigned long long kBsSentinel = ~0ull;
 __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __restrict__ Linv, double* S, long ld, const double* rhs,
-                                                               int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb, int zero_after /* number of janitor workgroups */) {
+                                                               int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb, int zero_after /* number of janitor workgroups */,
+                                                               const int* __restrict__ yb_map /* border index -> index into yb (< 0: zero); nullptr: the border's own order */) {
   // nown < nblk: the interior of a LEAF FRONT (cholesky_backsolve_front): block columns [0, nown) have owners, the unknowns of
   // the block rows below them — the front's border — are known (yb, in the border's order: the separators' solution); the block
   // rows from env.tail[kb] on are active in block column kb whatever its run (the right-hand-side row; a spike: SegmentLayout; the
@@ -1208,7 +1209,9 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
   while (cur > kb) {
     if (g_bs_stamps_on && t == 0 && cur == kb + 1) g_bs_stamps[kb][0] = wall_clock64();
     if (t < 128 && cur >= nown) {
-      ysh[t] = yb[(long)(cur - nown) * 128 + t];  // a border row: known
+      const int bi = (cur - nown) * 128 + t;      // a border row: known
+      const int src = yb_map ? yb_map[bi] : bi;
+      ysh[t] = src >= 0 ? yb[src] : 0.0;
     } else if (t < 128) {
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(y + (long)cur * 128 + t);
       unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2317,7 +2320,7 @@ void cholesky_backsolve(double* S, long ld, int n, int npad, int rhs_row, const 
     if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
     const int janitors = zero_after ? bs_janitors(nblk) : 0;
     hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), n, y, nblk, env, info, nblk, (const double*)nullptr,
-                       janitors);
+                       janitors, (const int*)nullptr);
     if (kt) kt->end("backsolve", s);
     if (bs_stamps) {
       (void)hipStreamSynchronize(s);
@@ -2413,7 +2416,7 @@ void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f
 // Interior part of L^T y = z for a leaf front whose border unknowns are known.  yb: border unknowns (border_blocks * 128
 // values, zero where the border has padding or its right-hand-side row).  w: scratch (ncols * 128); y: interior solution.
 void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info, bool zero_after, const int* tail) {
+                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info, bool zero_after, const int* tail, const int* yb_map) {
   const int ni = ncols * 128, m = (nblk - ncols) * 128;
   if (ncols <= 0) return;
   if (info && g_bs_resident && nblk <= kBsMaxBlocks) {
@@ -2428,9 +2431,10 @@ void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_r
     }
     (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)ni, s);
     const int janitors = zero_after ? bs_janitors(ncols) : 0;
-    hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), ni, y, nblk, env, info, ncols, yb, janitors);
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), ni, y, nblk, env, info, ncols, yb, janitors, yb_map);
     return;
   }
+  // (yb_map is the resident launch's: a caller that passes one has checked cholesky_backsolve_resident and info)
   hipLaunchKernelGGL(copy_row_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, S + (long)rhs_row * ld, w, ni, ni);
   // block rows' first non-zero block columns (the border rows: from the first interior column that reaches the border)
   std::vector<int> first(nblk, 0);
@@ -2519,8 +2523,11 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
       (void)hipStreamWaitEvent(ctxB->fork, ctxB->fork_ev, 0);
       sB = ctxB->fork;
     }
-    cholesky_gather_map(yR, d.mapB, ybB, m, sB);
-    cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, ybB, wB, yB, sB, d.B.last, false, 1, info, zero_after, d.B.tail);
+    // (the resident launch reads the root's solution through the map itself: no gather launch in front of the tail's chain of hops)
+    const bool mapped = info && cholesky_backsolve_resident(d.B.nblk);
+    if (!mapped) cholesky_gather_map(yR, d.mapB, ybB, m, sB);
+    cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, mapped ? yR : ybB, wB, yB, sB, d.B.last, false, 1, info, zero_after, d.B.tail,
+                             mapped ? d.mapB : nullptr);
   }
   // (yR is zero in the root's padding rows and in its right-hand-side row: it serves as A's border unknowns as it stands)
   if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after, d.A.tail);

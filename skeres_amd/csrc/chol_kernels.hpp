@@ -243,7 +243,8 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
 void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s);
 // info != nullptr: one resident launch (the kernel of cholesky_backsolve; tail_rows as in cholesky_factor); nullptr: one launch per block step
 void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike = false, int tail_rows = 1, int* info = nullptr, bool zero_after = false, const int* tail = nullptr);
+                              hipStream_t s, const int* last, bool spike = false, int tail_rows = 1, int* info = nullptr, bool zero_after = false, const int* tail = nullptr,
+                              const int* yb_map = nullptr);  // yb_map (resident launch only): border index -> index into yb (< 0: zero) instead of a gathered copy
 void cholesky_gather_map(const double* src, const int* map, double* dst, int m, hipStream_t s);
 // --- multi-way dissection: R segments of a block-banded system with R - 1 separators between them ---
 // Leaf front of one segment, in scalar rows.  The interior is followed by a border:

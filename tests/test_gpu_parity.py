@@ -845,6 +845,7 @@ def test_bordered_dense_schur_vs_oracle(C, P, N, seed, revisits):
     options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
     options.setMaxNumIterations(6)  # (the oracle factors a 7200 x 7200 reduced system per iteration)
     options.setCholeskyBorder("on")
+    options.setRetainedPoints("off")  # (this test is about the border of CAMERAS: left to itself the library would retain the revisits' tracks as well)
     solver = sk.StepSolver(options, problem)
     nb = solver.stat("border_cameras")
     assert 1 <= nb <= sum(w for _, _, w, _ in revisits) and solver.stat("dissected") == 0
@@ -868,7 +869,7 @@ def test_bordered_dense_schur_vs_oracle(C, P, N, seed, revisits):
     for u, v in zip(summary.iterations()[:5], s_off.iterations()[:5]):
         assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
     # ... and with an explicit SYRK depth, launch by launch (no resident chain)
-    x_g, s_g = solve_bal_gpu(prob, setCholeskyBorder="on", setCholeskyTuning=2, setMaxNumIterations=6)
+    x_g, s_g = solve_bal_gpu(prob, setCholeskyBorder="on", setCholeskyTuning=2, setMaxNumIterations=6, setRetainedPoints="off")
     for u, v in zip(s_g.iterations()[:5], s_off.iterations()[:5]):
         assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
 
@@ -990,6 +991,8 @@ def test_border_at_full_size_matches_the_plain_order_and_the_oracle():
         options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
         options.setMaxNumIterations(2)
         options.setCholeskyBorder(border)
+        if border == "off":
+            options.setRetainedPoints("off")  # (the band's own order with every point eliminated: left to itself the library would retain the revisits' tracks)
         solver = sk.StepSolver(options, problem)
         stats = {k: solver.stat(k) for k in ("border_cameras", "envelope_fill", "cholesky_columns_resident", "dissected")}
         while not solver.step():
