@@ -106,6 +106,7 @@ public final class SkeresNative {
   public static native int skOptionsSetCholeskyEnvelope(long o, int v);
   public static native int skOptionsSetCholeskyDissection(long o, int v);
   public static native int skOptionsSetCholeskyBorder(long o, int v);
+  public static native int skOptionsSetRetainedPoints(long o, int mode, int maxPoints);
   public static native int skOptionsSetResidentKernels(long o, int v);
   public static native int skOptionsSetGraphReplay(long o, int v);
   public static native int skOptionsSetMaxSegments(long o, int v);

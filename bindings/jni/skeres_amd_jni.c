@@ -305,6 +305,7 @@ SK_OPT_INT(skOptionsSetResidentKernels, sk_options_set_resident_kernels)
 SK_OPT_INT(skOptionsSetGraphReplay, sk_options_set_graph_replay)
 SK_OPT_INT(skOptionsSetMaxSegments, sk_options_set_max_segments)
 SK_OPT_INT(skOptionsSetDistributionMode, sk_options_set_distribution_mode)
+SK_JNI(jint, skOptionsSetRetainedPoints)(JNIEnv* env, jclass c, jlong o, jint mode, jint max_points) { (void)c; return check(env, sk_options_set_retained_points(PTR(sk_options, o), mode, max_points)); }
 SK_JNI(jint, skOptionsSetCholeskyTuning)(JNIEnv* env, jclass c, jlong o, jint group, jint lookahead) { (void)c; return check(env, sk_options_set_cholesky_tuning(PTR(sk_options, o), group, lookahead)); }
 /* multi-GPU from the JVM: the library's own RCCL hook (no collective to write on the JVM side) */
 SK_JNI(jbyteArray, skRcclUniqueId)(JNIEnv* env, jclass c) {

@@ -1139,6 +1139,28 @@ int BalSolver::setup() {
     packed_elems_ = (size_t)pack_off[nblk];
     pack_col0_h_ = pack_col0; pack_off_h_ = pack_off;
   }
+  // the buffer the reduced system travels in (the caller's, or our own)
+  auto prepare_pack = [&]() -> int {
+    if (opt_.reduce_buffer) {
+      if (opt_.reduce_buffer_bytes < packed_elems_ * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", packed_elems_ * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
+      b_pack_.adopt(static_cast<double*>(opt_.reduce_buffer), packed_elems_);
+    } else {
+      SK_HIP_TRY(b_pack_.alloc(packed_elems_));
+    }
+    SK_HIP_TRY(b_pack_.zero(stream_));
+    return SK_OK;
+  };
+  // Retained points rule out the segmented distribution (their rows couple with every segment), so a world of ranks decides HERE
+  // between sharding the points and replicating the solve — before the dissection: a rank that replicates is a single device from
+  // here on (choose_distribution), and takes the lock-step dissection a single device takes
+  bool distribution_decided = false;
+  if (opt_.allreduce && opt_.world > 1 && pseudo_cams_ > 0) {
+    int rc = prepare_pack();
+    if (rc) return rc;
+    rc = choose_distribution(opt);
+    if (rc) return rc;
+    distribution_decided = true;
+  }
   {
     const int nblk = npad_ / 128;
     // ---- dissect?  One process: only when forced (measured not to pay on one chip).  Several ranks: the SEGMENTED
@@ -1274,16 +1296,11 @@ int BalSolver::setup() {
     for (int kb = 0; kb < E; ++kb) pack_off_h_[kb + 1] = pack_off_h_[kb] + (long long)128 * 128 * (kb + 1 - pack_col0_h_[kb]);
     packed_elems_ = (size_t)pack_off_h_[E];
   }
-  if (opt_.allreduce) {
-    if (opt_.reduce_buffer) {
-      if (opt_.reduce_buffer_bytes < packed_elems_ * sizeof(double)) { set_error("reduce buffer too small: need %zu bytes", packed_elems_ * sizeof(double)); return SK_ERR_INVALID_ARGUMENT; }
-      b_pack_.adopt(static_cast<double*>(opt_.reduce_buffer), packed_elems_);
-    } else {
-      SK_HIP_TRY(b_pack_.alloc(packed_elems_));
-    }
-    SK_HIP_TRY(b_pack_.zero(stream_));
+  if (opt_.allreduce && !distribution_decided) {
+    int rc = prepare_pack();
+    if (rc) return rc;
     if (!segmented_) {
-      int rc = choose_distribution(opt);
+      rc = choose_distribution(opt);
       if (rc) return rc;
     }
   }

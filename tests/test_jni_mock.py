@@ -143,6 +143,7 @@ def test_status_codes_become_java_exceptions(jni):
     cls, msg = jni.exception()
     assert cls == "java/lang/RuntimeException" and "not implemented" in msg  # (SK_ERR_UNSUPPORTED)
     assert jni.call("skOptionsSetCholeskyBorder", o, 1, restype=C.c_int) == 0 and jni.call("skOptionsSetCholeskyBorder", o, 5, restype=C.c_int) != 0
+    assert jni.call("skOptionsSetRetainedPoints", o, 1, 12, restype=C.c_int) == 0 and jni.call("skOptionsSetRetainedPoints", o, 7, 0, restype=C.c_int) != 0
     assert jni.exception()[0] == "java/lang/IllegalArgumentException"
     # an unknown device functor: a NULL handle and an exception
     assert jni.call("skCostFunctionNewAutodiff", 12345, jni.array(K_DOUBLE, [1.0])) == 0
