@@ -603,11 +603,12 @@ int sk_options_set_retained_points(sk_options* o, int mode, int max_points) {
 }
 int sk_options_set_reduce_buffer(sk_options* o, void* ptr, size_t bytes) { o->o.reduce_buffer = ptr; o->o.reduce_buffer_bytes = bytes; return SK_OK; }
 size_t sk_reduce_buffer_bytes(const sk_options* o, const sk_problem* p) {
-  (void)o;
   // cameras = distinct blocks in parameter slot 0 of the residual blocks
   const Problem& P = p->p;
   std::vector<char> seen(P.block_size.size(), 0); size_t C = 0;
   for (size_t b = 0; b < P.rb_functor.size(); ++b) { const int c = P.rb_pidx[P.rb_pidx_off[b]]; if (!seen[c]) { seen[c] = 1; ++C; } }
+  // (+ the pseudo-cameras of retained points, three points each: as many as the options allow — sk_options_set_retained_points)
+  if (!o || o->o.retained != SK_RETAINED_OFF) C += (size_t)((o && o->o.retained_max > 0 ? o->o.retained_max : 1536) + 2) / 3;
   const size_t n = 9 * C, npad = ((n + 1 + 127) / 128) * 128;
   return tri_packed_elems((int)(npad / 128)) * sizeof(double);  // lower block triangle, packed
 }

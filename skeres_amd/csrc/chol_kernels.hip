@@ -2097,6 +2097,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     for (hipStream_t q : {sp, ctx->bulk, ctx->bulk_early}) if (q != s) (void)hipStreamWaitEvent(q, start_ev, 0);
   }
   if (!is_resident(0) && ncols > 0) panel(gb[0], gb[1]);
+  bool used_bulk_early = false;
   hipEvent_t syrk_done = nullptr;  // syrk(g-1), which writes the tiles next(g) updates
   hipEvent_t syrk_any = nullptr, syrk_done2 = nullptr;  // the completion of the last SYRK launched (whenever it carries an event), and of the one before it
   int seq = 0;                     // SYRK completions announced to the chain so far (chain_marker_kernel)
@@ -2127,6 +2128,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     const double* P = S + (long)k1 * 128 * ld + (long)k0 * 128;
     const int Tb = rs.main + rs.extra;
     if (la) sb = Tb >= ctx->early_tiles ? ctx->bulk_early : ctx->bulk;
+    if (la && Tb > 0 && sb == ctx->bulk_early) used_bulk_early = true;
     if (sb != sb_prev && syrk_done) (void)hipStreamWaitEvent(sb, syrk_done, 0);  // syrk(g) after syrk(g-1) across the two bulk streams
     sb_prev = sb;
     if (resident && pair) {
@@ -2280,7 +2282,9 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     partner_advance(st, ctx->bulk);
   }
   order(sp, s);
-  if (la) { order(ctx->bulk, s); order(ctx->bulk_early, s); }
+  // (a factorisation of chain-bound block columns never touches the stream of the wide SYRKs: one cross-queue dependency less in
+  // front of whatever follows — each is a packet of its own, ~10 us)
+  if (la) { order(ctx->bulk, s); if (used_bulk_early) order(ctx->bulk_early, s); }
   if (chain) order(srv, s);
   if (stamps_file) {
     (void)hipStreamSynchronize(s);
