@@ -674,8 +674,11 @@ def main():
             record("revisits", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 10, 2, local_rank, stream, rank, world, dist_mod, torch, revisits=REVISITS))
             # ... and the headline's problem with EVERY point eliminated (sk_options_set_retained_points(o, OFF): the plan of rounds 1-3)
             record("all_points_eliminated", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 10, 2, local_rank, stream, rank, world, dist_mod, torch, retained="off"))
+            # (border off, retained points AUTO: a border of POINTS — the revisits' tracks among them — instead of cameras)
+            record("revisits_retained_points_only", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 6, 2, local_rank, stream, rank, world, dist_mod, torch,
+                                                                       revisits=REVISITS, border="off"))
             record("revisits_plain_order", lambda: bal_record(sk, bal, "ladybug-1723-156502", SEED, 6, 2, local_rank, stream, rank, world, dist_mod, torch,
-                                                              revisits=REVISITS, border="off"))
+                                                              revisits=REVISITS, border="off", retained="off"))
         if not args.no_c5:
             record("c5", lambda: c5_record(sk, rank=rank, world=world, stream=stream, torch=torch, dist_mod=dist_mod))
     if timer:

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""scratch: Ladybug (or a smaller band) three iterations under several plans; costs side by side"""
+"""Developer tool: the first three LM steps of Ladybug-1723 (or of `C,P,N,seed`) under elimination orders that are equal in exact
+arithmetic — every point eliminated / twelve retained, one front / three — and how far their costs are apart (profiles/r04_elimination_order_rounding.txt)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

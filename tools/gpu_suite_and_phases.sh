@@ -1,5 +1,6 @@
 #!/bin/bash
-# scratch: the whole GPU suite (all failures listed), then the phase times
+# Developer tool: the whole GPU suite (every failure listed) and the phase times of the two big problems, in one gpurun call:
+#   gpurun --timeout 1200 -- "bash tools/gpu_suite_and_phases.sh <tag>"
 set -o pipefail
 tag=${1:-r5e}
 timeout -k 10 1100 python -m pytest tests -q -m gpu > gpurun_out/${tag}_tests.log 2>&1; rc=$?
