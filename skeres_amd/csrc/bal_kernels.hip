@@ -776,6 +776,10 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
 // 16-byte LDS broadcasts per entry where there were fourteen 16-byte global loads per lane (the texture path was the
 // limit: 17 load instructions per wave and entry group; 2.79 -> 2.12 ms on Venice-1778, 361 -> 264 us on Ladybug-1723).  The data of the next entry and the indices
 // of the one after it are in flight while the current one is multiplied.
+// (Round 4 tried fetching a record by LINE — lanes 0..7 of a group the eight 16-byte chunks of its first 128-byte line, lanes 0..5 the
+// six of its second, one line per group and load instruction instead of two, the row record through LDS as well: half the line
+// accesses of the texture path, the same bits — and the Schur assembly got SLOWER, 0.38 -> 0.43 ms on Ladybug-1723, 2.43 -> 2.70 on
+// Venice-1778: two more LDS writes and three reads per entry cost more than the line accesses saved.)
 constexpr int kPairSlot = 34;  // doubles per nine-lane group: 272 bytes, so that the seven groups' 16-byte reads fall on disjoint banks
 __device__ __forceinline__ void pair_accumulate(const BalDev& d, int e_begin, int e_end, int stride, int c, double* slot, double (&acc)[9]) {
   if (e_begin >= e_end) return;
