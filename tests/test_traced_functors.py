@@ -344,19 +344,24 @@ def _pinhole_problem(prob, residuals=2, host_every=0):
 
 
 @gpu
-@pytest.mark.parametrize("host_every", [0, 4])
-def test_dense_schur_on_a_smaller_block_shape_vs_oracle(host_every):
+@pytest.mark.parametrize("host_every,retained", [(0, 0), (4, 0), (0, 6), (4, 6)])
+def test_dense_schur_on_a_smaller_block_shape_vs_oracle(host_every, retained):
     """DENSE_SCHUR on a block shape other than the reference's (2; 9, 3) — round 4: until then such a problem went to the DENSE_QR
     alternate.  A pinhole camera of six parameters (intrinsics captured by the closure) and 3-D points, (2; 6, 3), as a recorded
     functor (and, host_every = 4, with every fourth block through the director path): the kernels run it padded to (2; 9, 3)
     with three inert coordinates per camera.  The oracle's Schur path solves the SAME problem as SnavelyReprojectionError with
-    the cameras' intrinsics held constant (cam_mask): per-iteration cost at 1e-10, the parameters it moved."""
+    the cameras' intrinsics held constant (cam_mask): per-iteration cost at 1e-10, the parameters it moved.  retained = 6: the six
+    widest tracks are not eliminated (sk_options_set_retained_points) — their rows of the reduced system are formed from the planes
+    the recorded functor and the director path wrote, as any other point's."""
     import oracle
     C, P, N = 16, 200, 900
     prob = bal.generate(C, P, N, seed=23)
     problem, params, keep = _pinhole_problem(prob, host_every=host_every)
     options = sk.Solver.Options()
     options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    if retained:
+        assert problem.retainedPlan("on", retained)["retained_points"] == retained
+        options.setRetainedPoints("on", retained)
     summary = sk.Solver.Summary()
     sk.ceres.solve(options, problem, summary)
     assert summary.linearSolverTypeUsed() == sk.LinearSolverType.DENSE_SCHUR  # (not the alternate)
