@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I skeres_amd/csrc tools/potrf_probe.hip -o gpurun_out/potrf_probe
 #define SK_POTRF_STAMPS 1
 #include "../skeres_amd/csrc/chol_kernels.hip"
+namespace sk { const DevKnobs& dev_knobs() { static DevKnobs k; return k; } }
 
 #include <cmath>
 #include <cstdio>
