@@ -125,11 +125,14 @@ int main(int argc, char** argv) {
       return st;
     };
     hipStream_t bulk4 = masked_stream(4, ncu / 8), bulk2 = masked_stream(2, ncu / 8), bulk8 = masked_stream(8, ncu / 8), panel_rest = masked_stream(1, ncu / 8), panel4 = masked_stream(1, 4), panel8 = masked_stream(1, 8);
-    hipStream_t plain = nullptr;
+    hipStream_t plain = nullptr, plain2 = nullptr;
     (void)hipStreamCreateWithFlags(&plain, hipStreamNonBlocking);
+    (void)hipStreamCreateWithFlags(&plain2, hipStreamNonBlocking);
     int* sink = nullptr;
     (void)hipMalloc(&sink, 4);
-    struct Cond { const char* name; hipStream_t syrk; hipStream_t squat; int nsquat; };
+    // ... and beside REAL panel work: the thin-tile update a column launch does (gemm_update_thin_f64_kernel over `nwork` 32 x 128 tiles,
+    // K = 128, s_setprio 2) on the panel stream, twice per SYRK as TRSM + next(j) are
+    struct Cond { const char* name; hipStream_t syrk; hipStream_t squat; int nsquat; int nwork = 0; };
     const Cond conds[] = {
         {"plain stream, alone", plain, nullptr, 0},
         {"off 4 CUs per XCD, alone", bulk4, nullptr, 0},
@@ -138,6 +141,9 @@ int main(int argc, char** argv) {
         {"off 4 CUs per XCD, 56 waiting workgroups anywhere but CU 0", bulk4, panel_rest, 56},
         {"off 4 CUs per XCD, 112 waiting workgroups on CUs 1-3 only", bulk4, panel4, 112},
         {"off 8 CUs per XCD, 112 waiting workgroups on CUs 1-7 only", bulk8, panel8, 112},
+        {"off 4 CUs per XCD, 2 x 160 thin update tiles anywhere but CU 0", bulk4, panel_rest, 0, 160},
+        {"off 4 CUs per XCD, 2 x 160 thin update tiles on CUs 1-3 only", bulk4, panel4, 0, 160},
+        {"plain stream, 2 x 160 thin update tiles on another plain stream", plain, plain2, 0, 160},
     };
     const Variant& v = variants[0];
     for (int T : {14, 20, 28}) {
@@ -155,6 +161,13 @@ int main(int argc, char** argv) {
           (void)hipEventRecord(e0, c.syrk);
           for (int i = 0; i < per; ++i) {
             if (c.nsquat) hipLaunchKernelGGL(squat_kernel, dim3(c.nsquat), dim3(256), 0, c.squat, (long long)4000, sink);  // 40 us of the 100 MHz clock
+            if (c.nwork) {  // (rows far below the SYRK's: no overlap of the data)
+              // 40 tile rows (block rows 36..45 of the 48) x nwork / 40 tile columns: inside the allocation
+              double* Cw = S + (size_t)36 * 128 * ld + (size_t)1 * 128;
+              const double* Aw = S + (size_t)36 * 128 * ld;
+              for (int rep = 0; rep < 2; ++rep)
+                hipLaunchKernelGGL(sk::gemm_update_thin_f64_kernel, dim3(c.nwork), dim3(256), 0, c.squat, Cw, ld, Aw, ld, Aw, ld, 128, 40, 0, 0x7fffffff, 0);
+            }
             hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, c.syrk, C, ld, A, ld, K, T * 4);
           }
           (void)hipEventRecord(e1, c.syrk);
