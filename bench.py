@@ -571,7 +571,12 @@ def main():
                          "note": "achieved/frac: live, inside the timed region, where the SYRK shares the chip with the look-ahead "
                                  "panel chain (masked off 16-32 CUs) and most launches are a few dozen tile rows (a sparse envelope); "
                                  "*_alone: same kernel, look-ahead off, 3 untimed steps; "
-                                 "flops_per_solve counts the blocks inside the envelope only"},
+                                 "flops_per_solve counts the blocks inside the envelope only.  With retained points (config.retained_points) "
+                                 "the factorisation has a fifth of the flops and every block column is bound by the serial panel chain: the "
+                                 "SYRK launches that are left are ~60 per iteration of ~20 us (a few hundred 32 x 128 tiles, K = 128) and no "
+                                 "longer where the time goes — by time the dominant kernel is the resident potrf server, which is latency-bound; "
+                                 "the record all_points_eliminated holds the SYRK-bound plan of rounds 1-3 (its launches at 0.44 of the peak: "
+                                 "profiles/r04_c_bench.json), roofline_full the dense case (0.57)"},
             "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(PHASE_NAMES)},
         }
         line["roofline_phases_hbm"] = phase_rooflines(line["phases_ms_per_step"], prob.num_observations if world == 1 else prob.num_observations / world,
