@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
         {"plain stream, 2 x 160 thin update tiles on another plain stream", plain, plain2, 0, 160},
     };
     const Variant& v = variants[0];
-    for (int T : {14, 20, 28}) {
+    for (int T : {14, 19, 20, 28}) {
       const int K = 128, c0 = 2;
       double* C = S + (size_t)c0 * 128 * ld + (size_t)c0 * 128;
       const double* A = S + (size_t)c0 * 128 * ld + (size_t)(c0 * 128 - K);
