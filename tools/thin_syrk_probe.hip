@@ -182,5 +182,35 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // ---- cold caches: in the factorisation a SYRK's C tiles were last written by the SYRK of the step before — other workgroups, other
+  // XCDs (the grid shrinks from step to step) — and its panel by a column launch; here every launch is preceded by a pass over 1 GB
+  // that evicts the L2s and the Infinity Cache, and timed by its own start / stop events
+  {
+    hipEvent_t es[40];
+    for (auto& e : es) (void)hipEventCreate(&e);
+    double* trash = nullptr;
+    const size_t trash_n = (size_t)1 << 27;  // 1 GB
+    if (hipMalloc(&trash, trash_n * 8) == hipSuccess) {
+      const Variant& v = variants[0];
+      for (int T : {14, 19, 28}) {
+        const int K = 128, c0 = 2;
+        double* C = S + (size_t)c0 * 128 * ld + (size_t)c0 * 128;
+        const double* A = S + (size_t)c0 * 128 * ld + (size_t)(c0 * 128 - K);
+        const int nb = T * (T + 1) / 2, grid = nb * 4;
+        const double flops = (double)nb * 2.0 * 128 * 128 * K;
+        for (int cold = 0; cold < 2; ++cold) {
+          float sum = 0.f;
+          for (int i = 0; i < 20; ++i) {
+            if (cold) (void)hipMemsetAsync(trash, i, trash_n * 8, 0);
+            hipExtLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, 0, es[2 * i], es[2 * i + 1], 0, C, ld, A, ld, K, T * 4);
+          }
+          (void)hipDeviceSynchronize();
+          for (int i = 0; i < 20; ++i) { float ms; (void)hipEventElapsedTime(&ms, es[2 * i], es[2 * i + 1]); sum += ms; }
+          printf("T = %2d, %s: %7.1f us per launch (own events), %5.1f TFLOP/s\n", T, cold ? "after a 1 GB memset (cold L2 and Infinity Cache)" : "back to back (warm)                            ",
+                 sum / 20 * 1e3, flops / (sum / 20 * 1e-3) * 1e-12);
+        }
+      }
+    }
+  }
   return 0;
 }
