@@ -1033,6 +1033,11 @@ int BalSolver::setup() {
     (void)hipGetLastError();
     opt_.lookahead = false;
   }
+  // The device's queue trial (once per device) BEFORE the plans below are chosen: on a device that cannot run the resident panel chain —
+  // shared with another process, its kernels serialised — the trial says so, and the lock-step dissection, which exists for that chain,
+  // is then not chosen (until round 4 the trial ran after the layout was fixed: two processes sharing one device took the dissected plan
+  // launch by launch, 1.9 s per iteration where the undissected one takes 0.2)
+  if (opt_.lookahead) cholesky_prepare(&chol_ctx_, stream_);
   if (opt_.allreduce && opt_.world > 1) {
     // the ranks must factor by ONE plan and take ONE distribution decision: a rank without CU-masked streams (no
     // look-ahead, hence no resident chain and no dissection) takes every rank there
