@@ -600,8 +600,18 @@ def main():
                 k = k if model_us.get(k, 0.0) > 0.0 else 1
                 # (ranks beyond the segments are replicas of one: the point work shards by segment, not by rank)
                 pred[str(n_dev)] = {"ms_per_step": ph["cholesky"] * model_us[k] / model_one + shard / k, "segments": k}
+            note = "chain model, calibrated on this run's Cholesky phase; no scaling curve has been measured on hardware"
+            if headline_stats.get("retained_points", 0) > 0:
+                # with retained points a world of ranks cannot segment the camera sequence (the points' rows couple with every segment): it
+                # shards the points or replicates, and on this problem the all-reduce of the envelope costs more than sharding saves
+                envelope_mb = plan["allreduce_bytes"] / 1e6
+                pred = {str(n): {"ms_per_step": line["ms_per_step"], "plan": "replicated"} for n in (2, 4, 8)}
+                note = ("with retained points a world of ranks shards the points or replicates (no segmented distribution): sharding saves %.2f ms x (1 - 1 / N) "
+                        "of this iteration and adds an all-reduce of %.0f MB, so AUTO is expected to replicate — every rank runs this run's one-device plan, "
+                        "speed-up 1; model_us_per_segments is the segmented plan WITHOUT retained points, for comparison; no scaling curve has been measured "
+                        "on hardware" % (shard, envelope_mb))
             line["predicted_multi_gpu"] = {"model_us_per_segments": {str(k): v for k, v in model_us.items() if v > 0.0}, "model_us_this_run": model_one, "per_n_gpus": pred,
-                                           "note": "chain model, calibrated on this run's Cholesky phase; no scaling curve has been measured on hardware"}
+                                           "note": note}
         # The whole Cholesky phase (factorisation + triangular solves, every kernel of it) against the MFMA peak.  The
         # timed region factors the blocks inside the envelope (cholesky_flops_plan); the structure-independent figure
         # is the FULL factorisation — SURVEY.md section 8(d)'s n^3 / 3 over the measured Cholesky phase of the side run
@@ -623,6 +633,13 @@ def main():
                 "frac": f_full / full_chol_s * 1e-12 / FP64_MFMA_PEAK_TFLOPS,
                 "note": "every 128-block factored (sk_options_set_cholesky_envelope(o, 0)): (9C)^3 / 3 flops over the measured Cholesky "
                         "phase, 3 untimed steps — what the iteration costs when the camera graph has no band to exploit"}
+        if world > 1 and dist_mode == "replicated":
+            # The solver measured that sharding this problem costs more than it saves, and every rank solved the WHOLE problem with no
+            # collective in the timed region: `value` above counts those K iterations once (strong scaling, speed-up 1).  What the same
+            # timed region also is: N complete, independent solves, one per GPU — the throughput a caller with N problems gets (weak
+            # scaling without a collective).  Reported beside the headline, never in its place.
+            line["independent_solves"] = {"value": world * args.steps / elapsed, "unit": "LM iterations/s over %d independent solves" % world, "scaling": "weak",
+                                          "note": "the timed region of this run: each of the %d ranks completed its own solve of the whole problem, no collective" % world}
         if args.cpu_iters > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, envelope=not args.full_factorisation, full_iters=args.cpu_full_iters)
         elif world == 1:
