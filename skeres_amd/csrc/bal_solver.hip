@@ -271,6 +271,7 @@ class BalSolver : public SolverBase {
   // pseudo-camera (final numbering) and the slot in it of retained point k.
   std::vector<int> retained_pts_, retained_cam_;
   int pseudo_cams_ = 0;
+  int border_members_ = 0;  // cameras and pseudo-cameras ordered behind the band (the bordered envelope's border; one device, dissected: the end of the separator)
   double retained_model_us_ = 0.0, retained_without_us_ = 0.0;
   std::vector<int> struct_ocam_, struct_opt_;   // the structure of the reduced system WITH pseudo-cameras (retained_graphs), final numbering; empty: ocam / opt as they are
   int struct_P_ = 0;
@@ -402,8 +403,12 @@ static double column_cost_us(int h, bool resident_capable) {
 // trailing run of chain-bound columns (CholeskyPartner), so a paired step costs the dearer of its two columns and the head's
 // block columns before that run are not shortened at all.
 // extra_sep: cameras that join the separator whatever the cut (the pseudo-cameras of retained points, which every camera may couple with)
+// extra_fwd (optional, per block column of the band): border block rows that are active in that column on top of its run — the tail
+// profile of the bordered envelope — when the head is eliminated front to back; extra_bwd: the same for the tail front, for which the
+// profile is not known (its columns reach the border's rows in another order): all of them.
 static Dissection choose_dissection(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
-                                    const std::vector<int>& first_col, bool tail_resident, bool lockstep = false, int extra_sep = 0) {
+                                    const std::vector<int>& first_col, bool tail_resident, bool lockstep = false, int extra_sep = 0,
+                                    const std::vector<int>* extra_fwd = nullptr, int extra_bwd = 0) {
   Dissection d;
   if (C < 64 || nblk < 24) return d;
   // reach[c]: the last camera that shares a point with any camera <= c (cameras in the chosen order)
@@ -418,10 +423,10 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
   std::vector<int> fc(first_col);
   for (int i = nblk - 2; i >= 0; --i) fc[i] = std::min(fc[i], fc[i + 1] < i + 1 ? fc[i + 1] : i);  // (monotone, as the backward envelope is)
   for (int c = 0; c < nblk; ++c) {
-    const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0);
+    const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0) + (extra_fwd && c < (int)extra_fwd->size() ? (*extra_fwd)[c] : 0);
     height[c] = hf;
     fwd[c] = column_cost_us(hf, true);
-    bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1, tail_resident);
+    bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1 + extra_bwd, tail_resident);
     d.t_plain += fwd[c];
   }
   for (int c = 0; c < nblk; ++c) { fwd_sum[c + 1] = fwd_sum[c] + fwd[c]; bwd_sum[c + 1] = bwd_sum[c] + bwd[c]; }
@@ -1171,12 +1176,16 @@ int BalSolver::setup() {
     // ---- dissect?  One process: only when forced (measured not to pay on one chip).  Several ranks: the SEGMENTED
     // distribution — every rank's device eliminates one segment of the camera sequence — when the model of the chains
     // predicts a gain (or when asked for). ----
-    // (a border of loop-closure cameras is not dissected; a border of pseudo-cameras alone is: on one device they join the separator,
-    // which both fronts border on — the band of real cameras is what is cut)
-    const bool pseudo_border = pseudo_cams_ > 0 && border_cams_ == 0;
-    const int Cband = C_ - (pseudo_border ? pseudo_cams_ : 0);
-    const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0 && (env_tail_.empty() || pseudo_border);
+    // (one device: a border — the cameras of loop closures, the pseudo-cameras of retained points — joins the ONE separator, which both
+    // fronts border on, and the band in front of it is what is cut; several ranks: a bordered system is not dissected)
     const bool multi = opt_.allreduce != nullptr && opt_.world >= 2;
+    border_members_ = env_tail_.empty() ? 0 : border_cams_ + pseudo_cams_;
+    // (a border of loop-closure cameras alone — every point eliminated — is left undissected, as until round 4: the band then keeps its
+    // SYRK-bound block columns, which the lock-step cannot pair and the border's rows make dearer; measured on Ladybug-1723 with three
+    // places revisited: 8.1-9.2 ms of Cholesky phase for three cuts against 8.2 undissected)
+    const bool pseudo_border = border_members_ > 0 && !multi && pseudo_cams_ > 0;
+    const int Cband = C_ - (pseudo_border ? border_members_ : 0);
+    const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0 && (env_tail_.empty() || pseudo_border);
     bool may_dissect = plan_ok && (multi ? (pseudo_cams_ == 0 && (opt_.distribution_mode == SK_DISTRIBUTION_AUTO || opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED))
                                          : (!opt_.allreduce && chol_ctx_b_.init_secondary(chol_ctx_) == hipSuccess));
     if (!may_dissect) (void)hipGetLastError();
@@ -1197,9 +1206,16 @@ int BalSolver::setup() {
     } else if (may_dissect) {
       Dissection ds;
       std::vector<int> first_col;
-      // what is cut: the cameras' band — with retained points, the band of the real cameras under the points that are eliminated
-      const std::vector<int>& docam = pseudo_border ? band_ocam : ocam;
-      const std::vector<int>& dopt = pseudo_border ? band_opt : opt;
+      // what is cut: the cameras' band — with a border, the band cameras under the points that are eliminated (the border's cameras
+      // and what they see belong to the separator whatever the cut)
+      std::vector<int> cut_ocam, cut_opt;
+      if (pseudo_border) {
+        const std::vector<int>& so = pseudo_cams_ > 0 ? band_ocam : ocam;
+        const std::vector<int>& sp = pseudo_cams_ > 0 ? band_opt : opt;
+        for (size_t b = 0; b < so.size(); ++b) if (so[b] < Cband) { cut_ocam.push_back(so[b]); cut_opt.push_back(sp[b]); }
+      }
+      const std::vector<int>& docam = pseudo_border ? cut_ocam : ocam;
+      const std::vector<int>& dopt = pseudo_border ? cut_opt : opt;
       const int dnblk = pseudo_border ? (9 * Cband + 1 + 127) / 128 : nblk;
       const std::vector<int> band_env = envelope_of_order(docam, dopt, [&] { std::vector<int> e(Cband); std::iota(e.begin(), e.end(), 0); return e; }(), Cband, P_total_, dnblk, &first_col);
       const std::vector<int>& denv = pseudo_border ? band_env : env_for_model;
@@ -1207,7 +1223,16 @@ int BalSolver::setup() {
       // (only under the resident chain: the partner front rides in ITS launches — with SK_CHOL_CHAIN_SERVER=0, or on a device that
       // lost its chain, a single device stays undissected)
       const bool lockstep_cut = !multi && opt_.dissection == SK_DISSECTION_AUTO && opt_.resident_kernels && cholesky_chain_enabled(&chol_ctx_);
-      ds = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, lockstep_cut, lockstep_cut, C_ - Cband);
+      // (the border's rows that a band column reaches on top of its run: the tail profile of the bordered envelope)
+      std::vector<int> extra_fwd;
+      int extra_bwd = 0;
+      if (pseudo_border) {
+        extra_fwd.assign(dnblk, 0);
+        for (int c = 0; c < dnblk && c < (int)env_tail_.size(); ++c) extra_fwd[c] = std::max(0, nblk - 1 - std::max(env_tail_[c], c + 1));
+        // (the tail front reaches the border's rows in another order; counting all of them in every one of its columns moved the cut of
+        // Venice-1778 to a worse place — Cholesky phase 5.26 against 4.94 ms — counting none did not: extra_bwd stays 0)
+      }
+      ds = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, lockstep_cut, lockstep_cut, C_ - Cband, pseudo_border ? &extra_fwd : nullptr, extra_bwd);
       if (lockstep_cut && ds.a > 0) {  // (two resident servers per factorisation: the fifth such solver alive on a device stays undissected)
         if (!pair_claimed_) pair_claimed_ = cholesky_claim_pair_servers(&chol_ctx_);
         if (!pair_claimed_) ds.a = ds.b = 0;
@@ -1266,7 +1291,7 @@ int BalSolver::setup() {
         for (int c = lo; c < hi; ++c) fin[c] = sg + 1 < R ? seg_off_[sg] + (c - lo) : seg_off_[sg] + (hi - 1 - c);
         if (sg + 1 < R) { sep_first_.push_back(sep_pos); for (int c = cut_a[sg]; c < cut_b[sg]; ++c) fin[c] = sep_pos++; }
       }
-      for (int c = Cband; c < C_; ++c) fin[c] = sep_pos++;  // the pseudo-cameras of retained points: the end of the (one) separator
+      for (int c = Cband; c < C_; ++c) fin[c] = sep_pos++;  // the border's members (loop-closure cameras, pseudo-cameras of retained points): the end of the (one) separator
       sep_first_.push_back(C_);
       std::vector<int> cb2(C_);
       for (int c = 0; c < C_; ++c) cb2[fin[c]] = cam_block_[c];
@@ -1505,15 +1530,16 @@ int BalSolver::setup() {
       for (int c = lo; c < hi; ++c) { pos[c] = 9 * (c - lo); interior[c] = 1; }
       const int bo = L.ncols * 128;
       for (int c = rl; c < rh; ++c) pos[c] = bo + lay.right_off + 9 * (c - rl);
-      // (the pseudo-cameras of retained points — one device: the end of the one separator — stay at the END of a reversed border too:
-      // their rows are tail rows of the front's envelope, a suffix of the matrix)
-      const int lreal = lh - (segmented_ ? 0 : pseudo_cams_);
+      // (the members of a border — one device: the end of the one separator — stay at the END of a reversed border too: their rows are
+      // tail rows of the front's envelope, a suffix of the matrix)
+      const int nbm = segmented_ ? 0 : border_members_;
+      const int lreal = lh - nbm;
       for (int c = ll; c < lh; ++c) pos[c] = bo + lay.left_off + (lay.reversed && c < lreal ? 9 * (lreal - 1 - c) : 9 * (c - ll));
-      if (struct_ocam_.empty()) {
-        L.last = front_envelope(ocam, opt, pos, interior, P_total_, L.nblk, L.tail_rows);
-      } else {
-        L.last = front_envelope(struct_ocam_, struct_opt_, pos, interior, struct_P_, L.nblk, L.tail_rows, pos[C_ - pseudo_cams_], &L.tail);
-      }
+      const std::vector<int>& fo = struct_ocam_.empty() ? ocam : struct_ocam_;
+      const std::vector<int>& fp = struct_ocam_.empty() ? opt : struct_opt_;
+      const int fP = struct_ocam_.empty() ? P_total_ : struct_P_;
+      if (nbm > 0) L.last = front_envelope(fo, fp, pos, interior, fP, L.nblk, L.tail_rows, pos[C_ - nbm], &L.tail);
+      else L.last = front_envelope(fo, fp, pos, interior, fP, L.nblk, L.tail_rows);
       border_row_h[f].assign(std::max(1, nsep), 0);
       for (int c = cam_b_; c < C_; ++c) border_row_h[f][c - cam_b_] = pos[c] >= 0 ? pos[c] : 0;  // (a separator that is not next to the segment: no block of it here)
       if (segmented_) {
@@ -1569,7 +1595,7 @@ int BalSolver::setup() {
   if (dissected_ && !segmented_) {
     const int nsep = C_ - cam_b_;
     std::vector<int> mapB((size_t)border_blocks_ * 128, -1);
-    const int nreal = nsep - pseudo_cams_;
+    const int nreal = nsep - border_members_;
     for (int k = 0; k < nsep; ++k) for (int c = 0; c < 9; ++c) mapB[9 * k + c] = k < nreal ? 9 * (nreal - 1 - k) + c : 9 * k + c;  // camera order reversed, coordinates in order (pseudo-cameras: in place)
     mapB[9 * nsep] = 9 * nsep;  // right-hand-side row
     SK_HIP_TRY(b_mapB_.upload(mapB, s));

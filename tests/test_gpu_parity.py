@@ -848,7 +848,7 @@ def test_bordered_dense_schur_vs_oracle(C, P, N, seed, revisits):
     options.setRetainedPoints("off")  # (this test is about the border of CAMERAS: left to itself the library would retain the revisits' tracks as well)
     solver = sk.StepSolver(options, problem)
     nb = solver.stat("border_cameras")
-    assert 1 <= nb <= sum(w for _, _, w, _ in revisits) and solver.stat("dissected") == 0
+    assert 1 <= nb <= sum(w for _, _, w, _ in revisits)  # (dissected or not: on one device the border's cameras join the separator)
     fill_on = solver.stat("envelope_fill")
     while not solver.step():
         pass
@@ -1002,7 +1002,7 @@ def test_border_at_full_size_matches_the_plain_order_and_the_oracle():
         return params.toArray(prob.num_parameters), summary, stats
     x_b, s_b, st_b = run("auto")
     x_p, s_p, st_p = run("off")
-    assert 100 <= st_b["border_cameras"] <= 124 and st_b["dissected"] == 0 and st_p["border_cameras"] == 0
+    assert 100 <= st_b["border_cameras"] <= 124 and st_p["border_cameras"] == 0
     assert st_b["envelope_fill"] < 0.45 and st_p["envelope_fill"] > 0.55
     assert st_b["cholesky_columns_resident"] >= 60
     for u, v in zip(s_b.iterations(), s_p.iterations()):

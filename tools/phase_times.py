@@ -53,6 +53,7 @@ def main():
     its = summ.iterations()
     n = max(1, len(its) - 1)
     ph = {k: 1e3 * summ.phaseSeconds(i) / n for i, k in enumerate(PHASES)}
+    print("  cut: head %d tail %d separator %d" % (solver.stat("dissection_head_cameras"), solver.stat("dissection_tail_cameras"), solver.stat("dissection_separator_cameras")))
     print("  retained points %d (model %.0f us, %.0f without), border cameras %d, dissected %d, envelope fill %.3f, resident columns %d" % (
         solver.stat("retained_points"), solver.stat("retained_model_us"), solver.stat("retained_model_us_without"), solver.stat("border_cameras"),
         solver.stat("dissected"), solver.stat("envelope_fill"), solver.stat("cholesky_columns_resident")))
