@@ -972,6 +972,24 @@ def test_retained_points_at_full_size_match_the_all_eliminated_solve_and_the_ora
         assert abs(it["cost"] - so.iterations[k].cost) <= (1e-10 if k < 2 else FULL_SIZE_ORDER_TOL) * so.iterations[k].cost
 
 
+def test_retained_points_border_and_dissection_in_combination():
+    """tools/fuzz_retained.py: seven sequence lengths (340 … 1200 cameras) with and without two revisited places, each under five plans —
+    AUTO, 6 / 24 retained points with the lock-step dissection or without it, retained points with the border of loop-closure
+    cameras forced on — against the all-eliminated, undissected, unbordered solve of the same problem: three LM iterations, costs at
+    1e-8, parameters at 1e-6 (observed: 1e-11; profiles/r04_fuzz_retained_border_dissection.txt).  Every combination of (retained
+    points, border cameras, dissected) occurs among the 65 cases."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_retained.py"), "4"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "FUZZ_RETAINED_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("ok")]
+    assert len(lines) >= 60
+    combos = {(int(ln.split("retained")[-1].split()[0]) > 0, int(ln.split("border")[-1].split()[0]) > 0, int(ln.split("dissected")[-1].split()[0])) for ln in lines}
+    assert {(True, True, 1), (True, False, 1), (True, True, 0), (True, False, 0), (False, True, 0), (False, False, 1)} <= combos, combos
+
+
 def test_sharded_solve_with_retained_points():
     """Two ranks sharing the GPU, points sharded, twelve retained points: whichever rank owns a retained point writes its rows of the
     reduced system, the all-reduce carries them with the envelope, every rank takes the same step."""
