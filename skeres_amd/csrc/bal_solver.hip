@@ -1183,7 +1183,13 @@ int BalSolver::setup() {
     // (a border of loop-closure cameras alone — every point eliminated — is left undissected, as until round 4: the band then keeps its
     // SYRK-bound block columns, which the lock-step cannot pair and the border's rows make dearer; measured on Ladybug-1723 with three
     // places revisited: 8.1-9.2 ms of Cholesky phase for three cuts against 8.2 undissected)
-    const bool pseudo_border = border_members_ > 0 && !multi && pseudo_cams_ > 0;
+    // ... unless no block column of the bordered band is SYRK-bound to begin with (a sequence of a few hundred cameras)
+    bool band_chain_bound = border_members_ > 0 && !env_for_model.empty() && !env_tail_.empty();
+    for (int c = 0; band_chain_bound && c < nblk - 1 && c < (9 * (C_ - border_members_)) / 128; ++c) {
+      const int lm = std::min(env_for_model[c], nblk - 1), main_rows = lm > c ? lm - c : 0;
+      band_chain_bound = main_rows + std::max(0, nblk - std::max(env_tail_[c], c + 1 + main_rows)) <= 24;
+    }
+    const bool pseudo_border = border_members_ > 0 && !multi && (pseudo_cams_ > 0 || band_chain_bound);
     const int Cband = C_ - (pseudo_border ? border_members_ : 0);
     const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0 && (env_tail_.empty() || pseudo_border);
     bool may_dissect = plan_ok && (multi ? (pseudo_cams_ == 0 && (opt_.distribution_mode == SK_DISTRIBUTION_AUTO || opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED))
