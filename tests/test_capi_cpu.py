@@ -121,6 +121,34 @@ def test_options_validation():
         o.setMaxNumIterations(-1)
     with pytest.raises(ValueError):
         o.setFunctionTolerance(-1.0)
+    # the library's own options of the reduced system: modes are checked
+    for setter in (o.setCholeskyBorder, o.setRetainedPoints):
+        for mode in ("auto", "on", "off"):
+            setter(mode)
+        with pytest.raises(sk.SkeresError):
+            setter(7)
+    with pytest.raises(sk.SkeresError):
+        o.setRetainedPoints("on", -3)
+
+
+def test_reduce_buffer_has_room_for_the_pseudo_cameras_of_retained_points():
+    """sk_reduce_buffer_bytes (what skeres_amd/dist.py allocates for the all-reduce of the reduced system): the packed lower block
+    triangle of the cameras' system — and, unless retained points are off, of as many nine-row pseudo-cameras as the options allow."""
+    from skeres_amd import api, bal
+    from helpers import bal_problem_to_sk
+    prob = bal.generate(40, 300, 1500, seed=3)
+    problem, params, loss = bal_problem_to_sk(prob)
+
+    def nbytes(mode, max_points=0):
+        o = sk.Solver.Options()
+        o.setRetainedPoints(mode, max_points)
+        return api.lib().sk_reduce_buffer_bytes(o._h, problem._h)
+
+    def tri(cams):
+        nblk = (9 * cams + 1 + 127) // 128
+        return 128 * 128 * 8 * nblk * (nblk + 1) // 2
+    assert nbytes("off") == tri(40)
+    assert nbytes("auto") == tri(40 + 512) and nbytes("on", 30) == tri(40 + 10)
 
 
 def test_predefined_loss_functions_construction_and_validation():
