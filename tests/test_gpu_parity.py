@@ -973,7 +973,8 @@ def test_retained_points_at_full_size_match_the_all_eliminated_solve_and_the_ora
 
 
 def test_retained_points_border_and_dissection_in_combination():
-    """tools/fuzz_retained.py: seven sequence lengths (340 … 1200 cameras) with and without two revisited places, each under five plans —
+    """tools/fuzz_retained.py: seven sequence lengths (340 … 1200 cameras; two of them with the cameras in a scrambled order, so that the
+    reverse Cuthill-McKee candidate has to find the sequence) with and without two revisited places, each under five plans —
     AUTO, 6 / 24 retained points with the lock-step dissection or without it, retained points with the border of loop-closure
     cameras forced on — against the all-eliminated, undissected, unbordered solve of the same problem: three LM iterations, costs at
     1e-8, parameters at 1e-6 (observed: 1e-11; profiles/r04_fuzz_retained_border_dissection.txt).  Every combination of (retained

@@ -40,6 +40,14 @@ def main():
         for revisits in ((), "two"):
             rv = [(C // 10, C // 2, C // 50 + 6, 30), (C // 4, (3 * C) // 4, C // 50 + 6, 30)] if revisits else ()
             prob = bal.generate(C, P, N, seed=seed, revisits=rv)
+            if C in (520, 1000):
+                # the cameras in a scrambled order (and the residual blocks shuffled): neither first appearance nor the memory order of the
+                # camera blocks is banded — the reverse Cuthill-McKee candidate has to find the sequence
+                perm = rng.permutation(C)
+                cams = prob.parameters[:9 * C].reshape(C, 9)
+                x0 = np.concatenate([cams[np.argsort(perm)].ravel(), prob.parameters[9 * C:]])
+                order = rng.permutation(prob.num_observations)
+                prob = bal.BalProblem(C, P, perm[prob.camera_index][order].astype(np.int32), prob.point_index[order].astype(np.int32), prob.observations[order], x0)
             ref, x_ref, st_ref = run(prob, setRetainedPoints="off", setCholeskyDissection="off", setCholeskyBorder="off")
             for name, kw in (("auto", {}), ("retained on:6", {"setRetainedPoints": ("on", 6)}), ("retained on:24", {"setRetainedPoints": ("on", 24)}),
                              ("retained on:24, undissected", {"setRetainedPoints": ("on", 24), "setCholeskyDissection": "off"}),
