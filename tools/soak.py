@@ -28,8 +28,11 @@ def make(prob):
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-    prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(5e-2, 5e-1, 5e-1))
+    revisits = [(200, 900, 40, 150), (450, 1300, 40, 150), (700, 1600, 40, 150)] if (len(sys.argv) > 2 and sys.argv[2] == "revisits") else ()
+    prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(5e-2, 5e-1, 5e-1), revisits=revisits)
     s, problem, params = make(prob)
+    print("plan: retained points %d, border cameras %d, dissected %d, block columns under the resident chain %d" % (
+        s.stat("retained_points"), s.stat("border_cameras"), s.stat("dissected"), s.stat("cholesky_columns_resident")), flush=True)
     t0 = time.time()
     worst, last = 0.0, time.time()
     for i in range(iters):
