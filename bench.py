@@ -20,7 +20,10 @@ pays.  The same line carries the other configurations of BASELINE.json: one GPU 
 (dense rows); several ranks — `venice` and `c5` (rows sharded), each with the distribution used, the bytes all-reduced per
 iteration and the milliseconds that takes; and on one GPU `predicted_multi_gpu`, the chain model's figures for 2, 4, 8.
 
-Rank 0 prints ONE JSON line.
+stdout carries ONE line: the compact headline (at most 4 KB — metric, value, config, `roofline`, `cpu_baseline`), printed by
+rank 0 as soon as it is complete.  Everything else this run measures (the headline's detailed record and the other
+configurations) goes to stderr, one compact JSON line per record, and to a side file (SK_BENCH_DETAILS, default
+gpurun_out/bench_details.json): an extra configuration can neither cost the headline its line nor make it unparseable.
 """
 import argparse
 import json
@@ -142,6 +145,91 @@ def phase_rooflines(phases_ms, n_obs, envelope_bytes):
 PHASE_NAMES = ["jacobian_eval", "schur_assemble", "cholesky", "back_substitute", "cost_eval", "allreduce"]
 
 
+def phase_snapshot(solver):
+    """Seconds the solver has accumulated per phase so far (HIP events on its stream; sk_solver_stat "phase_seconds_<i>")."""
+    return [solver.stat("phase_seconds_%d" % i) for i in range(len(PHASE_NAMES))]
+
+
+def phases_per_step(before, after, steps):
+    """Milliseconds per step of each phase over the timed region alone.  Under hipGraph replay (BAL-49) the solver has no events
+    inside the replayed graph and books the whole linear solve + candidate evaluation under "cholesky": the sum of the phases
+    still is what the stream spent per step, and can no longer exceed ms_per_step (round-4 verdict: it included the captures)."""
+    return {k: 1e3 * (after[i] - before[i]) / max(1, steps) for i, k in enumerate(PHASE_NAMES)}
+
+
+HEADLINE_MAX_BYTES = 4096
+
+
+def compact(x, digits=5):
+    """Floats to `digits` significant digits, recursively (the headline is for a parser and a reader, not for arithmetic)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: compact(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [compact(v, digits) for v in x]
+    return x
+
+
+def headline_line(d):
+    """The one stdout line: the contract's fields, `roofline` and `cpu_baseline`, nothing else — from the detailed record `d` that
+    main() assembles (its keys are the same with or without a GPU: tests/test_bench_line_cpu.py builds one from canned figures).
+    `roofline` describes what bounds the iteration: the Cholesky PHASE (every kernel of the factorisation and the triangular solves —
+    flops of the plan over the phase's duration by HIP events on the solver's stream) against the fp64 matrix peak, the serial chain
+    inside it (steps x microseconds per step; the resident potrf server is one launch per factorisation and has no roofline of its own:
+    it is latency-bound), and the trailing SYRK's launches as a sub-record."""
+    cfg = d["config"]
+    chol = d.get("roofline_cholesky_phase") or {}
+    syrk = d.get("roofline_syrk") or {}
+    full = d.get("roofline_full") or {}
+    steps = cfg.get("chain_steps") or 0
+    roof = {"bound": "mfma", "kernel": "Cholesky phase of the reduced camera system (all its kernels: potrf server, column launches, trailing SYRKs, triangular solves)",
+            "achieved": chol.get("achieved"), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": chol.get("frac"),
+            "flops_per_iteration": chol.get("flops"), "ms_per_iteration": chol.get("ms"),
+            # HBM bytes by the counters cannot be read inside a timed run; the committed passes are in syrk.traffic, with the plan they measured
+            "traffic": None,
+            "chain": {"steps": steps, "us_per_step": (1e3 * chol["ms"] / steps) if steps and chol.get("ms") else None,
+                      "model_us": (d.get("chain_model") or {}).get("model_us"), "measured_over_model": (d.get("chain_model") or {}).get("measured_over_model"),
+                      "what": "block columns in sequence (two leaf fronts in lock-step count once), each potrf128 + two tile round trips + hand-overs; latency-bound"},
+            "syrk": {"kernel": "sk::syrk_trailing(_thin)_f64_kernel", "achieved": syrk.get("achieved"), "frac": syrk.get("frac"),
+                     "launches_per_iteration": syrk.get("launches_per_iteration"), "avg_launch_us": 1e3 * syrk["avg_launch_ms"] if syrk.get("avg_launch_ms") else None,
+                     "flops_per_launch": (syrk.get("flops_per_solve") or 0.0) / max(1, syrk.get("launches_per_iteration") or 1),
+                     "frac_alone": syrk.get("frac_alone"), "traffic": syrk.get("traffic"),
+                     "traffic_algorithmic": (syrk.get("traffic_like_for_like") or {}).get("algorithmic_bytes_per_launch"),
+                     "traffic_from": (syrk.get("traffic_like_for_like") or {}).get("file")},
+            "full_factorisation": ({"achieved": full.get("achieved"), "frac": full.get("frac"), "ms_per_step": full.get("ms_per_step")} if full else None)}
+    cpu = d.get("cpu_baseline")
+    if cpu:
+        cpu = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "sample", "value_full_factorisation") if cpu.get(k) is not None}
+        if len(cpu.get("sample", "")) > 260:
+            cpu["sample"] = cpu["sample"][:257] + "..."
+    line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg["workload"], "linear_solver": cfg.get("linear_solver"), "plan": cfg.get("plan"), "chain_steps": steps,
+                      "retained_points": (cfg.get("retained_points") or {}).get("points"), "envelope_fill": cfg.get("envelope_fill"),
+                      "successful_steps_in_timed_region": cfg.get("successful_steps_in_timed_region"), "parallelism": cfg.get("parallelism_short") or cfg.get("parallelism")}
+    line["roofline"] = roof
+    line["phases_ms_per_step"] = d.get("phases_ms_per_step")
+    if d.get("distribution"):
+        line["distribution"] = d["distribution"]
+    if d.get("independent_solves"):
+        line["independent_solves"] = {k: d["independent_solves"][k] for k in ("value", "unit", "scaling")}
+    line["cpu_baseline"] = cpu
+    line["details"] = d.get("details_file")
+    line = compact(line)
+    text = json.dumps(line, separators=(",", ":"))
+    # (never over the cap: drop the optional sub-records first, then shorten the strings)
+    for drop in (("roofline", "full_factorisation"), ("roofline", "syrk"), ("phases_ms_per_step",), ("independent_solves",)):
+        if len(text) <= HEADLINE_MAX_BYTES:
+            break
+        tgt = line
+        for k in drop[:-1]:
+            tgt = tgt.get(k) or {}
+        tgt.pop(drop[-1], None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert "\n" not in text and len(text) <= HEADLINE_MAX_BYTES, len(text)
+    return text
+
+
 REVISITS = [(200, 900, 40, 150), (450, 1300, 40, 150), (700, 1600, 40, 150)]  # three places seen twice, 40 cameras and 150 tracks each
 
 
@@ -221,6 +309,7 @@ def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, wor
     if world > 1:
         dist_mod.barrier()
     torch.cuda.synchronize()
+    phases0 = phase_snapshot(solver)
     t0 = time.perf_counter()
     done = 0
     for _ in range(steps):
@@ -237,10 +326,10 @@ def bal_record(sk, bal, name, seed, steps, warmup, local_rank, stream, rank, wor
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
         elapsed = float(t.item())
+    phases = phases_per_step(phases0, phase_snapshot(solver), steps)  # the timed steps only (not set-up, warm-up or a graph's capture)
     summ = sk.Solver.Summary()
     solver.finish(summ)
     its = summ.iterations()
-    phases = {k: 1e3 * summ.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(PHASE_NAMES)}
     chol_s = phases["cholesky"] * 1e-3
     rec = {"workload": "BAL %s (synthetic, shape-exact: C=%d P=%d N=%d, seed %d%s%s), DENSE_SCHUR" % (
                name, prob.num_cameras, prob.num_points, prob.num_observations, seed, ", long_range_fraction %g" % long_range_fraction if long_range_fraction else "",
@@ -429,11 +518,12 @@ def main():
     allreduce_mb = solver.stat("allreduce_bytes") / 1e6 if world > 1 else 0.0
     for _ in range(args.warmup):
         solver.step()
-    solver.setKernelTiming(2)  # HIP events around the dominant kernel's launches only
+    solver.setKernelTiming(2)  # HIP events around the trailing SYRK's launches only
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    phases0 = phase_snapshot(solver)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if solver.step():
@@ -448,6 +538,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    phases_timed = phases_per_step(phases0, phase_snapshot(solver), args.steps)
     syrk_s, syrk_n = solver.kernelSeconds("gemm_syrk")
     syrk_flops = solver.syrkFlopsPerSolve()
     syrk_c_bytes = solver.syrkCBytesPerSolve()
@@ -468,7 +559,7 @@ def main():
         pass
     headline_stats = {}
     for k in ("model_us_segments_1", "border_cameras", "border_model_us", "dissected", "dissection_model_us", "retained_points", "retained_model_us",
-              "retained_model_us_without", "dissection_head_cameras", "dissection_tail_cameras", "dissection_separator_cameras"):
+              "retained_model_us_without", "dissection_head_cameras", "dissection_tail_cameras", "dissection_separator_cameras", "chain_steps"):
         try:
             headline_stats[k] = solver.stat(k)
         except sk.SkeresError:
@@ -551,7 +642,7 @@ def main():
                                 "replicated x%d: the solver measured %.1f ms for the all-reduce of the reduced system against %.1f ms of "
                                 "per-iteration work sharding would remove, and did not shard" % (world, 1e3 * t_allreduce, 1e3 * t_saved)),
                 "cost_first_timed": timed[0]["cost"] if timed else None, "cost_last_timed": timed[-1]["cost"] if timed else None},
-            "roofline": {"bound": "mfma", "kernel": "sk::syrk_trailing_f64_kernel / sk::syrk_trailing_thin_f64_kernel (Cholesky trailing SYRK, one GEMM "
+            "roofline_syrk": {"bound": "mfma", "kernel": "sk::syrk_trailing_f64_kernel / sk::syrk_trailing_thin_f64_kernel (Cholesky trailing SYRK, one GEMM "
                                                      "body in 128x128 and 32x128 tiles, v_mfma_f64_16x16x4_f64)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
@@ -577,8 +668,16 @@ def main():
                                  "longer where the time goes — by time the dominant kernel is the resident potrf server, which is latency-bound; "
                                  "the record all_points_eliminated holds the SYRK-bound plan of rounds 1-3 (its launches at 0.44 of the peak: "
                                  "profiles/r04_c_bench.json), roofline_full the dense case (0.57)"},
-            "phases_ms_per_step": {k: 1e3 * summary.phaseSeconds(i) / max(1, len(its) - 1) for i, k in enumerate(PHASE_NAMES)},
+            "phases_ms_per_step": phases_timed,  # the timed region alone
         }
+        hs = headline_stats
+        line["config"]["chain_steps"] = int(hs.get("chain_steps", 0))
+        line["config"]["plan"] = ("full factorisation" if args.full_factorisation else "block envelope") + (
+            "; %d retained points" % int(hs.get("retained_points", 0)) if hs.get("retained_points", 0) > 0 else "; every point eliminated") + (
+            "; lock-step dissection head %d | tail %d | separator %d cameras and pseudo-cameras" % (int(hs.get("dissection_head_cameras", 0)), int(hs.get("dissection_tail_cameras", 0)),
+                                                                                                  int(hs.get("dissection_separator_cameras", 0))) if hs.get("dissected", 0) else "; undissected") + (
+            "; launch by launch" if args.no_resident_kernels else "; resident panel chain")
+        line["config"]["parallelism_short"] = "one GPU" if world == 1 else "%s x%d (%.1f MB all-reduced per iteration)" % (dist_mode, world, allreduce_mb)
         line["roofline_phases_hbm"] = phase_rooflines(line["phases_ms_per_step"], prob.num_observations if world == 1 else prob.num_observations / world,
                                                       plan["allreduce_bytes"] if world == 1 else 0.0)
         if world > 1:
@@ -616,7 +715,7 @@ def main():
         # timed region factors the blocks inside the envelope (cholesky_flops_plan); the structure-independent figure
         # is the FULL factorisation — SURVEY.md section 8(d)'s n^3 / 3 over the measured Cholesky phase of the side run
         # that factors every block.
-        chol_live_s = summary.phaseSeconds(2) / max(1, len(its) - 1)
+        chol_live_s = 1e-3 * phases_timed["cholesky"]
         if world == 1:
             line["chain_model"] = chain_model_record(lambda k: headline_stats.get(k, 0.0), 1e3 * chol_live_s)
         line["roofline_cholesky_phase"] = {
@@ -644,28 +743,46 @@ def main():
             line["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, envelope=not args.full_factorisation, full_iters=args.cpu_full_iters)
         elif world == 1:
             line["cpu_baseline"] = None
-    # The headline is complete here.  The other configurations below run on every rank and use collectives: should one of them
-    # hang (a rank that died inside a collective), every rank's watchdog ends the run after SK_BENCH_EXTRAS_TIMEOUT seconds and
-    # rank 0 prints the headline as it stands — an extra configuration may not cost the headline its line.
-    import threading
-    printed = threading.Lock()
+    # The headline is complete here: rank 0 prints it NOW — the one stdout line of this run.  The other configurations below run on
+    # every rank (with several ranks they use collectives) and report on stderr and in the side file; should one of them hang, a
+    # watchdog ends the run after SK_BENCH_EXTRAS_TIMEOUT seconds with exit code 0 (a plain exit, never a re-exec) — whatever the
+    # number of ranks.
+    details_path = os.environ.get("SK_BENCH_DETAILS", os.path.join(ROOT, "gpurun_out", "bench_details.json"))
+    records = {}
 
-    def emit(extra_records):
-        if not printed.acquire(blocking=False):
+    def write_details():
+        if rank != 0:
             return
-        if rank == 0:
-            line.update(extra_records)
-            print(json.dumps(line), flush=True)
+        try:
+            os.makedirs(os.path.dirname(details_path), exist_ok=True)
+            with open(details_path + ".tmp", "w") as f:
+                json.dump(records, f, indent=1)
+            os.replace(details_path + ".tmp", details_path)
+        except OSError as e:  # (a read-only tree: stderr still has every record)
+            sys.stderr.write("[bench] details not written: %s\n" % e)
+
+    def report(key, rec):
+        """One record of the run: a compact line on stderr, and the side file rewritten (complete after every record)."""
+        if rank != 0:
+            return
+        records[key] = rec
+        sys.stderr.write(json.dumps({"record": key, **(rec if isinstance(rec, dict) else {"value": rec})}, separators=(",", ":")) + "\n")
+        sys.stderr.flush()
+        write_details()
+
+    if rank == 0:
+        line["details_file"] = os.path.relpath(details_path, ROOT) + " (and stderr: one JSON line per record)"
+        report("headline", line)
+        print(headline_line(line), flush=True)
+    import threading
+    timeout_s = float(os.environ.get("SK_BENCH_EXTRAS_TIMEOUT", "900"))
 
     def watchdog():
-        emit({"extras_error": "the extra configurations did not finish within %s s; the headline above them is complete" % timeout_s})
+        report("extras_error", {"error": "the extra configurations did not finish within %s s; the headline is complete" % timeout_s})
         os._exit(0)
-    timeout_s = float(os.environ.get("SK_BENCH_EXTRAS_TIMEOUT", "900"))
-    timer = None
-    if world > 1:
-        timer = threading.Timer(timeout_s, watchdog)
-        timer.daemon = True
-        timer.start()
+    timer = threading.Timer(timeout_s, watchdog)
+    timer.daemon = True
+    timer.start()
     # ---- the other configurations of BASELINE.json in the same run (every rank takes part; rank 0 reports).  None of them may
     # cost the headline its line: whatever goes wrong in one is recorded in its place. ----
     extra = {}
@@ -681,6 +798,7 @@ def main():
                 extra[key] = fn()
             except Exception as e:  # noqa: BLE001 (e.g. not enough free HBM for the 80 GB Jacobian on a shared device)
                 extra[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            report(key, extra[key])
         if world == 1:
             record("c2", lambda: bal_record(sk, bal, "problem-49-7776", 49, 20, 2, local_rank, stream, rank, world, dist_mod, torch))
         record("c4" if world == 1 else "venice",
@@ -703,9 +821,7 @@ def main():
                                                               revisits=REVISITS, border="off", retained="off"))
         if not args.no_c5:
             record("c5", lambda: c5_record(sk, rank=rank, world=world, stream=stream, torch=torch, dist_mod=dist_mod))
-    if timer:
-        timer.cancel()
-    emit(extra)
+    timer.cancel()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -192,6 +192,10 @@ class BalSolver : public SolverBase {
       *value = r;
       return true;
     }
+    if (name == "chain_steps") {  // serial steps of the factorisation: block columns, the two leaf fronts of a lock-step dissection counted as one sequence
+      *value = (dissected_ ? std::max(fr_[0].ncols, fr_[1].ncols) : 0) + fr_[2].ncols;
+      return true;
+    }
     if (name == "allreduce_bytes") { *value = (double)packed_elems_ * sizeof(double); return true; }
     if (name == "allreduce_bytes_full_triangle") { *value = (double)tri_packed_elems(nblk) * sizeof(double); return true; }
     if (name == "dissected") { *value = dissected_ ? 1.0 : 0.0; return true; }

@@ -716,6 +716,7 @@ int sk_solver_distribution(const sk_solver* s, double* allreduce_seconds, double
 int sk_solver_stat(const sk_solver* s, const char* name, double* value) {
   SK_GUARD_BEGIN
   if (!s || !name || !value) { set_error("null argument"); return SK_ERR_INVALID_ARGUMENT; }
+  if (strncmp(name, "phase_seconds_", 14) == 0 && name[14] >= '0' && name[14] <= '5' && !name[15]) { *value = s->impl->phase_seconds(name[14] - '0'); return SK_OK; }
   if (!s->impl->stat(name, value)) { set_error("this solver reports no figure named '%s'", name); return SK_ERR_INVALID_ARGUMENT; }
   return SK_OK;
   SK_GUARD_END(SK_ERR_INVALID_ARGUMENT)

@@ -26,6 +26,8 @@ class SolverBase {
   virtual double syrk_flops_per_solve() const { return 0.0; }
   virtual double syrk_c_bytes_per_solve() const { return 0.0; }  // C tiles read + written by those launches
   virtual bool stat(const std::string& name, double* value) const { (void)name; (void)value; return false; }  // sk_solver_stat
+  // seconds accumulated so far in phase i (the summary's phase_seconds, readable between steps: "phase_seconds_<i>" of sk_solver_stat)
+  double phase_seconds(int i) const { return (i >= 0 && i < 6) ? phase_[i] : 0.0; }
   // how a world > 1 is used (SK_DISTRIBUTION_*), with the estimates behind an automatic choice
   virtual int distribution(double* allreduce_s, double* saved_s) const {
     if (allreduce_s) *allreduce_s = 0.0;
