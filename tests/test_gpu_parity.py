@@ -367,6 +367,14 @@ def _reproj_rms(prob, x):
 FULL_SIZE_ORDER_TOL = 5e-10
 
 
+def full_size_cost_tol(k):
+    """Relative tolerance on the cost logged for iteration k when two elimination ORDERS of Ladybug-1723 at full size are compared
+    (or the device's order with the oracle's): 1e-10 — BASELINE.md section 6 — except on the cost after the SECOND step (k == 2),
+    which is a sensitive function of that step (orders equal in exact arithmetic differ by 2e-11 .. 1.6e-10 there): 5e-10; and
+    the orders must have come back together one iteration later: 1e-11 from k == 3 on (observed < 1e-12)."""
+    return 1e-10 if k < 2 else (FULL_SIZE_ORDER_TOL if k == 2 else 1e-11)
+
+
 def _check_against_oracle(prob, summary, x_gpu, so, x_cpu):
     g = [it["cost"] for it in summary.iterations()]
     c = so.costs()
@@ -939,15 +947,17 @@ def test_retained_points_dense_schur_vs_oracle(C, P, N, seed, max_points, extra)
 
 def test_retained_points_at_full_size_match_the_all_eliminated_solve_and_the_oracle():
     """Ladybug-1723 at full size: AUTO retains the twelve widest tracks (landmarks seen from up to 392 cameras), the block envelope
-    of the reduced system falls to a fifth of its flops, every block column is chain-bound — and three LM iterations agree at
-    1e-10 with the device's all-eliminated solve and with the oracle, which eliminates every point."""
+    of the reduced system falls to a fifth of its flops, every block column is chain-bound — and FOUR LM iterations agree with the
+    device's all-eliminated solve and with the oracle, which eliminates every point, at full_size_cost_tol: 1e-10, 5e-10 on the cost
+    after the second step, and 1e-11 after the third — the rounding difference between elimination orders does not grow, it goes
+    away (round-4 verdict: the explanation of the 5e-10 as a test)."""
     prob = bal.generate_named("ladybug-1723-156502", seed=1723, perturb=(1e-2, 1e-1, 1e-1))
 
     def run(mode):
         problem, params, loss = bal_problem_to_sk(prob)
         options = sk.Solver.Options()
         options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
-        options.setMaxNumIterations(3)
+        options.setMaxNumIterations(4)
         options.setRetainedPoints(mode)
         solver = sk.StepSolver(options, problem)
         stats = {k: solver.stat(k) for k in ("retained_points", "retained_model_us", "retained_model_us_without", "cholesky_flops_plan", "envelope_fill")}
@@ -961,15 +971,20 @@ def test_retained_points_at_full_size_match_the_all_eliminated_solve_and_the_ora
     assert st_r["retained_points"] >= 3 and st_e["retained_points"] == 0
     assert st_r["retained_model_us"] < 0.9 * st_r["retained_model_us_without"]
     assert st_r["cholesky_flops_plan"] < 0.5 * st_e["cholesky_flops_plan"]
-    for u, v in zip(s_r.iterations(), s_e.iterations()):
-        assert abs(u["cost"] - v["cost"]) <= FULL_SIZE_ORDER_TOL * v["cost"]
+    assert len(s_r.iterations()) == len(s_e.iterations()) == 5
+    deviation = []
+    for k, (u, v) in enumerate(zip(s_r.iterations(), s_e.iterations())):
+        deviation.append(abs(u["cost"] / v["cost"] - 1.0))
+        assert abs(u["cost"] - v["cost"]) <= full_size_cost_tol(k) * v["cost"], (k, u["cost"], v["cost"])
         assert abs(u["step_norm"] - v["step_norm"]) <= 1e-8 * max(1.0, v["step_norm"])
+    print("retained (AUTO, lock-step) against all eliminated, |cost ratio - 1| per iteration:", ["%.2e" % d for d in deviation])
     assert np.abs(x_r - x_e).max() <= 1e-7 * max(1.0, np.abs(x_e).max())
     C, P = prob.num_cameras, prob.num_points
     _, so = oracle.solve_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
-                             oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=_oracle_threads(), max_num_iterations=3, cholesky_envelope=1))
+                             oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=_oracle_threads(), max_num_iterations=4, cholesky_envelope=1))
+    assert so.num_logged == 5
     for k, it in enumerate(s_r.iterations()[:so.num_logged]):
-        assert abs(it["cost"] - so.iterations[k].cost) <= (1e-10 if k < 2 else FULL_SIZE_ORDER_TOL) * so.iterations[k].cost
+        assert abs(it["cost"] - so.iterations[k].cost) <= full_size_cost_tol(k) * so.iterations[k].cost, (k, it["cost"], so.iterations[k].cost)
 
 
 def test_retained_points_border_and_dissection_in_combination():
