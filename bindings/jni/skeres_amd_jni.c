@@ -51,6 +51,13 @@ static jlong check_handle(JNIEnv* env, const void* p) {
   if (!p) throw_status(env, SK_ERR_INVALID_ARGUMENT);
   return HANDLE(p);
 }
+/* ... and a factory that records a typed status of its own for a NULL result (sk_solver_create, sk_allreduce_rccl_init: both set
+ * sk_last_status on every call, so nothing stale can be read): that status decides the exception class — a communicator that
+ * cannot come up is SK_ERR_COMM / SK_ERR_NO_DEVICE, not an illegal argument. */
+static jlong check_handle_status(JNIEnv* env, const void* p) {
+  if (!p) { const int st = sk_last_status(); throw_status(env, st != SK_OK ? st : SK_ERR_INVALID_ARGUMENT); }
+  return HANDLE(p);
+}
 
 /* ---- library ---- */
 SK_JNI(jstring, skVersion)(JNIEnv* env, jclass c) { (void)c; return (*env)->NewStringUTF(env, sk_version()); }
@@ -320,7 +327,7 @@ SK_JNI(jlong, skAllreduceRcclInit)(JNIEnv* env, jclass c, jint rank, jint world,
   (void)c;
   char buf[128];
   (*env)->GetByteArrayRegion(env, id, 0, 128, (jbyte*)buf);
-  return check_handle(env, sk_allreduce_rccl_init(rank, world, buf));
+  return check_handle_status(env, sk_allreduce_rccl_init(rank, world, buf));
 }
 SK_JNI(void, skAllreduceRcclFree)(JNIEnv* env, jclass c, jlong h) { (void)env; (void)c; sk_allreduce_rccl_free(PTR(sk_rccl, h)); }
 SK_JNI(jint, skOptionsSetDistributedRccl)(JNIEnv* env, jclass c, jlong o, jint rank, jint world, jlong rccl) {

@@ -467,8 +467,9 @@ int sk_solve(const sk_options* options, sk_problem* problem, sk_summary* summary
  * drivers: create (uploads + iteration 0), step (ONE trust-region iteration),
  * finish (writes parameters back + fills the summary). */
 sk_solver* sk_solver_create(const sk_options* options, sk_problem* problem);
-/* The sk_status that goes with the last NULL returned by sk_solver_create on the calling thread (SK_OK after a
- * success): NULL alone cannot say whether the device is missing, the configuration unsupported or an argument wrong. */
+/* The sk_status that goes with the last NULL returned by sk_solver_create — or by sk_allreduce_rccl_init — on the calling thread
+ * (SK_OK after a success; both set it on every call): NULL alone cannot say whether the device is missing, the configuration
+ * unsupported, the communicator down or an argument wrong. */
 int sk_last_status(void);
 void sk_solver_free(sk_solver* s);
 /* Returns SK_OK and sets *done (boolean) when a termination test fired. */

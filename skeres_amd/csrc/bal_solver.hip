@@ -1870,7 +1870,10 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   }
   // ---- B. Schur complement assembly ----
   // (this step's back-substitution zeroes what it reads when it is the resident launch: decided here, once, for the whole step)
-  const bool zero_after = zero_by_backsolve_ && cholesky_backsolve_resident(npad_ / 128);
+  // (... and whether the back-substitutions of this step are the resident launch at all: one decision for every front — the process-wide
+  // switch can be cleared by another solver's time-out at any moment)
+  const int bs_resident = opt_.resident_kernels && cholesky_backsolve_resident(npad_ / 128) ? 1 : 0;
+  const bool zero_after = zero_by_backsolve_ && bs_resident;
   kt_.begin("memset_S", s);
   for (int f = 0; f < 3; ++f)
     if (fr_[f].nblk > 0) launch_zero_envelope(d_.front[f].S, (int)fr_[f].dim, (zero_by_backsolve_ && !need_full_zero_) ? b_zero_min_f_[f].p : b_zero_col0_f_[f].p, fr_[f].nblk, s);
@@ -1915,7 +1918,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvAssemble], s));
   // ---- C. dense Cholesky + solves ----
   CholeskyContext* ctx = opt_.lookahead ? &chol_ctx_ : nullptr;
-  int* bs_info = opt_.resident_kernels ? info_p_ : nullptr;  // (nullptr: the back-substitutions one launch per block step — nothing resident, nothing that waits)
+  int* bs_info = bs_resident ? info_p_ : nullptr;  // (nullptr: the back-substitutions one launch per block step — nothing resident, nothing that waits)
   double* yf[3] = {b_yf_.p + fr_[0].y_off, b_yf_.p + fr_[1].y_off, b_yf_.p + fr_[2].y_off};
   double* wf[3] = {b_wf_.p + fr_[0].y_off, b_wf_.p + fr_[1].y_off, b_wf_.p + fr_[2].y_off};
   if (segmented_) {
@@ -1937,18 +1940,18 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     launch_tri_pack(Rs, (int)R.dim, b_pack_.p, R.nblk, b_pack_col0_.p, b_pack_off_.p, false, s);
     finish_root();
     cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok());
-    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info, nullptr, zero_after);
+    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info, nullptr, zero_after, bs_resident);
     if (L.ncols > 0) {
       cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
-      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info, zero_after);
+      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info, zero_after, nullptr, nullptr, bs_resident);
     }
   } else if (dissected_) {
     cholesky_dissected_factor(ds_, info_p_, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
-    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, bs_info, zero_after);
+    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, bs_info, zero_after, bs_resident);
   } else {
     const FrontHost& R = fr_[2];
     cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok(), -1, 1, nullptr, R.tl());
-    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl(), zero_after);
+    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl(), zero_after, bs_resident);
   }
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----
@@ -2177,11 +2180,11 @@ int bal_border_plan(const Problem& p, int mode, std::vector<int>* final_index_of
   return plan.bordered ? plan.border.border_cams : 0;
 }
 
-int bal_retained_plan(const Problem& p, int mode, int max_points, int border_mode, std::vector<int>* retained_of_block, double* model_us, double* model_us_without) {
+int bal_retained_plan(const Problem& p, int mode, int max_points, int border_mode, std::vector<int>* retained_of_block, double* model_us, double* model_us_without, bool with_memory_order) {
   std::vector<int> cam_block, pt_block, ocam, opt;
   bal_index_problem(p, &cam_block, &pt_block, &ocam, &opt);
   const int C = (int)cam_block.size(), P = (int)pt_block.size();
-  const ReducedSystemPlan rp = plan_reduced_system(p, cam_block, ocam, opt, C, P, true, border_mode != SK_BORDER_OFF, border_mode, mode, max_points);
+  const ReducedSystemPlan rp = plan_reduced_system(p, cam_block, ocam, opt, C, P, with_memory_order, border_mode != SK_BORDER_OFF, border_mode, mode, max_points);
   std::vector<char> kept(P, 0);
   for (int q : rp.retained) kept[q] = 1;
   retained_of_block->resize(ocam.size());

@@ -607,8 +607,20 @@ size_t sk_reduce_buffer_bytes(const sk_options* o, const sk_problem* p) {
   const Problem& P = p->p;
   std::vector<char> seen(P.block_size.size(), 0); size_t C = 0;
   for (size_t b = 0; b < P.rb_functor.size(); ++b) { const int c = P.rb_pidx[P.rb_pidx_off[b]]; if (!seen[c]) { seen[c] = 1; ++C; } }
-  // (+ the pseudo-cameras of retained points, three points each: as many as the options allow — sk_options_set_retained_points)
-  if (!o || o->o.retained != SK_RETAINED_OFF) C += (size_t)((o && o->o.retained_max > 0 ? o->o.retained_max : 1536) + 2) / 3;
+  // (+ the pseudo-cameras of retained points, three points each — sk_options_set_retained_points: what the plan retains for this problem,
+  // which is a function of host data alone (bal_retained_plan), not the most the options would allow: 512 pseudo-cameras made a 16-camera
+  // problem's buffer 97 MB and Ladybug-1723's 1.6 GB instead of 0.98 — ADVICE r04.  A world of ranks may have to drop the memory-order
+  // candidate of the camera orders (setup: the ranks compare): the plan without it can retain more, so the larger of the two counts.)
+  if (!o || o->o.retained != SK_RETAINED_OFF) {
+    const int mode = o ? o->o.retained : SK_RETAINED_AUTO, maxp = o ? o->o.retained_max : 0, border = o ? o->o.border : SK_BORDER_AUTO;
+    std::string why;
+    size_t kept = 0;
+    if (problem_is_bal_shaped(P, &why)) {
+      std::vector<int> flags;
+      kept = (size_t)std::max(bal_retained_plan(P, mode, maxp, border, &flags, nullptr, nullptr, true), bal_retained_plan(P, mode, maxp, border, &flags, nullptr, nullptr, false));
+    }
+    C += (kept + 2) / 3;
+  }
   const size_t n = 9 * C, npad = ((n + 1 + 127) / 128) * 128;
   return tri_packed_elems((int)(npad / 128)) * sizeof(double);  // lower block triangle, packed
 }

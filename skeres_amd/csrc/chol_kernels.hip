@@ -1131,6 +1131,9 @@ __global__ __launch_bounds__(1024) void bs_step_kernel(const double* __restrict_
 // solution is the same, bit for bit (tests/test_gpu_parity.py::test_resident_backsolve_is_bitwise_the_launch_by_launch_one).
 // A poll gives up after kChainTimeoutTicks: info = 2 (the caller factors and solves again, launch by launch).
 // ---------------------------------------------------------------------------
+#ifdef SK_TESTING
+__device__ int g_bs_test_janitor_giveup;  // fault injection (SK_BS_TEST_JANITOR_GIVEUP=1, testing build only): janitor 0 of the next resident back-substitution gives up
+#endif
 __device__ long long g_bs_stamps[1024][4];  // developer timeline SK_BS_STAMPS=<file>: per block column, wall clock when its owner started waiting for
 __device__ int g_bs_stamps_on;              // the block row next to the diagonal, when that y had arrived, and when its own y was stored
 constexpr int kBsMaxBlocks = 960;  // (two tables of that many entries + the other arguments: inside the 4 KB kernel-argument segment)
@@ -1165,8 +1168,15 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
         int ok = 1;
         while (__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kBsSentinel) {
           __builtin_amdgcn_s_sleep(8);
-          if (wall_clock64() - t0 > kChainTimeoutTicks) { ok = 0; break; }  // (the owners report the time-out; the host then zeroes everything)
+          if (wall_clock64() - t0 > kChainTimeoutTicks) { ok = 0; break; }
         }
+#ifdef SK_TESTING
+        if (jn == 0 && g_bs_test_janitor_giveup && atomicExch(&g_bs_test_janitor_giveup, 0) != 0) ok = 0;  // fault injection: janitor 0 gives up once
+#endif
+        // A janitor that gives up leaves blocks of the envelope unzeroed — and may be the ONLY workgroup that timed out (an owner's clock
+        // restarts at every hop, a janitor's first wait spans up to 95 of them): it reports the time-out itself (info = 2: the host
+        // assembles and factors the same system again, after a full zero pass — BalSolver::try_step_once, need_full_zero_)
+        if (!ok && info) info_raise(info, 2);
         ok_s = ok;
       }
       __syncthreads();
@@ -1307,12 +1317,14 @@ static std::atomic<int> g_bs_resident{1};  // developer knob SK_BS_RESIDENT=0: t
 // times out (tests/chain_abort_worker.py).
 #ifdef SK_TESTING
 static std::atomic<int> g_test_withhold{-1};
+static std::atomic<int> g_test_janitor_giveup{0};  // SK_BS_TEST_JANITOR_GIVEUP=<n>: from the n-th resident back-substitution with janitors of a whole system on, once
 #endif
 hipError_t cholesky_init() {
   static std::once_flag once;
   std::call_once(once, [] {
 #ifdef SK_TESTING
     if (const char* e = getenv("SK_CHAIN_TEST_WITHHOLD_MARKER")) g_test_withhold.store(atoi(e));
+    if (const char* e = getenv("SK_BS_TEST_JANITOR_GIVEUP")) g_test_janitor_giveup.store(atoi(e) > 0 ? 1 : 0);
 #endif
     const DevKnobs& k = dev_knobs();
     g_bs_resident.store(k.bs_resident);
@@ -2310,9 +2322,9 @@ bool cholesky_backsolve_resident(int nblk) { return g_bs_resident.load() != 0 &&
 // to 96 — with the owners they stay inside the chip's 256 CUs (a workgroup of 1024 threads at 256 VGPRs fills one)
 static int bs_janitors(int owners) { return std::max(1, std::min(owners, 96)); }
 void cholesky_backsolve(double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt, const int* last, int* info, const int* tail, bool zero_after) {
+                        hipStream_t s, KernelTimer* kt, const int* last, int* info, const int* tail, bool zero_after, int resident) {
   const int nblk = npad / 128;
-  if (info && g_bs_resident && nblk <= kBsMaxBlocks) {
+  if (info && (resident < 0 ? g_bs_resident.load() != 0 : resident != 0) && nblk <= kBsMaxBlocks) {
     BsTop env;
     for (int c = 0; c < nblk; ++c) {
       env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1);
@@ -2323,6 +2335,9 @@ void cholesky_backsolve(double* S, long ld, int n, int npad, int rhs_row, const 
     const char* bs_stamps = dev_knobs().bs_stamps;
     if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
     const int janitors = zero_after ? bs_janitors(nblk) : 0;
+#ifdef SK_TESTING
+    if (janitors > 0) { int want = 1; if (g_test_janitor_giveup.compare_exchange_strong(want, 0)) { const int one = 1; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bs_test_janitor_giveup), &one, sizeof(int), 0, hipMemcpyHostToDevice, s); (void)hipStreamSynchronize(s); } }
+#endif
     hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), n, y, nblk, env, info, nblk, (const double*)nullptr,
                        janitors, (const int*)nullptr);
     if (kt) kt->end("backsolve", s);
@@ -2420,10 +2435,16 @@ void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f
 // Interior part of L^T y = z for a leaf front whose border unknowns are known.  yb: border unknowns (border_blocks * 128
 // values, zero where the border has padding or its right-hand-side row).  w: scratch (ncols * 128); y: interior solution.
 void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info, bool zero_after, const int* tail, const int* yb_map) {
+                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info, bool zero_after, const int* tail, const int* yb_map, int resident) {
   const int ni = ncols * 128, m = (nblk - ncols) * 128;
   if (ncols <= 0) return;
-  if (info && g_bs_resident && nblk <= kBsMaxBlocks) {
+  const bool res = info && (resident < 0 ? g_bs_resident.load() != 0 : resident != 0) && nblk <= kBsMaxBlocks;
+  if (yb_map && !res) {  // (a map is the resident launch's: the launch-by-launch form below reads yb in the border's own order — a caller's bug, loud)
+    std::fprintf(stderr, "[skeres_amd] internal: cholesky_backsolve_front got a border map without the resident launch\n");
+    if (info) (void)hipMemsetAsync(info, 0x7f, sizeof(int), s);
+    return;
+  }
+  if (res) {
     // one resident launch (bs_resident_kernel): an owner per interior block column, the border's unknowns read from yb.  Not the
     // same grouping of the border's terms as bs_border_kernel below (block row by block row there, sixteen interleaved row
     // groups here): equal to rounding, not to the bit — a front's interior solution belongs to one rank.
@@ -2514,8 +2535,9 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
 }
 
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,
-                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info, bool zero_after) {
-  cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last, info, nullptr, zero_after);
+                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info, bool zero_after, int resident) {
+  if (resident < 0) resident = g_bs_resident.load() != 0 ? 1 : 0;  // (once for the three fronts)
+  cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last, info, nullptr, zero_after, resident);
   if (kt) kt->begin("backsolve", s);
   const int m = d.border_blocks * 128;
   const bool side = d.B.ncols > 0 && d.A.ncols > 0 && ctxB && ctxB->fork;
@@ -2528,13 +2550,13 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
       sB = ctxB->fork;
     }
     // (the resident launch reads the root's solution through the map itself: no gather launch in front of the tail's chain of hops)
-    const bool mapped = info && cholesky_backsolve_resident(d.B.nblk);
+    const bool mapped = info && resident != 0 && d.B.nblk <= kBsMaxBlocks;
     if (!mapped) cholesky_gather_map(yR, d.mapB, ybB, m, sB);
     cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, mapped ? yR : ybB, wB, yB, sB, d.B.last, false, 1, info, zero_after, d.B.tail,
-                             mapped ? d.mapB : nullptr);
+                             mapped ? d.mapB : nullptr, resident);
   }
   // (yR is zero in the root's padding rows and in its right-hand-side row: it serves as A's border unknowns as it stands)
-  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after, d.A.tail);
+  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after, d.A.tail, nullptr, resident);
   if (side) {
     (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);

@@ -83,7 +83,10 @@ int sk_rccl_unique_id(void* id128) {
 }
 
 sk_rccl* sk_allreduce_rccl_init(int rank, int world, const void* id128) {
-  if (!id128 || world < 1 || rank < 0 || rank >= world) { sk::set_error("sk_allreduce_rccl_init: invalid argument"); return nullptr; }
+  // (a NULL handle carries a typed status — sk_last_status — as sk_solver_create's does: an argument, or the communicator)
+  sk::set_status(SK_OK);
+  if (!id128 || world < 1 || rank < 0 || rank >= world) { sk::set_error("sk_allreduce_rccl_init: invalid argument"); sk::set_status(SK_ERR_INVALID_ARGUMENT); return nullptr; }
+  sk::set_status(SK_ERR_COMM);  // (every failure below is the communicator's: librccl missing, no device, ncclCommInitRank)
   const Rccl* r = rccl();
   if (!r) return nullptr;
   ncclUniqueId_ id;
@@ -94,6 +97,7 @@ sk_rccl* sk_allreduce_rccl_init(int rank, int world, const void* id128) {
   sk_rccl* h = new (std::nothrow) sk_rccl();
   if (!h) { (void)r->comm_destroy(comm); return nullptr; }
   h->comm = comm; h->owned = true;
+  sk::set_status(SK_OK);
   return h;
 }
 

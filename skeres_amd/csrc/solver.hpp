@@ -80,7 +80,8 @@ int bal_segment_plan(const Problem& p, int max_segments, bool forced, std::vecto
 bool bal_block_shape(const Problem& p, int* r, int* c, int* q);
 int bal_border_plan(const Problem& p, int mode, std::vector<int>* final_index_of_block, int* gap, double* model_us, double* plain_us, double* fill);
 // the retained points as BalSolver::setup chooses them (one process): flag per residual block; returns their number
-int bal_retained_plan(const Problem& p, int mode, int max_points, int border_mode, std::vector<int>* retained_of_block, double* model_us, double* model_us_without);
+int bal_retained_plan(const Problem& p, int mode, int max_points, int border_mode, std::vector<int>* retained_of_block, double* model_us, double* model_us_without,
+                      bool with_memory_order = true);
 // Generic dense Jacobian path: DENSE_QR / DENSE_NORMAL_CHOLESKY.
 std::unique_ptr<SolverBase> make_dense_solver(const Options& o, Problem* p);
 // Tall dense rows over one parameter block (transposed Jacobian + long-K MFMA SYRK): DENSE_NORMAL_CHOLESKY.

@@ -148,7 +148,12 @@ def test_reduce_buffer_has_room_for_the_pseudo_cameras_of_retained_points():
         nblk = (9 * cams + 1 + 127) // 128
         return 128 * 128 * 8 * nblk * (nblk + 1) // 2
     assert nbytes("off") == tri(40)
-    assert nbytes("auto") == tri(40 + 512) and nbytes("on", 30) == tri(40 + 10)
+    # AUTO retains nothing below 64 cameras: the plain size (it used to add 512 pseudo-cameras whatever the problem);
+    # ON with a count: that many points (as far as the problem has wide tracks), three to a pseudo-camera — what the plan
+    # sk_problem_retained_plan reports, from host data alone
+    assert nbytes("auto") == tri(40)
+    kept = problem.retainedPlan("on", 30)["retained_points"]
+    assert 3 <= kept <= 30 and nbytes("on", 30) == tri(40 + (kept + 2) // 3)
 
 
 def test_predefined_loss_functions_construction_and_validation():

@@ -1128,6 +1128,19 @@ def test_resident_chain_timeout_is_reported_and_refactored():
         assert abs(a - b) <= FULL_SIZE_ORDER_TOL * abs(b)            # (launch by launch after the time-out: another summation order)
     for a, b in zip(hit["step_norms"], clean["step_norms"]):
         assert abs(a - b) <= 1e-9 * max(abs(b), 1e-300)
+    # a JANITOR workgroup of the resident back-substitution that gives up — it may be the only workgroup that
+    # timed out: an owner's clock restarts at every hop, a janitor's first wait spans up to 95 of them — leaves blocks of the
+    # envelope unzeroed, and the next assembly would accumulate onto stale blocks of L.  It must report the time-out itself
+    # (info = 2): the same system is then assembled (after a FULL zero pass) and factored again, launch by launch.  The testing
+    # build lets janitor 0 of the first resident back-substitution give up at once (SK_BS_TEST_JANITOR_GIVEUP=1).
+    jan, err_jan = run({"SK_BS_TEST_JANITOR_GIVEUP": "1", "SKERES_AMD_LIBRARY": testing})
+    assert "timed out" in err_jan
+    assert jan["resident_before"] >= 60 and jan["resident_after"] == 0
+    assert jan["valid"] == [1, 1, 1, 1]
+    for a, b in zip(jan["costs"], clean["costs"]):
+        assert abs(a - b) <= FULL_SIZE_ORDER_TOL * abs(b)
+    for a, b in zip(jan["step_norms"], clean["step_norms"]):
+        assert abs(a - b) <= 1e-9 * max(abs(b), 1e-300)
 
 
 def test_resident_backsolve_is_bitwise_the_launch_by_launch_one(tmp_path):
