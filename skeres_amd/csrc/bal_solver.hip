@@ -904,8 +904,9 @@ static RetainedGraphs retained_graphs(const std::vector<int>& ocam, const std::v
   return r;
 }
 // ocam: cameras in the banded numbering (the best candidate order, no border).  base_us: the model of the plan without retained points.
+// families: bit 0 — the widest tracks by span and by number of observations, in doubling counts; bit 1 — the tracks of loop closures (below)
 static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int mode, int max_points, bool gaps_ok,
-                                             double base_us) {
+                                             double base_us, int families = 3) {
   RetainedChoice out;
   if (mode == SK_RETAINED_OFF) return out;
   if (mode == SK_RETAINED_AUTO && (C < 64 || (9 * C + 128) / 128 < 16)) return out;  // (a reduced system of a few blocks: nothing to gain)
@@ -920,7 +921,7 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
   // Two orders of the candidates: by the span of their cameras (whatever widens the envelope: landmarks AND the tracks of loop
   // closures, which a border of retained points can take as well as a border of cameras can), and by the number of their
   // observations (the landmarks alone — the loop closures are then left to the border of cameras, when the problem has both)
-  for (int by_count = 0; by_count < (exactly ? 1 : 2); ++by_count) {
+  for (int by_count = 0; (families & 1) && by_count < (exactly ? 1 : 2); ++by_count) {
     std::sort(wide.begin(), wide.end(), [&](int a, int b) {
       const int sa = by_count ? cnt[a] : cmax[a] - cmin[a], sb = by_count ? cnt[b] : cmax[b] - cmin[b];
       return sa != sb ? sa > sb : a < b;
@@ -937,6 +938,51 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
       if (bc.model_us < best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; }
       if (bc.model_us > 1.5 * best_here) break;  // (well past the best count of this order: more border rows only cost)
       best_here = std::min(best_here, bc.model_us);
+    }
+  }
+  // A third family (round 5): the tracks of LOOP CLOSURES — points whose ascending camera list has a jump of more than `gap` cameras, the
+  // test choose_border applies to cameras — ALL of them, at their exact number, then the widest of the other tracks behind them.  The
+  // doubling counts above cannot find this set: 0.5 % of the Ladybug-shaped problem's tracks seen from two distant windows are 782 points,
+  // whose rows keep the envelope full until the last one of them is retained (768 points: nothing gained) and cost twice their rows at
+  // the next count (1536); retained exactly — 19 block rows of border — the band keeps its own width.
+  if (!exactly && C >= 64 && (families & 2)) {
+    std::vector<int> pstart(P + 1, 0), pcam(ocam.size());
+    for (int q : opt) pstart[q + 1]++;
+    for (int q = 0; q < P; ++q) pstart[q + 1] += pstart[q];
+    { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (size_t b = 0; b < ocam.size(); ++b) pcam[fill[opt[b]]++] = ocam[b]; }
+    std::vector<int> jump(P, 0);
+    int max_jump = 0;
+    for (int q = 0; q < P; ++q) {
+      std::sort(pcam.begin() + pstart[q], pcam.begin() + pstart[q + 1]);
+      for (int k = pstart[q] + 1; k < pstart[q + 1]; ++k) jump[q] = std::max(jump[q], pcam[k] - pcam[k - 1]);
+      max_jump = std::max(max_jump, jump[q]);
+    }
+    std::vector<int> by_cnt(wide);
+    std::sort(by_cnt.begin(), by_cnt.end(), [&](int a, int b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+    size_t prev_size = 0;
+    for (int gap = 16; gap < C && gap < max_jump; gap *= 2) {
+      std::vector<int> closing;
+      for (int q : wide) if (jump[q] > gap) closing.push_back(q);
+      if (closing.empty()) break;
+      if (dev_knobs().debug_envelope) std::fprintf(stderr, "[skeres_amd] retained candidates: %zu wide tracks with a jump of more than %d cameras (max_points %d)\n", closing.size(), gap, max_points);
+      if ((int)closing.size() > max_points || closing.size() == prev_size) continue;
+      prev_size = closing.size();
+      std::vector<char> in(P, 0);
+      for (int q : closing) in[q] = 1;
+      for (int more : {12, 48}) {  // ... and a few of the landmarks on top (by their number of observations)
+        std::vector<int> pts(closing);
+        int added = 0;
+        for (size_t k = 0; k < by_cnt.size() && (added < more || pts.size() % 3 != 0); ++k)
+          if (!in[by_cnt[k]]) { pts.push_back(by_cnt[k]); ++added; }
+        if (pts.size() % 3 != 0 || (int)pts.size() > max_points + 2) continue;
+        std::sort(pts.begin(), pts.end(), [&](int a, int b) { return cmin[a] != cmin[b] ? cmin[a] > cmin[b] : a < b; });
+        const RetainedGraphs rg = retained_graphs(ocam, opt, C, P, pts);
+        const int nblk = (9 * rg.Cx + 1 + 127) / 128;
+        BorderChoice bc;
+        if (!choose_border(rg.g(C, P), rg.x(), nblk, {}, SK_BORDER_AUTO, gaps_ok, &bc)) continue;
+        if (dev_knobs().debug_envelope) std::fprintf(stderr, "[skeres_amd] retained candidates: gap %d + %d landmarks = %zu points: chain model %.0f us (best so far %.0f, base %.0f)\n", gap, more, pts.size(), bc.model_us, best, base_us);
+        if (bc.model_us < best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; }
+      }
     }
   }
   return out;
@@ -958,14 +1004,38 @@ static ReducedSystemPlan plan_reduced_system(const Problem& p, const std::vector
   out.order = plan_camera_order(p, cam_block, g0, g0, npad, with_memory_order, border_ok, border_mode);
   out.without_us = out.order.model_us;
   if (retained_mode == SK_RETAINED_OFF) return out;
-  std::vector<int> oc(ocam.size());
-  for (size_t b = 0; b < ocam.size(); ++b) oc[b] = out.order.plain_id[ocam[b]];
-  const RetainedChoice rc = choose_retained_points(oc, opt, C, P, retained_mode, retained_max, border_ok, out.order.model_us);
-  if (rc.points.empty()) return out;
-  RetainedGraphs rg = retained_graphs(ocam, opt, C, P, rc.points);
-  const int npadx = ((9 * rg.Cx + 1 + 127) / 128) * 128;
-  CameraOrderPlan px = plan_camera_order(p, cam_block, rg.g(C, P), rg.x(), npadx, with_memory_order, border_ok, border_mode);
-  if (retained_mode == SK_RETAINED_ON || px.model_us < 0.9 * out.order.model_us) { out.order = std::move(px); out.retained = rc.points; out.graphs = std::move(rg); }
+  // The retained points are chosen on a banded numbering of the cameras: the best candidate order as it stands — and, round 5, the
+  // other candidates too: with loop closures all over the sequence the order with the fewest flops is a reverse Cuthill-McKee one in
+  // which every track has jumps, and the tracks that CLOSE loops (choose_retained_points, third family) can only be told from the
+  // others in the capture order (memory order / first appearance).  The chain model of the whole plan compares.
+  std::vector<std::vector<int>> bases;
+  std::vector<int> families;
+  const std::vector<std::vector<int>> cands = camera_order_candidates(p, cam_block, ocam, opt, C, P, with_memory_order);
+  bases.push_back(out.order.plain_id);
+  families.push_back(1 | ((out.order.plain_id == cands[0] || out.order.plain_id == cands[1]) ? 2 : 0));
+  for (int k = 0; k < 2; ++k)  // (the capture orders: first appearance, memory order)
+    if (std::find(bases.begin(), bases.end(), cands[k]) == bases.end()) { bases.push_back(cands[k]); families.push_back(2); }
+  std::vector<std::vector<int>> tried;
+  const CameraOrderPlan without = out.order;
+  for (size_t bi = 0; bi < bases.size(); ++bi) {
+    const std::vector<int>& base = bases[bi];
+    std::vector<int> oc(ocam.size());
+    for (size_t b = 0; b < ocam.size(); ++b) oc[b] = base[ocam[b]];
+    const RetainedChoice rc = choose_retained_points(oc, opt, C, P, retained_mode, retained_max, border_ok, without.model_us, families[bi]);
+    if (rc.points.empty()) continue;
+    std::vector<int> key(rc.points);
+    std::sort(key.begin(), key.end());
+    if (std::find(tried.begin(), tried.end(), key) != tried.end()) continue;
+    tried.push_back(key);
+    RetainedGraphs rg = retained_graphs(ocam, opt, C, P, rc.points);
+    const int npadx = ((9 * rg.Cx + 1 + 127) / 128) * 128;
+    CameraOrderPlan px = plan_camera_order(p, cam_block, rg.g(C, P), rg.x(), npadx, with_memory_order, border_ok, border_mode);
+    const bool first = out.retained.empty();
+    if (first ? (retained_mode == SK_RETAINED_ON || px.model_us < 0.9 * without.model_us) : px.model_us < out.order.model_us) {
+      out.order = std::move(px); out.retained = rc.points; out.graphs = std::move(rg);
+    }
+    if (retained_mode == SK_RETAINED_ON && retained_max > 0) break;  // (an exact count: the widest tracks of the plan's own order)
+  }
   return out;
 }
 

@@ -945,6 +945,48 @@ def test_retained_points_dense_schur_vs_oracle(C, P, N, seed, max_points, extra)
         assert np.abs(x_k - x_off).max() <= 1e-6 * max(1.0, np.abs(x_off).max())
 
 
+def test_loop_closure_tracks_are_retained_vs_oracle():
+    """Scattered loop closures (0.5 % of the tracks seen from two distant windows of the trajectory): in the capture order those tracks
+    are the ones whose camera list has a large jump, and AUTO retains exactly them (choose_retained_points, third family; round 5) —
+    the band keeps its width, where a border of cameras alone left the envelope at 0.87 of the blocks.  The oracle eliminates every
+    point: the same trajectory at 1e-10, and so does the device with retained points off."""
+    C, P, N = 600, 50000, 220000
+    prob = bal.generate(C, P, N, seed=9, long_range_fraction=0.005)
+    problem, params, loss = bal_problem_to_sk(prob)
+    plan = problem.retainedPlan("auto")
+    assert plan["retained_points"] >= 150 and plan["model_us"] < 0.8 * plan["model_us_without"]
+    # the retained points hold (nearly) every track with a jump of more than a quarter of the sequence
+    order = np.lexsort((prob.camera_index, prob.point_index))
+    pt, cam = prob.point_index[order], prob.camera_index[order].astype(np.int64)
+    jump = np.zeros(P, dtype=np.int64)
+    same = pt[1:] == pt[:-1]
+    np.maximum.at(jump, pt[1:][same], (cam[1:] - cam[:-1])[same])
+    kept = np.unique(prob.point_index[plan["retained_of_block"] == 1])
+    closing = np.nonzero(jump > C // 4)[0]
+    assert len(closing) >= 100 and np.isin(closing, kept).mean() >= 0.95
+    options = sk.Solver.Options()
+    options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
+    options.setMaxNumIterations(6)
+    solver = sk.StepSolver(options, problem)
+    assert solver.stat("retained_points") == plan["retained_points"]
+    fill = solver.stat("envelope_fill")
+    while not solver.step():
+        pass
+    summary = sk.Solver.Summary()
+    solver.finish(summary)
+    x_gpu = params.toArray(prob.num_parameters)
+    x_cpu, so = oracle.solve_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=_oracle_threads(), max_num_iterations=6, cholesky_envelope=1))
+    g, c = [it["cost"] for it in summary.iterations()], so.costs()
+    assert len(g) == len(c) == 7
+    for k in range(7):
+        assert abs(g[k] - c[k]) <= 1e-10 * abs(c[k]), (k, g[k], c[k])
+    assert np.linalg.norm(x_gpu - x_cpu) <= 1e-7 * np.linalg.norm(x_cpu - prob.parameters)
+    x_off, s_off = solve_bal_gpu(prob, setRetainedPoints="off", setMaxNumIterations=6)
+    for u, v in zip(summary.iterations(), s_off.iterations()):
+        assert abs(u["cost"] - v["cost"]) <= 1e-10 * v["cost"]
+
+
 def test_retained_points_at_full_size_match_the_all_eliminated_solve_and_the_oracle():
     """Ladybug-1723 at full size: AUTO retains the twelve widest tracks (landmarks seen from up to 392 cameras), the block envelope
     of the reduced system falls to a fifth of its flops, every block column is chain-bound — and FOUR LM iterations agree with the
