@@ -770,6 +770,32 @@ __global__ __launch_bounds__(kBlock) void bal_cam_diag_kernel(BalDev d) {
   }
 }
 
+// Two observations a, b of ONE point by ONE camera (BalDev::dup_*): the cross term of the point's Schur complement between them,
+//   S_ii -= What_a What_b^T + What_b What_a^T   (lower triangle),
+// which the pair lists leave out (block (i, i) is bal_cam_diag_kernel's).  A thread per (pair, entry of the lower triangle); pairs
+// of one camera are added one after the other (one thread per entry walks them: the same sums in the same order, run after run).
+__global__ __launch_bounds__(64) void bal_dup_diag_kernel(BalDev d) {
+  const int first = blockIdx.x;  // index of the first pair of a camera's run (the host lists the pairs camera by camera; one workgroup per run)
+  const int i = d.dup_cam[first];
+  if (first > 0 && d.dup_cam[first - 1] == i) return;
+  if (!d.front[bal_part(d, i)].S) return;
+  const int t = threadIdx.x;
+  if (t >= 45) return;
+  int c = 0, rem = t;
+  while (rem > c) { rem -= c + 1; ++c; }  // t = c (c + 1) / 2 + e2
+  const int e2 = rem;
+  double acc = 0.0;
+  for (int k = first; k < d.num_dup && d.dup_cam[k] == i; ++k) {
+    const double* wa = d.What + (size_t)d.dup_a[k] * kWs;
+    const double* wb = d.What + (size_t)d.dup_b[k] * kWs;
+    acc += (wa[3 * c] * wb[3 * e2] + wa[3 * c + 1] * wb[3 * e2 + 1] + wa[3 * c + 2] * wb[3 * e2 + 2]) +
+           (wb[3 * c] * wa[3 * e2] + wb[3 * c + 1] * wa[3 * e2 + 1] + wb[3 * c + 2] * wa[3 * e2 + 2]);
+  }
+  int ld;
+  double* blk = bal_block(d, i, i, &ld);
+  blk[(size_t)c * ld + e2] -= acc;
+}
+
 // acc[k] += sum over entries e = e_begin, e_begin + stride, ... < e_end of  What[row obs][3c..3c+2] . What[col obs][3k..3k+2].
 // The nine lanes of a block need the same 27 values of the column observation's record: each lane fetches three of them
 // (as it does of the row observation's) and the group shares them through `slot` (its 27 doubles of LDS) — fourteen
@@ -1137,7 +1163,10 @@ void launch_bal_kept_points(const BalDev& d, hipStream_t s) {
   hipLaunchKernelGGL(bal_kept_points_kernel, dim3(obs_blocks + (d.num_kept * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d, obs_blocks);
 }
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
-void launch_bal_cam_diag(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d); }
+void launch_bal_cam_diag(const BalDev& d, hipStream_t s) {
+  hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
+  if (d.num_dup > 0) hipLaunchKernelGGL(bal_dup_diag_kernel, dim3(d.num_dup), dim3(64), 0, s, d);  // (stream order: behind the diagonal blocks it adds to)
+}
 void launch_bal_pair(const BalDev& d, hipStream_t s) {
   // runs of eight logical blocks per XCD (developer variable SK_SCHEDULE_PLAIN=1: plain order.  Measured, Schur-assembly phase per iteration, plain -> 8:
   // Ladybug-1723 0.520 -> 0.499 ms, Venice-1778 3.02 -> 2.79 ms; 32 is worse on Ladybug — profiles/r03_pair_xcd_sweep.txt)

@@ -42,6 +42,12 @@ struct BalDev {
   const int* kept_pt;  const int* kept_cam;
   int num_kept_obs;  const int* kept_obs;  const int* kept_obs_slot;  // the retained points' observations, and which retained point (index into kept_pt) each belongs to
   const unsigned char* pseudo;  // [C]
+  // Two residual blocks on the SAME (camera, point) pair (the reference's set-up loop adds whatever the file holds,
+  // EX/SimpleBundleAdjuster.scala:139-145, and Ceres accepts it): every sum over observations takes both as they stand; what differs is
+  // the Schur complement's cross term between the two, which belongs to the camera's DIAGONAL block — such pairs are not in the pair
+  // lists (one writer per block), bal_dup_diag_kernel adds  -(What_a What_b^T + What_b What_a^T)  behind bal_cam_diag.  Slots of the
+  // camera-major records.  Usually none.
+  int num_dup;  const int* dup_a;  const int* dup_b;  const int* dup_cam;
   // state
   double* xc;  double* xp;          // current parameters [9C], [3P]
   double* xc_new;  double* xp_new;  // candidate
@@ -126,7 +132,7 @@ void launch_final_reduce_rows(const double* partial, int stride, const ReduceRow
 void launch_bal_point_block(const BalDev& d, hipStream_t s);
 void launch_bal_kept_points(const BalDev& d, hipStream_t s);  // after bal_point_block: the retained points' rows of the reduced system; M = 0, q = 0 for them
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s);
-void launch_bal_cam_diag(const BalDev& d, hipStream_t s);
+void launch_bal_cam_diag(const BalDev& d, hipStream_t s);  // (+ the cross terms of duplicate (camera, point) pairs, when there are any)
 void launch_bal_pair(const BalDev& d, hipStream_t s);
 void launch_finish_normal_matrix(double* S, int ld, int n, int npad, int rhs_row, const double* D, hipStream_t s);
 void launch_bal_finish_S(const BalDev& d, int parts, hipStream_t s);  // D_c^2 onto the diagonal entries of the cameras of `parts` (bit mask)

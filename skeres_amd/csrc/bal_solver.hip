@@ -280,6 +280,8 @@ class BalSolver : public SolverBase {
   std::vector<int> struct_ocam_, struct_opt_;   // the structure of the reduced system WITH pseudo-cameras (retained_graphs), final numbering; empty: ocam / opt as they are
   int struct_P_ = 0;
   DevBuf<int> b_kept_pt_, b_kept_cam_, b_kept_obs_, b_kept_obs_slot_;
+  DevBuf<int> b_dup_a_, b_dup_b_, b_dup_cam_;  // two residual blocks on one (camera, point) pair: BalDev::dup_*
+  int num_dup_ = 0;
   int num_kept_obs_ = 0;
   DevBuf<unsigned char> b_pseudo_;
   int border_cams_ = 0, border_gap_ = 0;          // cameras in that border; the jump in a point's camera list that made a visit
@@ -392,15 +394,25 @@ static std::vector<int> envelope_of_order(const std::vector<int>& ocam, const st
 // by a model of the two chains (microseconds per block column; constants measured on MI355X, profiles/r02_*): a block
 // column costs the larger of its panel chain and its trailing update.
 struct Dissection { int a = 0, b = 0; double t_plain = 0.0, t_dissected = 0.0; };
+// Round 5: recalibrated on the bench line's chain_model records of round 4 (measured / model was 1.22-1.47 on the plans with retained
+// points — every column chain-bound, two fronts in lock-step — 0.98 with every point eliminated, 0.83-0.89 on wide envelopes):
+//   - a chain-bound column's cycle is the LONGER of the panel chain (40 us; 44.5 us when two fronts share the launches) and the thin
+//     trailing SYRK it overlaps with, which the next column launch but one waits for: 12 us + 0.049 us per 32 x 128 tile, + 8 us of
+//     hand-over (180 tiles 21 us, 760 tiles 49 us: profiles/r04_factor_timeline*.txt; "40-50 us up to 13 trailing rows, 60 at 20, 100
+//     at 30" of round 1 is the same line);
+//   - wide updates run at 38 TFLOP/s at a few dozen block rows and at 44-46 towards a full matrix (roofline_full: 44.9);
+//   - the back-substitution is part of the phase the model is held against: 3.3 us per block column of a resident launch (+ 20 us).
+static double thin_syrk_us(double tiles) { return tiles > 0.0 ? 12.0 + 0.049 * tiles : 0.0; }
+static double thin_tiles(int h) { return h > 1 ? 2.0 * (h - 1.0) * h : 0.0; }  // 32 x 128 tiles of the trailing update behind the next block column: h - 1 block rows, lower triangle
 static double column_cost_us(int h, bool resident_capable) {
-  // trailing update: 14 TFLOP/s where it is a few dozen thin tiles, 38 TFLOP/s (+ 14 us between launches) where it is wide
   const double flops = 128.0 * 128.0 * 128.0 * ((double)h * h + h);
-  // (round 4, recalibrated on the bench line's chain_model records — the wide launches ran at 38-44 TFLOP/s in situ where 32 + 20 us
-  // was assumed: measured / model was 0.69-0.75 on the wide envelopes of the loop-closure problems, 0.87-0.9 on the banded ones)
-  const double update_us = h > 24 ? flops / 38e6 + 14.0 : flops / 14e6;
-  const double chain_us = (resident_capable && h <= 24) ? 42.0 : 70.0;  // resident panel chain / four launches per column
-  return std::max(update_us, chain_us);
+  if (resident_capable && h <= 24) return std::max(40.0, thin_syrk_us(thin_tiles(h)) + 8.0);
+  if (h <= 24) return std::max(70.0, flops / 14e6);  // four launches per column
+  return flops / (std::min(46.0, 34.0 + 0.12 * h) * 1e6) + 14.0;
 }
+// two chain-bound block columns, one of each leaf front, in ONE column launch and ONE thin SYRK (the lock-step dissection)
+static double pair_cost_us(int h1, int h2) { return std::max(44.5, thin_syrk_us(thin_tiles(h1) + thin_tiles(h2)) + 8.0); }
+static double backsolve_us(int block_columns) { return block_columns > 0 ? 20.0 + 3.3 * block_columns : 0.0; }
 // tail_resident: the tail has a device of its own (segmented world) and runs under a resident panel chain like the head;
 // on one device it is factored launch by launch next to the head's chain.
 // lockstep: the schedule of ONE device since the end of round 3 — the tail's block columns ride in the launches of the head's
@@ -423,16 +435,18 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
   for (int c = 1; c < C; ++c) reach[c] = std::max(reach[c], reach[c - 1]);
   // per block column: height forward (rows below, as the envelope has it) and backward (rows above: the tail's view)
   std::vector<double> fwd(nblk), bwd(nblk), fwd_sum(nblk + 1, 0.0), bwd_sum(nblk + 1, 0.0);
-  std::vector<int> height(nblk);
+  std::vector<int> height(nblk), height_b(nblk);
   std::vector<int> fc(first_col);
   for (int i = nblk - 2; i >= 0; --i) fc[i] = std::min(fc[i], fc[i + 1] < i + 1 ? fc[i + 1] : i);  // (monotone, as the backward envelope is)
   for (int c = 0; c < nblk; ++c) {
     const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0) + (extra_fwd && c < (int)extra_fwd->size() ? (*extra_fwd)[c] : 0);
     height[c] = hf;
     fwd[c] = column_cost_us(hf, true);
-    bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1 + extra_bwd, tail_resident);
+    height_b[c] = c - std::min(fc[c], c) + 1 + extra_bwd;
+    bwd[c] = column_cost_us(height_b[c], tail_resident);
     d.t_plain += fwd[c];
   }
+  d.t_plain += backsolve_us(nblk + (extra_sep > 0 ? (9 * extra_sep + 127) / 128 : 0));
   for (int c = 0; c < nblk; ++c) { fwd_sum[c + 1] = fwd_sum[c] + fwd[c]; bwd_sum[c + 1] = bwd_sum[c] + bwd[c]; }
   double best = d.t_plain;
   for (int a = 14; a + 14 < C; a += 7) {
@@ -442,14 +456,16 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
     if (E > 24) continue;  // a separator that wide is no separator: its dense system is factored after both chains, alone
     double root = 0.0;
     for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i, true);
-    double t = std::max(fwd_sum[ca], bwd_sum[nblk] - bwd_sum[cb]) + root + 120.0;  // + fork, join, border add
+    // (+ the back-substitutions: the root's, then the two interiors side by side)
+    const double bs = backsolve_us(E) + backsolve_us(std::max(ca, nblk - cb)) + 20.0;
+    double t = std::max(fwd_sum[ca], bwd_sum[nblk] - bwd_sum[cb]) + root + 120.0 + bs;  // + fork, join, border add
     if (lockstep) {
       // the head's chain-bound columns (its first few, and its trailing run) each carry one of the tail's; the others cost what they cost
       const int nb = nblk - cb;
       int k = 0;
-      t = root + 250.0;  // + border add, a second resident server's set-up, two more back-substitution launches
+      t = root + 180.0 + bs;  // + border add, a second resident server's set-up, the zeroing left to the assembly
       for (int c = 0; c < ca; ++c) {
-        if (height[c] <= 24 && k < nb) { t += std::max(fwd[c], bwd[nblk - 1 - k]); ++k; }
+        if (height[c] <= 24 && k < nb) { t += height_b[nblk - 1 - k] <= 24 ? pair_cost_us(height[c], height_b[nblk - 1 - k]) : std::max(fwd[c], bwd[nblk - 1 - k]); ++k; }
         else t += fwd[c];
       }
       for (; k < nb; ++k) t += bwd[nblk - 1 - k];
@@ -519,7 +535,8 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
       out.t_plain += fwd[c];
     }
     for (int c = 0; c < nblk; ++c) { fwd_sum[c + 1] = fwd_sum[c] + fwd[c]; bwd_sum[c + 1] = bwd_sum[c] + bwd[c]; }
-    out.model_us[1] = out.t_plain;
+    out.model_us[1] = out.t_plain + backsolve_us(nblk);
+    const double plain_with_solve = out.model_us[1];
     auto sep_blocks = [&](int a) { return (9 * (reach[a - 1] + 1 - a) + 1 + 127) / 128; };
     // room[k]: the last camera at which a segment may START so that k more cuts (each a candidate below, each followed by a
     // segment of at least 14 cameras) still fit behind it
@@ -550,7 +567,7 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
       }
       return bwd_sum[nblk] - bwd_sum[(9 * pos) / 128] <= T;
     };
-    double best = out.t_plain;
+    double best = plain_with_solve;
     std::vector<int> best_as;
     for (int Rn = 2; Rn <= max_segments; ++Rn) {
       std::vector<int> as;
@@ -573,7 +590,9 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
       }
       const int W = std::max(2, world);
       const double allreduce_us = 50.0 + 2.0 * (W - 1.0) / W * blocks * 128.0 * 128.0 * 8.0 / 153e3;
-      const double t = hi + root + 170.0 + allreduce_us;  // + fork, join, border add
+      int root_blocks = 0;
+      for (size_t k = 0; k < as.size(); ++k) root_blocks += sep_blocks(as[k]);
+      const double t = hi + root + 170.0 + allreduce_us + backsolve_us(root_blocks) + backsolve_us((nblk + Rn - 1) / Rn);  // + fork, join, border add; the root's and a segment's back-substitution
       out.model_us[Rn] = t;
       if (dev_knobs().debug_segments) std::fprintf(stderr, "[skeres_amd] %d segments: longest chain %.0f us, root %.0f us, all-reduce %.0f us (%.0f blocks) -> %.0f us (undissected %.0f)\n", Rn, hi, root, allreduce_us, blocks, t, out.t_plain);
       // (forced: a segment per rank, as far as the sequence can be cut; otherwise a further segment has to beat the plan so far by
@@ -581,7 +600,7 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
       if (forced ? true : t < best * (Rn > 2 ? 0.95 : 1.0)) { best = t; best_as = as; }
     }
     out.t_model = best;
-    if (!best_as.empty() && (forced || best <= 0.9 * out.t_plain)) {
+    if (!best_as.empty() && (forced || best <= 0.9 * plain_with_solve)) {
       for (int a : best_as) { out.a.push_back(a); out.b.push_back(reach[a - 1] + 1); }
       return out;
     }
@@ -706,7 +725,7 @@ static double envelope_model_us(int nblk, const std::vector<int>& last, const in
     const int h = main_rows + std::max(0, nblk - std::max(t0, c + 1 + main_rows));
     t += column_cost_us(h, true);
   }
-  return t;
+  return t + backsolve_us(nblk);
 }
 // A camera graph: per observation its camera and its point.  Two of them describe a problem with RETAINED points (below): `g`, the
 // observations of the points the Schur complement eliminates, over the C real cameras; `x`, the structure of the reduced system —
@@ -912,8 +931,16 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
   if (mode == SK_RETAINED_AUTO && (C < 64 || (9 * C + 128) / 128 < 16)) return out;  // (a reduced system of a few blocks: nothing to gain)
   std::vector<int> cmin(P, C), cmax(P, -1), cnt(P, 0);
   for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); cnt[opt[b]]++; }
+  // (a point with two residual blocks on one camera is never retained: the rows of a retained point have one writer per block)
+  std::vector<char> twice(P, 0);
+  {
+    std::vector<long long> key(ocam.size());
+    for (size_t b = 0; b < ocam.size(); ++b) key[b] = (long long)opt[b] * C + ocam[b];
+    std::sort(key.begin(), key.end());
+    for (size_t b = 1; b < key.size(); ++b) if (key[b] == key[b - 1]) twice[(size_t)(key[b] / C)] = 1;
+  }
   std::vector<int> wide;
-  for (int q = 0; q < P; ++q) if (cnt[q] >= 2 && 9 * (cmax[q] - cmin[q]) >= 128) wide.push_back(q);
+  for (int q = 0; q < P; ++q) if (cnt[q] >= 2 && 9 * (cmax[q] - cmin[q]) >= 128 && !twice[q]) wide.push_back(q);
   const bool exactly = mode == SK_RETAINED_ON && max_points > 0;  // (ON with a count: that many, as far as there are candidates)
   if (max_points <= 0) max_points = 1536;
   max_points = std::min(max_points - max_points % 3, (int)wide.size() - (int)wide.size() % 3);
@@ -1467,8 +1494,11 @@ int BalSolver::setup() {
     } else {
       for (int k = 0; k < nobs; ++k) obs[(size_t)k * N_ + o] = p.consts[p.rb_const_off[b] + k];
     }
-    if (o > 0 && pt[o] == pt[o - 1] && cam[o] == cam[o - 1]) { set_error("two residual blocks share the same (camera, point) pair: not supported by the Schur path"); return SK_ERR_UNSUPPORTED; }
   }
+  // Two residual blocks on one (camera, point) pair (the reference's set-up loop adds whatever the file holds: EX/SimpleBundleAdjuster.scala:139-145):
+  // both observations enter every sum; their cross term of the Schur complement belongs to the camera's diagonal block (BalDev::dup_*)
+  bool has_dup = false;
+  for (int o = 1; o < N_ && !has_dup; ++o) has_dup = pt[o] == pt[o - 1] && cam[o] == cam[o - 1];
   // camera CSR (ascending point because observation order is point-major)
   std::vector<int> cam_start(C_ + 1, 0), cam_obs(N_);
   for (int o = 0; o < N_; ++o) cam_start[cam[o] + 1]++;
@@ -1485,6 +1515,27 @@ int BalSolver::setup() {
   // pair lists: for every point that is eliminated, every (larger camera, smaller camera) pair of its observations
   size_t npairs = 0;
   for (int q = 0; q < P_; ++q) { if (kept_of_local[q] >= 0) continue; const size_t k = pt_start[q + 1] - pt_start[q]; npairs += k * (k - 1) / 2; }
+  std::vector<int> dup_a, dup_b, dup_cam;  // (observation indices here; record slots below)
+  if (has_dup) {
+    npairs = 0;
+    for (int q = 0; q < P_; ++q) {
+      bool q_dup = false;
+      for (int b = pt_start[q] + 1; b < pt_start[q + 1]; ++b)
+        for (int a = pt_start[q]; a < b; ++a) {
+          if (cam[b] != cam[a]) { if (kept_of_local[q] < 0) ++npairs; continue; }
+          q_dup = true;
+          dup_a.push_back(a); dup_b.push_back(b); dup_cam.push_back(cam[a]);
+        }
+      if (q_dup && kept_of_local[q] >= 0) { set_error("internal: a retained point has two residual blocks on one camera"); return SK_ERR_UNSUPPORTED; }
+    }
+    // camera by camera (bal_dup_diag_kernel: one workgroup per camera's run)
+    std::vector<int> ord(dup_cam.size());
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return dup_cam[x] < dup_cam[y]; });
+    std::vector<int> a2(ord.size()), b2(ord.size()), c2(ord.size());
+    for (size_t k = 0; k < ord.size(); ++k) { a2[k] = dup_a[ord[k]]; b2[k] = dup_b[ord[k]]; c2[k] = dup_cam[ord[k]]; }
+    dup_a.swap(a2); dup_b.swap(b2); dup_cam.swap(c2);
+  }
   if (npairs > 2000000000ull) { set_error("pair list too large"); return SK_ERR_UNSUPPORTED; }
   std::vector<int> pair_row(npairs), pair_col(npairs), seg_start, seg_row, seg_col;
   {
@@ -1493,7 +1544,7 @@ int BalSolver::setup() {
     for (int q = 0; q < P_; ++q) {
       if (kept_of_local[q] >= 0) continue;
       for (int b = pt_start[q] + 1; b < pt_start[q + 1]; ++b)
-        for (int a = pt_start[q]; a < b; ++a) count[(size_t)cam[b] * C_ + cam[a] + 1]++;
+        for (int a = pt_start[q]; a < b; ++a) if (cam[b] != cam[a]) count[(size_t)cam[b] * C_ + cam[a] + 1]++;
     }
     seg_start.push_back(0);
     std::vector<unsigned> pos(CC, 0);
@@ -1505,7 +1556,7 @@ int BalSolver::setup() {
     for (int q = 0; q < P_; ++q) {  // ascending point => entries of a segment are in ascending point order
       if (kept_of_local[q] >= 0) continue;
       for (int b = pt_start[q] + 1; b < pt_start[q + 1]; ++b)
-        for (int a = pt_start[q]; a < b; ++a) { const unsigned e = pos[(size_t)cam[b] * C_ + cam[a]]++; pair_row[e] = b; pair_col[e] = a; }
+        for (int a = pt_start[q]; a < b; ++a) { if (cam[b] == cam[a]) continue; const unsigned e = pos[(size_t)cam[b] * C_ + cam[a]]++; pair_row[e] = b; pair_col[e] = a; }
     }
   }
   // ---- device buffers ----
@@ -1520,7 +1571,11 @@ int BalSolver::setup() {
     // the pair lists address the What records, which are in camera-major order (bal_kernels.hpp: kWs)
     for (int& v : pair_row) v = slot[v];
     for (int& v : pair_col) v = slot[v];
+    for (int& v : dup_a) v = slot[v];
+    for (int& v : dup_b) v = slot[v];
   }
+  if (!dup_cam.empty()) { SK_HIP_TRY(b_dup_a_.upload(dup_a, s)); SK_HIP_TRY(b_dup_b_.upload(dup_b, s)); SK_HIP_TRY(b_dup_cam_.upload(dup_cam, s)); }
+  num_dup_ = (int)dup_cam.size();
   SK_HIP_TRY(b_seg_start_.upload(seg_start, s)); SK_HIP_TRY(b_seg_row_.upload(seg_row, s)); SK_HIP_TRY(b_seg_col_.upload(seg_col, s));
   SK_HIP_TRY(b_pair_row_.upload(pair_row, s)); SK_HIP_TRY(b_pair_col_.upload(pair_col, s));
   std::vector<int> short_segs, long_segs;
@@ -1689,6 +1744,7 @@ int BalSolver::setup() {
   d_.C = C_; d_.P = P_; d_.N = N_;
   d_.pseudo = pseudo_cams_ > 0 ? b_pseudo_.p : nullptr; d_.num_kept = pseudo_cams_ > 0 ? (int)kept_pt.size() : 0; d_.kept_pt = b_kept_pt_.p; d_.kept_cam = b_kept_cam_.p;
   d_.num_kept_obs = pseudo_cams_ > 0 ? num_kept_obs_ : 0; d_.kept_obs = b_kept_obs_.p; d_.kept_obs_slot = b_kept_obs_slot_.p;
+  d_.num_dup = num_dup_; d_.dup_a = b_dup_a_.p; d_.dup_b = b_dup_b_.p; d_.dup_cam = b_dup_cam_.p;
   d_.res_size = res_size_; d_.cam_size = cam_size_; d_.pt_size = pt_size_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p; d_.obs_slot = b_obs_slot_.p;
   d_.num_segments = (int)seg_row.size(); d_.seg_start = b_seg_start_.p; d_.seg_row = b_seg_row_.p; d_.seg_col = b_seg_col_.p;

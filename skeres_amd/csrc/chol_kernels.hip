@@ -1424,7 +1424,7 @@ static DeviceQueues* create_device_queues(int dev) {
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   // CUs per XCD kept free of the SYRK; developer knobs (0 = no mask)
   // (settled by the sweeps of rounds 1 and 2: profiles/r02_cu_reservation_sweep.txt, tools/sweep_early_tiles.sh)
-  const int per_xcd = 4, per_xcd_early = 2, early_tiles = 72;
+  const int per_xcd = dev_knobs().bulk_reserve >= 0 ? dev_knobs().bulk_reserve : 4, per_xcd_early = dev_knobs().bulk_reserve_early >= 0 ? dev_knobs().bulk_reserve_early : 2, early_tiles = 72;
   if (dev_knobs().queue_shift > 0) {  // developer variable SK_QUEUE_SHIFT: extra queues first, as another library in the process would create them
     std::vector<uint32_t> all((size_t)(ncu + 31) / 32, 0xffffffffu);
     for (int k = 0; k < dev_knobs().queue_shift; ++k) {

@@ -945,6 +945,32 @@ def test_retained_points_dense_schur_vs_oracle(C, P, N, seed, max_points, extra)
         assert np.abs(x_k - x_off).max() <= 1e-6 * max(1.0, np.abs(x_off).max())
 
 
+@pytest.mark.parametrize("C,P,N,seed,ndup", [(16, 600, 2600, 11, 5), (150, 3000, 14000, 5, 40)])
+def test_two_residual_blocks_on_one_camera_point_pair_vs_oracle(C, P, N, seed, ndup):
+    """The reference's set-up loop adds a residual block per line of the file, whatever it holds (EX/SimpleBundleAdjuster.scala:139-145),
+    and Ceres accepts two blocks on the same (camera, point) pair.  Until round 5 the Schur path refused them (one writer per block
+    of the reduced system: the cross term of such a pair belongs to the camera's DIAGONAL block); now they stay out of the pair lists
+    and bal_dup_diag_kernel adds their cross term behind the diagonal blocks.  Against the oracle, whose assembly takes them as they
+    come: 1e-10 per iteration — also with one pair tripled, and with the widest tracks retained (a duplicated point is never retained)."""
+    prob = bal.generate(C, P, N, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    pick = rng.choice(prob.num_observations, size=ndup, replace=False)
+    pick = np.concatenate([pick, pick[:1]])  # (the first pair three times)
+    cam = np.concatenate([prob.camera_index, prob.camera_index[pick]])
+    pt = np.concatenate([prob.point_index, prob.point_index[pick]])
+    obs = np.concatenate([prob.observations, prob.observations[pick] + rng.normal(0, 0.7, size=(len(pick), 2))])
+    shuffle = rng.permutation(len(cam))
+    dup = bal.BalProblem(C, P, cam[shuffle].astype(np.int32), pt[shuffle].astype(np.int32), obs[shuffle], prob.parameters.copy())
+    x_cpu, so = oracle.solve_bal(C, P, dup.camera_index, dup.point_index, dup.observations, dup.parameters,
+                                 oracle.default_options(linear_solver_type=oracle.DENSE_SCHUR, num_threads=4))
+    for kw in ({}, {"setRetainedPoints": ("on", 6), "setGraphReplay": False}, {"setCholeskyDissection": "on"}):
+        x_gpu, sg = solve_bal_gpu(dup, **kw)
+        _check_against_oracle(dup, sg, x_gpu, so, x_cpu)
+    # (the duplicates matter: the same problem without them has another optimum)
+    x0, s0 = solve_bal_gpu(prob)
+    assert abs(s0.finalCost() - so.final_cost) > 1e-6 * so.final_cost
+
+
 def test_loop_closure_tracks_are_retained_vs_oracle():
     """Scattered loop closures (0.5 % of the tracks seen from two distant windows of the trajectory): in the capture order those tracks
     are the ones whose camera list has a large jump, and AUTO retains exactly them (choose_retained_points, third family; round 5) —
