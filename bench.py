@@ -442,6 +442,7 @@ def main():
     ap.add_argument("--full-factorisation", action="store_true", help="factor every 128-block of the reduced system (no block envelope)")
     ap.add_argument("--no-resident-kernels", action="store_true", help="sk_options_set_resident_kernels(o, 0): the same plans launch by launch (counter-collection passes)")
     ap.add_argument("--dissection", default="auto", choices=["auto", "on", "off"], help="(tuning) two-way dissection of the camera sequence on ONE device")
+    ap.add_argument("--retained", default="auto", help="(tuning) retained points: auto, off, or a count (sk_options_set_retained_points(o, ON, count))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -498,6 +499,8 @@ def main():
     options.setCholeskyTuning(args.group, not args.no_lookahead)
     options.setCholeskyEnvelope(not args.full_factorisation)
     options.setCholeskyDissection(args.dissection)
+    if args.retained != "auto":
+        options.setRetainedPoints("off") if args.retained == "off" else options.setRetainedPoints("on", int(args.retained))
     if args.no_resident_kernels:
         options.setResidentKernels(False)
     # a stream of our own, not torch's default (null) stream: the null stream synchronises implicitly with every

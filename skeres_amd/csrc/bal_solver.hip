@@ -424,7 +424,7 @@ static double backsolve_us(int block_columns) { return block_columns > 0 ? 20.0 
 // profile is not known (its columns reach the border's rows in another order): all of them.
 static Dissection choose_dissection(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
                                     const std::vector<int>& first_col, bool tail_resident, bool lockstep = false, int extra_sep = 0,
-                                    const std::vector<int>* extra_fwd = nullptr, int extra_bwd = 0) {
+                                    const std::vector<int>* extra_fwd = nullptr, int extra_bwd = 0, const std::vector<int>* extra_bwd_col = nullptr) {
   Dissection d;
   if (C < 64 || nblk < 24) return d;
   // reach[c]: the last camera that shares a point with any camera <= c (cameras in the chosen order)
@@ -442,7 +442,7 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
     const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0) + (extra_fwd && c < (int)extra_fwd->size() ? (*extra_fwd)[c] : 0);
     height[c] = hf;
     fwd[c] = column_cost_us(hf, true);
-    height_b[c] = c - std::min(fc[c], c) + 1 + extra_bwd;
+    height_b[c] = c - std::min(fc[c], c) + 1 + (extra_bwd_col && c < (int)extra_bwd_col->size() ? (*extra_bwd_col)[c] : extra_bwd);
     bwd[c] = column_cost_us(height_b[c], tail_resident);
     d.t_plain += fwd[c];
   }
@@ -962,7 +962,11 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
       const int nblk = (9 * rg.Cx + 1 + 127) / 128;
       BorderChoice bc;
       if (!choose_border(rg.g(C, P), rg.x(), nblk, {}, SK_BORDER_AUTO, gaps_ok, &bc)) continue;
-      if (bc.model_us < best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; }
+      if (dev_knobs().debug_envelope) std::fprintf(stderr, "[skeres_amd] retained candidates: the %d widest tracks by %s: chain model %.0f us (best so far %.0f, base %.0f)\n", R, by_count ? "observations" : "span", bc.model_us, best, base_us);
+      // (a LARGER set has to beat a smaller one by 2 %: the model is no finer than that — 12 against 24 points on Ladybug-1723 are 5304
+      // against 5303 us in the model and 3.69 against 3.87 ms of Cholesky phase on the device — and every retained point is three more rows
+      // that every later column carries)
+      if (bc.model_us < (out.points.empty() || pts.size() <= out.points.size() ? 1.0 : 0.98) * best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; }
       if (bc.model_us > 1.5 * best_here) break;  // (well past the best count of this order: more border rows only cost)
       best_here = std::min(best_here, bc.model_us);
     }
@@ -1008,7 +1012,7 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
         BorderChoice bc;
         if (!choose_border(rg.g(C, P), rg.x(), nblk, {}, SK_BORDER_AUTO, gaps_ok, &bc)) continue;
         if (dev_knobs().debug_envelope) std::fprintf(stderr, "[skeres_amd] retained candidates: gap %d + %d landmarks = %zu points: chain model %.0f us (best so far %.0f, base %.0f)\n", gap, more, pts.size(), bc.model_us, best, base_us);
-        if (bc.model_us < best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; }
+        if (bc.model_us < (out.points.empty() || pts.size() <= out.points.size() ? 1.0 : 0.98) * best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; }
       }
     }
   }
@@ -1331,15 +1335,29 @@ int BalSolver::setup() {
       // lost its chain, a single device stays undissected)
       const bool lockstep_cut = !multi && opt_.dissection == SK_DISSECTION_AUTO && opt_.resident_kernels && cholesky_chain_enabled(&chol_ctx_);
       // (the border's rows that a band column reaches on top of its run: the tail profile of the bordered envelope)
-      std::vector<int> extra_fwd;
+      std::vector<int> extra_fwd, extra_bwd_col;
       int extra_bwd = 0;
       if (pseudo_border) {
         extra_fwd.assign(dnblk, 0);
         for (int c = 0; c < dnblk && c < (int)env_tail_.size(); ++c) extra_fwd[c] = std::max(0, nblk - 1 - std::max(env_tail_[c], c + 1));
         // (the tail front reaches the border's rows in another order; counting all of them in every one of its columns moved the cut of
-        // Venice-1778 to a worse place — Cholesky phase 5.26 against 4.94 ms — counting none did not: extra_bwd stays 0)
+        // Venice-1778 to a worse place — Cholesky phase 5.26 against 4.94 ms — and counting none made the model of a border of 800 retained
+        // points 40 % too low (round 5: 6.1 against 10.1 ms with the tracks of scattered loop closures retained).  Counted per column: a
+        // member of the border is active in the tail's columns from the LAST band camera that sees it back to the cut.)
+        const std::vector<int>& xo = struct_ocam_.empty() ? ocam : struct_ocam_;
+        const std::vector<int>& xp = struct_ocam_.empty() ? opt : struct_opt_;
+        const int xP = struct_ocam_.empty() ? P_total_ : struct_P_;
+        std::vector<int> pmax(xP, -1), reach_max(C_ - Cband, -1);
+        for (size_t b = 0; b < xo.size(); ++b) if (xo[b] < Cband) pmax[xp[b]] = std::max(pmax[xp[b]], xo[b]);
+        for (size_t b = 0; b < xo.size(); ++b) if (xo[b] >= Cband) reach_max[xo[b] - Cband] = std::max(reach_max[xo[b] - Cband], pmax[xp[b]]);
+        std::vector<int> active(dnblk + 1, 0);  // members whose last band camera lies in block column c or behind it
+        for (int m : reach_max) if (m >= 0) active[std::min(dnblk - 1, (9 * m) / 128)]++;
+        for (int c = dnblk - 2; c >= 0; --c) active[c] += active[c + 1];
+        extra_bwd_col.assign(dnblk, 0);
+        for (int c = 0; c < dnblk; ++c) extra_bwd_col[c] = (9 * active[c] + 127) / 128;
       }
-      ds = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, lockstep_cut, lockstep_cut, C_ - Cband, pseudo_border ? &extra_fwd : nullptr, extra_bwd);
+      ds = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, lockstep_cut, lockstep_cut, C_ - Cband, pseudo_border ? &extra_fwd : nullptr, extra_bwd,
+                             pseudo_border ? &extra_bwd_col : nullptr);
       if (lockstep_cut && ds.a > 0) {  // (two resident servers per factorisation: the fifth such solver alive on a device stays undissected)
         if (!pair_claimed_) pair_claimed_ = cholesky_claim_pair_servers(&chol_ctx_);
         if (!pair_claimed_) ds.a = ds.b = 0;
