@@ -427,15 +427,33 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 1
     const double e = __builtin_fma(-d, y, 1.0);
+#if SK_PROBE_VARIANT == 3
+    // (probe: the next column's value without waiting for the refined multiplier m — a[j+1] - m0 (1 + q) l1 as (a[j+1] - p) - q p with
+    // p = m0 l1 formed BESIDE the refinement: the dependent chain is rcp, e, q, a[j+1] instead of rcp, e, q, m, a[j+1])
+    const double pch = m0 * l1;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     SK_FILL(1)
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 2
     const double q = __builtin_fma(e, e, e);
+#if SK_PROBE_VARIANT == 3
+    const double t1 = j + 1 < 32 ? a[j + 1] - pch : 0.0;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     SK_FILL(2)
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 3
+#if SK_PROBE_VARIANT == 3
+    if (j + 1 < 32) {
+      a[j + 1] = __builtin_fma(-q, pch, t1);
+      colbuf[((j + 1) % 3) * 64 + lane] = a[j + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SK_FILL(3)
+    __builtin_amdgcn_sched_barrier(0);
+    const double m = __builtin_fma(m0, q, m0);  // (for the late updates of the next step)
+#else
     const double m = __builtin_fma(m0, q, m0);
     __builtin_amdgcn_sched_barrier(0);
     SK_FILL(3)
@@ -445,6 +463,7 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
       a[j + 1] = __builtin_fma(-m, l1, a[j + 1]);
       colbuf[((j + 1) % 3) * 64 + lane] = a[j + 1];
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     SK_FILL(4)
     __builtin_amdgcn_sched_barrier(0);
