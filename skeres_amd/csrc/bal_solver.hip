@@ -948,6 +948,7 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
   // Two orders of the candidates: by the span of their cameras (whatever widens the envelope: landmarks AND the tracks of loop
   // closures, which a border of retained points can take as well as a border of cameras can), and by the number of their
   // observations (the landmarks alone — the loop closures are then left to the border of cameras, when the problem has both)
+  std::vector<std::vector<int>> seen_sets;
   for (int by_count = 0; (families & 1) && by_count < (exactly ? 1 : 2); ++by_count) {
     std::sort(wide.begin(), wide.end(), [&](int a, int b) {
       const int sa = by_count ? cnt[a] : cmax[a] - cmin[a], sb = by_count ? cnt[b] : cmax[b] - cmin[b];
@@ -958,6 +959,9 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
       std::vector<int> pts(wide.begin(), wide.begin() + R);
       // pseudo-cameras in the order the border wants them: the points reached first come last
       std::sort(pts.begin(), pts.end(), [&](int a, int b) { return cmin[a] != cmin[b] ? cmin[a] > cmin[b] : a < b; });
+      // (the same set of points under the other order — the landmarks are usually the widest tracks by either measure — is not planned twice:
+      // a candidate of Venice-1778's size costs most of a second)
+      { std::vector<int> key(pts); std::sort(key.begin(), key.end()); if (std::find(seen_sets.begin(), seen_sets.end(), key) != seen_sets.end()) continue; seen_sets.push_back(key); }
       const RetainedGraphs rg = retained_graphs(ocam, opt, C, P, pts);
       const int nblk = (9 * rg.Cx + 1 + 127) / 128;
       BorderChoice bc;
@@ -967,7 +971,7 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
       // every later column carries.  Ladybug-1723, one box, Cholesky phase per iteration with 6 / 12 / 24 points retained: 4.06 / 3.82 /
       // 3.92 ms, where the model says 5362 / 5304 / 5303 us — profiles/r05_retained_count_ab.txt)
       if (bc.model_us < (out.points.empty() || pts.size() <= out.points.size() ? 1.0 : 0.99) * best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; }
-      if (bc.model_us > 1.5 * best_here) break;  // (well past the best count of this order: more border rows only cost)
+      if (bc.model_us > 1.25 * best_here) break;  // (well past the best count of this order: more border rows only cost)
       best_here = std::min(best_here, bc.model_us);
     }
   }

@@ -844,7 +844,15 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 // resident before the first column launch, and every wait gives up after kChainTimeoutTicks (then sets
 // the abort flag, which ends every other wait, and *info): the grid always drains.
 // ---------------------------------------------------------------------------
-enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncSyrkColumn = 3, kSyncHeader = 8 };  // then diag_ready[maxblk], x_ready[maxblk]
+// kSyncServerXcc .. kSyncDSlot: the XCD-local hand-over of round 5 (below): the server's XCD (+ 1), the column it has factored last (a flag that
+// lives in that XCD's L2), and sixteen slots each for the tiles of block row j + 1 — X(j+1,j) formed / S(j+1,j+1) updated — 64-byte aligned
+// so that one scalar load reads all sixteen.
+enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncSyrkColumn = 3, kSyncServerXcc = 4, kSyncPotrfFast = 5,
+             kSyncXSlot = 16, kSyncDSlot = 32, kSyncHeader = 64 };  // then diag_ready[maxblk], x_ready[maxblk], ticket[maxblk]
+constexpr int kSyncArrays = 3;
+// Workgroups at the head of a column launch that may become one of the 16 tiles of block row j + 1: those that find themselves on the
+// potrf server's XCD take a ticket, the first sixteen get a tile, the others leave (workgroups go to the eight XCDs round-robin: 20 each)
+constexpr int kCritCandidates = 160;
 constexpr long long kChainTimeoutTicks = 100000000;  // 1 s of the 100 MHz wall clock (a block column takes 40 us: 25 000 times that)
 
 // developer timeline (SK_CHAIN_STAMPS=<file>): wall-clock stamps of the server and of tile 0 of every column launch
@@ -900,15 +908,102 @@ __device__ __forceinline__ void chain_publish_through(int* p, int add) {
   if (threadIdx.x == 0) __hip_atomic_fetch_add(p, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- XCD-local hand-over (round 5) ----------------------------------------------------------------------------------------------
+// The L2 of an XCD is coherent for its own CUs.  When the sixteen tiles of block row j + 1 run on the potrf server's XCD, the chain's
+// hand-overs — potrf(j) done, X(j+1,j) formed, S(j+1,j+1) updated — need neither a write-back of that L2 nor an invalidation, and the
+// blocks handed over (W_jj, X, the diagonal block) are read from the L2 instead of memory: a flag is a plain store behind the data
+// (s_waitcnt vmcnt(0) + barrier first: every wave's stores are in the L2), a poll is a SCALAR load behind s_dcache_inv (the scalar cache
+// has just been emptied: the load comes from the L2; one request per wave — sixteen workgroups polling with device-scope vector loads
+// slowed every kernel on the chip), and what is read has not been read before by any workgroup of the launch (a scratch block per column),
+// so no stale line can sit in a CU's vector L1.  Everything that leaves the XCD — the thin tiles of the other rows, the trailing SYRK, the
+// launches that follow — still goes through the device-scope counters, behind a release, off the critical path.
+// (Round 1 measured the idea in a side experiment — a hop of 0.3-0.5 us instead of 1-2.5, a block from the L2 in 0.7 us instead of
+// 2 — and did not finish it: the diagonal tile then waited for a marker kernel behind the whole SYRK; since round 2 the SYRK's first
+// block column counts itself.)
+typedef int int16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int load_l2(const int* p) {
+  int v;
+  asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ int min16_l2(const int* p) {  // p: 64-byte aligned
+  int16v v;
+  asm volatile("s_dcache_inv\n\ts_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  int m = v[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m = v[i] < m ? v[i] : m;
+  return m;
+}
+__device__ __forceinline__ int xcc_id() {
+  int v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
+}
+__device__ __forceinline__ void store_l2(int* p, int v) { *(volatile int*)p = v; }  // (write-through L1: the store lands in the L2)
+// one lane, the writer on the same XCD: wait until *p >= target; false = aborted / timed out.  No fence: see above.
+__device__ __forceinline__ bool chain_wait_l2(const int* p, int target, int* abort_flag) {
+  if (load_l2(p) < target) {
+    const long long t0 = wall_clock64();
+    int spins = 0;
+    do {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 63) == 0) {
+        if (sync_load(abort_flag) != 0) return false;
+        if (wall_clock64() - t0 > kChainTimeoutTicks) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+      }
+    } while (load_l2(p) < target);
+  }
+  return true;
+}
+// ... until all sixteen slots are >= target
+__device__ __forceinline__ bool chain_wait_slots(const int* slots, int target, int* abort_flag) {
+  if (min16_l2(slots) < target) {
+    const long long t0 = wall_clock64();
+    int spins = 0;
+    do {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 63) == 0) {
+        if (sync_load(abort_flag) != 0) return false;
+        if (wall_clock64() - t0 > kChainTimeoutTicks) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+      }
+    } while (min16_l2(slots) < target);
+  }
+  return true;
+}
+// The server's wait for diagonal block j: the sixteen slots of the tiles on its own XCD (the usual case) — or the device-scope counter
+// (the first column of a resident run, set by the launch-by-launch part before it; a column whose block row lies outside the envelope;
+// a factorisation without the XCD-local hand-over), looked at every sixteenth poll, with the acquire that path needs.
+__device__ __forceinline__ bool server_wait_diag(int* sync, int j, int local) {
+  const int* slots = sync + kSyncDSlot;
+  const int* counter = sync + kSyncHeader + j;
+  int* abort_flag = sync + kSyncAbort;
+  if (!local) return chain_wait(counter, 16, abort_flag);
+  const long long t0 = wall_clock64();
+  for (int spins = 0;; ++spins) {
+    if (min16_l2(slots) >= j) return true;
+    if ((spins & 15) == 0) {
+      if (sync_load(counter) >= 16) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return true;
+      }
+      if (sync_load(abort_flag) != 0) return false;
+      if (wall_clock64() - t0 > kChainTimeoutTicks) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
 struct ChainRanges { int n; int begin[8], end[8]; };  // the resident runs of block columns, [begin, end)
 
-__device__ __forceinline__ void potrf_server_body(double* lds, double* S, long ld, const ChainRanges& ranges, double* Linv, int* info, int* sync, int maxblk) {
+__device__ __forceinline__ void potrf_server_body(double* lds, double* S, long ld, const ChainRanges& ranges, double* Linv, int* info, int* sync, int maxblk, int local) {
   __shared__ int ok_s;
   int done = 0;  // value of the potrf counter
+  if (local && threadIdx.x == 0) __hip_atomic_store(sync + kSyncServerXcc, 1 + xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // which XCD the tiles of block row j + 1 have to be on
   for (int r = 0; r < ranges.n; ++r)
     for (int j = ranges.begin[r]; j < ranges.end[r]; ++j) {
       if (j > 0) {  // the first column of a run: set by the launch-by-launch part before it; the others: by column launch j-1
-        if (threadIdx.x == 0) ok_s = chain_wait(sync + kSyncHeader + j, 16, sync + kSyncAbort) ? 1 : 0;
+        if (threadIdx.x == 0) ok_s = server_wait_diag(sync, j, local) ? 1 : 0;
         __syncthreads();
         if (!ok_s) {
           if (threadIdx.x == 0) info_raise(info, 2);
@@ -918,23 +1013,35 @@ __device__ __forceinline__ void potrf_server_body(double* lds, double* S, long l
       }
       SK_CHAIN_STAMP(j, 0)
       potrf128_body(lds, S + (long)j * 128 * ld + (long)j * 128, ld, Linv + (long)j * 128 * 128, info);
-      chain_publish(sync + kSyncPotrfDone, j + 1 - done);  // the counter reads j + 1 after column j
+      if (local) {
+        // L_jj and W_jj are in this XCD's L2: the tiles on this XCD may go ahead; then the write-back and the counter for everyone else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          store_l2(sync + kSyncPotrfFast, j + 1);
+          SK_CHAIN_STAMP(j, 1)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          __hip_atomic_fetch_add(sync + kSyncPotrfDone, j + 1 - done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        chain_publish(sync + kSyncPotrfDone, j + 1 - done);  // the counter reads j + 1 after column j
+        SK_CHAIN_STAMP(j, 1)
+      }
       done = j + 1;
-      SK_CHAIN_STAMP(j, 1)
     }
 }
-__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk) {
+__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk, int local) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  potrf_server_body(lds, S, ld, ranges, Linv, info, sync, maxblk);
+  potrf_server_body(lds, S, ld, ranges, Linv, info, sync, maxblk, local);
 }
 // Two fronts eliminated in ONE sequence of launches (cholesky_factor with a partner front): a
 // server workgroup each, on a CU 0 each.
 struct ServerArgs { double* S; long ld; ChainRanges ranges; double* Linv; int* sync; int maxblk; };
 struct ServerPair { ServerArgs f[2]; };
-__global__ __launch_bounds__(256, 1) void potrf_server_pair_kernel(ServerPair pair, int* info) {
+__global__ __launch_bounds__(256, 1) void potrf_server_pair_kernel(ServerPair pair, int* info, int local) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const ServerArgs& p = pair.f[blockIdx.x];  // (indexed in the kernel-argument segment: scalar loads)
-  potrf_server_body(lds, p.S, p.ld, p.ranges, p.Linv, info, p.sync, p.maxblk);
+  potrf_server_body(lds, p.S, p.ld, p.ranges, p.Linv, info, p.sync, p.maxblk, local);
 }
 
 // One 32 x 32 tile with K = 128 in a single memory round trip: C = A B^T (kMode 1) or C -= A B^T (kMode 0), A and B
@@ -979,8 +1086,11 @@ __device__ __forceinline__ long crit_tile_off(long ldc, int i) {
 // of the other active rows (thin tile 4 + (blockIdx.x - ncrit)).  ncrit == 0: block row j+1 is outside the envelope.
 // Xs: 128 x 128 scratch.  X(j+1,j) cannot be formed in place tile by tile (every column tile reads whole rows of
 // S(j+1,j)): the tiles go to Xs, which next(j) reads, and into S(j+1,j) once all 16 are known to have loaded theirs.
+// ncand > 16: the XCD-local hand-over (above).  The launch's first ncand workgroups are CANDIDATES for the 16 tiles: a candidate on the
+// potrf server's XCD takes a ticket — the first sixteen are the tiles, in ticket order — every other candidate leaves at once.
 __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int j, const double* Linv_j, int tiles_m, int main_t, int jump_t,
-                                                  int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info, int do_next, int wait_first) {
+                                                  int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info, int do_next, int wait_first,
+                                                  int ncand) {
   __shared__ __attribute__((aligned(16))) double sh[2 * 32 * kCritLd];
   static_assert(2 * 32 * kCritLd >= gemm_lds_doubles(16, 32, 128), "LDS of the thin tiles");
   __shared__ int ok_s;
@@ -988,12 +1098,102 @@ __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int
   double* A21 = S + (long)(j + 1) * 128 * ld + (long)j * 128;
   int* x_ready = sync + kSyncHeader + maxblk + j;
   int* diag_ready = sync + kSyncHeader + j + 1;
-  const bool crit = b < ncrit;
+  int* abort_flag = sync + kSyncAbort;
+  const bool local = ncand > ncrit;
+  bool crit = b < ncand;
+  if (crit && local) {
+    // a tile of block row j + 1 on the server's XCD, or nothing
+    if (threadIdx.x == 0) {
+      int t = -1;
+      if (chain_wait(sync + kSyncServerXcc, 1, abort_flag) && sync_load(sync + kSyncServerXcc) == 1 + xcc_id())
+        t = __hip_atomic_fetch_add(sync + kSyncHeader + 2 * maxblk + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok_s = t >= 0 && t < 16 ? t : -1;
+    }
+    __syncthreads();
+    const int tile = ok_s;
+    __syncthreads();
+    if (tile < 0) return;
+    b = tile;
+  }
   const int ri = b >> 2, q = b & 3;        // critical tile: rows ri * 32, columns q * 32 of the block
-  const int thin_id = 4 + (b - ncrit);     // other workgroups (ncrit == 16), or every workgroup from 0 (ncrit == 0)
+  const int thin_id = 4 + (b - ncand);     // other workgroups (ncrit == 16), or every workgroup from 0 (ncrit == 0)
   const int thin_bid = ncrit ? thin_id : b;
-  const bool stamp = b == 0;
+  const bool stamp = b == 0 && crit == (ncrit > 0);
   if (stamp) SK_CHAIN_STAMP(j, 2)
+  if (crit && local) {
+    // ---- the XCD-local path of a tile (ri, q) of block row j + 1
+    double* Xj = Xs + (size_t)j * 128 * 128;  // this column's own scratch block: nothing of it has been read before by anybody
+    const bool lower = q <= ri;               // the server reads the lower 32-blocks of the diagonal block only
+    double* Ct = A21 + 128 + (long)(ri * 32) * ld + q * 32;
+    // what comes from other XCDs — S(j+1,j) with column j-1's update (in memory since that launch ended) and S(j+1,j+1) with
+    // syrk(j-1)'s (its first block column, counted by its own workgroups) — first, while the chain is still inside potrf(j)
+    if (threadIdx.x == 0) ok_s = (chain_wait(sync + kSyncSyrkSeq, syrk_need, abort_flag) && chain_wait(sync + kSyncSyrkColumn, column_need, abort_flag)) ? 1 : 0;
+    __syncthreads();
+    if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (every wave: its loads below must not come from a stale line)
+    d4 cacc = {0.0, 0.0, 0.0, 0.0};
+    {
+      // rows ri of S(j+1,j) -> LDS (first half of sh); the C tile -> registers
+      const int t = threadIdx.x, row = t >> 3, c0 = (t & 7) * 16;
+      double2 va[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) va[i] = *reinterpret_cast<const double2*>(A21 + (long)(ri * 32 + row) * ld + c0 + 2 * i);
+      if (lower) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cacc[i] = -Ct[crit_tile_off(ld, i)];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(sh + row * kCritLd + c0 + 2 * i) = va[i];
+    }
+    // ---- potrf(j), through the L2
+    if (threadIdx.x == 0) ok_s = chain_wait_l2(sync + kSyncPotrfFast, j + 1, abort_flag) ? 1 : 0;
+    __syncthreads();
+    if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
+    if (stamp) SK_CHAIN_STAMP(j, 3)
+    {
+      // W_jj rows q -> LDS (second half of sh)
+      const int t = threadIdx.x, row = t >> 3, c0 = (t & 7) * 16;
+      double2 vb[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vb[i] = *reinterpret_cast<const double2*>(Linv_j + (long)(q * 32 + row) * 128 + c0 + 2 * i);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(sh + (32 + row) * kCritLd + c0 + 2 * i) = vb[i];
+    }
+    __syncthreads();
+    d4 xacc = {0.0, 0.0, 0.0, 0.0};
+    xacc = crit_tile_mma(sh, xacc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Xj[(long)(ri * 32) * 128 + q * 32 + crit_tile_off(128, i)] = xacc[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's part of the tile is in the L2
+    __syncthreads();
+    if (threadIdx.x == 0) store_l2(sync + kSyncXSlot + b, j + 1);
+    if (stamp) SK_CHAIN_STAMP(j, 4)
+    if (threadIdx.x == 0) ok_s = chain_wait_slots(sync + kSyncXSlot, j + 1, abort_flag) ? 1 : 0;
+    __syncthreads();
+    if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
+    if (stamp) SK_CHAIN_STAMP(j, 5)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A21[(long)(ri * 32) * ld + q * 32 + crit_tile_off(ld, i)] = xacc[i];  // every tile has read S(j+1,j) by now
+    if (b == 1 && threadIdx.x == 0) {
+      // (tile (0, 1) has no update to do) X(j+1,j) to memory for the thin tiles of this launch, which may be anywhere on the chip:
+      // one write-back of this XCD's L2 covers all sixteen tiles' stores
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(x_ready, 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lower) {
+      // S(j+1,j+1) tile -= X[rows ri] X[rows q]^T, X from the L2
+      crit_tile_load(sh, Xj + (long)ri * 32 * 128, 128, Xj + (long)q * 32 * 128, 128);
+      __syncthreads();
+      cacc = crit_tile_mma(sh, cacc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Ct[crit_tile_off(ld, i)] = -cacc[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) store_l2(sync + kSyncDSlot + b, j + 1);
+    if (stamp) SK_CHAIN_STAMP(j, 6)
+    return;
+  }
   // A wait that gave up (its own time-out, or the abort flag another wait raised): this column was NOT computed.  The
   // host must hear of it from whichever kernel noticed — the server may have nothing left to wait for (the last
   // column of a resident run hands back to launch-by-launch kernels, which would factor stale data): *info = 2.
@@ -1001,8 +1201,8 @@ __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int
   // column launch before this one, which stream order would cover): the server went ahead on the diagonal block alone, the
   // TRSM needs every row — the SYRK's first block columns, counted by its workgroups
   if (threadIdx.x == 0)
-    ok_s = (chain_wait(sync + kSyncPotrfDone, j + 1, sync + kSyncAbort) &&
-            (!wait_first || (chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort) && chain_wait(sync + kSyncSyrkColumn, column_need, sync + kSyncAbort)))) ? 1 : 0;
+    ok_s = (chain_wait(sync + kSyncPotrfDone, j + 1, abort_flag) &&
+            (!wait_first || (chain_wait(sync + kSyncSyrkSeq, syrk_need, abort_flag) && chain_wait(sync + kSyncSyrkColumn, column_need, abort_flag)))) ? 1 : 0;
   __syncthreads();
   if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
   SK_CHAIN_ACQUIRE_ALL
@@ -1026,13 +1226,14 @@ __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int
   // hands block column j + 1 to the server; only the 16 tiles of block row j + 1 have something left to do (X into place)
   if (!do_next && !crit) return;
   if (threadIdx.x == 0)
-    ok_s = (chain_wait(x_ready, ncrit, sync + kSyncAbort) && (!do_next || (chain_wait(sync + kSyncSyrkSeq, syrk_need, sync + kSyncAbort) &&
-            chain_wait(sync + kSyncSyrkColumn, column_need, sync + kSyncAbort)))) ? 1 : 0;
+    ok_s = (chain_wait(x_ready, ncrit, abort_flag) && (!do_next || (chain_wait(sync + kSyncSyrkSeq, syrk_need, abort_flag) &&
+            chain_wait(sync + kSyncSyrkColumn, column_need, abort_flag)))) ? 1 : 0;
   __syncthreads();
   if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
   SK_CHAIN_ACQUIRE_ALL
   if (stamp) SK_CHAIN_STAMP(j, 5)
   // ---- next(j): S(r,j+1) -= X(r,j) X(j+1,j)^T
+  const double* Xsrc = local ? (const double*)(Xs + (size_t)j * 128 * 128) : (const double*)Xs;  // (the XCD-local tiles wrote this column's own scratch block)
   if (crit) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) A21[(long)(ri * 32) * ld + q * 32 + crit_tile_off(ld, i)] = xacc[i];  // every tile has read S(j+1,j) by now
@@ -1050,23 +1251,24 @@ __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int
     }
     chain_publish_through(diag_ready, 1);  // (the copy of X into S(j+1,j) above is for after the factorisation: the end of the launch writes it back)
   } else {
-    const double* Bx = ncrit ? (const double*)Xs : (const double*)A21;
+    const double* Bx = ncrit ? Xsrc : (const double*)A21;
     gemm_nt_f64_body<0, 0, 16, 2, 32, 128>(sh, A21 + 128, ld, A21, ld, Bx, ncrit ? 128 : ld, 128, tiles_m, 1, main_t, jump_t, 0x7fffffff, 0, thin_bid);
     if (ncrit == 0 && b == 0) chain_publish(diag_ready, 16);
   }
   if (stamp) SK_CHAIN_STAMP(j, 6)
 }
 __global__ __launch_bounds__(256, 2) void chain_column_kernel(double* S, long ld, int j, const double* Linv_j, int tiles_m, int main_t, int jump_t,
-                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info, int do_next, int wait_first) {
-  chain_column_body((int)blockIdx.x, S, ld, j, Linv_j, tiles_m, main_t, jump_t, ncrit, Xs, sync, maxblk, syrk_need, column_need, info, do_next, wait_first);
+                                                              int ncrit, double* Xs, int* sync, int maxblk, int syrk_need, int column_need, int* info, int do_next, int wait_first,
+                                                              int ncand) {
+  chain_column_body((int)blockIdx.x, S, ld, j, Linv_j, tiles_m, main_t, jump_t, ncrit, Xs, sync, maxblk, syrk_need, column_need, info, do_next, wait_first, ncand);
 }
 // ... the column launches of two fronts as one launch: blockIdx.y picks the front (grid.x: the larger of the two grids)
-struct ColumnArgs { double* S; long ld; int j; const double* Linv_j; int tiles_m, main_t, jump_t, ncrit; double* Xs; int* sync; int maxblk, syrk_need, column_need, grid; };
+struct ColumnArgs { double* S; long ld; int j; const double* Linv_j; int tiles_m, main_t, jump_t, ncrit; double* Xs; int* sync; int maxblk, syrk_need, column_need, grid, ncand; };
 struct ColumnPair { ColumnArgs f[2]; };
 __global__ __launch_bounds__(256, 2) void chain_column_pair_kernel(ColumnPair pair, int* info) {
   const ColumnArgs& p = pair.f[blockIdx.y];
   if ((int)blockIdx.x >= p.grid) return;
-  chain_column_body((int)blockIdx.x, p.S, p.ld, p.j, p.Linv_j, p.tiles_m, p.main_t, p.jump_t, p.ncrit, p.Xs, p.sync, p.maxblk, p.syrk_need, p.column_need, info, 1, 0);
+  chain_column_body((int)blockIdx.x, p.S, p.ld, p.j, p.Linv_j, p.tiles_m, p.main_t, p.jump_t, p.ncrit, p.Xs, p.sync, p.maxblk, p.syrk_need, p.column_need, info, 1, 0, p.ncand);
 }
 
 // after a SYRK on its stream: the SYRK's completion (and its end-of-kernel write-back) as a counter the chain can poll
@@ -1330,6 +1532,7 @@ constexpr int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see chole
 static int g_pair_max_trailing = 0;
 constexpr int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK
 constexpr int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
+static int g_chain_local = 1;  // developer variable SK_CHAIN_XCD_LOCAL=0: the resident chain's hand-overs all through device-scope counters (rounds 1-4)
 static std::atomic<int> g_bs_resident{1};  // developer knob SK_BS_RESIDENT=0: the back-substitution as one launch per block step (bs_step_kernel)
 // Fault injection, compiled in only with -DSK_TESTING (libskeres_amd_testing.so, `make testing`; never in the product library):
 // SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds, once per process, what that column's launch waits for — the wait
@@ -1349,6 +1552,7 @@ hipError_t cholesky_init() {
     g_bs_resident.store(k.bs_resident);
     g_chain_server = k.chain_server;
     g_pair_max_trailing = k.pair_max_trailing;
+    g_chain_local = k.chain_xcd_local;
   });
   hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_server_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g_potrf_lds);
   if (rc != hipSuccess) return rc;
@@ -1366,13 +1570,15 @@ CholeskyContext::~CholeskyContext() {
 }
 
 int* CholeskyContext::sync_for(int nblk) {
-  if (!xs && hipMalloc(reinterpret_cast<void**>(&xs), sizeof(double) * 128 * 128) != hipSuccess) { (void)hipGetLastError(); xs = nullptr; return nullptr; }
   if (nblk > sync_blk) {
     if (sync) (void)hipFree(sync);
-    sync = nullptr;
+    if (xs) (void)hipFree(xs);
+    sync = nullptr; xs = nullptr;
     sync_blk = 0;
-    const int cap = (nblk + 255) / 256 * 256;
-    if (hipMalloc(reinterpret_cast<void**>(&sync), sizeof(int) * (size_t)(kSyncHeader + 2 * cap)) != hipSuccess) { (void)hipGetLastError(); sync = nullptr; return nullptr; }
+    const int cap = (nblk + 63) / 64 * 64;
+    // (a 128 x 128 scratch block PER block column: the XCD-local hand-over must not read an address twice within a factorisation)
+    if (hipMalloc(reinterpret_cast<void**>(&xs), sizeof(double) * 128 * 128 * (size_t)cap) != hipSuccess) { (void)hipGetLastError(); xs = nullptr; return nullptr; }
+    if (hipMalloc(reinterpret_cast<void**>(&sync), sizeof(int) * (size_t)(kSyncHeader + kSyncArrays * cap)) != hipSuccess) { (void)hipGetLastError(); sync = nullptr; return nullptr; }
     sync_blk = cap;
   }
   return sync;
@@ -1865,7 +2071,7 @@ static void tune_chain_queues(CholeskyContext* ctx, hipStream_t s) {
 bool cholesky_note_info(CholeskyContext* ctx, int info) {
   if (info == 2) g_bs_resident.store(0);  // (whichever resident kernel it was: the back-substitution is launch by launch from here on, too)
   if (info == 2 && ctx && ctx->sync && dev_knobs().debug_chain_abort) {  // developer knob: where the chain stood when a wait gave up
-    std::vector<int> h((size_t)kSyncHeader + 2 * ctx->sync_blk);
+    std::vector<int> h((size_t)kSyncHeader + kSyncArrays * ctx->sync_blk);
     (void)hipMemcpy(h.data(), ctx->sync, h.size() * sizeof(int), hipMemcpyDeviceToHost);
     std::fprintf(stderr, "[skeres_amd] chain abort: potrf_done %d abort %d syrk_seq %d syrk_column %d | diag_ready:", h[kSyncPotrfDone], h[kSyncAbort], h[kSyncSyrkSeq], h[kSyncSyrkColumn]);
     for (int j = 0; j < 40 && j < ctx->sync_blk; ++j) std::fprintf(stderr, " %d", h[kSyncHeader + j]);
@@ -2041,6 +2247,9 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   int* sync = chain ? ctx->sync_for(nblk) : nullptr;
   if (!sync) chain = false;  // (the same groups, launch by launch)
   auto is_resident = [&](int k) { return chain && k < nblk && plan.resident[k]; };
+  // the XCD-local hand-over between the server and the tiles of block row j + 1 (above): every resident single column's launch
+  const int local = chain && g_chain_local ? 1 : 0;
+  auto column_grid = [&](int ncrit, int T, int ncand) { return ncrit ? ncand + 4 * T - 4 : 4 * T; };
   const int maxblk = chain ? ctx->sync_blk : 0;
   const char* stamps_file = chain ? dev_knobs().chain_stamps : nullptr;
   hipStream_t srv = nullptr;
@@ -2069,8 +2278,9 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     st.Tb = rs.main + rs.extra;
     st.next_resident = k1 < pb.ncols;
     st.by_column = st.next_resident && g_early_column;
+    const int ncand = ncrit && local ? kCritCandidates : ncrit;
     st.col = ColumnArgs{pb.S, pb.ld, kB, pb.Linv + (long)kB * 128 * 128, 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, pb.xs, pb.sync, pb.maxblk, pb.seq, pb.col_seq,
-                        ncrit ? 16 + 4 * T - 4 : 4 * T};
+                        column_grid(ncrit, T, ncand), ncand};
     st.syrk = ThinSyrkArgs{pb.S + (long)(k1 + 1) * 128 * pb.ld + (long)(k1 + 1) * 128, pb.ld, pb.S + (long)(k1 + 1) * 128 * pb.ld + (long)kB * 128, pb.ld, 128, 4 * st.Tb,
                            4 * rs.main, 4 * rs.jump, rs.main, rs.jump, st.by_column ? pb.sync + kSyncSyrkColumn : (int*)nullptr, st.Tb > 0 ? 2 * st.Tb * (st.Tb + 1) : 0};
     return st;
@@ -2088,7 +2298,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     static int stamps_state = 0;
     if (stamps_on != stamps_state) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamps_on), &stamps_on, sizeof(int)); stamps_state = stamps_on; }
     srv = ctx->server;
-    (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * maxblk), s);
+    (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + kSyncArrays * maxblk), s);
     // ---- the partner front (see CholeskyPartner): taken along if every one of its block columns is a resident single column,
     // in the launches of this front's resident single columns
     if (partner && partner->ncols > 0 && partner->ctx && !(kt && kt->times_all())) {
@@ -2104,7 +2314,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
         pb.on = true; pb.start_at = start; pb.sync = sb_sync; pb.maxblk = partner->ctx->sync_blk; pb.xs = partner->ctx->xs;
         pb.nblk = partner->nblk; pb.ncols = partner->ncols; pb.tail0 = partner->nblk - std::max(1, std::min(partner->tail_rows, partner->nblk - partner->ncols));
         pb.last = partner->last; pb.tail = partner->tail; pb.S = partner->S; pb.ld = partner->ld; pb.Linv = partner->Linv;
-        (void)hipMemsetAsync(pb.sync, 0, sizeof(int) * (size_t)(kSyncHeader + 2 * pb.maxblk), s);
+        (void)hipMemsetAsync(pb.sync, 0, sizeof(int) * (size_t)(kSyncHeader + kSyncArrays * pb.maxblk), s);
         partner->taken = true;
       }
     }
@@ -2118,9 +2328,9 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       sp2.f[0] = ServerArgs{S, ld, ranges, Linv, sync, maxblk};
       ChainRanges rb; rb.n = 1; rb.begin[0] = 0; rb.end[0] = pb.ncols;
       sp2.f[1] = ServerArgs{pb.S, pb.ld, rb, pb.Linv, pb.sync, pb.maxblk};
-      hipLaunchKernelGGL(potrf_server_pair_kernel, dim3(2), dim3(256), potrf128_lds_bytes(), srv, sp2, info);
+      hipLaunchKernelGGL(potrf_server_pair_kernel, dim3(2), dim3(256), potrf128_lds_bytes(), srv, sp2, info, local);
     } else {
-      hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk);
+      hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk, local);
     }
   }
   if (la) {
@@ -2176,13 +2386,14 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
         const int ncrit = (rc.main > 0 || rc.jump == 0) ? 16 : 0;
         hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, c == 1 ? col_done : (hipEvent_t) nullptr, 0, S, ld,
                               k0 + c, (const double*)(Linv + (long)(k0 + c) * 128 * 128), 4 * T, 4 * rc.main, 4 * rc.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, info,
-                              c == 0 ? 1 : 0, c == 0 && after_pair ? 1 : 0);
+                              c == 0 ? 1 : 0, c == 0 && after_pair ? 1 : 0, ncrit);  // (the columns of a resident PAIR: the device-scope hand-over)
       }
       (void)hipStreamWaitEvent(sb, col_done, 0);
     } else if (resident) {
       const int T = rn.main + rn.extra;  // rows of X(.,k0) == rows that next(g) updates (K = 128, na == 1)
       // block row k0+1 is active as the start of the main run, or as the last block row itself
       const int ncrit = (rn.main > 0 || rn.jump == 0) ? 16 : 0;
+      const int ncand = ncrit && local && !after_pair ? kCritCandidates : ncrit;
       // (a partner rides only with SYRKs in the thin tiling, which all go to ctx->bulk: early_tiles > g_thin_syrk_tiles, or consecutive
       // SYRKs of a front could land on two streams with only their first block column awaited — ADVICE r03)
       with_partner = pb.on && k0 >= pb.start_at && pb.next < pb.ncols && !after_pair && Tb <= g_thin_syrk_tiles && ctx->early_tiles > g_thin_syrk_tiles;
@@ -2190,12 +2401,12 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       hipEvent_t col_done = (Tb > 0 || (with_partner && pst.Tb > 0)) ? ctx->event(ev++) : nullptr;
       if (with_partner) {
         ColumnPair cp;
-        cp.f[0] = ColumnArgs{S, ld, k0, Linv + (long)k0 * 128 * 128, 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, ncrit ? 16 + 4 * T - 4 : 4 * T};
+        cp.f[0] = ColumnArgs{S, ld, k0, Linv + (long)k0 * 128 * 128, 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, column_grid(ncrit, T, ncand), ncand};
         cp.f[1] = pst.col;
         hipExtLaunchKernelGGL(chain_column_pair_kernel, dim3(std::max(cp.f[0].grid, cp.f[1].grid), 2), dim3(256), 0, sp, nullptr, col_done, 0, cp, info);
       } else {
-        hipExtLaunchKernelGGL(chain_column_kernel, dim3(ncrit ? 16 + 4 * T - 4 : 4 * T), dim3(256), 0, sp, nullptr, col_done, 0, S, ld, k0,
-                              (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, info, 1, after_pair ? 1 : 0);
+        hipExtLaunchKernelGGL(chain_column_kernel, dim3(column_grid(ncrit, T, ncand)), dim3(256), 0, sp, nullptr, col_done, 0, S, ld, k0,
+                              (const double*)(Linv + (long)k0 * 128 * 128), 4 * T, 4 * rn.main, 4 * rn.jump, ncrit, ctx->xs, sync, maxblk, seq, col_seq, info, 1, after_pair ? 1 : 0, ncand);
       }
       if (col_done) (void)hipStreamWaitEvent(sb, col_done, 0);
     } else {
