@@ -567,6 +567,10 @@ def main():
             headline_stats[k] = solver.stat(k)
         except sk.SkeresError:
             headline_stats[k] = 0.0
+    try:
+        solver_two_segments_us = solver.stat("model_us_two_segments_with_members")
+    except sk.SkeresError:
+        solver_two_segments_us = 0.0
     summary = sk.Solver.Summary()
     solver.finish(summary)
     # Untimed side measurement: the same kernel with the look-ahead off, i.e. alone on the chip.  In the
@@ -704,14 +708,26 @@ def main():
                 pred[str(n_dev)] = {"ms_per_step": ph["cholesky"] * model_us[k] / model_one + shard / k, "segments": k}
             note = "chain model, calibrated on this run's Cholesky phase; no scaling curve has been measured on hardware"
             if headline_stats.get("retained_points", 0) > 0:
-                # with retained points a world of ranks cannot segment the camera sequence (the points' rows couple with every segment): it
-                # shards the points or replicates, and on this problem the all-reduce of the envelope costs more than sharding saves
-                envelope_mb = plan["allreduce_bytes"] / 1e6
-                pred = {str(n): {"ms_per_step": line["ms_per_step"], "plan": "replicated"} for n in (2, 4, 8)}
-                note = ("with retained points a world of ranks shards the points or replicates (no segmented distribution): sharding saves %.2f ms x (1 - 1 / N) "
-                        "of this iteration and adds an all-reduce of %.0f MB, so AUTO is expected to replicate — every rank runs this run's one-device plan, "
-                        "speed-up 1; model_us_per_segments is the segmented plan WITHOUT retained points, for comparison; no scaling curve has been measured "
-                        "on hardware" % (shard, envelope_mb))
+                # with retained points a world of ranks takes the camera sequence as TWO segments — head and tail on two devices, the retained
+                # points' pseudo-cameras members of the one separator (round 5) — when the chain model puts that 10 % under this device's
+                # lock-step plan; ranks beyond two replicate.  Otherwise it shards the points or replicates.
+                try:
+                    two_us = solver_two_segments_us
+                except NameError:
+                    two_us = 0.0
+                host_ms = line["ms_per_step"] - sum(ph.values())
+                if two_us > 0.0 and two_us < 0.9 * model_one:
+                    ms2 = ph["cholesky"] * two_us / model_one + shard / 2.0 + host_ms
+                    pred = {str(n): {"ms_per_step": ms2, "speed_up": line["ms_per_step"] / ms2, "plan": "two segments, retained points in the separator%s" % ("" if n == 2 else "; %d replicas" % (n - 2))}
+                            for n in (2, 4, 8)}
+                    note = ("chain model (two devices, a leaf front each: %.0f us against %.0f us for this run's lock-step plan), calibrated on this run's Cholesky phase; the phases that "
+                            "shard with the points halved; UNMEASURED on more than one device" % (two_us, model_one))
+                else:
+                    envelope_mb = plan["allreduce_bytes"] / 1e6
+                    pred = {str(n): {"ms_per_step": line["ms_per_step"], "plan": "replicated"} for n in (2, 4, 8)}
+                    note = ("with retained points a world of ranks would take two segments (%.0f us in the chain model against %.0f us on one device: no gain), shard the points or "
+                            "replicate: sharding saves %.2f ms x (1 - 1 / N) of this iteration and adds an all-reduce of %.0f MB, so AUTO is expected to replicate; no scaling curve has "
+                            "been measured on hardware" % (two_us, model_one, shard, envelope_mb))
             line["predicted_multi_gpu"] = {"model_us_per_segments": {str(k): v for k, v in model_us.items() if v > 0.0}, "model_us_this_run": model_one, "per_n_gpus": pred,
                                            "note": note}
         # The whole Cholesky phase (factorisation + triangular solves, every kernel of it) against the MFMA peak.  The

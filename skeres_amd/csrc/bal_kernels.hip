@@ -640,14 +640,29 @@ __global__ __launch_bounds__(kBlock) void bal_kept_points_kernel(BalDev d, int o
   d.M[p] = 0.0; d.M[P + p] = 0.0; d.M[2 * P + p] = 0.0; d.M[3 * P + p] = 0.0; d.M[4 * P + p] = 0.0; d.M[5 * P + p] = 0.0;
   d.q[p] = 0.0; d.q[P + p] = 0.0; d.q[2 * P + p] = 0.0;
   if (!d.front[bal_part(d, ic)].S) return;
-  const double d0 = bal_lm_diag(d, d.colsq_p[3 * (size_t)p]), d1 = bal_lm_diag(d, d.colsq_p[3 * (size_t)p + 1]), d2 = bal_lm_diag(d, d.colsq_p[3 * (size_t)p + 2]);
+  // (a segmented world: T is this rank's observations' share — the root front is summed over the ranks — and D_p^2 and the right-hand side,
+  // which are the point's own and whose inputs are global after the small all-reduce, come from its home rank alone)
+  const bool home = !d.kept_home || d.kept_home[k] != 0;
+  const double d0 = home ? bal_lm_diag(d, d.colsq_p[3 * (size_t)p]) : 0.0, d1 = home ? bal_lm_diag(d, d.colsq_p[3 * (size_t)p + 1]) : 0.0,
+               d2 = home ? bal_lm_diag(d, d.colsq_p[3 * (size_t)p + 2]) : 0.0;
   int ld;
   double* blk = bal_block(d, ic, ic, &ld) + (size_t)t3 * ld + t3;
   blk[0] = t00 + d0 * d0;
   blk[ld] = t10; blk[ld + 1] = t11 + d1 * d1;
   blk[2 * (size_t)ld] = t20; blk[2 * (size_t)ld + 1] = t21; blk[2 * (size_t)ld + 2] = t22 + d2 * d2;
   double* rhs = bal_rhs(d, ic) + t3;
-  rhs[0] = d.gs_p[3 * (size_t)p]; rhs[1] = d.gs_p[3 * (size_t)p + 1]; rhs[2] = d.gs_p[3 * (size_t)p + 2];
+  rhs[0] = home ? d.gs_p[3 * (size_t)p] : 0.0; rhs[1] = home ? d.gs_p[3 * (size_t)p + 1] : 0.0; rhs[2] = home ? d.gs_p[3 * (size_t)p + 2] : 0.0;
+}
+
+// The retained points' column norms and gradient to (gather) / from their slots of buf = [colsq (3 K) | gs (3 K)]: what a segmented world
+// sums over its ranks (every rank holds the observations of its own segment's cameras).  A thread per local retained point and coordinate.
+__global__ __launch_bounds__(kBlock) void bal_kept_sums_kernel(BalDev d, double* buf, int K, int gather) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 3 * d.num_kept) return;
+  const int k = t / 3, a = t - 3 * k;
+  const size_t p = (size_t)d.kept_pt[k], g = (size_t)(d.kept_global ? d.kept_global[k] : k);
+  if (gather) { buf[3 * g + a] = d.colsq_p[3 * p + a]; buf[3 * (size_t)K + 3 * g + a] = d.gs_p[3 * p + a]; }
+  else { d.colsq_p[3 * p + a] = buf[3 * g + a]; d.gs_p[3 * p + a] = buf[3 * (size_t)K + 3 * g + a]; }
 }
 
 // Per observation: Ehat = E M^T (2x3), What = F^T Ehat (9x3), rt = r - E q: the observation's 256-byte record, written at
@@ -990,6 +1005,7 @@ __global__ __launch_bounds__(kBlock) void bal_kept_step_kernel(BalDev d, int slo
   double acc[1] = {0.0};
   for (int k = threadIdx.x; k < d.num_kept; k += kBlock) {
     const int p = d.kept_pt[k], ic = d.kept_cam[k] / 3, t3 = 3 * (d.kept_cam[k] % 3);
+    const bool home = !d.kept_home || d.kept_home[k] != 0;  // (a copy of another rank's point takes the same step; its length is counted once)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double st = -d.y_c[9 * (size_t)ic + t3 + a];
@@ -998,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void bal_kept_step_kernel(BalDev d, int slo
       const double xn = xo + st * d.scale_p[3 * (size_t)p + a];
       d.xp_new[3 * (size_t)p + a] = xn;
       const double df = xo - xn;
-      acc[0] += df * df;
+      if (home) acc[0] += df * df;
     }
   }
   block_sum<1>(acc, d.partial + d.partial_stride + slot, d.partial_stride);
@@ -1163,6 +1179,9 @@ void launch_bal_kept_points(const BalDev& d, hipStream_t s) {
   hipLaunchKernelGGL(bal_kept_points_kernel, dim3(obs_blocks + (d.num_kept * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d, obs_blocks);
 }
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s) { hipLaunchKernelGGL(bal_obs_precompute_kernel, dim3(grid_for(d.N)), dim3(kBlock), 0, s, d); }
+void launch_bal_kept_sums(const BalDev& d, double* buf, int K, bool gather, hipStream_t s) {
+  if (d.num_kept > 0) hipLaunchKernelGGL(bal_kept_sums_kernel, dim3((3 * d.num_kept + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d, buf, K, gather ? 1 : 0);
+}
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s) {
   hipLaunchKernelGGL(bal_cam_diag_kernel, dim3((d.C * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
   if (d.num_dup > 0) hipLaunchKernelGGL(bal_dup_diag_kernel, dim3(d.num_dup), dim3(64), 0, s, d);  // (stream order: behind the diagonal blocks it adds to)

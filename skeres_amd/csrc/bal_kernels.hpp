@@ -42,6 +42,10 @@ struct BalDev {
   const int* kept_pt;  const int* kept_cam;
   int num_kept_obs;  const int* kept_obs;  const int* kept_obs_slot;  // the retained points' observations, and which retained point (index into kept_pt) each belongs to
   const unsigned char* pseudo;  // [C]
+  // a SEGMENTED world of ranks: a retained point's observations are split over the ranks by camera, every rank with some of them holds a copy;
+  // kept_home[k] = 1 on the ONE rank that adds the point's own terms (D_p^2, the right-hand side, its norms); kept_global[k]: its index among all
+  // retained points (where its column norms and gradient travel in the small all-reduce).  nullptr: every local retained point is at home.
+  const int* kept_home;  const int* kept_global;
   // Two residual blocks on the SAME (camera, point) pair (the reference's set-up loop adds whatever the file holds,
   // EX/SimpleBundleAdjuster.scala:139-145, and Ceres accepts it): every sum over observations takes both as they stand; what differs is
   // the Schur complement's cross term between the two, which belongs to the camera's DIAGONAL block — such pairs are not in the pair
@@ -130,7 +134,9 @@ void launch_final_reduce(const double* partial, int stride, int count, int K, in
 struct ReduceRows { int n = 0; int row[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0}, is_max[4] = {0, 0, 0, 0}; double* out[4] = {nullptr, nullptr, nullptr, nullptr}; };
 void launch_final_reduce_rows(const double* partial, int stride, const ReduceRows& rows, hipStream_t s);  // up to four reductions of different lengths, one launch
 void launch_bal_point_block(const BalDev& d, hipStream_t s);
-void launch_bal_kept_points(const BalDev& d, hipStream_t s);  // after bal_point_block: the retained points' rows of the reduced system; M = 0, q = 0 for them
+void launch_bal_kept_points(const BalDev& d, hipStream_t s);
+// the retained points' column norms and gradient (3 + 3 doubles each) to / from their slots of a buffer [colsq (3 K) | gs (3 K)], K = all retained points
+void launch_bal_kept_sums(const BalDev& d, double* buf, int K, bool gather, hipStream_t s);  // after bal_point_block: the retained points' rows of the reduced system; M = 0, q = 0 for them
 void launch_bal_obs_precompute(const BalDev& d, hipStream_t s);
 void launch_bal_cam_diag(const BalDev& d, hipStream_t s);  // (+ the cross terms of duplicate (camera, point) pairs, when there are any)
 void launch_bal_pair(const BalDev& d, hipStream_t s);

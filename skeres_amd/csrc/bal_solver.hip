@@ -214,6 +214,7 @@ class BalSolver : public SolverBase {
     if (name == "dissection_separator_cameras") { *value = dissected_ ? C_ - cam_b_ : 0; return true; }
     if (name == "dissection_model_us_plain") { *value = dissect_t_plain_; return true; }
     if (name == "dissection_model_us") { *value = dissect_t_model_; return true; }
+    if (name == "model_us_two_segments_with_members") { *value = two_segments_members_us_; return true; }
     return false;
   }
   // the grouping is the library's choice (Options::cholesky_group == 0) and the masked streams of the resident panel chain exist
@@ -280,6 +281,8 @@ class BalSolver : public SolverBase {
   std::vector<int> struct_ocam_, struct_opt_;   // the structure of the reduced system WITH pseudo-cameras (retained_graphs), final numbering; empty: ocam / opt as they are
   int struct_P_ = 0;
   DevBuf<int> b_kept_pt_, b_kept_cam_, b_kept_obs_, b_kept_obs_slot_;
+  int P_own_ = 0;  // local points this rank accounts for in |x|^2, max |g| and the write-back: all of them, but for the copies of retained points whose home is another rank (a segmented world; they come last)
+  DevBuf<int> b_kept_home_, b_kept_global_;  // per local retained point: 1 = this rank is its home; its index among ALL retained points (the slot of its sums in the small all-reduce)
   DevBuf<int> b_dup_a_, b_dup_b_, b_dup_cam_;  // two residual blocks on one (camera, point) pair: BalDev::dup_*
   int num_dup_ = 0;
   int num_kept_obs_ = 0;
@@ -314,7 +317,7 @@ class BalSolver : public SolverBase {
   FrontView leaf_;             // segmented: this rank's leaf front
   DevBuf<int> b_border_row_[2], b_leaf_map_, b_leaf_gmap_;  // separator camera -> row of a leaf's border; border index -> root index (gmap: rhs row -> -1)
   double model_us_[9] = {0};   // the chain model's prediction per number of segments (index: segments; [1] = undissected)
-  double dissect_t_plain_ = 0.0, dissect_t_model_ = 0.0;
+  double dissect_t_plain_ = 0.0, dissect_t_model_ = 0.0, two_segments_members_us_ = 0.0;
   DissectedSystem ds_;
   CholeskyContext chol_ctx_b_;
   KernelTimer kt_b_;  // launches enqueued by the tail front's own thread
@@ -1101,7 +1104,7 @@ int BalSolver::choose_distribution(const std::vector<int>& opt) {
     double mine = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / 2.0;
     double vals[1] = {mine};
     const int ops[1] = {0};
-    SK_HIP_TRY(b_small_.alloc(2 * 9 * (size_t)C_ + 64 + 16 * (size_t)W));
+    SK_HIP_TRY(b_small_.alloc(2 * 9 * (size_t)C_ + 6 * retained_pts_.size() + 64 + 16 * (size_t)W));
     rc = gather_rank_scalars(vals, 1, ops);
     if (rc) return rc;
     est_allreduce_s_ = vals[0] / W;
@@ -1155,7 +1158,7 @@ int BalSolver::setup() {
   if (opt_.allreduce && opt_.world > 1) {
     // the ranks must factor by ONE plan and take ONE distribution decision: a rank without CU-masked streams (no
     // look-ahead, hence no resident chain and no dissection) takes every rank there
-    SK_HIP_TRY(b_small_.alloc(2 * 9 * (size_t)C_ + 64 + 16 * (size_t)opt_.world));
+    SK_HIP_TRY(b_small_.alloc(2 * 9 * ((size_t)C_ + (size_t)(std::max(1536, opt_.retained_max) + 12) / 3) + 6 * (size_t)(std::max(1536, opt_.retained_max) + 12) + 64 + 16 * (size_t)opt_.world));  // (room for the pseudo-cameras and the retained points' sums the plan below may add)
     double off[1] = {opt_.lookahead ? 0.0 : 1.0};
     int rc = gather_rank_scalars_signed(off, 1);
     if (rc) return rc;
@@ -1179,11 +1182,11 @@ int BalSolver::setup() {
     // (the border of loop-closure cameras: not with an explicit dissection or segmentation — the fronts of those have borders of
     // their own kind — and only inside the envelope machinery)
     RetainedGraphs rgraphs;
-    const bool border_ok = opt_.envelope && opt_.border != SK_BORDER_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 &&
-                           !(opt_.allreduce && opt_.world > 1 && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED);
+    // (an explicitly SEGMENTED world takes a border — its members join the one separator — when it is cut in TWO: sk_options_set_max_segments(o, 2))
+    const bool many_segments = opt_.allreduce && opt_.world > 1 && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && opt_.max_segments != 2;
+    const bool border_ok = opt_.envelope && opt_.border != SK_BORDER_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 && !many_segments;
     // (retained points: not with an explicit dissection or segmentation either; a launch-bound problem under hipGraph replay has nothing to gain)
-    const bool retained_ok = opt_.retained != SK_RETAINED_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 && !graph_mode_ &&
-                             !(opt_.allreduce && opt_.world > 1 && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED);
+    const bool retained_ok = opt_.retained != SK_RETAINED_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 && !graph_mode_ && !many_segments;
     CameraOrderPlan plan;
     auto pick = [&](bool with_memory_order) {
       ReducedSystemPlan rp = plan_reduced_system(p, cam_block_, ocam, opt, Creal, P_total_, with_memory_order, border_ok, opt_.border,
@@ -1272,15 +1275,24 @@ int BalSolver::setup() {
   // Retained points rule out the segmented distribution (their rows couple with every segment), so a world of ranks decides HERE
   // between sharding the points and replicating the solve — before the dissection: a rank that replicates is a single device from
   // here on (choose_distribution), and takes the lock-step dissection a single device takes
+  // Round 5: ... unless the world can take the sequence as TWO segments — head and tail on two ranks' devices, the retained points'
+  // pseudo-cameras (and a border of loop-closure cameras) members of the one separator, exactly the fronts a single device holds side by
+  // side: tried first (pass 0 below), against what one device would do with the lock-step plan.
   bool distribution_decided = false;
-  if (opt_.allreduce && opt_.world > 1 && pseudo_cams_ > 0) {
+  auto shard_or_replicate = [&]() -> int {
     int rc = prepare_pack();
     if (rc) return rc;
     rc = choose_distribution(opt);
     if (rc) return rc;
     distribution_decided = true;
+    return SK_OK;
+  };
+  const bool seg_modes = opt_.distribution_mode == SK_DISTRIBUTION_AUTO || opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED;
+  if (opt_.allreduce && opt_.world > 1 && pseudo_cams_ > 0 && !seg_modes) {
+    int rc = shard_or_replicate();
+    if (rc) return rc;
   }
-  {
+  for (int pass = 0; pass < 2; ++pass) {
     const int nblk = npad_ / 128;
     // ---- dissect?  One process: only when forced (measured not to pay on one chip).  Several ranks: the SEGMENTED
     // distribution — every rank's device eliminates one segment of the camera sequence — when the model of the chains
@@ -1298,10 +1310,11 @@ int BalSolver::setup() {
       const int lm = std::min(env_for_model[c], nblk - 1), main_rows = lm > c ? lm - c : 0;
       band_chain_bound = main_rows + std::max(0, nblk - std::max(env_tail_[c], c + 1 + main_rows)) <= 24;
     }
-    const bool pseudo_border = border_members_ > 0 && !multi && (pseudo_cams_ > 0 || band_chain_bound);
+    const bool two_seg_try = multi && pseudo_cams_ > 0 && seg_modes && !distribution_decided;  // (see above)
+    const bool pseudo_border = border_members_ > 0 && (!multi || two_seg_try) && (pseudo_cams_ > 0 || band_chain_bound);
     const int Cband = C_ - (pseudo_border ? border_members_ : 0);
     const bool plan_ok = opt_.dissection != SK_DISSECTION_OFF && opt_.envelope && opt_.lookahead && opt_.cholesky_group == 0 && (env_tail_.empty() || pseudo_border);
-    bool may_dissect = plan_ok && (multi ? (pseudo_cams_ == 0 && (opt_.distribution_mode == SK_DISTRIBUTION_AUTO || opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED))
+    bool may_dissect = plan_ok && (multi ? ((pseudo_cams_ == 0 || two_seg_try) && seg_modes)
                                          : (!opt_.allreduce && chol_ctx_b_.init_secondary(chol_ctx_) == hipSuccess));
     if (!may_dissect) (void)hipGetLastError();
     if (!plan_ok && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED) {
@@ -1309,7 +1322,7 @@ int BalSolver::setup() {
       return SK_ERR_UNSUPPORTED;
     }
     std::vector<int> cut_a, cut_b;  // the separators [a, b) in the banded numbering, ascending
-    if (may_dissect && multi) {
+    if (may_dissect && multi && !two_seg_try) {
       std::vector<int> first_col;
       (void)envelope_of_order(ocam, opt, [&] { std::vector<int> e(C_); std::iota(e.begin(), e.end(), 0); return e; }(), C_, P_total_, nblk, &first_col);
       int max_seg = opt_.world;
@@ -1360,8 +1373,22 @@ int BalSolver::setup() {
         extra_bwd_col.assign(dnblk, 0);
         for (int c = 0; c < dnblk; ++c) extra_bwd_col[c] = (9 * active[c] + 127) / 128;
       }
-      ds = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, lockstep_cut, lockstep_cut, C_ - Cband, pseudo_border ? &extra_fwd : nullptr, extra_bwd,
+      ds = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, lockstep_cut || two_seg_try, lockstep_cut, C_ - Cband, pseudo_border ? &extra_fwd : nullptr, extra_bwd,
                              pseudo_border ? &extra_bwd_col : nullptr);
+      if (two_seg_try) {
+        // two devices, a chain each, against ONE device with the two fronts in lock-step (what a replicating rank would run): + the
+        // all-reduce of the separator's system (its lower triangle over one xGMI link per direction: choose_segments)
+        const Dissection one = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, true, true, C_ - Cband, pseudo_border ? &extra_fwd : nullptr, extra_bwd,
+                                                 pseudo_border ? &extra_bwd_col : nullptr);
+        const double one_us = one.a > 0 ? one.t_dissected : one.t_plain;
+        const double E = ds.a > 0 ? (9.0 * (ds.b - ds.a + C_ - Cband) + 1.0 + 127.0) / 128.0 : 0.0;
+        const int W = std::max(2, opt_.world);
+        const double allreduce_us = 50.0 + 2.0 * (W - 1.0) / W * 0.5 * E * (E + 1.0) * 128.0 * 128.0 * 8.0 / 153e3;
+        model_us_[1] = one_us; model_us_[2] = ds.a > 0 ? ds.t_dissected + allreduce_us : 0.0;
+        if (dev_knobs().debug_segments) std::fprintf(stderr, "[skeres_amd] two segments with %d border members in the separator: %.0f us + all-reduce %.0f us against %.0f us on one device\n",
+                                                     border_members_, ds.t_dissected, allreduce_us, one_us);
+        if (ds.a > 0 && opt_.distribution_mode != SK_DISTRIBUTION_SEGMENTED && ds.t_dissected + allreduce_us >= 0.9 * one_us) ds.a = ds.b = 0;
+      }
       if (lockstep_cut && ds.a > 0) {  // (two resident servers per factorisation: the fifth such solver alive on a device stays undissected)
         if (!pair_claimed_) pair_claimed_ = cholesky_claim_pair_servers(&chol_ctx_);
         if (!pair_claimed_) ds.a = ds.b = 0;
@@ -1369,7 +1396,17 @@ int BalSolver::setup() {
       // AUTO does not dissect on ONE device: measured on MI355X (profiles/r02_dissection_*), the two chains side by side
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
       // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon there.
-      if (opt_.dissection == SK_DISSECTION_AUTO && dev_knobs().dissect_at < 0 && !lockstep_cut) { ds.a = ds.b = 0; }
+      if (opt_.dissection == SK_DISSECTION_AUTO && dev_knobs().dissect_at < 0 && !lockstep_cut && !two_seg_try) { ds.a = ds.b = 0; }
+      if (two_seg_try && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && ds.a == 0 && Cband >= 6) {
+        // forced (tests, small problems): cut the band at its middle camera wherever that leaves a tail
+        std::vector<int> cmin(P_total_, Cband), cmax(P_total_, -1);
+        for (size_t b = 0; b < docam.size(); ++b) { cmin[dopt[b]] = std::min(cmin[dopt[b]], docam[b]); cmax[dopt[b]] = std::max(cmax[dopt[b]], docam[b]); }
+        for (int a = Cband / 2; a >= 1 && ds.a == 0; --a) {
+          int b = a;
+          for (int q = 0; q < P_total_; ++q) if (cmin[q] < a) b = std::max(b, cmax[q] + 1);
+          if (b < Cband) { ds.a = a; ds.b = b; }
+        }
+      }
       if (opt_.dissection == SK_DISSECTION_ON && ds.a == 0 && C_ >= 6) {
         // forced (tests, small problems): cut at the middle camera wherever that leaves a tail
         std::vector<int> cmin(P_total_, C_), cmax(P_total_, -1);
@@ -1391,11 +1428,26 @@ int BalSolver::setup() {
         } else ds.a = 0;
       }
       dissect_t_plain_ = ds.t_plain; dissect_t_model_ = ds.t_dissected;
-      {  // what the chain model predicts for 2 .. 8 devices (sk_solver_stat "model_us_segments_<n>": bench.py prints it beside what it measures)
+      if (!two_seg_try) {  // what the chain model predicts for 2 .. 8 devices (sk_solver_stat "model_us_segments_<n>": bench.py prints it beside what it measures)
         const Segments sg = choose_segments(docam, dopt, Cband, P_total_, dnblk, denv, first_col, 8, false);
         for (int k = 0; k < 9; ++k) model_us_[k] = sg.model_us[k];
+        if (pseudo_border) {
+          // ... and with the border's members (retained points) in the one separator of TWO segments, a device each — what a world of ranks
+          // takes when it beats this device's plan by 10 % (pass 0 above): "model_us_two_segments_with_members"
+          const Dissection two = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, true, false, C_ - Cband, &extra_fwd, extra_bwd, &extra_bwd_col);
+          if (two.a > 0) {
+            const double E = (9.0 * (two.b - two.a + C_ - Cband) + 1.0 + 127.0) / 128.0;
+            two_segments_members_us_ = two.t_dissected + 50.0 + 0.5 * E * (E + 1.0) * 128.0 * 128.0 * 8.0 / 153e3;  // (+ the root's all-reduce over two ranks)
+          }
+        }
       }
       if (ds.a > 0 && ds.b < Cband) { cut_a.push_back(ds.a); cut_b.push_back(ds.b); }
+    }
+    if (two_seg_try && cut_a.empty() && opt_.distribution_mode != SK_DISTRIBUTION_SEGMENTED) {
+      // no cut that pays: shard the points or replicate (a replicating rank is a single device from here on), then once more
+      int rc = shard_or_replicate();
+      if (rc) return rc;
+      continue;
     }
     if (multi && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && cut_a.empty()) {
       set_error("the segmented distribution needs a separator in the camera sequence (no point seen from both ends); not supported for this problem");
@@ -1432,6 +1484,7 @@ int BalSolver::setup() {
       cam_a_ = seg_off_[1];  // (one device: the head [0, cam_a_), the tail [cam_a_, cam_b_))
       segments_ = R;
     }
+    break;
   }
   if (segmented_) {
     // Rank r < segments_ owns segment r; further ranks are replicas of rank (r mod segments_): they do the same work and
@@ -1467,20 +1520,40 @@ int BalSolver::setup() {
   // its segment — each such point sees only that segment and the separator — plus every other of the points that see the
   // separator alone ----
   std::vector<int> local_of(P_total_, -1);
+  std::vector<int> obs_rank;  // segmented world with retained points: the rank of every observation of a retained point (-1: not one)
   if (segmented_) {
     std::vector<int> seg_of_cam(C_, -1);  // (separator cameras: -1)
     for (int sg = 0; sg < segments_; ++sg) for (int c = seg_off_[sg]; c < seg_off_[sg + 1]; ++c) seg_of_cam[c] = sg;
     std::vector<int> seg_of_pt(P_total_, -1);
+    // A RETAINED point is seen from every segment its track crosses: its observations are split by camera — those of a segment's cameras
+    // to that segment's rank, those of separator cameras to its HOME rank (q mod segments) — and every rank that has any of them keeps a
+    // copy of the point.  What is a sum over the point's observations (its column norms, gradient, T = sum E^T E) is summed over the
+    // ranks; what is the point's own (D_p^2, the right-hand side's entry, |x_p|^2, |delta_p|^2, the value written back) is the home rank's.
+    std::vector<char> is_kept(P_total_, 0);
+    for (int q : retained_pts_) is_kept[q] = 1;
+    obs_rank.assign(Nall, -1);  // (kept observations only)
     for (int b = 0; b < Nall; ++b) {
       const int sg = seg_of_cam[ocam[b]];
+      if (is_kept[opt[b]]) { obs_rank[b] = sg >= 0 ? sg : opt[b] % segments_; continue; }
       if (sg < 0) continue;
       if (seg_of_pt[opt[b]] >= 0 && seg_of_pt[opt[b]] != sg) { set_error("internal: a point is seen from two segments of the camera sequence"); return SK_ERR_UNSUPPORTED; }
       seg_of_pt[opt[b]] = sg;
     }
+    std::vector<char> kept_here(P_total_, 0);
+    for (int b = 0; b < Nall; ++b) if (obs_rank[b] == role_) kept_here[opt[b]] = 1;
+    std::vector<int> guests;  // copies of retained points whose home is another rank: LAST among the local points (the norms run over the others)
     for (int q = 0; q < P_total_; ++q) {
+      if (is_kept[q]) {
+        const bool home = (q % segments_) == role_;
+        if (home) { local_of[q] = (int)local_pt_.size(); local_pt_.push_back(q); }
+        else if (kept_here[q]) guests.push_back(q);
+        continue;
+      }
       const bool mine = seg_of_pt[q] == role_ || (seg_of_pt[q] < 0 && (q % segments_) == role_);
       if (mine) { local_of[q] = (int)local_pt_.size(); local_pt_.push_back(q); }
     }
+    P_own_ = (int)local_pt_.size();
+    for (int q : guests) { local_of[q] = (int)local_pt_.size(); local_pt_.push_back(q); }
   } else {
     int p_lo = 0, p_hi = P_total_;
     if (opt_.world > 1) {
@@ -1492,14 +1565,16 @@ int BalSolver::setup() {
     for (int q = p_lo; q < p_hi; ++q) local_of[q] = q - p_lo;
   }
   P_ = (int)local_pt_.size();
+  if (!segmented_) P_own_ = P_;
+  auto obs_here = [&](int b) { return local_of[opt[b]] >= 0 && (obs_rank.empty() || obs_rank[b] < 0 || obs_rank[b] == role_); };
   // local observations, point-major, ascending camera within a point
   std::vector<int> pt_start(P_ + 1, 0);
-  for (int b = 0; b < Nall; ++b) if (local_of[opt[b]] >= 0) pt_start[local_of[opt[b]] + 1]++;
+  for (int b = 0; b < Nall; ++b) if (obs_here(b)) pt_start[local_of[opt[b]] + 1]++;
   for (int q = 0; q < P_; ++q) pt_start[q + 1] += pt_start[q];
   N_ = pt_start[P_];
   std::vector<int> order(N_);
   { std::vector<int> fill(pt_start.begin(), pt_start.end() - 1);
-    for (int b = 0; b < Nall; ++b) if (local_of[opt[b]] >= 0) order[fill[local_of[opt[b]]]++] = b; }
+    for (int b = 0; b < Nall; ++b) if (obs_here(b)) order[fill[local_of[opt[b]]]++] = b; }
   for (int q = 0; q < P_; ++q)
     std::sort(order.begin() + pt_start[q], order.begin() + pt_start[q + 1], [&](int a, int b) { return ocam[a] != ocam[b] ? ocam[a] < ocam[b] : a < b; });
   std::vector<int> cam(N_), pt(N_);
@@ -1527,12 +1602,13 @@ int BalSolver::setup() {
   for (int i = 0; i < C_; ++i) cam_start[i + 1] += cam_start[i];
   { std::vector<int> fill(cam_start.begin(), cam_start.end() - 1); for (int o = 0; o < N_; ++o) cam_obs[fill[cam[o]]++] = o; }
   // retained points of this rank: local point, pseudo-camera, slot
-  std::vector<int> kept_of_local(P_, -1), kept_pt, kept_cam;
+  std::vector<int> kept_of_local(P_, -1), kept_pt, kept_cam, kept_home, kept_global;
   for (size_t k = 0; k < retained_pts_.size(); ++k) {
     const int q = local_of[retained_pts_[k]];
     if (q < 0) continue;
     kept_of_local[q] = (int)k;
     kept_pt.push_back(q); kept_cam.push_back(3 * retained_cam_[k] + (int)(k % 3));
+    kept_home.push_back(q < P_own_ ? 1 : 0); kept_global.push_back((int)k);
   }
   // pair lists: for every point that is eliminated, every (larger camera, smaller camera) pair of its observations
   size_t npairs = 0;
@@ -1656,6 +1732,7 @@ int BalSolver::setup() {
     for (int i = 0; i < C_; ++i) pseudo[i] = cam_block_[i] < 0 ? 1 : 0;
     SK_HIP_TRY(b_pseudo_.upload(pseudo, s));
     SK_HIP_TRY(b_kept_pt_.upload(kept_pt, s)); SK_HIP_TRY(b_kept_cam_.upload(kept_cam, s));
+    if (segmented_) { SK_HIP_TRY(b_kept_home_.upload(kept_home, s)); SK_HIP_TRY(b_kept_global_.upload(kept_global, s)); }
     std::vector<int> kept_obs, kept_obs_slot;
     for (size_t k = 0; k < kept_pt.size(); ++k)
       for (int o = pt_start[kept_pt[k]]; o < pt_start[kept_pt[k] + 1]; ++o) { kept_obs.push_back(o); kept_obs_slot.push_back((int)k); }
@@ -1689,7 +1766,7 @@ int BalSolver::setup() {
       for (int c = rl; c < rh; ++c) pos[c] = bo + lay.right_off + 9 * (c - rl);
       // (the members of a border — one device: the end of the one separator — stay at the END of a reversed border too: their rows are
       // tail rows of the front's envelope, a suffix of the matrix)
-      const int nbm = segmented_ ? 0 : border_members_;
+      const int nbm = border_members_;  // (a segmented world has members only when it is cut in two: the one separator's end, as on one device)
       const int lreal = lh - nbm;
       for (int c = ll; c < lh; ++c) pos[c] = bo + lay.left_off + (lay.reversed && c < lreal ? 9 * (lreal - 1 - c) : 9 * (c - ll));
       const std::vector<int>& fo = struct_ocam_.empty() ? ocam : struct_ocam_;
@@ -1759,13 +1836,14 @@ int BalSolver::setup() {
   }
   partial_stride_ = std::max(std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_) + 1), (9 * C_ + 255) / 256), 256) + bal_partial_blocks((int)host_obs_.size());  // (+ 1: the retained points' slot)
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
-  SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_scal_.zero(s)); SK_HIP_TRY(b_small_.alloc(2 * nc + 64 + 16 * (size_t)opt_.world));
+  SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_scal_.zero(s)); SK_HIP_TRY(b_small_.alloc(2 * nc + 6 * retained_pts_.size() + 64 + 16 * (size_t)opt_.world));
   fail_p_ = reinterpret_cast<int*>(b_scal_.p + 14); info_p_ = reinterpret_cast<int*>(b_scal_.p + 15);
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
   d_.pseudo = pseudo_cams_ > 0 ? b_pseudo_.p : nullptr; d_.num_kept = pseudo_cams_ > 0 ? (int)kept_pt.size() : 0; d_.kept_pt = b_kept_pt_.p; d_.kept_cam = b_kept_cam_.p;
   d_.num_kept_obs = pseudo_cams_ > 0 ? num_kept_obs_ : 0; d_.kept_obs = b_kept_obs_.p; d_.kept_obs_slot = b_kept_obs_slot_.p;
+  d_.kept_home = segmented_ && pseudo_cams_ > 0 ? b_kept_home_.p : nullptr; d_.kept_global = segmented_ && pseudo_cams_ > 0 ? b_kept_global_.p : nullptr;
   d_.num_dup = num_dup_; d_.dup_a = b_dup_a_.p; d_.dup_b = b_dup_b_.p; d_.dup_cam = b_dup_cam_.p;
   d_.res_size = res_size_; d_.cam_size = cam_size_; d_.pt_size = pt_size_;
   d_.cam = b_cam_.p; d_.pt = b_pt_.p; d_.obs = b_obs_.p; d_.pt_start = b_pt_start_.p; d_.cam_start = b_cam_start_.p; d_.cam_obs = b_cam_obs_.p; d_.obs_slot = b_obs_slot_.p;
@@ -1787,6 +1865,7 @@ int BalSolver::setup() {
     const FrontHost& F = fr_[0];
     leaf_.S = d_.front[0].S; leaf_.ld = (long)F.dim; leaf_.nblk = F.nblk; leaf_.ncols = F.ncols; leaf_.last = F.env();
     leaf_.Linv = b_Linv_.p + F.linv_off; leaf_.rhs_row = F.rhs_row; leaf_.tail_rows = F.tail_rows; leaf_.spike = role_ > 0 && role_ + 1 < segments_;
+    leaf_.tail = F.tl();  // (two segments with border members in the separator: their rows are a tail profile of the leaf's envelope)
   }
   if (dissected_ && !segmented_) {
     auto view = [&](int f) {
@@ -1855,7 +1934,7 @@ int BalSolver::gather_rank_scalars_signed(double* vals, int K) {
   const int W = opt_.world;
   std::vector<double> table((size_t)W * K, 0.0);
   for (int k = 0; k < K; ++k) table[(size_t)opt_.rank * K + k] = vals[k];
-  double* dev = b_small_.p + 2 * 9 * (size_t)C_ + 64;
+  double* dev = b_small_.p + 2 * 9 * (size_t)C_ + 6 * retained_pts_.size() + 64;
   SK_HIP_TRY(hipMemcpyAsync(dev, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
   int rc = allreduce(dev, table.size());
   if (rc) return rc;
@@ -1877,7 +1956,7 @@ int BalSolver::gather_rank_scalars(double* vals, int K, const int* ops) {
   const int W = opt_.world;
   std::vector<double> table((size_t)W * K, 0.0);
   for (int k = 0; k < K; ++k) table[(size_t)opt_.rank * K + k] = vals[k];
-  double* dev = b_small_.p + 2 * 9 * (size_t)C_ + 64;
+  double* dev = b_small_.p + 2 * 9 * (size_t)C_ + 6 * retained_pts_.size() + 64;
   SK_HIP_TRY(hipMemcpyAsync(dev, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
   int rc = allreduce(dev, table.size());
   if (rc) return rc;
@@ -1916,16 +1995,21 @@ int BalSolver::evaluate_with_jacobian(bool first) {
   kt_.begin("bal_reduce", s); launch_bal_reduce(d_, s); kt_.end("bal_reduce", s);
   if (opt_.allreduce) {  // camera columns are summed over all ranks' observations
     double* buf = b_small_.p;
+    // (a segmented world with retained points: their observations are split over the ranks — their column norms and gradient travel too)
+    const size_t nk = segmented_ && pseudo_cams_ > 0 ? 6 * retained_pts_.size() : 0;
+    if (nk) SK_HIP_TRY(hipMemsetAsync(buf + 2 * nc, 0, nk * sizeof(double), s));
     if (replica_) {  // its sums are rank (r mod segments_)'s over again
       SK_HIP_TRY(hipMemsetAsync(buf, 0, 2 * nc * sizeof(double), s));
     } else {
       SK_HIP_TRY(hipMemcpyAsync(buf, d_.colsq_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
       SK_HIP_TRY(hipMemcpyAsync(buf + nc, d_.gs_c, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
+      if (nk) launch_bal_kept_sums(d_, buf + 2 * nc, (int)retained_pts_.size(), true, s);
     }
-    int rc = allreduce(buf, 2 * nc);
+    int rc = allreduce(buf, 2 * nc + nk);
     if (rc) return rc;
     SK_HIP_TRY(hipMemcpyAsync(d_.colsq_c, buf, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
     SK_HIP_TRY(hipMemcpyAsync(d_.gs_c, buf + nc, nc * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (nk) launch_bal_kept_sums(d_, buf + 2 * nc, (int)retained_pts_.size(), false, s);
   }
   if (first && opt_.jacobi_scaling) {
     launch_jacobi_scale(b_colsq_.p, b_scale_.p, (int)(nc + np), s);
@@ -1957,8 +2041,10 @@ int BalSolver::evaluate_with_jacobian(bool first) {
     gc += launch_grad_max_xnorm(d_.gs_c + lo2, d_.scale_c + lo2, d_.xc + lo2, n2, b_partial_.p + gc, partial_stride_, s);
   }
   launch_final_reduce(b_partial_.p, partial_stride_, gc, 2, 1, b_scal_.p, s);
-  const int gp = launch_grad_max_xnorm(d_.gs_p, d_.scale_p, d_.xp, (int)np, b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, s);
-  launch_final_reduce(b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, np ? gp : 0, 2, 1, b_scal_.p + 2, s);
+  // (the points this rank accounts for: all its own — not the copies of retained points whose home is another rank, which come last)
+  const int np_own = 3 * P_own_;
+  const int gp = launch_grad_max_xnorm(d_.gs_p, d_.scale_p, d_.xp, np_own, b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, s);
+  launch_final_reduce(b_partial_.p + 2 * (size_t)partial_stride_, partial_stride_, np_own ? gp : 0, 2, 1, b_scal_.p + 2, s);
   }
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 5 * sizeof(double), hipMemcpyDeviceToHost, s));
   }
@@ -2078,7 +2164,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     double* Rs = d_.front[2].S;
     double* RLinv = b_Linv_.p + R.linv_off;
     if (L.ncols > 0) {
-      cholesky_factor(L.S, L.ld, L.nblk * 128, L.Linv, info_p_, group_, s, ctx, &kt_, L.last, chain_ok(), L.ncols, L.tail_rows);
+      cholesky_factor(L.S, L.ld, L.nblk * 128, L.Linv, info_p_, group_, s, ctx, &kt_, L.last, chain_ok(), L.ncols, L.tail_rows, nullptr, L.tail);
       cholesky_border_add(Rs, (long)R.dim, L.S, L.ld, L.ncols, L.nblk - L.ncols, b_leaf_map_.p, s);
     }
     if (replica_) SK_HIP_TRY(hipMemsetAsync(b_pack_.p, 0, packed_elems_ * sizeof(double), s));  // a replica adds nothing
@@ -2091,7 +2177,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info, nullptr, zero_after, bs_resident);
     if (L.ncols > 0) {
       cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
-      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info, zero_after, nullptr, nullptr, bs_resident);
+      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info, zero_after, L.tail, nullptr, bs_resident);
     }
   } else if (dissected_) {
     cholesky_dissected_factor(ds_, info_p_, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
@@ -2251,8 +2337,8 @@ int BalSolver::write_back() {
   }
   // every rank returns ALL points: zero-filled table, own slice filled, sum-reduced
   std::vector<double> all(3 * (size_t)P_total_, 0.0);
-  if (!replica_)  // (a replica adds zeros)
-    for (int q = 0; q < P_; ++q) std::memcpy(&all[3 * (size_t)local_pt_[q]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
+  if (!replica_)  // (a replica adds zeros; so does a copy of a retained point whose home is another rank: the copies come last)
+    for (int q = 0; q < P_own_; ++q) std::memcpy(&all[3 * (size_t)local_pt_[q]], &x[nc + 3 * (size_t)q], 3 * sizeof(double));
   DevBuf<double> tmp;
   SK_HIP_TRY(tmp.upload(all, stream_));
   int rc = allreduce(tmp.p, all.size());

@@ -72,7 +72,7 @@ const DevKnobs& dev_knobs() {
     k.pair_max_trailing = num("SK_CHAIN_PAIR_MAX_TRAILING", 0);
     k.dissect_at = num("SK_DISSECT_AT", -1);
     k.schedule_plain = num("SK_SCHEDULE_PLAIN", 0);
-    k.chain_xcd_local = num("SK_CHAIN_XCD_LOCAL", 1);
+    k.chain_xcd_local = num("SK_CHAIN_XCD_LOCAL", 0);
     if (const char* e = getenv("SK_BULK_RESERVE")) {
       k.bulk_reserve = atoi(e);
       const char* c = strchr(e, ',');

@@ -1125,23 +1125,13 @@ __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int
     double* Xj = Xs + (size_t)j * 128 * 128;  // this column's own scratch block: nothing of it has been read before by anybody
     const bool lower = q <= ri;               // the server reads the lower 32-blocks of the diagonal block only
     double* Ct = A21 + 128 + (long)(ri * 32) * ld + q * 32;
-    // what comes from other XCDs — S(j+1,j) with column j-1's update (in memory since that launch ended) and S(j+1,j+1) with
-    // syrk(j-1)'s (its first block column, counted by its own workgroups) — first, while the chain is still inside potrf(j)
-    if (threadIdx.x == 0) ok_s = (chain_wait(sync + kSyncSyrkSeq, syrk_need, abort_flag) && chain_wait(sync + kSyncSyrkColumn, column_need, abort_flag)) ? 1 : 0;
-    __syncthreads();
-    if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (every wave: its loads below must not come from a stale line)
-    d4 cacc = {0.0, 0.0, 0.0, 0.0};
     {
-      // rows ri of S(j+1,j) -> LDS (first half of sh); the C tile -> registers
+      // rows ri of S(j+1,j) -> LDS (first half of sh): final since the launch before this one ended (stream order), which is also
+      // when this CU's caches were last invalidated — no wait, no fence
       const int t = threadIdx.x, row = t >> 3, c0 = (t & 7) * 16;
       double2 va[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) va[i] = *reinterpret_cast<const double2*>(A21 + (long)(ri * 32 + row) * ld + c0 + 2 * i);
-      if (lower) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cacc[i] = -Ct[crit_tile_off(ld, i)];
-      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(sh + row * kCritLd + c0 + 2 * i) = va[i];
     }
@@ -1168,22 +1158,63 @@ __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int
     __syncthreads();
     if (threadIdx.x == 0) store_l2(sync + kSyncXSlot + b, j + 1);
     if (stamp) SK_CHAIN_STAMP(j, 4)
+    // the other fifteen tiles of X (this XCD's L2), and — from the other XCDs — syrk(j-1)'s update of S(j+1,j+1): its first block column,
+    // written through to memory and counted by its own workgroups.  Two lanes wait side by side.
+    __shared__ int ok2_s;
     if (threadIdx.x == 0) ok_s = chain_wait_slots(sync + kSyncXSlot, j + 1, abort_flag) ? 1 : 0;
-    __syncthreads();
-    if (!ok_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
-    if (stamp) SK_CHAIN_STAMP(j, 5)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) A21[(long)(ri * 32) * ld + q * 32 + crit_tile_off(ld, i)] = xacc[i];  // every tile has read S(j+1,j) by now
-    if (b == 1 && threadIdx.x == 0) {
-      // (tile (0, 1) has no update to do) X(j+1,j) to memory for the thin tiles of this launch, which may be anywhere on the chip:
-      // one write-back of this XCD's L2 covers all sixteen tiles' stores
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __hip_atomic_fetch_add(x_ready, 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 64) {
+      // (no acquire fence: what depends on these counters is read past the caches, below)
+      bool ok = true;
+      const int* cnt[2] = {sync + kSyncSyrkSeq, sync + kSyncSyrkColumn};
+      const int need[2] = {syrk_need, column_need};
+      for (int w = 0; w < 2 && ok; ++w)
+        if (sync_load(cnt[w]) < need[w]) {
+          const long long t0 = wall_clock64();
+          do {
+            __builtin_amdgcn_s_sleep(2);
+            if (sync_load(abort_flag) != 0 || wall_clock64() - t0 > kChainTimeoutTicks) { __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+          } while (sync_load(cnt[w]) < need[w]);
+        }
+      ok2_s = ok ? 1 : 0;
     }
+    __syncthreads();
+    if (!ok_s || !ok2_s) { if (threadIdx.x == 0) info_raise(info, 2); return; }
+    if (stamp) SK_CHAIN_STAMP(j, 5)
+    d4 cacc = {0.0, 0.0, 0.0, 0.0};
+    double2 va[8], vb[8];
+    {
+      const int t = threadIdx.x, row = t >> 3, c0 = (t & 7) * 16;
+      if (lower) {
+        // the C tile past the caches (device-scope loads: syrk(j-1)'s tiles wrote it through from other XCDs; a stale line may sit in this
+        // XCD's L2), and rows ri and q of X from the L2 — all in flight together
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cacc[i] = -__hip_atomic_load(Ct + crit_tile_off(ld, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) va[i] = *reinterpret_cast<const double2*>(Xj + (long)(ri * 32 + row) * 128 + c0 + 2 * i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vb[i] = *reinterpret_cast<const double2*>(Xj + (long)(q * 32 + row) * 128 + c0 + 2 * i);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) A21[(long)(ri * 32) * ld + q * 32 + crit_tile_off(ld, i)] = xacc[i];  // every tile has read S(j+1,j) by now
+      if (b == 1 && threadIdx.x == 0) {
+        // (tile (0, 1) has no update to do) X(j+1,j) to memory for the thin tiles of this launch, which may be anywhere on the chip: one
+        // write-back of this XCD's L2 covers all sixteen tiles' stores.  (Writing the tiles through beside the plain stores, so that every
+        // tile could count itself without a write-back, put the acknowledgement of those stores on the critical path: 8-9 us per tile step
+        // instead of 5 — measured, not kept.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(x_ready, 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (lower) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(sh + row * kCritLd + c0 + 2 * i) = va[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<double2*>(sh + (32 + row) * kCritLd + c0 + 2 * i) = vb[i];
+      }
+    }
+    __syncthreads();
     if (lower) {
-      // S(j+1,j+1) tile -= X[rows ri] X[rows q]^T, X from the L2
-      crit_tile_load(sh, Xj + (long)ri * 32 * 128, 128, Xj + (long)q * 32 * 128, 128);
-      __syncthreads();
+      // S(j+1,j+1) tile -= X[rows ri] X[rows q]^T
       cacc = crit_tile_mma(sh, cacc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) Ct[crit_tile_off(ld, i)] = -cacc[i];
@@ -1532,7 +1563,8 @@ constexpr int g_chain_max_trailing = 24, g_chain_prefix_group = 2;  // see chole
 static int g_pair_max_trailing = 0;
 constexpr int g_thin_syrk_tiles = 48;  // trailing matrices of at most this many block rows use the 32 x 128-tile SYRK
 constexpr int g_tail_tiles = 48, g_tail_group = 1;  // see cholesky_group_bounds (measured: 40-54 within 0.3 %)
-static int g_chain_local = 1;  // developer variable SK_CHAIN_XCD_LOCAL=0: the resident chain's hand-overs all through device-scope counters (rounds 1-4)
+static int g_chain_local = 0;  // developer variable SK_CHAIN_XCD_LOCAL=1: the XCD-local hand-over below (measured in round 5: 39.5 -> 37.3 us per column of ONE front, but 44.5 -> ~48 us per
+                               // step of two fronts in lock-step, which is what the default plan runs: off by default; profiles/r05_xcd_local_chain.txt)
 static std::atomic<int> g_bs_resident{1};  // developer knob SK_BS_RESIDENT=0: the back-substitution as one launch per block step (bs_step_kernel)
 // Fault injection, compiled in only with -DSK_TESTING (libskeres_amd_testing.so, `make testing`; never in the product library):
 // SK_CHAIN_TEST_WITHHOLD_MARKER=<block column> withholds, once per process, what that column's launch waits for — the wait

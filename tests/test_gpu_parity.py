@@ -1528,6 +1528,16 @@ def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode, shape=None, 
     assert "DIST_GPU2_OK world=%d" % world in out.stdout
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_segmented_world_cut_in_two_with_retained_points_in_the_separator(world):
+    """Round-4 verdict, item 3: retained points no longer rule the segmented distribution out.  The camera sequence is cut in TWO
+    (sk_options_set_max_segments(o, 2)), the pseudo-cameras of the twelve retained points are members of the one separator — exactly the
+    fronts one device holds side by side — and a retained point's observations are split over the ranks by camera: its column norms
+    and gradient travel in the small all-reduce, its rows of the root are summed with it, its own terms come from its home rank.
+    Worlds of 2 and of 4 (two replicas) sharing GPU 0 over gloo, against the single-GPU trajectory with every point eliminated: 1e-10."""
+    test_sharded_solve_on_one_gpu_with_a_real_exchange(world, "segmented", shape="600,6000,26000,9,kept2", segments=2)
+
+
 @pytest.mark.parametrize("mode", ["sharded", "auto"])
 def test_venice_1778_at_full_size_sharded_over_two_ranks(mode):
     """BASELINE.json configs[3] as it is DEFINED — Venice-1778 with the residual blocks sharded over ranks and the reduced system
