@@ -427,33 +427,19 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 1
     const double e = __builtin_fma(-d, y, 1.0);
-#if SK_PROBE_VARIANT == 3
-    // (probe: the next column's value without waiting for the refined multiplier m — a[j+1] - m0 (1 + q) l1 as (a[j+1] - p) - q p with
-    // p = m0 l1 formed BESIDE the refinement: the dependent chain is rcp, e, q, a[j+1] instead of rcp, e, q, m, a[j+1])
-    const double pch = m0 * l1;
-#endif
     __builtin_amdgcn_sched_barrier(0);
     SK_FILL(1)
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 2
     const double q = __builtin_fma(e, e, e);
-#if SK_PROBE_VARIANT == 3
-    const double t1 = j + 1 < 32 ? a[j + 1] - pch : 0.0;
-#endif
     __builtin_amdgcn_sched_barrier(0);
     SK_FILL(2)
     __builtin_amdgcn_sched_barrier(0);
     // ---- chain 3
-#if SK_PROBE_VARIANT == 3
-    if (j + 1 < 32) {
-      a[j + 1] = __builtin_fma(-q, pch, t1);
-      colbuf[((j + 1) % 3) * 64 + lane] = a[j + 1];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    SK_FILL(3)
-    __builtin_amdgcn_sched_barrier(0);
-    const double m = __builtin_fma(m0, q, m0);  // (for the late updates of the next step)
-#else
+    // (Round 5 tried the next column's value without waiting for the refined multiplier — (a[j+1] - m0 l1) - q (m0 l1), the dependent chain
+    // rcp, e, q, a[j+1] instead of rcp, e, q, m, a[j+1]: 8936 clocks per 32 columns against 8732.  The loop is bound by the ISSUE of its
+    // ~38 instructions per column — a lone wave issues an fp64 instruction every ~6 clocks, two waves on one SIMD every 3.9:
+    // tools/valu_f64_probe.hip — not by the chain's latency: without the late updates a column takes 158 clocks, with them 272.)
     const double m = __builtin_fma(m0, q, m0);
     __builtin_amdgcn_sched_barrier(0);
     SK_FILL(3)
@@ -463,7 +449,6 @@ __device__ __forceinline__ bool wave_potrf32(const double* D, double* colbuf, do
       a[j + 1] = __builtin_fma(-m, l1, a[j + 1]);
       colbuf[((j + 1) % 3) * 64 + lane] = a[j + 1];
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     SK_FILL(4)
     __builtin_amdgcn_sched_barrier(0);
