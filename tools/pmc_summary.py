@@ -72,7 +72,10 @@ def main():
         out["linear_solves_in_the_pass"] = iters
         out["hbm_bytes_per_iteration"] = totals
     if len(sys.argv) > 4:
-        line = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import bench_record
+        line = bench_record.load(sys.argv[4])  # (the run's detailed record: bench.py's side file, SK_BENCH_DETAILS)
         roof = line["roofline"]
         n_obs = line["config"].get("observations")
         alg = roof.get("algorithmic_c_tile_bytes_per_launch")

@@ -14,7 +14,10 @@ import sys
 
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "syrk_trailing" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-line = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench_record
+line = bench_record.load(sys.argv[2])  # (the run's detailed record: bench.py's side file, SK_BENCH_DETAILS)
 n = int(line["roofline"]["launches"])
 timed = rows[-n:]
 dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in timed]
