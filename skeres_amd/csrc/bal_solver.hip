@@ -1093,7 +1093,10 @@ int BalSolver::choose_distribution(const std::vector<int>& opt) {
     for (int v : opt) k[v]++;
     double pairs = 0.0;
     for (size_t v : k) pairs += 0.5 * (double)v * (double)(v - 1);
-    const double per_iter = 0.15e-9 * pairs + 1.9e-9 * (double)opt.size();  // seconds on one MI355X (profiles/r01_d_*)
+    // seconds on one MI355X of the phases that shard with the points (Jacobians, Schur assembly, back-substitution, candidate cost).  Round 5:
+    // recalibrated on the bench records — Ladybug-1723 0.66 ms (679 k observations, 2.4 M pair entries), Venice-1778 3.65 ms (5.0 M, 25 M);
+    // round 1's constants (0.15 ns per pair entry + 1.9 ns per observation) were those kernels three rounds ago
+    const double per_iter = 0.03e-9 * pairs + 0.6e-9 * (double)opt.size();
     est_saved_s_ = per_iter * (1.0 - 1.0 / W);
     int rc = allreduce(b_pack_.p, packed_elems_);  // first call: connection set-up, not timed
     if (rc) return rc;
@@ -1384,10 +1387,14 @@ int BalSolver::setup() {
         const double E = ds.a > 0 ? (9.0 * (ds.b - ds.a + C_ - Cband) + 1.0 + 127.0) / 128.0 : 0.0;
         const int W = std::max(2, opt_.world);
         const double allreduce_us = 50.0 + 2.0 * (W - 1.0) / W * 0.5 * E * (E + 1.0) * 128.0 * 128.0 * 8.0 / 153e3;
+        // (the phases that shard with the points — two ranks take half of them each: choose_distribution's constants)
+        double pairs = 0.0;
+        { std::vector<int> k(P_total_, 0); for (int v : opt) k[v]++; for (int v : k) pairs += 0.5 * (double)v * (double)(v - 1); }
+        const double shard_us = 1e6 * (0.03e-9 * pairs + 0.6e-9 * (double)opt.size());
         model_us_[1] = one_us; model_us_[2] = ds.a > 0 ? ds.t_dissected + allreduce_us : 0.0;
         if (dev_knobs().debug_segments) std::fprintf(stderr, "[skeres_amd] two segments with %d border members in the separator: %.0f us + all-reduce %.0f us against %.0f us on one device\n",
                                                      border_members_, ds.t_dissected, allreduce_us, one_us);
-        if (ds.a > 0 && opt_.distribution_mode != SK_DISTRIBUTION_SEGMENTED && ds.t_dissected + allreduce_us >= 0.9 * one_us) ds.a = ds.b = 0;
+        if (ds.a > 0 && opt_.distribution_mode != SK_DISTRIBUTION_SEGMENTED && ds.t_dissected + allreduce_us + 0.5 * shard_us >= 0.9 * (one_us + shard_us)) ds.a = ds.b = 0;
       }
       if (lockstep_cut && ds.a > 0) {  // (two resident servers per factorisation: the fifth such solver alive on a device stays undissected)
         if (!pair_claimed_) pair_claimed_ = cholesky_claim_pair_servers(&chol_ctx_);
