@@ -385,8 +385,12 @@ int sk_options_set_cholesky_border(sk_options* o, int mode);
  * the widest tracks, as many as the model of the factorisation's serial chain says pay, when it predicts 10 % less than
  * eliminating everything; ON: the best count whatever the model says (tests, small problems); OFF: every point is eliminated.
  * max_points: at most this many — with ON: exactly this many, as far as there are tracks wider than a block — (a multiple of three is
- * used; 0: the library's limit, 1536).  Not with the SEGMENTED distribution
- * of several ranks.  sk_solver_stat: "retained_points", "retained_model_us", "retained_model_us_without". */
+ * used; 0: the library's limit, 1536).  Candidates: the widest tracks by span and by number of observations, and the tracks of
+ * loop closures (a jump in the point's camera list) at their exact number.  A point with two residual blocks on one camera is never
+ * retained.  Several ranks: with the SEGMENTED distribution only when the sequence is cut in TWO (sk_options_set_max_segments(o, 2);
+ * AUTO tries that plan by itself): the pseudo-cameras are members of the one separator, a retained point's observations are split
+ * over the ranks by camera.  sk_solver_stat: "retained_points", "retained_model_us", "retained_model_us_without",
+ * "model_us_two_segments_with_members". */
 enum { SK_RETAINED_AUTO = 0, SK_RETAINED_ON = 1, SK_RETAINED_OFF = 2 };
 int sk_options_set_retained_points(sk_options* o, int mode, int max_points);
 /* Multi-GPU: this process is rank `rank` of `world` ranks,
@@ -506,6 +510,10 @@ int sk_solver_distribution(const sk_solver* s, double* allreduce_seconds, double
  *   "dissected"             1 when the camera sequence is dissected (sk_options_set_cholesky_dissection), with
  *   "dissection_head_cameras" / "dissection_separator_cameras" / "dissection_tail_cameras" and the model's
  *   "dissection_model_us_plain" / "dissection_model_us" (microseconds of factorisation it predicted either way)
+ *   "chain_steps"           serial steps of the factorisation (block columns; two leaf fronts in lock-step count once)
+ * every solver:
+ *   "phase_seconds_<i>"     seconds accumulated so far in phase i (0 Jacobians, 1 Schur assembly, 2 Cholesky, 3 back-substitution,
+ *                           4 candidate cost, 5 all-reduce): sk_summary_phase_seconds, readable between steps
  * dense rows (DENSE_NORMAL_CHOLESKY over one parameter block):
  *   "jtj_flops_algorithmic" m n (n + 1): SURVEY.md section 8(d)'s figure for J^T J (sk_solver_syrk_flops_per_solve counts
  *                           the padded 128 x 128 tiles the launch computes) */
