@@ -1181,6 +1181,14 @@ __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) A21[(long)(ri * 32) * ld + q * 32 + crit_tile_off(ld, i)] = xacc[i];  // every tile has read S(j+1,j) by now
+      if (b == 1 && threadIdx.x == 0) {
+        // (tile (0, 1) has no update to do) X(j+1,j) to memory for the thin tiles of this launch, which may be anywhere on the chip: one
+        // write-back of this XCD's L2 covers all sixteen tiles' stores.  (Writing the tiles through beside the plain stores, so that every
+        // tile could count itself without a write-back, put the acknowledgement of those stores on the critical path: 8-9 us per tile step
+        // instead of 5 — measured, not kept.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(x_ready, 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       if (lower) {
 #pragma unroll
@@ -1200,12 +1208,6 @@ __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int
     __syncthreads();
     if (threadIdx.x == 0) store_l2(sync + kSyncDSlot + b, j + 1);
     if (stamp) SK_CHAIN_STAMP(j, 6)
-    // Off the critical path: X(j+1,j) to memory for the thin tiles of this launch, which may be anywhere on the chip — this tile's part
-    // written through (device-scope stores of the values it still holds), then counted.  (v2 had tile (0, 1) write the XCD's whole L2 back
-    // for all sixteen; v3 wrote through BEFORE the update and waited for the acknowledgement on the critical path.)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) store_through(Xj + (long)(ri * 32) * 128 + q * 32 + crit_tile_off(128, i), xacc[i]);
-    chain_publish_through(x_ready, 1);
     return;
   }
   // A wait that gave up (its own time-out, or the abort flag another wait raised): this column was NOT computed.  The
