@@ -2265,7 +2265,8 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   if (!sync) chain = false;  // (the same groups, launch by launch)
   auto is_resident = [&](int k) { return chain && k < nblk && plan.resident[k]; };
   // the XCD-local hand-over between the server and the tiles of block row j + 1 (above): every resident single column's launch
-  const int local = chain && g_chain_local ? 1 : 0;
+  // (SK_CHAIN_XCD_LOCAL=2: only for a factorisation of ONE front — it pays there and not where a partner front rides in the launches)
+  const int local = chain && (g_chain_local == 1 || (g_chain_local == 2 && !(partner && partner->ncols > 0))) ? 1 : 0;
   auto column_grid = [&](int ncrit, int T, int ncand) { return ncrit ? ncand + 4 * T - 4 : 4 * T; };
   const int maxblk = chain ? ctx->sync_blk : 0;
   const char* stamps_file = chain ? dev_knobs().chain_stamps : nullptr;
