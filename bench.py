@@ -717,11 +717,19 @@ def main():
                     two_us = 0.0
                 host_ms = line["ms_per_step"] - sum(ph.values())
                 if two_us > 0.0 and two_us < 0.9 * model_one:
-                    ms2 = ph["cholesky"] * two_us / model_one + shard / 2.0 + host_ms
-                    pred = {str(n): {"ms_per_step": ms2, "speed_up": line["ms_per_step"] / ms2, "plan": "two segments, retained points in the separator%s" % ("" if n == 2 else "; %d replicas" % (n - 2))}
-                            for n in (2, 4, 8)}
-                    note = ("chain model (two devices, a leaf front each: %.0f us against %.0f us for this run's lock-step plan), calibrated on this run's Cholesky phase; the phases that "
-                            "shard with the points halved; UNMEASURED on more than one device" % (two_us, model_one))
+                    pred = {}
+                    for n in (2, 4, 8):
+                        # (more than two segments — the retained points' pseudo-cameras a border of the root and of every segment's front —
+                        # where the model puts that 5 % under two: the solver's own rule)
+                        k, us = 2, two_us
+                        for kk in range(3, n + 1):
+                            if model_us.get(kk, 0.0) > 0.0 and model_us[kk] < 0.95 * us:
+                                k, us = kk, model_us[kk]
+                        ms = ph["cholesky"] * us / model_one + shard / k + host_ms
+                        pred[str(n)] = {"ms_per_step": ms, "speed_up": line["ms_per_step"] / ms, "segments": k,
+                                        "plan": "%d segments, retained points in the %s%s" % (k, "separator" if k == 2 else "root's border", "" if n == k else "; %d replicas" % (n - k))}
+                    note = ("chain model (a device per segment: %.0f us in two against %.0f us for this run's lock-step plan), calibrated on this run's Cholesky phase; the phases that "
+                            "shard with the points divided by the segments; UNMEASURED on more than one device" % (two_us, model_one))
                 else:
                     envelope_mb = plan["allreduce_bytes"] / 1e6
                     pred = {str(n): {"ms_per_step": line["ms_per_step"], "plan": "replicated"} for n in (2, 4, 8)}

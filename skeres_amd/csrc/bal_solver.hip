@@ -313,7 +313,7 @@ class BalSolver : public SolverBase {
   int cam_a_ = 0, cam_b_ = 0, border_blocks_ = 0;
   std::vector<int> seg_off_;   // dissected: first camera of every segment in the final numbering, then cam_b_
   std::vector<int> sep_first_; // ... and of every separator, then C_
-  std::vector<int> root_last_; // segmented: block envelope of the root (empty: dense — one separator)
+  std::vector<int> root_last_, root_tail_; // segmented: block envelope of the root (empty: dense — one separator); its tail profile (members of a border behind several separators)
   FrontView leaf_;             // segmented: this rank's leaf front
   DevBuf<int> b_border_row_[2], b_leaf_map_, b_leaf_gmap_;  // separator camera -> row of a leaf's border; border index -> root index (gmap: rhs row -> -1)
   double model_us_[9] = {0};   // the chain model's prediction per number of segments (index: segments; [1] = undissected)
@@ -516,9 +516,13 @@ static std::vector<int> front_envelope(const std::vector<int>& ocam, const std::
 // column's cost as choose_dissection; the number of segments (at most max_segments) is the one with the shortest
 // predicted critical path.  forced: cut wherever separators exist (tests, small problems), as evenly as the sequence allows.
 struct Segments { std::vector<int> a, b; double t_plain = 0.0, t_model = 0.0; double model_us[9] = {0}; };
+// member_cams: cameras that join the root whatever the cuts (the border's members: pseudo-cameras of retained points, loop-closure cameras) —
+// rows of EVERY segment's front, active in a block column as extra_fwd / extra_bwd_col have it (as in choose_dissection), and a border of the root.
 static Segments choose_segments(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
-                                const std::vector<int>& first_col, int max_segments, bool forced, int world = 0) {
+                                const std::vector<int>& first_col, int max_segments, bool forced, int world = 0, int member_cams = 0,
+                                const std::vector<int>* extra_fwd = nullptr, const std::vector<int>* extra_bwd_col = nullptr) {
   Segments out;
+  const int mb = member_cams > 0 ? (9 * member_cams + 127) / 128 : 0;
   if (world <= 0) world = max_segments;
   max_segments = std::min(max_segments, 8);
   if (max_segments < 2 || C < 6) return out;
@@ -532,13 +536,14 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
     std::vector<int> fc(first_col);
     for (int i = nblk - 2; i >= 0; --i) fc[i] = std::min(fc[i], fc[i + 1] < i + 1 ? fc[i + 1] : i);
     for (int c = 0; c < nblk; ++c) {
-      const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0);
+      const int hf = std::min(last[c], nblk - 1) - c + (last[c] < nblk - 1 ? 1 : 0) + (extra_fwd && c < (int)extra_fwd->size() ? (*extra_fwd)[c] : mb);
       fwd[c] = column_cost_us(hf, true);
-      bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1, true);
+      bwd[c] = column_cost_us(c - std::min(fc[c], c) + 1 + (extra_bwd_col && c < (int)extra_bwd_col->size() ? (*extra_bwd_col)[c] : mb), true);
       out.t_plain += fwd[c];
     }
+    for (int i = 0; i < mb; ++i) out.t_plain += column_cost_us(mb - 1 - i, true);
     for (int c = 0; c < nblk; ++c) { fwd_sum[c + 1] = fwd_sum[c] + fwd[c]; bwd_sum[c + 1] = bwd_sum[c] + bwd[c]; }
-    out.model_us[1] = out.t_plain + backsolve_us(nblk);
+    out.model_us[1] = out.t_plain + backsolve_us(nblk + mb);
     const double plain_with_solve = out.model_us[1];
     auto sep_blocks = [&](int a) { return (9 * (reach[a - 1] + 1 - a) + 1 + 127) / 128; };
     // room[k]: the last camera at which a segment may START so that k more cuts (each a candidate below, each followed by a
@@ -581,19 +586,21 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
       double root = 0.0;  // the separators' block-tridiagonal system, one resident column after the other, on every rank
       for (size_t k = 0; k < as.size(); ++k) {
         const int E = sep_blocks(as[k]), Enext = k + 1 < as.size() ? sep_blocks(as[k + 1]) : 0;
-        for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i + Enext, true);
+        for (int i = 0; i < E; ++i) root += column_cost_us(E - 1 - i + Enext + mb, true);
       }
+      for (int i = 0; i < mb; ++i) root += column_cost_us(mb - 1 - i, true);  // (the members: a dense border of the root)
       // + the all-reduce of the root over the world's ranks: its lower triangle inside the block-tridiagonal envelope, a ring over
       // one xGMI link per direction (153 GB/s: 2 (W - 1) / W x the bytes) — 39 MB and 0.4 ms for ONE 24-block separator, which is
       // what keeps a second wide separator from paying on the Ladybug-shaped problem
       double blocks = 0.0;
       for (size_t k = 0; k < as.size(); ++k) {
         const double E = sep_blocks(as[k]), Eprev = k > 0 ? sep_blocks(as[k - 1]) : 0.0;
-        blocks += 0.5 * E * (E + 1.0) + E * Eprev;
+        blocks += 0.5 * E * (E + 1.0) + E * Eprev + E * mb;
       }
+      blocks += 0.5 * mb * (mb + 1.0);
       const int W = std::max(2, world);
       const double allreduce_us = 50.0 + 2.0 * (W - 1.0) / W * blocks * 128.0 * 128.0 * 8.0 / 153e3;
-      int root_blocks = 0;
+      int root_blocks = mb;
       for (size_t k = 0; k < as.size(); ++k) root_blocks += sep_blocks(as[k]);
       const double t = hi + root + 170.0 + allreduce_us + backsolve_us(root_blocks) + backsolve_us((nblk + Rn - 1) / Rn);  // + fork, join, border add; the root's and a segment's back-substitution
       out.model_us[Rn] = t;
@@ -1185,11 +1192,12 @@ int BalSolver::setup() {
     // (the border of loop-closure cameras: not with an explicit dissection or segmentation — the fronts of those have borders of
     // their own kind — and only inside the envelope machinery)
     RetainedGraphs rgraphs;
-    // (an explicitly SEGMENTED world takes a border — its members join the one separator — when it is cut in TWO: sk_options_set_max_segments(o, 2))
+    // (an explicitly SEGMENTED world takes a border of loop-closure cameras — its members join the one separator — when it is cut in TWO:
+    // sk_options_set_max_segments(o, 2); retained points it takes with any number of segments: their pseudo-cameras are a border of the root)
     const bool many_segments = opt_.allreduce && opt_.world > 1 && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && opt_.max_segments != 2;
     const bool border_ok = opt_.envelope && opt_.border != SK_BORDER_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 && !many_segments;
-    // (retained points: not with an explicit dissection or segmentation either; a launch-bound problem under hipGraph replay has nothing to gain)
-    const bool retained_ok = opt_.retained != SK_RETAINED_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 && !graph_mode_ && !many_segments;
+    // (retained points: not with an explicit dissection; a launch-bound problem under hipGraph replay has nothing to gain)
+    const bool retained_ok = opt_.retained != SK_RETAINED_OFF && opt_.dissection != SK_DISSECTION_ON && dev_knobs().dissect_at < 0 && !graph_mode_;
     CameraOrderPlan plan;
     auto pick = [&](bool with_memory_order) {
       ReducedSystemPlan rp = plan_reduced_system(p, cam_block_, ocam, opt, Creal, P_total_, with_memory_order, border_ok, opt_.border,
@@ -1336,7 +1344,8 @@ int BalSolver::setup() {
       for (int k = 0; k < 9; ++k) model_us_[k] = sg.model_us[k];
     } else if (may_dissect) {
       Dissection ds;
-      std::vector<int> first_col;
+      std::vector<int> first_col, many_cut_a, many_cut_b;
+      double dissect_t_model_many = 0.0;
       // what is cut: the cameras' band — with a border, the band cameras under the points that are eliminated (the border's cameras
       // and what they see belong to the separator whatever the cut)
       std::vector<int> cut_ocam, cut_opt;
@@ -1395,6 +1404,23 @@ int BalSolver::setup() {
         if (dev_knobs().debug_segments) std::fprintf(stderr, "[skeres_amd] two segments with %d border members in the separator: %.0f us + all-reduce %.0f us against %.0f us on one device\n",
                                                      border_members_, ds.t_dissected, allreduce_us, one_us);
         if (ds.a > 0 && opt_.distribution_mode != SK_DISTRIBUTION_SEGMENTED && ds.t_dissected + allreduce_us + 0.5 * shard_us >= 0.9 * (one_us + shard_us)) ds.a = ds.b = 0;
+        // ... and MORE than two segments, a device each: every segment's front has the members' rows in its border, the root is the
+        // separators' block-tridiagonal system bordered by the members (choose_segments; every rank factors it)
+        int max_seg = opt_.world;
+        if (opt_.max_segments >= 2) max_seg = std::min(max_seg, opt_.max_segments);
+        if (max_seg > 2) {
+          const bool forced = opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED;
+          const Segments sg = choose_segments(docam, dopt, Cband, P_total_, dnblk, denv, first_col, max_seg, forced, opt_.world, C_ - Cband,
+                                              pseudo_border ? &extra_fwd : nullptr, pseudo_border ? &extra_bwd_col : nullptr);
+          for (int k = 3; k < 9; ++k) model_us_[k] = sg.model_us[k];
+          const int Rn = (int)sg.a.size() + 1;
+          const double two_us = ds.a > 0 ? ds.t_dissected + allreduce_us + 0.5 * shard_us : 1e300;
+          if (Rn > 2 && (forced || (sg.t_model + shard_us / Rn < 0.95 * two_us && sg.t_model + shard_us / Rn < 0.9 * (one_us + shard_us)))) {
+            if (dev_knobs().debug_segments) std::fprintf(stderr, "[skeres_amd] %d segments with %d border members in the root: %.0f us against %.0f us in two\n", Rn, border_members_, sg.t_model, two_us);
+            many_cut_a = sg.a; many_cut_b = sg.b;
+            dissect_t_model_many = sg.t_model;
+          }
+        }
       }
       if (lockstep_cut && ds.a > 0) {  // (two resident servers per factorisation: the fifth such solver alive on a device stays undissected)
         if (!pair_claimed_) pair_claimed_ = cholesky_claim_pair_servers(&chol_ctx_);
@@ -1404,7 +1430,7 @@ int BalSolver::setup() {
       // on one chip take longer than one after the other — each alone 5.0 and 3.0 ms, together 10-13 ms; 6.6 ms only under
       // rocprofv3's kernel tracing — so the model's prediction (kept in sk_solver_stat) is not acted upon there.
       if (opt_.dissection == SK_DISSECTION_AUTO && dev_knobs().dissect_at < 0 && !lockstep_cut && !two_seg_try) { ds.a = ds.b = 0; }
-      if (two_seg_try && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && ds.a == 0 && Cband >= 6) {
+      if (two_seg_try && opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED && ds.a == 0 && many_cut_a.empty() && Cband >= 6) {
         // forced (tests, small problems): cut the band at its middle camera wherever that leaves a tail
         std::vector<int> cmin(P_total_, Cband), cmax(P_total_, -1);
         for (size_t b = 0; b < docam.size(); ++b) { cmin[dopt[b]] = std::min(cmin[dopt[b]], docam[b]); cmax[dopt[b]] = std::max(cmax[dopt[b]], docam[b]); }
@@ -1436,7 +1462,8 @@ int BalSolver::setup() {
       }
       dissect_t_plain_ = ds.t_plain; dissect_t_model_ = ds.t_dissected;
       if (!two_seg_try) {  // what the chain model predicts for 2 .. 8 devices (sk_solver_stat "model_us_segments_<n>": bench.py prints it beside what it measures)
-        const Segments sg = choose_segments(docam, dopt, Cband, P_total_, dnblk, denv, first_col, 8, false);
+        const Segments sg = choose_segments(docam, dopt, Cband, P_total_, dnblk, denv, first_col, 8, false, 0, C_ - Cband, pseudo_border ? &extra_fwd : nullptr,
+                                            pseudo_border ? &extra_bwd_col : nullptr);
         for (int k = 0; k < 9; ++k) model_us_[k] = sg.model_us[k];
         if (pseudo_border) {
           // ... and with the border's members (retained points) in the one separator of TWO segments, a device each — what a world of ranks
@@ -1448,7 +1475,8 @@ int BalSolver::setup() {
           }
         }
       }
-      if (ds.a > 0 && ds.b < Cband) { cut_a.push_back(ds.a); cut_b.push_back(ds.b); }
+      if (!many_cut_a.empty()) { cut_a = many_cut_a; cut_b = many_cut_b; dissect_t_model_ = dissect_t_model_many; }
+      else if (ds.a > 0 && ds.b < Cband) { cut_a.push_back(ds.a); cut_b.push_back(ds.b); }
     }
     if (two_seg_try && cut_a.empty() && opt_.distribution_mode != SK_DISTRIBUTION_SEGMENTED) {
       // no cut that pays: shard the points or replicate (a replicating rank is a single device from here on), then once more
@@ -1502,16 +1530,15 @@ int BalSolver::setup() {
     replica_ = opt_.rank >= segments_;
     fold_world_ = segments_;
     my_lo_ = seg_off_[role_]; my_hi_ = seg_off_[role_ + 1];
+    // (the border's members — behind the last separator — are a border of the root too: active from its first block column)
     std::vector<int> sep_off;  // scalar offsets of the separators in the root, then their total
-    for (int f : sep_first_) sep_off.push_back(9 * (f - cam_b_));
-    root_last_ = root_envelope(sep_off);
+    for (int f : sep_first_) sep_off.push_back(9 * (std::min(f, C_ - border_members_) - cam_b_));
+    root_tail_.clear();
+    root_last_ = root_envelope(sep_off, 9 * border_members_, &root_tail_);
     const int E = (9 * (C_ - cam_b_) + 1 + 127) / 128;
     pack_col0_h_.assign(E, 0);
     pack_off_h_.assign(E + 1, 0);
-    if (!root_last_.empty()) {
-      int c = 0;
-      for (int i = 0; i + 1 < E; ++i) { while (c < i && root_last_[c] < i) ++c; pack_col0_h_[i] = c; }
-    }
+    if (!root_last_.empty()) pack_col0_h_ = cholesky_row_first_cols(E, root_last_.data(), root_tail_.empty() ? nullptr : root_tail_.data());
     for (int kb = 0; kb < E; ++kb) pack_off_h_[kb + 1] = pack_off_h_[kb] + (long long)128 * 128 * (kb + 1 - pack_col0_h_[kb]);
     packed_elems_ = (size_t)pack_off_h_[E];
   }
@@ -1760,9 +1787,15 @@ int BalSolver::setup() {
       const int seg = segmented_ ? role_ : f;
       const int lo = seg_off_[seg], hi = seg_off_[seg + 1];
       // the separators next to the segment (cameras of the final numbering): left [ll, lh), right [rl, rh)
-      const int ll = seg > 0 ? sep_first_[seg - 1] : 0, lh = seg > 0 ? sep_first_[seg] : 0;
-      const int rl = seg + 1 < segments_ ? sep_first_[seg] : 0, rh = seg + 1 < segments_ ? sep_first_[seg + 1] : 0;
-      const SegmentLayout lay = segment_layout(9 * (hi - lo), 9 * (lh - ll), 9 * (rh - rl));
+      // (the members of a border — pseudo-cameras of retained points, loop-closure cameras — come behind the last separator and are
+      // rows of EVERY leaf front: the end of its border, before the right-hand side)
+      const int nbm = border_members_, mf = C_ - nbm;
+      const int ll = seg > 0 ? sep_first_[seg - 1] : 0, lh = seg > 0 ? std::min(sep_first_[seg], mf) : 0;
+      const int rl = seg + 1 < segments_ ? sep_first_[seg] : 0, rh = seg + 1 < segments_ ? std::min(sep_first_[seg + 1], mf) : 0;
+      const bool last_seg = seg > 0 && seg + 1 == segments_;
+      // first segment: [right | members | rhs]; last: [left reversed | members | rhs]; between two: [right, padded | left | members | rhs] —
+      // there the members are tail rows like the left separator's (active in every column)
+      const SegmentLayout lay = seg == 0 ? segment_layout(9 * (hi - lo), 0, 9 * (rh - rl + nbm)) : segment_layout(9 * (hi - lo), 9 * (lh - ll + nbm), 9 * (rh - rl));
       FrontHost& L = fr_[f];
       L.cams = hi - lo; L.ncols = lay.ncols; L.nblk = lay.nblk; L.dim = (size_t)L.nblk * 128; L.rhs_row = lay.rhs_row; L.tail_rows = lay.tail_rows;
       // rows of every camera in this front: its own interior, or (a separator next to it) the border
@@ -1773,13 +1806,13 @@ int BalSolver::setup() {
       for (int c = rl; c < rh; ++c) pos[c] = bo + lay.right_off + 9 * (c - rl);
       // (the members of a border — one device: the end of the one separator — stay at the END of a reversed border too: their rows are
       // tail rows of the front's envelope, a suffix of the matrix)
-      const int nbm = border_members_;  // (a segmented world has members only when it is cut in two: the one separator's end, as on one device)
-      const int lreal = lh - nbm;
-      for (int c = ll; c < lh; ++c) pos[c] = bo + lay.left_off + (lay.reversed && c < lreal ? 9 * (lreal - 1 - c) : 9 * (c - ll));
+      for (int c = ll; c < lh; ++c) pos[c] = bo + lay.left_off + (lay.reversed ? 9 * (lh - 1 - c) : 9 * (c - ll));
+      for (int c = mf; c < C_; ++c) pos[c] = (seg == 0 ? bo + lay.right_off + 9 * (rh - rl) : bo + lay.left_off + 9 * (lh - ll)) + 9 * (c - mf);
+      (void)last_seg;
       const std::vector<int>& fo = struct_ocam_.empty() ? ocam : struct_ocam_;
       const std::vector<int>& fp = struct_ocam_.empty() ? opt : struct_opt_;
       const int fP = struct_ocam_.empty() ? P_total_ : struct_P_;
-      if (nbm > 0) L.last = front_envelope(fo, fp, pos, interior, fP, L.nblk, L.tail_rows, pos[C_ - nbm], &L.tail);
+      if (nbm > 0 && !lay.spike) L.last = front_envelope(fo, fp, pos, interior, fP, L.nblk, L.tail_rows, pos[mf], &L.tail);
       else L.last = front_envelope(fo, fp, pos, interior, fP, L.nblk, L.tail_rows);
       border_row_h[f].assign(std::max(1, nsep), 0);
       for (int c = cam_b_; c < C_; ++c) border_row_h[f][c - cam_b_] = pos[c] >= 0 ? pos[c] : 0;  // (a separator that is not next to the segment: no block of it here)
@@ -1795,6 +1828,7 @@ int BalSolver::setup() {
     FrontHost& r = fr_[2];
     r.nblk = r.ncols = (9 * nsep + 1 + 127) / 128; r.cams = nsep; r.dim = (size_t)r.nblk * 128; r.rhs_row = 9 * nsep;
     r.last = root_last_;  // (one separator: dense)
+    r.tail = root_tail_;
   }
   {
     size_t s_off = 0, linv_off = 0, y_off = 0;
@@ -2180,8 +2214,8 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     if (rc) return rc;
     launch_tri_pack(Rs, (int)R.dim, b_pack_.p, R.nblk, b_pack_col0_.p, b_pack_off_.p, false, s);
     finish_root();
-    cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok());
-    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info, nullptr, zero_after, bs_resident);
+    cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok(), -1, 1, nullptr, R.tl());
+    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl(), zero_after, bs_resident);
     if (L.ncols > 0) {
       cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
       cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info, zero_after, L.tail, nullptr, bs_resident);

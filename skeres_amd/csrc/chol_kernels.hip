@@ -2870,15 +2870,22 @@ double cholesky_plan_flops(int nblk, const int* last, int ncols, int tail_rows, 
   return f;
 }
 
-std::vector<int> root_envelope(const std::vector<int>& sep_off) {
+std::vector<int> root_envelope(const std::vector<int>& sep_off, int members_n, std::vector<int>* tail_out) {
   const int nsep = (int)sep_off.size() - 1;
   if (nsep <= 1) return {};
-  const int total = sep_off[nsep], nblk = (total + 1 + 127) / 128;
+  const int total = sep_off[nsep] + (members_n > 0 ? members_n : 0), nblk = (total + 1 + 127) / 128;
   std::vector<int> first_col(nblk);
   for (int i = 0; i < nblk; ++i) first_col[i] = i;
   for (int k = 0; k < nsep; ++k) {
     const int col = sep_off[k > 0 ? k - 1 : 0] / 128;
     for (int r = sep_off[k] / 128; r <= (sep_off[k + 1] - 1) / 128 && r < nblk; ++r) first_col[r] = std::min(first_col[r], col);
+  }
+  if (members_n > 0 && tail_out) {
+    const int border_begin = sep_off[nsep] / 128;
+    for (int r = border_begin; r < nblk; ++r) first_col[r] = 0;
+    std::vector<int> last;
+    cholesky_envelope_bordered(first_col, border_begin, &last, tail_out);
+    return last;
   }
   return cholesky_envelope_last(first_col);
 }

@@ -288,7 +288,9 @@ inline SegmentLayout segment_layout(int interior_n, int left_n, int right_n) {
 // Block envelope of the root (every separator in sequence order, then the right-hand side): separator k couples with
 // separator k - 1 through the Schur complement of the segment between them.  sep_off: R entries, scalar offset of each
 // separator in the root and, last, their total.  Empty result: dense (one separator).
-std::vector<int> root_envelope(const std::vector<int>& sep_off);
+// members_n > 0: that many scalar rows behind the last separator couple with EVERY separator (the members of a border: pseudo-cameras of
+// retained points) — a border of the root in the sense of cholesky_envelope_bordered, its profile in *tail_out.
+std::vector<int> root_envelope(const std::vector<int>& sep_off, int members_n = 0, std::vector<int>* tail_out = nullptr);
 
 double cholesky_syrk_flops(int npad, int group, const int* last = nullptr, bool chain = false, double* c_tiles = nullptr, int ncols = -1, int tail_rows = 1,
                            const int* tail = nullptr);

@@ -46,8 +46,9 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "auto"
     fields = sys.argv[2].split(",") if len(sys.argv) > 2 else ["16", "600", "2600", "11"]
     revisits = len(fields) > 4 and fields[4] == "rev"  # loop closures: the revisiting cameras go to a border of the reduced system (round 4)
-    kept = len(fields) > 4 and fields[4] in ("kept", "kept2")  # retained points: the widest tracks stay in the reduced system (round 4)
+    kept = len(fields) > 4 and fields[4] in ("kept", "kept2", "keptN")  # retained points: the widest tracks stay in the reduced system (round 4)
     kept2 = len(fields) > 4 and fields[4] == "kept2"  # ... in a SEGMENTED world cut in two: their pseudo-cameras are members of the one separator (round 5)
+    keptN = len(fields) > 4 and fields[4] == "keptN"  # ... cut into a segment per rank: the pseudo-cameras are a border of the root and of every segment's front
     shape = [int(v) for v in fields[:4]]
     prob = bal.generate(shape[0], shape[1], shape[2], seed=shape[3], revisits=[(60, 350, 12, 40), (200, 520, 12, 40)] if revisits else ())
     x_plain, s_plain = solve_bal_gpu(prob, **({"setCholeskyBorder": "off"} if revisits else ({"setRetainedPoints": "off"} if kept else {})))
@@ -73,7 +74,7 @@ def main():
         assert solver.stat("allreduce_bytes") < solver.stat("allreduce_bytes_full_triangle")
     if kept:
         # every rank retains the same twelve points (the hash the ranks compare covers them); whichever rank owns one writes its rows
-        assert solver.stat("retained_points") == 12 and solver.stat("dissected") == (1 if kept2 else 0)
+        assert solver.stat("retained_points") == 12 and solver.stat("dissected") == (1 if kept2 or keptN else 0)
     if shape[0] >= 200 and mode == "sharded":
         # a camera sequence long enough for a band: only the blocks inside the envelope travel
         assert solver.stat("allreduce_bytes") < 0.9 * solver.stat("allreduce_bytes_full_triangle"), (solver.stat("allreduce_bytes"), solver.stat("allreduce_bytes_full_triangle"))

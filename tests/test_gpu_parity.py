@@ -1538,6 +1538,15 @@ def test_segmented_world_cut_in_two_with_retained_points_in_the_separator(world)
     test_sharded_solve_on_one_gpu_with_a_real_exchange(world, "segmented", shape="600,6000,26000,9,kept2", segments=2)
 
 
+@pytest.mark.parametrize("world", [3, 4])
+def test_segmented_world_of_a_segment_per_rank_with_retained_points_in_the_root(world):
+    """... and with MORE than two segments: every rank's device eliminates one segment, whose front has the retained points'
+    pseudo-cameras at the end of its border (tail rows of a segment between two separators, a tail profile of the first and the
+    last one); the root — every rank factors it — is the separators' block-tridiagonal system bordered by the pseudo-cameras.
+    Worlds of 3 and 4 sharing GPU 0 over gloo against the single-GPU trajectory with every point eliminated: 1e-10."""
+    test_sharded_solve_on_one_gpu_with_a_real_exchange(world, "segmented", shape="900,9000,40000,9,keptN", segments=world)
+
+
 @pytest.mark.parametrize("mode", ["sharded", "auto"])
 def test_venice_1778_at_full_size_sharded_over_two_ranks(mode):
     """BASELINE.json configs[3] as it is DEFINED — Venice-1778 with the residual blocks sharded over ranks and the reduced system
