@@ -2124,7 +2124,7 @@ int BalSolver::try_step(double radius, bool* valid, double* mcc, double* new_cos
 int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* new_cost, double* step_norm, bool* chain_lost) {
   hipStream_t s = stream_;
   *chain_lost = false;
-  const size_t nc = 9 * (size_t)C_, np = 3 * (size_t)P_;
+  const size_t nc = 9 * (size_t)C_;
   *valid = false;
   SK_HIP_TRY(hipEventRecord(ev_[kEvBegin], s));
   const bool graph = graph_ok();

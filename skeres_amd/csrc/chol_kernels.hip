@@ -843,7 +843,8 @@ constexpr long long kChainTimeoutTicks = 100000000;  // 1 s of the 100 MHz wall 
 // developer timeline (SK_CHAIN_STAMPS=<file>): wall-clock stamps of the server and of tile 0 of every column launch
 __device__ long long g_chain_stamps[1024][8];
 __device__ int g_chain_stamps_on;
-#define SK_CHAIN_STAMP(col, i) if (g_chain_stamps_on && threadIdx.x == 0 && (col) < 1024) g_chain_stamps[col][i] = wall_clock64();
+// (two fronts in lock-step: the partner front's columns at 512 + j; stamp_front is a local of the two bodies)
+#define SK_CHAIN_STAMP(col, i) if (g_chain_stamps_on && threadIdx.x == 0 && (col) < 512) g_chain_stamps[(col) + 512 * stamp_front][i] = wall_clock64();
 __device__ __forceinline__ int sync_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // one lane: wait until *p >= target; false = aborted / timed out
 __device__ __forceinline__ bool chain_wait(const int* p, int target, int* abort_flag) {
@@ -983,6 +984,7 @@ struct ChainRanges { int n; int begin[8], end[8]; };  // the resident runs of bl
 
 __device__ __forceinline__ void potrf_server_body(double* lds, double* S, long ld, const ChainRanges& ranges, double* Linv, int* info, int* sync, int maxblk, int local) {
   __shared__ int ok_s;
+  const int stamp_front = gridDim.x == 2 ? (int)blockIdx.x : 0;
   int done = 0;  // value of the potrf counter
   if (local && threadIdx.x == 0) __hip_atomic_store(sync + kSyncServerXcc, 1 + xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // which XCD the tiles of block row j + 1 have to be on
   for (int r = 0; r < ranges.n; ++r)
@@ -1079,6 +1081,7 @@ __device__ __forceinline__ void chain_column_body(int b, double* S, long ld, int
   __shared__ __attribute__((aligned(16))) double sh[2 * 32 * kCritLd];
   static_assert(2 * 32 * kCritLd >= gemm_lds_doubles(16, 32, 128), "LDS of the thin tiles");
   __shared__ int ok_s;
+  const int stamp_front = gridDim.y == 2 ? (int)blockIdx.y : 0;
   __builtin_amdgcn_s_setprio(2);
   double* A21 = S + (long)(j + 1) * 128 * ld + (long)j * 128;
   int* x_ready = sync + kSyncHeader + maxblk + j;
@@ -2550,13 +2553,21 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     (void)hipStreamSynchronize(s);
     std::vector<long long> st((size_t)1024 * 8);
     (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_chain_stamps), st.size() * sizeof(long long));
-    if (FILE* f = fopen(stamps_file, "w")) {
-      for (int j = 0; j < nblk && j < 1024; ++j) {
+    // (two fronts in lock-step: <file>.pair — the root's factorisation, which follows, writes <file>)
+    const std::string stamps_name = std::string(stamps_file) + (partner && partner->ncols > 0 ? ".pair" : "");
+    if (FILE* f = fopen(stamps_name.c_str(), "w")) {
+      for (int j = 0; j < nblk && j < 512; ++j) {
         if (!plan.resident[j]) continue;
         fprintf(f, "%d ", j);
         for (int i = 0; i < 7; ++i) fprintf(f, "%lld ", st[(size_t)j * 8 + i]);
         const Rows rs = rows_from(j + 2, j);
         fprintf(f, "%d\n", rs.main + rs.extra);
+      }
+      // (the partner front's block columns, two fronts in lock-step: 512 + j)
+      for (int j = 0; partner && j < partner->ncols && j < 512; ++j) {
+        fprintf(f, "%d ", 512 + j);
+        for (int i = 0; i < 7; ++i) fprintf(f, "%lld ", st[(size_t)(512 + j) * 8 + i]);
+        fprintf(f, "0\n");
       }
       fclose(f);
     }

@@ -1570,7 +1570,8 @@ def test_venice_1778_at_full_size_sharded_over_two_ranks(mode):
 @pytest.mark.parametrize("world,mode,shape,segments", [(8, "segmented", "900,30000,70000,8", 8), (8, "segmented", "400,12000,60000,3", None),
                                                        (8, "sharded", "400,12000,60000,3", None), (8, "rows", "5000,300", None),
                                                        (16, "segmented", "900,30000,70000,8", None), (3, "sharded", "400,12000,60000,3", "0 scrambled"),
-                                                       (3, "segmented", "400,12000,27000,3", "0 scrambled")])
+                                                       (3, "segmented", "400,12000,27000,3", "0 scrambled"),
+                                                       (8, "segmented", "900,30000,70000,8", "8 kept"), (6, "segmented", "400,12000,27000,3", "0 kept")])
 def test_world_of_eight_ranks_as_threads_of_one_process(world, mode, shape, segments):
     """VERDICT r02 item 1 asks for worlds of 4 and 8 sharing one GPU; a GPU box allows six processes on its card, so a world
     of eight runs as eight THREADS of one process (tests/threads_world_worker.py): a rank per thread — its own problem, solver and
@@ -1582,7 +1583,8 @@ def test_world_of_eight_ranks_as_threads_of_one_process(world, mode, shape, segm
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # ("0 scrambled": one rank keeps its cameras in another order in memory — the ranks' memory-order candidates for the camera
-    # sequence disagree, they notice and fall back to the rank-invariant ones)
+    # sequence disagree, they notice and fall back to the rank-invariant ones; "8 kept": twelve retained points in a world cut into eight
+    # segments — six of them between two separators, the points' pseudo-cameras tail rows of their fronts beside the left separator's spike)
     cmd = [sys.executable, os.path.join(root, "tests", "threads_world_worker.py"), str(world), mode, shape] + (str(segments).split() if segments else [])
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]

@@ -4,7 +4,7 @@ copies the rank's buffer to the host, meets the other ranks at a barrier, sums t
 same sum: the ranks stay bitwise equal) and copies the sum back.  The solvers factor CONCURRENTLY on the device's shared
 look-ahead streams (enqueued as one unit per factorisation: chol_kernels.hip, DeviceQueues::enqueue_mutex).
 
-  python tests/threads_world_worker.py <world> <mode: segmented | sharded | rows> <shape> [segments | 0] [scrambled]
+  python tests/threads_world_worker.py <world> <mode: segmented | sharded | rows> <shape> [segments | 0] [scrambled | kept]
 
 Used by tests/test_gpu_parity.py::test_world_of_eight_ranks_as_threads_*."""
 import ctypes
@@ -96,6 +96,7 @@ def main():
     x_plain, s_plain = solve_bal_gpu(prob)
 
     scrambled = len(sys.argv) > 5 and sys.argv[5] == "scrambled"
+    kept = len(sys.argv) > 5 and sys.argv[5] == "kept"  # twelve retained points: their pseudo-cameras border the root and every segment's front
 
     def body(rank, hook):
         if scrambled and rank == 1:
@@ -115,7 +116,11 @@ def main():
         options.setLinearSolverType(sk.LinearSolverType.DENSE_SCHUR)
         options.setDistributed(rank, world, hook)
         options.setDistributionMode({"sharded": 1, "segmented": 3}[mode])
+        if kept:
+            options.setRetainedPoints("on", 12)
         solver = sk.StepSolver(options, problem)
+        if kept:
+            assert 3 <= solver.stat("retained_points") <= 12, solver.stat("retained_points")
         used = solver.distribution()[0]
         segments = int(solver.stat("segments"))
         while not solver.step():

@@ -15,6 +15,9 @@ from skeres_amd import bal  # noqa: E402
 
 def main():
     path = os.path.join(tempfile.gettempdir(), "sk_chain_stamps.txt")
+    for f in (path, path + ".pair"):
+        if os.path.exists(f):
+            os.remove(f)
     os.environ["SK_CHAIN_STAMPS"] = path
     which = sys.argv[1] if len(sys.argv) > 1 else "ladybug-1723-156502"
     if which.startswith("band:"):  # a synthetic camera band of another size: band:C,P,N,seed
@@ -36,16 +39,30 @@ def main():
     s = sk.StepSolver(o, problem)
     for _ in range(4):
         s.step()
-    raw = np.loadtxt(path)
-    cols, st = raw[:, 0].astype(int), raw[:, 1:]
-    t0 = st[0, 0]
-    us = (st - t0) * 0.01
+    for f in (path + ".pair", path):  # (a lock-step dissection: the two leaf fronts, then the root)
+        if os.path.exists(f):
+            report(np.loadtxt(f))
+            os.remove(f)
+
+
+def report(raw):
+    t0 = raw[:, 1].min()
     names = ["potrf start", "potrf done", "col start", "saw potrf", "trsm done", "saw X+syrk", "next done"]
-    print("col  " + "  ".join("%11s" % n for n in names) + "   cycle  trailing rows")
-    for j in range(len(us)):
-        cyc = us[j, 0] - us[j - 1, 0] if j else 0.0
-        print("%3d  " % cols[j] + "  ".join("%11.1f" % us[j, i] for i in range(7)) + "   %6.1f  %4d" % (cyc, int(st[j, 7])))
-    print("total %.1f us, mean cycle %.1f us" % (us[-1, 1], (us[-1, 0] - us[0, 0]) / (len(us) - 1)))
+    # (two fronts in lock-step: the partner front's block columns are numbered from 512)
+    for front, rows in (("head / only front", raw[raw[:, 0] < 512]), ("partner front (lock-step)", raw[raw[:, 0] >= 512])):
+        if not len(rows):
+            continue
+        cols, st = rows[:, 0].astype(int), rows[:, 1:]
+        us = (st - t0) * 0.01
+        print("%s\ncol  " % front + "  ".join("%11s" % n for n in names) + "   cycle  trailing rows")
+        for j in range(len(us)):
+            cyc = us[j, 0] - us[j - 1, 0] if j else 0.0
+            print("%3d  " % (cols[j] % 512) + "  ".join("%11.1f" % us[j, i] for i in range(7)) + "   %6.1f  %4d" % (cyc, int(st[j, 7])))
+        d = np.diff(us[:, 0])
+        seg = np.stack([us[:, 1] - us[:, 0], us[:, 3] - us[:, 1], us[:, 4] - us[:, 3], us[:, 5] - us[:, 4], us[:, 6] - us[:, 5]], axis=1)
+        nxt = us[1:, 0] - us[:-1, 6]
+        print("total %.1f us, mean cycle %.1f us (median %.1f); medians: potrf %.1f, done->seen %.1f, trsm tile %.1f, X seen %.1f, next tile %.1f, next potrf start %.1f"
+              % (us[-1, 1] - us[0, 0], d.mean(), np.median(d), *np.median(seg, axis=0), np.median(nxt)))
 
 
 if __name__ == "__main__":
