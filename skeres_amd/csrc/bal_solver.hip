@@ -1395,7 +1395,9 @@ int BalSolver::setup() {
         const double one_us = one.a > 0 ? one.t_dissected : one.t_plain;
         const double E = ds.a > 0 ? (9.0 * (ds.b - ds.a + C_ - Cband) + 1.0 + 127.0) / 128.0 : 0.0;
         const int W = std::max(2, opt_.world);
-        const double allreduce_us = 50.0 + 2.0 * (W - 1.0) / W * 0.5 * E * (E + 1.0) * 128.0 * 128.0 * 8.0 / 153e3;
+        // (+ the three small collectives of a segmented iteration — column norms and gradient, two tables of scalars — at the ~40 us of a
+        // latency-bound all-reduce each)
+        const double allreduce_us = 50.0 + 3.0 * 40.0 + 2.0 * (W - 1.0) / W * 0.5 * E * (E + 1.0) * 128.0 * 128.0 * 8.0 / 153e3;
         // (the phases that shard with the points — two ranks take half of them each: choose_distribution's constants)
         double pairs = 0.0;
         { std::vector<int> k(P_total_, 0); for (int v : opt) k[v]++; for (int v : k) pairs += 0.5 * (double)v * (double)(v - 1); }
