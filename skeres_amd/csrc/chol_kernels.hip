@@ -1379,9 +1379,17 @@ __device__ int g_bs_stamps_on;              // the block row next to the diagona
 constexpr int kBsMaxBlocks = 960;  // (two tables of that many entries + the other arguments: inside the 4 KB kernel-argument segment)
 struct BsTop { unsigned short top[kBsMaxBlocks]; unsigned short tail[kBsMaxBlocks]; };  // per block column: the last block row of its contiguous run (<= nblk - 1), and the first of its tail rows
 constexpr unsigned long long kBsSentinel = ~0ull;
-__global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __restrict__ Linv, double* S, long ld, const double* rhs,
-                                                               int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb, int zero_after /* number of janitor workgroups */,
-                                                               const int* __restrict__ yb_map /* border index -> index into yb (< 0: zero); nullptr: the border's own order */) {
+// (the arguments of one front's back-substitution; the kernels below hand them to the body with the block's index in that front's launch)
+struct BsArgs {
+  const double* Linv; double* S; long ld; const double* rhs; int n; double* y; int nblk; int* info; int nown; const double* yb;
+  int janitors;       // number of janitor workgroups behind the owners
+  const int* yb_map;  // border index -> index into yb (< 0: zero); nullptr: the border's own order
+};
+template <typename Env>
+__device__ __forceinline__ void bs_resident_body(const BsArgs& a, const Env& env, const int block) {
+  const double* __restrict__ Linv = a.Linv; double* S = a.S; const long ld = a.ld; const double* rhs = a.rhs; const int n = a.n; double* y = a.y;
+  const int nblk = a.nblk; int* info = a.info; const int nown = a.nown; const double* __restrict__ yb = a.yb; const int zero_after = a.janitors;
+  const int* __restrict__ yb_map = a.yb_map;
   // nown < nblk: the interior of a LEAF FRONT (cholesky_backsolve_front): block columns [0, nown) have owners, the unknowns of
   // the block rows below them — the front's border — are known (yb, in the border's order: the separators' solution); the block
   // rows from env.tail[kb] on are active in block column kb whatever its run (the right-hand-side row; a spike: SegmentLayout; the
@@ -1398,8 +1406,8 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
   // block it reads no longer keeps up with the chain's 3.3 us per hop.)  The launch has idle CUs to spare (an owner per block
   // column on 256 CUs); a janitor waits for an owner, which was dispatched before it.  What the owners do not visit — the diagonal
   // blocks, a leaf front's border x border square — stays with zero_envelope_kernel (BalSolver: b_zero_min_f_).
-  if ((int)blockIdx.x >= nown) {
-    const int jn = (int)blockIdx.x - nown, t = threadIdx.x, c = t & 127, rg = t >> 7;
+  if (block >= nown) {
+    const int jn = block - nown, t = threadIdx.x, c = t & 127, rg = t >> 7;
     __shared__ int ok_s;
     for (int kb = nown - 1 - jn; kb >= 0; kb -= zero_after) {
       if (t == 0) {
@@ -1436,7 +1444,7 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
   }
   __shared__ double ysh[128], wsh[128], part[16][128];
   __shared__ int abort_s;
-  const int kb = nown - 1 - (int)blockIdx.x;
+  const int kb = nown - 1 - block;
   const int t = threadIdx.x, c = t & 127, rg = t >> 7;
   if (t == 0) abort_s = 0;
   if (t < 128) { const int j = kb * 128 + t; wsh[t] = j < n ? rhs[j] : 0.0; }
@@ -1520,6 +1528,31 @@ __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __re
     if (g_bs_stamps_on && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_bs_stamps[kb][2] = wall_clock64(); }
   }
   if (t == 0 && abort_s && info) info_raise(info, 2);
+}
+
+__global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __restrict__ Linv, double* S, long ld, const double* rhs,
+                                                               int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb, int zero_after /* number of janitor workgroups */,
+                                                               const int* __restrict__ yb_map) {
+  const BsArgs a{Linv, S, ld, rhs, n, y, nblk, info, nown, yb, zero_after, yb_map};
+  bs_resident_body(a, env, (int)blockIdx.x);
+}
+// Two leaf fronts' back-substitutions in ONE launch (round 5): side by side on two streams they cost a fork in front (~20 us) and, behind,
+// a join that the main stream reaches first and sits in blocked (~65 us until the queue wakes up: profiles/r05_iteration_trace.txt).
+// Owners of the two fronts alternate in dispatch order (each front's chain of hops starts at once), the janitors come behind all owners.
+constexpr int kBsPairMaxBlocks = 448;  // (two pairs of tables of that many entries: inside the 4 KB kernel-argument segment)
+struct BsTopHalf { unsigned short top[kBsPairMaxBlocks]; unsigned short tail[kBsPairMaxBlocks]; };
+struct BsPair { BsArgs f[2]; BsTopHalf env[2]; };
+__global__ __launch_bounds__(1024, 1) void bs_resident_pair_kernel(BsPair p) {
+  const int b = (int)blockIdx.x, nA = p.f[0].nown, nB = p.f[1].nown, own = nA + nB;
+  int front, blk;
+  if (b < own) {
+    const int m = nA < nB ? nA : nB;
+    if (b < 2 * m) { front = b & 1; blk = b >> 1; } else { front = nA > nB ? 0 : 1; blk = b - m; }
+  } else {
+    const int j = b - own;
+    if (j < p.f[0].janitors) { front = 0; blk = nA + j; } else { front = 1; blk = nB + (j - p.f[0].janitors); }
+  }
+  bs_resident_body(p.f[front], p.env[front], blk);  // (indexed in the kernel-argument segment)
 }
 
 __global__ void copy_row_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int npad) {
@@ -2799,8 +2832,32 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
   cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last, info, nullptr, zero_after, resident);
   if (kt) kt->begin("backsolve", s);
   const int m = d.border_blocks * 128;
-  const bool side = d.B.ncols > 0 && d.A.ncols > 0 && ctxB && ctxB->fork;
+  // both leaf fronts under the resident launch: ONE launch for the two (bs_resident_pair_kernel) — no fork, no join
+  const bool paired = dev_knobs().bs_pair != 0 && d.A.ncols > 0 && d.B.ncols > 0 && info && resident != 0 && d.A.nblk <= kBsPairMaxBlocks && d.B.nblk <= kBsPairMaxBlocks;
+  const bool side = !paired && d.B.ncols > 0 && d.A.ncols > 0 && ctxB && ctxB->fork;
   hipStream_t sB = s;
+  if (paired) {
+    BsPair p;
+    const FrontView* fv[2] = {&d.A, &d.B};
+    double* ys[2] = {yA, yB};
+    int grid = 0, jan = 0;
+    for (int f = 0; f < 2; ++f) {
+      const FrontView& F = *fv[f];
+      for (int c = 0; c < F.nblk; ++c) {
+        p.env[f].top[c] = (unsigned short)(F.last ? std::min(std::max(F.last[c], c), F.nblk - 1) : F.nblk - 1);
+        p.env[f].tail[c] = (unsigned short)(F.tail ? std::min(std::max(F.tail[c], 0), F.nblk - 1) : F.nblk - 1);
+      }
+      const int janitors = zero_after ? bs_janitors(F.ncols) : 0;
+      // (the tail front reads the root's solution through the map, the head as it stands: cholesky_backsolve_front below)
+      p.f[f] = BsArgs{F.Linv, F.S, F.ld, (const double*)(F.S + (long)F.rhs_row * F.ld), F.ncols * 128, ys[f], F.nblk, info, F.ncols, yR, janitors, f == 1 ? d.mapB : nullptr};
+      grid += F.ncols; jan += janitors;
+    }
+    // (one fill for the two solutions where they lie one behind the other)
+    const size_t nA = (size_t)d.A.ncols * 128, nB = (size_t)d.B.ncols * 128;
+    if (yB >= yA + nA && (size_t)(yB - yA) <= nA + 4096) (void)hipMemsetAsync(yA, 0xff, sizeof(double) * ((size_t)(yB - yA) + nB), s);
+    else { (void)hipMemsetAsync(yA, 0xff, sizeof(double) * nA, s); (void)hipMemsetAsync(yB, 0xff, sizeof(double) * nB, s); }
+    hipLaunchKernelGGL(bs_resident_pair_kernel, dim3(grid + jan), dim3(1024), 0, s, p);
+  } else {
   if (d.B.ncols > 0) {
     if (side) {
       fork_join_events(ctxB);
@@ -2814,8 +2871,9 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
     cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, mapped ? yR : ybB, wB, yB, sB, d.B.last, false, 1, info, zero_after, d.B.tail,
                              mapped ? d.mapB : nullptr, resident);
   }
+  }
   // (yR is zero in the root's padding rows and in its right-hand-side row: it serves as A's border unknowns as it stands)
-  if (d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after, d.A.tail, nullptr, resident);
+  if (!paired && d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after, d.A.tail, nullptr, resident);
   if (side) {
     (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);
