@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 // kSyncServerXcc .. kSyncDSlot: the XCD-local hand-over of round 5 (below): the server's XCD (+ 1), the column it has factored last (a flag that
 // lives in that XCD's L2), and sixteen slots each for the tiles of block row j + 1 — X(j+1,j) formed / S(j+1,j+1) updated — 64-byte aligned
 // so that one scalar load reads all sixteen.
-enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncSyrkColumn = 3, kSyncServerXcc = 4, kSyncPotrfFast = 5,
+enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncSyrkColumn = 3, kSyncServerXcc = 4, kSyncPotrfFast = 5, kSyncStart = 6,
              kSyncXSlot = 16, kSyncDSlot = 32, kSyncHeader = 64 };  // then diag_ready[maxblk], x_ready[maxblk], ticket[maxblk]
 constexpr int kSyncArrays = 3;
 // Workgroups at the head of a column launch that may become one of the 16 tiles of block row j + 1: those that find themselves on the
@@ -861,6 +861,22 @@ __device__ __forceinline__ bool chain_wait(const int* p, int target, int* abort_
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidation has completed before the barrier that releases the other waves
+  return true;
+}
+// one lane: wait until *p == value (the start signal of a factorisation: chain_start_kernel); false = aborted / timed out
+__device__ __forceinline__ bool chain_wait_start(const int* p, int value, int* abort_flag) {
+  if (sync_load(p) != value) {
+    const long long t0 = wall_clock64();
+    int spins = 0;
+    do {
+      __builtin_amdgcn_s_sleep(8);
+      // (the counters — the abort flag among them — are this factorisation's only after the signal: nothing else is looked at before it)
+      if ((++spins & 63) == 0 && wall_clock64() - t0 > 4 * kChainTimeoutTicks) return false;
+    } while (sync_load(p) != value);
+  }
+  (void)abort_flag;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   return true;
 }
 // every wave of a consumer invalidates after the workgroup barrier that follows the wait
@@ -982,10 +998,23 @@ __device__ __forceinline__ bool server_wait_diag(int* sync, int j, int local) {
 
 struct ChainRanges { int n; int begin[8], end[8]; };  // the resident runs of block columns, [begin, end)
 
-__device__ __forceinline__ void potrf_server_body(double* lds, double* S, long ld, const ChainRanges& ranges, double* Linv, int* info, int* sync, int maxblk, int local) {
+// start != 0 (round 5): the launch was enqueued without an event in front of it — a blocked cross-queue wait wakes up 25-60 us after its
+// signal (profiles/r05_iteration_trace.txt) — and waits here for chain_start_kernel, which the caller's stream runs once the system is
+// assembled and the counters are reset: sync[kSyncStart] == start (a number that no earlier factorisation of this context used).
+__device__ __forceinline__ void potrf_server_body(double* lds, double* S, long ld, const ChainRanges& ranges, double* Linv, int* info, int* sync, int maxblk, int local, int start) {
   __shared__ int ok_s;
   const int stamp_front = gridDim.x == 2 ? (int)blockIdx.x : 0;
   int done = 0;  // value of the potrf counter
+  if (start != 0) {
+    if (threadIdx.x == 0) ok_s = chain_wait_start(sync + kSyncStart, start, sync + kSyncAbort) ? 1 : 0;
+    __syncthreads();
+    if (!ok_s) {
+      if (threadIdx.x == 0) info_raise(info, 2);
+      return;
+    }
+    SK_CHAIN_ACQUIRE_ALL
+    __syncthreads();
+  }
   if (local && threadIdx.x == 0) __hip_atomic_store(sync + kSyncServerXcc, 1 + xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // which XCD the tiles of block row j + 1 have to be on
   for (int r = 0; r < ranges.n; ++r)
     for (int j = ranges.begin[r]; j < ranges.end[r]; ++j) {
@@ -1017,18 +1046,24 @@ __device__ __forceinline__ void potrf_server_body(double* lds, double* S, long l
       done = j + 1;
     }
 }
-__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk, int local) {
+__global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk, int local, int start) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  potrf_server_body(lds, S, ld, ranges, Linv, info, sync, maxblk, local);
+  potrf_server_body(lds, S, ld, ranges, Linv, info, sync, maxblk, local, start);
+}
+// the start signal of a factorisation whose server waits for it in the kernel (one thread; a second front's counters too)
+__global__ void chain_start_kernel(int* sync_a, int* sync_b, int value) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __hip_atomic_store(sync_a + kSyncStart, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (sync_b) __hip_atomic_store(sync_b + kSyncStart, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Two fronts eliminated in ONE sequence of launches (cholesky_factor with a partner front): a
 // server workgroup each, on a CU 0 each.
 struct ServerArgs { double* S; long ld; ChainRanges ranges; double* Linv; int* sync; int maxblk; };
 struct ServerPair { ServerArgs f[2]; };
-__global__ __launch_bounds__(256, 1) void potrf_server_pair_kernel(ServerPair pair, int* info, int local) {
+__global__ __launch_bounds__(256, 1) void potrf_server_pair_kernel(ServerPair pair, int* info, int local, int start) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const ServerArgs& p = pair.f[blockIdx.x];  // (indexed in the kernel-argument segment: scalar loads)
-  potrf_server_body(lds, p.S, p.ld, p.ranges, p.Linv, info, p.sync, p.maxblk, local);
+  potrf_server_body(lds, p.S, p.ld, p.ranges, p.Linv, info, p.sync, p.maxblk, local, start);
 }
 
 // One 32 x 32 tile with K = 128 in a single memory round trip: C = A B^T (kMode 1) or C -= A B^T (kMode 0), A and B
@@ -2376,15 +2411,27 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     // its own in that queue, in front of everything that follows
     start_ev = ctx->event(ev++);
     (void)hipEventRecord(start_ev, s);
-    (void)hipStreamWaitEvent(srv, start_ev, 0);
+    // the server: no event in front of it — it is resident as soon as its queue is free and waits for chain_start_kernel, which runs on
+    // the caller's stream behind the reset of the counters above (developer variable SK_CHAIN_EARLY_SERVER=0: the event, as until round 5;
+    // under stream capture too)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusActive; }
+    int start_value = 0;
+    if (dev_knobs().chain_early_server != 0 && capturing == hipStreamCaptureStatusNone) {
+      static std::atomic<int> epoch{0};
+      start_value = 1 + (epoch.fetch_add(1) & 0x3fffffff);
+      hipLaunchKernelGGL(chain_start_kernel, dim3(1), dim3(1), 0, s, sync, pb.on ? pb.sync : (int*)nullptr, start_value);
+    } else {
+      (void)hipStreamWaitEvent(srv, start_ev, 0);
+    }
     if (pb.on) {
       ServerPair sp2;
       sp2.f[0] = ServerArgs{S, ld, ranges, Linv, sync, maxblk};
       ChainRanges rb; rb.n = 1; rb.begin[0] = 0; rb.end[0] = pb.ncols;
       sp2.f[1] = ServerArgs{pb.S, pb.ld, rb, pb.Linv, pb.sync, pb.maxblk};
-      hipLaunchKernelGGL(potrf_server_pair_kernel, dim3(2), dim3(256), potrf128_lds_bytes(), srv, sp2, info, local);
+      hipLaunchKernelGGL(potrf_server_pair_kernel, dim3(2), dim3(256), potrf128_lds_bytes(), srv, sp2, info, local, start_value);
     } else {
-      hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk, local);
+      hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk, local, start_value);
     }
   }
   if (la) {
