@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256, 1) void potrf128_kernel(double* __restrict__ A
 // kSyncServerXcc .. kSyncDSlot: the XCD-local hand-over of round 5 (below): the server's XCD (+ 1), the column it has factored last (a flag that
 // lives in that XCD's L2), and sixteen slots each for the tiles of block row j + 1 — X(j+1,j) formed / S(j+1,j+1) updated — 64-byte aligned
 // so that one scalar load reads all sixteen.
-enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncSyrkColumn = 3, kSyncServerXcc = 4, kSyncPotrfFast = 5, kSyncStart = 6,
+enum : int { kSyncPotrfDone = 0, kSyncAbort = 1, kSyncSyrkSeq = 2, kSyncSyrkColumn = 3, kSyncServerXcc = 4, kSyncPotrfFast = 5, kSyncStart = 6, kSyncEnd = 7,
              kSyncXSlot = 16, kSyncDSlot = 32, kSyncHeader = 64 };  // then diag_ready[maxblk], x_ready[maxblk], ticket[maxblk]
 constexpr int kSyncArrays = 3;
 // Workgroups at the head of a column launch that may become one of the 16 tiles of block row j + 1: those that find themselves on the
@@ -998,6 +998,32 @@ __device__ __forceinline__ bool server_wait_diag(int* sync, int j, int local) {
 
 struct ChainRanges { int n; int begin[8], end[8]; };  // the resident runs of block columns, [begin, end)
 
+// The JOIN of a factorisation under the resident chain (round 5): instead of the caller's stream waiting for an event of each of the
+// chain's streams — it gets there first and sits in a blocked wait that wakes up 25-35 us after the last signal — every stream ends with
+// a one-thread marker (the server: its own exit) that counts into sync[kSyncEnd], and the caller's stream runs chain_gate_kernel, one
+// wave that polls the counter: what follows on that stream starts a few microseconds after the last marker.  The gate does not give
+// up on the chain's abort flag (kernels that abort still end, and their markers still run: what follows must not start next to them); a
+// stream that never ends costs it four time-outs, then info = 2.
+__device__ __forceinline__ void chain_end_signal(int* counter) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__global__ void chain_end_marker_kernel(int* counter) { chain_end_signal(counter); }
+__global__ void chain_gate_kernel(const int* counter, int expected, int* info) {
+  if (threadIdx.x != 0) return;
+  if (sync_load(counter) < expected) {
+    const long long t0 = wall_clock64();
+    int spins = 0;
+    do {
+      __builtin_amdgcn_s_sleep(4);
+      if ((++spins & 63) == 0 && wall_clock64() - t0 > 4 * kChainTimeoutTicks) { info_raise(info, 2); break; }
+    } while (sync_load(counter) < expected);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 // start != 0 (round 5): the launch was enqueued without an event in front of it — a blocked cross-queue wait wakes up 25-60 us after its
 // signal (profiles/r05_iteration_trace.txt) — and waits here for chain_start_kernel, which the caller's stream runs once the system is
 // assembled and the counters are reset: sync[kSyncStart] == start (a number that no earlier factorisation of this context used).
@@ -1049,6 +1075,7 @@ __device__ __forceinline__ void potrf_server_body(double* lds, double* S, long l
 __global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld, ChainRanges ranges, double* Linv, int* info, int* sync, int maxblk, int local, int start) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   potrf_server_body(lds, S, ld, ranges, Linv, info, sync, maxblk, local, start);
+  if (start != 0) chain_end_signal(sync + kSyncEnd);  // (the join of the factorisation: chain_gate_kernel)
 }
 // the start signal of a factorisation whose server waits for it in the kernel (one thread; a second front's counters too)
 __global__ void chain_start_kernel(int* sync_a, int* sync_b, int value) {
@@ -1064,6 +1091,7 @@ __global__ __launch_bounds__(256, 1) void potrf_server_pair_kernel(ServerPair pa
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const ServerArgs& p = pair.f[blockIdx.x];  // (indexed in the kernel-argument segment: scalar loads)
   potrf_server_body(lds, p.S, p.ld, p.ranges, p.Linv, info, p.sync, p.maxblk, local, start);
+  if (start != 0) chain_end_signal(pair.f[0].sync + kSyncEnd);  // (both servers count into the FIRST front's counter)
 }
 
 // One 32 x 32 tile with K = 128 in a single memory round trip: C = A B^T (kMode 1) or C -= A B^T (kMode 0), A and B
@@ -2343,6 +2371,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
   const char* stamps_file = chain ? dev_knobs().chain_stamps : nullptr;
   hipStream_t srv = nullptr;
   hipEvent_t start_ev = nullptr;
+  int start_value = 0;  // != 0: the server waits in the kernel for chain_start_kernel, and the join is chain_gate_kernel (no events: below)
   struct PartnerState {
     bool on = false; CholeskyPlan plan; int nblk = 0, ncols = 0, tail0 = 0, start_at = 0, maxblk = 0; const int* last = nullptr; const int* tail = nullptr;
     double* S = nullptr; long ld = 0; double* Linv = nullptr; int* sync = nullptr; double* xs = nullptr;
@@ -2416,7 +2445,6 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     // under stream capture too)
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusActive; }
-    int start_value = 0;
     if (dev_knobs().chain_early_server != 0 && capturing == hipStreamCaptureStatusNone) {
       static std::atomic<int> epoch{0};
       start_value = 1 + (epoch.fetch_add(1) & 0x3fffffff);
@@ -2624,11 +2652,19 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     }
     partner_advance(st, ctx->bulk);
   }
+  if (chain && start_value != 0) {
+    // the join without events (chain_gate_kernel): a marker at the end of every stream the factorisation used, the server's own exit
+    int expected = pb.on ? 2 : 1;
+    for (hipStream_t q : {sp, ctx->bulk, used_bulk_early ? ctx->bulk_early : (hipStream_t) nullptr})
+      if (q && q != s) { hipLaunchKernelGGL(chain_end_marker_kernel, dim3(1), dim3(64), 0, q, sync + kSyncEnd); ++expected; }
+    hipLaunchKernelGGL(chain_gate_kernel, dim3(1), dim3(64), 0, s, (const int*)(sync + kSyncEnd), expected, info);
+  } else {
   order(sp, s);
   // (a factorisation of chain-bound block columns never touches the stream of the wide SYRKs: one cross-queue dependency less in
   // front of whatever follows — each is a packet of its own, ~10 us)
   if (la) { order(ctx->bulk, s); if (used_bulk_early) order(ctx->bulk_early, s); }
   if (chain) order(srv, s);
+  }
   if (stamps_file) {
     (void)hipStreamSynchronize(s);
     std::vector<long long> st((size_t)1024 * 8);
