@@ -2198,6 +2198,10 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   int* bs_info = bs_resident ? info_p_ : nullptr;  // (nullptr: the back-substitutions one launch per block step — nothing resident, nothing that waits)
   double* yf[3] = {b_yf_.p + fr_[0].y_off, b_yf_.p + fr_[1].y_off, b_yf_.p + fr_[2].y_off};
   double* wf[3] = {b_wf_.p + fr_[0].y_off, b_wf_.p + fr_[1].y_off, b_wf_.p + fr_[2].y_off};
+  // (the resident back-substitutions find their "not there yet" pattern in every front's y already: one fill here, in front of the
+  // factorisation, instead of one in front of each of them, between the factorisation's end and the first hop)
+  const bool prefilled = bs_resident != 0;
+  if (prefilled) SK_HIP_TRY(hipMemsetAsync(b_yf_.p, 0xff, (fr_[0].dim + fr_[1].dim + fr_[2].dim) * sizeof(double), s));
   if (segmented_) {
     // this rank's segment: factor its interior, leave its Schur complement on the separators next to it; sum the root
     // fronts over the ranks (the separators' own blocks come from whichever rank owns the point, the Schur complements
@@ -2217,18 +2221,18 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
     launch_tri_pack(Rs, (int)R.dim, b_pack_.p, R.nblk, b_pack_col0_.p, b_pack_off_.p, false, s);
     finish_root();
     cholesky_factor(Rs, (long)R.dim, (int)R.dim, RLinv, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok(), -1, 1, nullptr, R.tl());
-    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl(), zero_after, bs_resident);
+    cholesky_backsolve(Rs, (long)R.dim, 9 * R.cams, (int)R.dim, R.rhs_row, RLinv, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl(), zero_after, bs_resident, prefilled);
     if (L.ncols > 0) {
       cholesky_gather_map(yf[2], b_leaf_gmap_.p, b_ybB_.p, (L.nblk - L.ncols) * 128, s);
-      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info, zero_after, L.tail, nullptr, bs_resident);
+      cholesky_backsolve_front(L.S, L.ld, L.nblk, L.ncols, L.rhs_row, L.Linv, b_ybB_.p, wf[0], yf[0], s, L.last, L.spike, L.tail_rows, bs_info, zero_after, L.tail, nullptr, bs_resident, prefilled);
     }
   } else if (dissected_) {
     cholesky_dissected_factor(ds_, info_p_, group_, s, ctx, &chol_ctx_b_, &kt_, &kt_b_, chain_ok());
-    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, bs_info, zero_after, bs_resident);
+    cholesky_dissected_backsolve(ds_, 9 * fr_[2].cams, wf[2], yf[2], wf[0], yf[0], wf[1], yf[1], b_ybB_.p, s, &chol_ctx_b_, &kt_, bs_info, zero_after, bs_resident, prefilled);
   } else {
     const FrontHost& R = fr_[2];
     cholesky_factor(d_.front[2].S, (long)R.dim, (int)R.dim, b_Linv_.p, info_p_, group_, s, ctx, &kt_, R.env(), chain_ok(), -1, 1, nullptr, R.tl());
-    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl(), zero_after, bs_resident);
+    cholesky_backsolve(d_.front[2].S, (long)R.dim, n_, (int)R.dim, R.rhs_row, b_Linv_.p, wf[2], yf[2], s, &kt_, R.env(), bs_info, R.tl(), zero_after, bs_resident, prefilled);
   }
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvChol], s));
   // ---- D. back-substitution, candidate point ----

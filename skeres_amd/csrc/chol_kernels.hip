@@ -1024,6 +1024,10 @@ __global__ void chain_gate_kernel(const int* counter, int expected, int* info) {
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
+__global__ void chain_start_gate_kernel(const int* p, int value, int* info) {
+  if (threadIdx.x != 0) return;
+  if (!chain_wait_start(p, value, nullptr)) info_raise(info, 2);
+}
 // start != 0 (round 5): the launch was enqueued without an event in front of it — a blocked cross-queue wait wakes up 25-60 us after its
 // signal (profiles/r05_iteration_trace.txt) — and waits here for chain_start_kernel, which the caller's stream runs once the system is
 // assembled and the counters are reset: sync[kSyncStart] == start (a number that no earlier factorisation of this context used).
@@ -1078,7 +1082,12 @@ __global__ __launch_bounds__(256, 1) void potrf_server_kernel(double* S, long ld
   if (start != 0) chain_end_signal(sync + kSyncEnd);  // (the join of the factorisation: chain_gate_kernel)
 }
 // the start signal of a factorisation whose server waits for it in the kernel (one thread; a second front's counters too)
-__global__ void chain_start_kernel(int* sync_a, int* sync_b, int value) {
+// (... and the reset of the counters themselves: n_a, n_b ints from sync_a, sync_b — one launch where there were two fills and a signal)
+__global__ __launch_bounds__(256) void chain_start_kernel(int* sync_a, int n_a, int* sync_b, int n_b, int value) {
+  for (int i = threadIdx.x; i < n_a; i += 256) sync_a[i] = 0;
+  if (sync_b) for (int i = threadIdx.x; i < n_b; i += 256) sync_b[i] = 0;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __hip_atomic_store(sync_a + kSyncStart, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (sync_b) __hip_atomic_store(sync_b + kSyncStart, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2416,7 +2425,11 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     static int stamps_state = 0;
     if (stamps_on != stamps_state) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamps_on), &stamps_on, sizeof(int)); stamps_state = stamps_on; }
     srv = ctx->server;
-    (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + kSyncArrays * maxblk), s);
+    // (whether the server waits in the kernel for its start signal — which then resets the counters too — or behind an event)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusActive; }
+    const bool early = dev_knobs().chain_early_server != 0 && capturing == hipStreamCaptureStatusNone;
+    if (!early) (void)hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(kSyncHeader + kSyncArrays * maxblk), s);
     // ---- the partner front (see CholeskyPartner): taken along if every one of its block columns is a resident single column,
     // in the launches of this front's resident single columns
     if (partner && partner->ncols > 0 && partner->ctx && !(kt && kt->times_all())) {
@@ -2432,7 +2445,7 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
         pb.on = true; pb.start_at = start; pb.sync = sb_sync; pb.maxblk = partner->ctx->sync_blk; pb.xs = partner->ctx->xs;
         pb.nblk = partner->nblk; pb.ncols = partner->ncols; pb.tail0 = partner->nblk - std::max(1, std::min(partner->tail_rows, partner->nblk - partner->ncols));
         pb.last = partner->last; pb.tail = partner->tail; pb.S = partner->S; pb.ld = partner->ld; pb.Linv = partner->Linv;
-        (void)hipMemsetAsync(pb.sync, 0, sizeof(int) * (size_t)(kSyncHeader + kSyncArrays * pb.maxblk), s);
+        if (!early) (void)hipMemsetAsync(pb.sync, 0, sizeof(int) * (size_t)(kSyncHeader + kSyncArrays * pb.maxblk), s);
         partner->taken = true;
       }
     }
@@ -2443,12 +2456,11 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
     // the server: no event in front of it — it is resident as soon as its queue is free and waits for chain_start_kernel, which runs on
     // the caller's stream behind the reset of the counters above (developer variable SK_CHAIN_EARLY_SERVER=0: the event, as until round 5;
     // under stream capture too)
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusActive; }
-    if (dev_knobs().chain_early_server != 0 && capturing == hipStreamCaptureStatusNone) {
+    if (early) {
       static std::atomic<int> epoch{0};
       start_value = 1 + (epoch.fetch_add(1) & 0x3fffffff);
-      hipLaunchKernelGGL(chain_start_kernel, dim3(1), dim3(1), 0, s, sync, pb.on ? pb.sync : (int*)nullptr, start_value);
+      hipLaunchKernelGGL(chain_start_kernel, dim3(1), dim3(256), 0, s, sync, kSyncHeader + kSyncArrays * maxblk, pb.on ? pb.sync : (int*)nullptr,
+                         pb.on ? kSyncHeader + kSyncArrays * pb.maxblk : 0, start_value);
     } else {
       (void)hipStreamWaitEvent(srv, start_ev, 0);
     }
@@ -2462,7 +2474,11 @@ void cholesky_factor(double* S, long ld, int npad, double* Linv, int* info, int 
       hipLaunchKernelGGL(potrf_server_kernel, dim3(1), dim3(256), potrf128_lds_bytes(), srv, S, ld, ranges, Linv, info, sync, maxblk, local, start_value);
     }
   }
-  if (la) {
+  if (la && chain && start_value != 0 && sp != s) {
+    // the panel stream starts behind a polling wave as well (chain_start_gate_kernel), not behind a blocked wait; the bulk streams need
+    // nothing in front: every kernel they get waits for an event of the panel stream, which lies behind that wave
+    hipLaunchKernelGGL(chain_start_gate_kernel, dim3(1), dim3(64), 0, sp, (const int*)(sync + kSyncStart), start_value, info);
+  } else if (la) {
     if (!start_ev) { start_ev = ctx->event(ev++); (void)hipEventRecord(start_ev, s); }
     for (hipStream_t q : {sp, ctx->bulk, ctx->bulk_early}) if (q != s) (void)hipStreamWaitEvent(q, start_ev, 0);
   }
@@ -2697,7 +2713,7 @@ bool cholesky_backsolve_resident(int nblk) { return g_bs_resident.load() != 0 &&
 // to 96 — with the owners they stay inside the chip's 256 CUs (a workgroup of 1024 threads at 256 VGPRs fills one)
 static int bs_janitors(int owners) { return std::max(1, std::min(owners, 96)); }
 void cholesky_backsolve(double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt, const int* last, int* info, const int* tail, bool zero_after, int resident) {
+                        hipStream_t s, KernelTimer* kt, const int* last, int* info, const int* tail, bool zero_after, int resident, bool prefilled) {
   const int nblk = npad / 128;
   if (info && (resident < 0 ? g_bs_resident.load() != 0 : resident != 0) && nblk <= kBsMaxBlocks) {
     BsTop env;
@@ -2706,7 +2722,7 @@ void cholesky_backsolve(double* S, long ld, int n, int npad, int rhs_row, const 
       env.tail[c] = (unsigned short)(tail ? std::min(std::max(tail[c], 0), nblk - 1) : nblk - 1);
     }
     if (kt) kt->begin("backsolve", s);
-    (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);
+    if (!prefilled) (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);  // (prefilled: the caller has set the sentinels, off the critical path)
     const char* bs_stamps = dev_knobs().bs_stamps;
     if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
     const int janitors = zero_after ? bs_janitors(nblk) : 0;
@@ -2810,7 +2826,8 @@ void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f
 // Interior part of L^T y = z for a leaf front whose border unknowns are known.  yb: border unknowns (border_blocks * 128
 // values, zero where the border has padding or its right-hand-side row).  w: scratch (ncols * 128); y: interior solution.
 void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
-                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info, bool zero_after, const int* tail, const int* yb_map, int resident) {
+                              hipStream_t s, const int* last, bool spike, int tail_rows, int* info, bool zero_after, const int* tail, const int* yb_map, int resident,
+                              bool prefilled) {
   const int ni = ncols * 128, m = (nblk - ncols) * 128;
   if (ncols <= 0) return;
   const bool res = info && (resident < 0 ? g_bs_resident.load() != 0 : resident != 0) && nblk <= kBsMaxBlocks;
@@ -2829,7 +2846,7 @@ void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_r
       env.top[c] = (unsigned short)(last ? std::min(std::max(last[c], c), nblk - 1) : nblk - 1);
       env.tail[c] = (unsigned short)(tail ? std::min(std::max(tail[c], 0), nblk - 1) : nblk - tail_rows);
     }
-    (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)ni, s);
+    if (!prefilled) (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)ni, s);
     const int janitors = zero_after ? bs_janitors(ncols) : 0;
     hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), ni, y, nblk, env, info, ncols, yb, janitors, yb_map);
     return;
@@ -2910,9 +2927,9 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
 }
 
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,
-                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info, bool zero_after, int resident) {
+                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info, bool zero_after, int resident, bool prefilled) {
   if (resident < 0) resident = g_bs_resident.load() != 0 ? 1 : 0;  // (once for the three fronts)
-  cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last, info, nullptr, zero_after, resident);
+  cholesky_backsolve(d.R.S, d.R.ld, n_root, d.R.nblk * 128, d.R.rhs_row, d.R.Linv, wR, yR, s, nullptr, d.R.last, info, nullptr, zero_after, resident, prefilled);
   if (kt) kt->begin("backsolve", s);
   const int m = d.border_blocks * 128;
   // both leaf fronts under the resident launch: ONE launch for the two (bs_resident_pair_kernel) — no fork, no join
@@ -2937,7 +2954,8 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
     }
     // (one fill for the two solutions where they lie one behind the other)
     const size_t nA = (size_t)d.A.ncols * 128, nB = (size_t)d.B.ncols * 128;
-    if (yB >= yA + nA && (size_t)(yB - yA) <= nA + 4096) (void)hipMemsetAsync(yA, 0xff, sizeof(double) * ((size_t)(yB - yA) + nB), s);
+    if (prefilled) {}
+    else if (yB >= yA + nA && (size_t)(yB - yA) <= nA + 4096) (void)hipMemsetAsync(yA, 0xff, sizeof(double) * ((size_t)(yB - yA) + nB), s);
     else { (void)hipMemsetAsync(yA, 0xff, sizeof(double) * nA, s); (void)hipMemsetAsync(yB, 0xff, sizeof(double) * nB, s); }
     hipLaunchKernelGGL(bs_resident_pair_kernel, dim3(grid + jan), dim3(1024), 0, s, p);
   } else {
@@ -2952,11 +2970,11 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
     const bool mapped = info && resident != 0 && d.B.nblk <= kBsMaxBlocks;
     if (!mapped) cholesky_gather_map(yR, d.mapB, ybB, m, sB);
     cholesky_backsolve_front(d.B.S, d.B.ld, d.B.nblk, d.B.ncols, d.B.rhs_row, d.B.Linv, mapped ? yR : ybB, wB, yB, sB, d.B.last, false, 1, info, zero_after, d.B.tail,
-                             mapped ? d.mapB : nullptr, resident);
+                             mapped ? d.mapB : nullptr, resident, prefilled);
   }
   }
   // (yR is zero in the root's padding rows and in its right-hand-side row: it serves as A's border unknowns as it stands)
-  if (!paired && d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after, d.A.tail, nullptr, resident);
+  if (!paired && d.A.ncols > 0) cholesky_backsolve_front(d.A.S, d.A.ld, d.A.nblk, d.A.ncols, d.A.rhs_row, d.A.Linv, yR, wA, yA, s, d.A.last, false, 1, info, zero_after, d.A.tail, nullptr, resident, prefilled);
   if (side) {
     (void)hipEventRecord(ctxB->join_ev, ctxB->fork);
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);

@@ -214,7 +214,8 @@ int cholesky_plan_max_group(const CholeskyPlan& plan);
 // taken once for all the back-substitutions of one linear solve (cholesky_backsolve_resident) — the fronts of a dissected system must
 // all be solved the same way, and what zero_after promises the next assembly depends on it
 void cholesky_backsolve(double* S, long ld, int n, int npad, int rhs_row, const double* Linv, double* w, double* y,
-                        hipStream_t s, KernelTimer* kt, const int* last = nullptr, int* info = nullptr, const int* tail = nullptr, bool zero_after = false, int resident = -1);
+                        hipStream_t s, KernelTimer* kt, const int* last = nullptr, int* info = nullptr, const int* tail = nullptr, bool zero_after = false, int resident = -1,
+                        bool prefilled = false);  // prefilled (resident launch): y already holds the "not there yet" pattern (all bits set) — the caller filled it off the critical path
 bool cholesky_backsolve_resident(int nblk);  // would cholesky_backsolve(..., info != nullptr) of a system of nblk block rows be the resident launch?
 // --- dissected factorisation (chol_kernels.hip, "Two-way dissection") ---
 struct FrontView {
@@ -240,7 +241,7 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
 // Solve: root, then the two interiors side by side.  yR / yA / yB: solutions in each front's own order; w*: scratch of the
 // fronts' sizes; ybB: scratch of border size.  The right-hand sides are the fronts' rhs rows after the factorisation.
 void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* wR, double* yR, double* wA, double* yA, double* wB, double* yB, double* ybB,
-                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info = nullptr, bool zero_after = false, int resident = -1);
+                                  hipStream_t s, CholeskyContext* ctxB, KernelTimer* kt, int* info = nullptr, bool zero_after = false, int resident = -1, bool prefilled = false);
 // root += border x border block of a leaf front (front: ncols interior block columns, then border_blocks block rows);
 // map: root index of each border index (nullptr: identity; < 0: skip)
 void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s);
@@ -248,7 +249,7 @@ void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f
 void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_row, const double* Linv, const double* yb, double* w, double* y,
                               hipStream_t s, const int* last, bool spike = false, int tail_rows = 1, int* info = nullptr, bool zero_after = false, const int* tail = nullptr,
                               const int* yb_map = nullptr,  // yb_map (resident launch only): border index -> index into yb (< 0: zero) instead of a gathered copy
-                              int resident = -1);
+                              int resident = -1, bool prefilled = false);
 void cholesky_gather_map(const double* src, const int* map, double* dst, int m, hipStream_t s);
 // --- multi-way dissection: R segments of a block-banded system with R - 1 separators between them ---
 // Leaf front of one segment, in scalar rows.  The interior is followed by a border:
