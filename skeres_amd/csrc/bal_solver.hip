@@ -334,6 +334,7 @@ class BalSolver : public SolverBase {
   bool graph_ok() const { return graph_mode_ && !kt_.enabled(); }
   int finish_capture(hipStream_t s, hipGraphExec_t* exec);
   DevBuf<int> b_zero_col0_f_[3], b_mapB_;
+  bool mapB_involution_ = false;
   DevBuf<double> b_yf_, b_wf_, b_ybB_;
   double order_hash_ = 0.0;    // of the camera order and the envelope: equal on every rank, or setup() fails
   int camera_order_ = 0;       // which candidate order of the cameras was kept (0 first appearance, 1 memory, 2 RCM)
@@ -1876,6 +1877,8 @@ int BalSolver::setup() {
     for (int k = 0; k < nsep; ++k) for (int c = 0; c < 9; ++c) mapB[9 * k + c] = k < nreal ? 9 * (nreal - 1 - k) + c : 9 * k + c;  // camera order reversed, coordinates in order (pseudo-cameras: in place)
     mapB[9 * nsep] = 9 * nsep;  // right-hand-side row
     SK_HIP_TRY(b_mapB_.upload(mapB, s));
+    mapB_involution_ = true;  // (a reversal of the real separator cameras, the rest in place)
+    for (size_t i = 0; i < mapB.size() && mapB_involution_; ++i) if (mapB[i] >= 0 && mapB[(size_t)mapB[i]] != (int)i) mapB_involution_ = false;
   }
   partial_stride_ = std::max(std::max(std::max(bal_partial_blocks(N_), bal_point_blocks(P_) + 1), (9 * C_ + 255) / 256), 256) + bal_partial_blocks((int)host_obs_.size());  // (+ 1: the retained points' slot)
   SK_HIP_TRY(b_partial_.alloc(4 * (size_t)partial_stride_));
@@ -1917,7 +1920,7 @@ int BalSolver::setup() {
       v.Linv = b_Linv_.p + fr_[f].linv_off; v.rhs_row = fr_[f].rhs_row; v.tail = fr_[f].tl();
       return v;
     };
-    ds_.A = view(0); ds_.B = view(1); ds_.R = view(2); ds_.border_blocks = border_blocks_; ds_.mapB = b_mapB_.p;
+    ds_.A = view(0); ds_.B = view(1); ds_.R = view(2); ds_.border_blocks = border_blocks_; ds_.mapB = b_mapB_.p; ds_.mapB_involution = mapB_involution_;
   }
   d_.partial = b_partial_.p; d_.partial_stride = partial_stride_; d_.fail_flag = fail_p_;
   d_.loss_nodes = nullptr; d_.loss_root = p.rb_loss.empty() ? -1 : p.rb_loss[0]; d_.loss_of_obs = nullptr;

@@ -2817,6 +2817,25 @@ __global__ void gather_map_kernel(const double* __restrict__ src, const int* __r
   if (i < m) dst[i] = map ? (map[i] >= 0 ? src[map[i]] : 0.0) : src[i];
 }
 
+// root += the head's border (in the root's order), then += the tail's (through the map, which is its own inverse: the root entry (i, j)
+// takes the tail's entry (map[i], map[j])) — the same two additions in the same order as two border_add_kernel launches, in one
+__global__ __launch_bounds__(256) void border_add2_kernel(double* __restrict__ root, long ld_r, const double* __restrict__ a, long ld_a, const double* __restrict__ b, long ld_b,
+                                                          int m, const int* __restrict__ map) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)m * m) return;
+  const int i = (int)(e / m), j = (int)(e % m);
+  if (j > i) return;
+  double v = root[(long)i * ld_r + j];
+  bool touched = false;
+  const double va = a[(long)i * ld_a + j];
+  if (va != 0.0) { v += va; touched = true; }
+  const int bi = map[i], bj = map[j];
+  if (bi >= 0 && bj >= 0) {
+    const double vb = bi >= bj ? b[(long)bi * ld_b + bj] : b[(long)bj * ld_b + bi];
+    if (vb != 0.0) { v += vb; touched = true; }
+  }
+  if (touched) root[(long)i * ld_r + j] = v;
+}
 void cholesky_border_add(double* root, long ld_r, const double* front, long ld_f, int ncols, int border_blocks, const int* map, hipStream_t s) {
   const int m = border_blocks * 128;
   const long total = (long)m * m;
@@ -2921,8 +2940,15 @@ void cholesky_dissected_factor(const DissectedSystem& d, int* info, int group, h
     ctxB->runner->wait();  // (the join event has been recorded)
     (void)hipStreamWaitEvent(s, ctxB->join_ev, 0);
   }
-  if (d.A.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.A.S, d.A.ld, d.A.ncols, d.border_blocks, nullptr, s);
-  if (d.B.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.B.S, d.B.ld, d.B.ncols, d.border_blocks, d.mapB, s);
+  if (d.A.ncols > 0 && d.B.ncols > 0 && d.mapB && d.mapB_involution) {
+    const int m = d.border_blocks * 128;
+    hipLaunchKernelGGL(border_add2_kernel, dim3((unsigned)(((long)m * m + 255) / 256)), dim3(256), 0, s, d.R.S, d.R.ld,
+                       (const double*)(d.A.S + (long)d.A.ncols * 128 * d.A.ld + (long)d.A.ncols * 128), d.A.ld,
+                       (const double*)(d.B.S + (long)d.B.ncols * 128 * d.B.ld + (long)d.B.ncols * 128), d.B.ld, m, d.mapB);
+  } else {
+    if (d.A.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.A.S, d.A.ld, d.A.ncols, d.border_blocks, nullptr, s);
+    if (d.B.ncols > 0) cholesky_border_add(d.R.S, d.R.ld, d.B.S, d.B.ld, d.B.ncols, d.border_blocks, d.mapB, s);
+  }
   cholesky_factor(d.R.S, d.R.ld, d.R.nblk * 128, d.R.Linv, info, group, s, ctxA, kt, d.R.last, allow_chain);
 }
 

@@ -233,6 +233,7 @@ struct DissectedSystem {
   FrontView A, B, R;                  // head, tail (B.ncols == 0: none), root
   int border_blocks = 0;              // block rows of the leaves' borders == R.nblk
   const int* mapB = nullptr;          // device: B's border index -> root index (< 0: padding)
+  bool mapB_involution = false;       // mapB[mapB[i]] == i wherever mapB[i] >= 0 (a reversal is): the two fronts' borders are then added to the root in ONE launch
 };
 // Factor A and B side by side (B on ctxB's streams, launch by launch), add their Schur complements to the root, factor it.
 // ktB: the timer of the tail's launches (they are enqueued by ctxB's own thread: a KernelTimer belongs to one thread).
