@@ -467,7 +467,7 @@ static Dissection choose_dissection(const std::vector<int>& ocam, const std::vec
       // the head's chain-bound columns (its first few, and its trailing run) each carry one of the tail's; the others cost what they cost
       const int nb = nblk - cb;
       int k = 0;
-      t = root + 180.0 + bs;  // + border add, a second resident server's set-up, the zeroing left to the assembly
+      t = root + 100.0 + bs;  // + border add, the root's own start and join (180 us until the chain's starts and joins lost their events: round 5)
       for (int c = 0; c < ca; ++c) {
         if (height[c] <= 24 && k < nb) { t += height_b[nblk - 1 - k] <= 24 ? pair_cost_us(height[c], height_b[nblk - 1 - k]) : std::max(fwd[c], bwd[nblk - 1 - k]); ++k; }
         else t += fwd[c];
