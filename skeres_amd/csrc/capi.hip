@@ -74,6 +74,7 @@ const DevKnobs& dev_knobs() {
     k.schedule_plain = num("SK_SCHEDULE_PLAIN", 0);
     k.chain_xcd_local = num("SK_CHAIN_XCD_LOCAL", 0);
     if (const char* e = getenv("SK_BS_PAIR")) k.bs_pair = atoi(e);
+    if (const char* e = getenv("SK_BS_SPREAD")) k.bs_spread = atoi(e);
     if (const char* e = getenv("SK_CHAIN_EARLY_SERVER")) k.chain_early_server = atoi(e);
     if (const char* e = getenv("SK_BULK_RESERVE")) {
       k.bulk_reserve = atoi(e);

@@ -1456,7 +1456,15 @@ struct BsArgs {
   const double* Linv; double* S; long ld; const double* rhs; int n; double* y; int nblk; int* info; int nown; const double* yb;
   int janitors;       // number of janitor workgroups behind the owners
   const int* yb_map;  // border index -> index into yb (< 0: zero); nullptr: the border's own order
+  int jan_parts;      // > 0 (the XCD-spread launch, below): a janitor takes ONE block column — janitor jn: column nown - 1 - jn / jan_parts — and every jan_parts-th block row of it
+  int l2_poll;        // the owners sit on ONE XCD: a solution block is stored plainly first (into that XCD's L2) and polled with L1-bypassing loads
 };
+// 8-byte load that bypasses the CU's vector L1 (served by the XCD's L2)
+__device__ __forceinline__ unsigned long long load_sc0_u64(const unsigned long long* p) {
+  unsigned long long v;
+  asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 template <typename Env>
 __device__ __forceinline__ void bs_resident_body(const BsArgs& a, const Env& env, const int block) {
   const double* __restrict__ Linv = a.Linv; double* S = a.S; const long ld = a.ld; const double* rhs = a.rhs; const int n = a.n; double* y = a.y;
@@ -1481,7 +1489,8 @@ __device__ __forceinline__ void bs_resident_body(const BsArgs& a, const Env& env
   if (block >= nown) {
     const int jn = block - nown, t = threadIdx.x, c = t & 127, rg = t >> 7;
     __shared__ int ok_s;
-    for (int kb = nown - 1 - jn; kb >= 0; kb -= zero_after) {
+    const int parts = a.jan_parts > 0 ? a.jan_parts : 1, part = a.jan_parts > 0 ? jn % a.jan_parts : 0;
+    for (int kb = nown - 1 - (a.jan_parts > 0 ? jn / a.jan_parts : jn); kb >= 0; kb -= (a.jan_parts > 0 ? nown : zero_after)) {
       if (t == 0) {
         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(y + (long)kb * 128);
         const long long t0 = wall_clock64();
@@ -1504,8 +1513,10 @@ __device__ __forceinline__ void bs_resident_body(const BsArgs& a, const Env& env
       const int top = min((int)env.top[kb], nblk - 1);
       const int tlo = max((int)env.tail[kb], top + 1);
       double* col = S + (long)(rg * 16) * ld + (long)kb * 128 + c;
+      int visited = 0;
       for (int cur = kb + 1; cur < nblk; ++cur) {
         if (cur > top && cur < tlo) { cur = tlo - 1; continue; }
+        if ((visited++) % parts != part) continue;
         double* pz = col + (long)cur * 128 * ld;
 #pragma unroll
         for (int i = 0; i < 16; ++i) pz[(long)i * ld] = 0.0;
@@ -1544,14 +1555,22 @@ __device__ __forceinline__ void bs_resident_body(const BsArgs& a, const Env& env
       ysh[t] = src >= 0 ? yb[src] : 0.0;
     } else if (t < 128) {
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(y + (long)cur * 128 + t);
-      unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (l2_poll: the producer is on this XCD — its plain store is in the L2 both share a microsecond and a half before the device-scope
+      // one is visible; every poll looks there first, then at the device scope, which is what counts wherever the producer really is)
+      unsigned long long v = a.l2_poll ? load_sc0_u64(src) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (v == kBsSentinel) {
         // (four polls in flight instead of one at a time: measured, no difference — a hop waits for one coherent read, 1.9 us
         // from the producer's completed store to the consumer's barrier, not for the poll that happens to see it)
         const long long t0 = wall_clock64();
+        int spins = 0;
         do {
           __builtin_amdgcn_s_sleep(1);
-          v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (a.l2_poll) {
+            v = load_sc0_u64(src);
+            if (v == kBsSentinel && (++spins & 3) == 0) v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           if (v == kBsSentinel && wall_clock64() - t0 > kChainTimeoutTicks) { abort_s = 1; v = 0ull; }
         } while (v == kBsSentinel);
       }
@@ -1596,6 +1615,7 @@ __device__ __forceinline__ void bs_resident_body(const BsArgs& a, const Env& env
     for (int q = 0; q < 8; ++q) sacc += part[q][t];
     unsigned long long bits = (unsigned long long)__double_as_longlong(sacc);
     if (bits == kBsSentinel) bits ^= 1ull;  // (a NaN out of a failed factorisation must not look like "not there yet")
+    if (a.l2_poll) *reinterpret_cast<volatile unsigned long long*>(y + (long)kb * 128 + t) = bits;  // (into this XCD's L2: the next owner's first look)
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(y + (long)kb * 128 + t), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (g_bs_stamps_on && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_bs_stamps[kb][2] = wall_clock64(); }
   }
@@ -1605,8 +1625,12 @@ __device__ __forceinline__ void bs_resident_body(const BsArgs& a, const Env& env
 __global__ __launch_bounds__(1024, 1) void bs_resident_kernel(const double* __restrict__ Linv, double* S, long ld, const double* rhs,
                                                                int n, double* y, int nblk, BsTop env, int* info, int nown, const double* __restrict__ yb, int zero_after /* number of janitor workgroups */,
                                                                const int* __restrict__ yb_map) {
-  const BsArgs a{Linv, S, ld, rhs, n, y, nblk, info, nown, yb, zero_after, yb_map};
-  bs_resident_body(a, env, (int)blockIdx.x);
+  // spread != 0 (round 5): workgroup b of a launch goes to XCD b mod 8 — the owners are the workgroups 0, 8, 16, ... (all on ONE XCD: a hop's
+  // hand-over goes through that XCD's L2), the seven between two owners are the janitors of the earlier one's block column, a seventh of its block rows each
+  const int spread = zero_after < 0 ? 1 : 0;
+  const BsArgs a{Linv, S, ld, rhs, n, y, nblk, info, nown, yb, spread ? 7 * nown : zero_after, yb_map, spread ? 7 : 0, spread};
+  const int b = (int)blockIdx.x;
+  bs_resident_body(a, env, spread ? ((b & 7) == 0 ? b >> 3 : nown + (b >> 3) * 7 + (b & 7) - 1) : b);
 }
 // Two leaf fronts' back-substitutions in ONE launch (round 5): side by side on two streams they cost a fork in front (~20 us) and, behind,
 // a join that the main stream reaches first and sits in blocked (~65 us until the queue wakes up: profiles/r05_iteration_trace.txt).
@@ -1617,6 +1641,17 @@ struct BsPair { BsArgs f[2]; BsTopHalf env[2]; };
 __global__ __launch_bounds__(1024, 1) void bs_resident_pair_kernel(BsPair p) {
   const int b = (int)blockIdx.x, nA = p.f[0].nown, nB = p.f[1].nown, own = nA + nB;
   int front, blk;
+  if (p.f[0].jan_parts > 0) {
+    // the XCD-spread launch: slot 0 of every eight workgroups an owner of the first front (XCD 0), slot 4 one of the second (XCD 4), slots
+    // 1-3 and 5-7 the janitors of those two block columns, a third of the block rows each
+    const int g = b >> 3, slot = b & 7;
+    front = slot >> 2;
+    const int nown = front ? nB : nA;
+    if (g >= nown) return;
+    blk = (slot & 3) == 0 ? g : nown + g * 3 + (slot & 3) - 1;
+    bs_resident_body(p.f[front], p.env[front], blk);
+    return;
+  }
   if (b < own) {
     const int m = nA < nB ? nA : nB;
     if (b < 2 * m) { front = b & 1; blk = b >> 1; } else { front = nA > nB ? 0 : 1; blk = b - m; }
@@ -2725,12 +2760,13 @@ void cholesky_backsolve(double* S, long ld, int n, int npad, int rhs_row, const 
     if (!prefilled) (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)npad, s);  // (prefilled: the caller has set the sentinels, off the critical path)
     const char* bs_stamps = dev_knobs().bs_stamps;
     if (bs_stamps) { static bool on = false; if (!on) { const int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bs_stamps_on), &one, sizeof(int)); on = true; } }
+    const bool spread = zero_after && dev_knobs().bs_spread != 0;  // (the XCD-spread launch: bs_resident_kernel)
     const int janitors = zero_after ? bs_janitors(nblk) : 0;
 #ifdef SK_TESTING
     if (janitors > 0) { int want = 1; if (g_test_janitor_giveup.compare_exchange_strong(want, 0)) { const int one = 1; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bs_test_janitor_giveup), &one, sizeof(int), 0, hipMemcpyHostToDevice, s); (void)hipStreamSynchronize(s); } }
 #endif
-    hipLaunchKernelGGL(bs_resident_kernel, dim3(nblk + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), n, y, nblk, env, info, nblk, (const double*)nullptr,
-                       janitors, (const int*)nullptr);
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(spread ? 8 * nblk : nblk + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), n, y, nblk, env, info, nblk,
+                       (const double*)nullptr, spread ? -1 : janitors, (const int*)nullptr);
     if (kt) kt->end("backsolve", s);
     if (bs_stamps) {
       (void)hipStreamSynchronize(s);
@@ -2866,8 +2902,10 @@ void cholesky_backsolve_front(double* S, long ld, int nblk, int ncols, int rhs_r
       env.tail[c] = (unsigned short)(tail ? std::min(std::max(tail[c], 0), nblk - 1) : nblk - tail_rows);
     }
     if (!prefilled) (void)hipMemsetAsync(y, 0xff, sizeof(double) * (size_t)ni, s);
+    const bool spread = zero_after && dev_knobs().bs_spread != 0;
     const int janitors = zero_after ? bs_janitors(ncols) : 0;
-    hipLaunchKernelGGL(bs_resident_kernel, dim3(ncols + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), ni, y, nblk, env, info, ncols, yb, janitors, yb_map);
+    hipLaunchKernelGGL(bs_resident_kernel, dim3(spread ? 8 * ncols : ncols + janitors), dim3(1024), 0, s, Linv, S, ld, (const double*)(S + (long)rhs_row * ld), ni, y, nblk, env, info, ncols, yb,
+                       spread ? -1 : janitors, yb_map);
     return;
   }
   // (yb_map is the resident launch's: a caller that passes one has checked cholesky_backsolve_resident and info)
@@ -2964,6 +3002,7 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
   hipStream_t sB = s;
   if (paired) {
     BsPair p;
+    const bool spread = zero_after && dev_knobs().bs_spread != 0;  // (the XCD-spread launch: bs_resident_pair_kernel)
     const FrontView* fv[2] = {&d.A, &d.B};
     double* ys[2] = {yA, yB};
     int grid = 0, jan = 0;
@@ -2973,11 +3012,13 @@ void cholesky_dissected_backsolve(const DissectedSystem& d, int n_root, double* 
         p.env[f].top[c] = (unsigned short)(F.last ? std::min(std::max(F.last[c], c), F.nblk - 1) : F.nblk - 1);
         p.env[f].tail[c] = (unsigned short)(F.tail ? std::min(std::max(F.tail[c], 0), F.nblk - 1) : F.nblk - 1);
       }
-      const int janitors = zero_after ? bs_janitors(F.ncols) : 0;
+      const int janitors = spread ? 3 * F.ncols : (zero_after ? bs_janitors(F.ncols) : 0);
       // (the tail front reads the root's solution through the map, the head as it stands: cholesky_backsolve_front below)
-      p.f[f] = BsArgs{F.Linv, F.S, F.ld, (const double*)(F.S + (long)F.rhs_row * F.ld), F.ncols * 128, ys[f], F.nblk, info, F.ncols, yR, janitors, f == 1 ? d.mapB : nullptr};
+      p.f[f] = BsArgs{F.Linv, F.S, F.ld, (const double*)(F.S + (long)F.rhs_row * F.ld), F.ncols * 128, ys[f], F.nblk, info, F.ncols, yR, janitors, f == 1 ? d.mapB : nullptr,
+                      spread ? 3 : 0, spread ? 1 : 0};
       grid += F.ncols; jan += janitors;
     }
+    if (spread) { grid = 8 * std::max(d.A.ncols, d.B.ncols); jan = 0; }
     // (one fill for the two solutions where they lie one behind the other)
     const size_t nA = (size_t)d.A.ncols * 128, nB = (size_t)d.B.ncols * 128;
     if (prefilled) {}

@@ -19,6 +19,7 @@ struct DevKnobs {
   int pair_max_trailing = 0;       // SK_CHAIN_PAIR_MAX_TRAILING=<rows>: the resident-pairs plan of round 3 (off by default; tests/pair_plan_worker.py)
   int dissect_at = -1;             // SK_DISSECT_AT=<cameras>: head size of a forced two-way dissection (0: none) — cut sweeps
   int chain_early_server = 1;  // SK_CHAIN_EARLY_SERVER=0: the potrf server's launch behind an event of the caller's stream (until round 5) instead of waiting in the kernel for chain_start_kernel
+  int bs_spread = 1;  // SK_BS_SPREAD=0: the resident back-substitution's owners on consecutive workgroups (eight XCDs in turn) and every hop through memory, as until round 5
   int bs_pair = 1;  // SK_BS_PAIR=0: the two leaf fronts' back-substitutions as two launches on two streams (until round 5) instead of one launch
   int bulk_reserve = -1, bulk_reserve_early = -1;  // SK_BULK_RESERVE=<a>[,<b>]: CUs per XCD kept free of the SYRKs on the bulk / early-bulk streams (sweeps; default 4, 2)
   int chain_xcd_local = 0;         // SK_CHAIN_XCD_LOCAL=1: the resident chain's critical hand-overs through the potrf server's XCD's L2 instead of device-scope counters (round 5: pays on one front, not on two in lock-step)
