@@ -1119,6 +1119,7 @@ int BalSolver::choose_distribution(const std::vector<int>& opt) {
     rc = gather_rank_scalars(vals, 1, ops);
     if (rc) return rc;
     est_allreduce_s_ = vals[0] / W;
+    collect_allreduce_time(true);
     phase_[5] = 0.0;  // the probe is set-up, not an iteration phase
     if (est_allreduce_s_ <= est_saved_s_) return SK_OK;  // sharding pays
   }

@@ -46,6 +46,8 @@ const char* termination_name(int t) {
 
 SolverBase::~SolverBase() {
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ar_pending_) (void)hipEventDestroy(e);
+  for (auto& e : ar_free_) (void)hipEventDestroy(e);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -71,19 +73,38 @@ int SolverBase::init_device() {
   return SK_OK;
 }
 
+// The hook runs on the solver's stream and the solver goes on enqueueing behind it: NO host synchronisation here (until round 5 every
+// collective ended in one — four per iteration of a segmented world, the device idle while the host caught up with its launches).  The
+// time of the all-reduce phase comes from event pairs that are read once they have completed (here, opportunistically, and in finish()).
+void SolverBase::collect_allreduce_time(bool all) {
+  size_t done = 0;
+  for (; done + 1 < ar_pending_.size(); done += 2) {
+    if (!all && hipEventQuery(ar_pending_[done + 1]) != hipSuccess) { (void)hipGetLastError(); break; }
+    if (all) (void)hipEventSynchronize(ar_pending_[done + 1]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ar_pending_[done], ar_pending_[done + 1]) == hipSuccess) phase_[5] += 1e-3 * ms;
+    else (void)hipGetLastError();
+    ar_free_.push_back(ar_pending_[done]); ar_free_.push_back(ar_pending_[done + 1]);
+  }
+  ar_pending_.erase(ar_pending_.begin(), ar_pending_.begin() + (long)done);
+}
+
 int SolverBase::allreduce(double* dev, size_t count) {
   if (!opt_.allreduce) return SK_OK;  // the hook decides: a world of 1 with a hook still exercises the whole path
-  hipEvent_t a = ev_[kEvCount], b = ev_[kEvCount + 1];
-  if (!a) { SK_HIP_TRY(hipEventCreate(&ev_[kEvCount])); SK_HIP_TRY(hipEventCreate(&ev_[kEvCount + 1])); a = ev_[kEvCount]; b = ev_[kEvCount + 1]; }
-  SK_HIP_TRY(hipEventRecord(a, stream_));
+  collect_allreduce_time(ar_pending_.size() >= 64);
+  hipEvent_t ab[2];
+  for (hipEvent_t& e : ab) {
+    if (!ar_free_.empty()) { e = ar_free_.back(); ar_free_.pop_back(); }
+    else SK_HIP_TRY(hipEventCreate(&e));
+  }
+  SK_HIP_TRY(hipEventRecord(ab[0], stream_));
   if (opt_.allreduce(opt_.allreduce_user, dev, count, (void*)stream_) != 0) {
+    ar_free_.push_back(ab[0]); ar_free_.push_back(ab[1]);
     set_error("allreduce hook failed");
     return SK_ERR_COMM;
   }
-  SK_HIP_TRY(hipEventRecord(b, stream_));
-  SK_HIP_TRY(hipEventSynchronize(b));
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, a, b) == hipSuccess) phase_[5] += 1e-3 * ms;
+  SK_HIP_TRY(hipEventRecord(ab[1], stream_));
+  ar_pending_.push_back(ab[0]); ar_pending_.push_back(ab[1]);
   return SK_OK;
 }
 
@@ -208,6 +229,7 @@ int SolverBase::step(bool* done) {
 int SolverBase::finish(Summary* s) {
   int rc = write_back();
   if (rc) return rc;
+  collect_allreduce_time(true);
   sum_.final_cost = cost_;
   sum_.num_successful_steps = n_success_;
   sum_.num_unsuccessful_steps = n_unsuccess_;

@@ -27,7 +27,8 @@ class SolverBase {
   virtual double syrk_c_bytes_per_solve() const { return 0.0; }  // C tiles read + written by those launches
   virtual bool stat(const std::string& name, double* value) const { (void)name; (void)value; return false; }  // sk_solver_stat
   // seconds accumulated so far in phase i (the summary's phase_seconds, readable between steps: "phase_seconds_<i>" of sk_solver_stat)
-  double phase_seconds(int i) const { return (i >= 0 && i < 6) ? phase_[i] : 0.0; }
+  // (between steps the stream is idle: the all-reduce phase takes in every collective's event pair first)
+  double phase_seconds(int i) { if (i == 5) collect_allreduce_time(true); return (i >= 0 && i < 6) ? phase_[i] : 0.0; }
   // how a world > 1 is used (SK_DISTRIBUTION_*), with the estimates behind an automatic choice
   virtual int distribution(double* allreduce_s, double* saved_s) const {
     if (allreduce_s) *allreduce_s = 0.0;
@@ -49,6 +50,8 @@ class SolverBase {
   double now() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); }
   void log_iteration(int it, double cost_change, double step_norm, double rho, int valid, int success, double iter_time);
   int allreduce(double* dev, size_t count);
+  void collect_allreduce_time(bool all);  // phase_[5] from the event pairs of collectives that have completed (all: wait for every one)
+  std::vector<hipEvent_t> ar_pending_, ar_free_;
 
   Options opt_;
   Problem* problem_;
