@@ -387,9 +387,10 @@ int sk_options_set_cholesky_border(sk_options* o, int mode);
  * max_points: at most this many — with ON: exactly this many, as far as there are tracks wider than a block — (a multiple of three is
  * used; 0: the library's limit, 1536).  Candidates: the widest tracks by span and by number of observations, and the tracks of
  * loop closures (a jump in the point's camera list) at their exact number.  A point with two residual blocks on one camera is never
- * retained.  Several ranks: with the SEGMENTED distribution only when the sequence is cut in TWO (sk_options_set_max_segments(o, 2);
- * AUTO tries that plan by itself): the pseudo-cameras are members of the one separator, a retained point's observations are split
- * over the ranks by camera.  sk_solver_stat: "retained_points", "retained_model_us", "retained_model_us_without",
+ * retained.  Several ranks: the SEGMENTED distribution takes them with any number of segments — cut in two, the pseudo-cameras are
+ * members of the one separator; cut in more, a border of the root and of every segment's front (AUTO tries two segments first and more
+ * where its model says so; sk_options_set_max_segments caps the number) — and a retained point's observations are split over the
+ * ranks by camera.  sk_solver_stat: "retained_points", "retained_model_us", "retained_model_us_without",
  * "model_us_two_segments_with_members". */
 enum { SK_RETAINED_AUTO = 0, SK_RETAINED_ON = 1, SK_RETAINED_OFF = 2 };
 int sk_options_set_retained_points(sk_options* o, int mode, int max_points);
@@ -397,7 +398,9 @@ int sk_options_set_retained_points(sk_options* o, int mode, int max_points);
  * one per GPU.  Points (e-blocks) are partitioned over ranks; the
  * normal-equation terms are summed with `allreduce` once per linear solve.
  * The hook must sum `count` doubles in device memory in place across all
- * ranks, ordered after prior work on `hip_stream`, and return 0. */
+ * ranks, ordered after prior work on `hip_stream`, and return 0.  It may return as soon as the collective is ENQUEUED on
+ * `hip_stream` (the solver goes on enqueueing behind it and synchronises only where it reads a result: no host
+ * synchronisation follows the hook since round 5); a hook that stages through the host synchronises the stream itself. */
 typedef int (*sk_allreduce_fn)(void* user, double* device_buffer, size_t count, void* hip_stream);
 int sk_options_set_distributed(sk_options* o, int rank, int world, sk_allreduce_fn allreduce,
                                void* user);
