@@ -1171,6 +1171,30 @@ int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x
   hipLaunchKernelGGL(grad_max_xnorm_kernel, dim3(g), dim3(kBlock), 0, s, gs, scale, x, n, partial, stride);
   return g;
 }
+// This rank's row of the table of scalars a world of ranks sums (BalSolver::gather_rank_scalars), formed on the device from the
+// reductions' results — zeros in the other ranks' rows — so that the all-reduce follows without a round trip through the host.
+//   mode 0 (after an evaluation): sum r^2, max |g| of what this rank accounts for, |x|^2 of it
+//   mode 1 (after a step):        sum r_new^2, model term, |delta|^2 of what this rank accounts for, failure flags
+__global__ void bal_pack_rank_scalars_kernel(const double* __restrict__ scal, double* __restrict__ table, int rank, int world, int mode, int segmented) {
+  const int K = mode == 0 ? 3 : 4;
+  for (int i = threadIdx.x; i < world * K; i += blockDim.x) table[i] = 0.0;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double* t = table + (size_t)rank * K;
+  if (mode == 0) {
+    t[0] = scal[4];
+    t[1] = segmented ? fmax(scal[2], scal[0]) : scal[2];
+    t[2] = scal[3] + (segmented ? scal[1] : 0.0);
+  } else {
+    const int fail = *reinterpret_cast<const int*>(scal + 14), info = *reinterpret_cast<const int*>(scal + 15);
+    t[0] = scal[0]; t[1] = scal[1];
+    t[2] = scal[9] + (segmented ? scal[8] : 0.0);
+    t[3] = (double)(fail | info);
+  }
+}
+void launch_bal_pack_rank_scalars(const double* scal, double* table, int rank, int world, int mode, bool segmented, hipStream_t s) {
+  hipLaunchKernelGGL(bal_pack_rank_scalars_kernel, dim3(1), dim3(64), 0, s, scal, table, rank, world, mode, segmented ? 1 : 0);
+}
 void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s) { hipLaunchKernelGGL(final_reduce_kernel, dim3(K), dim3(kBlock), 0, s, partial, stride, count, K, maxmask, out); }
 void launch_bal_point_block(const BalDev& d, hipStream_t s) { if (d.P > 0) hipLaunchKernelGGL(bal_point_block_kernel, dim3(point_grid(d.P)), dim3(kBlock), 0, s, d); }
 void launch_bal_kept_points(const BalDev& d, hipStream_t s) {

@@ -131,6 +131,7 @@ void launch_apply_scale_to_reductions(double* colsq, double* gs, const double* s
 void launch_lm_diagonal(const double* colsq, double* D, int n, double lo, double hi, double radius, hipStream_t s);
 int launch_grad_max_xnorm(const double* gs, const double* scale, const double* x, int n, double* partial, int stride, hipStream_t s);
 void launch_final_reduce(const double* partial, int stride, int count, int K, int maxmask, double* out, hipStream_t s);
+void launch_bal_pack_rank_scalars(const double* scal, double* table, int rank, int world, int mode, bool segmented, hipStream_t s);  // (bal_pack_rank_scalars_kernel)
 struct ReduceRows { int n = 0; int row[4] = {0, 0, 0, 0}, count[4] = {0, 0, 0, 0}, is_max[4] = {0, 0, 0, 0}; double* out[4] = {nullptr, nullptr, nullptr, nullptr}; };
 void launch_final_reduce_rows(const double* partial, int stride, const ReduceRows& rows, hipStream_t s);  // up to four reductions of different lengths, one launch
 void launch_bal_point_block(const BalDev& d, hipStream_t s);

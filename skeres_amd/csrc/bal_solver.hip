@@ -256,6 +256,9 @@ class BalSolver : public SolverBase {
   DevBuf<double> b_host_rows_;
   std::vector<int> h_cam_, h_pt_;             // camera / local point of every local observation (host copy, for the callbacks)
   int gather_rank_scalars_signed(double* vals, int K);
+  bool rank_table_on_device(int K) const;
+  int enqueue_rank_table(int mode, int K);
+  int fold_rank_table(double* vals, int K, const int* ops);
 
   int C_ = 0, P_total_ = 0, P_ = 0, N_ = 0;   // cameras, all points, local points, local observations
   int res_size_ = 2, cam_size_ = 9, pt_size_ = 3;  // the problem's own (r; c, q) (bal_block_shape): padded to (2; 9, 3) inside
@@ -1977,6 +1980,28 @@ int BalSolver::setup() {
 }
 
 // max over ranks of each value (values of either sign)
+// The same table formed on the DEVICE (bal_pack_rank_scalars_kernel), summed and copied to pinned host memory behind whatever the
+// stream holds — the caller synchronises once and folds.  For worlds whose table fits the pinned scalars' spare room.
+bool BalSolver::rank_table_on_device(int K) const { return opt_.allreduce != nullptr && opt_.world > 1 && opt_.world * K <= 24; }
+int BalSolver::enqueue_rank_table(int mode, int K) {
+  double* dev = b_small_.p + 2 * 9 * (size_t)C_ + 6 * retained_pts_.size() + 64;
+  launch_bal_pack_rank_scalars(b_scal_.p, dev, opt_.rank, opt_.world, mode, segmented_, stream_);
+  int rc = allreduce(dev, (size_t)opt_.world * K);
+  if (rc) return rc;
+  SK_HIP_TRY(hipMemcpyAsync(h_scal_ + 36, dev, (size_t)opt_.world * K * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  return SK_OK;
+}
+int BalSolver::fold_rank_table(double* vals, int K, const int* ops) {
+  const int W = opt_.world;
+  const double* table = h_scal_ + 36;
+  const int fold = fold_world_ > 0 ? std::min(fold_world_, W) : W;
+  for (int k = 0; k < K; ++k) {
+    double a = 0.0;
+    for (int r = 0; r < fold; ++r) a = ops[k] ? std::max(a, table[(size_t)r * K + k]) : a + table[(size_t)r * K + k];
+    vals[k] = a;
+  }
+  return SK_OK;
+}
 int BalSolver::gather_rank_scalars_signed(double* vals, int K) {
   const int W = opt_.world;
   std::vector<double> table((size_t)W * K, 0.0);
@@ -2100,13 +2125,17 @@ int BalSolver::evaluate_with_jacobian(bool first) {
     SK_HIP_TRY(hipGraphLaunch(g_eval_[parity_], s));
   }
   SK_HIP_TRY(hipEventRecord(ev_[kEvJac], s));
+  // a world of ranks: the table of the ranks' scalars is formed on the device and summed BEFORE the one host synchronisation (round 5;
+  // until then: synchronise, pack on the host, copy up, all-reduce, copy down, synchronise again)
+  const bool dev_gather = rank_table_on_device(3) && !graph;
+  if (dev_gather) { int rc = enqueue_rank_table(0, 3); if (rc) return rc; }
   SK_HIP_TRY(hipStreamSynchronize(s));
   const double sumsq = h_scal_[4];
   const double gmax_c = h_scal_[0], x2_c = h_scal_[1];
   // local: sum r^2, max |g_p|, |x_p|^2 — and in a segmented world this rank's cameras' share of max |g_c| and |x_c|^2 too
   double loc[3] = {sumsq, segmented_ ? std::max(h_scal_[2], gmax_c) : h_scal_[2], h_scal_[3] + (segmented_ ? x2_c : 0.0)};
   const int ops3[3] = {0, 1, 0};
-  int rc = gather_rank_scalars(loc, 3, ops3);
+  int rc = dev_gather ? fold_rank_table(loc, 3, ops3) : gather_rank_scalars(loc, 3, ops3);
   if (rc) return rc;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, ev_[kEvBegin], ev_[kEvJac]) == hipSuccess) phase_[0] += 1e-3 * ms;
@@ -2263,6 +2292,8 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   if (!graph) SK_HIP_TRY(hipEventRecord(ev_[kEvCost], s));
   SK_HIP_TRY(hipMemcpyAsync(h_scal_, b_scal_.p, 16 * sizeof(double), hipMemcpyDeviceToHost, s));  // scalars 0-9, the two flags in 14 and 15
   }
+  const bool dev_gather = rank_table_on_device(4) && !graph;  // (see evaluate_with_jacobian)
+  if (dev_gather) { int rc = enqueue_rank_table(1, 4); if (rc) return rc; }
   if (graph) {
     if (!replay) { capture.release(); int rc = finish_capture(s, &g_step_[parity_]); if (rc) return rc; if (!graph_mode_) return try_step_once(radius, valid, mcc, new_cost, step_norm, chain_lost); }
     SK_HIP_TRY(hipGraphLaunch(g_step_[parity_], s));
@@ -2294,7 +2325,7 @@ int BalSolver::try_step_once(double radius, bool* valid, double* mcc, double* ne
   // sum r_new^2, model term, |delta_p|^2 (segmented: + this rank's cameras' |delta_c|^2, which no other rank has), failure
   double loc[4] = {h_scal_[0], h_scal_[1], h_scal_[9] + (segmented_ ? h_scal_[8] : 0.0), (double)(fail | info)};
   const int ops4[4] = {0, 0, 0, 1};
-  int rc = gather_rank_scalars(loc, 4, ops4);
+  int rc = dev_gather ? fold_rank_table(loc, 4, ops4) : gather_rank_scalars(loc, 4, ops4);
   if (rc) return rc;
   if (opt_.allreduce && loc[3] >= 2.0) cholesky_disable_chain(&chol_ctx_);  // a rank's chain timed out (info == 2): launch by launch on every rank from here on
   const double step_sq = (segmented_ ? 0.0 : h_scal_[8]) + loc[2];
