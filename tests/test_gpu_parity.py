@@ -1528,6 +1528,29 @@ def test_sharded_solve_on_one_gpu_with_a_real_exchange(world, mode, shape=None, 
     assert "DIST_GPU2_OK world=%d" % world in out.stdout
 
 
+def test_event_forms_and_event_free_forms_are_the_same_arithmetic():
+    """Round 5 took the cross-queue events out of the chain's starts and joins (the potrf server waits in the kernel for a start signal,
+    the join is a counter of end markers polled by one wave), made the two leaf fronts' back-substitutions one launch and spread its
+    owners over the XCDs by role, and adds the two borders to the root in one launch.  None of it changes an operation or its order: the
+    same solve in four fresh processes — the default forms, and each of SK_CHAIN_EARLY_SERVER / SK_BS_PAIR / SK_BS_SPREAD at 0 (the
+    forms of round 4) — gives the same costs and the same parameters, bit for bit (tests/knob_forms_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for name, env in (("default", {}), ("events", {"SK_CHAIN_EARLY_SERVER": "0"}), ("two_launches", {"SK_BS_PAIR": "0"}), ("consecutive_owners", {"SK_BS_SPREAD": "0"}),
+                      ("round_4", {"SK_CHAIN_EARLY_SERVER": "0", "SK_BS_PAIR": "0", "SK_BS_SPREAD": "0"})):
+        out = subprocess.run([sys.executable, os.path.join(root, "tests", "knob_forms_worker.py")], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("FORMS ")]
+        assert line, out.stdout[-2000:]
+        lines[name] = line[-1]
+    assert "dissected=1" in lines["default"] and "resident=0" not in lines["default"], lines["default"]  # (the forms in question are the ones that run)
+    for name, line in lines.items():
+        assert line == lines["default"], (name, line, lines["default"])
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_segmented_world_cut_in_two_with_retained_points_in_the_separator(world):
     """Round-4 verdict, item 3: retained points no longer rule the segmented distribution out.  The camera sequence is cut in TWO

@@ -39,10 +39,15 @@ def main():
     s = sk.StepSolver(o, problem)
     for _ in range(4):
         s.step()
-    for f in (path + ".pair", path):  # (a lock-step dissection: the two leaf fronts, then the root)
-        if os.path.exists(f):
-            report(np.loadtxt(f))
-            os.remove(f)
+    files = [f for f in (path + ".pair", path) if os.path.exists(f)]  # (a lock-step dissection: the two leaf fronts, then the root)
+    raws = [np.loadtxt(f) for f in files]
+    origin = min(r[:, 1].min() for r in raws)
+    for f, r in zip(files, raws):
+        report(r)
+        # (one clock for all of them: where a factorisation's chain begins and ends against the other's)
+        print("on the common clock: first potrf start %+.1f us, last potrf done %+.1f us, last tile done %+.1f us\n"
+              % ((r[:, 1].min() - origin) * 0.01, (r[:, 2].max() - origin) * 0.01, (r[:, 7].max() - origin) * 0.01))
+        os.remove(f)
 
 
 def report(raw):
