@@ -6,6 +6,9 @@
 // are partitioned over ranks, cameras are replicated, and the reduced system
 // is summed with one all-reduce per linear solve.
 #include <algorithm>
+#include <atomic>
+#include <map>
+#include <thread>
 #include <cmath>
 #include <limits>
 #include <numeric>
@@ -639,18 +642,37 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
 
 static std::vector<int> rcm_order(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P) {
   // co-visibility graph, thinned: the cameras of a point are chained in index order and the ends joined
-  std::vector<std::vector<int>> of_point(P);
-  for (size_t b = 0; b < ocam.size(); ++b) of_point[opt[b]].push_back(ocam[b]);
-  std::vector<std::pair<int, int>> edges;
-  for (auto& v : of_point) {
-    std::sort(v.begin(), v.end());
-    for (size_t i = 0; i + 1 < v.size(); ++i) edges.emplace_back(v[i], v[i + 1]);
-    if (v.size() > 2) edges.emplace_back(v.front(), v.back());
-  }
-  std::sort(edges.begin(), edges.end());
-  edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+  // (the cameras of every point as flat sorted lists — a counting sort and one small sort per point)
+  std::vector<int> pstart((size_t)P + 1, 0), pcam(ocam.size());
+  for (int q : opt) pstart[(size_t)q + 1]++;
+  for (int q = 0; q < P; ++q) pstart[(size_t)q + 1] += pstart[(size_t)q];
+  { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (size_t b = 0; b < ocam.size(); ++b) pcam[(size_t)fill[(size_t)opt[b]]++] = ocam[b]; }
+  for (int q = 0; q < P; ++q) std::sort(pcam.begin() + pstart[(size_t)q], pcam.begin() + pstart[(size_t)q + 1]);
   std::vector<std::vector<int>> adj(C);
-  for (auto& e : edges) if (e.first != e.second) { adj[e.first].push_back(e.second); adj[e.second].push_back(e.first); }
+  if (C <= 16384) {
+    // the edge set as a bit matrix (32 MB at 16384 cameras): no list of a few hundred thousand pairs to sort and to thin out
+    const size_t words = ((size_t)C + 63) / 64;
+    std::vector<unsigned long long> bits((size_t)C * words, 0ull);
+    auto edge = [&](int a, int b) { if (a != b) { bits[(size_t)a * words + (size_t)b / 64] |= 1ull << (b % 64); bits[(size_t)b * words + (size_t)a / 64] |= 1ull << (a % 64); } };
+    for (int q = 0; q < P; ++q) {
+      const int a = pstart[(size_t)q], e = pstart[(size_t)q + 1];
+      for (int k = a; k + 1 < e; ++k) edge(pcam[(size_t)k], pcam[(size_t)k + 1]);
+      if (e - a > 2) edge(pcam[(size_t)a], pcam[(size_t)e - 1]);
+    }
+    for (int u = 0; u < C; ++u)
+      for (size_t w = 0; w < words; ++w)
+        for (unsigned long long m = bits[(size_t)u * words + w]; m; m &= m - 1) adj[(size_t)u].push_back((int)(w * 64) + __builtin_ctzll(m));
+  } else {
+    std::vector<std::pair<int, int>> edges;
+    for (int q = 0; q < P; ++q) {
+      const int a = pstart[(size_t)q], e = pstart[(size_t)q + 1];
+      for (int k = a; k + 1 < e; ++k) edges.emplace_back(pcam[(size_t)k], pcam[(size_t)k + 1]);
+      if (e - a > 2) edges.emplace_back(pcam[(size_t)a], pcam[(size_t)e - 1]);
+    }
+    std::sort(edges.begin(), edges.end());
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    for (auto& e : edges) if (e.first != e.second) { adj[e.first].push_back(e.second); adj[e.second].push_back(e.first); }
+  }
   for (auto& a : adj) std::sort(a.begin(), a.end(), [&](int x, int y) { return adj[x].size() != adj[y].size() ? adj[x].size() < adj[y].size() : x < y; });
   std::vector<int> order, level(C, -1);
   order.reserve(C);
@@ -713,6 +735,28 @@ static void choose_camera_order(const std::vector<std::vector<int>>& cand, const
   *best_flops = best;
 }
 
+// f(i) for i in [0, n) on up to twelve host threads (the caller's among them).  The planner's candidates — each a handful of passes over every
+// observation — are independent of each other; which one is taken is decided afterwards, in the candidates' own order, so the plan does not
+// depend on the number of threads (round 5: the plan of the reduced system was 0.7 s of Ladybug-1723's 0.8 s of set-up, 8 s of Venice-1778's 9).
+static std::atomic<int> g_plan_helpers{0};  // helper threads of the planner alive in this process (nested calls share one budget)
+template <class F>
+static void plan_parallel_for(int n, F f) {
+  const int budget = std::min(12, std::max(1, (int)std::thread::hardware_concurrency())) - 1;
+  int helpers = 0;
+  while (helpers < n - 1) {  // (claim helper threads one by one, as far as the budget goes)
+    int cur = g_plan_helpers.load();
+    if (cur >= budget) break;
+    if (g_plan_helpers.compare_exchange_weak(cur, cur + 1)) ++helpers;
+  }
+  if (helpers == 0) { for (int i = 0; i < n; ++i) f(i); return; }
+  std::atomic<int> next{0};
+  auto work = [&] { for (int i; (i = next.fetch_add(1)) < n;) f(i); };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < helpers; ++t) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
+  g_plan_helpers.fetch_sub(helpers);
+}
 // ---- loop closures: the cameras that revisit a place, ordered into a trailing BORDER (round 4) ------------------------------
 // A camera sequence that comes back to a street it has seen couples two distant windows of the band: in the band's own
 // order every block column between the two windows is dragged into the envelope (a handful of such tracks fill it: 0.37 ->
@@ -753,20 +797,46 @@ static void point_camera_lists(const CamGraph& g, std::vector<int>* pstart, std:
   { std::vector<int> fill(pstart->begin(), pstart->end() - 1); for (size_t b = 0; b < g.ocam->size(); ++b) (*pcam)[fill[(*g.opt)[b]]++] = (*g.ocam)[b]; }
   for (int q = 0; q < g.P; ++q) std::sort(pcam->begin() + (*pstart)[q], pcam->begin() + (*pstart)[q + 1]);
 }
+// The cameras of every point as lists (point_camera_lists) — what choose_border works on.  A caller that scores many variants of one
+// graph (choose_retained_points: the same observations with a few points taken out) forms them once and derives each variant's
+// by copying, instead of a counting sort and 150 000 small sorts per variant.
+struct PointLists { std::vector<int> start, cam; };
+// first_col of envelope_of_order from the lists: block row of every camera of a point <- the block column of the point's first camera
+static void first_cols_from_lists(const std::vector<int>& start, const std::vector<int>& cam, const std::vector<int>& new_id, int nblk, std::vector<int>* first_col) {
+  first_col->resize((size_t)nblk);
+  for (int i = 0; i < nblk; ++i) (*first_col)[(size_t)i] = i;
+  const int P = (int)start.size() - 1;
+  for (int q = 0; q < P; ++q) {
+    const int a = start[(size_t)q], e = start[(size_t)q + 1];
+    if (a == e) continue;
+    int mn = new_id[(size_t)cam[(size_t)a]];
+    for (int k = a + 1; k < e; ++k) mn = std::min(mn, new_id[(size_t)cam[(size_t)k]]);
+    const int col = (9 * mn) / 128;
+    for (int k = a; k < e; ++k) {
+      const int c = new_id[(size_t)cam[(size_t)k]];
+      for (int row = (9 * c) / 128; row <= (9 * c + 8) / 128; ++row) (*first_col)[(size_t)row] = std::min((*first_col)[(size_t)row], col);
+    }
+  }
+}
 // g, x: cameras in the banded numbering (pseudo-cameras behind the real ones).  mode: SK_BORDER_AUTO (the model decides) / SK_BORDER_ON
 // (the best candidate whatever the model says).  gaps_ok: loop-closure cameras may go to the border; pseudo-cameras always do, and with
 // them a border is always returned (plain_us is then the model of the border of pseudo-cameras alone).
-static bool choose_border(const CamGraph& g, const CamGraph& x, int nblk, const std::vector<int>& plain_last, int mode, bool gaps_ok, BorderChoice* out) {
+// gl, xl (optional): the lists of g and of x, formed by the caller — g.ocam / x.ocam may then be null (the lists are all that is read).
+static bool choose_border(const CamGraph& g, const CamGraph& x, int nblk, const std::vector<int>& plain_last, int mode, bool gaps_ok, BorderChoice* out,
+                          const PointLists* gl = nullptr, const PointLists* xl = nullptr) {
   const int C = g.C, Cx = x.C;
   const bool forced = Cx > C;
   out->plain_us = forced ? 0.0 : envelope_model_us(nblk, plain_last, nullptr);
   if (!forced && (C < 8 || !gaps_ok)) return false;
   // cameras of every point, ascending
-  std::vector<int> pstart, pcam, xstart_s, xcam_s;
-  point_camera_lists(g, &pstart, &pcam);
-  if (forced) point_camera_lists(x, &xstart_s, &xcam_s);
-  const std::vector<int>& xstart = forced ? xstart_s : pstart;
-  const std::vector<int>& xcam = forced ? xcam_s : pcam;
+  std::vector<int> pstart_s, pcam_s, xstart_s, xcam_s;
+  if (!gl) point_camera_lists(g, &pstart_s, &pcam_s);
+  if (forced && !xl) point_camera_lists(x, &xstart_s, &xcam_s);
+  const std::vector<int>& pstart = gl ? gl->start : pstart_s;
+  const std::vector<int>& pcam = gl ? gl->cam : pcam_s;
+  const std::vector<int>& xstart = forced ? (xl ? xl->start : xstart_s) : pstart;
+  const std::vector<int>& xcam = forced ? (xl ? xl->cam : xcam_s) : pcam;
+  const int xP = (int)xstart.size() - 1;  // (== x.P)
   int max_jump = 0;
   for (int q = 0; q < g.P; ++q)
     for (int k = pstart[q] + 1; k < pstart[q + 1]; ++k) max_jump = std::max(max_jump, pcam[k] - pcam[k - 1]);
@@ -781,7 +851,7 @@ static bool choose_border(const CamGraph& g, const CamGraph& x, int nblk, const 
     int Cb = 0;
     for (int c = 0; c < Cx; ++c) if (!mark[c]) band_id[c] = Cb++;
     std::vector<int> first_band(Cx, Cx);
-    for (int q = 0; q < x.P; ++q) {
+    for (int q = 0; q < xP; ++q) {
       int mn = Cx;
       for (int k = xstart[q]; k < xstart[q + 1]; ++k) if (!mark[xcam[k]]) { mn = band_id[xcam[k]]; break; }
       for (int k = xstart[q]; k < xstart[q + 1]; ++k) if (mark[xcam[k]]) first_band[xcam[k]] = std::min(first_band[xcam[k]], mn);
@@ -792,7 +862,8 @@ static bool choose_border(const CamGraph& g, const CamGraph& x, int nblk, const 
     cand->new_id = band_id;
     for (size_t k = 0; k < border.size(); ++k) cand->new_id[border[k]] = Cb + (int)k;
     std::vector<int> first_col;
-    (void)envelope_of_order(*x.ocam, *x.opt, cand->new_id, Cx, x.P, nblk, &first_col);
+    if (xl || (gl && !forced)) first_cols_from_lists(xstart, xcam, cand->new_id, nblk, &first_col);  // (the same minima as envelope_of_order's, point by point)
+    else (void)envelope_of_order(*x.ocam, *x.opt, cand->new_id, Cx, x.P, nblk, &first_col);
     cholesky_envelope_bordered(first_col, (9 * Cb) / 128, &cand->last, &cand->tail);
     cand->model_us = envelope_model_us(nblk, cand->last, cand->tail.data());
     cand->border_cams = nb; cand->gap = gap; cand->variant = variant;
@@ -807,6 +878,10 @@ static bool choose_border(const CamGraph& g, const CamGraph& x, int nblk, const 
     *out = cand; found = true;
     best = mode == SK_BORDER_ON ? cand.model_us : 0.9 * cand.model_us;  // (loop-closure cameras on top of the pseudo-cameras: when the model gains another 10 %)
   }
+  // the candidates (gap, variant): their marks first — cheap, and a candidate whose marks repeat the one before it is dropped — then their
+  // envelopes side by side on host threads (plan_parallel_for), then the choice, in the candidates' order
+  struct GapCand { int gap, variant, nb; std::vector<char> mark; BorderChoice bc; };
+  std::vector<GapCand> gc;
   std::vector<char> prev_mark;
   for (int gap = 4; gaps_ok && C >= 8 && gap < C && gap < max_jump; gap *= 2) {
     for (int variant = 0; variant < 2; ++variant) {
@@ -827,11 +902,13 @@ static bool choose_border(const CamGraph& g, const CamGraph& x, int nblk, const 
       if (nb == 0 || nb > C / 4 || C - nb < 4) continue;   // (a border that wide is no border: its dense system would be the factorisation)
       if (mark == prev_mark) continue;
       prev_mark = mark;
-      BorderChoice cand;
-      candidate(mark, nb, gap, variant, &cand);
-      cand.plain_us = out->plain_us;
-      if (cand.model_us < best) { best = cand.model_us; *out = cand; found = true; }
+      gc.push_back(GapCand{gap, variant, nb, std::move(mark), BorderChoice()});
     }
+  }
+  plan_parallel_for((int)gc.size(), [&](int i) { candidate(gc[(size_t)i].mark, gc[(size_t)i].nb, gc[(size_t)i].gap, gc[(size_t)i].variant, &gc[(size_t)i].bc); });
+  for (GapCand& c : gc) {
+    c.bc.plain_us = out->plain_us;
+    if (c.bc.model_us < best) { best = c.bc.model_us; *out = c.bc; found = true; }
   }
   return found;
 }
@@ -841,6 +918,7 @@ static bool choose_border(const CamGraph& g, const CamGraph& x, int nblk, const 
 struct CameraOrderPlan {
   std::vector<int> id;           // first-appearance numbering -> final numbering (pseudo-cameras of retained points: indices >= the real cameras')
   std::vector<int> plain_id;     // ... of the best candidate as it stands (real cameras only; what the retained points are chosen on)
+  std::vector<std::vector<int>> candidates;  // the candidate orders this plan was chosen from (camera_order_candidates of g)
   std::vector<int> last, tail;   // the envelope of the reduced system in that numbering (tail: empty unless bordered)
   int candidate = 0;             // 0 first appearance, 1 memory order, 2 RCM
   bool bordered = false;
@@ -863,16 +941,24 @@ static CameraOrderPlan plan_camera_order(const Problem& p, const std::vector<int
   if (border_ok || forced) {
     // every candidate order may hide a band behind a few revisits: the border is tried on each, the chain model compares
     double best_us = 0.0;
-    for (size_t k = 0; k < cand.size(); ++k) {
-      if (k == 1 && !with_memory_order) continue;  // (the slot repeats candidate 0)
+    // (the candidates' borders side by side on host threads; which one is taken: in the candidates' order, below)
+    std::vector<BorderChoice> bcs(cand.size());
+    std::vector<char> bc_ok(cand.size(), 0);
+    plan_parallel_for((int)cand.size(), [&](int ki) {
+      const size_t k = (size_t)ki;
+      if (k == 1 && !with_memory_order) return;  // (the slot repeats candidate 0)
       std::vector<int> oc(g.ocam->size()), ocx;
       for (size_t b = 0; b < oc.size(); ++b) oc[b] = cand[k][(*g.ocam)[b]];
       if (forced) { ocx.resize(x.ocam->size()); for (size_t b = 0; b < ocx.size(); ++b) { const int c = (*x.ocam)[b]; ocx[b] = c < C ? cand[k][c] : c; } }
       const CamGraph gk{&oc, g.opt, C, g.P}, xk{forced ? &ocx : &oc, x.opt, Cx, x.P};
       std::vector<int> plain;
       if (!forced) plain = (int)k == best_k ? best_env : envelope_of_order(*g.ocam, *g.opt, cand[k], C, g.P, nblk);
-      BorderChoice bc;
-      if (!choose_border(gk, xk, nblk, plain, border_mode, border_ok, &bc)) continue;
+      bc_ok[k] = choose_border(gk, xk, nblk, plain, border_mode, border_ok, &bcs[k]) ? 1 : 0;
+    });
+    for (size_t k = 0; k < cand.size(); ++k) {
+      if (k == 1 && !with_memory_order) continue;
+      if (!bc_ok[k]) continue;
+      const BorderChoice& bc = bcs[k];
       if (!out.bordered || bc.model_us < best_us) {
         best_us = bc.model_us; out.bordered = true; out.candidate = (int)k;
         out.border = bc;
@@ -886,6 +972,7 @@ static CameraOrderPlan plan_camera_order(const Problem& p, const std::vector<int
     }
   }
   if (!forced) { out.border.plain_us = envelope_model_us(nblk, best_env, nullptr); out.plain_id = cand[best_k]; }
+  out.candidates = cand;
   if (out.bordered) {
     out.id = out.border.new_id; out.last = out.border.last; out.tail = out.border.tail;
     out.flops = cholesky_syrk_flops(npad, 1, out.last.data(), false, nullptr, -1, 1, out.tail.data());
@@ -927,6 +1014,7 @@ static RetainedGraphs retained_graphs(const std::vector<int>& ocam, const std::v
   std::vector<int> slot(P, -1);
   for (size_t s = 0; s < points.size(); ++s) slot[points[s]] = (int)s;
   r.Cx = C + ((int)points.size() + 2) / 3; r.Px = P;
+  r.ocam_g.reserve(ocam.size()); r.opt_g.reserve(ocam.size()); r.ocam_x.reserve(ocam.size() + ocam.size() / 8); r.opt_x.reserve(ocam.size() + ocam.size() / 8);
   for (size_t b = 0; b < ocam.size(); ++b) {
     const int s = slot[opt[b]];
     if (s < 0) { r.ocam_g.push_back(ocam[b]); r.opt_g.push_back(opt[b]); r.ocam_x.push_back(ocam[b]); r.opt_x.push_back(opt[b]); continue; }
@@ -962,6 +1050,65 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
   // Two orders of the candidates: by the span of their cameras (whatever widens the envelope: landmarks AND the tracks of loop
   // closures, which a border of retained points can take as well as a border of cameras can), and by the number of their
   // observations (the landmarks alone — the loop closures are then left to the border of cameras, when the problem has both)
+  // One candidate set of points -> the chain model of the plan with them retained (a border of their pseudo-cameras, loop-closure cameras on top
+  // where that pays).  Memoised, and evaluated a few candidates AHEAD in parallel: the loops below take them in their own order.
+  struct Scored { bool ok = false; double model_us = 0.0; };
+  std::map<std::vector<int>, Scored> scored;  // (key: the set, sorted)
+  // the cameras of every point, once; a candidate's graphs are these lists with the retained points' taken out (g) and, behind them, a point
+  // of two cameras — the observation's and the retained point's pseudo-camera — for every observation of a retained point (x: retained_graphs)
+  PointLists base;
+  { const CamGraph g0{&ocam, &opt, C, P}; point_camera_lists(g0, &base.start, &base.cam); }
+  auto lists_with = [&](const std::vector<int>& pts, PointLists* l, int* Cx, int* Px) {
+    std::vector<int> slot((size_t)P, -1);
+    for (size_t k = 0; k < pts.size(); ++k) slot[(size_t)pts[k]] = (int)k;
+    int extra = 0;
+    for (int q : pts) extra += base.start[(size_t)q + 1] - base.start[(size_t)q];
+    *Cx = C + ((int)pts.size() + 2) / 3; *Px = P + extra;
+    l->start.assign((size_t)*Px + 1, 0);
+    l->cam.clear(); l->cam.reserve(base.cam.size() + (size_t)extra);
+    for (int q = 0; q < P; ++q) {
+      if (slot[(size_t)q] < 0) l->cam.insert(l->cam.end(), base.cam.begin() + base.start[(size_t)q], base.cam.begin() + base.start[(size_t)q + 1]);
+      l->start[(size_t)q + 1] = (int)l->cam.size();
+    }
+    int np = P;
+    for (int q : pts)
+      for (int k = base.start[(size_t)q]; k < base.start[(size_t)q + 1]; ++k) {
+        l->cam.push_back(base.cam[(size_t)k]); l->cam.push_back(C + slot[(size_t)q] / 3);
+        l->start[(size_t)++np] = (int)l->cam.size();
+      }
+  };
+  auto key_of = [](const std::vector<int>& pts) { std::vector<int> k(pts); std::sort(k.begin(), k.end()); return k; };
+  auto score_ahead = [&](const std::vector<std::vector<int>>& sets) {
+    std::vector<const std::vector<int>*> todo;
+    std::vector<std::vector<int>> keys;
+    for (const std::vector<int>& pts : sets) {
+      std::vector<int> k = key_of(pts);
+      if (scored.count(k) || std::find(keys.begin(), keys.end(), k) != keys.end()) continue;
+      keys.push_back(std::move(k)); todo.push_back(&pts);
+    }
+    std::vector<Scored> res(todo.size());
+    plan_parallel_for((int)todo.size(), [&](int i) {
+      PointLists l;
+      int Cx = 0, Px = 0;
+      lists_with(*todo[i], &l, &Cx, &Px);
+      const int nblk = (9 * Cx + 1 + 127) / 128;
+      BorderChoice bc;
+      // (g's lists are the first P of x's: one object serves as both)
+      res[i].ok = choose_border(CamGraph{nullptr, nullptr, C, P}, CamGraph{nullptr, nullptr, Cx, Px}, nblk, {}, SK_BORDER_AUTO, gaps_ok, &bc, &l, &l);
+      res[i].model_us = bc.model_us;
+    });
+    for (size_t i = 0; i < todo.size(); ++i) scored[keys[i]] = res[i];
+  };
+  auto score = [&](const std::vector<int>& pts) { std::vector<int> k = key_of(pts); if (!scored.count(k)) score_ahead({pts}); return scored[k]; };
+  // the candidate sets of one order of the wide tracks, in doubling counts
+  auto sets_of_order = [&](std::vector<std::vector<int>>* sets) {
+    for (int R = exactly ? std::max(3, max_points) : 3; R <= max_points; R = R < 6 ? 6 : 2 * R) {
+      std::vector<int> pts(wide.begin(), wide.begin() + R);
+      // pseudo-cameras in the order the border wants them: the points reached first come last
+      std::sort(pts.begin(), pts.end(), [&](int a, int b) { return cmin[a] != cmin[b] ? cmin[a] > cmin[b] : a < b; });
+      sets->push_back(std::move(pts));
+    }
+  };
   std::vector<std::vector<int>> seen_sets;
   for (int by_count = 0; (families & 1) && by_count < (exactly ? 1 : 2); ++by_count) {
     std::sort(wide.begin(), wide.end(), [&](int a, int b) {
@@ -969,17 +1116,19 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
       return sa != sb ? sa > sb : a < b;
     });
     double best_here = std::numeric_limits<double>::max();
-    for (int R = exactly ? std::max(3, max_points) : 3; R <= max_points; R = R < 6 ? 6 : 2 * R) {
-      std::vector<int> pts(wide.begin(), wide.begin() + R);
-      // pseudo-cameras in the order the border wants them: the points reached first come last
-      std::sort(pts.begin(), pts.end(), [&](int a, int b) { return cmin[a] != cmin[b] ? cmin[a] > cmin[b] : a < b; });
+    std::vector<std::vector<int>> sets;
+    sets_of_order(&sets);
+    for (size_t si = 0; si < sets.size(); ++si) {
+      const std::vector<int>& pts = sets[si];
+      const int R = (int)pts.size();
       // (the same set of points under the other order — the landmarks are usually the widest tracks by either measure — is not planned twice:
       // a candidate of Venice-1778's size costs most of a second)
-      { std::vector<int> key(pts); std::sort(key.begin(), key.end()); if (std::find(seen_sets.begin(), seen_sets.end(), key) != seen_sets.end()) continue; seen_sets.push_back(key); }
-      const RetainedGraphs rg = retained_graphs(ocam, opt, C, P, pts);
-      const int nblk = (9 * rg.Cx + 1 + 127) / 128;
-      BorderChoice bc;
-      if (!choose_border(rg.g(C, P), rg.x(), nblk, {}, SK_BORDER_AUTO, gaps_ok, &bc)) continue;
+      { std::vector<int> key = key_of(pts); if (std::find(seen_sets.begin(), seen_sets.end(), key) != seen_sets.end()) continue; seen_sets.push_back(key); }
+      // (this candidate and the next three: the loop usually ends — 25 % past its best — within a few counts of where it is)
+      if (!scored.count(key_of(pts))) score_ahead(std::vector<std::vector<int>>(sets.begin() + (long)si, sets.begin() + (long)std::min(sets.size(), si + 4)));
+      const Scored sc = score(pts);
+      if (!sc.ok) continue;
+      struct { double model_us; } bc{sc.model_us};
       if (dev_knobs().debug_envelope) std::fprintf(stderr, "[skeres_amd] retained candidates: the %d widest tracks by %s: chain model %.0f us (best so far %.0f, base %.0f)\n", R, by_count ? "observations" : "span", bc.model_us, best, base_us);
       // (a LARGER set has to beat a smaller one by 1 %: the model is no finer than that, and every retained point is three more rows that
       // every later column carries.  Ladybug-1723, one box, Cholesky phase per iteration with 6 / 12 / 24 points retained: 4.06 / 3.82 /
@@ -995,14 +1144,11 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
   // whose rows keep the envelope full until the last one of them is retained (768 points: nothing gained) and cost twice their rows at
   // the next count (1536); retained exactly — 19 block rows of border — the band keeps its own width.
   if (!exactly && C >= 64 && (families & 2)) {
-    std::vector<int> pstart(P + 1, 0), pcam(ocam.size());
-    for (int q : opt) pstart[q + 1]++;
-    for (int q = 0; q < P; ++q) pstart[q + 1] += pstart[q];
-    { std::vector<int> fill(pstart.begin(), pstart.end() - 1); for (size_t b = 0; b < ocam.size(); ++b) pcam[fill[opt[b]]++] = ocam[b]; }
+    const std::vector<int>& pstart = base.start;  // (the cameras of every point, ascending: formed above)
+    const std::vector<int>& pcam = base.cam;
     std::vector<int> jump(P, 0);
     int max_jump = 0;
     for (int q = 0; q < P; ++q) {
-      std::sort(pcam.begin() + pstart[q], pcam.begin() + pstart[q + 1]);
       for (int k = pstart[q] + 1; k < pstart[q + 1]; ++k) jump[q] = std::max(jump[q], pcam[k] - pcam[k - 1]);
       max_jump = std::max(max_jump, jump[q]);
     }
@@ -1018,17 +1164,24 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
       prev_size = closing.size();
       std::vector<char> in(P, 0);
       for (int q : closing) in[q] = 1;
+      std::vector<std::vector<int>> both;
       for (int more : {12, 48}) {  // ... and a few of the landmarks on top (by their number of observations)
         std::vector<int> pts(closing);
         int added = 0;
         for (size_t k = 0; k < by_cnt.size() && (added < more || pts.size() % 3 != 0); ++k)
           if (!in[by_cnt[k]]) { pts.push_back(by_cnt[k]); ++added; }
-        if (pts.size() % 3 != 0 || (int)pts.size() > max_points + 2) continue;
+        if (pts.size() % 3 != 0 || (int)pts.size() > max_points + 2) { both.emplace_back(); continue; }
         std::sort(pts.begin(), pts.end(), [&](int a, int b) { return cmin[a] != cmin[b] ? cmin[a] > cmin[b] : a < b; });
-        const RetainedGraphs rg = retained_graphs(ocam, opt, C, P, pts);
-        const int nblk = (9 * rg.Cx + 1 + 127) / 128;
-        BorderChoice bc;
-        if (!choose_border(rg.g(C, P), rg.x(), nblk, {}, SK_BORDER_AUTO, gaps_ok, &bc)) continue;
+        both.push_back(std::move(pts));
+      }
+      { std::vector<std::vector<int>> ahead; for (const auto& v : both) if (!v.empty()) ahead.push_back(v); score_ahead(ahead); }
+      for (int mi = 0; mi < 2; ++mi) {
+        const int more = mi == 0 ? 12 : 48;
+        const std::vector<int>& pts = both[mi];
+        if (pts.empty()) continue;
+        const Scored sc = score(pts);
+        if (!sc.ok) continue;
+        struct { double model_us; } bc{sc.model_us};
         if (dev_knobs().debug_envelope) std::fprintf(stderr, "[skeres_amd] retained candidates: gap %d + %d landmarks = %zu points: chain model %.0f us (best so far %.0f, base %.0f)\n", gap, more, pts.size(), bc.model_us, best, base_us);
         if (bc.model_us < (out.points.empty() || pts.size() <= out.points.size() ? 1.0 : 0.99) * best) { best = bc.model_us; out.points = pts; out.model_us = bc.model_us; }
       }
@@ -1059,7 +1212,7 @@ static ReducedSystemPlan plan_reduced_system(const Problem& p, const std::vector
   // others in the capture order (memory order / first appearance).  The chain model of the whole plan compares.
   std::vector<std::vector<int>> bases;
   std::vector<int> families;
-  const std::vector<std::vector<int>> cands = camera_order_candidates(p, cam_block, ocam, opt, C, P, with_memory_order);
+  const std::vector<std::vector<int>> cands = out.order.candidates;  // (of the same graph: formed once)
   bases.push_back(out.order.plain_id);
   families.push_back(1 | ((out.order.plain_id == cands[0] || out.order.plain_id == cands[1]) ? 2 : 0));
   for (int k = 0; k < 2; ++k)  // (the capture orders: first appearance, memory order)
@@ -1133,6 +1286,15 @@ int BalSolver::choose_distribution(const std::vector<int>& opt) {
 }
 
 int BalSolver::setup() {
+  // (SK_DEBUG=setup: where the set-up's wall time goes, one line per stage on stderr)
+  const auto setup_t0 = std::chrono::steady_clock::now();
+  auto stage = [&, last = setup_t0](const char* what) mutable {
+    if (!dev_knobs().debug_setup) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[skeres_amd] set-up: %-40s %8.1f ms (at %.1f ms)\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
+                 std::chrono::duration<double, std::milli>(now - setup_t0).count());
+    last = now;
+  };
   std::string why;
   if (!problem_is_bal_shaped(*problem_, &why)) { set_error("%s", why.c_str()); return SK_ERR_UNSUPPORTED; }
   const Problem& p = *problem_;
@@ -1217,7 +1379,9 @@ int BalSolver::setup() {
       for (int v : plan.tail) { h ^= (unsigned)v; h *= 1099511628211ull; }
       order_hash_ = (double)(h >> 12);  // 52 bits: exact in a double
     };
+    stage("structure, queue trial");
     pick(true);
+    stage("plan of the reduced system");
     if (opt_.allreduce && opt_.world > 1) {
       double v[2] = {order_hash_, -order_hash_};
       int rc = gather_rank_scalars_signed(v, 2);
@@ -1264,6 +1428,7 @@ int BalSolver::setup() {
                      border_cams_, border_gap_, border_model_us_, border_plain_us_);
     }
   }
+  stage("camera order applied");
   // ---- multi-GPU: shard the points, or replicate? ----
   // What travels in the all-reduce of the reduced system is the part of its lower block triangle INSIDE the envelope:
   // block row kb from the first block column that reaches it (the right-hand-side row whole) — 0.36 GB instead of 0.98 GB
@@ -1651,6 +1816,7 @@ int BalSolver::setup() {
     kept_pt.push_back(q); kept_cam.push_back(3 * retained_cam_[k] + (int)(k % 3));
     kept_home.push_back(q < P_own_ ? 1 : 0); kept_global.push_back((int)k);
   }
+  stage("dissection, local observations, camera lists");
   // pair lists: for every point that is eliminated, every (larger camera, smaller camera) pair of its observations
   size_t npairs = 0;
   for (int q = 0; q < P_; ++q) { if (kept_of_local[q] >= 0) continue; const size_t k = pt_start[q + 1] - pt_start[q]; npairs += k * (k - 1) / 2; }
@@ -1780,6 +1946,7 @@ int BalSolver::setup() {
     SK_HIP_TRY(b_kept_obs_.upload(kept_obs, s)); SK_HIP_TRY(b_kept_obs_slot_.upload(kept_obs_slot, s));
     num_kept_obs_ = (int)kept_obs.size();
   }
+  stage("pair lists, uploads");
   // ---- the fronts of the reduced camera system ----
   std::vector<int> border_row_h[2], leaf_map_h, leaf_gmap_h;
   if (!dissected_) {
@@ -1889,6 +2056,7 @@ int BalSolver::setup() {
   SK_HIP_TRY(b_scal_.alloc(16)); SK_HIP_TRY(b_scal_.zero(s)); SK_HIP_TRY(b_small_.alloc(2 * nc + 6 * retained_pts_.size() + 64 + 16 * (size_t)opt_.world));
   fail_p_ = reinterpret_cast<int*>(b_scal_.p + 14); info_p_ = reinterpret_cast<int*>(b_scal_.p + 15);
   SK_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_scal_), 64 * sizeof(double), hipHostMallocDefault));
+  stage("fronts, zero pass, tables");
   // ---- device view ----
   d_.C = C_; d_.P = P_; d_.N = N_;
   d_.pseudo = pseudo_cams_ > 0 ? b_pseudo_.p : nullptr; d_.num_kept = pseudo_cams_ > 0 ? (int)kept_pt.size() : 0; d_.kept_pt = b_kept_pt_.p; d_.kept_cam = b_kept_cam_.p;
@@ -1976,6 +2144,7 @@ int BalSolver::setup() {
     if (rc) return rc;
     if (off[0] > 0.0) cholesky_disable_chain(&chol_ctx_);
   }
+  stage("device view, the ranks' agreement");
   return SK_OK;
 }
 

@@ -65,6 +65,7 @@ const DevKnobs& dev_knobs() {
       k.debug_queues = topics.find(",queues,") != std::string::npos;
       k.debug_envelope = topics.find(",envelope,") != std::string::npos;
       k.debug_segments = topics.find(",segments,") != std::string::npos;
+      k.debug_setup = topics.find(",setup,") != std::string::npos;
       k.debug_chain_abort = topics.find(",chain_abort,") != std::string::npos;
     }
     k.queue_shift = num("SK_QUEUE_SHIFT", 0);

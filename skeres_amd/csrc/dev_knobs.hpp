@@ -13,7 +13,7 @@ struct DevKnobs {
   int bs_resident = 1;             // SK_BS_RESIDENT=0: the back-substitution as one launch per block step (the bitwise comparison of the two forms)
   const char* chain_stamps = nullptr;  // SK_CHAIN_STAMPS=<file>: device time stamps of the resident chain (tools/chain_timeline.py)
   const char* bs_stamps = nullptr;     // SK_BS_STAMPS=<file>: ... of the resident back-substitution
-  bool debug_queues = false, debug_envelope = false, debug_segments = false, debug_chain_abort = false;  // SK_DEBUG=queues,envelope,segments,chain_abort: lines on stderr
+  bool debug_queues = false, debug_envelope = false, debug_segments = false, debug_chain_abort = false, debug_setup = false;  // SK_DEBUG=queues,envelope,segments,chain_abort,setup: lines on stderr
   int queue_shift = 0;             // SK_QUEUE_SHIFT=<n>: creates n hardware queues first, as another library in the process would (queue-placement tests)
   int chain_queues = -1;           // SK_CHAIN_QUEUES=<k>: fixes the (bulk, panel, server) queue combination instead of the trial run
   int pair_max_trailing = 0;       // SK_CHAIN_PAIR_MAX_TRAILING=<rows>: the resident-pairs plan of round 3 (off by default; tests/pair_plan_worker.py)
