@@ -752,7 +752,10 @@ static void plan_parallel_for(int n, F f) {
   std::atomic<int> next{0};
   auto work = [&] { for (int i; (i = next.fetch_add(1)) < n;) f(i); };
   std::vector<std::thread> pool;
-  for (int t = 0; t < helpers; ++t) pool.emplace_back(work);
+  pool.reserve((size_t)helpers);
+  for (int t = 0; t < helpers; ++t) {
+    try { pool.emplace_back(work); } catch (...) { break; }  // (no thread to be had: the ones there are, and this one, do the work)
+  }
   work();
   for (std::thread& t : pool) t.join();
   g_plan_helpers.fetch_sub(helpers);
