@@ -884,28 +884,36 @@ static bool choose_border(const CamGraph& g, const CamGraph& x, int nblk, const 
   // the candidates (gap, variant): their marks first — cheap, and a candidate whose marks repeat the one before it is dropped — then their
   // envelopes side by side on host threads (plan_parallel_for), then the choice, in the candidates' order
   struct GapCand { int gap, variant, nb; std::vector<char> mark; BorderChoice bc; };
-  std::vector<GapCand> gc;
-  std::vector<char> prev_mark;
-  for (int gap = 4; gaps_ok && C >= 8 && gap < C && gap < max_jump; gap *= 2) {
-    for (int variant = 0; variant < 2; ++variant) {
-      std::vector<char> mark(C, 0);
-      int nb = 0;
-      for (int q = 0; q < g.P; ++q) {
-        const int a = pstart[q], e = pstart[q + 1];
-        if (variant == 0) {  // everything behind the first jump
-          int k = a + 1;
-          while (k < e && pcam[k] - pcam[k - 1] <= gap) ++k;
-          for (; k < e; ++k) if (!mark[pcam[k]]) { mark[pcam[k]] = 1; ++nb; }
-        } else {             // everything before the last jump
-          int k = e - 1;
-          while (k > a && pcam[k] - pcam[k - 1] <= gap) --k;
-          for (int i = a; i < k; ++i) if (!mark[pcam[i]]) { mark[pcam[i]] = 1; ++nb; }
-        }
+  std::vector<GapCand> gc, all;
+  for (int gap = 4; gaps_ok && C >= 8 && gap < C && gap < max_jump; gap *= 2)
+    for (int variant = 0; variant < 2; ++variant) all.push_back(GapCand{gap, variant, 0, std::vector<char>(), BorderChoice()});
+  plan_parallel_for((int)all.size(), [&](int ai) {  // (a pass over every point's list per candidate: side by side)
+    GapCand& c = all[(size_t)ai];
+    const int gap = c.gap;
+    std::vector<char>& mark = c.mark;
+    mark.assign((size_t)C, 0);
+    int nb = 0;
+    for (int q = 0; q < g.P; ++q) {
+      const int a = pstart[q], e = pstart[q + 1];
+      if (c.variant == 0) {  // everything behind the first jump
+        int k = a + 1;
+        while (k < e && pcam[k] - pcam[k - 1] <= gap) ++k;
+        for (; k < e; ++k) if (!mark[pcam[k]]) { mark[pcam[k]] = 1; ++nb; }
+      } else {             // everything before the last jump
+        int k = e - 1;
+        while (k > a && pcam[k] - pcam[k - 1] <= gap) --k;
+        for (int i = a; i < k; ++i) if (!mark[pcam[i]]) { mark[pcam[i]] = 1; ++nb; }
       }
-      if (nb == 0 || nb > C / 4 || C - nb < 4) continue;   // (a border that wide is no border: its dense system would be the factorisation)
-      if (mark == prev_mark) continue;
-      prev_mark = mark;
-      gc.push_back(GapCand{gap, variant, nb, std::move(mark), BorderChoice()});
+    }
+    c.nb = nb;
+  });
+  {
+    std::vector<char> prev_mark;
+    for (GapCand& c : all) {
+      if (c.nb == 0 || c.nb > C / 4 || C - c.nb < 4) continue;   // (a border that wide is no border: its dense system would be the factorisation)
+      if (c.mark == prev_mark) continue;
+      prev_mark = c.mark;
+      gc.push_back(std::move(c));
     }
   }
   plan_parallel_for((int)gc.size(), [&](int i) { candidate(gc[(size_t)i].mark, gc[(size_t)i].nb, gc[(size_t)i].gap, gc[(size_t)i].variant, &gc[(size_t)i].bc); });
@@ -1037,13 +1045,13 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
   std::vector<int> cmin(P, C), cmax(P, -1), cnt(P, 0);
   for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); cnt[opt[b]]++; }
   // (a point with two residual blocks on one camera is never retained: the rows of a retained point have one writer per block)
+  // (the cameras of every point, ascending — formed once: the candidates' graphs are derived from these lists, below — and a camera that
+  // comes twice in a point's list is two residual blocks on one pair)
+  PointLists base;
+  { const CamGraph g0{&ocam, &opt, C, P}; point_camera_lists(g0, &base.start, &base.cam); }
   std::vector<char> twice(P, 0);
-  {
-    std::vector<long long> key(ocam.size());
-    for (size_t b = 0; b < ocam.size(); ++b) key[b] = (long long)opt[b] * C + ocam[b];
-    std::sort(key.begin(), key.end());
-    for (size_t b = 1; b < key.size(); ++b) if (key[b] == key[b - 1]) twice[(size_t)(key[b] / C)] = 1;
-  }
+  for (int q = 0; q < P; ++q)
+    for (int k = base.start[(size_t)q] + 1; k < base.start[(size_t)q + 1]; ++k) if (base.cam[(size_t)k] == base.cam[(size_t)k - 1]) twice[(size_t)q] = 1;
   std::vector<int> wide;
   for (int q = 0; q < P; ++q) if (cnt[q] >= 2 && 9 * (cmax[q] - cmin[q]) >= 128 && !twice[q]) wide.push_back(q);
   const bool exactly = mode == SK_RETAINED_ON && max_points > 0;  // (ON with a count: that many, as far as there are candidates)
@@ -1059,8 +1067,6 @@ static RetainedChoice choose_retained_points(const std::vector<int>& ocam, const
   std::map<std::vector<int>, Scored> scored;  // (key: the set, sorted)
   // the cameras of every point, once; a candidate's graphs are these lists with the retained points' taken out (g) and, behind them, a point
   // of two cameras — the observation's and the retained point's pseudo-camera — for every observation of a retained point (x: retained_graphs)
-  PointLists base;
-  { const CamGraph g0{&ocam, &opt, C, P}; point_camera_lists(g0, &base.start, &base.cam); }
   auto lists_with = [&](const std::vector<int>& pts, PointLists* l, int* Cx, int* Px) {
     std::vector<int> slot((size_t)P, -1);
     for (size_t k = 0; k < pts.size(); ++k) slot[(size_t)pts[k]] = (int)k;
