@@ -513,10 +513,12 @@ def main():
         from skeres_amd import dist as sk_dist
         hook = sk_dist.attach(options, problem, rank, world)  # reduce buffer + all-reduce hook over torch.distributed (RCCL)
 
+    t_create = time.time()
     try:
         solver = sk.StepSolver(options, problem)  # uploads the shard, builds the pair lists, runs iteration 0 (several ranks: the first calls of the all-reduce hook)
     except Exception as e:  # noqa: BLE001
         fail("solver set-up", e)
+    t_create = time.time() - t_create  # (not part of `value`: the plan of the reduced system, the lists, the uploads, the device's one-time queue trial, iteration 0)
     dist_mode, t_allreduce, t_saved = solver.distribution() if world > 1 else ("single", 0.0, 0.0)
     allreduce_mb = solver.stat("allreduce_bytes") / 1e6 if world > 1 else 0.0
     for _ in range(args.warmup):
@@ -641,6 +643,7 @@ def main():
                 "dissection": {"dissected": int(headline_stats.get("dissected", 0)), "head_cameras": int(headline_stats.get("dissection_head_cameras", 0)),
                                "tail_cameras": int(headline_stats.get("dissection_tail_cameras", 0)),
                                "separator_cameras_and_pseudo_cameras": int(headline_stats.get("dissection_separator_cameras", 0))},
+                "solver_create_seconds": t_create,
                 "successful_steps_in_timed_region": n_success, "parallelism": ("one GPU" if world == 1 else
                                 "camera sequence cut into %d segments over the %d ranks (SK_DISTRIBUTION_SEGMENTED): rank r's device eliminates segment r "
                                 "and its points (ranks beyond the segments replicate and add zeros); per iteration the separators' block-tridiagonal "
