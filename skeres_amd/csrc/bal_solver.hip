@@ -1975,7 +1975,6 @@ int BalSolver::setup() {
       const int nbm = border_members_, mf = C_ - nbm;
       const int ll = seg > 0 ? sep_first_[seg - 1] : 0, lh = seg > 0 ? std::min(sep_first_[seg], mf) : 0;
       const int rl = seg + 1 < segments_ ? sep_first_[seg] : 0, rh = seg + 1 < segments_ ? std::min(sep_first_[seg + 1], mf) : 0;
-      const bool last_seg = seg > 0 && seg + 1 == segments_;
       // first segment: [right | members | rhs]; last: [left reversed | members | rhs]; between two: [right, padded | left | members | rhs] —
       // there the members are tail rows like the left separator's (active in every column)
       const SegmentLayout lay = seg == 0 ? segment_layout(9 * (hi - lo), 0, 9 * (rh - rl + nbm)) : segment_layout(9 * (hi - lo), 9 * (lh - ll + nbm), 9 * (rh - rl));
@@ -1991,7 +1990,6 @@ int BalSolver::setup() {
       // tail rows of the front's envelope, a suffix of the matrix)
       for (int c = ll; c < lh; ++c) pos[c] = bo + lay.left_off + (lay.reversed ? 9 * (lh - 1 - c) : 9 * (c - ll));
       for (int c = mf; c < C_; ++c) pos[c] = (seg == 0 ? bo + lay.right_off + 9 * (rh - rl) : bo + lay.left_off + 9 * (lh - ll)) + 9 * (c - mf);
-      (void)last_seg;
       const std::vector<int>& fo = struct_ocam_.empty() ? ocam : struct_ocam_;
       const std::vector<int>& fp = struct_ocam_.empty() ? opt : struct_opt_;
       const int fP = struct_ocam_.empty() ? P_total_ : struct_P_;

@@ -864,7 +864,7 @@ __device__ __forceinline__ bool chain_wait(const int* p, int target, int* abort_
   return true;
 }
 // one lane: wait until *p == value (the start signal of a factorisation: chain_start_kernel); false = aborted / timed out
-__device__ __forceinline__ bool chain_wait_start(const int* p, int value, int* abort_flag) {
+__device__ __forceinline__ bool chain_wait_start(const int* p, int value) {
   if (sync_load(p) != value) {
     const long long t0 = wall_clock64();
     int spins = 0;
@@ -874,7 +874,6 @@ __device__ __forceinline__ bool chain_wait_start(const int* p, int value, int* a
       if ((++spins & 63) == 0 && wall_clock64() - t0 > 4 * kChainTimeoutTicks) return false;
     } while (sync_load(p) != value);
   }
-  (void)abort_flag;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   return true;
@@ -1026,7 +1025,7 @@ __global__ void chain_gate_kernel(const int* counter, int expected, int* info) {
 }
 __global__ void chain_start_gate_kernel(const int* p, int value, int* info) {
   if (threadIdx.x != 0) return;
-  if (!chain_wait_start(p, value, nullptr)) info_raise(info, 2);
+  if (!chain_wait_start(p, value)) info_raise(info, 2);
 }
 // start != 0 (round 5): the launch was enqueued without an event in front of it — a blocked cross-queue wait wakes up 25-60 us after its
 // signal (profiles/r05_iteration_trace.txt) — and waits here for chain_start_kernel, which the caller's stream runs once the system is
@@ -1036,7 +1035,7 @@ __device__ __forceinline__ void potrf_server_body(double* lds, double* S, long l
   const int stamp_front = gridDim.x == 2 ? (int)blockIdx.x : 0;
   int done = 0;  // value of the potrf counter
   if (start != 0) {
-    if (threadIdx.x == 0) ok_s = chain_wait_start(sync + kSyncStart, start, sync + kSyncAbort) ? 1 : 0;
+    if (threadIdx.x == 0) ok_s = chain_wait_start(sync + kSyncStart, start) ? 1 : 0;
     __syncthreads();
     if (!ok_s) {
       if (threadIdx.x == 0) info_raise(info, 2);
