@@ -640,6 +640,31 @@ static Segments choose_segments(const std::vector<int>& ocam, const std::vector<
   return out;
 }
 
+// f(i) for i in [0, n) on up to twelve host threads (the caller's among them).  The planner's candidates — each a handful of passes over every
+// observation — are independent of each other; which one is taken is decided afterwards, in the candidates' own order, so the plan does not
+// depend on the number of threads (round 5: the plan of the reduced system was 0.7 s of Ladybug-1723's 0.8 s of set-up, 8 s of Venice-1778's 9).
+static std::atomic<int> g_plan_helpers{0};  // helper threads of the planner alive in this process (nested calls share one budget)
+template <class F>
+static void plan_parallel_for(int n, F f) {
+  const int budget = std::min(12, std::max(1, (int)std::thread::hardware_concurrency())) - 1;
+  int helpers = 0;
+  while (helpers < n - 1) {  // (claim helper threads one by one, as far as the budget goes)
+    int cur = g_plan_helpers.load();
+    if (cur >= budget) break;
+    if (g_plan_helpers.compare_exchange_weak(cur, cur + 1)) ++helpers;
+  }
+  if (helpers == 0) { for (int i = 0; i < n; ++i) f(i); return; }
+  std::atomic<int> next{0};
+  auto work = [&] { for (int i; (i = next.fetch_add(1)) < n;) f(i); };
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)helpers);
+  for (int t = 0; t < helpers; ++t) {
+    try { pool.emplace_back(work); } catch (...) { break; }  // (no thread to be had: the ones there are, and this one, do the work)
+  }
+  work();
+  for (std::thread& t : pool) t.join();
+  g_plan_helpers.fetch_sub(helpers);
+}
 static std::vector<int> rcm_order(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P) {
   // co-visibility graph, thinned: the cameras of a point are chained in index order and the ends joined
   // (the cameras of every point as flat sorted lists — a counting sort and one small sort per point)
@@ -727,39 +752,19 @@ static std::vector<std::vector<int>> camera_order_candidates(const Problem& p, c
 static void choose_camera_order(const std::vector<std::vector<int>>& cand, const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int npad,
                                 int* best_k, std::vector<int>* best_env, double* best_flops) {
   double best = -1.0;
+  std::vector<std::vector<int>> envs(cand.size());
+  std::vector<double> flops(cand.size(), 0.0);
+  plan_parallel_for((int)cand.size(), [&](int k) {  // (the candidates' envelopes side by side; the choice in their order)
+    envs[(size_t)k] = envelope_of_order(ocam, opt, cand[(size_t)k], C, P, npad / 128);
+    flops[(size_t)k] = cholesky_syrk_flops(npad, 1, envs[(size_t)k].data());
+  });
   for (size_t k = 0; k < cand.size(); ++k) {
-    std::vector<int> env = envelope_of_order(ocam, opt, cand[k], C, P, npad / 128);
-    const double f = cholesky_syrk_flops(npad, 1, env.data());
-    if (best < 0.0 || f < best * (1.0 - 1e-9)) { best = f; *best_k = (int)k; best_env->swap(env); }
+    const double f = flops[k];
+    if (best < 0.0 || f < best * (1.0 - 1e-9)) { best = f; *best_k = (int)k; best_env->swap(envs[k]); }
   }
   *best_flops = best;
 }
 
-// f(i) for i in [0, n) on up to twelve host threads (the caller's among them).  The planner's candidates — each a handful of passes over every
-// observation — are independent of each other; which one is taken is decided afterwards, in the candidates' own order, so the plan does not
-// depend on the number of threads (round 5: the plan of the reduced system was 0.7 s of Ladybug-1723's 0.8 s of set-up, 8 s of Venice-1778's 9).
-static std::atomic<int> g_plan_helpers{0};  // helper threads of the planner alive in this process (nested calls share one budget)
-template <class F>
-static void plan_parallel_for(int n, F f) {
-  const int budget = std::min(12, std::max(1, (int)std::thread::hardware_concurrency())) - 1;
-  int helpers = 0;
-  while (helpers < n - 1) {  // (claim helper threads one by one, as far as the budget goes)
-    int cur = g_plan_helpers.load();
-    if (cur >= budget) break;
-    if (g_plan_helpers.compare_exchange_weak(cur, cur + 1)) ++helpers;
-  }
-  if (helpers == 0) { for (int i = 0; i < n; ++i) f(i); return; }
-  std::atomic<int> next{0};
-  auto work = [&] { for (int i; (i = next.fetch_add(1)) < n;) f(i); };
-  std::vector<std::thread> pool;
-  pool.reserve((size_t)helpers);
-  for (int t = 0; t < helpers; ++t) {
-    try { pool.emplace_back(work); } catch (...) { break; }  // (no thread to be had: the ones there are, and this one, do the work)
-  }
-  work();
-  for (std::thread& t : pool) t.join();
-  g_plan_helpers.fetch_sub(helpers);
-}
 // ---- loop closures: the cameras that revisit a place, ordered into a trailing BORDER (round 4) ------------------------------
 // A camera sequence that comes back to a street it has seen couples two distant windows of the band: in the band's own
 // order every block column between the two windows is dragged into the envelope (a handful of such tracks fill it: 0.37 ->
