@@ -432,17 +432,25 @@ static double backsolve_us(int block_columns) { return block_columns > 0 ? 20.0 
 // extra_fwd (optional, per block column of the band): border block rows that are active in that column on top of its run — the tail
 // profile of the bordered envelope — when the head is eliminated front to back; extra_bwd: the same for the tail front, for which the
 // profile is not known (its columns reach the border's rows in another order): all of them.
-static Dissection choose_dissection(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
-                                    const std::vector<int>& first_col, bool tail_resident, bool lockstep = false, int extra_sep = 0,
-                                    const std::vector<int>* extra_fwd = nullptr, int extra_bwd = 0, const std::vector<int>* extra_bwd_col = nullptr) {
-  Dissection d;
-  if (C < 64 || nblk < 24) return d;
-  // reach[c]: the last camera that shares a point with any camera <= c (cameras in the chosen order)
+// reach[c]: the last camera that shares a point with any camera <= c (cameras in the chosen order) — what a cut behind camera c - 1 needs
+// as its separator's end.  Three passes over the observations: a caller that plans several cuts of one sequence forms it once (reach_in).
+static std::vector<int> camera_reach(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P) {
   std::vector<int> cmin(P, C), cmax(P, -1), reach(C);
   for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); }
   for (int c = 0; c < C; ++c) reach[c] = c;
   for (int q = 0; q < P; ++q) if (cmax[q] >= 0) reach[cmin[q]] = std::max(reach[cmin[q]], cmax[q]);
   for (int c = 1; c < C; ++c) reach[c] = std::max(reach[c], reach[c - 1]);
+  return reach;
+}
+static Dissection choose_dissection(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
+                                    const std::vector<int>& first_col, bool tail_resident, bool lockstep = false, int extra_sep = 0,
+                                    const std::vector<int>* extra_fwd = nullptr, int extra_bwd = 0, const std::vector<int>* extra_bwd_col = nullptr,
+                                    const std::vector<int>* reach_in = nullptr) {
+  Dissection d;
+  if (C < 64 || nblk < 24) return d;
+  // reach[c]: the last camera that shares a point with any camera <= c (cameras in the chosen order)
+  const std::vector<int> reach_own = reach_in ? std::vector<int>() : camera_reach(ocam, opt, C, P);
+  const std::vector<int>& reach = reach_in ? *reach_in : reach_own;
   // per block column: height forward (rows below, as the envelope has it) and backward (rows above: the tail's view)
   std::vector<double> fwd(nblk), bwd(nblk), fwd_sum(nblk + 1, 0.0), bwd_sum(nblk + 1, 0.0);
   std::vector<int> height(nblk), height_b(nblk);
@@ -527,17 +535,15 @@ struct Segments { std::vector<int> a, b; double t_plain = 0.0, t_model = 0.0; do
 // rows of EVERY segment's front, active in a block column as extra_fwd / extra_bwd_col have it (as in choose_dissection), and a border of the root.
 static Segments choose_segments(const std::vector<int>& ocam, const std::vector<int>& opt, int C, int P, int nblk, const std::vector<int>& last,
                                 const std::vector<int>& first_col, int max_segments, bool forced, int world = 0, int member_cams = 0,
-                                const std::vector<int>* extra_fwd = nullptr, const std::vector<int>* extra_bwd_col = nullptr) {
+                                const std::vector<int>* extra_fwd = nullptr, const std::vector<int>* extra_bwd_col = nullptr,
+                                const std::vector<int>* reach_in = nullptr) {
   Segments out;
   const int mb = member_cams > 0 ? (9 * member_cams + 127) / 128 : 0;
   if (world <= 0) world = max_segments;
   max_segments = std::min(max_segments, 8);
   if (max_segments < 2 || C < 6) return out;
-  std::vector<int> cmin(P, C), cmax(P, -1), reach(C);
-  for (size_t b = 0; b < ocam.size(); ++b) { cmin[opt[b]] = std::min(cmin[opt[b]], ocam[b]); cmax[opt[b]] = std::max(cmax[opt[b]], ocam[b]); }
-  for (int c = 0; c < C; ++c) reach[c] = c;
-  for (int q = 0; q < P; ++q) if (cmax[q] >= 0) reach[cmin[q]] = std::max(reach[cmin[q]], cmax[q]);
-  for (int c = 1; c < C; ++c) reach[c] = std::max(reach[c], reach[c - 1]);
+  const std::vector<int> reach_own = reach_in ? std::vector<int>() : camera_reach(ocam, opt, C, P);
+  const std::vector<int>& reach = reach_in ? *reach_in : reach_own;
   if (C >= 64 && nblk >= 24) {
     std::vector<double> fwd(nblk), bwd(nblk), fwd_sum(nblk + 1, 0.0), bwd_sum(nblk + 1, 0.0);
     std::vector<int> fc(first_col);
@@ -1569,13 +1575,14 @@ int BalSolver::setup() {
         extra_bwd_col.assign(dnblk, 0);
         for (int c = 0; c < dnblk; ++c) extra_bwd_col[c] = (9 * active[c] + 127) / 128;
       }
+      const std::vector<int> band_reach = camera_reach(docam, dopt, Cband, P_total_);  // (once for every cut planned on this sequence, below)
       ds = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, lockstep_cut || two_seg_try, lockstep_cut, C_ - Cband, pseudo_border ? &extra_fwd : nullptr, extra_bwd,
-                             pseudo_border ? &extra_bwd_col : nullptr);
+                             pseudo_border ? &extra_bwd_col : nullptr, &band_reach);
       if (two_seg_try) {
         // two devices, a chain each, against ONE device with the two fronts in lock-step (what a replicating rank would run): + the
         // all-reduce of the separator's system (its lower triangle over one xGMI link per direction: choose_segments)
         const Dissection one = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, true, true, C_ - Cband, pseudo_border ? &extra_fwd : nullptr, extra_bwd,
-                                                 pseudo_border ? &extra_bwd_col : nullptr);
+                                                 pseudo_border ? &extra_bwd_col : nullptr, &band_reach);
         const double one_us = one.a > 0 ? one.t_dissected : one.t_plain;
         const double E = ds.a > 0 ? (9.0 * (ds.b - ds.a + C_ - Cband) + 1.0 + 127.0) / 128.0 : 0.0;
         const int W = std::max(2, opt_.world);
@@ -1597,7 +1604,7 @@ int BalSolver::setup() {
         if (max_seg > 2) {
           const bool forced = opt_.distribution_mode == SK_DISTRIBUTION_SEGMENTED;
           const Segments sg = choose_segments(docam, dopt, Cband, P_total_, dnblk, denv, first_col, max_seg, forced, opt_.world, C_ - Cband,
-                                              pseudo_border ? &extra_fwd : nullptr, pseudo_border ? &extra_bwd_col : nullptr);
+                                              pseudo_border ? &extra_fwd : nullptr, pseudo_border ? &extra_bwd_col : nullptr, &band_reach);
           for (int k = 3; k < 9; ++k) model_us_[k] = sg.model_us[k];
           const int Rn = (int)sg.a.size() + 1;
           const double two_us = ds.a > 0 ? ds.t_dissected + allreduce_us + 0.5 * shard_us : 1e300;
@@ -1649,12 +1656,12 @@ int BalSolver::setup() {
       dissect_t_plain_ = ds.t_plain; dissect_t_model_ = ds.t_dissected;
       if (!two_seg_try) {  // what the chain model predicts for 2 .. 8 devices (sk_solver_stat "model_us_segments_<n>": bench.py prints it beside what it measures)
         const Segments sg = choose_segments(docam, dopt, Cband, P_total_, dnblk, denv, first_col, 8, false, 0, C_ - Cband, pseudo_border ? &extra_fwd : nullptr,
-                                            pseudo_border ? &extra_bwd_col : nullptr);
+                                            pseudo_border ? &extra_bwd_col : nullptr, &band_reach);
         for (int k = 0; k < 9; ++k) model_us_[k] = sg.model_us[k];
         if (pseudo_border) {
           // ... and with the border's members (retained points) in the one separator of TWO segments, a device each — what a world of ranks
           // takes when it beats this device's plan by 10 % (pass 0 above): "model_us_two_segments_with_members"
-          const Dissection two = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, true, false, C_ - Cband, &extra_fwd, extra_bwd, &extra_bwd_col);
+          const Dissection two = choose_dissection(docam, dopt, Cband, P_total_, dnblk, denv, first_col, true, false, C_ - Cband, &extra_fwd, extra_bwd, &extra_bwd_col, &band_reach);
           if (two.a > 0) {
             const double E = (9.0 * (two.b - two.a + C_ - Cband) + 1.0 + 127.0) / 128.0;
             two_segments_members_us_ = two.t_dissected + 50.0 + 0.5 * E * (E + 1.0) * 128.0 * 128.0 * 8.0 / 153e3;  // (+ the root's all-reduce over two ranks)
