@@ -870,8 +870,10 @@ __device__ __forceinline__ bool chain_wait_start(const int* p, int value) {
     int spins = 0;
     do {
       __builtin_amdgcn_s_sleep(8);
-      // (the counters — the abort flag among them — are this factorisation's only after the signal: nothing else is looked at before it)
-      if ((++spins & 63) == 0 && wall_clock64() - t0 > 4 * kChainTimeoutTicks) return false;
+      // (the counters — the abort flag among them — are this factorisation's only after the signal: nothing else is looked at before it.
+      // The signal is a kernel on the caller's stream, enqueued before this launch: it cannot be lost, only late — behind whatever else that
+      // stream holds, a caller's own kernels included — so the wait is a long one: thirty time-outs)
+      if ((++spins & 63) == 0 && wall_clock64() - t0 > 30 * kChainTimeoutTicks) return false;
     } while (sync_load(p) != value);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
