@@ -966,16 +966,28 @@ static CameraOrderPlan plan_camera_order(const Problem& p, const std::vector<int
     // (the candidates' borders side by side on host threads; which one is taken: in the candidates' order, below)
     std::vector<BorderChoice> bcs(cand.size());
     std::vector<char> bc_ok(cand.size(), 0);
+    // the cameras of every point once, in the numbering the graphs come in: a candidate order's lists are these, renumbered and sorted again
+    // point by point (no counting sort over every observation per candidate)
+    PointLists gl0, xl0;
+    point_camera_lists(g, &gl0.start, &gl0.cam);
+    if (forced) point_camera_lists(x, &xl0.start, &xl0.cam);
+    auto renumbered = [&](const PointLists& l0, const std::vector<int>& id, PointLists* out) {
+      out->start = l0.start;
+      out->cam.resize(l0.cam.size());
+      for (size_t i = 0; i < l0.cam.size(); ++i) { const int c = l0.cam[i]; out->cam[i] = c < C ? id[(size_t)c] : c; }  // (pseudo-cameras keep their places behind the real ones)
+      const int P = (int)l0.start.size() - 1;
+      for (int q = 0; q < P; ++q) std::sort(out->cam.begin() + l0.start[(size_t)q], out->cam.begin() + l0.start[(size_t)q + 1]);
+    };
     plan_parallel_for((int)cand.size(), [&](int ki) {
       const size_t k = (size_t)ki;
       if (k == 1 && !with_memory_order) return;  // (the slot repeats candidate 0)
-      std::vector<int> oc(g.ocam->size()), ocx;
-      for (size_t b = 0; b < oc.size(); ++b) oc[b] = cand[k][(*g.ocam)[b]];
-      if (forced) { ocx.resize(x.ocam->size()); for (size_t b = 0; b < ocx.size(); ++b) { const int c = (*x.ocam)[b]; ocx[b] = c < C ? cand[k][c] : c; } }
-      const CamGraph gk{&oc, g.opt, C, g.P}, xk{forced ? &ocx : &oc, x.opt, Cx, x.P};
+      PointLists glk, xlk;
+      renumbered(gl0, cand[k], &glk);
+      if (forced) renumbered(xl0, cand[k], &xlk);
+      const CamGraph gk{nullptr, nullptr, C, g.P}, xk{nullptr, nullptr, Cx, x.P};  // (choose_border reads the lists alone)
       std::vector<int> plain;
       if (!forced) plain = (int)k == best_k ? best_env : envelope_of_order(*g.ocam, *g.opt, cand[k], C, g.P, nblk);
-      bc_ok[k] = choose_border(gk, xk, nblk, plain, border_mode, border_ok, &bcs[k]) ? 1 : 0;
+      bc_ok[k] = choose_border(gk, xk, nblk, plain, border_mode, border_ok, &bcs[k], &glk, forced ? &xlk : nullptr) ? 1 : 0;
     });
     for (size_t k = 0; k < cand.size(); ++k) {
       if (k == 1 && !with_memory_order) continue;
